@@ -1,0 +1,236 @@
+/*
+ * acf_hip.h — C ABI of the MI355X (gfx950) ACF detection backend.
+ *
+ * This is the drop-in boundary for the chnsPyramid + acfDetect hot path of
+ * elucideye/acf.  The reference has no C ABI of its own (its boundary is the
+ * C++ class acf::Detector, src/lib/acf/acf/ACF.h:50-624); each entry point
+ * below names the reference interface it stands in for.  The host-side C++
+ * class in acf_amd/host/ (same method names as acf::Detector) dlopen()s this
+ * library; tests and bench.py bind it with ctypes.
+ *
+ * Conventions
+ *  - Every function returns an int status (ACF_HIP_OK == 0) and never throws.
+ *    The reference returns 0 on the hot path and throws on precondition
+ *    failures (ACF.cpp:135-141, wrappers.hpp:29-32); here those become codes.
+ *  - A plane is float[w][h] with h (image height, image-y) contiguous: the
+ *    reference's transposed planar layout (MatP, MatP.cpp:51-73; ACF.cpp:137).
+ *    A frame is `d` planes back to back; a batch is frames back to back.
+ *  - All sizes are given in upright-image terms (h = image height, w = image
+ *    width).  The reference stores them in cv::Size with the members swapped
+ *    ({width = h, height = w}, ACFIO.h:168-181); the host class does that
+ *    translation, this ABI never sees cv::Size.
+ *  - "dev" pointers are HIP device pointers; "host" pointers are ordinary
+ *    memory.  No torch / OpenCV types appear in any signature.
+ */
+#ifndef ACF_HIP_H
+#define ACF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACF_HIP_ABI_VERSION 1
+
+enum {
+    ACF_HIP_OK = 0,
+    ACF_HIP_E_INVALID = 1,     /* bad argument / precondition (reference: CV_Assert) */
+    ACF_HIP_E_UNSUPPORTED = 2, /* option the HIP path does not implement */
+    ACF_HIP_E_NOMODEL = 3,     /* set_model not called */
+    ACF_HIP_E_NOPLAN = 4,      /* plan not called */
+    ACF_HIP_E_HIP = 5,         /* HIP runtime error, see acf_hip_last_error */
+    ACF_HIP_E_NODEVICE = 6,    /* no gfx950 device visible */
+    ACF_HIP_E_CAPACITY = 7     /* more detections than the planned capacity */
+};
+
+/* rgbConvert flags (rgbConvert.cpp:106-128) */
+enum {
+    ACF_HIP_CS_GRAY = 0,
+    ACF_HIP_CS_RGB = 1,
+    ACF_HIP_CS_LUV = 2,
+    ACF_HIP_CS_HSV = 3, /* unsupported */
+    ACF_HIP_CS_ORIG = 4
+};
+
+/*
+ * Model + options: the fields of Detector::Classifier (ACF.h:292-310) and of
+ * the Options tree (ACF.h:68-275) that the hot path reads.  Tree arrays are
+ * row-major [nTrees][nTreeNodes] (the layout after the load-time transpose,
+ * ACFIO.cpp:61-67) and are copied by acf_hip_set_model.
+ */
+typedef struct acf_hip_params
+{
+    /* Classifier */
+    int32_t nTrees;
+    int32_t nTreeNodes;
+    int32_t treeDepth; /* 1..8 fixed depth, 0 = walk child[] (acfDetect1.cpp:100-166) */
+    const uint32_t* fids;
+    const float* thrs;
+    const float* hs;
+    const uint32_t* child; /* may be NULL when treeDepth > 0 */
+
+    /* Options: modelDs, modelDsPad, stride, cascThr (ACF.h:204-211) */
+    int32_t modelDs_h, modelDs_w;
+    int32_t modelDsPad_h, modelDsPad_w;
+    int32_t stride;
+    double cascThr;
+
+    /* Options::Pyramid (ACF.h:97-202) */
+    int32_t nPerOct, nOctUp, nApprox;
+    int32_t nLambdas; /* 0 or 3 (colour, gradMag, gradHist); 0 is ACF_HIP_E_UNSUPPORTED on the device path */
+    double lambdas[3];
+    int32_t pad_h, pad_w;
+    int32_t minDs_h, minDs_w;
+    double smooth; /* final channel smoothing radius (chnsPyramid.cpp:399-407) */
+
+    /* Options::Pyramid::Chns (ACF.h:99-182) */
+    int32_t shrink;
+    int32_t colorEnabled;
+    double colorSmooth;
+    int32_t colorSpace; /* ACF_HIP_CS_* */
+    int32_t gradMagEnabled;
+    int32_t colorChn;
+    int32_t normRad;
+    double normConst;
+    int32_t full;
+    int32_t gradHistEnabled;
+    int32_t binSize; /* 0 = shrink */
+    int32_t nOrients;
+    int32_t softBin;
+    int32_t isLuv; /* Detector::setIsLuv (ACF.h:560-567) */
+} acf_hip_params;
+
+/* One detection in upright image coordinates (ACF.cpp:302-312, Detection ACF.h:510-525). */
+typedef struct acf_hip_detection
+{
+    int32_t x, y, w, h;
+    float score;
+    int32_t scale; /* pyramid level that produced it */
+} acf_hip_detection;
+
+/* One cascade hit before box mapping: DetectionSink::add({c,r},h) (acfDetect1.cpp:39-47,92-95). */
+typedef struct acf_hip_hit
+{
+    int32_t scale, c, r;
+    float score;
+} acf_hip_hit;
+
+/* Geometry of one pyramid level as planned by acf_hip_plan. */
+typedef struct acf_hip_level
+{
+    double scale;            /* Pyramid::scales (ACF.h:374) */
+    double scalehw_h;        /* Pyramid::scaleshw, image-height axis */
+    double scalehw_w;        /* Pyramid::scaleshw, image-width axis */
+    int32_t isReal;          /* computed exactly (chnsPyramid.cpp:274-277) */
+    int32_t realIndex;       /* level it is approximated from (itself if real) */
+    int32_t hC, wC;          /* channel plane size before padding (cells) */
+    int32_t hP, wP;          /* plane size after BORDER_REFLECT padding = what the cascade sees */
+    int32_t nWinR, nWinC;    /* window grid height1, width1 (acfDetect1.cpp:258-259) */
+    int64_t offset;          /* float offset of this level inside one frame's fused pyramid */
+} acf_hip_level;
+
+typedef struct acf_hip_ctx acf_hip_ctx;
+
+/* ---- lifecycle ------------------------------------------------------- */
+
+/* Bind a context to `device` and to `stream` (a hipStream_t, or NULL for a
+ * stream owned by the context).  Replaces constructing an acf::Detector
+ * (ACF.h:59-66); good() == (return value == ACF_HIP_OK). */
+int acf_hip_create(int device, void* stream, acf_hip_ctx** out);
+int acf_hip_destroy(acf_hip_ctx* ctx);
+int acf_hip_abi_version(void);
+/* Last error text for this context (thread-compatible, like one Detector per thread). */
+const char* acf_hip_last_error(const acf_hip_ctx* ctx);
+
+/* Upload classifier + options.  Replaces Detector::deserialize*() filling
+ * `clf` and `opts` (ACF.h:277,312) and acfModify's effects (acfModify.cpp:139-143),
+ * which the caller applies to the struct before the call. */
+int acf_hip_set_model(acf_hip_ctx* ctx, const acf_hip_params* p);
+
+/* Plan for frames of h x w with `d` input planes (1 or 3) and up to
+ * `max_batch` frames per call and `max_hits` hits per frame: runs getScales
+ * (chnsPyramid.cpp:461-529) and the real/approximate split
+ * (chnsPyramid.cpp:272-292), builds resampling tables and allocates every
+ * device buffer.  Nothing is allocated after this call. */
+int acf_hip_plan(acf_hip_ctx* ctx, int h, int w, int d, int max_batch, int max_hits);
+int acf_hip_num_levels(const acf_hip_ctx* ctx, int* nScales, int* nChns);
+int acf_hip_get_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
+/* Floats in one frame's fused pyramid (sum over levels of nChns*wP*hP). */
+int acf_hip_pyramid_floats(const acf_hip_ctx* ctx, int64_t* n);
+
+/* ---- the hot path ---------------------------------------------------- */
+
+/* Detector::chnsPyramid for a batch (chnsPyramid.cpp:160-456).  `frames_dev`:
+ * n_frames x d planes of float[w][h] already on the device.  Asynchronous on
+ * the context's stream. */
+int acf_hip_pyramid(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
+
+/* Detector::operator()(const Pyramid&) without NMS (ACF.cpp:268-367) on the
+ * pyramid of the last acf_hip_pyramid call: acfDetect1 on every level
+ * (acfDetect1.cpp:309-335) + box mapping.  Asynchronous. */
+int acf_hip_detect(acf_hip_ctx* ctx);
+
+/* acf_hip_pyramid + acf_hip_detect: Detector::operator()(const MatP&) (ACF.cpp:246-265). */
+int acf_hip_run(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
+
+/* Same with frames in host memory (H2D copy included). */
+int acf_hip_run_host(acf_hip_ctx* ctx, const float* frames_host, int n_frames);
+
+/* Wait for the stream, then return frame `frame`'s detections in the
+ * reference's order (level ascending, then c, then r; ACF.cpp:326-329,
+ * acfDetect1.cpp:86-96).  `*count` is the true number even if > cap. */
+int acf_hip_get_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
+int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, int cap, int* count);
+
+/* Device-side export for the multi-GPU gather: writes, for every frame of the
+ * last batch, a fixed-capacity record [count, then cap x {x,y,w,h,score bits,scale}]
+ * of int32 into `dst_dev` (n_frames * (1 + 6*cap) int32), sorted as above. */
+int acf_hip_export_detections(acf_hip_ctx* ctx, int32_t* dst_dev, int cap);
+
+int acf_hip_synchronize(acf_hip_ctx* ctx);
+
+/* ---- parity taps (tests only; not on the timed path) ------------------ */
+
+/* Copy level `level` of frame `frame`'s fused pyramid ([nChns][wP][hP]) to host. */
+int acf_hip_read_level(acf_hip_ctx* ctx, int frame, int level, float* host_out);
+
+enum {
+    ACF_HIP_TAP_IMAGE = 0,    /* resampled image at a real scale, before smoothing: d planes */
+    ACF_HIP_TAP_SMOOTHED = 1, /* after convTri (logger tags L,U,V chnsCompute.cpp:241-250) */
+    ACF_HIP_TAP_M = 2,        /* gradMag before normalisation (tag M, gradientMag.cpp:112-117) */
+    ACF_HIP_TAP_O = 3,        /* orientation (tag O) */
+    ACF_HIP_TAP_S = 4,        /* convTri(M, normRad) */
+    ACF_HIP_TAP_MNORM = 5,    /* tag Mnorm */
+    ACF_HIP_TAP_CHNS = 6      /* unsmoothed, unpadded channels of a level: nChns planes [wC][hC] */
+};
+/* `index`: real-scale ordinal for taps 0-5, level for ACF_HIP_TAP_CHNS. */
+int acf_hip_read_tap(acf_hip_ctx* ctx, int frame, int tap, int index, float* host_out, int64_t cap_floats);
+
+/* ---- single operators on host planes ---------------------------------
+ * The reference exposes these as static members of acf::Detector
+ * (ACF.h:441-493) and as free functions; each runs the same HIP kernel the
+ * pyramid uses, on one plane set, synchronously. */
+
+/* Detector::rgbConvert (rgbConvert.cpp:101-170) flag = ACF_HIP_CS_LUV or GRAY. */
+int acf_hip_op_rgb_convert(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int flag);
+/* Detector::convTri (convTri.cpp:204-253): r in (0,1] -> convTri1 with the
+ * reference's in-place aliasing semantics when `aliased` != 0; r > 1 -> convTri. */
+int acf_hip_op_conv_tri(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int d, double r, int aliased);
+/* Detector::gradientMag (gradientMag.cpp:102-135). S_out may be NULL. */
+int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float* M, float* O, float* S_out,
+    int h, int w, int normRad, double normConst, int full);
+/* Detector::gradientHist (gradientHist.cpp:92-115), softBin 0. */
+int acf_hip_op_gradient_hist(acf_hip_ctx* ctx, const float* M, const float* O, float* H,
+    int h, int w, int bin, int nOrients, int full);
+/* imResample (imResampleMex.cpp:385-420). */
+int acf_hip_op_im_resample(acf_hip_ctx* ctx, const float* in, float* out, int ha, int wa, int hb, int wb, int d, double nrm);
+/* Detector::acfDetect1 on one host channel buffer [nChns][wP][hP] (acfDetect1.cpp:309-335). */
+int acf_hip_op_acf_detect1(acf_hip_ctx* ctx, const float* chns, int hP, int wP, int nChns,
+    acf_hip_hit* out, int cap, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACF_HIP_H */

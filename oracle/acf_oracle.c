@@ -1,0 +1,1658 @@
+/*
+ * acf_oracle.c — CPU restatement of the reference's chnsPyramid + acfDetect path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under acf_amd/ may include, link or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / reported baseline.
+ *
+ * Each function cites the reference lines it follows (paths relative to
+ * /root/reference/src/lib/acf/acf/, T/ = toolbox/).  Arithmetic is plain IEEE
+ * binary32 in the reference's association order, compiled with
+ * -ffp-contract=off (the reference is a plain SSE2 build: no FMA).
+ *
+ * Pinning status (see tests/test_oracle_vs_ref.py, oracle/Makefile):
+ *  - convTri1 (incl. the in-place aliased call), convTri, grad1/gradMag's
+ *    gradients, gradHist: BIT-EXACT against the reference's own toolbox
+ *    sources compiled unmodified into oracle/_ref/libacfref.so.
+ *  - gradMag M/O, gradMagNorm: the reference uses _mm_rsqrt_ps/_mm_rcp_ps
+ *    (T/sse.hpp:185-192), ~12-bit approximations whose bits are CPU-vendor
+ *    specific; this oracle uses exact 1/sqrt and 1/x at those three sites
+ *    ("T-exact").  Pinned against _ref within the rcp/rsqrt bound (1.5*2^-12
+ *    relative per op).
+ *  - resample / rgb2luv (T/imResampleMex.cpp, T/rgbConvertMex.cpp): those two
+ *    files include OpenCV headers that are absent from this image, so they are
+ *    unbuildable here: PARITY UNPINNED for these two functions (restated line
+ *    by line; checked only through analytic properties).
+ *  - getScales / chnsPyramid / chnsCompute / acfDetect1 / box mapping: integer
+ *    and double control logic restated from OpenCV-typed code that cannot be
+ *    compiled here; the reference's tests hold no golden vectors for them
+ *    (SURVEY.md §4): PARITY UNPINNED by the reference, pinned by the
+ *    committed fixtures in tests/golden/ generated from this file.
+ */
+#include "../include/acf_hip.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ACFO_API __attribute__((visibility("default")))
+
+static void* xmalloc(size_t n)
+{
+    void* p = malloc(n ? n : 1);
+    if (!p)
+    {
+        abort();
+    }
+    return p;
+}
+
+/* ------------------------------------------------------------------------
+ * a1  Detector::getScales — chnsPyramid.cpp:461-529.
+ * Upright naming: H = image height (reference sz.width, because the image is
+ * transposed: chnsPyramid.cpp:232, ACF.cpp:137), W = image width (sz.height).
+ * minDs_h/minDs_w likewise (reference minDs.width/minDs.height, ACFIO.h:168-181).
+ * ---------------------------------------------------------------------- */
+ACFO_API int acfo_get_scales(int nPerOct, int nOctUp, int minDs_h, int minDs_w, int shrink, int H, int W,
+    double* scales, double* shw_h, double* shw_w, int cap)
+{
+    if ((long)H * (long)W == 0)
+    {
+        return 0; /* :476-479 */
+    }
+    /* :481-482  util::log2(x) = log(x)/log(2) (util/acf_math.h:20-29) */
+    double ratio_w = (double)H / (double)minDs_h;
+    double ratio_h = (double)W / (double)minDs_w;
+    double rmin = (ratio_h < ratio_w) ? ratio_h : ratio_w; /* std::min(ratio.width, ratio.height) */
+    int nScales = (int)floor((double)nPerOct * ((double)nOctUp + log(rmin) / log(2.0)) + 1.0);
+    if (nScales <= 0)
+    {
+        return 0;
+    }
+    /* :484-488 */
+    double d0 = (double)W, d1 = (double)H;
+    if (W >= H)
+    {
+        double t = d0;
+        d0 = d1;
+        d1 = t;
+    }
+    double* tmp = (double*)xmalloc(sizeof(double) * (size_t)(nScales + 1));
+    for (int i = 0; i < nScales; i++) /* :490-510 */
+    {
+        double s = pow(2.0, -(double)i / (double)nPerOct + (double)nOctUp);
+        double s0 = (round(d0 * s / shrink) * shrink - 0.25 * shrink) / d0;
+        double s1 = (round(d0 * s / shrink) * shrink + 0.25 * shrink) / d0;
+        double best_ss = 0, best_es = DBL_MAX;
+        for (double j = 0.0; j < 1.0 - DBL_EPSILON; j += 0.01)
+        {
+            double ss = (j * (s1 - s0) + s0);
+            double es0 = d0 * ss;
+            es0 = fabs(es0 - round(es0 / shrink) * shrink);
+            double es1 = d1 * ss;
+            es1 = fabs(es1 - round(es1 / shrink) * shrink);
+            double es = es0 < es1 ? es1 : es0; /* std::max(es0, es1) */
+            if (es < best_es)
+            {
+                best_ss = ss;
+                best_es = es;
+            }
+        }
+        tmp[i] = best_ss;
+    }
+    tmp[nScales] = 0; /* :512-513 */
+    int n = 0;
+    for (int i = 1; i < nScales + 1; i++) /* :515-526 */
+    {
+        if (tmp[i] != tmp[i - 1])
+        {
+            double s = tmp[i - 1];
+            if (n < cap)
+            {
+                scales[n] = s;
+                shw_h[n] = round((double)H * s / shrink) * shrink / H; /* x: sz.width */
+                shw_w[n] = round((double)W * s / shrink) * shrink / W; /* y: sz.height */
+            }
+            n++;
+        }
+    }
+    free(tmp);
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * a9  resampleCoef<float> — T/imResampleMex.cpp:24-121
+ * ---------------------------------------------------------------------- */
+typedef struct
+{
+    int n;
+    int* yas;
+    int* ybs;
+    float* wts;
+    int bd[2];
+} coef_t;
+
+static void resample_coef(int ha, int hb, coef_t* c, int pad)
+{
+    const float s = (float)hb / (float)ha, sInv = 1 / s;
+    float wt, wt0 = (float)1e-3 * s;
+    int ds = ha > hb;
+    int nMax, n;
+    c->bd[0] = c->bd[1] = 0;
+    if (ds)
+    {
+        n = 0;
+        nMax = ha + (pad > 2 ? pad : 2) * hb;
+    }
+    else
+    {
+        n = nMax = hb;
+    }
+    c->wts = (float*)xmalloc(sizeof(float) * (size_t)nMax);
+    c->yas = (int*)xmalloc(sizeof(int) * (size_t)nMax);
+    c->ybs = (int*)xmalloc(sizeof(int) * (size_t)nMax);
+    if (ds)
+    {
+        for (int yb = 0; yb < hb; yb++) /* :47-92 */
+        {
+            float ya0f = yb * sInv, ya1f = ya0f + sInv, W = 0;
+            int ya0 = (int)ceilf(ya0f), ya1 = (int)ya1f, n1 = 0;
+            for (int ya = ya0 - 1; ya < ya1 + 1; ya++)
+            {
+                wt = s;
+                if (ya == ya0 - 1)
+                {
+                    wt = (ya0 - ya0f) * s;
+                }
+                else if (ya == ya1)
+                {
+                    wt = (ya1f - ya1) * s;
+                }
+                if (wt > wt0 && ya >= 0)
+                {
+                    c->ybs[n] = yb;
+                    c->yas[n] = ya;
+                    c->wts[n] = wt;
+                    n++;
+                    n1++;
+                    W += wt;
+                }
+            }
+            if (W > 1)
+            {
+                for (int i = 0; i < n1; i++)
+                {
+                    c->wts[n - n1 + i] /= W;
+                }
+            }
+            if (n1 > c->bd[0])
+            {
+                c->bd[0] = n1;
+            }
+            while (n1 < pad)
+            {
+                c->ybs[n] = yb;
+                c->yas[n] = c->yas[n - 1];
+                c->wts[n] = 0;
+                n++;
+                n1++;
+            }
+        }
+    }
+    else
+    {
+        for (int yb = 0; yb < hb; yb++) /* :96-119 */
+        {
+            float yaf = ((float).5 + yb) * sInv - (float).5;
+            int ya = (int)floorf(yaf);
+            wt = 1;
+            if (ya >= 0 && ya < ha - 1)
+            {
+                wt = 1 - (yaf - ya);
+            }
+            if (ya < 0)
+            {
+                ya = 0;
+                c->bd[0]++;
+            }
+            if (ya >= ha - 1)
+            {
+                ya = ha - 1;
+                c->bd[1]++;
+            }
+            c->ybs[yb] = yb;
+            c->yas[yb] = ya;
+            c->wts[yb] = wt;
+        }
+    }
+    c->n = n;
+}
+
+static void coef_free(coef_t* c)
+{
+    free(c->wts);
+    free(c->yas);
+    free(c->ybs);
+}
+
+/* resample<float> — T/imResampleMex.cpp:124-383.  The SSE and scalar bodies
+ * of the reference compute the same expression (ADD is left-associated,
+ * T/sse.hpp:135-142), so one scalar restatement covers both. */
+ACFO_API int acfo_resample(const float* A, float* B, int ha, int hb, int wa, int wb, int d, float r)
+{
+    if (!A || !B || A == B)
+    {
+        return ACF_HIP_E_INVALID; /* :127-129 */
+    }
+    int hn, wn, x, x1 = 0, y, z, xa, xb, ya;
+    const float *A0, *A1, *A2, *A3;
+    float *B0, wt, wt1;
+    float* C = (float*)xmalloc(sizeof(float) * (size_t)(ha + 4));
+    for (y = ha; y < ha + 4; y++)
+    {
+        C[y] = 0;
+    }
+    coef_t cx, cy;
+    resample_coef(wa, wb, &cx, 0);
+    resample_coef(ha, hb, &cy, 4);
+    wn = cx.n;
+    hn = cy.n;
+    (void)wn;
+    int *xas = cx.yas, *xbs = cx.ybs, *yas = cy.yas, *ybs = cy.ybs;
+    float *xwts = cx.wts, *ywts = cy.wts;
+    int* xbd = cx.bd;
+    int* ybd = cy.bd;
+    if (wa == 2 * wb)
+    {
+        r /= 2;
+    }
+    if (wa == 3 * wb)
+    {
+        r /= 3;
+    }
+    if (wa == 4 * wb)
+    {
+        r /= 4;
+    }
+    r /= (float)(1 + 1e-6);
+    for (y = 0; y < hn; y++)
+    {
+        ywts[y] *= r;
+    }
+    for (z = 0; z < d; z++)
+    {
+        for (x = 0; x < wb; x++)
+        {
+            if (x == 0)
+            {
+                x1 = 0;
+            }
+            xa = xas[x1];
+            xb = xbs[x1];
+            wt = xwts[x1];
+            wt1 = 1 - wt;
+            A0 = A + (size_t)z * ha * wa + (size_t)xa * ha;
+            A1 = A0 + ha;
+            A2 = A1 + ha;
+            A3 = A2 + ha;
+            B0 = B + (size_t)z * hb * wb + (size_t)xb * hb;
+            /* x direction (A -> C) :190-280 */
+            if (wa == 2 * wb)
+            {
+                for (y = 0; y < ha; y++)
+                {
+                    C[y] = A0[y] + A1[y];
+                }
+                x1 += 2;
+            }
+            else if (wa == 3 * wb)
+            {
+                for (y = 0; y < ha; y++)
+                {
+                    C[y] = A0[y] + A1[y] + A2[y];
+                }
+                x1 += 3;
+            }
+            else if (wa == 4 * wb)
+            {
+                for (y = 0; y < ha; y++)
+                {
+                    C[y] = A0[y] + A1[y] + A2[y] + A3[y];
+                }
+                x1 += 4;
+            }
+            else if (wa > wb)
+            {
+                int m = 1;
+                while (x1 + m < cx.n && xb == xbs[x1 + m])
+                {
+                    m++;
+                }
+                if (m == 1)
+                {
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = A0[y] * xwts[x1 + 0];
+                    }
+                }
+                if (m == 2)
+                {
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = A0[y] * xwts[x1 + 0] + A1[y] * xwts[x1 + 1];
+                    }
+                }
+                if (m == 3)
+                {
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = A0[y] * xwts[x1 + 0] + A1[y] * xwts[x1 + 1] + A2[y] * xwts[x1 + 2];
+                    }
+                }
+                if (m >= 4)
+                {
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = A0[y] * xwts[x1 + 0] + A1[y] * xwts[x1 + 1] + A2[y] * xwts[x1 + 2] + A3[y] * xwts[x1 + 3];
+                    }
+                }
+                for (int x0 = 4; x0 < m; x0++)
+                {
+                    A1 = A0 + (size_t)x0 * ha;
+                    wt1 = xwts[x1 + x0];
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = C[y] + A1[y] * wt1;
+                    }
+                }
+                x1 += m;
+            }
+            else
+            {
+                int xBd = x < xbd[0] || x >= wb - xbd[1];
+                x1++;
+                if (xBd)
+                {
+                    memcpy(C, A0, sizeof(float) * (size_t)ha);
+                }
+                else
+                {
+                    for (y = 0; y < ha; y++)
+                    {
+                        C[y] = A0[y] * wt + A1[y] * wt1;
+                    }
+                }
+            }
+            /* y direction (C -> B) :283-373 */
+            if (ha == hb * 2)
+            {
+                float r2 = r / 2;
+                for (y = 0; y < hb; y++)
+                {
+                    B0[y] = (C[2 * y] + C[2 * y + 1]) * r2;
+                }
+            }
+            else if (ha == hb * 3)
+            {
+                for (y = 0; y < hb; y++)
+                {
+                    B0[y] = (C[3 * y] + C[3 * y + 1] + C[3 * y + 2]) * (r / 3);
+                }
+            }
+            else if (ha == hb * 4)
+            {
+                for (y = 0; y < hb; y++)
+                {
+                    B0[y] = (C[4 * y] + C[4 * y + 1] + C[4 * y + 2] + C[4 * y + 3]) * (r / 4);
+                }
+            }
+            else if (ha > hb)
+            {
+                y = 0;
+#define U(o) C[ya + o] * ywts[y * 4 + o]
+                if (ybd[0] == 2)
+                {
+                    for (; y < hb; y++)
+                    {
+                        ya = yas[y * 4];
+                        B0[y] = U(0) + U(1);
+                    }
+                }
+                if (ybd[0] == 3)
+                {
+                    for (; y < hb; y++)
+                    {
+                        ya = yas[y * 4];
+                        B0[y] = U(0) + U(1) + U(2);
+                    }
+                }
+                if (ybd[0] == 4)
+                {
+                    for (; y < hb; y++)
+                    {
+                        ya = yas[y * 4];
+                        B0[y] = U(0) + U(1) + U(2) + U(3);
+                    }
+                }
+                if (ybd[0] > 4)
+                {
+                    memset(B0, 0, sizeof(float) * (size_t)hb);
+                    for (; y < hn; y++)
+                    {
+                        B0[ybs[y]] += C[yas[y]] * ywts[y];
+                    }
+                }
+#undef U
+            }
+            else
+            {
+                for (y = 0; y < ybd[0]; y++)
+                {
+                    B0[y] = C[yas[y]] * ywts[y];
+                }
+                for (; y < hb - ybd[1]; y++)
+                {
+                    B0[y] = C[yas[y]] * ywts[y] + C[yas[y] + 1] * (r - ywts[y]);
+                }
+                for (; y < hb; y++)
+                {
+                    B0[y] = C[yas[y]] * ywts[y];
+                }
+            }
+        }
+    }
+    coef_free(&cx);
+    coef_free(&cy);
+    free(C);
+    return ACF_HIP_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * a3  rgb2luv — T/rgbConvertMex.cpp:20-59 (setup), :62-84 (scalar),
+ *               :88-190 (SSE body).  nrm = 1.
+ * ---------------------------------------------------------------------- */
+static float g_lTable[1064];
+static int g_lInit = 0;
+
+ACFO_API const float* acfo_luv_table(void)
+{
+    if (!g_lInit)
+    {
+        const float y0 = (float)((6.0 / 29) * (6.0 / 29) * (6.0 / 29));
+        const float a = (float)((29.0 / 3) * (29.0 / 3) * (29.0 / 3));
+        float maxi = (float)1.0 / 270;
+        for (int i = 0; i < 1025; i++) /* :47-52 */
+        {
+            float y = (float)(i / 1024.0);
+            float l = y > y0 ? 116 * (float)pow((double)y, 1.0 / 3.0) - 16 : y * a;
+            g_lTable[i] = l * maxi;
+        }
+        for (int i = 1025; i < 1064; i++)
+        {
+            g_lTable[i] = g_lTable[i - 1];
+        }
+        g_lInit = 1;
+    }
+    return g_lTable;
+}
+
+/* I: 3 planes of n floats (R,G,B); J: 3 planes (L,U,V).  The reference takes
+ * the SSE body iff n%4==0 and pointers are 16-byte aligned (:92, :343; cv::Mat
+ * data is); otherwise the scalar body, which associates the denominator
+ * differently and divides (:80-82).  Both are restated; rcp -> exact 1/x. */
+ACFO_API void acfo_rgb2luv(const float* I, float* J, int n)
+{
+    const float* lTable = acfo_luv_table();
+    const float z1 = 1.0f;
+    float mr[3], mg[3], mb[3];
+    const float un = (float)0.197833, vn = (float)0.468331;
+    mr[0] = (float)0.430574 * z1;
+    mr[1] = (float)0.222015 * z1;
+    mr[2] = (float)0.020183 * z1;
+    mg[0] = (float)0.341550 * z1;
+    mg[1] = (float)0.706655 * z1;
+    mg[2] = (float)0.129553 * z1;
+    mb[0] = (float)0.178325 * z1;
+    mb[1] = (float)0.071330 * z1;
+    mb[2] = (float)0.939180 * z1;
+    float maxi = (float)1.0 / 270;
+    const float minu = -88 * maxi, minv = -134 * maxi;
+    const float *R = I, *G = I + n, *Bp = I + 2 * (size_t)n;
+    float *L = J, *U = J + n, *V = J + 2 * (size_t)n;
+    if (n % 4 == 0)
+    {
+        const float cun = 13 * un, cvn = 13 * vn;
+        for (int i = 0; i < n; i++)
+        {
+            float r = R[i], g = G[i], b = Bp[i];
+            float x = (r * mr[0] + g * mg[0]) + b * mb[0]; /* :139 */
+            float y = (r * mr[1] + g * mg[1]) + b * mb[1];
+            float z = (r * mr[2] + g * mg[2]) + b * mb[2];
+            float zz = 1.0f / (x + (1e-35f + (15.0f * y + 3.0f * z))); /* :161, RCP -> exact */
+            float lf = 1024.0f * y;                                   /* :162 */
+            float u = (52.0f * x) * zz - cun;                         /* :163 */
+            float v = (117.0f * y) * zz - cvn;                        /* :164 */
+            float l = lTable[(int)lf];                                /* :171 */
+            L[i] = l;
+            U[i] = l * u - minu; /* :182 */
+            V[i] = l * v - minv; /* :184 */
+        }
+    }
+    else
+    {
+        for (int i = 0; i < n; i++) /* :69-83 */
+        {
+            float r = R[i], g = G[i], b = Bp[i];
+            float x = mr[0] * r + mg[0] * g + mb[0] * b;
+            float y = mr[1] * r + mg[1] * g + mb[1] * b;
+            float z = mr[2] * r + mg[2] * g + mb[2] * b;
+            float l = lTable[(int)(y * 1024)];
+            L[i] = l;
+            z = 1 / (x + 15 * y + 3 * z + (float)1e-35);
+            U[i] = l * (13 * 4 * x * z - 13 * un) - minu;
+            V[i] = l * (13 * 9 * y * z - 13 * vn) - minv;
+        }
+    }
+}
+
+/* rgb2gray — T/rgbConvertMex.cpp:241-252 (nrm = 1) */
+ACFO_API void acfo_rgb2gray(const float* I, float* J, int n)
+{
+    const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
+    const float *R = I, *G = I + n, *B = I + 2 * (size_t)n;
+    for (int i = 0; i < n; i++)
+    {
+        J[i] = R[i] * mr + G[i] * mg + B[i] * mb;
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * a4  convTri1 / convTri1Y (s == 1) — T/convConst.cpp:445-525.
+ * O may alias I: that is how the pyramid calls it (chnsCompute.cpp:239,
+ * chnsPyramid.cpp:404; MatP::create is a no-op for an equal shape,
+ * MatP.cpp:51-73), and then column i-1 has already been overwritten with
+ * output when column i is filtered (H2 in SURVEY.md).  Restated literally so
+ * the aliasing falls out of the pointer arithmetic.
+ * ---------------------------------------------------------------------- */
+static void conv_tri1_y(const float* I, float* O, int h, float p)
+{
+    /* :468-489 (s == 1 branch; SSE C4 == the scalar expression) */
+    int j = 0;
+    O[j] = (1 + p) * I[j] + I[j + 1];
+    j++;
+    for (; j < h - 1; j++)
+    {
+        O[j] = I[j - 1] + p * I[j] + I[j + 1];
+    }
+    O[j] = I[j - 1] + (1 + p) * I[j];
+}
+
+ACFO_API int acfo_conv_tri1(float* I, float* O, int h, int w, int d, float p, int s)
+{
+    if (s != 1 || h < 2)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    const float nrm = 1.0f / ((p + 2) * (p + 2));
+    float* T = (float*)xmalloc(sizeof(float) * (size_t)h);
+    for (int d0 = 0; d0 < d; d0++)
+    {
+        for (int i = s / 2; i < w; i += s)
+        {
+            float *Il, *Im, *Ir;
+            Il = Im = Ir = I + (size_t)i * h + (size_t)d0 * h * w;
+            if (i > 0)
+            {
+                Il -= h;
+            }
+            if (i < w - 1)
+            {
+                Ir += h;
+            }
+            for (int j = 0; j < h; j++)
+            {
+                T[j] = nrm * (Il[j] + p * Im[j] + Ir[j]);
+            }
+            conv_tri1_y(T, O, h, p);
+            O += h / s;
+        }
+    }
+    free(T);
+    return ACF_HIP_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * a6  convTri / convTriY (s == 1) — T/convConst.cpp:269-344, 347-442
+ * ---------------------------------------------------------------------- */
+static void conv_tri_y(const float* I, float* O, int h, int r)
+{
+    r++;
+    float t, u;
+    int j, r0 = r - 1, r1 = r + 1, r2 = 2 * h - r, h0 = r + 1, h1 = h - r + 1, h2 = h;
+    u = t = I[0];
+    for (j = 1; j < r; j++)
+    {
+        u += t += I[j];
+    }
+    u = 2 * u - t;
+    t = 0;
+    O[0] = u;
+    j = 1;
+    for (; j < h0; j++)
+    {
+        O[j] = u += t += I[r - j] + I[r0 + j] - 2 * I[j - 1];
+    }
+    for (; j < h1; j++)
+    {
+        O[j] = u += t += I[j - r1] + I[r0 + j] - 2 * I[j - 1];
+    }
+    for (; j < h2; j++)
+    {
+        O[j] = u += t += I[j - r1] + I[r2 - j] - 2 * I[j - 1];
+    }
+}
+
+ACFO_API int acfo_conv_tri(const float* I, float* O, int h, int w, int d, int r, int s)
+{
+    if (s != 1)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    r++;
+    float nrm = 1.0f / (r * r * r * r);
+    int i, j;
+    float *T = (float*)xmalloc(sizeof(float) * 2 * (size_t)h), *U = T + h;
+    while (d-- > 0)
+    {
+        for (j = 0; j < h; j++) /* :366-400 */
+        {
+            U[j] = T[j] = I[j];
+        }
+        for (i = 1; i < r; i++)
+        {
+            for (j = 0; j < h; j++)
+            {
+                U[j] += T[j] += I[j + (size_t)i * h];
+            }
+        }
+        for (j = 0; j < h; j++)
+        {
+            U[j] = nrm * (2 * U[j] - T[j]);
+            T[j] = 0;
+        }
+        conv_tri_y(U, O, h, r - 1); /* :402-408 with s == 1 */
+        O += h;
+        for (i = 1; i < w; i++) /* :409-438 */
+        {
+            const float* Il = I + (ptrdiff_t)(i - 1 - r) * h;
+            if (i <= r)
+            {
+                Il = I + (ptrdiff_t)(r - i) * h;
+            }
+            const float* Im = I + (ptrdiff_t)(i - 1) * h;
+            const float* Ir = I + (ptrdiff_t)(i - 1 + r) * h;
+            if (i > w - r)
+            {
+                Ir = I + (ptrdiff_t)(2 * w - r - i) * h;
+            }
+            for (j = 0; j < h; j++)
+            {
+                U[j] += nrm * (T[j] += Il[j] + Ir[j] - 2 * Im[j]);
+            }
+            conv_tri_y(U, O, h, r - 1);
+            O += h;
+        }
+        I += (size_t)w * h;
+    }
+    free(T);
+    return ACF_HIP_OK;
+}
+
+/* Detector::convTri dispatch — convTri.cpp:204-253 (+ convConst :144-200).
+ * I may equal J (in place).  The sepFilter2D fallback (:224-251, planes
+ * smaller than 4 or 2r+1 >= min dim) is unreachable from the pyramid because
+ * minDs >= 4*shrink (chnsPyramid.cpp:200) and is reported as unsupported. */
+ACFO_API int acfo_conv_tri_dispatch(float* I, float* J, int h, int w, int d, double r, int s)
+{
+    if (r == 0 && s == 1)
+    {
+        if (I != J)
+        {
+            memcpy(J, I, sizeof(float) * (size_t)h * w * d);
+        }
+        return ACF_HIP_OK;
+    }
+    int m = h < w ? h : w;
+    int nomex = ((m < 4) || (2 * r + 1) >= m);
+    if (nomex)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if ((r > 0) && (r <= 1.0) && (s <= 2))
+    {
+        float p = (float)(12.0 / r / (r + 2.0) - 2.0);
+        return acfo_conv_tri1(I, J, h, w, d, p, s);
+    }
+    float pf = (float)r;
+    int ri = (int)roundf(pf); /* convConst: int r = std::round(p) */
+    if (ri >= m / 2)
+    {
+        return ACF_HIP_E_INVALID; /* "mask larger than image" :166-169 */
+    }
+    if (I == J)
+    {
+        return ACF_HIP_E_INVALID; /* the pyramid never calls convTri(r>1) in place */
+    }
+    return acfo_conv_tri(I, J, h, w, d, ri, s);
+}
+
+/* ------------------------------------------------------------------------
+ * a5  grad1 / ACosTable / gradMag — T/gradientMex.cpp:17-87,103-165,168-251
+ * ---------------------------------------------------------------------- */
+#define ACFO_PI 3.14159265f
+#define ACOS_N 10000
+#define ACOS_B 10
+static float g_acos[ACOS_N * 2 + ACOS_B * 2];
+static int g_acosInit = 0;
+
+ACFO_API const float* acfo_acos_table(void)
+{
+    if (!g_acosInit)
+    {
+        float* a1 = g_acos + ACOS_N + ACOS_B;
+        int i;
+        const int n = ACOS_N, b = ACOS_B;
+        for (i = -n - b; i < -n; i++)
+        {
+            a1[i] = ACFO_PI;
+        }
+        for (i = -n; i < n; i++)
+        {
+            a1[i] = acosf(i / (float)n); /* float(std::acos(float)) */
+        }
+        for (i = n; i < n + b; i++)
+        {
+            a1[i] = 0;
+        }
+        for (i = -n - b; i < n / 10; i++)
+        {
+            if (a1[i] > ACFO_PI - 1e-6f)
+            {
+                a1[i] = ACFO_PI - 1e-6f;
+            }
+        }
+        g_acosInit = 1;
+    }
+    return g_acos; /* index with [i + ACOS_N + ACOS_B] */
+}
+
+static void grad1(const float* I, float* Gx, float* Gy, int h, int w, int x)
+{
+    int y;
+    const float *Ip, *In;
+    float r;
+    Ip = I - h;
+    In = I + h;
+    r = .5f;
+    if (x == 0)
+    {
+        r = 1;
+        Ip += h;
+    }
+    else if (x == w - 1)
+    {
+        r = 1;
+        In -= h;
+    }
+    for (y = 0; y < h; y++)
+    {
+        Gx[y] = (In[y] - Ip[y]) * r;
+    }
+    /* GRADY(1); Ip--; for(y=1; y<h-1; y++) GRADY(.5f); In--; GRADY(1);  :58 */
+    Gy[0] = (I[1] - I[0]) * 1;
+    for (y = 1; y < h - 1; y++)
+    {
+        Gy[y] = (I[y + 1] - I[y - 1]) * .5f;
+    }
+    Gy[h - 1] = (I[h - 1] - I[h - 2]) * 1;
+}
+
+/* Exported so the oracle's gradients can be pinned bit-exactly against the
+ * reference's grad2 (T/gradientMex.cpp:90-101). */
+ACFO_API void acfo_grad2(const float* I, float* Gx, float* Gy, int h, int w, int d)
+{
+    for (int c = 0; c < d; c++)
+    {
+        for (int x = 0; x < w; x++)
+        {
+            size_t o = (size_t)c * w * h + (size_t)x * h;
+            grad1(I + o, Gx + o, Gy + o, h, w, x);
+        }
+    }
+}
+
+ACFO_API int acfo_grad_mag(const float* I, float* M, float* O, int h, int w, int d, int full)
+{
+    if (h < 2 || w < 2)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    const float* acosT = acfo_acos_table() + ACOS_N + ACOS_B;
+    const float acMult = (float)ACOS_N;
+    const float upper = (float)(ACOS_N + ACOS_B - 1), lower = -(float)(ACOS_N + ACOS_B - 1);
+    float* Gx = (float*)xmalloc(sizeof(float) * (size_t)h * d);
+    float* Gy = (float*)xmalloc(sizeof(float) * (size_t)h * d);
+    float* M2 = (float*)xmalloc(sizeof(float) * (size_t)h * d);
+    for (int x = 0; x < w; x++)
+    {
+        for (int c = 0; c < d; c++) /* :191-207 */
+        {
+            grad1(I + (size_t)x * h + (size_t)c * w * h, Gx + (size_t)c * h, Gy + (size_t)c * h, h, w, x);
+            for (int y = 0; y < h; y++)
+            {
+                size_t y1 = (size_t)h * c + y;
+                M2[y1] = Gx[y1] * Gx[y1] + Gy[y1] * Gy[y1];
+                if (c == 0)
+                {
+                    continue;
+                }
+                if (M2[y1] > M2[y])
+                {
+                    M2[y] = M2[y1];
+                    Gx[y] = Gx[y1];
+                    Gy[y] = Gy[y1];
+                }
+            }
+        }
+        for (int y = 0; y < h; y++) /* :209-219; RCPSQRT/RCP -> exact */
+        {
+            float m = 1.0f / sqrtf(M2[y]);
+            m = m < 1e10f ? m : 1e10f; /* _mm_min_ps(a,b): a<b ? a : b */
+            M2[y] = 1.0f / m;
+            if (O)
+            {
+                float g = (Gx[y] * m) * acMult;
+                if (signbit(Gy[y]))
+                {
+                    g = -g; /* XOR with the sign bit of Gy */
+                }
+                g = g < upper ? g : upper; /* MIN_sse */
+                g = g > lower ? g : lower; /* MAX_sse */
+                Gx[y] = g;
+            }
+        }
+        memcpy(M + (size_t)x * h, M2, sizeof(float) * (size_t)h);
+        if (O)
+        {
+            for (int y = 0; y < h; y++)
+            {
+                O[(size_t)x * h + y] = acosT[(int)Gx[y]];
+            }
+            if (full)
+            {
+                for (int y = 0; y < h; y++)
+                {
+                    O[(size_t)x * h + y] += (Gy[y] < 0) * ACFO_PI;
+                }
+            }
+        }
+    }
+    free(Gx);
+    free(Gy);
+    free(M2);
+    return ACF_HIP_OK;
+}
+
+/* a7 gradMagNorm — T/gradientMex.cpp:254-275.  Vector body M*rcp(S+norm) with
+ * rcp -> exact reciprocal; the scalar tail (n%4 trailing elements, or every
+ * element when M/S are not 16-byte aligned) divides.  cv::Mat planes are
+ * aligned, so the tail is the last n%4 elements. */
+ACFO_API void acfo_grad_mag_norm(float* M, const float* S, int h, int w, float norm)
+{
+    int i = 0, n = h * w, n4 = n / 4;
+    for (; i < n4 * 4; i++)
+    {
+        M[i] = M[i] * (1.0f / (S[i] + norm));
+    }
+    for (; i < n; i++)
+    {
+        M[i] /= (S[i] + norm);
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * a8  gradQuantize + gradHist, softBin >= 0 and even ("interpolate w.r.t.
+ * orientation only") — T/gradientMex.cpp:278-372, 375-391, 451-509.
+ * ---------------------------------------------------------------------- */
+ACFO_API int acfo_grad_hist(const float* M, const float* O, float* H, int h, int w, int bin, int nOrients, int softBin, int full)
+{
+    if (softBin < 0 || softBin % 2 != 0)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    const int hb = h / bin, wb = w / bin, h0 = hb * bin, w0 = wb * bin, nb = wb * hb;
+    const float s = (float)bin, sInv2 = 1 / s / s;
+    const float oMult = (float)nOrients / (full ? 2 * ACFO_PI : ACFO_PI);
+    const int oMax = nOrients * nb;
+    int* O0 = (int*)xmalloc(sizeof(int) * (size_t)h);
+    int* O1 = (int*)xmalloc(sizeof(int) * (size_t)h);
+    float* M0 = (float*)xmalloc(sizeof(float) * (size_t)h);
+    float* M1 = (float*)xmalloc(sizeof(float) * (size_t)h);
+    for (int x = 0; x < w0; x++)
+    {
+        const float* Oc = O + (size_t)x * h;
+        const float* Mc = M + (size_t)x * h;
+        for (int i = 0; i < h0; i++) /* gradQuantize, interpolate=true :296-313,331-353 */
+        {
+            float o = Oc[i] * oMult;
+            int o0 = (int)o;
+            float od = o - o0;
+            o0 *= nb;
+            if (o0 >= oMax)
+            {
+                o0 = 0;
+            }
+            O0[i] = o0;
+            int o1 = o0 + nb;
+            if (o1 == oMax)
+            {
+                o1 = 0;
+            }
+            O1[i] = o1;
+            float m = Mc[i] * sInv2;
+            M1[i] = od * m;
+            M0[i] = m - M1[i];
+        }
+        float* H1 = H + (size_t)(x / bin) * hb; /* :454 */
+        for (int y = 0; y < h0;)
+        {
+            for (int y1 = 0; y1 < bin; y1++)
+            {
+                H1[O0[y]] += M0[y];
+                H1[O1[y]] += M1[y];
+                y++;
+            }
+            H1++;
+        }
+    }
+    free(O0);
+    free(O1);
+    free(M0);
+    free(M1);
+    return ACF_HIP_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * Plan: scale list, real/approx split, per-level geometry.
+ * chnsPyramid.cpp:270-292 + acfDetect1.cpp:258-259.
+ * ---------------------------------------------------------------------- */
+static int n_chns(const acf_hip_params* p, int d_color)
+{
+    int n = 0;
+    if (p->colorEnabled)
+    {
+        n += d_color;
+    }
+    if (p->gradMagEnabled)
+    {
+        n += 1;
+    }
+    if (p->gradHistEnabled)
+    {
+        n += p->nOrients;
+    }
+    return n;
+}
+
+/* number of colour planes after rgbConvert (rgbConvert.cpp:101-170) */
+static int color_planes(const acf_hip_params* p, int d_in)
+{
+    if (p->colorSpace == ACF_HIP_CS_GRAY)
+    {
+        return 1;
+    }
+    (void)d_in;
+    return 3;
+}
+
+ACFO_API int acfo_plan(const acf_hip_params* p, int H, int W, int d_in, acf_hip_level* lv, int cap, int* nChnsOut)
+{
+    double* sc = (double*)xmalloc(sizeof(double) * 3 * 4096);
+    int n = acfo_get_scales(p->nPerOct, p->nOctUp, p->minDs_h, p->minDs_w, p->shrink, H, W, sc, sc + 4096, sc + 8192, 4096);
+    int nC = n_chns(p, color_planes(p, d_in));
+    if (nChnsOut)
+    {
+        *nChnsOut = nC;
+    }
+    if (n > cap)
+    {
+        free(sc);
+        return n;
+    }
+    const int shrink = p->shrink;
+    /* :272-292 (1-based isR/isN in the reference, 0-based here) */
+    int* isR = (int*)xmalloc(sizeof(int) * (size_t)(n + 1));
+    int nR = 0;
+    for (int i = 0; i < n; i++)
+    {
+        if ((i % (p->nApprox + 1)) == 0)
+        {
+            isR[nR++] = i + 1;
+        }
+    }
+    int* isH = (int*)xmalloc(sizeof(int) * (size_t)(nR + 2));
+    for (int i = 0; i < nR + 1; i++)
+    {
+        isH[i] = 0;
+    }
+    isH[nR] = n;
+    for (int i = 0; i < (nR - 1 > 0 ? nR - 1 : 0); i++)
+    {
+        isH[i + 1] = (isR[i] + isR[i + 1]) / 2;
+    }
+    int64_t off = 0;
+    for (int i = 0; i < nR; i++)
+    {
+        for (int j = isH[i]; j < isH[i + 1]; j++)
+        {
+            lv[j].realIndex = isR[i] - 1;
+        }
+    }
+    for (int i = 0; i < n; i++)
+    {
+        lv[i].scale = sc[i];
+        lv[i].scalehw_h = sc[4096 + i];
+        lv[i].scalehw_w = sc[8192 + i];
+        lv[i].isReal = (i % (p->nApprox + 1)) == 0;
+        /* :300 / :390: round(sz*s/shrink) */
+        lv[i].hC = (int)round((double)H * sc[i] / (double)shrink);
+        lv[i].wC = (int)round((double)W * sc[i] / (double)shrink);
+        lv[i].hP = lv[i].hC + 2 * (p->pad_h / shrink); /* :417-420 */
+        lv[i].wP = lv[i].wC + 2 * (p->pad_w / shrink);
+        /* acfDetect1.cpp:258-259 */
+        lv[i].nWinR = (int)ceilf((float)(lv[i].hP * shrink - p->modelDsPad_h + 1) / p->stride);
+        lv[i].nWinC = (int)ceilf((float)(lv[i].wP * shrink - p->modelDsPad_w + 1) / p->stride);
+        if (lv[i].nWinR < 0)
+        {
+            lv[i].nWinR = 0;
+        }
+        if (lv[i].nWinC < 0)
+        {
+            lv[i].nWinC = 0;
+        }
+        lv[i].offset = off;
+        off += (int64_t)nC * lv[i].hP * lv[i].wP;
+    }
+    free(isR);
+    free(isH);
+    free(sc);
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * a10  chnsCompute + addChn — chnsCompute.cpp:146-370.
+ * I: d planes [w][h] (colour space already applied, "orig"); smoothed IN
+ * PLACE exactly as the reference does (:239).  out: nC planes [w/shrink][h/shrink].
+ * Optional taps (any may be NULL): M before normalisation, O, S, Mnorm.
+ * ---------------------------------------------------------------------- */
+typedef struct acfo_taps
+{
+    float* image;    /* d planes, before smoothing */
+    float* smoothed; /* d planes */
+    float* M;
+    float* O;
+    float* S;
+    float* Mnorm;
+} acfo_taps;
+
+static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps)
+{
+    const int shrink = p->shrink;
+    if (h % shrink || w % shrink)
+    {
+        return ACF_HIP_E_UNSUPPORTED; /* crop :203-217 never triggers from chnsPyramid */
+    }
+    const int hs = h / shrink, ws = w / shrink;
+    const size_t np = (size_t)h * w, ns = (size_t)hs * ws;
+    int rc;
+    if (taps && taps->image)
+    {
+        memcpy(taps->image, I, sizeof(float) * np * d);
+    }
+    /* :235-239 rgbConvert "orig" = no-op; convTri(I, I, pColor.smooth, 1) in place */
+    rc = acfo_conv_tri_dispatch(I, I, h, w, d, p->colorSmooth, 1);
+    if (rc)
+    {
+        return rc;
+    }
+    if (taps && taps->smoothed)
+    {
+        memcpy(taps->smoothed, I, sizeof(float) * np * d);
+    }
+    float* o = out;
+    if (p->colorEnabled) /* :253-256 addChn -> imResample(.., 1.0) :346-351 */
+    {
+        if (shrink == 1)
+        {
+            memcpy(o, I, sizeof(float) * np * d);
+        }
+        else
+        {
+            rc = acfo_resample(I, o, h, hs, w, ws, d, 1.0f);
+            if (rc)
+            {
+                return rc;
+            }
+        }
+        o += ns * d;
+    }
+    if (!(p->gradMagEnabled || p->gradHistEnabled))
+    {
+        return ACF_HIP_OK;
+    }
+    /* :263-308 */
+    float* M = (float*)xmalloc(sizeof(float) * np);
+    float* O = (float*)xmalloc(sizeof(float) * np);
+    if (p->colorChn < 0 || p->colorChn >= d)
+    {
+        free(M);
+        free(O);
+        return ACF_HIP_E_INVALID;
+    }
+    rc = acfo_grad_mag(I + np * (size_t)p->colorChn, M, O, h, w, 1, p->full); /* gradientMag.cpp:90-98: d = 1 */
+    if (rc)
+    {
+        free(M);
+        free(O);
+        return rc;
+    }
+    if (taps && taps->M)
+    {
+        memcpy(taps->M, M, sizeof(float) * np);
+    }
+    if (taps && taps->O)
+    {
+        memcpy(taps->O, O, sizeof(float) * np);
+    }
+    if (p->normRad != 0) /* gradientMag.cpp:120-132 */
+    {
+        float* S = (float*)xmalloc(sizeof(float) * np);
+        rc = acfo_conv_tri_dispatch(M, S, h, w, 1, (double)p->normRad, 1);
+        if (rc)
+        {
+            free(S);
+            free(M);
+            free(O);
+            return rc;
+        }
+        acfo_grad_mag_norm(M, S, h, w, (float)p->normConst);
+        if (taps && taps->S)
+        {
+            memcpy(taps->S, S, sizeof(float) * np);
+        }
+        free(S);
+    }
+    if (taps && taps->Mnorm)
+    {
+        memcpy(taps->Mnorm, M, sizeof(float) * np);
+    }
+    if (p->gradMagEnabled) /* :303-307 */
+    {
+        if (shrink == 1)
+        {
+            memcpy(o, M, sizeof(float) * np);
+        }
+        else
+        {
+            rc = acfo_resample(M, o, h, hs, w, ws, 1, 1.0f);
+        }
+        o += ns;
+    }
+    if (!rc && p->gradHistEnabled) /* :310-333 */
+    {
+        int binSize = p->binSize ? p->binSize : shrink;
+        if (binSize != shrink)
+        {
+            rc = ACF_HIP_E_UNSUPPORTED;
+        }
+        else
+        {
+            memset(o, 0, sizeof(float) * ns * (size_t)p->nOrients); /* gradientHist.cpp:94-95 */
+            rc = acfo_grad_hist(M, O, o, h, w, binSize, p->nOrients, p->softBin, p->full);
+        }
+    }
+    free(M);
+    free(O);
+    return rc;
+}
+
+ACFO_API int acfo_chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps)
+{
+    return chns_compute(I, h, w, d, p, out, taps);
+}
+
+/* cv::copyMakeBorder(BORDER_REFLECT) on one plane [w][h] -> [w+2px][h+2py]
+ * (chnsPyramid.cpp:410-424; MatP.cpp:122-129).  fedcba|abcdefgh|hgfedcb */
+static inline int reflect(int i, int n)
+{
+    while (i < 0 || i >= n)
+    {
+        if (i < 0)
+        {
+            i = -i - 1;
+        }
+        else
+        {
+            i = 2 * n - 1 - i;
+        }
+    }
+    return i;
+}
+
+static void pad_reflect(const float* src, float* dst, int h, int w, int py, int px)
+{
+    const int hP = h + 2 * py, wP = w + 2 * px;
+    for (int x = 0; x < wP; x++)
+    {
+        int sx = reflect(x - px, w);
+        for (int y = 0; y < hP; y++)
+        {
+            int sy = reflect(y - py, h);
+            dst[(size_t)x * hP + y] = src[(size_t)sx * h + sy];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * a2 + a11  Detector::chnsPyramid — chnsPyramid.cpp:160-456.
+ * frame: d_in planes [W][H].  The caller's frame is NOT modified (the
+ * reference smooths the caller's planes in place through shallow copies when
+ * isLuv; here a private copy takes that role, which yields the same outputs).
+ * levels: from acfo_plan.  out: one frame's fused pyramid (level offsets from
+ * the plan).  taps: per real-scale ordinal, may be NULL.  chns_taps: per
+ * level, unsmoothed/unpadded channels, may be NULL.
+ * ---------------------------------------------------------------------- */
+ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const acf_hip_params* p,
+    const acf_hip_level* lv, int nScales, float* out, const acfo_taps* taps, float* const* chns_taps)
+{
+    if (p->nLambdas != 3 && p->nApprox > 0)
+    {
+        return ACF_HIP_E_UNSUPPORTED; /* a12: image-specific lambdas (:341-374) depend on cv::sum order */
+    }
+    if (p->softBin != 0)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    const int shrink = p->shrink;
+    const size_t np0 = (size_t)H * W;
+    int rc = ACF_HIP_OK;
+    /* :230-263 colour conversion once at full resolution */
+    int d = 0;
+    float* I = NULL; /* current source image for real scales ("I" in the reference) */
+    int Ih = H, Iw = W;
+    {
+        const int cs = p->colorSpace;
+        float* pI;
+        int dI = d_in;
+        if (d_in == 1 && (cs == ACF_HIP_CS_GRAY || cs == ACF_HIP_CS_ORIG)) /* :234-244 replicate to 3 planes */
+        {
+            pI = (float*)xmalloc(sizeof(float) * np0 * 3);
+            for (int k = 0; k < 3; k++)
+            {
+                memcpy(pI + np0 * k, frame, sizeof(float) * np0);
+            }
+            dI = 3;
+        }
+        else if (d_in == 3)
+        {
+            pI = (float*)xmalloc(sizeof(float) * np0 * 3);
+            memcpy(pI, frame, sizeof(float) * np0 * 3);
+        }
+        else
+        {
+            return ACF_HIP_E_INVALID;
+        }
+        /* rgbConvert(pI, I, cs, true, isLuv) — rgbConvert.cpp:101-170 */
+        if (cs == ACF_HIP_CS_ORIG || cs == ACF_HIP_CS_RGB || (p->isLuv && cs == ACF_HIP_CS_LUV))
+        {
+            I = pI;
+            d = dI;
+        }
+        else if (cs == ACF_HIP_CS_LUV)
+        {
+            I = (float*)xmalloc(sizeof(float) * np0 * 3);
+            acfo_rgb2luv(pI, I, (int)np0);
+            free(pI);
+            d = 3;
+        }
+        else if (cs == ACF_HIP_CS_GRAY)
+        {
+            if (p->isLuv)
+            {
+                free(pI);
+                return ACF_HIP_E_INVALID; /* CV_Assert(flag == 2) :150-155 */
+            }
+            I = (float*)xmalloc(sizeof(float) * np0);
+            acfo_rgb2gray(pI, I, (int)np0);
+            free(pI);
+            d = 1;
+        }
+        else
+        {
+            free(pI);
+            return ACF_HIP_E_UNSUPPORTED;
+        }
+    }
+    int nC = n_chns(p, d);
+    /* unsmoothed, unpadded channels per level */
+    float** data = (float**)xmalloc(sizeof(float*) * (size_t)nScales);
+    for (int i = 0; i < nScales; i++)
+    {
+        data[i] = (float*)xmalloc(sizeof(float) * (size_t)nC * lv[i].hC * lv[i].wC);
+    }
+    /* :294-338 real scales, sequential.  Buffer ownership mimics the
+     * reference's shallow copies: I1 == I when sz == sz1 (so chnsCompute's
+     * in-place smoothing mutates I), and I = I1 when s == 0.5. */
+    int realOrd = 0;
+    for (int i = 0; i < nScales && !rc; i++)
+    {
+        if (!lv[i].isReal)
+        {
+            continue;
+        }
+        double s = lv[i].scale;
+        int h1 = (int)round((double)H * s / (double)shrink) * shrink;
+        int w1 = (int)round((double)W * s / (double)shrink) * shrink;
+        float* I1;
+        int I1_is_I = 0;
+        /* NB: the reference compares against sz = Iin.size() (the ORIGINAL
+         * size, :232,:303), not the size of the current I. */
+        if (H == h1 && W == w1)
+        {
+            if (Ih != H || Iw != W)
+            {
+                /* I was replaced by a half-size image yet sz == sz1: the
+                 * reference would hand a wrong-sized I to chnsCompute; this
+                 * cannot happen because scales are strictly decreasing. */
+                rc = ACF_HIP_E_INVALID;
+                break;
+            }
+            I1 = I;
+            I1_is_I = 1;
+        }
+        else
+        {
+            I1 = (float*)xmalloc(sizeof(float) * (size_t)h1 * w1 * d);
+            rc = acfo_resample(I, I1, Ih, h1, Iw, w1, d, 1.0f);
+            if (rc)
+            {
+                free(I1);
+                break;
+            }
+        }
+        if ((s == 0.5) && ((p->nApprox > 0) || (p->nPerOct == 1))) /* :313-316 */
+        {
+            if (!I1_is_I)
+            {
+                free(I);
+                I = I1;
+                Ih = h1;
+                Iw = w1;
+                I1_is_I = 1;
+            }
+        }
+        rc = chns_compute(I1, h1, w1, d, p, data[i], taps ? &taps[realOrd] : NULL);
+        if (!I1_is_I)
+        {
+            free(I1);
+        }
+        realOrd++;
+    }
+    /* :385-397 approximated scales */
+    for (int i = 0; i < nScales && !rc; i++)
+    {
+        if (lv[i].isReal)
+        {
+            continue;
+        }
+        const int iR = lv[i].realIndex;
+        const int hb = lv[i].hC, wb = lv[i].wC, ha = lv[iR].hC, wa = lv[iR].wC;
+        const int nTypeCh[3] = { p->colorEnabled ? d : 0, p->gradMagEnabled ? 1 : 0, p->gradHistEnabled ? p->nOrients : 0 };
+        size_t offA = 0, offB = 0;
+        for (int j = 0; j < 3 && !rc; j++)
+        {
+            if (!nTypeCh[j])
+            {
+                continue;
+            }
+            double ratio = pow(lv[i].scale / lv[iR].scale, -p->lambdas[j]);
+            rc = acfo_resample(data[iR] + offA, data[i] + offB, ha, hb, wa, wb, nTypeCh[j], (float)ratio);
+            offA += (size_t)nTypeCh[j] * ha * wa;
+            offB += (size_t)nTypeCh[j] * hb * wb;
+        }
+    }
+    /* :399-435 smooth (in place, per type = per plane), pad, concat */
+    for (int i = 0; i < nScales && !rc; i++)
+    {
+        const int hC = lv[i].hC, wC = lv[i].wC;
+        if (chns_taps && chns_taps[i])
+        {
+            memcpy(chns_taps[i], data[i], sizeof(float) * (size_t)nC * hC * wC);
+        }
+        rc = acfo_conv_tri_dispatch(data[i], data[i], hC, wC, nC, p->smooth, 1);
+        if (rc)
+        {
+            break;
+        }
+        float* dst = out + lv[i].offset;
+        const int py = p->pad_h / shrink, px = p->pad_w / shrink;
+        for (int c = 0; c < nC; c++)
+        {
+            pad_reflect(data[i] + (size_t)c * hC * wC, dst + (size_t)c * lv[i].hP * lv[i].wP, hC, wC, py, px);
+        }
+    }
+    for (int i = 0; i < nScales; i++)
+    {
+        free(data[i]);
+    }
+    free(data);
+    free(I);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------
+ * a13-a15  createDetector / ParallelDetectionBody / acfDetect1 —
+ * T/acfDetect1.cpp:72-166, 231-335, 390-406 (column-major, no rois).
+ * chns: nC planes [wP][hP].  u8 != 0 selects the uint8_t body (chns/thrs are
+ * then uint8_t arrays, :157-166,187-192).
+ * ---------------------------------------------------------------------- */
+static float evaluate_window(const void* chns1v, int u8, const uint32_t* cids, const acf_hip_params* p, const void* thrsv, float cascThr)
+{
+    const uint32_t* fids = p->fids;
+    const float* hs = p->hs;
+    const uint32_t* child = p->child;
+    const int nTrees = p->nTrees, nTreeNodes = p->nTreeNodes, kDepth = p->treeDepth;
+    const float* cf = (const float*)chns1v;
+    const uint8_t* cu = (const uint8_t*)chns1v;
+    const float* tf = (const float*)thrsv;
+    const uint8_t* tu = (const uint8_t*)thrsv;
+    float h = 0.f;
+    uint32_t isZero = (kDepth == 0);
+    for (int t = 0; t < nTrees; t++) /* :123-138 */
+    {
+        uint32_t offset = (uint32_t)t * (uint32_t)nTreeNodes, k = offset, k0 = (k * isZero);
+        if (kDepth > 0)
+        {
+            for (int i = 0; i < kDepth; i++) /* getChild :100-107 */
+            {
+                uint32_t index = cids[fids[k]];
+                float ftr = u8 ? (float)cu[index] : cf[index];
+                float thr = u8 ? (float)tu[k] : tf[k];
+                k = (ftr < thr) ? 1 : 2;
+                k0 = k += k0 * 2;
+                k += offset;
+            }
+        }
+        else
+        {
+            while (child[k]) /* :146-166 */
+            {
+                uint32_t index = cids[fids[k]];
+                float ftr = u8 ? (float)cu[index] : cf[index];
+                float thr = u8 ? (float)tu[k] : tf[k];
+                k = (ftr < thr) ? 1 : 0;
+                k0 = k = child[k0] - k + offset;
+            }
+        }
+        h += hs[k];
+        if (h <= cascThr)
+        {
+            break;
+        }
+    }
+    return h;
+}
+
+ACFO_API int acfo_acf_detect1(const void* chns, int u8, const void* thrs, int hP, int wP, int nChns, const acf_hip_params* p,
+    acf_hip_hit* out, int cap, int scale_tag)
+{
+    const int shrink = p->shrink, stride = p->stride;
+    const int modelHt = p->modelDsPad_h, modelWd = p->modelDsPad_w; /* after the swap :252-256 */
+    const int height = hP, width = wP;
+    const int height1 = (int)ceilf((float)(height * shrink - modelHt + 1) / stride);
+    const int width1 = (int)ceilf((float)(width * shrink - modelWd + 1) / stride);
+    const int mW = modelWd / shrink, mH = modelHt / shrink;
+    const int rowStride = hP;
+    uint32_t* cids = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)nChns * mW * mH);
+    {
+        int m = 0, area = width * height; /* :390-406 */
+        for (int z = 0; z < nChns; z++)
+        {
+            for (int c = 0; c < mW; c++)
+            {
+                for (int r = 0; r < mH; r++)
+                {
+                    cids[m++] = (uint32_t)(z * area + c * height + r);
+                }
+            }
+        }
+    }
+    const float cascThr = (float)p->cascThr; /* detector->cascThr = cascThr (float member) :323 */
+    int n = 0;
+    for (int c = 0; c < width1; c++) /* :84-98 */
+    {
+        for (int r = 0; r < height1; r++)
+        {
+            int offset = (r * stride / shrink) + (c * stride / shrink) * rowStride;
+            const void* base = u8 ? (const void*)((const uint8_t*)chns + offset) : (const void*)((const float*)chns + offset);
+            float h = evaluate_window(base, u8, cids, p, thrs, cascThr);
+            if (h > cascThr)
+            {
+                if (n < cap)
+                {
+                    out[n].scale = scale_tag;
+                    out[n].c = c;
+                    out[n].r = r;
+                    out[n].score = h;
+                }
+                n++;
+            }
+        }
+    }
+    free(cids);
+    return n;
+}
+
+/* Mean number of trees evaluated per window (diagnostic for the synthetic
+ * model calibration; no reference counterpart). */
+ACFO_API double acfo_mean_trees(const float* chns, int hP, int wP, int nChns, const acf_hip_params* p)
+{
+    const int shrink = p->shrink, stride = p->stride;
+    const int height1 = (int)ceilf((float)(hP * shrink - p->modelDsPad_h + 1) / stride);
+    const int width1 = (int)ceilf((float)(wP * shrink - p->modelDsPad_w + 1) / stride);
+    const int mW = p->modelDsPad_w / shrink, mH = p->modelDsPad_h / shrink;
+    if (height1 <= 0 || width1 <= 0 || p->treeDepth <= 0)
+    {
+        return 0;
+    }
+    const float cascThr = (float)p->cascThr;
+    double total = 0;
+    for (int c = 0; c < width1; c++)
+    {
+        for (int r = 0; r < height1; r++)
+        {
+            const float* c1 = chns + (r * stride / shrink) + (c * stride / shrink) * hP;
+            float h = 0;
+            int t;
+            for (t = 0; t < p->nTrees; t++)
+            {
+                uint32_t offset = (uint32_t)t * p->nTreeNodes, k0 = 0, k = offset;
+                for (int i = 0; i < p->treeDepth; i++)
+                {
+                    uint32_t f = p->fids[k];
+                    uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
+                    float ftr = c1[(size_t)z * hP * wP + cc * hP + rr];
+                    k = (ftr < p->thrs[k]) ? 1 : 2;
+                    k0 = k += k0 * 2;
+                    k += offset;
+                }
+                h += p->hs[k];
+                if (h <= cascThr)
+                {
+                    t++;
+                    break;
+                }
+            }
+            total += t;
+        }
+    }
+    return total / ((double)height1 * width1);
+}
+
+/* ------------------------------------------------------------------------
+ * a16  Detector::operator()(const Pyramid&) without NMS — ACF.cpp:268-367.
+ * pyr: one frame's fused pyramid.  Returns the number of detections.
+ * ---------------------------------------------------------------------- */
+ACFO_API int acfo_detect(const float* pyr, const acf_hip_params* p, const acf_hip_level* lv, int nScales, int nChns,
+    acf_hip_detection* out, acf_hip_hit* hits_out, int cap)
+{
+    /* shift = (modelDsPad - modelDs)/2 - pad  (:275; cv::Size integer ops) */
+    const int shift_h = (p->modelDsPad_h - p->modelDs_h) / 2 - p->pad_h;
+    const int shift_w = (p->modelDsPad_w - p->modelDs_w) / 2 - p->pad_w;
+    acf_hip_hit* hits = (acf_hip_hit*)xmalloc(sizeof(acf_hip_hit) * (size_t)(cap > 0 ? cap : 1));
+    int n = 0;
+    for (int i = 0; i < nScales; i++)
+    {
+        int room = cap - n > 0 ? cap - n : 0;
+        int k = acfo_acf_detect1(pyr + lv[i].offset, 0, p->thrs, lv[i].hP, lv[i].wP, nChns, p, hits, room, i);
+        for (int j = 0; j < k && j < room; j++)
+        {
+            /* acfDetect1.cpp:326-333: roi = ({c*stride, r*stride}, winSize) then swap;
+             * ACF.cpp:302-312: scale up, then swap back. */
+            int rx = hits[j].c * p->stride, ry = hits[j].r * p->stride;
+            /* cv::Size size(cv::Size2d(modelDs) / scale): saturate_cast<int> = cvRound = lrint */
+            int sh = (int)lrint((double)p->modelDs_h / lv[i].scale);
+            int sw = (int)lrint((double)p->modelDs_w / lv[i].scale);
+            acf_hip_detection dd;
+            dd.y = (int)((double)(ry + shift_h) / lv[i].scalehw_h);
+            dd.x = (int)((double)(rx + shift_w) / lv[i].scalehw_w);
+            dd.h = sh;
+            dd.w = sw;
+            dd.score = hits[j].score;
+            dd.scale = i;
+            if (out)
+            {
+                out[n + j] = dd;
+            }
+            if (hits_out)
+            {
+                hits_out[n + j] = hits[j];
+            }
+        }
+        n += k;
+    }
+    free(hits);
+    return n;
+}

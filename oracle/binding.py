@@ -1,0 +1,195 @@
+"""ctypes binding of oracle/liboracle.so and (when present) oracle/_ref/libacfref.so.
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from acf_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libacfref.so")
+
+fp = C.POINTER(C.c_float)
+
+
+class Taps(C.Structure):
+    _fields_ = [("image", fp), ("smoothed", fp), ("M", fp), ("O", fp), ("S", fp), ("Mnorm", fp)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+_o = None
+_r = None
+
+
+def lib():
+    global _o
+    if _o is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        o = C.CDLL(ORACLE_SO)
+        P = C.POINTER(capi.Params)
+        L = C.POINTER(capi.Level)
+        dp = C.POINTER(C.c_double)
+        o.acfo_get_scales.argtypes = [C.c_int] * 7 + [dp, dp, dp, C.c_int]
+        o.acfo_get_scales.restype = C.c_int
+        o.acfo_resample.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+        o.acfo_resample.restype = C.c_int
+        o.acfo_luv_table.restype = fp
+        o.acfo_acos_table.restype = fp
+        o.acfo_rgb2luv.argtypes = [fp, fp, C.c_int]
+        o.acfo_rgb2gray.argtypes = [fp, fp, C.c_int]
+        o.acfo_conv_tri1.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        o.acfo_conv_tri1.restype = C.c_int
+        o.acfo_conv_tri.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        o.acfo_conv_tri.restype = C.c_int
+        o.acfo_conv_tri_dispatch.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        o.acfo_conv_tri_dispatch.restype = C.c_int
+        o.acfo_grad2.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int]
+        o.acfo_grad_mag.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        o.acfo_grad_mag.restype = C.c_int
+        o.acfo_grad_mag_norm.argtypes = [fp, fp, C.c_int, C.c_int, C.c_float]
+        o.acfo_grad_hist.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        o.acfo_grad_hist.restype = C.c_int
+        o.acfo_plan.argtypes = [P, C.c_int, C.c_int, C.c_int, L, C.c_int, C.POINTER(C.c_int)]
+        o.acfo_plan.restype = C.c_int
+        o.acfo_chns_compute.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, fp, C.POINTER(Taps)]
+        o.acfo_chns_compute.restype = C.c_int
+        o.acfo_chns_pyramid.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, L, C.c_int, fp, C.POINTER(Taps), C.POINTER(fp)]
+        o.acfo_chns_pyramid.restype = C.c_int
+        o.acfo_acf_detect1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, P,
+                                       C.POINTER(capi.Hit), C.c_int, C.c_int]
+        o.acfo_acf_detect1.restype = C.c_int
+        o.acfo_mean_trees.argtypes = [fp, C.c_int, C.c_int, C.c_int, P]
+        o.acfo_mean_trees.restype = C.c_double
+        o.acfo_detect.argtypes = [fp, P, L, C.c_int, C.c_int, C.POINTER(capi.Detection), C.POINTER(capi.Hit), C.c_int]
+        o.acfo_detect.restype = C.c_int
+        _o = o
+    return _o
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    """The reference's own toolbox kernels (oracle/_ref/libacfref.so)."""
+    global _r
+    if _r is None:
+        r = C.CDLL(REF_SO)
+        r.ref_convTri.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        r.ref_convTri1.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+        r.ref_grad2.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int]
+        r.ref_gradMag.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        r.ref_gradMagNorm.argtypes = [fp, fp, C.c_int, C.c_int, C.c_float]
+        r.ref_gradHist.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in (r.ref_convTri, r.ref_convTri1, r.ref_grad2, r.ref_gradMag, r.ref_gradMagNorm, r.ref_gradHist):
+            f.restype = None
+        _r = r
+    return _r
+
+
+def aligned(shape, dtype=np.float32, align=64):
+    """numpy array whose data pointer is `align`-byte aligned (the reference's
+    SSE paths require 16-byte alignment, like cv::Mat storage)."""
+    n = int(np.prod(shape))
+    item = np.dtype(dtype).itemsize
+    raw = np.zeros(n * item + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * item].view(dtype).reshape(shape)
+
+
+def aligned_copy(a):
+    b = aligned(a.shape, a.dtype)
+    b[...] = a
+    return b
+
+
+F = capi.fptr
+
+# ---------------------------------------------------------------- high level
+
+
+class Plan:
+    def __init__(self, model, H, W, d_in):
+        self.model = model
+        self.params, self._keep = capi.make_params(model)
+        self.H, self.W, self.d_in = H, W, d_in
+        lv = (capi.Level * 256)()
+        nC = C.c_int(0)
+        n = lib().acfo_plan(C.byref(self.params), H, W, d_in, lv, 256, C.byref(nC))
+        assert 0 <= n <= 256
+        self.levels = lv
+        self.nScales = n
+        self.nChns = nC.value
+        self.total = sum(self.nChns * lv[i].hP * lv[i].wP for i in range(n))
+        self.real = [i for i in range(n) if lv[i].isReal]
+
+    def level_view(self, pyr, i):
+        l = self.levels[i]
+        return pyr[l.offset:l.offset + self.nChns * l.hP * l.wP].reshape(self.nChns, l.wP, l.hP)
+
+
+def chns_pyramid(plan, frame, want_taps=False, want_chns=False):
+    """Oracle chnsPyramid on one frame [d][W][H] -> (flat pyramid, taps, chns)."""
+    o = lib()
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    out = np.zeros(plan.total, dtype=np.float32)
+    taps_c = None
+    taps = None
+    lv = plan.levels
+    d = 1 if plan.model["colorSpace"] == capi.CS_GRAY else 3
+    if want_taps:
+        taps_c = (Taps * len(plan.real))()
+        taps = []
+        sh = plan.model["shrink"]
+        for k, i in enumerate(plan.real):
+            h1, w1 = lv[i].hC * sh, lv[i].wC * sh
+            t = dict(image=np.zeros((d, w1, h1), np.float32), smoothed=np.zeros((d, w1, h1), np.float32),
+                     M=np.zeros((w1, h1), np.float32), O=np.zeros((w1, h1), np.float32),
+                     S=np.zeros((w1, h1), np.float32), Mnorm=np.zeros((w1, h1), np.float32))
+            for name in t:
+                setattr(taps_c[k], name, F(t[name]))
+            taps.append(t)
+    chns_c = None
+    chns = None
+    if want_chns:
+        chns = [np.zeros((plan.nChns, lv[i].wC, lv[i].hC), np.float32) for i in range(plan.nScales)]
+        chns_c = (fp * plan.nScales)(*[F(a) for a in chns])
+    rc = o.acfo_chns_pyramid(F(frame), plan.H, plan.W, plan.d_in, C.byref(plan.params), lv, plan.nScales, F(out),
+                             taps_c, chns_c)
+    if rc:
+        raise RuntimeError("acfo_chns_pyramid rc=%d" % rc)
+    return out, taps, chns
+
+
+def detect(plan, pyr, cap=1 << 16):
+    o = lib()
+    det = np.zeros(cap, dtype=capi.DET_DTYPE)
+    hits = np.zeros(cap, dtype=capi.HIT_DTYPE)
+    n = o.acfo_detect(F(pyr), C.byref(plan.params), plan.levels, plan.nScales, plan.nChns,
+                      det.ctypes.data_as(C.POINTER(capi.Detection)), hits.ctypes.data_as(C.POINTER(capi.Hit)), cap)
+    if n > cap:
+        raise RuntimeError("capacity %d < %d" % (cap, n))
+    return det[:n].copy(), hits[:n].copy()
+
+
+def mean_trees(plan, pyr):
+    o = lib()
+    lv = plan.levels
+    tot, cnt = 0.0, 0
+    for i in range(plan.nScales):
+        nw = max(lv[i].nWinR, 0) * max(lv[i].nWinC, 0)
+        if nw == 0:
+            continue
+        v = plan.level_view(pyr, i)
+        tot += o.acfo_mean_trees(F(v), lv[i].hP, lv[i].wP, plan.nChns, C.byref(plan.params)) * nw
+        cnt += nw
+    return tot / max(cnt, 1), cnt
