@@ -1,0 +1,1830 @@
+// acf_hip.hip — implementation of the C ABI in include/acf_hip.h: context,
+// planning, buffer ownership and kernel launches.  All device work is
+// enqueued on the context's stream; nothing here falls back to the CPU.
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace acfhip;
+
+namespace
+{
+
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct RealScale
+{
+    int level = 0, h = 0, w = 0;
+    bool resampled = false; // image produced by imResample (else it is the current I itself)
+    bool adoptAsI = false;  // after this scale, I := smoothed image of this scale
+    int src_h = 0, src_w = 0;
+    int descIndex = -1;
+    float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
+};
+
+} // namespace
+
+struct acf_hip_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    mutable std::string err;
+    bool hasModel = false, hasPlan = false;
+    int taps = 0;
+
+    acf_hip_params p{};
+    std::vector<uint32_t> fids, child;
+    std::vector<float> thrs, hs;
+
+    Plan plan;
+    int maxBatch = 0, maxHits = 0, lastBatch = 0;
+    bool pyramidValid = false, detectValid = false;
+
+    std::vector<void*> allocs;
+    // constant tables
+    float* d_lTable = nullptr;
+    float* d_acos = nullptr;
+    // planning tables
+    std::vector<RealScale> real;
+    std::vector<ResampleDesc> h_descs; // [real-image resamples..., approx levels...]
+    int nImgDescs = 0, nApproxDescs = 0;
+    ResampleDesc* d_descs = nullptr;
+    int32_t* d_it = nullptr;
+    float* d_ft = nullptr;
+    SmoothJob* d_realJobs = nullptr; // one per real scale
+    SmoothJob* d_finalJobs = nullptr;
+    PadJob* d_padJobs = nullptr;
+    int finalMaxH = 0;
+    int64_t approxMaxElems = 0, padMaxElems = 0;
+    // frame buffers
+    float* d_color = nullptr; // colour-converted full-resolution image (if a conversion is needed)
+    float* d_chns = nullptr;
+    float* d_pyr = nullptr;
+    const float* lastFrames = nullptr;
+    float* d_stage = nullptr; // H2D staging for run_host
+    // cascade
+    CascLevel* d_cascLevels = nullptr;
+    int32_t* d_blockLevel = nullptr;
+    int blocksPerFrame = 0;
+    uint32_t* d_cidAll = nullptr;
+    float *d_thrs = nullptr, *d_hs = nullptr;
+    uint32_t* d_child = nullptr;
+    CascNode2* d_nodes2 = nullptr;
+    BoxLevel* d_boxLevels = nullptr;
+    acf_hip_hit *d_hits = nullptr, *d_sorted = nullptr;
+    acf_hip_detection* d_dets = nullptr;
+    int32_t* d_counts = nullptr;
+    std::vector<int32_t> h_counts;
+    bool countsFetched = false;
+};
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+        {                                                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return ACF_HIP_E_HIP;                                                                          \
+        }                                                                                                  \
+    } while (0)
+
+#define LAUNCHCHK(ctx, what)                                                                               \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                                 \
+        if (e_ != hipSuccess)                                                                              \
+        {                                                                                                  \
+            (ctx)->err = std::string("launch ") + what + ": " + hipGetErrorString(e_);                    \
+            return ACF_HIP_E_HIP;                                                                          \
+        }                                                                                                  \
+    } while (0)
+
+namespace
+{
+
+int fail(const acf_hip_ctx* c, int code, const std::string& msg)
+{
+    c->err = msg;
+    return code;
+}
+
+template <class T>
+int devAlloc(acf_hip_ctx* c, T** out, size_t count)
+{
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    c->allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return ACF_HIP_OK;
+}
+
+template <class T>
+int devUpload(acf_hip_ctx* c, T** out, const std::vector<T>& v)
+{
+    int rc = devAlloc(c, out, v.size());
+    if (rc)
+    {
+        return rc;
+    }
+    if (!v.empty())
+    {
+        HIPCHK(c, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    return ACF_HIP_OK;
+}
+
+void freeAll(acf_hip_ctx* c)
+{
+    for (void* p : c->allocs)
+    {
+        (void)hipFree(p);
+    }
+    c->allocs.clear();
+    c->hasPlan = false;
+    c->d_lTable = c->d_acos = nullptr;
+}
+
+// rgb2luv_setup's table (toolbox/rgbConvertMex.cpp:39-58)
+std::vector<float> makeLTable()
+{
+    std::vector<float> t(1064);
+    const float y0 = (float)((6.0 / 29) * (6.0 / 29) * (6.0 / 29));
+    const float a = (float)((29.0 / 3) * (29.0 / 3) * (29.0 / 3));
+    const float maxi = (float)1.0 / 270;
+    for (int i = 0; i < 1025; i++)
+    {
+        float y = (float)(i / 1024.0);
+        float l = y > y0 ? 116 * (float)pow((double)y, 1.0 / 3.0) - 16 : y * a;
+        t[i] = l * maxi;
+    }
+    for (int i = 1025; i < 1064; i++)
+    {
+        t[i] = t[i - 1];
+    }
+    return t;
+}
+
+LuvConsts makeLuvConsts()
+{
+    LuvConsts k;
+    const float z = 1.0f;
+    k.un = (float)0.197833;
+    k.vn = (float)0.468331;
+    k.mr[0] = (float)0.430574 * z;
+    k.mr[1] = (float)0.222015 * z;
+    k.mr[2] = (float)0.020183 * z;
+    k.mg[0] = (float)0.341550 * z;
+    k.mg[1] = (float)0.706655 * z;
+    k.mg[2] = (float)0.129553 * z;
+    k.mb[0] = (float)0.178325 * z;
+    k.mb[1] = (float)0.071330 * z;
+    k.mb[2] = (float)0.939180 * z;
+    const float maxi = (float)1.0 / 270;
+    k.minu = -88 * maxi;
+    k.minv = -134 * maxi;
+    k.cun = 13 * k.un;
+    k.cvn = 13 * k.vn;
+    return k;
+}
+
+// ACosTable (toolbox/gradientMex.cpp:103-165): 2*(n+b) entries, centre at n+b.
+std::vector<float> makeAcosTable()
+{
+    const int n = 10000, b = 10;
+    const float PI = 3.14159265f;
+    std::vector<float> a(2 * n + 2 * b);
+    float* a1 = a.data() + n + b;
+    for (int i = -n - b; i < -n; i++)
+    {
+        a1[i] = PI;
+    }
+    for (int i = -n; i < n; i++)
+    {
+        a1[i] = float(std::acos(i / float(n)));
+    }
+    for (int i = n; i < n + b; i++)
+    {
+        a1[i] = 0;
+    }
+    for (int i = -n - b; i < n / 10; i++)
+    {
+        if (a1[i] > PI - 1e-6f)
+        {
+            a1[i] = PI - 1e-6f;
+        }
+    }
+    return a;
+}
+
+int ensureConstTables(acf_hip_ctx* c)
+{
+    if (c->d_lTable)
+    {
+        return ACF_HIP_OK;
+    }
+    int rc = devUpload(c, &c->d_lTable, makeLTable());
+    if (rc)
+    {
+        return rc;
+    }
+    return devUpload(c, &c->d_acos, makeAcosTable());
+}
+
+inline int cdiv(int64_t a, int64_t b)
+{
+    return int((a + b - 1) / b);
+}
+
+// ---- kernel launch helpers (shared by the pyramid and the op_* entry points) ----
+
+int launchSmooth(acf_hip_ctx* c, const float* in, float* out, const SmoothJob* d_jobs, int nJobs, int maxPlanes, int maxH,
+    int64_t in_fs, int64_t out_fs, int nFrames, float p, bool aliased)
+{
+    // threads along y; up to 1024 per workgroup, R interleaved rows per thread
+    int nt = std::min(1024, ((maxH + 63) / 64) * 64);
+    if (maxH <= 512)
+    {
+        nt = std::min(nt, 256);
+    }
+    const int R = (maxH + nt - 1) / nt;
+    const int ldsStride = maxH + 1;
+    const size_t lds = 2 * size_t(ldsStride) * sizeof(float);
+    dim3 grid(maxPlanes, nJobs, nFrames), block(nt);
+#define SM_LAUNCH(RR)                                                                                                    \
+    if (aliased)                                                                                                         \
+        hipLaunchKernelGGL((k_smooth_tri1<RR, true>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride); \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((k_smooth_tri1<RR, false>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride);
+    switch (R)
+    {
+        case 1:
+            SM_LAUNCH(1);
+            break;
+        case 2:
+            SM_LAUNCH(2);
+            break;
+        case 3:
+            SM_LAUNCH(3);
+            break;
+        case 4:
+            SM_LAUNCH(4);
+            break;
+        default:
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "smooth: plane taller than 4096 rows");
+    }
+#undef SM_LAUNCH
+    LAUNCHCHK(c, "k_smooth_tri1");
+    return ACF_HIP_OK;
+}
+
+int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames)
+{
+    if (rad > 15)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "convTri: radius > 15");
+    }
+    hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
+    LAUNCHCHK(c, "k_tri_x");
+    hipLaunchKernelGGL(k_tri_y, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, rad, fs);
+    LAUNCHCHK(c, "k_tri_y");
+    return ACF_HIP_OK;
+}
+
+float shrinkGainY(int S)
+{
+    // imResampleMex.cpp:145-157 with r = 1 and wa == S*wb, then :286/:316 r/S
+    float r = 1.0f;
+    r /= (float)S;
+    r /= float(1 + 1e-6);
+    return r / (float)S;
+}
+
+int launchChns(acf_hip_ctx* c, const ChnsArgs& a, int shrink, int nFrames)
+{
+    const int hc = a.h / shrink, wc = a.w / shrink;
+    dim3 grid(cdiv(hc, 256), wc, nFrames), block(256);
+    if (hc <= 64)
+    {
+        block = dim3(64);
+        grid = dim3(cdiv(hc, 64), wc, nFrames);
+    }
+    else if (hc <= 128)
+    {
+        block = dim3(128);
+        grid = dim3(cdiv(hc, 128), wc, nFrames);
+    }
+    if (shrink == 4)
+    {
+        hipLaunchKernelGGL(k_chns<4>, grid, block, 0, c->stream, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_chns<2>, grid, block, 0, c->stream, a);
+    }
+    LAUNCHCHK(c, "k_chns");
+    return ACF_HIP_OK;
+}
+
+} // namespace
+
+namespace
+{
+struct Scratch
+{
+    std::vector<void*> ptrs;
+    ~Scratch()
+    {
+        for (void* p : ptrs)
+        {
+            (void)hipFree(p);
+        }
+    }
+    template <class T>
+    T* alloc(size_t n)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess)
+        {
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    template <class T>
+    T* upload(const T* h, size_t n)
+    {
+        T* d = alloc<T>(n);
+        if (d && n && hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+        {
+            return nullptr;
+        }
+        return d;
+    }
+};
+} // namespace
+
+// gradMagNorm as a stand-alone kernel (only the op_gradient_mag entry point
+// needs it; the pyramid fuses it into k_chns).  toolbox/gradientMex.cpp:254-275.
+__global__ void __launch_bounds__(256) k_norm(float* __restrict__ M, const float* __restrict__ S, int n, float norm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const int n4 = (n / 4) * 4;
+    if (i < n4)
+    {
+        M[i] = M[i] * (1.0f / (S[i] + norm));
+    }
+    else
+    {
+        M[i] = M[i] / (S[i] + norm);
+    }
+}
+
+// Strided plane copy for smooth == 0 (convTri.cpp:206-210: J = I).
+__global__ void __launch_bounds__(256) k_copy_planes(const float* __restrict__ in, float* __restrict__ out, const SmoothJob* __restrict__ jobs,
+    int64_t in_fs, int64_t out_fs)
+{
+    const SmoothJob j = jobs[blockIdx.y];
+    const int64_t per = int64_t(j.h) * j.w;
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= per * j.nplanes)
+    {
+        return;
+    }
+    const int z = int(e / per);
+    const int rem = int(e - int64_t(z) * per);
+    const int x = rem / j.h, y = rem - x * j.h;
+    out[int64_t(blockIdx.z) * out_fs + j.out_off + int64_t(z) * j.out_ps + int64_t(x) * j.out_cs + y] =
+        in[int64_t(blockIdx.z) * in_fs + j.in_off + int64_t(z) * j.in_ps + rem];
+}
+
+extern "C" {
+
+int acf_hip_abi_version(void)
+{
+    return ACF_HIP_ABI_VERSION;
+}
+
+int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
+{
+    if (!out)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    {
+        return ACF_HIP_E_NODEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess)
+    {
+        return ACF_HIP_E_NODEVICE;
+    }
+    acf_hip_ctx* c = new (std::nothrow) acf_hip_ctx();
+    if (!c)
+    {
+        return ACF_HIP_E_HIP;
+    }
+    c->device = device;
+    if (stream)
+    {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    }
+    else
+    {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        {
+            delete c;
+            return ACF_HIP_E_HIP;
+        }
+        c->ownStream = true;
+    }
+    *out = c;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_destroy(acf_hip_ctx* c)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    freeAll(c);
+    if (c->ownStream)
+    {
+        (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+    return ACF_HIP_OK;
+}
+
+const char* acf_hip_last_error(const acf_hip_ctx* c)
+{
+    return c ? c->err.c_str() : "null context";
+}
+
+int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
+{
+    if (!c || !key)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (!strcmp(key, "taps"))
+    {
+        c->taps = value != 0;
+        return ACF_HIP_OK;
+    }
+    return fail(c, ACF_HIP_E_INVALID, std::string("unknown option ") + key);
+}
+
+int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
+{
+    if (!c || !p)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (p->nTrees <= 0 || p->nTreeNodes <= 0 || !p->fids || !p->thrs || !p->hs)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: empty classifier");
+    }
+    if (p->treeDepth < 0 || p->treeDepth > 8)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: treeDepth must be 0..8 (acfDetect1.cpp:204-226)");
+    }
+    if (p->treeDepth == 0 && !p->child)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: treeDepth 0 needs child[]");
+    }
+    if (p->treeDepth > 0 && p->nTreeNodes < (1 << (p->treeDepth + 1)) - 1)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: nTreeNodes too small for treeDepth");
+    }
+    if (p->stride <= 0 || p->shrink <= 0 || p->modelDsPad_h % p->shrink || p->modelDsPad_w % p->shrink)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: stride/shrink/modelDsPad");
+    }
+    if (p->nOrients < 1 || p->nOrients > 12)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "set_model: nOrients must be 1..12");
+    }
+    const size_t n = size_t(p->nTrees) * p->nTreeNodes;
+    c->p = *p;
+    c->fids.assign(p->fids, p->fids + n);
+    c->thrs.assign(p->thrs, p->thrs + n);
+    c->hs.assign(p->hs, p->hs + n);
+    if (p->child)
+    {
+        c->child.assign(p->child, p->child + n);
+    }
+    else
+    {
+        c->child.assign(n, 0u);
+    }
+    c->p.fids = c->fids.data();
+    c->p.thrs = c->thrs.data();
+    c->p.hs = c->hs.data();
+    c->p.child = c->child.data();
+    c->hasModel = true;
+    if (c->hasPlan)
+    {
+        (void)hipStreamSynchronize(c->stream);
+        freeAll(c);
+    }
+    return ACF_HIP_OK;
+}
+
+// Build the cascade tables for a list of level geometries (hP, wP) into the
+// context.  Shared by acf_hip_plan and acf_hip_op_acf_detect1.
+static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns,
+    CascLevel** d_levels, int32_t** d_blockLevel, int* blocksPerFrame, uint32_t** d_cidAll, CascNode2** d_nodes2)
+{
+    const acf_hip_params& p = c->p;
+    const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
+    const uint32_t nF = uint32_t(nChns) * mH * mW;
+    const size_t nNodes = size_t(p.nTrees) * p.nTreeNodes;
+    const bool packed = p.treeDepth == 2;
+    std::vector<CascLevel> cl(lv.size());
+    std::vector<int32_t> bl;
+    std::vector<uint32_t> cidAll;
+    std::vector<CascNode2> nodes2;
+    // which nodes carry a feature test
+    std::vector<uint8_t> internal(nNodes, 0);
+    for (int t = 0; t < p.nTrees; t++)
+    {
+        for (int k = 0; k < p.nTreeNodes; k++)
+        {
+            const size_t q = size_t(t) * p.nTreeNodes + k;
+            internal[q] = p.treeDepth > 0 ? (k < (1 << p.treeDepth) - 1) : (c->child[q] != 0);
+            if (internal[q] && c->fids[q] >= nF)
+            {
+                return fail(c, ACF_HIP_E_INVALID, "model: feature id out of range for modelDsPad/shrink/channels");
+            }
+            if (p.treeDepth == 0 && c->child[q] != 0)
+            {
+                // child[k0]-k+offset must stay inside the tree
+                if (c->child[q] >= uint32_t(p.nTreeNodes) || c->child[q] < 1)
+                {
+                    return fail(c, ACF_HIP_E_INVALID, "model: child index out of range");
+                }
+            }
+        }
+    }
+    int block = 0;
+    for (size_t i = 0; i < lv.size(); i++)
+    {
+        CascLevel& L = cl[i];
+        L.hP = lv[i].hP;
+        L.wP = lv[i].wP;
+        L.nWinR = lv[i].nWinR;
+        L.nWinC = lv[i].nWinC;
+        L.nWin = L.nWinR * L.nWinC;
+        L.off = lv[i].offset;
+        L.firstBlock = block;
+        const int nb = cdiv(L.nWin, 256);
+        for (int b = 0; b < nb; b++)
+        {
+            bl.push_back(int32_t(i));
+        }
+        block += nb;
+        const int64_t area = int64_t(L.hP) * L.wP;
+        if (area * nChns >= (int64_t(1) << 31))
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "level too large for 32-bit channel offsets");
+        }
+        if (packed)
+        {
+            L.nodeOff = int64_t(nodes2.size());
+            for (int t = 0; t < p.nTrees; t++)
+            {
+                CascNode2 nd{};
+                const size_t q = size_t(t) * p.nTreeNodes;
+                for (int k = 0; k < 3; k++)
+                {
+                    const uint32_t f = c->fids[q + k];
+                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
+                    nd.cid[k] = uint32_t(z * area + int64_t(cc) * L.hP + rr); // computeChannelIndexColMajor, acfDetect1.cpp:390-406
+                    nd.thr[k] = c->thrs[q + k];
+                }
+                for (int k = 0; k < 4; k++)
+                {
+                    nd.hs[k] = c->hs[q + 3 + k];
+                }
+                nodes2.push_back(nd);
+            }
+        }
+        else
+        {
+            L.nodeOff = int64_t(cidAll.size());
+            for (size_t q = 0; q < nNodes; q++)
+            {
+                uint32_t v = 0;
+                if (internal[q])
+                {
+                    const uint32_t f = c->fids[q];
+                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
+                    v = uint32_t(z * area + int64_t(cc) * L.hP + rr);
+                }
+                cidAll.push_back(v);
+            }
+        }
+    }
+    *blocksPerFrame = block;
+    int rc;
+    if ((rc = devUpload(c, d_levels, cl)))
+    {
+        return rc;
+    }
+    if ((rc = devUpload(c, d_blockLevel, bl)))
+    {
+        return rc;
+    }
+    if ((rc = devUpload(c, d_cidAll, cidAll)))
+    {
+        return rc;
+    }
+    if ((rc = devUpload(c, d_nodes2, nodes2)))
+    {
+        return rc;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_hits)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (!c->hasModel)
+    {
+        return fail(c, ACF_HIP_E_NOMODEL, "plan: set_model first");
+    }
+    if (max_batch <= 0 || max_hits <= 0)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "plan: max_batch/max_hits");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    freeAll(c);
+    const acf_hip_params& p = c->p;
+    int rc = buildPlan(p, H, W, d_in, c->plan, c->err);
+    if (rc)
+    {
+        return rc;
+    }
+    Plan& pl = c->plan;
+    // smoothing radii the recursion kernel implements (convTri.cpp:215-218)
+    for (double r : { p.colorSmooth, p.smooth })
+    {
+        if (!(r == 0.0 || (r > 0 && r <= 1.0)))
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: smoothing radius must be 0 or in (0,1]");
+        }
+    }
+    if (p.normRad < 0 || p.normRad == 1 || p.normRad > 15)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: normRad must be 0 or 2..15");
+    }
+    if ((rc = ensureConstTables(c)))
+    {
+        return rc;
+    }
+    c->maxBatch = max_batch;
+    c->maxHits = max_hits;
+    const int B = max_batch;
+    const int shrink = p.shrink;
+    const int d = pl.d;
+    const int64_t np0 = int64_t(H) * W;
+
+    // colour conversion buffer (chnsPyramid.cpp:230-263)
+    const bool passthrough = (d_in == 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+    if (!passthrough)
+    {
+        if ((rc = devAlloc(c, &c->d_color, size_t(B) * d * np0)))
+        {
+            return rc;
+        }
+    }
+
+    // real scales: mirror the reference's shallow-copy bookkeeping (chnsPyramid.cpp:297-338)
+    TableArena arena;
+    c->h_descs.clear();
+    c->real.clear();
+    int curH = H, curW = W;
+    std::vector<SmoothJob> realJobs;
+    for (size_t k = 0; k < pl.real.size(); k++)
+    {
+        RealScale rs;
+        rs.level = pl.real[k];
+        rs.h = pl.real_h[k];
+        rs.w = pl.real_w[k];
+        const double s = pl.levels[rs.level].scale;
+        const bool same = (H == rs.h && W == rs.w); // sz == sz1 (:303), compared against the ORIGINAL size
+        if (same && (curH != H || curW != W))
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: scale order");
+        }
+        rs.resampled = !same;
+        rs.src_h = curH;
+        rs.src_w = curW;
+        const int64_t np = int64_t(rs.h) * rs.w;
+        if (rs.resampled)
+        {
+            ResampleDesc dd;
+            if ((rc = buildResample(curH, curW, rs.h, rs.w, dd, arena)))
+            {
+                return fail(c, rc, "plan: degenerate resample geometry");
+            }
+            const double one[3] = { 1.0, 1.0, 1.0 };
+            setResampleGain(dd, one, d, d);
+            dd.nplanes = d;
+            dd.src_off = 0;
+            dd.dst_off = 0;
+            dd.src_frame_stride = int64_t(d) * curH * curW;
+            dd.dst_frame_stride = int64_t(d) * np;
+            rs.descIndex = int(c->h_descs.size());
+            c->h_descs.push_back(dd);
+            if ((rc = devAlloc(c, &rs.img, size_t(B) * d * np)))
+            {
+                return rc;
+            }
+        }
+        const bool halfCond = (s == 0.5) && ((p.nApprox > 0) || (p.nPerOct == 1)); // :313-316
+        rs.adoptAsI = same || halfCond;
+        if (rs.adoptAsI)
+        {
+            curH = rs.h;
+            curW = rs.w;
+        }
+        if ((rc = devAlloc(c, &rs.sm, size_t(B) * d * np)))
+        {
+            return rc;
+        }
+        if (p.gradMagEnabled || p.gradHistEnabled)
+        {
+            if ((rc = devAlloc(c, &rs.M, size_t(B) * np)) || (rc = devAlloc(c, &rs.O, size_t(B) * np)))
+            {
+                return rc;
+            }
+            if (p.normRad)
+            {
+                if ((rc = devAlloc(c, &rs.U, size_t(B) * np)) || (rc = devAlloc(c, &rs.S, size_t(B) * np)))
+                {
+                    return rc;
+                }
+            }
+            if (c->taps)
+            {
+                if ((rc = devAlloc(c, &rs.Mn, size_t(B) * np)))
+                {
+                    return rc;
+                }
+            }
+        }
+        SmoothJob j{};
+        j.h = rs.h;
+        j.w = rs.w;
+        j.nplanes = d;
+        j.out_cs = rs.h;
+        j.in_off = 0;
+        j.out_off = 0;
+        j.in_ps = np;
+        j.out_ps = np;
+        realJobs.push_back(j);
+        c->real.push_back(rs);
+    }
+    c->nImgDescs = int(c->h_descs.size());
+
+    // approximated levels (chnsPyramid.cpp:385-397)
+    const int nColor = p.colorEnabled ? d : 0;
+    const int nMag = p.gradMagEnabled ? 1 : 0;
+    c->approxMaxElems = 0;
+    for (size_t i = 0; i < pl.levels.size(); i++)
+    {
+        const acf_hip_level& l = pl.levels[i];
+        if (l.isReal)
+        {
+            continue;
+        }
+        const acf_hip_level& lr = pl.levels[l.realIndex];
+        ResampleDesc dd;
+        if ((rc = buildResample(lr.hC, lr.wC, l.hC, l.wC, dd, arena)))
+        {
+            return fail(c, rc, "plan: degenerate resample geometry (approximated level)");
+        }
+        double ratio[3];
+        for (int j = 0; j < 3; j++)
+        {
+            ratio[j] = std::pow(l.scale / lr.scale, -p.lambdas[j]); // :393
+        }
+        setResampleGain(dd, ratio, nColor, nColor + nMag);
+        dd.nplanes = pl.nChns;
+        dd.src_off = pl.raw_off[l.realIndex];
+        dd.dst_off = pl.raw_off[i];
+        dd.src_frame_stride = pl.raw_floats;
+        dd.dst_frame_stride = pl.raw_floats;
+        c->h_descs.push_back(dd);
+        c->approxMaxElems = std::max<int64_t>(c->approxMaxElems, int64_t(pl.nChns) * l.hC * l.wC);
+    }
+    c->nApproxDescs = int(c->h_descs.size()) - c->nImgDescs;
+
+    // final smoothing + padding jobs (chnsPyramid.cpp:399-435)
+    std::vector<SmoothJob> finalJobs;
+    std::vector<PadJob> padJobs;
+    c->finalMaxH = 0;
+    c->padMaxElems = 0;
+    const int py = p.pad_h / shrink, px = p.pad_w / shrink;
+    for (size_t i = 0; i < pl.levels.size(); i++)
+    {
+        const acf_hip_level& l = pl.levels[i];
+        SmoothJob j{};
+        j.h = l.hC;
+        j.w = l.wC;
+        j.nplanes = pl.nChns;
+        j.out_cs = l.hP;
+        j.in_off = pl.raw_off[i];
+        j.out_off = l.offset + int64_t(px) * l.hP + py;
+        j.in_ps = int64_t(l.hC) * l.wC;
+        j.out_ps = int64_t(l.hP) * l.wP;
+        finalJobs.push_back(j);
+        c->finalMaxH = std::max(c->finalMaxH, l.hC);
+        PadJob q{};
+        q.hC = l.hC;
+        q.wC = l.wC;
+        q.hP = l.hP;
+        q.wP = l.wP;
+        q.py = py;
+        q.px = px;
+        q.nplanes = pl.nChns;
+        q.off = l.offset;
+        padJobs.push_back(q);
+        c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * l.hP * l.wP);
+    }
+    if ((rc = devUpload(c, &c->d_descs, c->h_descs)) || (rc = devUpload(c, &c->d_it, arena.ints)) || (rc = devUpload(c, &c->d_ft, arena.floats)) ||
+        (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)))
+    {
+        return rc;
+    }
+    if ((rc = devAlloc(c, &c->d_chns, size_t(B) * pl.raw_floats)) || (rc = devAlloc(c, &c->d_pyr, size_t(B) * pl.pyr_floats)))
+    {
+        return rc;
+    }
+    // cascade
+    if ((rc = buildCascadeTables(c, pl.levels, pl.nChns, &c->d_cascLevels, &c->d_blockLevel, &c->blocksPerFrame, &c->d_cidAll, &c->d_nodes2)))
+    {
+        return rc;
+    }
+    if ((rc = devUpload(c, &c->d_thrs, c->thrs)) || (rc = devUpload(c, &c->d_hs, c->hs)) || (rc = devUpload(c, &c->d_child, c->child)))
+    {
+        return rc;
+    }
+    std::vector<BoxLevel> box(pl.levels.size());
+    for (size_t i = 0; i < pl.levels.size(); i++)
+    {
+        box[i].shw_h = pl.levels[i].scalehw_h;
+        box[i].shw_w = pl.levels[i].scalehw_w;
+        // cv::Size(cv::Size2d(modelDs) / scale): saturate_cast<int>(double) == cvRound (ACF.cpp:304)
+        box[i].bh = int(std::lrint(double(p.modelDs_h) / pl.levels[i].scale));
+        box[i].bw = int(std::lrint(double(p.modelDs_w) / pl.levels[i].scale));
+    }
+    if ((rc = devUpload(c, &c->d_boxLevels, box)))
+    {
+        return rc;
+    }
+    if ((rc = devAlloc(c, &c->d_hits, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->d_sorted, size_t(B) * max_hits)) ||
+        (rc = devAlloc(c, &c->d_dets, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->d_counts, size_t(B))))
+    {
+        return rc;
+    }
+    c->h_counts.assign(B, 0);
+    c->hasPlan = true;
+    c->pyramidValid = c->detectValid = false;
+    c->lastBatch = 0;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_num_levels(const acf_hip_ctx* c, int* nScales, int* nChns)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (nScales)
+    {
+        *nScales = int(c->plan.levels.size());
+    }
+    if (nChns)
+    {
+        *nChns = c->plan.nChns;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_levels(const acf_hip_ctx* c, acf_hip_level* out, int cap)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (!out || cap < int(c->plan.levels.size()))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "get_levels: capacity");
+    }
+    std::copy(c->plan.levels.begin(), c->plan.levels.end(), out);
+    return ACF_HIP_OK;
+}
+
+int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    *n = c->plan.pyr_floats;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
+{
+    if (!c || !c->hasPlan)
+    {
+        return c ? fail(c, ACF_HIP_E_NOPLAN, "pyramid: plan first") : ACF_HIP_E_INVALID;
+    }
+    if (!frames || nF <= 0 || nF > c->maxBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const acf_hip_params& p = c->p;
+    const Plan& pl = c->plan;
+    const int H = pl.H, W = pl.W, d = pl.d, d_in = pl.d_in, shrink = p.shrink;
+    const int64_t np0 = int64_t(H) * W;
+    c->pyramidValid = c->detectValid = false;
+    c->lastFrames = frames;
+    int rc;
+
+    // ---- colour conversion, once at full resolution (chnsPyramid.cpp:230-263)
+    const float* cur = frames; // "I"
+    int64_t cur_fs = int64_t(d_in) * np0;
+    int curH = H, curW = W;
+    if (c->d_color)
+    {
+        dim3 grid(cdiv(np0, 256), 1, nF), block(256);
+        const int64_t out_fs = int64_t(d) * np0;
+        if (p.colorSpace == ACF_HIP_CS_LUV)
+        {
+            // d_in == 3, RGB -> LUV; the reference takes the SSE body iff n % 4 == 0 (rgbConvertMex.cpp:92,343)
+            if (np0 % 4 == 0)
+            {
+                hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs);
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs);
+            }
+        }
+        else if (p.colorSpace == ACF_HIP_CS_GRAY)
+        {
+            const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
+            if (d_in == 1)
+            {
+                hipLaunchKernelGGL(k_rgb2gray<true>, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs, mr, mg, mb);
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs, mr, mg, mb);
+            }
+        }
+        else // ORIG / RGB with a 1-plane input: replicate
+        {
+            hipLaunchKernelGGL(k_replicate3, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs);
+        }
+        LAUNCHCHK(c, "colour conversion");
+        cur = c->d_color;
+        cur_fs = out_fs;
+    }
+
+    // ---- real scales, in order (chnsPyramid.cpp:297-338 + chnsCompute.cpp:146-338)
+    const float pColor = p.colorSmooth > 0 ? float(12.0 / p.colorSmooth / (p.colorSmooth + 2.0) - 2.0) : 0.f;
+    for (size_t k = 0; k < c->real.size(); k++)
+    {
+        RealScale& rs = c->real[k];
+        const int64_t np = int64_t(rs.h) * rs.w;
+        const float* img = cur;
+        int64_t img_fs = cur_fs;
+        if (rs.resampled)
+        {
+            if (rs.src_h != curH || rs.src_w != curW)
+            {
+                return fail(c, ACF_HIP_E_INVALID, "pyramid: internal plan mismatch");
+            }
+            if (c->h_descs[rs.descIndex].src_frame_stride != cur_fs)
+            {
+                return fail(c, ACF_HIP_E_INVALID, "pyramid: internal frame-stride mismatch");
+            }
+            hipLaunchKernelGGL(k_resample, dim3(cdiv(np * d, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
+                (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
+            LAUNCHCHK(c, "k_resample(image)");
+            img = rs.img;
+            img_fs = int64_t(d) * np;
+        }
+        // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
+        if (p.colorSmooth > 0)
+        {
+            if ((rc = launchSmooth(c, img, rs.sm, c->d_realJobs + k, 1, d, rs.h, img_fs, int64_t(d) * np, nF, pColor, true)))
+            {
+                return rc;
+            }
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(np * d, 256), 1, nF), dim3(256), 0, c->stream, img, rs.sm,
+                (const SmoothJob*)(c->d_realJobs + k), img_fs, int64_t(d) * np);
+            LAUNCHCHK(c, "k_copy_planes");
+        }
+        if (rs.adoptAsI)
+        {
+            cur = rs.sm;
+            cur_fs = int64_t(d) * np;
+            curH = rs.h;
+            curW = rs.w;
+        }
+        if (p.gradMagEnabled || p.gradHistEnabled)
+        {
+            hipLaunchKernelGGL(k_grad_mag, dim3(cdiv(rs.h, 256), rs.w, nF), dim3(256), 0, c->stream,
+                (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)(c->d_acos + 10010), rs.h, rs.w, p.full, int64_t(d) * np, np);
+            LAUNCHCHK(c, "k_grad_mag");
+            if (p.normRad)
+            {
+                if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF)))
+                {
+                    return rc;
+                }
+            }
+        }
+        ChnsArgs a{};
+        a.sm = rs.sm;
+        a.M = rs.M;
+        a.S = rs.S;
+        a.O = rs.O;
+        a.Mn = c->taps ? rs.Mn : nullptr;
+        a.chns = c->d_chns + pl.raw_off[rs.level];
+        a.sm_fs = int64_t(d) * np;
+        a.m_fs = np;
+        a.chns_fs = pl.raw_floats;
+        a.h = rs.h;
+        a.w = rs.w;
+        a.d = d;
+        a.colorEnabled = p.colorEnabled;
+        a.magEnabled = p.gradMagEnabled;
+        a.histEnabled = p.gradHistEnabled;
+        a.nOrients = p.nOrients;
+        a.doNorm = p.normRad != 0;
+        a.full = p.full;
+        a.normConst = float(p.normConst);
+        a.rq_y = shrinkGainY(shrink);
+        if ((rc = launchChns(c, a, shrink, nF)))
+        {
+            return rc;
+        }
+    }
+
+    // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
+    if (c->nApproxDescs > 0)
+    {
+        hipLaunchKernelGGL(k_resample, dim3(cdiv(c->approxMaxElems, 256), c->nApproxDescs, nF), dim3(256), 0, c->stream,
+            (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft);
+        LAUNCHCHK(c, "k_resample(approx)");
+    }
+
+    // ---- smooth every plane of every level into the fused, padded pyramid (chnsPyramid.cpp:399-435)
+    const int nL = int(pl.levels.size());
+    if (p.smooth > 0)
+    {
+        const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
+        if ((rc = launchSmooth(c, c->d_chns, c->d_pyr, c->d_finalJobs, nL, pl.nChns, c->finalMaxH, pl.raw_floats, pl.pyr_floats, nF, pS, true)))
+        {
+            return rc;
+        }
+    }
+    else
+    {
+        int64_t maxE = 0;
+        for (const auto& l : pl.levels)
+        {
+            maxE = std::max<int64_t>(maxE, int64_t(pl.nChns) * l.hC * l.wC);
+        }
+        hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(maxE, 256), nL, nF), dim3(256), 0, c->stream, (const float*)c->d_chns, c->d_pyr,
+            (const SmoothJob*)c->d_finalJobs, pl.raw_floats, pl.pyr_floats);
+        LAUNCHCHK(c, "k_copy_planes(final)");
+    }
+    if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
+    {
+        hipLaunchKernelGGL(k_pad_reflect, dim3(cdiv(c->padMaxElems, 256), nL, nF), dim3(256), 0, c->stream, c->d_pyr, (const PadJob*)c->d_padJobs, pl.pyr_floats);
+        LAUNCHCHK(c, "k_pad_reflect");
+    }
+    c->lastBatch = nF;
+    c->pyramidValid = true;
+    return ACF_HIP_OK;
+}
+
+static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const CascLevel* d_levels, const int32_t* d_blockLevel, int blocksPerFrame,
+    const uint32_t* d_cidAll, const CascNode2* d_nodes2, const BoxLevel* d_box, int nF)
+{
+    const acf_hip_params& p = c->p;
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * nF, c->stream));
+    if (blocksPerFrame > 0)
+    {
+        CascArgs a{};
+        a.pyr = pyr;
+        a.pyr_fs = pyr_fs;
+        a.levels = d_levels;
+        a.blockLevel = d_blockLevel;
+        a.blocksPerFrame = blocksPerFrame;
+        a.nTrees = p.nTrees;
+        a.nTreeNodes = p.nTreeNodes;
+        a.treeDepth = p.treeDepth;
+        a.stride = p.stride;
+        a.shrink = p.shrink;
+        a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
+        a.cidAll = d_cidAll;
+        a.thrs = c->d_thrs;
+        a.hs = c->d_hs;
+        a.child = c->d_child;
+        a.nodes2 = d_nodes2;
+        a.hits = c->d_hits;
+        a.counts = c->d_counts;
+        a.maxHits = c->maxHits;
+        dim3 grid(blocksPerFrame, nF), block(256);
+        if (p.treeDepth == 2)
+        {
+            hipLaunchKernelGGL(k_cascade<2>, grid, block, 0, c->stream, a);
+        }
+        else if (p.treeDepth > 0)
+        {
+            hipLaunchKernelGGL(k_cascade<1>, grid, block, 0, c->stream, a);
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_cascade<0>, grid, block, 0, c->stream, a);
+        }
+        LAUNCHCHK(c, "k_cascade");
+    }
+    // shift = (modelDsPad - modelDs)/2 - pad (ACF.cpp:275; cv::Size integer arithmetic)
+    const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
+    const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
+    hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->d_hits, (const int32_t*)c->d_counts, c->maxHits,
+        d_box, p.stride, shift_h, shift_w, c->d_sorted, c->d_dets);
+    LAUNCHCHK(c, "k_sort_map");
+    c->countsFetched = false;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_detect(acf_hip_ctx* c)
+{
+    if (!c || !c->hasPlan)
+    {
+        return c ? fail(c, ACF_HIP_E_NOPLAN, "detect: plan first") : ACF_HIP_E_INVALID;
+    }
+    if (!c->pyramidValid)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "detect: no pyramid (call acf_hip_pyramid)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_cascLevels, c->d_blockLevel, c->blocksPerFrame, c->d_cidAll, c->d_nodes2, c->d_boxLevels, c->lastBatch);
+    if (rc)
+    {
+        return rc;
+    }
+    c->detectValid = true;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
+{
+    int rc = acf_hip_pyramid(c, frames, nF);
+    if (rc)
+    {
+        return rc;
+    }
+    return acf_hip_detect(c);
+}
+
+int acf_hip_run_host(acf_hip_ctx* c, const float* frames_host, int nF)
+{
+    if (!c || !c->hasPlan)
+    {
+        return c ? fail(c, ACF_HIP_E_NOPLAN, "run_host: plan first") : ACF_HIP_E_INVALID;
+    }
+    if (!frames_host || nF <= 0 || nF > c->maxBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "run_host: n_frames out of range");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t per = size_t(c->plan.d_in) * c->plan.H * c->plan.W;
+    if (!c->d_stage)
+    {
+        int rc = devAlloc(c, &c->d_stage, size_t(c->maxBatch) * per);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, frames_host, per * nF * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return acf_hip_run(c, c->d_stage, nF);
+}
+
+int acf_hip_synchronize(acf_hip_ctx* c)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ACF_HIP_OK;
+}
+
+static int fetchCounts(acf_hip_ctx* c)
+{
+    if (!c->detectValid)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "no detections (call acf_hip_detect)");
+    }
+    if (!c->countsFetched)
+    {
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(int32_t) * c->lastBatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->countsFetched = true;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, int cap, int* count)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    int rc = fetchCounts(c);
+    if (rc)
+    {
+        return rc;
+    }
+    if (frame < 0 || frame >= c->lastBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "get_detections: frame index");
+    }
+    const int n = c->h_counts[frame];
+    if (count)
+    {
+        *count = n;
+    }
+    const int m = std::min(std::min(n, c->maxHits), cap);
+    if (m > 0 && out)
+    {
+        HIPCHK(c, hipMemcpy(out, c->d_dets + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
+    }
+    if (n > c->maxHits)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "more hits than max_hits; re-plan with a larger capacity");
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_hits(acf_hip_ctx* c, int frame, acf_hip_hit* out, int cap, int* count)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    int rc = fetchCounts(c);
+    if (rc)
+    {
+        return rc;
+    }
+    if (frame < 0 || frame >= c->lastBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "get_hits: frame index");
+    }
+    const int n = c->h_counts[frame];
+    if (count)
+    {
+        *count = n;
+    }
+    const int m = std::min(std::min(n, c->maxHits), cap);
+    if (m > 0 && out)
+    {
+        HIPCHK(c, hipMemcpy(out, c->d_sorted + size_t(frame) * c->maxHits, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost));
+    }
+    if (n > c->maxHits)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "more hits than max_hits; re-plan with a larger capacity");
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_export_detections(acf_hip_ctx* c, int32_t* dst_dev, int cap)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (!c->detectValid || !dst_dev || cap <= 0)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "export_detections: nothing to export");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_export, dim3(cdiv(cap, 256), c->lastBatch), dim3(256), 0, c->stream, (const acf_hip_detection*)c->d_dets,
+        (const int32_t*)c->d_counts, c->maxHits, cap, dst_dev);
+    LAUNCHCHK(c, "k_export");
+    return ACF_HIP_OK;
+}
+
+int acf_hip_read_level(acf_hip_ctx* c, int frame, int level, float* host_out)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (!c->pyramidValid || frame < 0 || frame >= c->lastBatch || level < 0 || level >= int(c->plan.levels.size()) || !host_out)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "read_level: arguments");
+    }
+    const acf_hip_level& l = c->plan.levels[level];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out, c->d_pyr + size_t(frame) * c->plan.pyr_floats + l.offset, sizeof(float) * c->plan.nChns * l.hP * l.wP, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_read_tap(acf_hip_ctx* c, int frame, int tap, int index, float* host_out, int64_t cap)
+{
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (!c->pyramidValid || frame < 0 || frame >= c->lastBatch || !host_out)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "read_tap: arguments");
+    }
+    const Plan& pl = c->plan;
+    const float* src = nullptr;
+    int64_t n = 0;
+    if (tap == ACF_HIP_TAP_CHNS)
+    {
+        if (index < 0 || index >= int(pl.levels.size()))
+        {
+            return fail(c, ACF_HIP_E_INVALID, "read_tap: level");
+        }
+        const acf_hip_level& l = pl.levels[index];
+        n = int64_t(pl.nChns) * l.hC * l.wC;
+        src = c->d_chns + size_t(frame) * pl.raw_floats + pl.raw_off[index];
+    }
+    else
+    {
+        if (index < 0 || index >= int(c->real.size()))
+        {
+            return fail(c, ACF_HIP_E_INVALID, "read_tap: real-scale ordinal");
+        }
+        const RealScale& rs = c->real[index];
+        const int64_t np = int64_t(rs.h) * rs.w;
+        switch (tap)
+        {
+            case ACF_HIP_TAP_IMAGE:
+                n = np * pl.d;
+                if (rs.resampled)
+                {
+                    src = rs.img + size_t(frame) * n;
+                }
+                else if (c->d_color)
+                {
+                    src = c->d_color + size_t(frame) * n;
+                }
+                else
+                {
+                    src = c->lastFrames + size_t(frame) * n;
+                }
+                break;
+            case ACF_HIP_TAP_SMOOTHED:
+                n = np * pl.d;
+                src = rs.sm + size_t(frame) * n;
+                break;
+            case ACF_HIP_TAP_M:
+                n = np;
+                src = rs.M ? rs.M + size_t(frame) * n : nullptr;
+                break;
+            case ACF_HIP_TAP_O:
+                n = np;
+                src = rs.O ? rs.O + size_t(frame) * n : nullptr;
+                break;
+            case ACF_HIP_TAP_S:
+                n = np;
+                src = rs.S ? rs.S + size_t(frame) * n : nullptr;
+                break;
+            case ACF_HIP_TAP_MNORM:
+                n = np;
+                src = rs.Mn ? rs.Mn + size_t(frame) * n : nullptr;
+                break;
+            default:
+                return fail(c, ACF_HIP_E_INVALID, "read_tap: unknown tap");
+        }
+        if (!src)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "read_tap: tap not kept (set option \"taps\" before acf_hip_plan)");
+        }
+    }
+    if (cap < n)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "read_tap: capacity");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_out, src, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+/* ---- single operators on host planes ---------------------------------- */
+
+
+#define OP_PROLOGUE(c)                      \
+    if (!(c))                               \
+    {                                       \
+        return ACF_HIP_E_INVALID;           \
+    }                                       \
+    HIPCHK(c, hipSetDevice((c)->device));   \
+    {                                       \
+        int rc0_ = ensureConstTables(c);    \
+        if (rc0_)                           \
+        {                                   \
+            return rc0_;                    \
+        }                                   \
+    }
+
+int acf_hip_op_rgb_convert(acf_hip_ctx* c, const float* in, float* out, int h, int w, int flag)
+{
+    OP_PROLOGUE(c);
+    if (!in || !out || h <= 0 || w <= 0)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_rgb_convert: arguments");
+    }
+    const int n = h * w;
+    Scratch s;
+    float* di = s.upload(in, size_t(3) * n);
+    const int dOut = flag == ACF_HIP_CS_GRAY ? 1 : 3;
+    float* dout = s.alloc<float>(size_t(dOut) * n);
+    if (!di || !dout)
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_rgb_convert: allocation");
+    }
+    dim3 grid(cdiv(n, 256), 1, 1), block(256);
+    if (flag == ACF_HIP_CS_LUV)
+    {
+        if (n % 4 == 0)
+        {
+            hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0));
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0));
+        }
+    }
+    else if (flag == ACF_HIP_CS_GRAY)
+    {
+        const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
+        hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, (const float*)di, dout, n, int64_t(0), int64_t(0), mr, mg, mb);
+    }
+    else
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_rgb_convert: flag");
+    }
+    LAUNCHCHK(c, "op_rgb_convert");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, sizeof(float) * dOut * n, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_conv_tri(acf_hip_ctx* c, const float* in, float* out, int h, int w, int d, double r, int aliased)
+{
+    OP_PROLOGUE(c);
+    if (!in || !out || h <= 0 || w <= 0 || d <= 0)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_conv_tri: arguments");
+    }
+    const int m = std::min(h, w);
+    if (m < 4 || (2 * r + 1) >= m)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_conv_tri: plane too small (sepFilter2D fallback, convTri.cpp:224-251)");
+    }
+    const int64_t np = int64_t(h) * w;
+    Scratch s;
+    float* di = s.upload(in, size_t(np) * d);
+    float* dout = s.alloc<float>(size_t(np) * d);
+    if (!di || !dout)
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_conv_tri: allocation");
+    }
+    int rc;
+    if (r > 0 && r <= 1.0)
+    {
+        SmoothJob j{};
+        j.h = h;
+        j.w = w;
+        j.nplanes = d;
+        j.out_cs = h;
+        j.in_ps = np;
+        j.out_ps = np;
+        SmoothJob* dj = s.upload(&j, 1);
+        if (!dj)
+        {
+            return fail(c, ACF_HIP_E_HIP, "op_conv_tri: allocation");
+        }
+        const float p = float(12.0 / r / (r + 2.0) - 2.0);
+        if ((rc = launchSmooth(c, di, dout, dj, 1, d, h, 0, 0, 1, p, aliased != 0)))
+        {
+            return rc;
+        }
+    }
+    else if (r > 1)
+    {
+        const int ri = int(std::round(float(r)));
+        if (ri >= m / 2)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "op_conv_tri: mask larger than image (convTri.cpp:166-169)");
+        }
+        float* dU = s.alloc<float>(size_t(np) * d);
+        if (!dU)
+        {
+            return fail(c, ACF_HIP_E_HIP, "op_conv_tri: allocation");
+        }
+        if ((rc = launchTri(c, di, dU, dout, h, w, ri, np, d)))
+        {
+            return rc;
+        }
+    }
+    else
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_conv_tri: radius");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, sizeof(float) * np * d, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O, float* S_out, int h, int w, int normRad, double normConst, int full)
+{
+    OP_PROLOGUE(c);
+    if (!in || !M || !O || h < 2 || w < 2)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_gradient_mag: arguments");
+    }
+    const int64_t np = int64_t(h) * w;
+    Scratch s;
+    float* di = s.upload(in, size_t(np));
+    float *dM = s.alloc<float>(np), *dO = s.alloc<float>(np), *dU = s.alloc<float>(np), *dS = s.alloc<float>(np);
+    if (!di || !dM || !dO || !dU || !dS)
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_gradient_mag: allocation");
+    }
+    hipLaunchKernelGGL(k_grad_mag, dim3(cdiv(h, 256), w, 1), dim3(256), 0, c->stream, (const float*)di, dM, dO, (const float*)(c->d_acos + 10010), h, w, full, int64_t(0), int64_t(0));
+    LAUNCHCHK(c, "k_grad_mag");
+    if (normRad)
+    {
+        if (std::min(h, w) < 4 || 2 * normRad + 1 >= std::min(h, w) || normRad < 2)
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "op_gradient_mag: normRad");
+        }
+        int rc = launchTri(c, dM, dU, dS, h, w, normRad, np, 1);
+        if (rc)
+        {
+            return rc;
+        }
+        hipLaunchKernelGGL(k_norm, dim3(cdiv(np, 256)), dim3(256), 0, c->stream, dM, (const float*)dS, int(np), float(normConst));
+        LAUNCHCHK(c, "k_norm");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(M, dM, sizeof(float) * np, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(O, dO, sizeof(float) * np, hipMemcpyDeviceToHost));
+    if (S_out && normRad)
+    {
+        HIPCHK(c, hipMemcpy(S_out, dS, sizeof(float) * np, hipMemcpyDeviceToHost));
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_gradient_hist(acf_hip_ctx* c, const float* M, const float* O, float* H, int h, int w, int bin, int nOrients, int full)
+{
+    OP_PROLOGUE(c);
+    if (!M || !O || !H || h <= 0 || w <= 0 || nOrients < 1 || nOrients > 12)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_gradient_hist: arguments");
+    }
+    if ((bin != 2 && bin != 4) || h % bin || w % bin)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_gradient_hist: bin must be 2 or 4 and divide h, w");
+    }
+    const int64_t np = int64_t(h) * w, nc = np / (bin * bin);
+    Scratch s;
+    float *dM = s.upload(M, np), *dO = s.upload(O, np), *dH = s.alloc<float>(nc * nOrients);
+    if (!dM || !dO || !dH)
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_gradient_hist: allocation");
+    }
+    ChnsArgs a{};
+    a.M = dM;
+    a.S = dM;
+    a.O = dO;
+    a.chns = dH;
+    a.h = h;
+    a.w = w;
+    a.d = 0;
+    a.histEnabled = 1;
+    a.nOrients = nOrients;
+    a.full = full;
+    a.rq_y = shrinkGainY(bin);
+    int rc = launchChns(c, a, bin, 1);
+    if (rc)
+    {
+        return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(H, dH, sizeof(float) * nc * nOrients, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, int wa, int hb, int wb, int d, double nrm)
+{
+    OP_PROLOGUE(c);
+    if (!in || !out || ha <= 0 || wa <= 0 || hb <= 0 || wb <= 0 || d <= 0)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_im_resample: arguments");
+    }
+    TableArena arena;
+    ResampleDesc dd;
+    int rc = buildResample(ha, wa, hb, wb, dd, arena);
+    if (rc)
+    {
+        return fail(c, rc, "op_im_resample: degenerate geometry");
+    }
+    const double ratio[3] = { nrm, nrm, nrm };
+    setResampleGain(dd, ratio, d, d);
+    dd.nplanes = d;
+    Scratch s;
+    float* di = s.upload(in, size_t(d) * ha * wa);
+    float* dout = s.alloc<float>(size_t(d) * hb * wb);
+    ResampleDesc* ddesc = s.upload(&dd, 1);
+    int32_t* dit = s.upload(arena.ints.data(), arena.ints.size());
+    float* dft = s.upload(arena.floats.data(), arena.floats.size());
+    if (!di || !dout || !ddesc || !dit || !dft)
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
+    }
+    hipLaunchKernelGGL(k_resample, dim3(cdiv(int64_t(d) * hb * wb, 256), 1, 1), dim3(256), 0, c->stream, (const float*)di, dout,
+        (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft);
+    LAUNCHCHK(c, "k_resample");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, sizeof(float) * d * hb * wb, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, int nChns, acf_hip_hit* out, int cap, int* count)
+{
+    OP_PROLOGUE(c);
+    if (!c->hasModel)
+    {
+        return fail(c, ACF_HIP_E_NOMODEL, "op_acf_detect1: set_model first");
+    }
+    if (!chns || hP <= 0 || wP <= 0 || nChns <= 0 || cap <= 0 || !count)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_acf_detect1: arguments");
+    }
+    const acf_hip_params& p = c->p;
+    std::vector<acf_hip_level> lv(1);
+    lv[0] = acf_hip_level{};
+    lv[0].scale = 1.0;
+    lv[0].scalehw_h = lv[0].scalehw_w = 1.0;
+    lv[0].hP = lv[0].hC = hP;
+    lv[0].wP = lv[0].wC = wP;
+    lv[0].nWinR = std::max(0, int(std::ceil(float(hP * p.shrink - p.modelDsPad_h + 1) / p.stride)));
+    lv[0].nWinC = std::max(0, int(std::ceil(float(wP * p.shrink - p.modelDsPad_w + 1) / p.stride)));
+    lv[0].offset = 0;
+    // temporary tables are registered in the context's allocation list only for the duration of this call
+    const size_t mark = c->allocs.size();
+    const int savedMaxHits = c->maxHits;
+    acf_hip_hit *sHits = c->d_hits, *sSorted = c->d_sorted;
+    acf_hip_detection* sDets = c->d_dets;
+    int32_t* sCounts = c->d_counts;
+    float *sThr = c->d_thrs, *sHs = c->d_hs;
+    uint32_t* sChild = c->d_child;
+    auto restore = [&]() {
+        for (size_t i = mark; i < c->allocs.size(); i++)
+        {
+            (void)hipFree(c->allocs[i]);
+        }
+        c->allocs.resize(mark);
+        c->maxHits = savedMaxHits;
+        c->d_hits = sHits;
+        c->d_sorted = sSorted;
+        c->d_dets = sDets;
+        c->d_counts = sCounts;
+        c->d_thrs = sThr;
+        c->d_hs = sHs;
+        c->d_child = sChild;
+    };
+    CascLevel* dL = nullptr;
+    int32_t* dBL = nullptr;
+    uint32_t* dCid = nullptr;
+    CascNode2* dN2 = nullptr;
+    BoxLevel* dBox = nullptr;
+    float* dChn = nullptr;
+    int bpf = 0;
+    int rc = buildCascadeTables(c, lv, nChns, &dL, &dBL, &bpf, &dCid, &dN2);
+    std::vector<BoxLevel> box(1);
+    box[0].shw_h = box[0].shw_w = 1.0;
+    box[0].bw = p.modelDs_w;
+    box[0].bh = p.modelDs_h;
+    c->maxHits = cap;
+    if (!rc)
+    {
+        rc = devUpload(c, &dBox, box);
+    }
+    if (!rc)
+    {
+        rc = devUpload(c, &c->d_thrs, c->thrs);
+    }
+    if (!rc)
+    {
+        rc = devUpload(c, &c->d_hs, c->hs);
+    }
+    if (!rc)
+    {
+        rc = devUpload(c, &c->d_child, c->child);
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_hits, size_t(cap));
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_sorted, size_t(cap));
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_dets, size_t(cap));
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_counts, 1);
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &dChn, size_t(nChns) * hP * wP);
+    }
+    if (!rc && hipMemcpy(dChn, chns, sizeof(float) * nChns * hP * wP, hipMemcpyHostToDevice) != hipSuccess)
+    {
+        rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: upload");
+    }
+    if (!rc)
+    {
+        rc = runCascade(c, dChn, 0, dL, dBL, bpf, dCid, dN2, dBox, 1);
+    }
+    int n = 0;
+    if (!rc)
+    {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&n, c->d_counts, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        {
+            rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: sync");
+        }
+    }
+    if (!rc)
+    {
+        *count = n;
+        const int m = std::min(n, cap);
+        if (m > 0 && out && hipMemcpy(out, c->d_sorted, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost) != hipSuccess)
+        {
+            rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: download");
+        }
+        if (!rc && n > cap)
+        {
+            rc = fail(c, ACF_HIP_E_CAPACITY, "op_acf_detect1: more hits than cap");
+        }
+    }
+    restore();
+    return rc;
+}
+
+} // extern "C"

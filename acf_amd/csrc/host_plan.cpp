@@ -1,0 +1,415 @@
+// host_plan.cpp — see host_plan.h.
+#include "host_plan.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <limits>
+
+namespace acfhip
+{
+
+// Detector::getScales, chnsPyramid.cpp:461-529.  The reference works on the
+// transposed image, so its sz.width is the upright height H and sz.height the
+// upright width W; minDs likewise (ACFIO.h:168-181).
+ScaleList getScales(int nPerOct, int nOctUp, int minDs_h, int minDs_w, int shrink, int H, int W)
+{
+    ScaleList out;
+    if (H <= 0 || W <= 0)
+    {
+        return out;
+    }
+    const double szw = H, szh = W; // reference members
+    const double ratio_w = szw / double(minDs_h), ratio_h = szh / double(minDs_w);
+    // util::log2(x) = std::log(x) / std::log(2.0)  (util/acf_math.h:20-29)
+    const double lg = std::log(std::min(ratio_w, ratio_h)) / std::log(2.0);
+    const int nScales = int(std::floor(double(nPerOct) * (double(nOctUp) + lg) + 1.0));
+    double d0 = szh, d1 = szw;
+    if (szh >= szw)
+    {
+        std::swap(d0, d1);
+    }
+    std::vector<double> cand;
+    for (int i = 0; i < nScales; i++)
+    {
+        const double s = std::pow(2.0, -double(i) / double(nPerOct) + double(nOctUp));
+        const double base = std::round(d0 * s / shrink) * shrink;
+        const double s0 = (base - 0.25 * shrink) / d0;
+        const double s1 = (base + 0.25 * shrink) / d0;
+        double bestS = 0, bestE = std::numeric_limits<double>::max();
+        // the reference accumulates j += 0.01 in double; keep that exact sequence
+        for (double j = 0.0; j < 1.0 - std::numeric_limits<double>::epsilon(); j += 0.01)
+        {
+            const double ss = (j * (s1 - s0) + s0);
+            double e0 = d0 * ss;
+            e0 = std::abs(e0 - std::round(e0 / shrink) * shrink);
+            double e1 = d1 * ss;
+            e1 = std::abs(e1 - std::round(e1 / shrink) * shrink);
+            const double e = std::max(e0, e1);
+            if (e < bestE)
+            {
+                bestS = ss;
+                bestE = e;
+            }
+        }
+        cand.push_back(bestS);
+    }
+    cand.push_back(0.0);
+    for (size_t i = 1; i < cand.size(); i++)
+    {
+        if (cand[i] != cand[i - 1])
+        {
+            const double s = cand[i - 1];
+            out.scales.push_back(s);
+            out.shw_h.push_back(std::round(szw * s / shrink) * shrink / szw);
+            out.shw_w.push_back(std::round(szh * s / shrink) * shrink / szh);
+        }
+    }
+    return out;
+}
+
+// resampleCoef<float>, imResampleMex.cpp:24-121.
+AxisCoef resampleCoef(int na, int nb, int pad)
+{
+    AxisCoef c;
+    c.na = na;
+    c.nb = nb;
+    c.down = na > nb;
+    const float s = float(nb) / float(na), sInv = 1 / s;
+    const float wt0 = float(1e-3) * s;
+    if (c.down)
+    {
+        c.start.assign(1, 0);
+        for (int yb = 0; yb < nb; yb++)
+        {
+            const float ya0f = yb * sInv, ya1f = ya0f + sInv;
+            const int ya0 = int(std::ceil(ya0f)), ya1 = int(ya1f);
+            float W = 0;
+            int n1 = 0;
+            const size_t first = c.src.size();
+            for (int ya = ya0 - 1; ya < ya1 + 1; ya++)
+            {
+                float wt = s;
+                if (ya == ya0 - 1)
+                {
+                    wt = (ya0 - ya0f) * s;
+                }
+                else if (ya == ya1)
+                {
+                    wt = (ya1f - ya1) * s;
+                }
+                if (wt > wt0 && ya >= 0)
+                {
+                    c.src.push_back(ya);
+                    c.wt.push_back(wt);
+                    n1++;
+                    W += wt;
+                }
+            }
+            if (W > 1)
+            {
+                for (int i = 0; i < n1; i++)
+                {
+                    c.wt[first + i] /= W;
+                }
+            }
+            c.bd[0] = std::max(c.bd[0], n1);
+            while (n1 < pad)
+            {
+                // zero-weight filler repeating the previous source index (:84-91)
+                c.src.push_back(c.src.empty() ? 0 : c.src.back());
+                c.wt.push_back(0.f);
+                n1++;
+            }
+            c.start.push_back(int(c.src.size()));
+        }
+    }
+    else
+    {
+        for (int yb = 0; yb < nb; yb++)
+        {
+            const float yaf = (float(.5) + yb) * sInv - float(.5);
+            int ya = int(std::floor(yaf));
+            float wt = 1;
+            if (ya >= 0 && ya < na - 1)
+            {
+                wt = 1 - (yaf - ya);
+            }
+            if (ya < 0)
+            {
+                ya = 0;
+                c.bd[0]++;
+            }
+            if (ya >= na - 1)
+            {
+                ya = na - 1;
+                c.bd[1]++;
+            }
+            c.src.push_back(ya);
+            c.wt.push_back(wt);
+        }
+    }
+    return c;
+}
+
+static int exactFactor(int na, int nb)
+{
+    for (int k = 2; k <= 4; k++)
+    {
+        if (na == k * nb)
+        {
+            return k;
+        }
+    }
+    return 0;
+}
+
+int buildResample(int ha, int wa, int hb, int wb, ResampleDesc& d, TableArena& arena)
+{
+    d = ResampleDesc();
+    d.ha = ha;
+    d.hb = hb;
+    d.wa = wa;
+    d.wb = wb;
+    // x axis: resampleCoef(wa, wb, pad 0) (:143)
+    AxisCoef cx = resampleCoef(wa, wb, 0);
+    d.xk = exactFactor(wa, wb);
+    d.xbd0 = cx.bd[0];
+    d.xbd1 = cx.bd[1];
+    if (d.xk)
+    {
+        // the reference advances x1 += k and reads xas[x1] (:198-215): the first source column of group x
+        d.xmode = RS_EXACT;
+        d.x_src = int(arena.ints.size());
+        for (int x = 0; x < wb; x++)
+        {
+            const size_t x1 = size_t(x) * d.xk;
+            if (x1 >= cx.src.size())
+            {
+                return ACF_HIP_E_UNSUPPORTED;
+            }
+            arena.ints.push_back(cx.src[x1]);
+        }
+    }
+    else if (cx.down)
+    {
+        d.xmode = RS_DOWN;
+        d.x_start = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cx.start.begin(), cx.start.end());
+        d.x_src = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cx.src.begin(), cx.src.end());
+        d.x_wt = int(arena.floats.size());
+        arena.floats.insert(arena.floats.end(), cx.wt.begin(), cx.wt.end());
+    }
+    else
+    {
+        d.xmode = RS_UP;
+        d.x_src = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cx.src.begin(), cx.src.end());
+        d.x_wt = int(arena.floats.size());
+        arena.floats.insert(arena.floats.end(), cx.wt.begin(), cx.wt.end());
+    }
+    // y axis: resampleCoef(ha, hb, pad 4) (:144)
+    AxisCoef cy = resampleCoef(ha, hb, 4);
+    d.yk = exactFactor(ha, hb);
+    d.ybd0 = cy.bd[0];
+    d.ybd1 = cy.bd[1];
+    if (d.yk)
+    {
+        d.ymode = RS_EXACT;
+    }
+    else if (cy.down)
+    {
+        if (cy.bd[0] < 2)
+        {
+            return ACF_HIP_E_UNSUPPORTED; // the reference leaves B unwritten in this case (:325-356)
+        }
+        d.ymode = RS_DOWN;
+        d.y_start = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cy.start.begin(), cy.start.end());
+        d.y_src = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cy.src.begin(), cy.src.end());
+        d.y_wt = int(arena.floats.size());
+        arena.floats.insert(arena.floats.end(), cy.wt.begin(), cy.wt.end());
+    }
+    else
+    {
+        d.ymode = RS_UP;
+        d.y_src = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), cy.src.begin(), cy.src.end());
+        d.y_wt = int(arena.floats.size());
+        arena.floats.insert(arena.floats.end(), cy.wt.begin(), cy.wt.end());
+    }
+    return ACF_HIP_OK;
+}
+
+// imResampleMex.cpp:145-157 (and :286,:309,:316 for the exact y path).
+void setResampleGain(ResampleDesc& d, const double ratio[3], int c1, int c2)
+{
+    d.c1 = c1;
+    d.c2 = c2;
+    for (int j = 0; j < 3; j++)
+    {
+        float r = float(ratio[j]);
+        if (d.wa == 2 * d.wb)
+        {
+            r /= 2;
+        }
+        if (d.wa == 3 * d.wb)
+        {
+            r /= 3;
+        }
+        if (d.wa == 4 * d.wb)
+        {
+            r /= 4;
+        }
+        r /= float(1 + 1e-6);
+        d.r[j] = r;
+        d.rk[j] = d.yk ? r / float(d.yk) : r;
+    }
+}
+
+int colorPlanes(const acf_hip_params& p)
+{
+    return p.colorSpace == ACF_HIP_CS_GRAY ? 1 : 3;
+}
+
+int numChannels(const acf_hip_params& p)
+{
+    return (p.colorEnabled ? colorPlanes(p) : 0) + (p.gradMagEnabled ? 1 : 0) + (p.gradHistEnabled ? p.nOrients : 0);
+}
+
+int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err)
+{
+    plan = Plan();
+    if (H <= 0 || W <= 0 || (d_in != 1 && d_in != 3))
+    {
+        err = "plan: bad frame geometry";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.shrink != 4 && p.shrink != 2)
+    {
+        err = "plan: shrink must be 2 or 4";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.binSize != 0 && p.binSize != p.shrink)
+    {
+        err = "plan: binSize != shrink";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.softBin != 0)
+    {
+        err = "plan: softBin != 0";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.nApprox > 0 && p.nLambdas != 3)
+    {
+        err = "plan: lambdas must be supplied (image-specific lambdas, chnsPyramid.cpp:341-374, are not computed)";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (!(p.gradMagEnabled || p.gradHistEnabled || p.colorEnabled))
+    {
+        err = "plan: no channels enabled";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.colorSpace != ACF_HIP_CS_LUV && p.colorSpace != ACF_HIP_CS_GRAY && p.colorSpace != ACF_HIP_CS_ORIG && p.colorSpace != ACF_HIP_CS_RGB)
+    {
+        err = "plan: colour space";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (d_in == 1 && !(p.colorSpace == ACF_HIP_CS_GRAY || p.colorSpace == ACF_HIP_CS_ORIG))
+    {
+        err = "plan: 1-plane input needs colorSpace gray or orig (rgbConvert.cpp:140-148)";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.isLuv && p.colorSpace == ACF_HIP_CS_GRAY)
+    {
+        err = "plan: isLuv with gray (rgbConvert.cpp:150-155)";
+        return ACF_HIP_E_INVALID;
+    }
+    plan.H = H;
+    plan.W = W;
+    plan.d_in = d_in;
+    plan.d = colorPlanes(p);
+    plan.nChns = numChannels(p);
+    if (p.colorChn < 0 || p.colorChn >= plan.d)
+    {
+        err = "plan: colorChn";
+        return ACF_HIP_E_INVALID;
+    }
+    const int shrink = p.shrink;
+    ScaleList sl = getScales(p.nPerOct, p.nOctUp, p.minDs_h, p.minDs_w, shrink, H, W);
+    const int n = int(sl.scales.size());
+    if (n == 0)
+    {
+        err = "plan: no scales (frame smaller than minDs)";
+        return ACF_HIP_E_INVALID;
+    }
+    plan.levels.resize(n);
+    // real/approx split and nearest real scale, chnsPyramid.cpp:272-292 (1-based there)
+    std::vector<int> isR;
+    for (int i = 0; i < n; i++)
+    {
+        if (i % (p.nApprox + 1) == 0)
+        {
+            isR.push_back(i + 1);
+        }
+    }
+    std::vector<int> isH(isR.size() + 1, 0);
+    isH.back() = n;
+    for (int i = 0; i + 1 < int(isR.size()); i++)
+    {
+        isH[i + 1] = (isR[i] + isR[i + 1]) / 2;
+    }
+    std::vector<int> isN(n, 0);
+    for (size_t i = 0; i < isR.size(); i++)
+    {
+        for (int j = isH[i]; j < isH[i + 1]; j++)
+        {
+            isN[j] = isR[i];
+        }
+    }
+    int64_t off = 0, roff = 0;
+    plan.raw_off.resize(n);
+    for (int i = 0; i < n; i++)
+    {
+        acf_hip_level& l = plan.levels[i];
+        l.scale = sl.scales[i];
+        l.scalehw_h = sl.shw_h[i];
+        l.scalehw_w = sl.shw_w[i];
+        l.isReal = (i % (p.nApprox + 1)) == 0;
+        l.realIndex = isN[i] - 1;
+        l.hC = int(std::round(double(H) * l.scale / double(shrink)));
+        l.wC = int(std::round(double(W) * l.scale / double(shrink)));
+        l.hP = l.hC + 2 * (p.pad_h / shrink);
+        l.wP = l.wC + 2 * (p.pad_w / shrink);
+        l.nWinR = std::max(0, int(std::ceil(float(l.hP * shrink - p.modelDsPad_h + 1) / p.stride)));
+        l.nWinC = std::max(0, int(std::ceil(float(l.wP * shrink - p.modelDsPad_w + 1) / p.stride)));
+        l.offset = off;
+        off += int64_t(plan.nChns) * l.hP * l.wP;
+        plan.raw_off[i] = roff;
+        roff += int64_t(plan.nChns) * l.hC * l.wC;
+        if (l.hC < 4 || l.wC < 4)
+        {
+            err = "plan: level smaller than 4 cells (convTri's sepFilter2D fallback, convTri.cpp:224-251, is not implemented)";
+            return ACF_HIP_E_UNSUPPORTED;
+        }
+        if (l.isReal)
+        {
+            plan.real.push_back(i);
+            plan.real_h.push_back(l.hC * shrink);
+            plan.real_w.push_back(l.wC * shrink);
+            const int m = std::min(l.hC, l.wC) * shrink;
+            if (p.normRad != 0 && (2 * p.normRad + 1) >= m)
+            {
+                err = "plan: normRad too large for the smallest real scale";
+                return ACF_HIP_E_UNSUPPORTED;
+            }
+        }
+    }
+    plan.pyr_floats = off;
+    plan.raw_floats = roff;
+    return ACF_HIP_OK;
+}
+
+} // namespace acfhip

@@ -1,0 +1,167 @@
+"""Thin Python handle on the C ABI (include/acf_hip.h) for tests and bench.py.
+
+Every method is a direct call into libacf_hip.so; there is no Python or CPU
+implementation behind it.  Frames are float32 [n][d][W][H] (H contiguous, the
+reference's transposed planar layout, MatP.cpp:51-73) either as a torch CUDA
+tensor / raw device pointer (run, pyramid) or as a numpy array (run_host).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("acf_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _dev_ptr(x):
+    if isinstance(x, int):
+        return x
+    # torch tensor
+    assert x.is_cuda and x.is_contiguous() and x.dtype.is_floating_point and x.element_size() == 4
+    return x.data_ptr()
+
+
+class HipDetector:
+    def __init__(self, model=None, H=0, W=0, d_in=3, max_batch=1, max_hits=4096, device=0, stream=None, taps=False):
+        self.lib = capi.load()
+        self.ctx = C.c_void_p()
+        rc = self.lib.acf_hip_create(device, C.c_void_p(stream or 0), C.byref(self.ctx))
+        if rc:
+            raise HipError(rc, "acf_hip_create failed (no gfx950 device?)")
+        self._keep = None
+        self.levels = []
+        self.nChns = 0
+        if taps:
+            self._chk(self.lib.acf_hip_set_option(self.ctx, b"taps", 1))
+        if model is not None:
+            self.set_model(model)
+            if H and W:
+                self.plan(H, W, d_in, max_batch, max_hits)
+
+    def _chk(self, rc):
+        if rc:
+            raise HipError(rc, (self.lib.acf_hip_last_error(self.ctx) or b"").decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.acf_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_model(self, model):
+        self.model = model
+        self.params, self._keep = capi.make_params(model)
+        self._chk(self.lib.acf_hip_set_model(self.ctx, C.byref(self.params)))
+
+    def plan(self, H, W, d_in=3, max_batch=1, max_hits=4096):
+        self._chk(self.lib.acf_hip_plan(self.ctx, H, W, d_in, max_batch, max_hits))
+        self.H, self.W, self.d_in, self.max_batch, self.max_hits = H, W, d_in, max_batch, max_hits
+        n, nc = C.c_int(), C.c_int()
+        self._chk(self.lib.acf_hip_num_levels(self.ctx, C.byref(n), C.byref(nc)))
+        lv = (capi.Level * n.value)()
+        self._chk(self.lib.acf_hip_get_levels(self.ctx, lv, n.value))
+        self.levels = list(lv)
+        self.nChns = nc.value
+        tot = C.c_int64()
+        self._chk(self.lib.acf_hip_pyramid_floats(self.ctx, C.byref(tot)))
+        self.pyr_floats = tot.value
+
+    # ---- hot path
+    def pyramid(self, frames, n=None):
+        n = n if n is not None else frames.shape[0]
+        self._chk(self.lib.acf_hip_pyramid(self.ctx, C.c_void_p(_dev_ptr(frames)), n))
+
+    def detect(self):
+        self._chk(self.lib.acf_hip_detect(self.ctx))
+
+    def run(self, frames, n=None):
+        n = n if n is not None else frames.shape[0]
+        self._chk(self.lib.acf_hip_run(self.ctx, C.c_void_p(_dev_ptr(frames)), n))
+
+    def run_host(self, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        self._chk(self.lib.acf_hip_run_host(self.ctx, capi.fptr(frames), frames.shape[0]))
+
+    def synchronize(self):
+        self._chk(self.lib.acf_hip_synchronize(self.ctx))
+
+    def export_detections(self, dst, cap):
+        self._chk(self.lib.acf_hip_export_detections(self.ctx, C.c_void_p(dst.data_ptr()), cap))
+
+    def detections(self, frame):
+        det = np.zeros(self.max_hits, dtype=capi.DET_DTYPE)
+        hits = np.zeros(self.max_hits, dtype=capi.HIT_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.acf_hip_get_detections(self.ctx, frame, det.ctypes.data_as(C.POINTER(capi.Detection)), self.max_hits, C.byref(n)))
+        self._chk(self.lib.acf_hip_get_hits(self.ctx, frame, hits.ctypes.data_as(C.POINTER(capi.Hit)), self.max_hits, C.byref(n)))
+        return det[:n.value].copy(), hits[:n.value].copy()
+
+    # ---- parity taps
+    def read_level(self, frame, level):
+        l = self.levels[level]
+        out = np.zeros((self.nChns, l.wP, l.hP), dtype=np.float32)
+        self._chk(self.lib.acf_hip_read_level(self.ctx, frame, level, capi.fptr(out)))
+        return out
+
+    def read_pyramid(self, frame):
+        return np.concatenate([self.read_level(frame, i).ravel() for i in range(len(self.levels))])
+
+    def read_tap(self, frame, tap, index, shape):
+        out = np.zeros(shape, dtype=np.float32)
+        self._chk(self.lib.acf_hip_read_tap(self.ctx, frame, tap, index, capi.fptr(out), out.size))
+        return out
+
+    # ---- single operators (host planes in, host planes out)
+    def op_rgb_convert(self, a, flag):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        _, w, h = a.shape
+        out = np.zeros((1 if flag == capi.CS_GRAY else 3, w, h), dtype=np.float32)
+        self._chk(self.lib.acf_hip_op_rgb_convert(self.ctx, capi.fptr(a), capi.fptr(out), h, w, flag))
+        return out
+
+    def op_conv_tri(self, a, r, aliased=True):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d, w, h = a.shape
+        out = np.zeros_like(a)
+        self._chk(self.lib.acf_hip_op_conv_tri(self.ctx, capi.fptr(a), capi.fptr(out), h, w, d, float(r), int(aliased)))
+        return out
+
+    def op_gradient_mag(self, a, normRad=0, normConst=0.005, full=0):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        w, h = a.shape
+        M, O, S = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+        self._chk(self.lib.acf_hip_op_gradient_mag(self.ctx, capi.fptr(a), capi.fptr(M), capi.fptr(O), capi.fptr(S), h, w, normRad, normConst, full))
+        return M, O, S
+
+    def op_gradient_hist(self, M, O, bin=4, nOrients=6, full=0):
+        M = np.ascontiguousarray(M, dtype=np.float32)
+        O = np.ascontiguousarray(O, dtype=np.float32)
+        w, h = M.shape
+        H = np.zeros((nOrients, w // bin, h // bin), dtype=np.float32)
+        self._chk(self.lib.acf_hip_op_gradient_hist(self.ctx, capi.fptr(M), capi.fptr(O), capi.fptr(H), h, w, bin, nOrients, full))
+        return H
+
+    def op_im_resample(self, a, hb, wb, nrm=1.0):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d, wa, ha = a.shape
+        out = np.zeros((d, wb, hb), dtype=np.float32)
+        self._chk(self.lib.acf_hip_op_im_resample(self.ctx, capi.fptr(a), capi.fptr(out), ha, wa, hb, wb, d, float(nrm)))
+        return out
+
+    def op_acf_detect1(self, chns, cap=1 << 16):
+        chns = np.ascontiguousarray(chns, dtype=np.float32)
+        nC, wP, hP = chns.shape
+        hits = np.zeros(cap, dtype=capi.HIT_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.acf_hip_op_acf_detect1(self.ctx, capi.fptr(chns), hP, wP, nC, hits.ctypes.data_as(C.POINTER(capi.Hit)), cap, C.byref(n)))
+        return hits[:n.value].copy()

@@ -144,6 +144,12 @@ int acf_hip_abi_version(void);
 /* Last error text for this context (thread-compatible, like one Detector per thread). */
 const char* acf_hip_last_error(const acf_hip_ctx* ctx);
 
+/* Runtime knobs, the counterpart of the reference's setters (ACF.h:495-595).
+ * Keys: "taps" (0/1: keep per-stage intermediates readable through
+ * acf_hip_read_tap, the role of setLogger's MatLoggerType tap,
+ * chnsCompute.cpp:241-250,285-300; costs one extra full-resolution write). */
+int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
+
 /* Upload classifier + options.  Replaces Detector::deserialize*() filling
  * `clf` and `opts` (ACF.h:277,312) and acfModify's effects (acfModify.cpp:139-143),
  * which the caller applies to the struct before the call. */

@@ -1,0 +1,186 @@
+"""GPU parity, operator by operator: each HIP kernel (called through the C ABI's
+acf_hip_op_* entry points) against the oracle on the same seeded inputs.
+Everything here is bit-exact: the kernels and the oracle evaluate the same IEEE
+expressions in the same order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from acf_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 48), (63, 50), (37, 41), (120, 160), (270, 480), (1080, 192)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def rnd(seed, shape, lo=0.0, hi=1.0):
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * synth.uniform(seed, n, 3)).astype(np.float32).reshape(shape)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from acf_amd.detector import HipDetector
+    d = HipDetector()
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("aliased", [True, False])
+def test_conv_tri1(dev, oracle, h, w, aliased):
+    a = rnd(h * 13 + w, (3, w, h))
+    got = dev.op_conv_tri(a, 1.0, aliased=aliased)
+    want = a.copy()
+    if aliased:
+        assert oracle.lib().acfo_conv_tri1(oracle.F(want), oracle.F(want), h, w, 3, 2.0, 1) == 0
+    else:
+        src = a.copy()
+        assert oracle.lib().acfo_conv_tri1(oracle.F(src), oracle.F(want), h, w, 3, 2.0, 1) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_conv_tri1_tall_plane(dev, oracle):
+    """R = 3 rows per thread (taller than 2048 rows: the 4K case)."""
+    h, w = 2160, 24
+    a = rnd(5, (1, w, h))
+    got = dev.op_conv_tri(a, 1.0, aliased=True)
+    want = a.copy()
+    oracle.lib().acfo_conv_tri1(oracle.F(want), oracle.F(want), h, w, 1, 2.0, 1)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_conv_tri1_other_radius(dev, oracle):
+    h, w = 96, 72
+    a = rnd(6, (2, w, h))
+    r = 0.5
+    p = np.float32(12.0 / r / (r + 2.0) - 2.0)
+    got = dev.op_conv_tri(a, r, aliased=True)
+    want = a.copy()
+    oracle.lib().acfo_conv_tri1(oracle.F(want), oracle.F(want), h, w, 2, float(p), 1)
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("r", [5, 2])
+def test_conv_tri_running_sums(dev, oracle, h, w, r):
+    a = rnd(h * 3 + w * 5 + r, (2, w, h))
+    got = dev.op_conv_tri(a, float(r), aliased=False)
+    want = np.zeros_like(a)
+    assert oracle.lib().acfo_conv_tri(oracle.F(a), oracle.F(want), h, w, 2, r, 1) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("full", [0, 1])
+def test_gradient_mag(dev, oracle, h, w, full):
+    a = synth.make_frame(h + w, h, w, "gray")[0]
+    M, O, _ = dev.op_gradient_mag(a, 0, 0.005, full)
+    Mo, Oo = np.zeros_like(a), np.zeros_like(a)
+    assert oracle.lib().acfo_grad_mag(oracle.F(a), oracle.F(Mo), oracle.F(Oo), h, w, 1, full) == 0
+    assert np.array_equal(bits(M), bits(Mo))
+    assert np.array_equal(bits(O), bits(Oo))
+
+
+def test_gradient_mag_flat_and_extreme(dev, oracle):
+    """M2 == 0 (rsqrt -> inf, clamped to 1e10), exact +-1 cosines, denormal gradients."""
+    h, w = 32, 32
+    a = np.zeros((w, h), np.float32)
+    a[8:16, :] = 1.0           # pure Gx edges
+    a[:, 20:] += 0.5           # pure Gy edges
+    a[24:, :] += np.float32(1e-39)  # denormal step
+    M, O, _ = dev.op_gradient_mag(a, 0, 0.005, 0)
+    Mo, Oo = np.zeros_like(a), np.zeros_like(a)
+    oracle.lib().acfo_grad_mag(oracle.F(a), oracle.F(Mo), oracle.F(Oo), h, w, 1, 0)
+    assert np.array_equal(bits(M), bits(Mo))
+    assert np.array_equal(bits(O), bits(Oo))
+    assert M.min() == np.float32(1.0) / np.float32(1e10)
+
+
+@pytest.mark.parametrize("h,w", [(64, 48), (120, 160), (272, 484)])
+def test_gradient_mag_normalised(dev, oracle, h, w):
+    a = synth.make_frame(h * w, h, w, "gray")[0]
+    M, O, S = dev.op_gradient_mag(a, 5, 0.005, 0)
+    Mo, Oo, So = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+    oracle.lib().acfo_grad_mag(oracle.F(a), oracle.F(Mo), oracle.F(Oo), h, w, 1, 0)
+    oracle.lib().acfo_conv_tri(oracle.F(Mo), oracle.F(So), h, w, 1, 5, 1)
+    oracle.lib().acfo_grad_mag_norm(oracle.F(Mo), oracle.F(So), h, w, 0.005)
+    assert np.array_equal(bits(S), bits(So))
+    assert np.array_equal(bits(M), bits(Mo))
+
+
+@pytest.mark.parametrize("h,w", [(64, 48), (120, 160), (1080, 64)])
+@pytest.mark.parametrize("bin", [4, 2])
+@pytest.mark.parametrize("full", [0, 1])
+def test_gradient_hist(dev, oracle, h, w, bin, full):
+    M = rnd(h + w + bin, (w, h), 0, 0.6)
+    hi = 2 * np.pi if full else np.pi
+    O = rnd(h + w + bin + 1, (w, h), 0.0, float(hi) - 1e-6)
+    got = dev.op_gradient_hist(M, O, bin, 6, full)
+    want = np.zeros_like(got)
+    assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(want), h, w, bin, 6, 0, full) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
+RESAMPLE_CASES = [
+    # (ha, wa, hb, wb): exact /2 /3 /4, mixed exact, generic down (2,3,4,>4 taps), up, up x2, down in one axis / up in other
+    (64, 48, 32, 24), (60, 48, 20, 16), (64, 48, 16, 12), (64, 48, 32, 12),
+    (100, 80, 71, 57), (100, 80, 51, 41), (135, 240, 124, 220), (540, 960, 136, 240), (540, 96, 68, 12),
+    (64, 48, 91, 67), (48, 64, 96, 128), (68, 121, 62, 110), (30, 40, 33, 37), (270, 480, 248, 441),
+]
+
+
+@pytest.mark.parametrize("ha,wa,hb,wb", RESAMPLE_CASES)
+@pytest.mark.parametrize("nrm", [1.0, 1.0832])
+def test_im_resample(dev, oracle, ha, wa, hb, wb, nrm):
+    a = rnd(ha * 7 + wb, (2, wa, ha))
+    got = dev.op_im_resample(a, hb, wb, nrm)
+    want = np.zeros_like(got)
+    assert oracle.lib().acfo_resample(oracle.F(a), oracle.F(want), ha, hb, wa, wb, 2, np.float32(nrm)) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("h,w", [(64, 48), (63, 49), (120, 160)])
+def test_rgb2luv(dev, oracle, h, w):
+    a = synth.make_frame(h * w + 1, h, w, "rgb")
+    got = dev.op_rgb_convert(a, capi.CS_LUV)
+    want = np.zeros_like(a)
+    oracle.lib().acfo_rgb2luv(oracle.F(a), oracle.F(want), h * w)
+    assert np.array_equal(bits(got), bits(want))
+    g = dev.op_rgb_convert(a, capi.CS_GRAY)
+    wg = np.zeros((1, w, h), np.float32)
+    oracle.lib().acfo_rgb2gray(oracle.F(a), oracle.F(wg), h * w)
+    assert np.array_equal(bits(g), bits(wg))
+
+
+@pytest.mark.parametrize("depth", [2, 1, 3, 0])
+def test_acf_detect1(dev, oracle, depth):
+    """The cascade on a random channel buffer: hits identical in number, order, position and score bits."""
+    nC, wP, hP = 10, 60, 44
+    chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
+    kw = dict(treeDepth=depth)
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=128, cascThr=-1.0, **kw)
+    # thresholds inside the data range so both branches are taken
+    m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
+    if depth not in (0, 2):
+        n_int = (1 << depth) - 1
+        m["hs"] = (rnd(6, m["hs"].shape, -0.2, 0.25)).astype(np.float32)
+        m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
+        assert m["fids"].shape[1] >= 2 * n_int + 1
+    dev.set_model(m)
+    got = dev.op_acf_detect1(chns)
+    params, keep = capi.make_params(m)
+    want = np.zeros(1 << 16, dtype=capi.HIT_DTYPE)
+    n = oracle.lib().acfo_acf_detect1(chns.ctypes.data_as(C.c_void_p), 0, keep["thrs"].ctypes.data_as(C.c_void_p), hP, wP, nC,
+                                      C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
+    want = want[:n]
+    assert n > 0 and n < (wP - 3) * (hP - 3), n
+    assert len(got) == n
+    for k in ("scale", "c", "r"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(bits(got["score"]), bits(want["score"]))

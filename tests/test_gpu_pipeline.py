@@ -1,0 +1,145 @@
+"""GPU parity of the whole hot path through the C ABI: chnsPyramid stage taps,
+every level of the fused pyramid, cascade hits and mapped boxes — all compared
+bit-for-bit with the oracle on the same seeded frames and models."""
+import numpy as np
+import pytest
+
+from acf_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+CONFIGS = {
+    # name: (H, W, frame kind, d_in, model kwargs)
+    "tiny_luv": (96, 128, "luv", 3, dict(name="TINY", nTrees=256)),
+    "odd_luv": (130, 175, "luv", 3, dict(name="TINY", nTrees=128, cascThr=-2.5)),          # sz != sz1 at scale 1: image is resampled first
+    "rgb_inria_pad": (240, 320, "rgb", 3, dict(name="INRIA", nTrees=256)),  # RGB->LUV, pad [16 12], nOctUp 1 (up-sampled real scale)
+    "gray_face64": (240, 320, "gray", 1, dict(name="FACE64", nTrees=256)),  # 7 channels, colour disabled, 1-plane input
+    "luv_nperoct4": (200, 260, "luv", 3, dict(name="TINY", nTrees=128, nPerOct=4, nApprox=3, minDs_h=24, minDs_w=24, cascThr=-2.5)),
+    "all_real": (120, 160, "luv", 3, dict(name="TINY", nTrees=64, nApprox=0, minDs_h=32, minDs_w=32)),
+    "shrink2": (96, 128, "luv", 3, dict(name="TINY", nTrees=64, shrink=2, modelDsPad_h=16, modelDsPad_w=16, minDs_h=32, minDs_w=32)),
+    "face80_vga": (480, 640, "luv", 3, dict(name="FACE80", nTrees=512)),
+}
+
+
+def build(cfg, batch=1, taps=True):
+    from acf_amd.detector import HipDetector
+    H, W, kind, d_in, kw = CONFIGS[cfg]
+    model = synth.make_model(seed=3, **kw)
+    det = HipDetector(model, H, W, d_in, max_batch=batch, max_hits=1 << 16, taps=taps)
+    return det, model, (H, W, kind, d_in)
+
+
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_pipeline_bit_exact(oracle, cfg):
+    import torch
+    det, model, (H, W, kind, d_in) = build(cfg)
+    frame = synth.make_frame(17, H, W, kind)
+    plan = oracle.Plan(model, H, W, d_in)
+    # plan geometry agrees (host_plan.cpp vs the oracle's independent restatement)
+    assert len(det.levels) == plan.nScales and det.nChns == plan.nChns
+    for a, b in zip(det.levels, list(plan.levels)[:plan.nScales]):
+        for f, _ in capi.Level._fields_:
+            assert getattr(a, f) == getattr(b, f), f
+    pyr, taps, chns = oracle.chns_pyramid(plan, frame, want_taps=True, want_chns=True)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    d = 1 if model["colorSpace"] == capi.CS_GRAY else 3
+    for k, lvl in enumerate(plan.real):
+        t = taps[k]
+        w1, h1 = t["M"].shape
+        for name, tap, shape in (("image", capi.TAP_IMAGE, (d, w1, h1)), ("smoothed", capi.TAP_SMOOTHED, (d, w1, h1)),
+                                 ("M", capi.TAP_M, (w1, h1)), ("O", capi.TAP_O, (w1, h1)), ("S", capi.TAP_S, (w1, h1)),
+                                 ("Mnorm", capi.TAP_MNORM, (w1, h1))):
+            got = det.read_tap(0, tap, k, shape)
+            assert np.array_equal(bits(got), bits(t[name])), (cfg, "real scale", k, name, float(np.abs(got - t[name]).max()))
+    for i in range(plan.nScales):
+        l = plan.levels[i]
+        got = det.read_tap(0, capi.TAP_CHNS, i, (plan.nChns, l.wC, l.hC))
+        assert np.array_equal(bits(got), bits(chns[i])), (cfg, "raw channels level", i, float(np.abs(got - chns[i]).max()))
+        gl = det.read_level(0, i)
+        assert np.array_equal(bits(gl), bits(plan.level_view(pyr, i))), (cfg, "pyramid level", i)
+    want, want_hits = oracle.detect(plan, pyr)
+    got, got_hits = det.detections(0)
+    assert len(got) == len(want), (len(got), len(want))
+    assert len(want) > 0, "config produces no detections: the cascade comparison would be vacuous"
+    for k in ("scale", "c", "r"):
+        assert np.array_equal(got_hits[k], want_hits[k]), k
+    for k in ("x", "y", "w", "h", "scale"):
+        assert np.array_equal(got[k], want[k]), k
+    # north_star tolerance is 1e-4 on scores; we require bit equality
+    assert np.array_equal(bits(got["score"]), bits(want["score"]))
+    det.close()
+
+
+def test_batch_frames_independent(oracle):
+    """A batch is processed frame by frame identically: frame i of a batch of 5 == the oracle on frame i."""
+    import torch
+    det, model, (H, W, kind, d_in) = build("tiny_luv", batch=5, taps=False)
+    frames = np.stack([synth.make_frame(100 + i, H, W, kind) for i in range(5)])
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, d_in)
+    for i in range(5):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[i])
+        assert np.array_equal(bits(det.read_pyramid(i)), bits(pyr))
+        want, _ = oracle.detect(plan, pyr)
+        got, _ = det.detections(i)
+        assert len(got) == len(want)
+        assert np.array_equal(bits(got["score"]), bits(want["score"]))
+        assert np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"])
+    # host-pointer entry gives the same result as the device-pointer entry
+    det.run_host(frames[:3])
+    for i in range(3):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[i])
+        assert np.array_equal(bits(det.read_pyramid(i)), bits(pyr))
+    det.close()
+
+
+def test_input_frame_not_modified():
+    """The reference smooths the caller's planes in place when isLuv (shallow copies,
+    chnsPyramid.cpp:247,305); the HIP path is out-of-place and must leave the input intact."""
+    import torch
+    det, model, (H, W, kind, d_in) = build("tiny_luv", taps=False)
+    frame = synth.make_frame(4, H, W, kind)
+    t = torch.from_numpy(frame[None]).cuda()
+    det.run(t)
+    det.synchronize()
+    assert np.array_equal(t.cpu().numpy()[0], frame)
+    det.close()
+
+
+def test_capacity_error_is_reported():
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    H, W, kind, d_in, kw = CONFIGS["tiny_luv"]
+    model = synth.make_model(seed=3, **dict(kw, cascThr=-1e9))  # nothing is ever rejected
+    det = HipDetector(model, H, W, d_in, max_batch=1, max_hits=16)
+    det.run(torch.from_numpy(synth.make_frame(1, H, W, kind)[None]).cuda())
+    with pytest.raises(HipError) as e:
+        det.detections(0)
+    assert e.value.code == 7
+    det.close()
+
+
+def test_export_detections_layout(oracle):
+    import torch
+    det, model, (H, W, kind, d_in) = build("tiny_luv", batch=2, taps=False)
+    frames = np.stack([synth.make_frame(50 + i, H, W, kind) for i in range(2)])
+    det.run(torch.from_numpy(frames).cuda())
+    cap = 64
+    dst = torch.full((2, 1 + 6 * cap), -7, dtype=torch.int32, device="cuda")
+    det.export_detections(dst, cap)
+    det.synchronize()
+    rec = dst.cpu().numpy()
+    for i in range(2):
+        got, _ = det.detections(i)
+        n = min(len(got), cap)
+        assert rec[i, 0] == len(got)
+        body = rec[i, 1:].reshape(cap, 6)
+        assert np.array_equal(body[:n, 0], got["x"][:n]) and np.array_equal(body[:n, 3], got["h"][:n])
+        assert np.array_equal(body[:n, 4].view(np.float32), got["score"][:n])
+        assert np.all(body[n:] == 0)
+    det.close()
