@@ -34,6 +34,12 @@ extern "C" {
 
 #define ACF_HIP_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define ACF_HIP_API __attribute__((visibility("default")))
+#else
+#define ACF_HIP_API
+#endif
+
 enum {
     ACF_HIP_OK = 0,
     ACF_HIP_E_INVALID = 1,     /* bad argument / precondition (reference: CV_Assert) */
@@ -138,69 +144,69 @@ typedef struct acf_hip_ctx acf_hip_ctx;
 /* Bind a context to `device` and to `stream` (a hipStream_t, or NULL for a
  * stream owned by the context).  Replaces constructing an acf::Detector
  * (ACF.h:59-66); good() == (return value == ACF_HIP_OK). */
-int acf_hip_create(int device, void* stream, acf_hip_ctx** out);
-int acf_hip_destroy(acf_hip_ctx* ctx);
-int acf_hip_abi_version(void);
+ACF_HIP_API int acf_hip_create(int device, void* stream, acf_hip_ctx** out);
+ACF_HIP_API int acf_hip_destroy(acf_hip_ctx* ctx);
+ACF_HIP_API int acf_hip_abi_version(void);
 /* Last error text for this context (thread-compatible, like one Detector per thread). */
-const char* acf_hip_last_error(const acf_hip_ctx* ctx);
+ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
 
 /* Runtime knobs, the counterpart of the reference's setters (ACF.h:495-595).
  * Keys: "taps" (0/1: keep per-stage intermediates readable through
  * acf_hip_read_tap, the role of setLogger's MatLoggerType tap,
  * chnsCompute.cpp:241-250,285-300; costs one extra full-resolution write). */
-int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
+ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* Upload classifier + options.  Replaces Detector::deserialize*() filling
  * `clf` and `opts` (ACF.h:277,312) and acfModify's effects (acfModify.cpp:139-143),
  * which the caller applies to the struct before the call. */
-int acf_hip_set_model(acf_hip_ctx* ctx, const acf_hip_params* p);
+ACF_HIP_API int acf_hip_set_model(acf_hip_ctx* ctx, const acf_hip_params* p);
 
 /* Plan for frames of h x w with `d` input planes (1 or 3) and up to
  * `max_batch` frames per call and `max_hits` hits per frame: runs getScales
  * (chnsPyramid.cpp:461-529) and the real/approximate split
  * (chnsPyramid.cpp:272-292), builds resampling tables and allocates every
  * device buffer.  Nothing is allocated after this call. */
-int acf_hip_plan(acf_hip_ctx* ctx, int h, int w, int d, int max_batch, int max_hits);
-int acf_hip_num_levels(const acf_hip_ctx* ctx, int* nScales, int* nChns);
-int acf_hip_get_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
+ACF_HIP_API int acf_hip_plan(acf_hip_ctx* ctx, int h, int w, int d, int max_batch, int max_hits);
+ACF_HIP_API int acf_hip_num_levels(const acf_hip_ctx* ctx, int* nScales, int* nChns);
+ACF_HIP_API int acf_hip_get_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
 /* Floats in one frame's fused pyramid (sum over levels of nChns*wP*hP). */
-int acf_hip_pyramid_floats(const acf_hip_ctx* ctx, int64_t* n);
+ACF_HIP_API int acf_hip_pyramid_floats(const acf_hip_ctx* ctx, int64_t* n);
 
 /* ---- the hot path ---------------------------------------------------- */
 
 /* Detector::chnsPyramid for a batch (chnsPyramid.cpp:160-456).  `frames_dev`:
  * n_frames x d planes of float[w][h] already on the device.  Asynchronous on
  * the context's stream. */
-int acf_hip_pyramid(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
+ACF_HIP_API int acf_hip_pyramid(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
 
 /* Detector::operator()(const Pyramid&) without NMS (ACF.cpp:268-367) on the
  * pyramid of the last acf_hip_pyramid call: acfDetect1 on every level
  * (acfDetect1.cpp:309-335) + box mapping.  Asynchronous. */
-int acf_hip_detect(acf_hip_ctx* ctx);
+ACF_HIP_API int acf_hip_detect(acf_hip_ctx* ctx);
 
 /* acf_hip_pyramid + acf_hip_detect: Detector::operator()(const MatP&) (ACF.cpp:246-265). */
-int acf_hip_run(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
+ACF_HIP_API int acf_hip_run(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
 
 /* Same with frames in host memory (H2D copy included). */
-int acf_hip_run_host(acf_hip_ctx* ctx, const float* frames_host, int n_frames);
+ACF_HIP_API int acf_hip_run_host(acf_hip_ctx* ctx, const float* frames_host, int n_frames);
 
 /* Wait for the stream, then return frame `frame`'s detections in the
  * reference's order (level ascending, then c, then r; ACF.cpp:326-329,
  * acfDetect1.cpp:86-96).  `*count` is the true number even if > cap. */
-int acf_hip_get_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
-int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, int cap, int* count);
+ACF_HIP_API int acf_hip_get_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
+ACF_HIP_API int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, int cap, int* count);
 
 /* Device-side export for the multi-GPU gather: writes, for every frame of the
  * last batch, a fixed-capacity record [count, then cap x {x,y,w,h,score bits,scale}]
  * of int32 into `dst_dev` (n_frames * (1 + 6*cap) int32), sorted as above. */
-int acf_hip_export_detections(acf_hip_ctx* ctx, int32_t* dst_dev, int cap);
+ACF_HIP_API int acf_hip_export_detections(acf_hip_ctx* ctx, int32_t* dst_dev, int cap);
 
-int acf_hip_synchronize(acf_hip_ctx* ctx);
+ACF_HIP_API int acf_hip_synchronize(acf_hip_ctx* ctx);
 
 /* ---- parity taps (tests only; not on the timed path) ------------------ */
 
 /* Copy level `level` of frame `frame`'s fused pyramid ([nChns][wP][hP]) to host. */
-int acf_hip_read_level(acf_hip_ctx* ctx, int frame, int level, float* host_out);
+ACF_HIP_API int acf_hip_read_level(acf_hip_ctx* ctx, int frame, int level, float* host_out);
 
 enum {
     ACF_HIP_TAP_IMAGE = 0,    /* resampled image at a real scale, before smoothing: d planes */
@@ -212,7 +218,7 @@ enum {
     ACF_HIP_TAP_CHNS = 6      /* unsmoothed, unpadded channels of a level: nChns planes [wC][hC] */
 };
 /* `index`: real-scale ordinal for taps 0-5, level for ACF_HIP_TAP_CHNS. */
-int acf_hip_read_tap(acf_hip_ctx* ctx, int frame, int tap, int index, float* host_out, int64_t cap_floats);
+ACF_HIP_API int acf_hip_read_tap(acf_hip_ctx* ctx, int frame, int tap, int index, float* host_out, int64_t cap_floats);
 
 /* ---- single operators on host planes ---------------------------------
  * The reference exposes these as static members of acf::Detector
@@ -220,20 +226,20 @@ int acf_hip_read_tap(acf_hip_ctx* ctx, int frame, int tap, int index, float* hos
  * pyramid uses, on one plane set, synchronously. */
 
 /* Detector::rgbConvert (rgbConvert.cpp:101-170) flag = ACF_HIP_CS_LUV or GRAY. */
-int acf_hip_op_rgb_convert(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int flag);
+ACF_HIP_API int acf_hip_op_rgb_convert(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int flag);
 /* Detector::convTri (convTri.cpp:204-253): r in (0,1] -> convTri1 with the
  * reference's in-place aliasing semantics when `aliased` != 0; r > 1 -> convTri. */
-int acf_hip_op_conv_tri(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int d, double r, int aliased);
+ACF_HIP_API int acf_hip_op_conv_tri(acf_hip_ctx* ctx, const float* in, float* out, int h, int w, int d, double r, int aliased);
 /* Detector::gradientMag (gradientMag.cpp:102-135). S_out may be NULL. */
-int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float* M, float* O, float* S_out,
+ACF_HIP_API int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float* M, float* O, float* S_out,
     int h, int w, int normRad, double normConst, int full);
 /* Detector::gradientHist (gradientHist.cpp:92-115), softBin 0. */
-int acf_hip_op_gradient_hist(acf_hip_ctx* ctx, const float* M, const float* O, float* H,
+ACF_HIP_API int acf_hip_op_gradient_hist(acf_hip_ctx* ctx, const float* M, const float* O, float* H,
     int h, int w, int bin, int nOrients, int full);
 /* imResample (imResampleMex.cpp:385-420). */
-int acf_hip_op_im_resample(acf_hip_ctx* ctx, const float* in, float* out, int ha, int wa, int hb, int wb, int d, double nrm);
+ACF_HIP_API int acf_hip_op_im_resample(acf_hip_ctx* ctx, const float* in, float* out, int ha, int wa, int hb, int wb, int d, double nrm);
 /* Detector::acfDetect1 on one host channel buffer [nChns][wP][hP] (acfDetect1.cpp:309-335). */
-int acf_hip_op_acf_detect1(acf_hip_ctx* ctx, const float* chns, int hP, int wP, int nChns,
+ACF_HIP_API int acf_hip_op_acf_detect1(acf_hip_ctx* ctx, const float* chns, int hP, int wP, int nChns,
     acf_hip_hit* out, int cap, int* count);
 
 #ifdef __cplusplus

@@ -165,13 +165,11 @@ def test_acf_detect1(dev, oracle, depth):
     chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
     kw = dict(treeDepth=depth)
     m = synth.make_model(seed=11 + depth, name="TINY", nTrees=128, cascThr=-1.0, **kw)
-    # thresholds inside the data range so both branches are taken
+    # thresholds inside the data range so both branches are taken; leaf values with a
+    # slight negative drift so that part of the windows is rejected at every depth
     m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
-    if depth not in (0, 2):
-        n_int = (1 << depth) - 1
-        m["hs"] = (rnd(6, m["hs"].shape, -0.2, 0.25)).astype(np.float32)
-        m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
-        assert m["fids"].shape[1] >= 2 * n_int + 1
+    m["hs"] = rnd(6, m["hs"].shape, -0.25, 0.2)
+    m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
     dev.set_model(m)
     got = dev.op_acf_detect1(chns)
     params, keep = capi.make_params(m)
