@@ -157,6 +157,7 @@ def load():
         "acf_hip_get_hits": ([ctx, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_export_detections": ([ctx, C.c_void_p, C.c_int], C.c_int),
         "acf_hip_synchronize": ([ctx], C.c_int),
+        "acf_hip_profile_get": ([ctx, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int], C.c_int),
         "acf_hip_read_level": ([ctx, C.c_int, C.c_int, fp], C.c_int),
         "acf_hip_read_tap": ([ctx, C.c_int, C.c_int, C.c_int, fp, C.c_int64], C.c_int),
         "acf_hip_op_rgb_convert": ([ctx, fp, fp, C.c_int, C.c_int, C.c_int], C.c_int),
@@ -180,7 +181,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_set_model",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_pyramid_floats", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_get_detections", "acf_hip_get_hits",
-    "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_read_level", "acf_hip_read_tap",
+    "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",
     "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_op_gradient_hist",
     "acf_hip_op_im_resample", "acf_hip_op_acf_detect1",
 ]

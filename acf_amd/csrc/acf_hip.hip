@@ -41,6 +41,10 @@ struct acf_hip_ctx
     mutable std::string err;
     bool hasModel = false, hasPlan = false;
     int taps = 0;
+    int profile = 0;
+    std::vector<hipEvent_t> evPool;
+    std::vector<const char*> evName;
+    size_t evUsed = 0;
 
     acf_hip_params p{};
     std::vector<uint32_t> fids, child;
@@ -117,6 +121,29 @@ int fail(const acf_hip_ctx* c, int code, const std::string& msg)
 {
     c->err = msg;
     return code;
+}
+
+// Profile marker: an event recorded on the stream before the launch named
+// `name`; a kernel's time is the span to the next marker.
+void prof(acf_hip_ctx* c, const char* name)
+{
+    if (!c->profile)
+    {
+        return;
+    }
+    if (c->evUsed == c->evPool.size())
+    {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess)
+        {
+            return;
+        }
+        c->evPool.push_back(e);
+        c->evName.push_back(name);
+    }
+    c->evName[c->evUsed] = name;
+    (void)hipEventRecord(c->evPool[c->evUsed], c->stream);
+    c->evUsed++;
 }
 
 template <class T>
@@ -259,6 +286,7 @@ int launchSmooth(acf_hip_ctx* c, const float* in, float* out, const SmoothJob* d
     }
     const int R = (maxH + nt - 1) / nt;
     const int ldsStride = maxH + 1;
+    prof(c, nJobs > 1 ? "k_smooth_tri1(levels)" : "k_smooth_tri1(image)");
     const size_t lds = 2 * size_t(ldsStride) * sizeof(float);
     dim3 grid(maxPlanes, nJobs, nFrames), block(nt);
 #define SM_LAUNCH(RR)                                                                                                    \
@@ -294,8 +322,10 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     {
         return fail(c, ACF_HIP_E_UNSUPPORTED, "convTri: radius > 15");
     }
+    prof(c, "k_tri_x");
     hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
     LAUNCHCHK(c, "k_tri_x");
+    prof(c, "k_tri_y");
     hipLaunchKernelGGL(k_tri_y, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, rad, fs);
     LAUNCHCHK(c, "k_tri_y");
     return ACF_HIP_OK;
@@ -324,6 +354,7 @@ int launchChns(acf_hip_ctx* c, const ChnsArgs& a, int shrink, int nFrames)
         block = dim3(128);
         grid = dim3(cdiv(hc, 128), wc, nFrames);
     }
+    prof(c, "k_chns");
     if (shrink == 4)
     {
         hipLaunchKernelGGL(k_chns<4>, grid, block, 0, c->stream, a);
@@ -467,6 +498,10 @@ int acf_hip_destroy(acf_hip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     freeAll(c);
+    for (hipEvent_t e : c->evPool)
+    {
+        (void)hipEventDestroy(e);
+    }
     if (c->ownStream)
     {
         (void)hipStreamDestroy(c->stream);
@@ -489,6 +524,12 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "taps"))
     {
         c->taps = value != 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "profile"))
+    {
+        c->profile = value != 0;
+        c->evUsed = 0;
         return ACF_HIP_OK;
     }
     return fail(c, ACF_HIP_E_INVALID, std::string("unknown option ") + key);
@@ -986,6 +1027,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     int curH = H, curW = W;
     if (c->d_color)
     {
+        prof(c, "k_colour");
         dim3 grid(cdiv(np0, 256), 1, nF), block(256);
         const int64_t out_fs = int64_t(d) * np0;
         if (p.colorSpace == ACF_HIP_CS_LUV)
@@ -1039,6 +1081,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
             {
                 return fail(c, ACF_HIP_E_INVALID, "pyramid: internal frame-stride mismatch");
             }
+            prof(c, "k_resample(image)");
             hipLaunchKernelGGL(k_resample, dim3(cdiv(np * d, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
                 (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
             LAUNCHCHK(c, "k_resample(image)");
@@ -1068,6 +1111,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         }
         if (p.gradMagEnabled || p.gradHistEnabled)
         {
+            prof(c, "k_grad_mag");
             hipLaunchKernelGGL(k_grad_mag, dim3(cdiv(rs.h, 256), rs.w, nF), dim3(256), 0, c->stream,
                 (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)(c->d_acos + 10010), rs.h, rs.w, p.full, int64_t(d) * np, np);
             LAUNCHCHK(c, "k_grad_mag");
@@ -1109,6 +1153,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
     if (c->nApproxDescs > 0)
     {
+        prof(c, "k_resample(approx)");
         hipLaunchKernelGGL(k_resample, dim3(cdiv(c->approxMaxElems, 256), c->nApproxDescs, nF), dim3(256), 0, c->stream,
             (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft);
         LAUNCHCHK(c, "k_resample(approx)");
@@ -1137,9 +1182,11 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     }
     if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
     {
+        prof(c, "k_pad_reflect");
         hipLaunchKernelGGL(k_pad_reflect, dim3(cdiv(c->padMaxElems, 256), nL, nF), dim3(256), 0, c->stream, c->d_pyr, (const PadJob*)c->d_padJobs, pl.pyr_floats);
         LAUNCHCHK(c, "k_pad_reflect");
     }
+    prof(c, "(end)");
     c->lastBatch = nF;
     c->pyramidValid = true;
     return ACF_HIP_OK;
@@ -1149,6 +1196,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
     const uint32_t* d_cidAll, const CascNode2* d_nodes2, const BoxLevel* d_box, int nF)
 {
     const acf_hip_params& p = c->p;
+    prof(c, "k_cascade");
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * nF, c->stream));
     if (blocksPerFrame > 0)
     {
@@ -1190,9 +1238,11 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
     // shift = (modelDsPad - modelDs)/2 - pad (ACF.cpp:275; cv::Size integer arithmetic)
     const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
     const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
+    prof(c, "k_sort_map");
     hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->d_hits, (const int32_t*)c->d_counts, c->maxHits,
         d_box, p.stride, shift_h, shift_w, c->d_sorted, c->d_dets);
     LAUNCHCHK(c, "k_sort_map");
+    prof(c, "(end)");
     c->countsFetched = false;
     return ACF_HIP_OK;
 }
@@ -1258,6 +1308,65 @@ int acf_hip_synchronize(acf_hip_ctx* c)
         return ACF_HIP_E_INVALID;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_profile_get(acf_hip_ctx* c, int* n, const char** names, float* ms, int* launches, int cap)
+{
+    if (!c || !n)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<const char*> nm;
+    std::vector<float> tot;
+    std::vector<int> cnt;
+    for (size_t i = 0; i + 1 < c->evUsed; i++)
+    {
+        const char* name = c->evName[i];
+        if (!strcmp(name, "(end)"))
+        {
+            continue;
+        }
+        float dt = 0;
+        if (hipEventElapsedTime(&dt, c->evPool[i], c->evPool[i + 1]) != hipSuccess)
+        {
+            continue;
+        }
+        size_t k = 0;
+        for (; k < nm.size(); k++)
+        {
+            if (!strcmp(nm[k], name))
+            {
+                break;
+            }
+        }
+        if (k == nm.size())
+        {
+            nm.push_back(name);
+            tot.push_back(0.f);
+            cnt.push_back(0);
+        }
+        tot[k] += dt;
+        cnt[k]++;
+    }
+    c->evUsed = 0;
+    *n = int(nm.size());
+    for (int k = 0; k < *n && k < cap; k++)
+    {
+        if (names)
+        {
+            names[k] = nm[k];
+        }
+        if (ms)
+        {
+            ms[k] = tot[k];
+        }
+        if (launches)
+        {
+            launches[k] = cnt[k];
+        }
+    }
     return ACF_HIP_OK;
 }
 

@@ -95,6 +95,19 @@ class HipDetector:
     def synchronize(self):
         self._chk(self.lib.acf_hip_synchronize(self.ctx))
 
+    def set_option(self, key, value):
+        self._chk(self.lib.acf_hip_set_option(self.ctx, key.encode(), int(value)))
+
+    def profile(self):
+        """{kernel name: (total ms, launches)} since the last call (option "profile")."""
+        cap = 64
+        n = C.c_int()
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (C.c_int * cap)()
+        self._chk(self.lib.acf_hip_profile_get(self.ctx, C.byref(n), names, ms, cnt, cap))
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(min(n.value, cap))}
+
     def export_detections(self, dst, cap):
         self._chk(self.lib.acf_hip_export_detections(self.ctx, C.c_void_p(dst.data_ptr()), cap))
 

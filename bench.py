@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — detector FPS @1080p, 8 scales/octave, FACE80 model on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One "step" = one pass of the hot path (acf_hip_run: chnsPyramid + acfDetect,
+then the device-side export of the detection records) over a batch of B
+synthetic 1080p planar-f32 LUV frames that are already resident in HBM.  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its
+own B frames (weak scaling, no data-path collective) and the fixed-capacity
+detection records are gathered to rank 0 over RCCL inside the timed step.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with
+ - value: whole-job frames/s,
+ - roofline: whole-path algorithmic bytes (B = B_in + 2*B_pyr per
+   frame) over the kernels' HIP-event time, plus the dominant kernel's own share,
+ - cpu_baseline: the oracle (CPU restatement, 1 thread) on a bounded sample of the
+   same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_bytes_per_frame(det, model):
+    """Algorithmic (compulsory in+out) bytes per frame of each kernel, from the plan."""
+    lv = det.levels
+    nC = det.nChns
+    d = 1 if model["colorSpace"] == 0 else 3
+    sh = model["shrink"]
+    real = [l for l in lv if l.isReal]
+    np_real = [l.hC * sh * l.wC * sh for l in real]
+    cells = [l.hC * l.wC for l in lv]
+    raw = 4 * nC * sum(cells)
+    pyr = 4 * det.pyr_floats
+    b = {}
+    b["k_smooth_tri1(image)"] = sum(2 * d * n * 4 for n in np_real)
+    b["k_grad_mag"] = sum(3 * n * 4 for n in np_real)
+    b["k_tri_x"] = sum(2 * n * 4 for n in np_real)
+    b["k_tri_y"] = sum(2 * n * 4 for n in np_real)
+    b["k_chns"] = sum((d + 3) * n * 4 + nC * (n // (sh * sh)) * 4 for n in np_real)
+    b["k_resample(image)"] = sum(d * 4 * (np_real[0] if i == 1 else np_real[1]) + d * 4 * np_real[i] for i in range(1, len(np_real))) if len(np_real) > 1 else 0
+    b["k_resample(approx)"] = raw
+    b["k_smooth_tri1(levels)"] = raw + pyr
+    b["k_cascade"] = pyr
+    b["k_sort_map"] = 0
+    b["k_pad_reflect"] = 0
+    b["k_colour"] = 0
+    return b
+
+
+def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
+    """Oracle (oracle/acf_oracle.c, the CPU restatement) timed single-threaded on a
+    bounded sample of the same workload.  Reported baseline, not the thing measured."""
+    from oracle import binding as ob
+    plan = ob.Plan(model, H, W, 3)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        f = frames_np[n % len(frames_np)]
+        pyr, _, _ = ob.chns_pyramid(plan, f)
+        ob.detect(plan, pyr)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 200:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 1080p LUV frames, FACE80 synthetic model, oracle/acf_oracle.c (gcc -O2), 1 thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--cap", type=int, default=1024, help="detections exported per frame (gather record capacity)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from acf_amd import synth
+    from acf_amd.detector import HipDetector
+    from acf_amd.dist import gather_records
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    H, W, B = args.height, args.width, args.batch
+
+    model = synth.make_model(seed=1, name="FACE80")
+    # distinct base frames per rank, expanded to B distinct frames by cyclic shifts (cheap, on device)
+    nbase = 4
+    base_np = [synth.make_frame(1000 * rank + i + 1, H, W, "luv") for i in range(nbase)]
+    base = torch.from_numpy(np.stack(base_np)).to(dev)
+    frames = torch.empty((B, 3, W, H), dtype=torch.float32, device=dev)
+    for i in range(B):
+        frames[i] = torch.roll(base[i % nbase], shifts=(37 * (i // nbase), 53 * (i // nbase)), dims=(1, 2))
+    del base
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    det = HipDetector(model, H, W, 3, max_batch=B, max_hits=8192, device=local, stream=stream)
+    if not args.no_profile:
+        det.set_option("profile", 1)
+    rec = torch.zeros((B, 1 + 6 * args.cap), dtype=torch.int32, device=dev)
+
+    def step():
+        det.run(frames, B)
+        det.export_detections(rec, args.cap)
+        if world > 1:
+            return gather_records(rec, world, rank)
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        det.profile()  # drop warm-up events
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    prof = det.profile() if not args.no_profile else {}
+    counts = rec[:, 0].cpu().numpy()
+    if rank == 0:
+        frames_total = B * world * args.steps
+        fps = frames_total / dt
+        b_in = 3 * 4 * H * W
+        b_pyr = 4 * det.pyr_floats
+        b_frame = b_in + 2 * b_pyr
+        out = {
+            "metric": "detector FPS @1080p, 8 scales/octave, FACE80 model",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d planar f32 LUV frames, synthetic FACE80-shaped model (80x80, 10 ch, depth 2, 2048 trees), "
+                                   "nPerOct 8, nApprox 7, shrink 4; %d frames resident in HBM per GPU per step" % (W, H, B),
+                       "frames_per_gpu_per_step": B, "levels": len(det.levels), "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in det.levels)),
+                       "mean_detections_per_frame": float(counts.mean()), "parallelism": "frames sharded, %d rank(s)" % world},
+        }
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "bytes_per_frame": b_frame}
+        if prof:
+            tot_ms = sum(v[0] for v in prof.values())
+            kb = kernel_bytes_per_frame(det, model)
+            dom = max(prof, key=lambda k: prof[k][0])
+            # whole path: algorithmic bytes of all frames of all timed steps / summed kernel time (HIP events on the launch stream)
+            ach = b_frame * B * args.steps / (tot_ms * 1e-3) / 1e9
+            roof.update({
+                "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                "scope": "whole hot path per step (all kernels); dominant kernel below",
+                "kernel": dom, "kernel_share": prof[dom][0] / tot_ms,
+                "kernel_avg_ms": prof[dom][0] / max(prof[dom][1], 1),
+                "kernel_achieved": (kb.get(dom, 0) * B * args.steps / (prof[dom][0] * 1e-3) / 1e9) if prof[dom][0] > 0 else None,
+                "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            })
+        else:
+            ach = b_frame * fps / world / 1e9
+            roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "scope": "whole hot path, wall clock"})
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, base_np, H, W)
+        else:
+            out["cpu_baseline"] = None
+        if gathered is not None:
+            out["config"]["gathered_records"] = int(gathered.shape[0])
+        print(json.dumps(out))
+    det.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

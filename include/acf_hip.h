@@ -153,7 +153,9 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
 /* Runtime knobs, the counterpart of the reference's setters (ACF.h:495-595).
  * Keys: "taps" (0/1: keep per-stage intermediates readable through
  * acf_hip_read_tap, the role of setLogger's MatLoggerType tap,
- * chnsCompute.cpp:241-250,285-300; costs one extra full-resolution write). */
+ * chnsCompute.cpp:241-250,285-300; costs one extra full-resolution write; set
+ * before acf_hip_plan), "profile" (0/1: record HIP events around every kernel,
+ * read with acf_hip_profile_get). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* Upload classifier + options.  Replaces Detector::deserialize*() filling
@@ -202,6 +204,13 @@ ACF_HIP_API int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, 
 ACF_HIP_API int acf_hip_export_detections(acf_hip_ctx* ctx, int32_t* dst_dev, int cap);
 
 ACF_HIP_API int acf_hip_synchronize(acf_hip_ctx* ctx);
+
+/* Per-kernel timing with HIP events recorded on the context's stream (option
+ * "profile" = 1): the counterpart of the reference's ScopeTimeLogger stage
+ * timers (GPUDetectionPipeline.cpp:366,415,485).  Synchronises, then returns
+ * up to `cap` kernel names (static strings), their accumulated milliseconds and
+ * launch counts since the last call, and resets the accumulation. */
+ACF_HIP_API int acf_hip_profile_get(acf_hip_ctx* ctx, int* n, const char** names, float* ms, int* launches, int cap);
 
 /* ---- parity taps (tests only; not on the timed path) ------------------ */
 
