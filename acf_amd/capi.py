@@ -145,6 +145,8 @@ def load():
         "acf_hip_last_error": ([ctx], C.c_char_p),
         "acf_hip_set_option": ([ctx, C.c_char_p, C.c_int], C.c_int),
         "acf_hip_set_model": ([ctx, C.POINTER(Params)], C.c_int),
+        "acf_hip_get_scales": ([C.c_int] * 7 + [C.POINTER(C.c_double)] * 3 + [C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "acf_hip_plan_levels": ([C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(Level), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "acf_hip_plan": ([ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "acf_hip_num_levels": ([ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_levels": ([ctx, C.POINTER(Level), C.c_int], C.c_int),
@@ -178,7 +180,7 @@ def load():
 
 DECLARED_SYMBOLS = [
     "acf_hip_create", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
-    "acf_hip_set_model",
+    "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_pyramid_floats", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_get_detections", "acf_hip_get_hits",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",

@@ -535,6 +535,58 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     return fail(c, ACF_HIP_E_INVALID, std::string("unknown option ") + key);
 }
 
+int acf_hip_get_scales(int nPerOct, int nOctUp, int minDs_h, int minDs_w, int shrink, int h, int w,
+    double* scales, double* shw_h, double* shw_w, int cap, int* n)
+{
+    if (!n || nPerOct <= 0 || minDs_h <= 0 || minDs_w <= 0 || shrink <= 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    ScaleList sl = getScales(nPerOct, nOctUp, minDs_h, minDs_w, shrink, h, w);
+    *n = int(sl.scales.size());
+    for (int i = 0; i < *n && i < cap; i++)
+    {
+        if (scales)
+        {
+            scales[i] = sl.scales[i];
+        }
+        if (shw_h)
+        {
+            shw_h[i] = sl.shw_h[i];
+        }
+        if (shw_w)
+        {
+            shw_w[i] = sl.shw_w[i];
+        }
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_plan_levels(const acf_hip_params* p, int h, int w, int d, acf_hip_level* out, int cap, int* nScales, int* nChns)
+{
+    if (!p || !nScales)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    Plan plan;
+    std::string err;
+    int rc = buildPlan(*p, h, w, d, plan, err);
+    if (rc)
+    {
+        return rc;
+    }
+    *nScales = int(plan.levels.size());
+    if (nChns)
+    {
+        *nChns = plan.nChns;
+    }
+    for (int i = 0; i < *nScales && i < cap && out; i++)
+    {
+        out[i] = plan.levels[i];
+    }
+    return ACF_HIP_OK;
+}
+
 int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
 {
     if (!c || !p)

@@ -4,7 +4,7 @@
 //
 // Follows Detector::getScales / chnsPyramid's scale bookkeeping
 // (reference chnsPyramid.cpp:270-292,461-529) and resampleCoef
-// (toolbox/imResampleMex.cpp:24-121).  Written independently of oracle/.
+// (toolbox/imResampleMex.cpp:24-121).  Shares no code with the CPU checker.
 #pragma once
 
 #include "../../include/acf_hip.h"

@@ -158,6 +158,17 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * read with acf_hip_profile_get). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
+/* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.
+ * Writes up to `cap` scales and returns the total count in *n. */
+ACF_HIP_API int acf_hip_get_scales(int nPerOct, int nOctUp, int minDs_h, int minDs_w, int shrink, int h, int w,
+    double* scales, double* scaleshw_h, double* scaleshw_w, int cap, int* n);
+
+/* The level geometry acf_hip_plan would produce for these options and frame
+ * size, computed on the host without touching a device (what chnsPyramid's
+ * bookkeeping, chnsPyramid.cpp:270-292, and createDetector's window grid,
+ * acfDetect1.cpp:258-259, yield). */
+ACF_HIP_API int acf_hip_plan_levels(const acf_hip_params* p, int h, int w, int d, acf_hip_level* out, int cap, int* nScales, int* nChns);
+
 /* Upload classifier + options.  Replaces Detector::deserialize*() filling
  * `clf` and `opts` (ACF.h:277,312) and acfModify's effects (acfModify.cpp:139-143),
  * which the caller applies to the struct before the call. */
