@@ -131,6 +131,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # A process that also uses torch must let torch load ITS bundled HIP runtime
+    # first: if libacf_hip.so pulls in the system libamdhip64 before torch is
+    # imported, torch later reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libacf_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "

@@ -69,7 +69,8 @@ struct acf_hip_ctx
     SmoothJob* d_finalJobs = nullptr;
     PadJob* d_padJobs = nullptr;
     int finalMaxH = 0;
-    int64_t approxMaxElems = 0, padMaxElems = 0;
+    int approxMaxBlocks = 0;
+    int64_t padMaxElems = 0;
     // frame buffers
     float* d_color = nullptr; // colour-converted full-resolution image (if a conversion is needed)
     float* d_chns = nullptr;
@@ -83,11 +84,15 @@ struct acf_hip_ctx
     uint32_t* d_cidAll = nullptr;
     float *d_thrs = nullptr, *d_hs = nullptr;
     uint32_t* d_child = nullptr;
+    uint32_t* d_fids = nullptr;
     CascNode2* d_nodes2 = nullptr;
     BoxLevel* d_boxLevels = nullptr;
     acf_hip_hit *d_hits = nullptr, *d_sorted = nullptr;
     acf_hip_detection* d_dets = nullptr;
     int32_t* d_counts = nullptr;
+    uint2* d_queue[2] = { nullptr, nullptr }; // survivor queues between cascade stages
+    int32_t* d_qcounts = nullptr;             // [stage][frame]
+    int qcap = 0;
     std::vector<int32_t> h_counts;
     bool countsFetched = false;
 };
@@ -697,30 +702,13 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         }
         block += nb;
         const int64_t area = int64_t(L.hP) * L.wP;
-        if (area * nChns >= (int64_t(1) << 31))
+        if (area * nChns >= (int64_t(1) << 31) || L.nWin >= (1 << 24))
         {
-            return fail(c, ACF_HIP_E_UNSUPPORTED, "level too large for 32-bit channel offsets");
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "level too large for 32-bit channel offsets / 24-bit window ids");
         }
         if (packed)
         {
-            L.nodeOff = int64_t(nodes2.size());
-            for (int t = 0; t < p.nTrees; t++)
-            {
-                CascNode2 nd{};
-                const size_t q = size_t(t) * p.nTreeNodes;
-                for (int k = 0; k < 3; k++)
-                {
-                    const uint32_t f = c->fids[q + k];
-                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
-                    nd.cid[k] = uint32_t(z * area + int64_t(cc) * L.hP + rr); // computeChannelIndexColMajor, acfDetect1.cpp:390-406
-                    nd.thr[k] = c->thrs[q + k];
-                }
-                for (int k = 0; k < 4; k++)
-                {
-                    nd.hs[k] = c->hs[q + 3 + k];
-                }
-                nodes2.push_back(nd);
-            }
+            L.nodeOff = 0;
         }
         else
         {
@@ -736,6 +724,33 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 }
                 cidAll.push_back(v);
             }
+        }
+    }
+    if (packed)
+    {
+        // one level-independent table: feature ids kept as (z, c, r) of
+        // computeChannelIndexColMajor (acfDetect1.cpp:390-406); the kernel rebuilds
+        // z*area + c*hP + r from the lane's level geometry
+        if (mW > 4095 || mH > 4095 || nChns > 255 || lv.size() > 255)
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "model window / channel count too large for the packed node table");
+        }
+        for (int t = 0; t < p.nTrees; t++)
+        {
+            CascNode2 nd{};
+            const size_t q = size_t(t) * p.nTreeNodes;
+            for (int k = 0; k < 3; k++)
+            {
+                const uint32_t f = c->fids[q + k];
+                const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
+                nd.zcr[k] = (z << 24) | (cc << 12) | rr;
+                nd.thr[k] = c->thrs[q + k];
+            }
+            for (int k = 0; k < 4; k++)
+            {
+                nd.hs[k] = c->hs[q + 3 + k];
+            }
+            nodes2.push_back(nd);
         }
     }
     *blocksPerFrame = block;
@@ -908,7 +923,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     // approximated levels (chnsPyramid.cpp:385-397)
     const int nColor = p.colorEnabled ? d : 0;
     const int nMag = p.gradMagEnabled ? 1 : 0;
-    c->approxMaxElems = 0;
+    c->approxMaxBlocks = 0;
     for (size_t i = 0; i < pl.levels.size(); i++)
     {
         const acf_hip_level& l = pl.levels[i];
@@ -934,7 +949,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         dd.src_frame_stride = pl.raw_floats;
         dd.dst_frame_stride = pl.raw_floats;
         c->h_descs.push_back(dd);
-        c->approxMaxElems = std::max<int64_t>(c->approxMaxElems, int64_t(pl.nChns) * l.hC * l.wC);
+        c->approxMaxBlocks = std::max(c->approxMaxBlocks, resampleBlocks(dd));
     }
     c->nApproxDescs = int(c->h_descs.size()) - c->nImgDescs;
 
@@ -984,7 +999,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     {
         return rc;
     }
-    if ((rc = devUpload(c, &c->d_thrs, c->thrs)) || (rc = devUpload(c, &c->d_hs, c->hs)) || (rc = devUpload(c, &c->d_child, c->child)))
+    if ((rc = devUpload(c, &c->d_thrs, c->thrs)) || (rc = devUpload(c, &c->d_hs, c->hs)) || (rc = devUpload(c, &c->d_child, c->child)) ||
+        (rc = devUpload(c, &c->d_fids, c->fids)))
     {
         return rc;
     }
@@ -1005,6 +1021,19 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         (rc = devAlloc(c, &c->d_dets, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->d_counts, size_t(B))))
     {
         return rc;
+    }
+    {
+        int64_t nWinTotal = 0;
+        for (const auto& l : pl.levels)
+        {
+            nWinTotal += int64_t(l.nWinR) * l.nWinC;
+        }
+        c->qcap = int(std::max<int64_t>(nWinTotal, 1));
+        if ((rc = devAlloc(c, &c->d_queue[0], size_t(B) * c->qcap)) || (rc = devAlloc(c, &c->d_queue[1], size_t(B) * c->qcap)) ||
+            (rc = devAlloc(c, &c->d_qcounts, size_t(8) * B)))
+        {
+            return rc;
+        }
     }
     c->h_counts.assign(B, 0);
     c->hasPlan = true;
@@ -1134,7 +1163,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
                 return fail(c, ACF_HIP_E_INVALID, "pyramid: internal frame-stride mismatch");
             }
             prof(c, "k_resample(image)");
-            hipLaunchKernelGGL(k_resample, dim3(cdiv(np * d, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
+            hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(c->h_descs[rs.descIndex]), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
                 (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
             LAUNCHCHK(c, "k_resample(image)");
             img = rs.img;
@@ -1206,7 +1235,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     if (c->nApproxDescs > 0)
     {
         prof(c, "k_resample(approx)");
-        hipLaunchKernelGGL(k_resample, dim3(cdiv(c->approxMaxElems, 256), c->nApproxDescs, nF), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nF), dim3(64, 4), 0, c->stream,
             (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft);
         LAUNCHCHK(c, "k_resample(approx)");
     }
@@ -1245,19 +1274,36 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
 }
 
 static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const CascLevel* d_levels, const int32_t* d_blockLevel, int blocksPerFrame,
-    const uint32_t* d_cidAll, const CascNode2* d_nodes2, const BoxLevel* d_box, int nF)
+    const uint32_t* d_cidAll, const CascNode2* d_nodes2, const BoxLevel* d_box, int nF, int nChns)
 {
     const acf_hip_params& p = c->p;
     prof(c, "k_cascade");
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * nF, c->stream));
     if (blocksPerFrame > 0)
     {
+        // stage boundaries (see kernels.hip.h): [0,16) [16,32) [32,128) [128,nTrees)
+        std::vector<int> bounds;
+        for (int b : { 16, 32, 128 })
+        {
+            if (b < p.nTrees)
+            {
+                bounds.push_back(b);
+            }
+        }
+        bounds.push_back(p.nTrees);
+        const int nStages = int(bounds.size());
+        HIPCHK(c, hipMemsetAsync(c->d_qcounts, 0, sizeof(int32_t) * size_t(nStages) * c->maxBatch, c->stream));
         CascArgs a{};
         a.pyr = pyr;
         a.pyr_fs = pyr_fs;
         a.levels = d_levels;
         a.blockLevel = d_blockLevel;
         a.blocksPerFrame = blocksPerFrame;
+        a.nFrames = nF;
+        a.mH = p.modelDsPad_h / p.shrink;
+        a.mW = p.modelDsPad_w / p.shrink;
+        a.nChns = nChns;
+        a.fids = c->d_fids;
         a.nTrees = p.nTrees;
         a.nTreeNodes = p.nTreeNodes;
         a.treeDepth = p.treeDepth;
@@ -1269,23 +1315,76 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
         a.hs = c->d_hs;
         a.child = c->d_child;
         a.nodes2 = d_nodes2;
+        a.qcap = c->qcap;
         a.hits = c->d_hits;
         a.counts = c->d_counts;
         a.maxHits = c->maxHits;
-        dim3 grid(blocksPerFrame, nF), block(256);
-        if (p.treeDepth == 2)
+        const int mode = p.treeDepth == 2 ? 2 : (p.treeDepth > 0 ? 1 : 0);
+        // later stages see a shrinking survivor set; grid-stride loops cover any count
+        const int qGrid[3] = { std::max(1, blocksPerFrame / 2), std::max(1, blocksPerFrame / 8), std::max(1, std::min(blocksPerFrame, 64)) };
+        for (int sidx = 0; sidx < nStages; sidx++)
         {
-            hipLaunchKernelGGL(k_cascade<2>, grid, block, 0, c->stream, a);
+            a.t0 = sidx == 0 ? 0 : bounds[sidx - 1];
+            a.t1 = bounds[sidx];
+            a.last = sidx == nStages - 1;
+            a.qin = sidx > 0 ? c->d_queue[(sidx - 1) & 1] : nullptr;
+            a.qinCount = sidx > 0 ? c->d_qcounts + size_t(sidx - 1) * c->maxBatch : nullptr;
+            a.qout = c->d_queue[sidx & 1];
+            a.qoutCount = c->d_qcounts + size_t(sidx) * c->maxBatch;
+            dim3 block(256);
+            const size_t winBytes = sizeof(float) * size_t(nChns) * a.mH * a.mW;
+            const bool tail = a.last && sidx > 0 && a.t0 >= 128 && winBytes <= 64 * 1024;
+            if (sidx == 0)
+            {
+                dim3 grid(blocksPerFrame * nF);
+                if (mode == 2)
+                {
+                    hipLaunchKernelGGL(k_cascade_first<2>, grid, block, 0, c->stream, a);
+                }
+                else if (mode == 1)
+                {
+                    hipLaunchKernelGGL(k_cascade_first<1>, grid, block, 0, c->stream, a);
+                }
+                else
+                {
+                    hipLaunchKernelGGL(k_cascade_first<0>, grid, block, 0, c->stream, a);
+                }
+            }
+            else if (tail)
+            {
+                // one wave per surviving window; enough waves per frame to fill the chip
+                dim3 grid(std::max(1, 8192 / nF) * nF);
+                if (mode == 2)
+                {
+                    hipLaunchKernelGGL(k_cascade_tail<2>, grid, dim3(64), winBytes, c->stream, a);
+                }
+                else if (mode == 1)
+                {
+                    hipLaunchKernelGGL(k_cascade_tail<1>, grid, dim3(64), winBytes, c->stream, a);
+                }
+                else
+                {
+                    hipLaunchKernelGGL(k_cascade_tail<0>, grid, dim3(64), winBytes, c->stream, a);
+                }
+            }
+            else
+            {
+                dim3 grid(qGrid[std::min(sidx - 1, 2)] * nF);
+                if (mode == 2)
+                {
+                    hipLaunchKernelGGL(k_cascade_queue<2>, grid, block, 0, c->stream, a);
+                }
+                else if (mode == 1)
+                {
+                    hipLaunchKernelGGL(k_cascade_queue<1>, grid, block, 0, c->stream, a);
+                }
+                else
+                {
+                    hipLaunchKernelGGL(k_cascade_queue<0>, grid, block, 0, c->stream, a);
+                }
+            }
+            LAUNCHCHK(c, "k_cascade stage");
         }
-        else if (p.treeDepth > 0)
-        {
-            hipLaunchKernelGGL(k_cascade<1>, grid, block, 0, c->stream, a);
-        }
-        else
-        {
-            hipLaunchKernelGGL(k_cascade<0>, grid, block, 0, c->stream, a);
-        }
-        LAUNCHCHK(c, "k_cascade");
     }
     // shift = (modelDsPad - modelDs)/2 - pad (ACF.cpp:275; cv::Size integer arithmetic)
     const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
@@ -1310,7 +1409,7 @@ int acf_hip_detect(acf_hip_ctx* c)
         return fail(c, ACF_HIP_E_INVALID, "detect: no pyramid (call acf_hip_pyramid)");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_cascLevels, c->d_blockLevel, c->blocksPerFrame, c->d_cidAll, c->d_nodes2, c->d_boxLevels, c->lastBatch);
+    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_cascLevels, c->d_blockLevel, c->blocksPerFrame, c->d_cidAll, c->d_nodes2, c->d_boxLevels, c->lastBatch, c->plan.nChns);
     if (rc)
     {
         return rc;
@@ -1854,7 +1953,7 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
     {
         return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
     }
-    hipLaunchKernelGGL(k_resample, dim3(cdiv(int64_t(d) * hb * wb, 256), 1, 1), dim3(256), 0, c->stream, (const float*)di, dout,
+    hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(dd), 1, 1), dim3(64, 4), 0, c->stream, (const float*)di, dout,
         (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft);
     LAUNCHCHK(c, "k_resample");
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1889,8 +1988,13 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     acf_hip_hit *sHits = c->d_hits, *sSorted = c->d_sorted;
     acf_hip_detection* sDets = c->d_dets;
     int32_t* sCounts = c->d_counts;
+    uint2* sQ0 = c->d_queue[0];
+    uint2* sQ1 = c->d_queue[1];
+    int32_t* sQc = c->d_qcounts;
+    const int sQcap = c->qcap, sMaxBatch = c->maxBatch;
     float *sThr = c->d_thrs, *sHs = c->d_hs;
     uint32_t* sChild = c->d_child;
+    uint32_t* sFids = c->d_fids;
     auto restore = [&]() {
         for (size_t i = mark; i < c->allocs.size(); i++)
         {
@@ -1902,9 +2006,15 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
         c->d_sorted = sSorted;
         c->d_dets = sDets;
         c->d_counts = sCounts;
+        c->d_queue[0] = sQ0;
+        c->d_queue[1] = sQ1;
+        c->d_qcounts = sQc;
+        c->qcap = sQcap;
+        c->maxBatch = sMaxBatch;
         c->d_thrs = sThr;
         c->d_hs = sHs;
         c->d_child = sChild;
+        c->d_fids = sFids;
     };
     CascLevel* dL = nullptr;
     int32_t* dBL = nullptr;
@@ -1937,6 +2047,10 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     }
     if (!rc)
     {
+        rc = devUpload(c, &c->d_fids, c->fids);
+    }
+    if (!rc)
+    {
         rc = devAlloc(c, &c->d_hits, size_t(cap));
     }
     if (!rc)
@@ -1953,6 +2067,20 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     }
     if (!rc)
     {
+        c->qcap = std::max(1, lv[0].nWinR * lv[0].nWinC);
+        c->maxBatch = 1;
+        rc = devAlloc(c, &c->d_queue[0], size_t(c->qcap));
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_queue[1], size_t(c->qcap));
+    }
+    if (!rc)
+    {
+        rc = devAlloc(c, &c->d_qcounts, 8);
+    }
+    if (!rc)
+    {
         rc = devAlloc(c, &dChn, size_t(nChns) * hP * wP);
     }
     if (!rc && hipMemcpy(dChn, chns, sizeof(float) * nChns * hP * wP, hipMemcpyHostToDevice) != hipSuccess)
@@ -1961,7 +2089,7 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     }
     if (!rc)
     {
-        rc = runCascade(c, dChn, 0, dL, dBL, bpf, dCid, dN2, dBox, 1);
+        rc = runCascade(c, dChn, 0, dL, dBL, bpf, dCid, dN2, dBox, 1, nChns);
     }
     int n = 0;
     if (!rc)

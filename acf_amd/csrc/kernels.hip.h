@@ -677,146 +677,280 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
 // reference's column buffer is recomputed for the few source rows an output
 // needs, in the reference's left-to-right association.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ float rs_C(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    const float* __restrict__ A, int xb, int row)
+// x-pass value C(row) for output column xb, with the column's taps already in
+// scalar registers (xb is wave-uniform).
+struct RsX
 {
-    if (row >= d.ha)
+    int xa, m;      // first source column, tap count (DOWN) / 1 or 2 (UP) / k (EXACT)
+    float w[4];     // first four weights (DOWN), {wt, 1-wt} (UP)
+    int wofs;       // float-table offset of this column's weights (DOWN, for taps >= 4)
+    bool border;    // UP: clamped column, copy
+};
+
+__device__ __forceinline__ float rs_C(int xmode, int ha, const RsX& X, const float* __restrict__ ft,
+    const float* __restrict__ A, int row)
+{
+    if (row >= ha)
     {
         return 0.f; // C[ha .. ha+3] = 0 (:133-137)
     }
-    if (d.xmode == RS_EXACT)
+    const float* A0 = A + int64_t(X.xa) * ha + row;
+    if (xmode == RS_EXACT)
     {
-        const float* A0 = A + int64_t(it[d.x_src + xb]) * d.ha + row;
-        float s = A0[0] + A0[d.ha];
-        if (d.xk > 2)
+        float s = A0[0] + A0[ha];
+        if (X.m > 2)
         {
-            s = s + A0[2 * int64_t(d.ha)];
+            s = s + A0[2 * int64_t(ha)];
         }
-        if (d.xk > 3)
+        if (X.m > 3)
         {
-            s = s + A0[3 * int64_t(d.ha)];
+            s = s + A0[3 * int64_t(ha)];
         }
         return s;
     }
-    if (d.xmode == RS_DOWN)
+    if (xmode == RS_DOWN)
     {
-        const int s0 = it[d.x_start + xb], s1 = it[d.x_start + xb + 1];
-        const float* A0 = A + int64_t(it[d.x_src + s0]) * d.ha + row;
-        float s = A0[0] * ft[d.x_wt + s0];
-        for (int j = 1; j < s1 - s0; j++)
+        float s = A0[0] * X.w[0];
+        if (X.m > 1)
         {
-            s = s + A0[int64_t(j) * d.ha] * ft[d.x_wt + s0 + j];
+            s = s + A0[ha] * X.w[1];
+        }
+        if (X.m > 2)
+        {
+            s = s + A0[2 * int64_t(ha)] * X.w[2];
+        }
+        if (X.m > 3)
+        {
+            s = s + A0[3 * int64_t(ha)] * X.w[3];
+        }
+        for (int j = 4; j < X.m; j++)
+        {
+            s = s + A0[int64_t(j) * ha] * ft[X.wofs + j];
         }
         return s;
     }
-    const float* A0 = A + int64_t(it[d.x_src + xb]) * d.ha + row;
-    const bool xBd = xb < d.xbd0 || xb >= d.wb - d.xbd1;
-    if (xBd)
+    if (X.border)
     {
         return A0[0];
     }
-    const float wt = ft[d.x_wt + xb];
-    const float wt1 = 1 - wt;
-    return A0[0] * wt + A0[d.ha] * wt1;
+    return A0[0] * X.w[0] + A0[ha] * X.w[1];
 }
+
+// Thread layout: blockDim = (64, 4).  A wave owns 64 consecutive output rows yb
+// and RS_XT consecutive output columns; the four waves of a block take adjacent
+// column groups.  xb, the plane z and the level are wave-uniform, so all table
+// reads for the x axis are scalar loads; each lane keeps its y taps in
+// registers across the RS_XT columns.
+#define RS_XT 8
 
 __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src, float* __restrict__ dst,
     const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft)
 {
-    const ResampleDesc d = descs[blockIdx.y];
-    const int64_t per = int64_t(d.hb) * d.wb;
-    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= per * d.nplanes)
+    const ResampleDesc& d = descs[blockIdx.y];
+    const int ha = d.ha, hb = d.hb, wb = d.wb;
+    const int ntY = (hb + 63) >> 6;
+    const int ntX = (wb + 4 * RS_XT - 1) / (4 * RS_XT);
+    int t = blockIdx.x;
+    const int ytile = t % ntY;
+    t /= ntY;
+    const int xtile = t % ntX;
+    const int z = t / ntX;
+    if (z >= d.nplanes)
     {
         return;
     }
-    const int z = int(e / per);
-    const int rem = int(e - int64_t(z) * per);
-    const int xb = rem / d.hb, yb = rem - xb * d.hb;
-    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
-    const float r = d.r[ty];
-    const float* A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * d.ha * d.wa;
-    float v;
-    if (d.ymode == RS_EXACT)
+    const int yb = ytile * 64 + threadIdx.x;
+    const int xb0 = __builtin_amdgcn_readfirstlane((xtile * 4 + (int)threadIdx.y) * RS_XT);
+    if (xb0 >= wb)
     {
-        const int k = d.yk;
-        float s = rs_C(d, it, ft, A, xb, k * yb) + rs_C(d, it, ft, A, xb, k * yb + 1);
-        if (k > 2)
-        {
-            s = s + rs_C(d, it, ft, A, xb, k * yb + 2);
-        }
-        if (k > 3)
-        {
-            s = s + rs_C(d, it, ft, A, xb, k * yb + 3);
-        }
-        v = s * d.rk[ty];
+        return;
     }
-    else if (d.ymode == RS_DOWN)
+    const bool act = yb < hb;
+    const int ybc = act ? yb : hb - 1;
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty], rk = d.rk[ty];
+    const int xmode = d.xmode, ymode = d.ymode;
+    const float* A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * d.wa;
+    float* B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+
+    // ---- this lane's y taps
+    int ya = 0, ny = 0, q0 = 0, q1 = 0;
+    float wy[4] = { 0.f, 0.f, 0.f, 0.f };
+    const bool ySlow = (ymode == RS_DOWN) && d.ybd0 > 4;
+    if (ymode == RS_EXACT)
     {
-        const int s0 = it[d.y_start + yb], s1 = it[d.y_start + yb + 1];
-        if (d.ybd0 <= 4)
+        ya = d.yk * ybc;
+        ny = d.yk;
+    }
+    else if (ymode == RS_DOWN)
+    {
+        q0 = it[d.y_start + ybc];
+        q1 = it[d.y_start + ybc + 1];
+        ya = it[d.y_src + q0];
+        ny = d.ybd0;
+        if (!ySlow)
         {
-            // U(0)+U(1)(+U(2)(+U(3))) with exactly ybd0 terms, rows ya+o (:324-348)
-            const int ya = it[d.y_src + s0];
-            v = rs_C(d, it, ft, A, xb, ya) * (ft[d.y_wt + s0] * r);
-            for (int o = 1; o < d.ybd0; o++)
+#pragma unroll
+            for (int o = 0; o < 4; o++)
             {
-                v = v + rs_C(d, it, ft, A, xb, ya + o) * (ft[d.y_wt + s0 + o] * r);
-            }
-        }
-        else
-        {
-            // B0 zeroed then += over this output's entries in order (:349-356)
-            v = 0.f;
-            for (int q = s0; q < s1; q++)
-            {
-                v = v + rs_C(d, it, ft, A, xb, it[d.y_src + q]) * (ft[d.y_wt + q] * r);
+                if (o < ny)
+                {
+                    wy[o] = ft[d.y_wt + q0 + o] * r; // ywts[y] *= r (:158-161)
+                }
             }
         }
     }
     else
     {
-        const int ya = it[d.y_src + yb];
-        const float wy = ft[d.y_wt + yb] * r;
-        if (yb < d.ybd0 || yb >= d.hb - d.ybd1)
+        ya = it[d.y_src + ybc];
+        wy[0] = ft[d.y_wt + ybc] * r;
+        wy[1] = r - wy[0];
+        ny = (ybc < d.ybd0 || ybc >= hb - d.ybd1) ? 1 : 2;
+    }
+
+    for (int xi = 0; xi < RS_XT; xi++)
+    {
+        const int xb = xb0 + xi;
+        if (xb >= wb)
         {
-            v = rs_C(d, it, ft, A, xb, ya) * wy;
+            break;
+        }
+        RsX X;
+        X.wofs = 0;
+        X.border = false;
+        X.w[0] = X.w[1] = X.w[2] = X.w[3] = 0.f;
+        if (xmode == RS_EXACT)
+        {
+            X.xa = it[d.x_src + xb];
+            X.m = d.xk;
+        }
+        else if (xmode == RS_DOWN)
+        {
+            const int s0 = it[d.x_start + xb], s1 = it[d.x_start + xb + 1];
+            X.xa = it[d.x_src + s0];
+            X.m = s1 - s0;
+            X.wofs = d.x_wt + s0;
+            X.w[0] = ft[X.wofs];
+            if (X.m > 1)
+            {
+                X.w[1] = ft[X.wofs + 1];
+            }
+            if (X.m > 2)
+            {
+                X.w[2] = ft[X.wofs + 2];
+            }
+            if (X.m > 3)
+            {
+                X.w[3] = ft[X.wofs + 3];
+            }
         }
         else
         {
-            v = rs_C(d, it, ft, A, xb, ya) * wy + rs_C(d, it, ft, A, xb, ya + 1) * (r - wy);
+            X.xa = it[d.x_src + xb];
+            X.m = 2;
+            X.border = xb < d.xbd0 || xb >= wb - d.xbd1;
+            X.w[0] = ft[d.x_wt + xb];
+            X.w[1] = 1 - X.w[0];
+        }
+        float v;
+        if (ymode == RS_EXACT)
+        {
+            float s = rs_C(xmode, ha, X, ft, A, ya) + rs_C(xmode, ha, X, ft, A, ya + 1);
+            if (ny > 2)
+            {
+                s = s + rs_C(xmode, ha, X, ft, A, ya + 2);
+            }
+            if (ny > 3)
+            {
+                s = s + rs_C(xmode, ha, X, ft, A, ya + 3);
+            }
+            v = s * rk;
+        }
+        else if (ymode == RS_DOWN)
+        {
+            if (!ySlow)
+            {
+                // U(0)+U(1)(+U(2)(+U(3))) with exactly ybd0 terms, rows ya+o (:324-348)
+                v = rs_C(xmode, ha, X, ft, A, ya) * wy[0];
+                v = v + rs_C(xmode, ha, X, ft, A, ya + 1) * wy[1];
+                if (ny > 2)
+                {
+                    v = v + rs_C(xmode, ha, X, ft, A, ya + 2) * wy[2];
+                }
+                if (ny > 3)
+                {
+                    v = v + rs_C(xmode, ha, X, ft, A, ya + 3) * wy[3];
+                }
+            }
+            else
+            {
+                // B0 zeroed then += over this output's entries in order (:349-356)
+                v = 0.f;
+                for (int q = q0; q < q1; q++)
+                {
+                    v = v + rs_C(xmode, ha, X, ft, A, it[d.y_src + q]) * (ft[d.y_wt + q] * r);
+                }
+            }
+        }
+        else
+        {
+            v = rs_C(xmode, ha, X, ft, A, ya) * wy[0];
+            if (ny > 1)
+            {
+                v = v + rs_C(xmode, ha, X, ft, A, ya + 1) * wy[1];
+            }
+        }
+        if (act)
+        {
+            B[int64_t(xb) * hb + yb] = v;
         }
     }
-    dst[int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * per + rem] = v;
+}
+
+// grid.x needed for one descriptor
+static inline int resampleBlocks(const ResampleDesc& d)
+{
+    return ((d.hb + 63) / 64) * ((d.wb + 4 * RS_XT - 1) / (4 * RS_XT)) * d.nplanes;
 }
 
 // ------------------------------------------------------------------------
 // The cascade: ParallelDetectionBody::operator()/evaluate
 // (toolbox/acfDetect1.cpp:84-138) for every window of every level of every
-// frame in one launch.  One lane per window, lanes consecutive along r (the
-// contiguous image-y axis) so each feature fetch of a wave is a contiguous
-// segment of the level's channel buffer.
+// frame.  One lane per window; in the first stage lanes are consecutive along
+// r (the contiguous image-y axis), so each feature fetch of a wave is one
+// contiguous segment of the level's channel buffer.
 //
-// Depth-2 fast path: the three internal nodes' channel offsets and
-// thresholds and the four leaf values of tree t are wave-uniform, so they are
-// fetched with scalar loads from a per-level packed table; the only vector
-// memory traffic is three feature fetches per tree.  A wave leaves the tree
-// loop as soon as a ballot shows that none of its windows is still alive
-// (early cascade rejection); hits are compacted with a ballot prefix sum and
-// one atomic per wave.
+// Staging.  A window's score is a running sum that stops at the first
+// h <= cascThr; on the headline workload 76 % of the windows are gone after
+// 16 trees and 99.5 % after 64, but a wave lives as long as its longest lane
+// (131 trees on average).  The tree range is therefore cut into stages
+// [0,16) [16,32) [32,128) [128,nTrees): after each stage the surviving lanes
+// are compacted (wave ballot + prefix count, one atomic per wave) into a
+// per-frame queue of {level, window, h}, and the next stage runs dense waves
+// over that queue.  Scores are unaffected: each window still adds the same
+// leaves in the same order.
+//
+// Depth-2 fast path.  A node's feature id is kept as packed (z, c, r); its
+// channel offset z*area + c*hP + r is rebuilt from the lane's level geometry,
+// so ONE level-independent node table serves every level and every stage, and
+// tree t's three nodes / four leaves are wave-uniform scalar loads.  Feature
+// addresses do not depend on h, so the loads of CG consecutive trees (three
+// per tree: root and both children) are issued together before the
+// comparisons are resolved in order — the dependent-load chain per tree
+// becomes CG*3 independent loads in flight.
 // ------------------------------------------------------------------------
 struct CascLevel
 {
     int32_t hP, wP, nWinR, nWinC;
-    int32_t firstBlock; // first block index of this level inside one frame's grid
+    int32_t firstBlock; // first block index of this level inside one frame's stage-0 grid
     int32_t nWin;
     int64_t off;        // level offset in the fused pyramid
-    int64_t nodeOff;    // offset (in units of CascNode2 / uint32) of this level's node table
+    int64_t nodeOff;    // generic path: offset of this level's cid table
 };
 
 struct __attribute__((aligned(16))) CascNode2
 {
-    uint32_t cid[4]; // cid[3] unused
+    uint32_t zcr[4]; // (z << 24) | (c << 12) | r for nodes 0,1,2; [3] unused
     float thr[4];    // thr[3] unused
     float hs[4];     // leaves 3..6
 };
@@ -826,55 +960,106 @@ struct CascArgs
     const float* pyr;
     int64_t pyr_fs;
     const CascLevel* levels;
-    const int32_t* blockLevel; // block -> level
-    int32_t blocksPerFrame;
+    const int32_t* blockLevel; // stage-0 block -> level
+    int32_t blocksPerFrame, nFrames;
     int32_t nTrees, nTreeNodes, treeDepth;
     int32_t stride, shrink;
+    int32_t mH, mW, nChns;   // model window in cells (modelDsPad / shrink), channels
     float cascThr;
     // generic path tables
     const uint32_t* cidAll;  // [level][nTrees*nTreeNodes]
+    const uint32_t* fids;    // [nTrees*nTreeNodes] raw feature ids (tail stage)
     const float* thrs;       // [nTrees*nTreeNodes]
     const float* hs;
     const uint32_t* child;
-    const CascNode2* nodes2; // depth-2 packed tables
+    const CascNode2* nodes2; // depth-2 packed table [nTrees]
+    // stage
+    int32_t t0, t1;          // tree range of this stage
+    int32_t last;            // t1 == nTrees: survivors are hits
+    const uint2* qin;        // [frame][qcap] {(level << 24) | window, h bits}
+    const int32_t* qinCount; // [frame]
+    uint2* qout;
+    int32_t* qoutCount;
+    int32_t qcap;
     // output
     acf_hip_hit* hits; // [frame][maxHits]
     int32_t* counts;   // [frame]
     int32_t maxHits;
 };
 
+#define CASC_CG 4
+
 template <int MODE> // 2: packed depth-2 path; 1: generic fixed depth; 0: child walk
-__global__ void __launch_bounds__(256) k_cascade(CascArgs a)
+__device__ __forceinline__ void casc_eval(const CascArgs& a, const float* __restrict__ chn, int hP, int area, int64_t nodeOff, float& h, bool& alive)
 {
-    const int frame = blockIdx.y;
-    const int lvl = a.blockLevel[blockIdx.x];
-    const CascLevel L = a.levels[lvl];
-    const int n = (blockIdx.x - L.firstBlock) * blockDim.x + threadIdx.x;
-    bool alive = n < L.nWin;
-    const int c = alive ? n / L.nWinR : 0;
-    const int r = alive ? n - c * L.nWinR : 0;
-    const float* chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + (r * a.stride / a.shrink) + int64_t(c * a.stride / a.shrink) * L.hP;
     const float thrC = a.cascThr;
-    float h = 0.f;
     if (MODE == 2)
     {
-        const CascNode2* nodes = a.nodes2 + L.nodeOff;
-        for (int t = 0; t < a.nTrees; t++)
+        const CascNode2* __restrict__ nodes = a.nodes2;
+        int t = a.t0;
+        for (; t + CASC_CG <= a.t1; t += CASC_CG)
         {
             if (!__any(alive))
             {
-                break;
+                return;
             }
-            const CascNode2 nd = nodes[t]; // uniform address: scalar loads
+            CascNode2 nd[CASC_CG];
+#pragma unroll
+            for (int g = 0; g < CASC_CG; g++)
+            {
+                nd[g] = nodes[t + g]; // uniform address: scalar loads
+            }
+            // Issue all CG*3 feature loads first (addresses do not depend on h), then
+            // resolve the trees in order with selects only: one basic block, so the
+            // loads stay batched instead of being sunk behind per-tree branches.
+            float f0[CASC_CG], f1[CASC_CG], f2[CASC_CG];
+#pragma unroll
+            for (int g = 0; g < CASC_CG; g++)
+            {
+                f0[g] = f1[g] = f2[g] = 0.f;
+            }
             if (alive)
             {
-                const float f0 = chn[nd.cid[0]];
-                const bool lt0 = f0 < nd.thr[0];
-                const float f1 = chn[lt0 ? nd.cid[1] : nd.cid[2]];
-                const float th1 = lt0 ? nd.thr[1] : nd.thr[2];
-                const bool lt1 = f1 < th1;
+#pragma unroll
+                for (int g = 0; g < CASC_CG; g++)
+                {
+                    const uint32_t a0 = nd[g].zcr[0], a1 = nd[g].zcr[1], a2 = nd[g].zcr[2];
+                    f0[g] = chn[(a0 >> 24) * area + ((a0 >> 12) & 0xfff) * hP + (a0 & 0xfff)];
+                    f1[g] = chn[(a1 >> 24) * area + ((a1 >> 12) & 0xfff) * hP + (a1 & 0xfff)];
+                    f2[g] = chn[(a2 >> 24) * area + ((a2 >> 12) & 0xfff) * hP + (a2 & 0xfff)];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < CASC_CG; g++)
+            {
+                const bool lt0 = f0[g] < nd[g].thr[0];
+                const float fc = lt0 ? f1[g] : f2[g];
+                const float th1 = lt0 ? nd[g].thr[1] : nd[g].thr[2];
+                const bool lt1 = fc < th1;
                 // k after two steps: lt0 ? (lt1 ? 3 : 4) : (lt1 ? 5 : 6)
-                const float hv = lt0 ? (lt1 ? nd.hs[0] : nd.hs[1]) : (lt1 ? nd.hs[2] : nd.hs[3]);
+                const float hv = lt0 ? (lt1 ? nd[g].hs[0] : nd[g].hs[1]) : (lt1 ? nd[g].hs[2] : nd[g].hs[3]);
+                const float hn = h + hv;
+                h = alive ? hn : h;          // a rejected window keeps the score it was rejected with
+                alive = alive && (hn > thrC);
+            }
+        }
+        for (; t < a.t1; t++)
+        {
+            if (!__any(alive))
+            {
+                return;
+            }
+            const CascNode2 n1 = nodes[t];
+            if (alive)
+            {
+                const uint32_t a0 = n1.zcr[0], a1 = n1.zcr[1], a2 = n1.zcr[2];
+                const float g0 = chn[(a0 >> 24) * area + ((a0 >> 12) & 0xfff) * hP + (a0 & 0xfff)];
+                const bool lt0 = g0 < n1.thr[0];
+                const uint32_t ac = lt0 ? a1 : a2;
+                const float fc = chn[(ac >> 24) * area + ((ac >> 12) & 0xfff) * hP + (ac & 0xfff)];
+                const float th1 = lt0 ? n1.thr[1] : n1.thr[2];
+                const bool lt1 = fc < th1;
+                const float hv = lt0 ? (lt1 ? n1.hs[0] : n1.hs[1]) : (lt1 ? n1.hs[2] : n1.hs[3]);
                 h += hv;
                 alive = h > thrC;
             }
@@ -882,13 +1067,13 @@ __global__ void __launch_bounds__(256) k_cascade(CascArgs a)
     }
     else if (MODE == 1)
     {
-        const uint32_t* cid = a.cidAll + L.nodeOff;
+        const uint32_t* cid = a.cidAll + nodeOff;
         const int D = a.treeDepth;
-        for (int t = 0; t < a.nTrees; t++)
+        for (int t = a.t0; t < a.t1; t++)
         {
             if (!__any(alive))
             {
-                break;
+                return;
             }
             if (alive)
             {
@@ -908,12 +1093,12 @@ __global__ void __launch_bounds__(256) k_cascade(CascArgs a)
     }
     else
     {
-        const uint32_t* cid = a.cidAll + L.nodeOff;
-        for (int t = 0; t < a.nTrees; t++)
+        const uint32_t* cid = a.cidAll + nodeOff;
+        for (int t = a.t0; t < a.t1; t++)
         {
             if (!__any(alive))
             {
-                break;
+                return;
             }
             if (alive)
             {
@@ -930,21 +1115,193 @@ __global__ void __launch_bounds__(256) k_cascade(CascArgs a)
             }
         }
     }
-    // hit compaction: ballot + prefix count, one atomic per wave
+}
+
+// Survivors of a stage: hits if this was the last stage, else queue entries.
+// Compaction is two-level: a ballot prefix inside each wave, the four wave
+// totals combined through LDS, ONE atomic per workgroup on the frame's counter
+// (a counter word saturates near 88 atomics/us, so per-wave atomics from ten
+// thousand waves of one frame serialise the whole stage).  Must be reached by
+// every thread of the block.
+__device__ __forceinline__ void casc_emit(const CascArgs& a, int frame, bool alive, int lvl, int n, int nWinR, float h)
+{
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
     const unsigned long long mask = __ballot(alive);
-    if (mask)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
     {
-        const int lane = threadIdx.x & 63;
-        const int cnt = __popcll(mask);
-        int base = 0;
-        if (lane == (__ffsll((long long)mask) - 1))
+        s_cnt[wv] = __popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd((a.last ? a.counts : a.qoutCount) + frame, tot) : 0;
+    }
+    __syncthreads();
+    if (alive)
+    {
+        int base = s_base;
+        for (int q = 0; q < wv; q++)
         {
-            base = atomicAdd(a.counts + frame, cnt);
+            base += s_cnt[q];
         }
-        base = __shfl(base, __ffsll((long long)mask) - 1);
-        if (alive)
+        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (a.last)
         {
-            const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = n / nWinR;
+                hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+        else if (idx < a.qcap)
+        {
+            a.qout[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
+        }
+    }
+    __syncthreads(); // s_cnt / s_base are reused by the next grid-stride iteration
+}
+
+// Stage 0: windows enumerated in (level, c, r) order, level uniform per block.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_cascade_first(CascArgs a)
+{
+    // 1-D grid, frame index fastest: consecutive hardware blocks belong to
+    // different frames, so (i) concurrent workgroups spread their queue atomics
+    // over nFrames counter words and (ii) with block b on XCD b % 8 each XCD works
+    // on the same window blocks of 1/8 of the frames, whose overlapping 20x20xnC
+    // footprints then share that XCD's L2.
+    const int frame = blockIdx.x % a.nFrames;
+    const int bx = blockIdx.x / a.nFrames;
+    const int lvl = a.blockLevel[bx];
+    const CascLevel L = a.levels[lvl];
+    const int n = (bx - L.firstBlock) * blockDim.x + threadIdx.x;
+    bool alive = n < L.nWin;
+    const int c = alive ? n / L.nWinR : 0;
+    const int r = alive ? n - c * L.nWinR : 0;
+    const float* chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + (r * a.stride / a.shrink) + int64_t(c * a.stride / a.shrink) * L.hP;
+    float h = 0.f;
+    casc_eval<MODE>(a, chn, L.hP, L.hP * L.wP, L.nodeOff, h, alive);
+    casc_emit(a, frame, alive, lvl, n, L.nWinR, h);
+}
+
+// Later stages: dense waves over the previous stage's survivor queue.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_cascade_queue(CascArgs a)
+{
+    const int frame = blockIdx.x % a.nFrames;
+    const int bq = blockIdx.x / a.nFrames, nbq = gridDim.x / a.nFrames;
+    const int cnt = min(a.qinCount[frame], a.qcap);
+    for (int base = bq * blockDim.x; base < cnt; base += nbq * blockDim.x)
+    {
+        const int i = base + threadIdx.x;
+        bool alive = i < cnt;
+        const uint2 e = alive ? a.qin[int64_t(frame) * a.qcap + i] : make_uint2(0u, 0u);
+        const int lvl = int(e.x >> 24);
+        const int n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR;
+        const int r = n - c * L.nWinR;
+        const float* chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + (r * a.stride / a.shrink) + int64_t(c * a.stride / a.shrink) * L.hP;
+        float h = __uint_as_float(e.y);
+        casc_eval<MODE>(a, chn, L.hP, L.hP * L.wP, L.nodeOff, h, alive);
+        casc_emit(a, frame, alive, lvl, n, L.nWinR, h);
+    }
+}
+
+// Tail stage [t0, nTrees): the few windows that are still alive (0.14 % on the
+// headline workload) each need thousands of feature reads scattered over their
+// own modelDsPad footprint.  With one lane per window every read is a separate
+// cache line and nothing is reused, which makes the stage HBM-bound on 4-byte
+// gathers.  Here one WAVE owns one window instead: the window's footprint
+// (nChns*mW*mH floats = 16 KB for an 80x80 model — exactly the cids[] index
+// space, acfDetect1.cpp:390-406, so a feature id addresses it directly) is
+// copied to LDS once, then the 64 lanes evaluate 64 consecutive trees at a time
+// from LDS and the leaf values are added to the running score strictly in tree
+// order (a wave-uniform loop over lanes), stopping at the first h <= cascThr
+// exactly like ParallelDetectionBody::evaluate (:123-138).
+template <int MODE>
+__global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
+{
+    extern __shared__ float win[]; // nChns * mW * mH
+    const int frame = blockIdx.x % a.nFrames;
+    const int bq = blockIdx.x / a.nFrames, nbq = gridDim.x / a.nFrames;
+    const int cnt = min(a.qinCount[frame], a.qcap);
+    const int lane = threadIdx.x;
+    const int cellsW = a.mW * a.mH, nFeat = a.nChns * cellsW;
+    const float thrC = a.cascThr;
+    for (int i = bq; i < cnt; i += nbq)
+    {
+        const uint2 e = a.qin[int64_t(frame) * a.qcap + i];
+        const int lvl = int(e.x >> 24);
+        const int n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR;
+        const int r = n - c * L.nWinR;
+        const float* chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + (r * a.stride / a.shrink) + int64_t(c * a.stride / a.shrink) * L.hP;
+        const int area = L.hP * L.wP;
+        __syncthreads();
+        for (int f = lane; f < nFeat; f += 64)
+        {
+            const int z = f / cellsW, rem = f - z * cellsW;
+            const int cc = rem / a.mH, rr = rem - cc * a.mH;
+            win[f] = chn[z * area + cc * L.hP + rr];
+        }
+        __syncthreads();
+        float h = __uint_as_float(e.y);
+        bool alive = true;
+        for (int tb = a.t0; tb < a.t1 && alive; tb += 64)
+        {
+            const int t = tb + lane;
+            float hv = 0.f;
+            if (t < a.t1)
+            {
+                const uint32_t offset = uint32_t(t) * uint32_t(a.nTreeNodes);
+                uint32_t k = offset;
+                if (MODE != 0)
+                {
+                    uint32_t k0 = 0;
+                    const int D = (MODE == 2) ? 2 : a.treeDepth;
+                    for (int q = 0; q < D; q++)
+                    {
+                        const float ftr = win[a.fids[k]];
+                        k = (ftr < a.thrs[k]) ? 1 : 2;
+                        k0 = k += k0 * 2;
+                        k += offset;
+                    }
+                }
+                else
+                {
+                    uint32_t k0 = offset;
+                    while (a.child[k])
+                    {
+                        const float ftr = win[a.fids[k]];
+                        k = (ftr < a.thrs[k]) ? 1 : 0;
+                        k0 = k = a.child[k0] - k + offset;
+                    }
+                }
+                hv = a.hs[k];
+            }
+            const int nt = min(64, a.t1 - tb);
+            for (int q = 0; q < nt; q++)
+            {
+                h += __shfl(hv, q); // wave-uniform, tree order
+                if (!(h > thrC))
+                {
+                    alive = false;
+                    break;
+                }
+            }
+        }
+        if (alive && lane == 0)
+        {
+            const int idx = atomicAdd(a.counts + frame, 1);
             if (idx < a.maxHits)
             {
                 acf_hip_hit hit;

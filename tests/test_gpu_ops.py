@@ -159,12 +159,14 @@ def test_rgb2luv(dev, oracle, h, w):
 
 
 @pytest.mark.parametrize("depth", [2, 1, 3, 0])
-def test_acf_detect1(dev, oracle, depth):
-    """The cascade on a random channel buffer: hits identical in number, order, position and score bits."""
+@pytest.mark.parametrize("nTrees", [128, 300, 20])
+def test_acf_detect1(dev, oracle, depth, nTrees):
+    """The cascade on a random channel buffer: hits identical in number, order, position and score bits.
+    nTrees 20 / 128 / 300 end in the first / a queue / the LDS tail stage of the staged cascade."""
     nC, wP, hP = 10, 60, 44
     chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
     kw = dict(treeDepth=depth)
-    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=128, cascThr=-1.0, **kw)
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=nTrees, cascThr=-1.0 if nTrees < 300 else -1.6, **kw)
     # thresholds inside the data range so both branches are taken; leaf values with a
     # slight negative drift so that part of the windows is rejected at every depth
     m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
