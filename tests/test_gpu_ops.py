@@ -166,7 +166,7 @@ def test_acf_detect1(dev, oracle, depth, nTrees):
     nC, wP, hP = 10, 60, 44
     chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
     kw = dict(treeDepth=depth)
-    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=nTrees, cascThr=-1.0 if nTrees < 300 else -1.6, **kw)
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=nTrees, cascThr=-1.0 if nTrees < 300 else -4.0, **kw)
     # thresholds inside the data range so both branches are taken; leaf values with a
     # slight negative drift so that part of the windows is rejected at every depth
     m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
