@@ -1,0 +1,581 @@
+#include "HipDetector.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace acf
+{
+
+static int colorSpaceFlag(const std::string& s)
+{
+    // rgbConvert.cpp:106-128
+    if (s == "gray") return ACF_HIP_CS_GRAY;
+    if (s == "rgb") return ACF_HIP_CS_RGB;
+    if (s == "luv") return ACF_HIP_CS_LUV;
+    if (s == "hsv") return ACF_HIP_CS_HSV;
+    if (s == "orig") return ACF_HIP_CS_ORIG;
+    throw Exception(ACF_HIP_E_INVALID, "unknown colorSpace: " + s);
+}
+
+HipDetector::HipDetector(const Options& o, const Classifier& c, int device)
+{
+    setModel(o, c, device);
+}
+
+HipDetector::~HipDetector()
+{
+    if (m_ctx && m_api)
+    {
+        m_api->acf_hip_destroy(m_ctx);
+    }
+}
+
+void HipDetector::check(int rc, const char* what) const
+{
+    if (rc != ACF_HIP_OK)
+    {
+        std::string msg = std::string(what) + ": ";
+        msg += (m_ctx && m_api) ? m_api->acf_hip_last_error(m_ctx) : "no context";
+        throw Exception(rc, msg);
+    }
+}
+
+void HipDetector::setModel(const Options& o, const Classifier& c, int device)
+{
+    m_good = false;
+    opts = o;
+    clf = c;
+    const size_t n = size_t(c.nTrees) * c.nTreeNodes;
+    if (c.nTrees <= 0 || c.nTreeNodes <= 0 || c.fids.size() != n || c.thrs.size() != n || c.hs.size() != n ||
+        (c.treeDepth == 0 && c.child.size() != n))
+    {
+        return; // like a failed deserialize: !good() (ACF.cpp:38-46)
+    }
+    m_api = &hip::load();
+    if (!m_ctx)
+    {
+        if (m_api->acf_hip_create(device, nullptr, &m_ctx) != ACF_HIP_OK)
+        {
+            m_ctx = nullptr;
+            return;
+        }
+    }
+    m_dirty = true;
+    m_planH = m_planW = 0;
+    m_good = true;
+}
+
+void HipDetector::fillParams(acf_hip_params& p) const
+{
+    p = acf_hip_params{};
+    p.nTrees = clf.nTrees;
+    p.nTreeNodes = clf.nTreeNodes;
+    p.treeDepth = clf.treeDepth;
+    p.fids = clf.fids.data();
+    p.thrs = clf.thrs.data();
+    p.hs = clf.hs.data();
+    p.child = clf.child.empty() ? nullptr : clf.child.data();
+    // cv::Size {width = image-height axis, height = image-width axis} -> upright h / w
+    p.modelDs_h = opts.modelDs.width;
+    p.modelDs_w = opts.modelDs.height;
+    p.modelDsPad_h = opts.modelDsPad.width;
+    p.modelDsPad_w = opts.modelDsPad.height;
+    p.stride = opts.stride;
+    p.cascThr = opts.cascThr;
+    const auto& py = opts.pPyramid;
+    p.nPerOct = py.nPerOct;
+    p.nOctUp = py.nOctUp;
+    p.nApprox = py.nApprox;
+    p.nLambdas = int(std::min<size_t>(py.lambdas.size(), 3));
+    for (int i = 0; i < p.nLambdas; i++)
+    {
+        p.lambdas[i] = py.lambdas[i];
+    }
+    p.pad_h = py.pad.width;
+    p.pad_w = py.pad.height;
+    p.minDs_h = py.minDs.width;
+    p.minDs_w = py.minDs.height;
+    p.smooth = py.smooth;
+    const auto& ch = py.pChns;
+    p.shrink = ch.shrink;
+    p.colorEnabled = ch.pColor.enabled;
+    p.colorSmooth = ch.pColor.smooth;
+    p.colorSpace = colorSpaceFlag(ch.pColor.colorSpace);
+    p.gradMagEnabled = ch.pGradMag.enabled;
+    p.colorChn = ch.pGradMag.colorChn;
+    p.normRad = ch.pGradMag.normRad;
+    p.normConst = ch.pGradMag.normConst;
+    p.full = ch.pGradMag.full;
+    p.gradHistEnabled = ch.pGradHist.enabled;
+    p.binSize = ch.pGradHist.binSize;
+    p.nOrients = ch.pGradHist.nOrients;
+    p.softBin = ch.pGradHist.softBin;
+    p.isLuv = m_isLuv ? 1 : 0;
+}
+
+int HipDetector::acfModify(const Modify& params)
+{
+    // acfModify.cpp:83-152.  The reference merges each override with
+    // Field::merge, which only fills fields the model does NOT already have
+    // (ACFField.h:54-60); a loaded model has them all, and this flattened
+    // Options has them by construction, so — exactly as in the reference for a
+    // complete model — the effects are the stride rounding (:139) and the
+    // calibration offset on every hs entry (:143).
+    const double shrink = opts.pPyramid.pChns.shrink;
+    opts.stride = int(std::max(1.0, std::round(double(opts.stride) / shrink)) * shrink);
+    if (params.has_cascCal)
+    {
+        for (auto& h : clf.hs)
+        {
+            h += float(params.cascCal);
+        }
+        opts.cascCal = params.cascCal;
+    }
+    m_dirty = true;
+    return 0;
+}
+
+void HipDetector::ensurePlan(int imgH, int imgW, int d, int batch)
+{
+    if (!m_good)
+    {
+        throw Exception(ACF_HIP_E_NOMODEL, "HipDetector: no model");
+    }
+    if (m_dirty)
+    {
+        acf_hip_params p;
+        fillParams(p);
+        check(m_api->acf_hip_set_model(m_ctx, &p), "acf_hip_set_model");
+        m_dirty = false;
+        m_planH = 0;
+    }
+    if (imgH != m_planH || imgW != m_planW || d != m_planD || batch > m_planBatch)
+    {
+        check(m_api->acf_hip_plan(m_ctx, imgH, imgW, d, batch, 1 << 16), "acf_hip_plan");
+        m_planH = imgH;
+        m_planW = imgW;
+        m_planD = d;
+        m_planBatch = batch;
+        int n = 0;
+        check(m_api->acf_hip_num_levels(m_ctx, &n, &m_nChns), "acf_hip_num_levels");
+        m_levels.resize(size_t(n));
+        check(m_api->acf_hip_get_levels(m_ctx, m_levels.data(), n), "acf_hip_get_levels");
+    }
+}
+
+void HipDetector::prune(RectVec& objects, RealVec& scores) const
+{
+    // ObjectDetector.cpp:28-44
+    if (objects.size() > 1)
+    {
+        int cutoff = 1;
+        for (size_t i = 1; i < std::min(m_maxDetectionCount, objects.size()); i++)
+        {
+            cutoff = int(i) + 1;
+            if (scores[i] < (scores[0] * m_detectionScorePruneRatio))
+            {
+                break;
+            }
+        }
+        objects.erase(objects.begin() + cutoff, objects.end());
+        scores.erase(scores.begin() + cutoff, scores.end());
+    }
+}
+
+int HipDetector::bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, DetectionVec& bbs)
+{
+    // bbNms.cpp:229-304 + nmsMax :111-192.  ms / cover are stubs in the reference (:100-108): pass-through.
+    bbs = bbsIn;
+    if (bbs.empty() || pNms.type == "none" || pNms.type == "ms" || pNms.type == "cover")
+    {
+        return 0;
+    }
+    if (pNms.type != "max" && pNms.type != "maxg")
+    {
+        throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown type " + pNms.type);
+    }
+    int ovrDnm;
+    if (pNms.ovrDnm == "union") ovrDnm = 1;
+    else if (pNms.ovrDnm == "min") ovrDnm = 0;
+    else throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown ovrDnm " + pNms.ovrDnm);
+    const double thr = pNms.thr;
+    bbs.erase(std::remove_if(bbs.begin(), bbs.end(), [=](const Detection& b) { return b.score < thr; }), bbs.end());
+    if (bbs.empty())
+    {
+        return 0;
+    }
+    const bool greedy = pNms.type == "maxg";
+    const size_t n = bbs.size();
+    std::vector<size_t> ord(n);
+    std::iota(ord.begin(), ord.end(), size_t(0));
+    // The reference uses std::sort (util/ordered.h:27), whose order among equal scores is unspecified;
+    // a stable sort is one of its valid outcomes and is deterministic.
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return bbs[a].score > bbs[b].score; });
+    struct R { int as, xs, xe, ys, ye, kp; };
+    std::vector<R> c(n);
+    DetectionVec sorted(n);
+    for (size_t i = 0; i < n; i++)
+    {
+        sorted[i] = bbs[ord[i]];
+        const Rect& r = sorted[i].roi;
+        c[i] = R{ r.width * r.height, r.x, r.x + r.width, r.y, r.y + r.height, 1 };
+    }
+    for (size_t i = 0; i < n; i++)
+    {
+        if (greedy && !c[i].kp)
+        {
+            continue;
+        }
+        for (size_t j = i + 1; j < n; j++)
+        {
+            if (!c[j].kp)
+            {
+                continue;
+            }
+            const int iw = std::min(c[i].xe, c[j].xe) - std::max(c[i].xs, c[j].xs);
+            if (iw <= 0)
+            {
+                continue;
+            }
+            const int ih = std::min(c[i].ye, c[j].ye) - std::max(c[i].ys, c[j].ys);
+            if (ih <= 0)
+            {
+                continue;
+            }
+            double o = double(iw * ih);
+            const double u = ovrDnm ? (c[i].as + c[j].as - o) : std::min(c[i].as, c[j].as);
+            o /= u;
+            if (o > pNms.overlap)
+            {
+                c[j].kp = 0;
+            }
+        }
+    }
+    bbs.clear();
+    for (size_t i = 0; i < n; i++)
+    {
+        if (c[i].kp)
+        {
+            bbs.push_back(sorted[i]);
+        }
+    }
+    return 0;
+}
+
+void HipDetector::fetch(int frame, RectVec& objects, RealVec* scores)
+{
+    int n = 0;
+    check(m_api->acf_hip_get_detections(m_ctx, frame, nullptr, 0, &n), "acf_hip_get_detections");
+    std::vector<acf_hip_detection> d(size_t(std::max(n, 1)));
+    check(m_api->acf_hip_get_detections(m_ctx, frame, d.data(), n, &n), "acf_hip_get_detections");
+    DetectionVec bbs(static_cast<size_t>(n));
+    for (int i = 0; i < n; i++)
+    {
+        bbs[size_t(i)].roi = Rect(d[size_t(i)].x, d[size_t(i)].y, d[size_t(i)].w, d[size_t(i)].h);
+        bbs[size_t(i)].score = double(d[size_t(i)].score);
+    }
+    if (m_doNms)
+    {
+        // ACF.cpp:332-353
+        if (!bbs.empty())
+        {
+            DetectionVec out;
+            bbNms(bbs, opts.pNms, out);
+            RealVec bbScores;
+            for (auto& b : out)
+            {
+                objects.push_back(b.roi);
+                bbScores.push_back(b.score);
+            }
+            prune(objects, bbScores);
+            if (scores)
+            {
+                *scores = bbScores;
+            }
+        }
+    }
+    else
+    {
+        // ACF.cpp:354-364
+        for (auto& b : bbs)
+        {
+            objects.push_back(b.roi);
+            if (scores)
+            {
+                scores->push_back(b.score);
+            }
+        }
+    }
+}
+
+int HipDetector::operator()(const MatP& Ip, RectVec& objects, RealVec* scores)
+{
+    if (Ip.empty())
+    {
+        throw Exception(ACF_HIP_E_INVALID, "operator(): empty image");
+    }
+    // rows = image width, cols = image height
+    ensurePlan(Ip.cols(), Ip.rows(), Ip.channels(), 1);
+    check(m_api->acf_hip_run_host(m_ctx, Ip.data(), 1), "acf_hip_run_host");
+    fetch(0, objects, scores);
+    return 0;
+}
+
+int HipDetector::operator()(const float* rgb, int rows, int cols, RectVec& objects, RealVec* scores)
+{
+    // ACF.cpp:135-141: transpose unless the caller already did, split interleaved -> planar (MatP.cpp:18-34)
+    const int W = m_isTranspose ? rows : cols, H = m_isTranspose ? cols : rows;
+    MatP Ip(W, H, 3);
+    for (int z = 0; z < 3; z++)
+    {
+        float* P = Ip[z];
+        for (int r = 0; r < rows; r++)
+        {
+            for (int c = 0; c < cols; c++)
+            {
+                const float v = rgb[(size_t(r) * cols + c) * 3 + z];
+                if (m_isTranspose)
+                {
+                    P[size_t(r) * cols + c] = v; // already [W][H]
+                }
+                else
+                {
+                    P[size_t(c) * rows + r] = v;
+                }
+            }
+        }
+    }
+    return (*this)(Ip, objects, scores);
+}
+
+int HipDetector::detectBatch(const float* frames, int nFrames, int rows, int cols, int channels,
+    std::vector<RectVec>& objects, std::vector<RealVec>* scores)
+{
+    ensurePlan(cols, rows, channels, nFrames);
+    check(m_api->acf_hip_run_host(m_ctx, frames, nFrames), "acf_hip_run_host");
+    objects.assign(size_t(nFrames), RectVec());
+    if (scores)
+    {
+        scores->assign(size_t(nFrames), RealVec());
+    }
+    for (int f = 0; f < nFrames; f++)
+    {
+        fetch(f, objects[size_t(f)], scores ? &(*scores)[size_t(f)] : nullptr);
+    }
+    return 0;
+}
+
+void HipDetector::computePyramid(const MatP& Ip, Pyramid& P)
+{
+    chnsPyramid(Ip, &opts.pPyramid, P, true);
+}
+
+int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& P, bool)
+{
+    if (pPyramid && pPyramid != &opts.pPyramid)
+    {
+        opts.pPyramid = *pPyramid;
+        m_dirty = true;
+    }
+    ensurePlan(I.cols(), I.rows(), I.channels(), 1);
+    // upload + pyramid only
+    {
+        // run_host = H2D + pyramid + detect; the pyramid alone needs a device frame, so stage through run_host's
+        // buffer by running the whole path (the cascade result is simply not fetched).
+        check(m_api->acf_hip_run_host(m_ctx, I.data(), 1), "acf_hip_run_host");
+    }
+    P.clear();
+    P.nScales = int(m_levels.size());
+    P.nChns = m_nChns;
+    P.nTypes = (opts.pPyramid.pChns.pColor.enabled ? 1 : 0) + (opts.pPyramid.pChns.pGradMag.enabled ? 1 : 0) +
+        (opts.pPyramid.pChns.pGradHist.enabled ? 1 : 0);
+    P.lambdas = opts.pPyramid.lambdas;
+    P.data.resize(m_levels.size());
+    for (size_t i = 0; i < m_levels.size(); i++)
+    {
+        const acf_hip_level& l = m_levels[i];
+        P.scales.push_back(l.scale);
+        Size2d s;
+        s.width = l.scalehw_h; // cv::Size2d {width = image-height axis}
+        s.height = l.scalehw_w;
+        P.scaleshw.push_back(s);
+        P.data[i].resize(1);
+        P.data[i][0].create(l.wP * m_nChns, l.hP, 1); // fused: planes stacked along rows (ACF.h:653-672)
+        check(m_api->acf_hip_read_level(m_ctx, 0, int(i), P.data[i][0].data()), "acf_hip_read_level");
+    }
+    P.deviceTag = ++m_generation;
+    return 0;
+}
+
+int HipDetector::operator()(const Pyramid& P, RectVec& objects, RealVec* scores)
+{
+    if (P.nScales != int(m_levels.size()) || P.nScales == 0)
+    {
+        throw Exception(ACF_HIP_E_NOPLAN, "operator()(Pyramid): pyramid was not produced by this detector");
+    }
+    if (P.deviceTag == m_generation && P.deviceTag != 0)
+    {
+        // still resident: the cascade ran with it (acf_hip_run_host); results are on the device
+        fetch(0, objects, scores);
+        return 0;
+    }
+    // a host pyramid: one acfDetect1 per level + box mapping (ACF.cpp:268-367)
+    const int shift_w = (opts.modelDsPad.width - opts.modelDs.width) / 2 - opts.pPyramid.pad.width;   // image-height axis
+    const int shift_h = (opts.modelDsPad.height - opts.modelDs.height) / 2 - opts.pPyramid.pad.height; // image-width axis
+    DetectionVec all;
+    for (int i = 0; i < P.nScales; i++)
+    {
+        DetectionVec ds;
+        acfDetect1(P.data[size_t(i)][0], opts.pPyramid.pChns.shrink, opts.modelDsPad, opts.stride, opts.cascThr, ds);
+        // ACF.cpp:302-312 — ds rois are in the transposed convention (x along image-y)
+        const double sw = P.scaleshw[size_t(i)].width, sh = P.scaleshw[size_t(i)].height;
+        const int bw = int(std::nearbyint(double(opts.modelDs.width) / P.scales[size_t(i)]));
+        const int bh = int(std::nearbyint(double(opts.modelDs.height) / P.scales[size_t(i)]));
+        for (auto& d : ds)
+        {
+            const int x = int(double(d.roi.x + shift_w) / sw);
+            const int y = int(double(d.roi.y + shift_h) / sh);
+            Detection o;
+            o.roi = Rect(y, x, bh, bw); // swap back to upright (ACF.cpp:310-311)
+            o.score = d.score;
+            all.push_back(o);
+        }
+    }
+    if (m_doNms)
+    {
+        if (!all.empty())
+        {
+            DetectionVec out;
+            bbNms(all, opts.pNms, out);
+            RealVec bbScores;
+            for (auto& b : out)
+            {
+                objects.push_back(b.roi);
+                bbScores.push_back(b.score);
+            }
+            prune(objects, bbScores);
+            if (scores)
+            {
+                *scores = bbScores;
+            }
+        }
+    }
+    else
+    {
+        for (auto& b : all)
+        {
+            objects.push_back(b.roi);
+            if (scores)
+            {
+                scores->push_back(b.score);
+            }
+        }
+    }
+    return 0;
+}
+
+void HipDetector::acfDetect1(const MatP& chns, int, const Size&, int, double, DetectionVec& objects)
+{
+    // chns: fused level buffer, rows = nChns * wP, cols = hP
+    if (!m_good)
+    {
+        throw Exception(ACF_HIP_E_NOMODEL, "acfDetect1: no model");
+    }
+    if (m_dirty)
+    {
+        acf_hip_params p;
+        fillParams(p);
+        check(m_api->acf_hip_set_model(m_ctx, &p), "acf_hip_set_model");
+        m_dirty = false;
+        m_planH = 0;
+    }
+    const auto& ch = opts.pPyramid.pChns;
+    const int nColor = ch.pColor.enabled ? (ch.pColor.colorSpace == "gray" ? 1 : 3) : 0;
+    const int nC = nColor + (ch.pGradMag.enabled ? 1 : 0) + (ch.pGradHist.enabled ? ch.pGradHist.nOrients : 0);
+    const int wP = chns.rows() / nC, hP = chns.cols();
+    const int cap = std::max(1, wP * hP);
+    std::vector<acf_hip_hit> hits(static_cast<size_t>(cap));
+    int n = 0;
+    check(m_api->acf_hip_op_acf_detect1(m_ctx, chns.data(), hP, wP, nC, hits.data(), cap, &n), "acf_hip_op_acf_detect1");
+    for (int i = 0; i < n; i++)
+    {
+        Detection d;
+        // acfDetect1.cpp:326-332: Rect(c*stride, r*stride, modelWd, modelHt) then swapped into the transposed convention
+        d.roi = Rect(hits[size_t(i)].r * opts.stride, hits[size_t(i)].c * opts.stride, opts.modelDsPad.width, opts.modelDsPad.height);
+        d.score = double(hits[size_t(i)].score);
+        objects.push_back(d);
+    }
+}
+
+void HipDetector::getScales(int nPerOct, int nOctUp, const Size& minDs, int shrink, const Size& sz,
+    std::vector<double>& scales, std::vector<Size2d>& scaleshw)
+{
+    const hip::Api& api = hip::load();
+    int n = 0;
+    std::vector<double> s(512), a(512), b(512);
+    const int rc = api.acf_hip_get_scales(nPerOct, nOctUp, minDs.width, minDs.height, shrink, sz.width, sz.height, s.data(), a.data(), b.data(), 512, &n);
+    if (rc != ACF_HIP_OK)
+    {
+        throw Exception(rc, "getScales");
+    }
+    scales.assign(s.begin(), s.begin() + n);
+    scaleshw.resize(size_t(n));
+    for (int i = 0; i < n; i++)
+    {
+        scaleshw[size_t(i)].width = a[size_t(i)];
+        scaleshw[size_t(i)].height = b[size_t(i)];
+    }
+}
+
+int HipDetector::rgbConvert(const MatP& I, MatP& J, const std::string& colorSpace)
+{
+    const int flag = colorSpaceFlag(colorSpace);
+    if (!m_ctx)
+    {
+        m_api = &hip::load();
+        check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
+    }
+    J.create(I.rows(), I.cols(), flag == ACF_HIP_CS_GRAY ? 1 : 3);
+    check(m_api->acf_hip_op_rgb_convert(m_ctx, I.data(), J.data(), I.cols(), I.rows(), flag), "acf_hip_op_rgb_convert");
+    return 0;
+}
+
+int HipDetector::convTri(const MatP& I, MatP& J, double r, bool inPlaceSemantics)
+{
+    if (!m_ctx)
+    {
+        m_api = &hip::load();
+        check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
+    }
+    J.create(I.rows(), I.cols(), I.channels());
+    check(m_api->acf_hip_op_conv_tri(m_ctx, I.data(), J.data(), I.cols(), I.rows(), I.channels(), r, inPlaceSemantics ? 1 : 0), "acf_hip_op_conv_tri");
+    return 0;
+}
+
+int HipDetector::gradientMag(const MatP& I, MatP& M, MatP& O, int normRad, double normConst, int full)
+{
+    if (!m_ctx)
+    {
+        m_api = &hip::load();
+        check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
+    }
+    M.create(I.rows(), I.cols(), 1);
+    O.create(I.rows(), I.cols(), 1);
+    check(m_api->acf_hip_op_gradient_mag(m_ctx, I.data(), M.data(), O.data(), nullptr, I.cols(), I.rows(), normRad, normConst, full), "acf_hip_op_gradient_mag");
+    return 0;
+}
+
+int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full)
+{
+    if (!m_ctx)
+    {
+        m_api = &hip::load();
+        check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
+    }
+    H.create(M.rows() / binSize, M.cols() / binSize, nOrients);
+    check(m_api->acf_hip_op_gradient_hist(m_ctx, M.data(), O.data(), H.data(), M.cols(), M.rows(), binSize, nOrients, full), "acf_hip_op_gradient_hist");
+    return 0;
+}
+
+} // namespace acf

@@ -1,0 +1,269 @@
+// HipDetector.h — host-side C++ mirror of the reference's acf::Detector for the
+// chnsPyramid + acfDetect hot path, backed by libacf_hip.so (MI355X / gfx950).
+//
+// Same method names, argument meaning and error behaviour as acf::Detector
+// (reference src/lib/acf/acf/ACF.h:50-624, ObjectDetector.h:31-48); it plays
+// the role acf::GLDetector plays for the GL backend (src/app/acf/GLDetector.h:
+// 28-52): build the pyramid on the device, then run the multi-scale search.
+// OpenCV is not available in this build image, so the three cv:: value types
+// the API traffics in are restated here with the same member names; a
+// maintainer wiring this into the reference replaces them by the cv:: ones
+// (INTEGRATION.md shows the subclass).
+//
+// Layout contract (reference MatP.cpp:51-73, ACF.cpp:137): every plane is the
+// TRANSPOSED image, float[rows = image width][cols = image height] with
+// image-y contiguous.  cv::Size members for modelDs/modelDsPad/pad/minDs hold
+// {width = image-height axis, height = image-width axis} (ACFIO.h:168-181);
+// this class keeps that convention at its surface and converts to the C
+// ABI's upright h/w names internally.
+#pragma once
+
+#include "acf_hip_loader.h"
+
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace acf
+{
+
+struct Size
+{
+    int width = 0, height = 0;
+    Size() = default;
+    Size(int w, int h) : width(w), height(h) {}
+    int area() const { return width * height; }
+    bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+};
+
+struct Size2d
+{
+    double width = 0, height = 0;
+};
+
+struct Rect
+{
+    int x = 0, y = 0, width = 0, height = 0;
+    Rect() = default;
+    Rect(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {}
+    bool operator==(const Rect& o) const { return x == o.x && y == o.y && width == o.width && height == o.height; }
+};
+
+// Planar float image (reference MatP.h:25-190): `channels` planes of rows x cols,
+// stored back to back (plane stride rows*cols), cols contiguous.
+class MatP
+{
+public:
+    MatP() = default;
+    MatP(int rows, int cols, int channels) { create(rows, cols, channels); }
+    // non-owning view over caller memory (the reference wraps cv::Mat headers the same way, MatP.cpp:51-73)
+    MatP(int rows, int cols, int channels, float* data) : m_rows(rows), m_cols(cols), m_channels(channels), m_ptr(data) {}
+    MatP(const MatP& o) { *this = o; }
+    MatP& operator=(const MatP& o)
+    {
+        if (this != &o)
+        {
+            m_rows = o.m_rows;
+            m_cols = o.m_cols;
+            m_channels = o.m_channels;
+            m_store = o.m_store;
+            m_ptr = o.m_store.empty() ? o.m_ptr : m_store.data(); // owning copies re-point; views stay views
+        }
+        return *this;
+    }
+    void create(int rows, int cols, int channels)
+    {
+        m_rows = rows;
+        m_cols = cols;
+        m_channels = channels;
+        m_store.assign(size_t(rows) * cols * channels, 0.f);
+        m_ptr = m_store.data();
+    }
+    int rows() const { return m_rows; }
+    int cols() const { return m_cols; }
+    int channels() const { return m_channels; }
+    bool empty() const { return !m_ptr || !m_rows || !m_cols || !m_channels; }
+    Size size() const { return Size(m_cols, m_rows); }
+    float* operator[](int c) { return m_ptr + size_t(c) * m_rows * m_cols; }
+    const float* operator[](int c) const { return m_ptr + size_t(c) * m_rows * m_cols; }
+    float* data() { return m_ptr; }
+    const float* data() const { return m_ptr; }
+    size_t numel() const { return size_t(m_rows) * m_cols * m_channels; }
+
+private:
+    int m_rows = 0, m_cols = 0, m_channels = 0;
+    float* m_ptr = nullptr;
+    std::vector<float> m_store;
+};
+
+// cv::Exception stand-in: precondition failures throw (reference: CV_Assert), the hot path returns 0.
+class Exception : public std::runtime_error
+{
+public:
+    Exception(int code_, const std::string& what) : std::runtime_error(what), code(code_) {}
+    int code;
+};
+
+class HipDetector
+{
+public:
+    using RealVec = std::vector<double>;
+    using RectVec = std::vector<Rect>;
+
+    // The fields of the Options tree (ACF.h:68-275) the hot path reads, flattened.
+    struct Options
+    {
+        struct Nms
+        {
+            std::string type = "maxg"; // acfTrain default pNms; bbNms.cpp:229-304 handles max / maxg / none
+            double thr = -1.7976931348623157e308;
+            double overlap = 0.65;
+            std::string ovrDnm = "min";
+        } pNms;
+        struct Pyramid
+        {
+            struct Chns
+            {
+                int shrink = 4;
+                struct Color { int enabled = 1; double smooth = 1; std::string colorSpace = "luv"; } pColor;
+                struct GradMag { int enabled = 1; int colorChn = 0; int normRad = 5; double normConst = 0.005; int full = 0; } pGradMag;
+                struct GradHist { int enabled = 1; int binSize = 0; int nOrients = 6; int softBin = 0; } pGradHist;
+            } pChns;
+            int nPerOct = 8, nOctUp = 0, nApprox = 7;
+            std::vector<double> lambdas{ 0.0, 0.1105, 0.1083 };
+            Size pad{ 0, 0 };    // {width = image-height axis, height = image-width axis}
+            Size minDs{ 16, 16 };
+            double smooth = 1;
+        } pPyramid;
+        Size modelDs{ 16, 16 }, modelDsPad{ 16, 16 };
+        int stride = 4;
+        double cascThr = -1;
+        double cascCal = 0;
+    };
+
+    // Detector::Classifier (ACF.h:292-310): row-major [nTrees][nTreeNodes] (after ACFIO.cpp:61-67's transpose).
+    struct Classifier
+    {
+        int nTrees = 0, nTreeNodes = 0, treeDepth = 0;
+        std::vector<uint32_t> fids, child;
+        std::vector<float> thrs, hs;
+    };
+
+    // Detector::Modify (ACF.h:391-408): the subset acfModify may override (acfModify.cpp:83-152).
+    struct Modify
+    {
+        bool has_nPerOct = false, has_nOctUp = false, has_nApprox = false, has_lambdas = false, has_pad = false,
+             has_minDs = false, has_stride = false, has_cascThr = false, has_cascCal = false;
+        int nPerOct = 0, nOctUp = 0, nApprox = 0, stride = 0;
+        std::vector<double> lambdas;
+        Size pad, minDs;
+        double cascThr = 0, cascCal = 0;
+    };
+
+    // Detector::Pyramid (ACF.h:364-389).  data[i][0] is level i's fused channel
+    // buffer [nChns planes][wP rows][hP cols] (ACF.h:653-672 fuseChannels).
+    struct Pyramid
+    {
+        int nTypes = 0, nScales = 0, nChns = 0;
+        std::vector<std::vector<MatP>> data;
+        std::vector<double> lambdas, scales;
+        std::vector<Size2d> scaleshw;
+        uint64_t deviceTag = 0; // != 0: this pyramid is also resident on the device (generation counter)
+        void clear()
+        {
+            data.clear();
+            lambdas.clear();
+            scales.clear();
+            scaleshw.clear();
+            nScales = 0;
+            deviceTag = 0;
+        }
+    };
+
+    // Detector::Detection (ACF.h:510-525)
+    struct Detection
+    {
+        Rect roi;
+        double score = 0;
+    };
+    using DetectionVec = std::vector<Detection>;
+
+    Options opts;
+    Classifier clf;
+
+    HipDetector() = default; // !good() until a model is supplied
+    HipDetector(const Options& o, const Classifier& c, int device = 0);
+    ~HipDetector();
+    HipDetector(const HipDetector&) = delete;
+    HipDetector& operator=(const HipDetector&) = delete;
+
+    bool good() const { return m_good; }
+    explicit operator bool() const { return m_good; }
+    void setModel(const Options& o, const Classifier& c, int device = 0);
+
+    // ObjectDetector knobs (ObjectDetector.h:37-47, ACF.h:495-595)
+    void setDoNonMaximaSuppression(bool flag) { m_doNms = flag; }
+    bool getDoNonMaximaSuppression() const { return m_doNms; }
+    void setMaxDetectionCount(size_t n) { m_maxDetectionCount = n; }
+    void setDetectionScorePruneRatio(double r) { m_detectionScorePruneRatio = r; }
+    void setIsLuv(bool flag) { m_isLuv = flag; m_dirty = true; }
+    bool getIsLuv() const { return m_isLuv; }
+    void setIsTranspose(bool flag) { m_isTranspose = flag; }
+    bool getIsTranspose() const { return m_isTranspose; }
+    void setDoParallel(bool) {} // scales/frames always run concurrently on the device
+    Size getWindowSize() const { return opts.modelDs; }
+    int acfModify(const Modify& params); // acfModify.cpp:83-152
+
+    // Detection: planar f32 transposed image (RGB in [0,1], or LUV after setIsLuv(true)); ACF.cpp:246-265.
+    // Returns 0, APPENDS to objects; scores appended (no NMS) or assigned (NMS) exactly like ACF.cpp:332-364.
+    int operator()(const MatP& IpTranspose, RectVec& objects, RealVec* scores = nullptr);
+    // Packed interleaved RGB f32 in [0,1], upright rows x cols x 3 unless setIsTranspose(true) (ACF.cpp:135-141).
+    int operator()(const float* rgbInterleaved, int rows, int cols, RectVec& objects, RealVec* scores = nullptr);
+    // Multi-scale search on a pyramid (ACF.cpp:268-367).
+    int operator()(const Pyramid& P, RectVec& objects, RealVec* scores = nullptr);
+    // Batch of frames (no reference precedent; frames are independent): per-frame outputs.
+    int detectBatch(const float* framesTransposedPlanar, int nFrames, int rows, int cols, int channels,
+        std::vector<RectVec>& objects, std::vector<RealVec>* scores = nullptr);
+
+    void computePyramid(const MatP& Ip, Pyramid& P); // ACF.cpp:147-159
+    int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false); // chnsPyramid.cpp:160-456
+    // chnsPyramid.cpp:461-529; sz = {width = image height, height = image width}
+    static void getScales(int nPerOct, int nOctUp, const Size& minDs, int shrink, const Size& sz,
+        std::vector<double>& scales, std::vector<Size2d>& scaleshw);
+
+    // acfDetect1.cpp:309-335: one level; rois unused on this path (fused buffers only)
+    void acfDetect1(const MatP& chns, int shrink, const Size& modelDsPad, int stride, double cascThr, DetectionVec& objects);
+    // bbNms.cpp:229-304 (max / maxg / none), ObjectDetector.cpp:28-44
+    static int bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, DetectionVec& bbs);
+    void prune(RectVec& objects, RealVec& scores) const;
+
+    // Single operators (static members of acf::Detector, ACF.h:441-493), on host planes.
+    int rgbConvert(const MatP& I, MatP& J, const std::string& colorSpace);
+    int convTri(const MatP& I, MatP& J, double r, bool inPlaceSemantics = false);
+    int gradientMag(const MatP& I, MatP& M, MatP& O, int normRad, double normConst, int full);
+    int gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full);
+
+    acf_hip_ctx* context() { return m_ctx; }
+
+private:
+    void check(int rc, const char* what) const;
+    void fillParams(acf_hip_params& p) const;
+    void ensurePlan(int imgH, int imgW, int d, int batch);
+    void fetch(int frame, RectVec& objects, RealVec* scores);
+
+    const hip::Api* m_api = nullptr;
+    acf_hip_ctx* m_ctx = nullptr;
+    bool m_good = false, m_dirty = true;
+    bool m_doNms = false, m_isLuv = false, m_isTranspose = false;
+    size_t m_maxDetectionCount = 10;
+    double m_detectionScorePruneRatio = 0.0;
+    int m_planH = 0, m_planW = 0, m_planD = 0, m_planBatch = 0;
+    uint64_t m_generation = 0;
+    std::vector<acf_hip_level> m_levels;
+    int m_nChns = 0;
+    std::vector<float> m_upright; // scratch for operator()(interleaved)
+};
+
+} // namespace acf

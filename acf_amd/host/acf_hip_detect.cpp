@@ -1,0 +1,232 @@
+// acf_hip_detect — C++ host CLI over acf::HipDetector (the role of the
+// reference's acf-detect app, src/app/acf/acf.cpp, for this path only).
+//
+//   acf_hip_detect --model m.acfm --frames f.raw --rows W --cols H --channels d --count N
+//                  [--luv] [--nms] [--batch] [--via-pyramid] [--max-count K] [--prune-ratio R]
+//   acf_hip_detect --nms-only boxes.txt [--type maxg] [--overlap .65] [--ovrdnm min]   (host logic only, no GPU)
+//
+// Model file ("ACFHIPM1", written by acf_amd/modelio.py): text header of
+// "key value" lines terminated by "END", then raw little-endian arrays
+// fids u32, thrs f32, hs f32, child u32, each nTrees*nTreeNodes.
+// Frames: raw f32, transposed planar [count][channels][rows=W][cols=H].
+// Output: "frame i n" then n lines "x y w h score scorebits".
+#include "HipDetector.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+using acf::HipDetector;
+
+static bool loadModel(const std::string& path, HipDetector::Options& o, HipDetector::Classifier& c)
+{
+    std::ifstream is(path, std::ios::binary);
+    std::string line;
+    if (!std::getline(is, line) || line != "ACFHIPM1")
+    {
+        return false;
+    }
+    std::map<std::string, std::string> kv;
+    while (std::getline(is, line) && line != "END")
+    {
+        const size_t sp = line.find(' ');
+        if (sp != std::string::npos)
+        {
+            kv[line.substr(0, sp)] = line.substr(sp + 1);
+        }
+    }
+    auto I = [&](const char* k) { return std::stoi(kv.at(k)); };
+    auto D = [&](const char* k) { return std::stod(kv.at(k)); };
+    c.nTrees = I("nTrees");
+    c.nTreeNodes = I("nTreeNodes");
+    c.treeDepth = I("treeDepth");
+    o.modelDs = acf::Size(I("modelDs_h"), I("modelDs_w")); // {width = image-height axis}
+    o.modelDsPad = acf::Size(I("modelDsPad_h"), I("modelDsPad_w"));
+    o.stride = I("stride");
+    o.cascThr = D("cascThr");
+    auto& p = o.pPyramid;
+    p.nPerOct = I("nPerOct");
+    p.nOctUp = I("nOctUp");
+    p.nApprox = I("nApprox");
+    p.lambdas.clear();
+    {
+        std::istringstream ls(kv["lambdas"]);
+        double v;
+        while (ls >> v)
+        {
+            p.lambdas.push_back(v);
+        }
+    }
+    p.pad = acf::Size(I("pad_h"), I("pad_w"));
+    p.minDs = acf::Size(I("minDs_h"), I("minDs_w"));
+    p.smooth = D("smooth");
+    p.pChns.shrink = I("shrink");
+    p.pChns.pColor.enabled = I("colorEnabled");
+    p.pChns.pColor.smooth = D("colorSmooth");
+    const char* cs[] = { "gray", "rgb", "luv", "hsv", "orig" };
+    p.pChns.pColor.colorSpace = cs[I("colorSpace")];
+    p.pChns.pGradMag.enabled = I("gradMagEnabled");
+    p.pChns.pGradMag.colorChn = I("colorChn");
+    p.pChns.pGradMag.normRad = I("normRad");
+    p.pChns.pGradMag.normConst = D("normConst");
+    p.pChns.pGradMag.full = I("full");
+    p.pChns.pGradHist.enabled = I("gradHistEnabled");
+    p.pChns.pGradHist.binSize = I("binSize");
+    p.pChns.pGradHist.nOrients = I("nOrients");
+    p.pChns.pGradHist.softBin = I("softBin");
+    const size_t n = size_t(c.nTrees) * c.nTreeNodes;
+    c.fids.resize(n);
+    c.thrs.resize(n);
+    c.hs.resize(n);
+    c.child.resize(n);
+    is.read(reinterpret_cast<char*>(c.fids.data()), std::streamsize(n * 4));
+    is.read(reinterpret_cast<char*>(c.thrs.data()), std::streamsize(n * 4));
+    is.read(reinterpret_cast<char*>(c.hs.data()), std::streamsize(n * 4));
+    is.read(reinterpret_cast<char*>(c.child.data()), std::streamsize(n * 4));
+    return bool(is);
+}
+
+static void printFrame(int f, const HipDetector::RectVec& objs, const HipDetector::RealVec& scores)
+{
+    std::printf("frame %d %zu\n", f, objs.size());
+    for (size_t i = 0; i < objs.size(); i++)
+    {
+        const float s = float(scores[i]);
+        uint32_t b;
+        std::memcpy(&b, &s, 4);
+        std::printf("%d %d %d %d %.9g %08x\n", objs[i].x, objs[i].y, objs[i].width, objs[i].height, scores[i], b);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    std::map<std::string, std::string> a;
+    for (int i = 1; i < argc; i++)
+    {
+        std::string k = argv[i];
+        if (k.rfind("--", 0) == 0)
+        {
+            if (i + 1 < argc && std::string(argv[i + 1]).rfind("--", 0) != 0)
+            {
+                a[k.substr(2)] = argv[++i];
+            }
+            else
+            {
+                a[k.substr(2)] = "1";
+            }
+        }
+    }
+    try
+    {
+        if (a.count("nms-only"))
+        {
+            HipDetector::Options::Nms p;
+            if (a.count("type")) p.type = a["type"];
+            if (a.count("overlap")) p.overlap = std::stod(a["overlap"]);
+            if (a.count("ovrdnm")) p.ovrDnm = a["ovrdnm"];
+            if (a.count("thr")) p.thr = std::stod(a["thr"]);
+            std::ifstream is(a["nms-only"]);
+            HipDetector::DetectionVec in, out;
+            HipDetector::Detection d;
+            while (is >> d.roi.x >> d.roi.y >> d.roi.width >> d.roi.height >> d.score)
+            {
+                in.push_back(d);
+            }
+            HipDetector::bbNms(in, p, out);
+            HipDetector det; // prune() needs only the knobs
+            if (a.count("max-count")) det.setMaxDetectionCount(size_t(std::stoul(a["max-count"])));
+            if (a.count("prune-ratio")) det.setDetectionScorePruneRatio(std::stod(a["prune-ratio"]));
+            HipDetector::RectVec objs;
+            HipDetector::RealVec scores;
+            for (auto& b : out)
+            {
+                objs.push_back(b.roi);
+                scores.push_back(b.score);
+            }
+            if (a.count("prune"))
+            {
+                det.prune(objs, scores);
+            }
+            printFrame(0, objs, scores);
+            return 0;
+        }
+        HipDetector::Options o;
+        HipDetector::Classifier c;
+        if (!loadModel(a.at("model"), o, c))
+        {
+            std::fprintf(stderr, "cannot read model %s\n", a["model"].c_str());
+            return 2;
+        }
+        HipDetector det(o, c);
+        if (!det.good())
+        {
+            std::fprintf(stderr, "detector not good (no device / bad model)\n");
+            return 3;
+        }
+        det.setIsLuv(a.count("luv") != 0);
+        det.setDoNonMaximaSuppression(a.count("nms") != 0);
+        if (a.count("max-count")) det.setMaxDetectionCount(size_t(std::stoul(a["max-count"])));
+        if (a.count("prune-ratio")) det.setDetectionScorePruneRatio(std::stod(a["prune-ratio"]));
+        if (a.count("casc-cal"))
+        {
+            HipDetector::Modify m;
+            m.has_cascCal = true;
+            m.cascCal = std::stod(a["casc-cal"]);
+            det.acfModify(m);
+        }
+        const int rows = std::stoi(a.at("rows")), cols = std::stoi(a.at("cols")), ch = std::stoi(a.at("channels")), cnt = std::stoi(a.at("count"));
+        std::vector<float> frames(size_t(rows) * cols * ch * cnt);
+        {
+            std::ifstream is(a.at("frames"), std::ios::binary);
+            is.read(reinterpret_cast<char*>(frames.data()), std::streamsize(frames.size() * 4));
+            if (!is)
+            {
+                std::fprintf(stderr, "short frames file\n");
+                return 2;
+            }
+        }
+        const size_t per = size_t(rows) * cols * ch;
+        if (a.count("batch"))
+        {
+            std::vector<HipDetector::RectVec> objs;
+            std::vector<HipDetector::RealVec> scores;
+            det.detectBatch(frames.data(), cnt, rows, cols, ch, objs, &scores);
+            for (int f = 0; f < cnt; f++)
+            {
+                printFrame(f, objs[size_t(f)], scores[size_t(f)]);
+            }
+        }
+        else
+        {
+            for (int f = 0; f < cnt; f++)
+            {
+                acf::MatP Ip(rows, cols, ch, frames.data() + per * size_t(f));
+                HipDetector::RectVec objs;
+                HipDetector::RealVec scores;
+                if (a.count("via-pyramid"))
+                {
+                    // computePyramid -> host Pyramid -> operator()(Pyramid) on a *copy* (forces the per-level path)
+                    HipDetector::Pyramid P;
+                    det.computePyramid(Ip, P);
+                    HipDetector::Pyramid Q = P;
+                    Q.deviceTag = 0;
+                    det(Q, objs, &scores);
+                }
+                else
+                {
+                    det(Ip, objs, &scores);
+                }
+                printFrame(f, objs, scores);
+            }
+        }
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,172 @@
+"""The C++ host side (acf_amd/host: acf::HipDetector + dlopen loader + CLI).
+
+CPU tests: it builds with g++ alone, its NMS / prune host logic matches a
+line-by-line numpy restatement of the reference's nmsMax (bbNms.cpp:111-192)
+and prune (ObjectDetector.cpp:28-44), and it fails loudly when libacf_hip.so is
+missing.  GPU tests: the CLI's detections through every entry (image, batch,
+host-pyramid round trip, NMS) equal the oracle's.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from acf_amd import capi, synth
+from acf_amd.modelio import write_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "acf_amd", "host")
+CLI = os.path.join(HOST, "acf_hip_detect")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return CLI
+
+
+def run(cli, args, env=None, ok=True):
+    e = dict(os.environ)
+    e["ACF_HIP_LIBRARY"] = capi.LIB_PATH
+    if env:
+        e.update(env)
+    p = subprocess.run([cli] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    if ok:
+        assert p.returncode == 0, p.stderr
+    return p
+
+
+def parse(out):
+    frames = []
+    cur = None
+    for line in out.strip().splitlines():
+        t = line.split()
+        if t[0] == "frame":
+            cur = []
+            frames.append(cur)
+        else:
+            cur.append((int(t[0]), int(t[1]), int(t[2]), int(t[3]), int(t[5], 16)))
+    return frames
+
+
+def nms_ref(boxes, scores, overlap, greedy, ovr_union, thr=-np.inf):
+    """nmsMax restated (bbNms.cpp:111-192) with a stable descending sort."""
+    keep_thr = [i for i in range(len(boxes)) if not scores[i] < thr]
+    boxes = [boxes[i] for i in keep_thr]
+    scores = [scores[i] for i in keep_thr]
+    order = sorted(range(len(boxes)), key=lambda i: -scores[i])  # python's sort is stable
+    b = [boxes[i] for i in order]
+    s = [scores[i] for i in order]
+    n = len(b)
+    kp = [1] * n
+    for i in range(n):
+        if greedy and not kp[i]:
+            continue
+        for j in range(i + 1, n):
+            if not kp[j]:
+                continue
+            iw = min(b[i][0] + b[i][2], b[j][0] + b[j][2]) - max(b[i][0], b[j][0])
+            if iw <= 0:
+                continue
+            ih = min(b[i][1] + b[i][3], b[j][1] + b[j][3]) - max(b[i][1], b[j][1])
+            if ih <= 0:
+                continue
+            o = float(iw * ih)
+            ai, aj = b[i][2] * b[i][3], b[j][2] * b[j][3]
+            u = (ai + aj - o) if ovr_union else min(ai, aj)
+            if o / u > overlap:
+                kp[j] = 0
+    return [b[i] for i in range(n) if kp[i]], [s[i] for i in range(n) if kp[i]]
+
+
+def prune_ref(boxes, scores, max_count, ratio):
+    if len(boxes) > 1:
+        cutoff = 1
+        for i in range(1, min(max_count, len(boxes))):
+            cutoff = i + 1
+            if scores[i] < scores[0] * ratio:
+                break
+        return boxes[:cutoff], scores[:cutoff]
+    return boxes, scores
+
+
+@pytest.mark.parametrize("typ,ovr,overlap", [("maxg", "min", 0.65), ("max", "union", 0.5), ("maxg", "union", 0.3), ("none", "min", 0.5)])
+def test_nms_and_prune_match_restated_reference(cli, tmp_path, typ, ovr, overlap):
+    u = synth.uniform(5, 400 * 5, 3).reshape(400, 5)
+    boxes = [(int(r[0] * 300), int(r[1] * 200), 20 + int(r[2] * 60), 20 + int(r[3] * 60)) for r in u]
+    scores = [float(np.float32(r[4] * 30)) for r in u]
+    path = tmp_path / "boxes.txt"
+    path.write_text("\n".join("%d %d %d %d %.9g" % (b + (s,)) for b, s in zip(boxes, scores)))
+    p = run(cli, ["--nms-only", str(path), "--type", typ, "--ovrdnm", ovr, "--overlap", str(overlap), "--prune", "--max-count", "7", "--prune-ratio", "0.5"])
+    got = parse(p.stdout)[0]
+    if typ == "none":
+        wb, ws = boxes, scores
+    else:
+        wb, ws = nms_ref(boxes, scores, overlap, typ == "maxg", ovr == "union")
+    wb, ws = prune_ref(wb, ws, 7, 0.5)
+    assert [g[:4] for g in got] == [tuple(b) for b in wb]
+    assert [g[4] for g in got] == [int(np.float32(s).view(np.uint32)) for s in ws]
+
+
+def test_missing_library_fails_loudly(cli, tmp_path):
+    m = synth.make_model(seed=3, name="TINY", nTrees=8)
+    write_model(str(tmp_path / "m.acfm"), m)
+    (tmp_path / "f.raw").write_bytes(np.zeros((3, 80, 64), np.float32).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", "80", "--cols", "64", "--channels", "3", "--count", "1"],
+            env={"ACF_HIP_LIBRARY": "/nonexistent/libacf_hip.so"}, ok=False)
+    assert p.returncode != 0 and "dlopen" in p.stderr
+
+
+# ------------------------------------------------------------------ GPU
+
+def _oracle_dets(oracle, model, frames, H, W, d_in):
+    plan = oracle.Plan(model, H, W, d_in)
+    out = []
+    for f in frames:
+        pyr, _, _ = oracle.chns_pyramid(plan, f)
+        det, _ = oracle.detect(plan, pyr)
+        out.append([(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--batch"], ["--via-pyramid"]])
+@pytest.mark.parametrize("cfg", ["luv", "rgb_pad"])
+def test_cli_matches_oracle(cli, oracle, tmp_path, mode, cfg):
+    if cfg == "luv":
+        H, W, kind, kw, extra = 96, 128, "luv", dict(name="TINY", nTrees=96), ["--luv"]
+    else:
+        H, W, kind, kw, extra = 112, 96, "rgb", dict(name="INRIA", nTrees=64, cascThr=-1.5), []
+    model = synth.make_model(seed=3, **kw)
+    frames = [synth.make_frame(40 + i, H, W, kind) for i in range(3)]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", "3"] + extra + mode)
+    got = parse(p.stdout)
+    want = _oracle_dets(oracle, model, frames, H, W, 3)
+    assert sum(len(w) for w in want) > 0
+    assert [len(g) for g in got] == [len(w) for w in want], p.stderr
+    for g, w in zip(got, want):
+        assert g == w, [(a, b) for a, b in zip(g, w) if a != b][:5]
+
+
+@pytest.mark.gpu
+def test_cli_nms_and_calibration(cli, oracle, tmp_path):
+    H, W = 96, 128
+    model = synth.make_model(seed=3, name="TINY", nTrees=96)
+    frames = [synth.make_frame(40, H, W, "luv")]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", "1", "--luv", "--nms", "--max-count", "5", "--casc-cal", "0.01"])
+    got = parse(p.stdout)[0]
+    m2 = dict(model)
+    m2["hs"] = (model["hs"] + np.float32(0.01)).astype(np.float32)  # acfModify.cpp:143
+    want = _oracle_dets(oracle, m2, frames, H, W, 3)[0]
+    scores = [float(np.uint32(w[4]).view(np.float32)) for w in want]
+    wb, ws = nms_ref([w[:4] for w in want], scores, 0.65, True, False)
+    wb, ws = prune_ref(wb, ws, 5, 0.0)
+    assert len(got) > 0
+    assert [g[:4] for g in got] == [tuple(b) for b in wb]
