@@ -331,7 +331,14 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
     LAUNCHCHK(c, "k_tri_x");
     prof(c, "k_tri_y");
-    hipLaunchKernelGGL(k_tri_y, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, rad, fs);
+    if (rad == 5 && h % 4 == 0 && h >= 48 && fs % 4 == 0 && ((uintptr_t(U) | uintptr_t(S)) & 15) == 0)
+    {
+        hipLaunchKernelGGL(k_tri_y5, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, fs);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_tri_y, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, rad, fs);
+    }
     LAUNCHCHK(c, "k_tri_y");
     return ACF_HIP_OK;
 }

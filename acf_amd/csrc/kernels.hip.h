@@ -130,6 +130,10 @@ struct SmoothJob
     int64_t in_ps, out_ps;         // plane strides
 };
 
+// Columns are loaded SM_CH at a time, one chunk ahead of the recursion, so SM_CH
+// column loads per thread are in flight while a chunk is being filtered.
+#define SM_CH 8
+
 template <int R, bool ALIASED>
 __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ in, float* __restrict__ out,
     const SmoothJob* __restrict__ jobs, int64_t in_fs, int64_t out_fs, float p, int ldsStride)
@@ -147,9 +151,9 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
     const float nrm = 1.0f / ((p + 2) * (p + 2));
     const float p1 = 1 + p;
 
-    float c[4][R], nx[4][R], prev[R];
+    float c[SM_CH][R], nx[SM_CH][R], prev[R];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < SM_CH; j++)
     {
 #pragma unroll
         for (int k = 0; k < R; k++)
@@ -164,21 +168,21 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
         prev[k] = c[0][k]; // Il = Im at i == 0 (:503-507)
     }
     int buf = 0;
-    for (int i0 = 0; i0 < w; i0 += 4)
+    for (int i0 = 0; i0 < w; i0 += SM_CH)
     {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < SM_CH; j++)
         {
 #pragma unroll
             for (int k = 0; k < R; k++)
             {
                 const int y = tid + k * nt;
-                const int col = i0 + 4 + j;
+                const int col = i0 + SM_CH + j;
                 nx[j][k] = (col < w && y < h) ? I[int64_t(col) * h + y] : 0.f;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < SM_CH; j++)
         {
             const int i = i0 + j;
             if (i < w) // uniform across the workgroup
@@ -190,9 +194,9 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
                 {
                     const int y = tid + k * nt;
                     const float Im = c[j][k];
-                    const float Irn = (j < 3) ? c[(j + 1) & 3][k] : nx[0][k];
+                    const float Irn = (j < SM_CH - 1) ? c[(j + 1) % SM_CH][k] : nx[0][k];
                     const float Ir = (i < w - 1) ? Irn : Im;
-                    const float Il = ALIASED ? prev[k] : ((i > 0) ? ((j > 0) ? c[(j + 3) & 3][k] : prev[k]) : Im);
+                    const float Il = ALIASED ? prev[k] : ((i > 0) ? ((j > 0) ? c[(j + SM_CH - 1) % SM_CH][k] : prev[k]) : Im);
                     T[k] = nrm * (Il + p * Im + Ir);
                     if (y < h)
                     {
@@ -235,11 +239,11 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
 #pragma unroll
             for (int k = 0; k < R; k++)
             {
-                prev[k] = c[3][k];
+                prev[k] = c[SM_CH - 1][k];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < SM_CH; j++)
         {
 #pragma unroll
             for (int k = 0; k < R; k++)
@@ -386,19 +390,20 @@ __global__ void __launch_bounds__(256) k_tri_x(const float* __restrict__ in, flo
         U += nrm * T;
         Uc[int64_t(i) * h] = U;
     }
-    // body: r < i <= w - r, loads independent of the recurrence (4 columns in flight)
-    for (; i + 3 <= w - r; i += 4)
+    // body: r < i <= w - r, loads independent of the recurrence (TX_CH columns = 3*TX_CH loads in flight)
+    constexpr int TX_CH = 8;
+    for (; i + TX_CH - 1 <= w - r; i += TX_CH)
     {
-        float a[4], b[4], c[4];
+        float a[TX_CH], b[TX_CH], c[TX_CH];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < TX_CH; j++)
         {
             a[j] = I[int64_t(i + j - 1 - r) * h];
             b[j] = I[int64_t(i + j - 1 + r) * h];
             c[j] = I[int64_t(i + j - 1) * h];
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < TX_CH; j++)
         {
             T += a[j] + b[j] - 2 * c[j];
             U += nrm * T;
@@ -490,6 +495,134 @@ __global__ void __launch_bounds__(64) k_tri_y(const float* __restrict__ Ui, floa
                 O[int64_t(c) * h + yb + lane] = tout[c * (TY_CH + 1) + lane];
             }
         }
+    }
+}
+
+// convTriY for radius 5 (the normalisation radius every model uses), h % 4 == 0,
+// h >= 48: streaming version.  One LANE owns one image column and walks down
+// it; the 64 lanes of a wave own 64 adjacent columns.  A lane reads its
+// column as aligned float4 groups (each lane a different 128-byte line, eight
+// groups per line) into a 16-slot register ring that holds rows j-8 .. j+7:
+// step j needs rows j-7 (a), j-1 (c) and j+5 (b), so with the loop unrolled 16x
+// every ring index is static and each input is read from memory exactly once.
+// Loads for the next 16 rows are issued one iteration ahead.  No LDS, no
+// barriers, one wave per block: thousands of independent waves hide the HBM
+// latency, and the recurrence itself (2 dependent adds per row) is exactly the
+// reference's u += t += a + b - 2c.
+__global__ void __launch_bounds__(64) k_tri_y5(const float* __restrict__ Ui, float* __restrict__ So, int h, int w, int64_t fs)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w)
+    {
+        return;
+    }
+    const float* __restrict__ col = Ui + int64_t(blockIdx.z) * fs + int64_t(x) * h;
+    float* __restrict__ out = So + int64_t(blockIdx.z) * fs + int64_t(x) * h;
+    const float4* __restrict__ col4 = reinterpret_cast<const float4*>(col);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
+    constexpr int r = 6, r0 = 5, r1 = 7, h0 = 7;
+    const int r2 = 2 * h - r, h1 = h - r + 1;
+    float t, u;
+    // rows 0..15: the reference's head (reflected taps), straight from memory
+    u = t = col[0];
+#pragma unroll
+    for (int q = 1; q < r; q++)
+    {
+        t += col[q];
+        u += t;
+    }
+    u = 2 * u - t;
+    t = 0;
+    float o[4];
+    o[0] = u;
+#pragma unroll
+    for (int j = 1; j < 16; j++)
+    {
+        const float a = (j < h0) ? col[r - j] : col[j - r1];
+        const float b = col[r0 + j];
+        t += a + b - 2 * col[j - 1];
+        u += t;
+        o[j & 3] = u;
+        if ((j & 3) == 3)
+        {
+            out4[j >> 2] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
+    float ring[16];
+    {
+        const float4 g0 = col4[2], g1 = col4[3], g2 = col4[4], g3 = col4[5]; // rows 8..23
+        ring[8] = g0.x, ring[9] = g0.y, ring[10] = g0.z, ring[11] = g0.w;
+        ring[12] = g1.x, ring[13] = g1.y, ring[14] = g1.z, ring[15] = g1.w;
+        ring[0] = g2.x, ring[1] = g2.y, ring[2] = g2.z, ring[3] = g2.w;
+        ring[4] = g3.x, ring[5] = g3.y, ring[6] = g3.z, ring[7] = g3.w;
+    }
+    int J = 16;
+    // groups for rows J+8 .. J+23 of the current iteration
+    float4 nx[4];
+    const int lastFast = h - 24; // J + 23 <= h - 1 and every j <= J + 15 < h1
+    if (J <= lastFast)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            nx[q] = col4[(J + 8) / 4 + q];
+        }
+    }
+    for (; J <= lastFast; J += 16)
+    {
+        float4 nn[4];
+        const bool more = J + 16 <= lastFast;
+        if (more)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                nn[q] = col4[(J + 24) / 4 + q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            float ov[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+            {
+                const int jj = 4 * q + s; // j = J + jj, J % 16 == 0
+                if (s == 3)
+                {
+                    // rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago)
+                    ring[(8 + 4 * q) & 15] = nx[q].x;
+                    ring[(9 + 4 * q) & 15] = nx[q].y;
+                    ring[(10 + 4 * q) & 15] = nx[q].z;
+                    ring[(11 + 4 * q) & 15] = nx[q].w;
+                }
+                const float a = ring[(jj - 7) & 15];
+                const float b = ring[(jj + 5) & 15];
+                const float cc = ring[(jj - 1) & 15];
+                t += a + b - 2 * cc;
+                u += t;
+                ov[s] = u;
+            }
+            out4[(J >> 2) + q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
+        if (more)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                nx[q] = nn[q];
+            }
+        }
+    }
+    // remaining rows (the reflected tail), from memory
+    for (int j = J; j < h; j++)
+    {
+        const float a = col[j - r1];
+        const float b = (j < h1) ? col[r0 + j] : col[r2 - j];
+        t += a + b - 2 * col[j - 1];
+        u += t;
+        out[j] = u;
     }
 }
 

@@ -76,6 +76,17 @@ def test_conv_tri_running_sums(dev, oracle, h, w, r):
     assert np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("h", [44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 100, 540])
+def test_conv_tri_r5_streaming_boundaries(dev, oracle, h):
+    """Every residue of the 16-row unrolled streaming column kernel (k_tri_y5) and its head / tail hand-over."""
+    w = 70
+    a = rnd(h * 7 + 1, (1, w, h))
+    got = dev.op_conv_tri(a, 5.0, aliased=False)
+    want = np.zeros_like(a)
+    assert oracle.lib().acfo_conv_tri(oracle.F(a), oracle.F(want), h, w, 1, 5, 1) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
 @pytest.mark.parametrize("h,w", SIZES)
 @pytest.mark.parametrize("full", [0, 1])
 def test_gradient_mag(dev, oracle, h, w, full):
