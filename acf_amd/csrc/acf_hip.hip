@@ -33,6 +33,33 @@ struct RealScale
 
 } // namespace
 
+// Everything the cascade launch needs on the device.
+struct CascState
+{
+    CascLevel* d_cascLevels = nullptr;
+    int32_t* d_blockLevel = nullptr;
+    int blocksPerFrame = 0;
+    uint32_t* d_cidAll = nullptr;
+    float *d_thrs = nullptr, *d_hs = nullptr;
+    uint32_t* d_child = nullptr;
+    uint32_t* d_fids = nullptr;
+    CascNode2* d_nodes2 = nullptr;
+    acf_hip_hit *d_hits = nullptr, *d_sorted = nullptr;
+    acf_hip_detection* d_dets = nullptr;
+    int32_t* d_counts = nullptr;
+    uint2* d_queue[2] = { nullptr, nullptr }; // survivor queues between cascade stages
+    int32_t* d_qcounts = nullptr;             // [stage][frame]
+    int qcap = 0;
+    // LDS-tiled path (depth-2 models, stride a multiple of shrink)
+    bool useTiles = false;
+    CascTile* d_tiles = nullptr;
+    int nTiles = 0;
+    TreeNode* d_tileNodes = nullptr; // offsets in the tile's LDS layout, trees [0, tEnd)
+    TreeNode* d_tailNodes = nullptr; // offsets = feature ids (window-local layout), all trees
+    TileGeom geom{};
+    int tailWaves = 0;
+};
+
 struct acf_hip_ctx
 {
     int device = 0;
@@ -42,6 +69,7 @@ struct acf_hip_ctx
     bool hasModel = false, hasPlan = false;
     int taps = 0;
     int profile = 0;
+    int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     std::vector<hipEvent_t> evPool;
     std::vector<const char*> evName;
     size_t evUsed = 0;
@@ -77,22 +105,10 @@ struct acf_hip_ctx
     float* d_pyr = nullptr;
     const float* lastFrames = nullptr;
     float* d_stage = nullptr; // H2D staging for run_host
-    // cascade
-    CascLevel* d_cascLevels = nullptr;
-    int32_t* d_blockLevel = nullptr;
-    int blocksPerFrame = 0;
-    uint32_t* d_cidAll = nullptr;
-    float *d_thrs = nullptr, *d_hs = nullptr;
-    uint32_t* d_child = nullptr;
-    uint32_t* d_fids = nullptr;
-    CascNode2* d_nodes2 = nullptr;
+    // cascade (tables, model arrays, work queues, outputs): one value so that
+    // acf_hip_op_acf_detect1 can swap in a temporary set and restore the plan's
+    CascState cs;
     BoxLevel* d_boxLevels = nullptr;
-    acf_hip_hit *d_hits = nullptr, *d_sorted = nullptr;
-    acf_hip_detection* d_dets = nullptr;
-    int32_t* d_counts = nullptr;
-    uint2* d_queue[2] = { nullptr, nullptr }; // survivor queues between cascade stages
-    int32_t* d_qcounts = nullptr;             // [stage][frame]
-    int qcap = 0;
     std::vector<int32_t> h_counts;
     bool countsFetched = false;
 };
@@ -544,6 +560,11 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
         c->evUsed = 0;
         return ACF_HIP_OK;
     }
+    if (!strcmp(key, "cascade_tiles"))
+    {
+        c->noTiles = value == 0;
+        return ACF_HIP_OK;
+    }
     return fail(c, ACF_HIP_E_INVALID, std::string("unknown option ") + key);
 }
 
@@ -657,9 +678,13 @@ int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
 
 // Build the cascade tables for a list of level geometries (hP, wP) into the
 // context.  Shared by acf_hip_plan and acf_hip_op_acf_detect1.
-static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns,
-    CascLevel** d_levels, int32_t** d_blockLevel, int* blocksPerFrame, uint32_t** d_cidAll, CascNode2** d_nodes2)
+static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, CascState& cs)
 {
+    CascLevel** d_levels = &cs.d_cascLevels;
+    int32_t** d_blockLevel = &cs.d_blockLevel;
+    int* blocksPerFrame = &cs.blocksPerFrame;
+    uint32_t** d_cidAll = &cs.d_cidAll;
+    CascNode2** d_nodes2 = &cs.d_nodes2;
     const acf_hip_params& p = c->p;
     const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
     const uint32_t nF = uint32_t(nChns) * mH * mW;
@@ -777,6 +802,137 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     if ((rc = devUpload(c, d_nodes2, nodes2)))
     {
         return rc;
+    }
+    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile / k_cascade_tail2)
+    cs.useTiles = false;
+    if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
+    {
+        TileGeom g{};
+        g.step = p.stride / p.shrink;
+        g.TR = 32;
+        g.winFloats = nChns * mW * mH;
+        // stage boundaries (kernels.hip.h): A [0,16) and B [16,32) one lane per window; no stage C; D [32,128) one wave per window
+        int bounds[5] = { 0, 16, 32, 32, 128 };
+        if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
+        {
+            int v1, v2, v3, v4;
+            if (sscanf(e, "%d,%d,%d,%d", &v1, &v2, &v3, &v4) == 4 && 0 < v1 && v1 <= v2 && v2 <= v3 && v3 <= v4)
+            {
+                bounds[1] = v1;
+                bounds[2] = v2;
+                bounds[3] = v3;
+                bounds[4] = v4;
+            }
+        }
+        for (int i = 0; i < 5; i++)
+        {
+            g.b[i] = std::min(bounds[i], p.nTrees);
+        }
+        // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for two
+        // workgroups per CU (160 KiB LDS), else one
+        auto ldsBytes = [&](int nw) {
+            const int tc = nw * 64 / g.TR;
+            const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
+            const int64_t rowsP = (rows + 3) / 4 * 4;
+            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * 64 * 8 + int64_t(48) * std::min(32, p.nTrees);
+        };
+        int nw = 0;
+        for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
+        {
+            for (int cand : { 8, 4, 2, 1 })
+            {
+                if (!nw && ldsBytes(cand) <= limit)
+                {
+                    nw = cand;
+                }
+            }
+        }
+        int tw = 0;
+        for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
+        {
+            for (int cand : { 4, 2, 1 })
+            {
+                if (!tw && int64_t(cand) * g.winFloats * 4 <= limit)
+                {
+                    tw = cand;
+                }
+            }
+        }
+        if (nw && tw)
+        {
+            g.NW = nw;
+            g.TC = nw * 64 / g.TR;
+            g.rowsT = (g.TR - 1) * g.step + mH;
+            g.colsT = (g.TC - 1) * g.step + mW;
+            g.rowsP = (g.rowsT + 3) / 4 * 4;
+            g.tileFloats = nChns * g.rowsP * g.colsT;
+            g.cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.rowsP / 4) - 1) / uint32_t(g.rowsP / 4));
+            g.colsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.colsT) - 1) / uint32_t(g.colsT));
+            std::vector<CascTile> tiles;
+            bool ok = true;
+            {
+                // the fill kernel divides chunk indices by mulhi with these magics: check every index it will see
+                const uint32_t cps = uint32_t(g.rowsP / 4), nSeg = uint32_t(nChns * g.colsT);
+                for (uint32_t q = 0; q < nSeg * cps && ok; q++)
+                {
+                    const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32);
+                    ok = seg == q / cps && uint32_t((uint64_t(seg) * g.colsMagic) >> 32) == seg / uint32_t(g.colsT);
+                }
+            }
+            for (size_t i = 0; i < lv.size() && ok; i++)
+            {
+                for (int c0 = 0; c0 < lv[i].nWinC; c0 += g.TC)
+                {
+                    for (int r0 = 0; r0 < lv[i].nWinR; r0 += g.TR)
+                    {
+                        if (r0 > 32767 || c0 > 32767)
+                        {
+                            ok = false;
+                            break;
+                        }
+                        CascTile t{};
+                        t.level = int16_t(i);
+                        t.r0 = int16_t(r0);
+                        t.c0 = int16_t(c0);
+                        tiles.push_back(t);
+                    }
+                }
+            }
+            if (ok)
+            {
+                std::vector<TreeNode> tileNodes(size_t(std::max(g.b[4], 1))), tailNodes(size_t(p.nTrees));
+                for (int t = 0; t < p.nTrees; t++)
+                {
+                    const size_t q = size_t(t) * p.nTreeNodes;
+                    TreeNode a{}, b{};
+                    for (int k = 0; k < 3; k++)
+                    {
+                        const uint32_t f = c->fids[q + k];
+                        const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
+                        a.off[k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
+                        b.off[k] = f;
+                        a.thr[k] = b.thr[k] = c->thrs[q + k];
+                    }
+                    for (int k = 0; k < 4; k++)
+                    {
+                        a.hs[k] = b.hs[k] = c->hs[q + 3 + k];
+                    }
+                    if (t < g.b[4])
+                    {
+                        tileNodes[size_t(t)] = a;
+                    }
+                    tailNodes[size_t(t)] = b;
+                }
+                cs.geom = g;
+                cs.tailWaves = tw;
+                cs.nTiles = int(tiles.size());
+                if ((rc = devUpload(c, &cs.d_tiles, tiles)) || (rc = devUpload(c, &cs.d_tileNodes, tileNodes)) || (rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
+                {
+                    return rc;
+                }
+                cs.useTiles = true;
+            }
+        }
     }
     return ACF_HIP_OK;
 }
@@ -997,17 +1153,17 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     {
         return rc;
     }
-    if ((rc = devAlloc(c, &c->d_chns, size_t(B) * pl.raw_floats)) || (rc = devAlloc(c, &c->d_pyr, size_t(B) * pl.pyr_floats)))
+    if ((rc = devAlloc(c, &c->d_chns, size_t(B) * pl.raw_floats)) || (rc = devAlloc(c, &c->d_pyr, size_t(B) * pl.pyr_floats + 64)) /* + slack: the cascade's 16-byte tile fill may read a few floats past the last plane */)
     {
         return rc;
     }
     // cascade
-    if ((rc = buildCascadeTables(c, pl.levels, pl.nChns, &c->d_cascLevels, &c->d_blockLevel, &c->blocksPerFrame, &c->d_cidAll, &c->d_nodes2)))
+    if ((rc = buildCascadeTables(c, pl.levels, pl.nChns, c->cs)))
     {
         return rc;
     }
-    if ((rc = devUpload(c, &c->d_thrs, c->thrs)) || (rc = devUpload(c, &c->d_hs, c->hs)) || (rc = devUpload(c, &c->d_child, c->child)) ||
-        (rc = devUpload(c, &c->d_fids, c->fids)))
+    if ((rc = devUpload(c, &c->cs.d_thrs, c->thrs)) || (rc = devUpload(c, &c->cs.d_hs, c->hs)) || (rc = devUpload(c, &c->cs.d_child, c->child)) ||
+        (rc = devUpload(c, &c->cs.d_fids, c->fids)))
     {
         return rc;
     }
@@ -1024,8 +1180,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     {
         return rc;
     }
-    if ((rc = devAlloc(c, &c->d_hits, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->d_sorted, size_t(B) * max_hits)) ||
-        (rc = devAlloc(c, &c->d_dets, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->d_counts, size_t(B))))
+    if ((rc = devAlloc(c, &c->cs.d_hits, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->cs.d_sorted, size_t(B) * max_hits)) ||
+        (rc = devAlloc(c, &c->cs.d_dets, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->cs.d_counts, size_t(B))))
     {
         return rc;
     }
@@ -1035,9 +1191,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             nWinTotal += int64_t(l.nWinR) * l.nWinC;
         }
-        c->qcap = int(std::max<int64_t>(nWinTotal, 1));
-        if ((rc = devAlloc(c, &c->d_queue[0], size_t(B) * c->qcap)) || (rc = devAlloc(c, &c->d_queue[1], size_t(B) * c->qcap)) ||
-            (rc = devAlloc(c, &c->d_qcounts, size_t(8) * B)))
+        c->cs.qcap = int(std::max<int64_t>(nWinTotal, 1));
+        if ((rc = devAlloc(c, &c->cs.d_queue[0], size_t(B) * c->cs.qcap)) || (rc = devAlloc(c, &c->cs.d_queue[1], size_t(B) * c->cs.qcap)) ||
+            (rc = devAlloc(c, &c->cs.d_qcounts, size_t(8) * B)))
         {
             return rc;
         }
@@ -1280,13 +1436,149 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     return ACF_HIP_OK;
 }
 
-static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const CascLevel* d_levels, const int32_t* d_blockLevel, int blocksPerFrame,
-    const uint32_t* d_cidAll, const CascNode2* d_nodes2, const BoxLevel* d_box, int nF, int nChns)
+static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+    {
+        HIPCHK(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    }
+    return ACF_HIP_OK;
+}
+
+static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int nF, int nChns)
 {
     const acf_hip_params& p = c->p;
+    const CascState& cs = c->cs;
+    const TileGeom& g = cs.geom;
+    HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * 2 * size_t(c->maxBatch), c->stream));
+    TileArgs a{};
+    a.pyr = pyr;
+    a.pyr_fs = pyr_fs;
+    a.levels = cs.d_cascLevels;
+    a.tiles = cs.d_tiles;
+    a.nTiles = cs.nTiles;
+    a.nFrames = nF;
+    a.nChns = nChns;
+    a.mH = p.modelDsPad_h / p.shrink;
+    a.mW = p.modelDsPad_w / p.shrink;
+    a.nTrees = p.nTrees;
+    a.g = g;
+    a.tileNodes = cs.d_tileNodes;
+    a.tailNodes = cs.d_tailNodes;
+    a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
+    a.q = cs.d_queue[0];
+    a.qcount = cs.d_qcounts;
+    a.qhead = cs.d_qcounts + c->maxBatch;
+    a.qcap = cs.qcap;
+    a.hits = cs.d_hits;
+    a.counts = cs.d_counts;
+    a.maxHits = c->maxHits;
+    if (const char* e = getenv("ACF_HIP_CASC_DEBUG"))
+    {
+        a.debug = atoi(e);
+    }
+    if (a.debug & 4)
+    {
+        const int64_t total = int64_t(cs.nTiles) * nF;
+        HIPCHK(c, hipMalloc(&a.stamps, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long)));
+        HIPCHK(c, hipMemsetAsync(a.stamps, 0, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long), c->stream));
+    }
+    if (cs.nTiles > 0)
+    {
+        const int64_t total = int64_t(cs.nTiles) * nF;
+        const int64_t perX = (total + 7) / 8;
+        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * 64 * 8 + size_t(48) * g.b[2];
+        dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
+        int rc = 0;
+#define TILE_LAUNCH(N)                                                        \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N>), lds)))                           \
+        return rc;                                                            \
+    hipLaunchKernelGGL(k_cascade_tile<N>, grid, block, lds, c->stream, a);
+        switch (g.NW)
+        {
+            case 8:
+                TILE_LAUNCH(8);
+                break;
+            case 4:
+                TILE_LAUNCH(4);
+                break;
+            case 2:
+                TILE_LAUNCH(2);
+                break;
+            default:
+                TILE_LAUNCH(1);
+                break;
+        }
+#undef TILE_LAUNCH
+        LAUNCHCHK(c, "k_cascade_tile");
+        if (a.debug & 4)
+        {
+            // debug only: mean cycles per phase of thread 0 of every block
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::vector<long long> st(size_t(grid.x) * 8);
+            HIPCHK(c, hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+            double acc[4] = { 0, 0, 0, 0 };
+            long long nb = 0;
+            for (size_t b = 0; b < size_t(grid.x); b++)
+            {
+                if (st[b * 8 + 4] > st[b * 8])
+                {
+                    for (int k = 0; k < 4; k++)
+                    {
+                        acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
+                    }
+                    nb++;
+                }
+            }
+            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles\n", nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb);
+            (void)hipFree(a.stamps);
+        }
+        if (g.b[4] < p.nTrees)
+        {
+            const size_t tl = size_t(cs.tailWaves) * g.winFloats * 4;
+            dim3 tgrid(std::max(1, 512 / nF) * nF), tblock(cs.tailWaves * 64);
+#define TAIL_LAUNCH(N)                                                        \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail2<N>), tl)))                           \
+        return rc;                                                            \
+    hipLaunchKernelGGL(k_cascade_tail2<N>, tgrid, tblock, tl, c->stream, a);
+            switch (cs.tailWaves)
+            {
+                case 4:
+                    TAIL_LAUNCH(4);
+                    break;
+                case 2:
+                    TAIL_LAUNCH(2);
+                    break;
+                default:
+                    TAIL_LAUNCH(1);
+                    break;
+            }
+#undef TAIL_LAUNCH
+            LAUNCHCHK(c, "k_cascade_tail2");
+        }
+    }
+    return ACF_HIP_OK;
+}
+
+static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const BoxLevel* d_box, int nF, int nChns)
+{
+    const acf_hip_params& p = c->p;
+    const CascLevel* d_levels = c->cs.d_cascLevels;
+    const int32_t* d_blockLevel = c->cs.d_blockLevel;
+    const int blocksPerFrame = c->cs.blocksPerFrame;
+    const uint32_t* d_cidAll = c->cs.d_cidAll;
+    const CascNode2* d_nodes2 = c->cs.d_nodes2;
     prof(c, "k_cascade");
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * nF, c->stream));
-    if (blocksPerFrame > 0)
+    HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
+    if (c->cs.useTiles && !c->noTiles)
+    {
+        int rc = runCascadeTiled(c, pyr, pyr_fs, nF, nChns);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    else if (blocksPerFrame > 0)
     {
         // stage boundaries (see kernels.hip.h): [0,16) [16,32) [32,128) [128,nTrees)
         std::vector<int> bounds;
@@ -1299,7 +1591,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
         }
         bounds.push_back(p.nTrees);
         const int nStages = int(bounds.size());
-        HIPCHK(c, hipMemsetAsync(c->d_qcounts, 0, sizeof(int32_t) * size_t(nStages) * c->maxBatch, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cs.d_qcounts, 0, sizeof(int32_t) * size_t(nStages) * c->maxBatch, c->stream));
         CascArgs a{};
         a.pyr = pyr;
         a.pyr_fs = pyr_fs;
@@ -1310,7 +1602,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
         a.mH = p.modelDsPad_h / p.shrink;
         a.mW = p.modelDsPad_w / p.shrink;
         a.nChns = nChns;
-        a.fids = c->d_fids;
+        a.fids = c->cs.d_fids;
         a.nTrees = p.nTrees;
         a.nTreeNodes = p.nTreeNodes;
         a.treeDepth = p.treeDepth;
@@ -1318,13 +1610,13 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
         a.shrink = p.shrink;
         a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
         a.cidAll = d_cidAll;
-        a.thrs = c->d_thrs;
-        a.hs = c->d_hs;
-        a.child = c->d_child;
+        a.thrs = c->cs.d_thrs;
+        a.hs = c->cs.d_hs;
+        a.child = c->cs.d_child;
         a.nodes2 = d_nodes2;
-        a.qcap = c->qcap;
-        a.hits = c->d_hits;
-        a.counts = c->d_counts;
+        a.qcap = c->cs.qcap;
+        a.hits = c->cs.d_hits;
+        a.counts = c->cs.d_counts;
         a.maxHits = c->maxHits;
         const int mode = p.treeDepth == 2 ? 2 : (p.treeDepth > 0 ? 1 : 0);
         // later stages see a shrinking survivor set; grid-stride loops cover any count
@@ -1334,10 +1626,10 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
             a.t0 = sidx == 0 ? 0 : bounds[sidx - 1];
             a.t1 = bounds[sidx];
             a.last = sidx == nStages - 1;
-            a.qin = sidx > 0 ? c->d_queue[(sidx - 1) & 1] : nullptr;
-            a.qinCount = sidx > 0 ? c->d_qcounts + size_t(sidx - 1) * c->maxBatch : nullptr;
-            a.qout = c->d_queue[sidx & 1];
-            a.qoutCount = c->d_qcounts + size_t(sidx) * c->maxBatch;
+            a.qin = sidx > 0 ? c->cs.d_queue[(sidx - 1) & 1] : nullptr;
+            a.qinCount = sidx > 0 ? c->cs.d_qcounts + size_t(sidx - 1) * c->maxBatch : nullptr;
+            a.qout = c->cs.d_queue[sidx & 1];
+            a.qoutCount = c->cs.d_qcounts + size_t(sidx) * c->maxBatch;
             dim3 block(256);
             const size_t winBytes = sizeof(float) * size_t(nChns) * a.mH * a.mW;
             const bool tail = a.last && sidx > 0 && a.t0 >= 128 && winBytes <= 64 * 1024;
@@ -1397,8 +1689,8 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Ca
     const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
     const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
     prof(c, "k_sort_map");
-    hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->d_hits, (const int32_t*)c->d_counts, c->maxHits,
-        d_box, p.stride, shift_h, shift_w, c->d_sorted, c->d_dets);
+    hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, (const int32_t*)c->cs.d_counts, c->maxHits,
+        d_box, p.stride, shift_h, shift_w, c->cs.d_sorted, c->cs.d_dets);
     LAUNCHCHK(c, "k_sort_map");
     prof(c, "(end)");
     c->countsFetched = false;
@@ -1416,7 +1708,7 @@ int acf_hip_detect(acf_hip_ctx* c)
         return fail(c, ACF_HIP_E_INVALID, "detect: no pyramid (call acf_hip_pyramid)");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_cascLevels, c->d_blockLevel, c->blocksPerFrame, c->d_cidAll, c->d_nodes2, c->d_boxLevels, c->lastBatch, c->plan.nChns);
+    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_boxLevels, c->lastBatch, c->plan.nChns);
     if (rc)
     {
         return rc;
@@ -1536,7 +1828,7 @@ static int fetchCounts(acf_hip_ctx* c)
     }
     if (!c->countsFetched)
     {
-        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(int32_t) * c->lastBatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->cs.d_counts, sizeof(int32_t) * c->lastBatch, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->countsFetched = true;
     }
@@ -1566,7 +1858,7 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
     const int m = std::min(std::min(n, c->maxHits), cap);
     if (m > 0 && out)
     {
-        HIPCHK(c, hipMemcpy(out, c->d_dets + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(out, c->cs.d_dets + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
     }
     if (n > c->maxHits)
     {
@@ -1598,7 +1890,7 @@ int acf_hip_get_hits(acf_hip_ctx* c, int frame, acf_hip_hit* out, int cap, int* 
     const int m = std::min(std::min(n, c->maxHits), cap);
     if (m > 0 && out)
     {
-        HIPCHK(c, hipMemcpy(out, c->d_sorted + size_t(frame) * c->maxHits, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(out, c->cs.d_sorted + size_t(frame) * c->maxHits, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost));
     }
     if (n > c->maxHits)
     {
@@ -1618,8 +1910,8 @@ int acf_hip_export_detections(acf_hip_ctx* c, int32_t* dst_dev, int cap)
         return fail(c, ACF_HIP_E_INVALID, "export_detections: nothing to export");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_export, dim3(cdiv(cap, 256), c->lastBatch), dim3(256), 0, c->stream, (const acf_hip_detection*)c->d_dets,
-        (const int32_t*)c->d_counts, c->maxHits, cap, dst_dev);
+    hipLaunchKernelGGL(k_export, dim3(cdiv(cap, 256), c->lastBatch), dim3(256), 0, c->stream, (const acf_hip_detection*)c->cs.d_dets,
+        (const int32_t*)c->cs.d_counts, c->maxHits, cap, dst_dev);
     LAUNCHCHK(c, "k_export");
     return ACF_HIP_OK;
 }
@@ -1989,19 +2281,12 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     lv[0].nWinR = std::max(0, int(std::ceil(float(hP * p.shrink - p.modelDsPad_h + 1) / p.stride)));
     lv[0].nWinC = std::max(0, int(std::ceil(float(wP * p.shrink - p.modelDsPad_w + 1) / p.stride)));
     lv[0].offset = 0;
-    // temporary tables are registered in the context's allocation list only for the duration of this call
+    // temporary tables are registered in the context's allocation list only for the duration of this call;
+    // the plan's cascade state is swapped out and back
     const size_t mark = c->allocs.size();
-    const int savedMaxHits = c->maxHits;
-    acf_hip_hit *sHits = c->d_hits, *sSorted = c->d_sorted;
-    acf_hip_detection* sDets = c->d_dets;
-    int32_t* sCounts = c->d_counts;
-    uint2* sQ0 = c->d_queue[0];
-    uint2* sQ1 = c->d_queue[1];
-    int32_t* sQc = c->d_qcounts;
-    const int sQcap = c->qcap, sMaxBatch = c->maxBatch;
-    float *sThr = c->d_thrs, *sHs = c->d_hs;
-    uint32_t* sChild = c->d_child;
-    uint32_t* sFids = c->d_fids;
+    const int savedMaxHits = c->maxHits, savedMaxBatch = c->maxBatch;
+    const CascState saved = c->cs;
+    c->cs = CascState{};
     auto restore = [&]() {
         for (size_t i = mark; i < c->allocs.size(); i++)
         {
@@ -2009,86 +2294,70 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
         }
         c->allocs.resize(mark);
         c->maxHits = savedMaxHits;
-        c->d_hits = sHits;
-        c->d_sorted = sSorted;
-        c->d_dets = sDets;
-        c->d_counts = sCounts;
-        c->d_queue[0] = sQ0;
-        c->d_queue[1] = sQ1;
-        c->d_qcounts = sQc;
-        c->qcap = sQcap;
-        c->maxBatch = sMaxBatch;
-        c->d_thrs = sThr;
-        c->d_hs = sHs;
-        c->d_child = sChild;
-        c->d_fids = sFids;
+        c->maxBatch = savedMaxBatch;
+        c->cs = saved;
     };
-    CascLevel* dL = nullptr;
-    int32_t* dBL = nullptr;
-    uint32_t* dCid = nullptr;
-    CascNode2* dN2 = nullptr;
     BoxLevel* dBox = nullptr;
     float* dChn = nullptr;
-    int bpf = 0;
-    int rc = buildCascadeTables(c, lv, nChns, &dL, &dBL, &bpf, &dCid, &dN2);
+    int rc = buildCascadeTables(c, lv, nChns, c->cs);
     std::vector<BoxLevel> box(1);
     box[0].shw_h = box[0].shw_w = 1.0;
     box[0].bw = p.modelDs_w;
     box[0].bh = p.modelDs_h;
     c->maxHits = cap;
+    c->maxBatch = 1;
     if (!rc)
     {
         rc = devUpload(c, &dBox, box);
     }
     if (!rc)
     {
-        rc = devUpload(c, &c->d_thrs, c->thrs);
+        rc = devUpload(c, &c->cs.d_thrs, c->thrs);
     }
     if (!rc)
     {
-        rc = devUpload(c, &c->d_hs, c->hs);
+        rc = devUpload(c, &c->cs.d_hs, c->hs);
     }
     if (!rc)
     {
-        rc = devUpload(c, &c->d_child, c->child);
+        rc = devUpload(c, &c->cs.d_child, c->child);
     }
     if (!rc)
     {
-        rc = devUpload(c, &c->d_fids, c->fids);
+        rc = devUpload(c, &c->cs.d_fids, c->fids);
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_hits, size_t(cap));
+        rc = devAlloc(c, &c->cs.d_hits, size_t(cap));
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_sorted, size_t(cap));
+        rc = devAlloc(c, &c->cs.d_sorted, size_t(cap));
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_dets, size_t(cap));
+        rc = devAlloc(c, &c->cs.d_dets, size_t(cap));
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_counts, 1);
+        rc = devAlloc(c, &c->cs.d_counts, 1);
     }
     if (!rc)
     {
-        c->qcap = std::max(1, lv[0].nWinR * lv[0].nWinC);
-        c->maxBatch = 1;
-        rc = devAlloc(c, &c->d_queue[0], size_t(c->qcap));
+        c->cs.qcap = std::max(1, lv[0].nWinR * lv[0].nWinC);
+        rc = devAlloc(c, &c->cs.d_queue[0], size_t(c->cs.qcap));
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_queue[1], size_t(c->qcap));
+        rc = devAlloc(c, &c->cs.d_queue[1], size_t(c->cs.qcap));
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->d_qcounts, 8);
+        rc = devAlloc(c, &c->cs.d_qcounts, 8);
     }
     if (!rc)
     {
-        rc = devAlloc(c, &dChn, size_t(nChns) * hP * wP);
+        rc = devAlloc(c, &dChn, size_t(nChns) * hP * wP + 64);
     }
     if (!rc && hipMemcpy(dChn, chns, sizeof(float) * nChns * hP * wP, hipMemcpyHostToDevice) != hipSuccess)
     {
@@ -2096,12 +2365,12 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     }
     if (!rc)
     {
-        rc = runCascade(c, dChn, 0, dL, dBL, bpf, dCid, dN2, dBox, 1, nChns);
+        rc = runCascade(c, dChn, 0, dBox, 1, nChns);
     }
     int n = 0;
     if (!rc)
     {
-        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&n, c->d_counts, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&n, c->cs.d_counts, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
         {
             rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: sync");
         }
@@ -2110,7 +2379,7 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     {
         *count = n;
         const int m = std::min(n, cap);
-        if (m > 0 && out && hipMemcpy(out, c->d_sorted, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost) != hipSuccess)
+        if (m > 0 && out && hipMemcpy(out, c->cs.d_sorted, sizeof(acf_hip_hit) * m, hipMemcpyDeviceToHost) != hipSuccess)
         {
             rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: download");
         }

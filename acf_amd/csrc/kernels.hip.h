@@ -1448,6 +1448,625 @@ __global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
     }
 }
 
+// ------------------------------------------------------------------------
+// LDS-tiled cascade (depth-2 models, stride a multiple of shrink).
+//
+// A workgroup owns a tile of TR x TC windows of one level of one frame.  The
+// tile's channel footprint — nChns planes of ((TC-1)*step + mW) columns by
+// ((TR-1)*step + mH) rows — is read from the pyramid ONCE, with row-contiguous
+// (coalesced) loads, into LDS; every feature fetch of every tree then comes
+// from LDS.  With 32 x 16 windows of an 80x80 / 10-channel model that is 71 KB,
+// two workgroups per CU, and each pyramid cell is fetched ~2.8x per frame in
+// total instead of once per (window, tree node) touching it.
+//
+//   stage A  trees [b0,b1): one lane per window (lanes run along r, so a wave's
+//            LDS addresses are consecutive: conflict-free), node data by scalar
+//            loads from one level-independent table of LDS offsets.
+//   compaction in LDS (ballot prefix + one LDS atomic per wave), then
+//   stage B  [b1,b2) and stage C [b2,b3): dense lanes over the survivor list.
+//   stage D  [b3,b4): the handful of windows still alive get one WAVE each,
+//            lanes = 64 consecutive trees (wave_eval_trees below).
+//   survivors of the last tile stage go to the frame's tail queue (or are hits
+//   if the model has no more trees).
+//
+// Scores are those of ParallelDetectionBody::evaluate (acfDetect1.cpp:123-138):
+// every window adds the same leaves in the same order and stops at the first
+// h <= cascThr.
+// ------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gptr_t;  // global
+typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4* cptr4_t; // constant: loads through it may use the scalar unit
+
+struct CascTile
+{
+    int16_t level, pad_;
+    int16_t r0, c0; // first window row / column of the tile
+};
+
+struct __attribute__((aligned(16))) TreeNode
+{
+    uint32_t off[4]; // float offset of nodes 0,1,2 relative to the window's first cell; [3] unused
+    float thr[4];
+    float hs[4];     // leaves 3..6
+};
+
+struct TileGeom
+{
+    int32_t TR, TC, NW;        // window rows / columns per tile (TR * TC == 64 * NW), waves per workgroup
+    int32_t step;              // stride / shrink, cells between adjacent windows
+    int32_t rowsT, colsT;      // footprint rows / columns
+    int32_t rowsP;             // LDS column stride: rowsT rounded up to 4 floats (16-byte fill chunks)
+    int32_t tileFloats;        // nChns * colsT * rowsP
+    uint32_t cpsMagic, colsMagic; // ceil(2^32 / (rowsP/4)), ceil(2^32 / colsT): exact q/d by mulhi for every chunk index (checked at plan time)
+    int32_t b[5];              // stage boundaries b0=0 <= b1 <= b2 <= b3 <= b4 = tEnd
+    int32_t winFloats;         // nChns * mW * mH (tail kernel's per-wave window)
+};
+
+struct TileArgs
+{
+    const float* pyr;
+    int64_t pyr_fs;
+    const CascLevel* levels;
+    const CascTile* tiles;
+    int32_t nTiles, nFrames, nChns, mH, mW, nTrees;
+    TileGeom g;
+    const TreeNode* tileNodes;
+    const TreeNode* tailNodes;
+    float cascThr;
+    // tail queue [frame][qcap] {(level << 24) | window, h bits}; qcount[frame], qhead[frame]
+    uint2* q;
+    int32_t* qcount;
+    int32_t* qhead;
+    int32_t qcap;
+    acf_hip_hit* hits;
+    int32_t* counts;
+    int32_t maxHits;
+    int32_t debug; // timing experiments only (ACF_HIP_CASC_DEBUG): 1 = skip the tile fill, 2 = stop after the fill, 4 = phase stamps
+    long long* stamps; // [block][8] s_memtime at phase boundaries (debug & 4)
+};
+
+// Keep scalar / vector values materialised at this point: stops the compiler from
+// sinking the loads that produce them into the data-dependent selects below (which
+// turns straight-line select code into branches with a memory wait in every arm).
+#define ACF_PIN_S4(q) asm volatile("" ::"s"((q).x), "s"((q).y), "s"((q).z), "s"((q).w))
+#define ACF_PIN_V(x) asm volatile("" : "+v"(x))
+
+// Lanes = windows.  `win` points at the lane's window inside the LDS tile.  Trees are
+// taken TG at a time.  The node table is read through the constant address space, so
+// the (wave-uniform) loads go through the scalar unit: measured against wave-uniform
+// vector loads (12 per 4 trees, each a full 64-lane pass through the texture
+// addresser) the scalar path is 1.7x faster for the whole kernel; TG = 4 without
+// software prefetch measured faster than TG = 2 with the next batch requested early
+// (SGPR budget does not allow two batches of four).
+#define CASC_TG 4
+struct NodeBatch
+{
+    u32x4 o[CASC_TG], tq[CASC_TG], hq[CASC_TG];
+};
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) u32x16* cptr16_t;
+
+// CASC_TG = 4 nodes = 192 contiguous bytes = three s_load_dwordx16 (fewer, larger scalar requests)
+__device__ __forceinline__ void load_nodes(NodeBatch& b, const TreeNode* __restrict__ nodes, int t)
+{
+    cptr16_t np = (cptr16_t)(uintptr_t)(nodes + t);
+    const u32x16 q0 = np[0], q1 = np[1], q2 = np[2];
+    uint32_t w[48];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        w[i] = q0[i];
+        w[16 + i] = q1[i];
+        w[32 + i] = q2[i];
+    }
+#pragma unroll
+    for (int g = 0; g < CASC_TG; g++)
+    {
+        b.o[g] = u32x4{ w[12 * g + 0], w[12 * g + 1], w[12 * g + 2], w[12 * g + 3] };
+        b.tq[g] = u32x4{ w[12 * g + 4], w[12 * g + 5], w[12 * g + 6], w[12 * g + 7] };
+        b.hq[g] = u32x4{ w[12 * g + 8], w[12 * g + 9], w[12 * g + 10], w[12 * g + 11] };
+    }
+}
+
+__device__ __forceinline__ void tile_eval(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h, bool& alive)
+{
+    int t = t0;
+    for (; t + CASC_TG <= t1; t += CASC_TG)
+    {
+        if (!__any(alive))
+        {
+            return;
+        }
+        NodeBatch cur;
+        load_nodes(cur, nodes, t);
+        {
+            float f0[CASC_TG], f1[CASC_TG], f2[CASC_TG];
+#pragma unroll
+            for (int g = 0; g < CASC_TG; g++)
+            {
+                f0[g] = win[cur.o[g].x];
+                f1[g] = win[cur.o[g].y];
+                f2[g] = win[cur.o[g].z];
+            }
+#pragma unroll
+            for (int g = 0; g < CASC_TG; g++)
+            {
+                ACF_PIN_V(f0[g]);
+                ACF_PIN_V(f1[g]);
+                ACF_PIN_V(f2[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < CASC_TG; g++)
+            {
+                const bool lt0 = f0[g] < __uint_as_float(cur.tq[g].x);
+                const float fc = lt0 ? f1[g] : f2[g];
+                const float th1 = __uint_as_float(lt0 ? cur.tq[g].y : cur.tq[g].z);
+                const bool lt1 = fc < th1;
+                const float hv = __uint_as_float(lt0 ? (lt1 ? cur.hq[g].x : cur.hq[g].y) : (lt1 ? cur.hq[g].z : cur.hq[g].w));
+                const float hn = h + hv;
+                h = alive ? hn : h; // a rejected window keeps the score it was rejected with
+                alive = alive && (hn > thrC);
+            }
+        }
+    }
+    for (; t < t1; t++)
+    {
+        if (!__any(alive))
+        {
+            return;
+        }
+        cptr4_t np = (cptr4_t)(uintptr_t)(nodes + t);
+        const u32x4 o = np[0], tq = np[1], hq = np[2];
+        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
+        ACF_PIN_V(f0);
+        ACF_PIN_V(f1);
+        ACF_PIN_V(f2);
+        const bool lt0 = f0 < __uint_as_float(tq.x);
+        const float fc = lt0 ? f1 : f2;
+        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+        const bool lt1 = fc < th1;
+        const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
+        const float hn = h + hv;
+        h = alive ? hn : h;
+        alive = alive && (hn > thrC);
+    }
+}
+
+// Same, with the node table staged in LDS (three wave-uniform ds_read_b128 per
+// tree: every lane the same address, served as a broadcast).  Measured against the
+// scalar-load version above the per-batch latency drops from ~1700 to a few hundred
+// cycles: scalar-cache loads of a 192-byte batch were the slowest link of the
+// per-tile dependency chain.
+__device__ __forceinline__ void tile_eval_lds(const float* win, const uint4* nodesL, int t0, int t1, float thrC, float& h, bool& alive)
+{
+    constexpr int TG = 4;
+    int t = t0;
+    for (; t + TG <= t1; t += TG)
+    {
+        if (!__any(alive))
+        {
+            return;
+        }
+        uint4 o[TG], tq[TG], hq[TG];
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+        {
+            o[g] = nodesL[3 * (t + g) + 0];
+            tq[g] = nodesL[3 * (t + g) + 1];
+            hq[g] = nodesL[3 * (t + g) + 2];
+        }
+        float f0[TG], f1[TG], f2[TG];
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+        {
+            f0[g] = win[o[g].x];
+            f1[g] = win[o[g].y];
+            f2[g] = win[o[g].z];
+        }
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+        {
+            ACF_PIN_V(f0[g]);
+            ACF_PIN_V(f1[g]);
+            ACF_PIN_V(f2[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+        {
+            const bool lt0 = f0[g] < __uint_as_float(tq[g].x);
+            const float fc = lt0 ? f1[g] : f2[g];
+            const float th1 = __uint_as_float(lt0 ? tq[g].y : tq[g].z);
+            const bool lt1 = fc < th1;
+            const float hv = __uint_as_float(lt0 ? (lt1 ? hq[g].x : hq[g].y) : (lt1 ? hq[g].z : hq[g].w));
+            const float hn = h + hv;
+            h = alive ? hn : h;
+            alive = alive && (hn > thrC);
+        }
+    }
+    for (; t < t1; t++)
+    {
+        if (!__any(alive))
+        {
+            return;
+        }
+        const uint4 o = nodesL[3 * t + 0], tq = nodesL[3 * t + 1], hq = nodesL[3 * t + 2];
+        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
+        ACF_PIN_V(f0);
+        ACF_PIN_V(f1);
+        ACF_PIN_V(f2);
+        const bool lt0 = f0 < __uint_as_float(tq.x);
+        const float fc = lt0 ? f1 : f2;
+        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+        const bool lt1 = fc < th1;
+        const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
+        const float hn = h + hv;
+        h = alive ? hn : h;
+        alive = alive && (hn > thrC);
+    }
+}
+
+// Lanes = trees: one wave evaluates trees [t0,t1) of ONE window, 64 at a time.
+// Each lane walks its own tree against the window's features in LDS, then the
+// 64 leaf values are added to the running score strictly in tree order (a
+// wave-uniform chain of v_readlane + add); the window is rejected if any prefix
+// falls to cascThr or below — exactly evaluate()'s early exit.  Returns whether
+// the window is still alive after t1; h is exact for windows that are.
+__device__ __forceinline__ bool wave_eval_trees(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h)
+{
+    const int lane = threadIdx.x & 63;
+    for (int tb = t0; tb < t1; tb += 64)
+    {
+        const int nt = min(64, t1 - tb);
+        float hv = 0.f;
+        if (lane < nt)
+        {
+            const uint4* np = reinterpret_cast<const uint4*>(nodes + tb + lane);
+            const uint4 o = np[0];
+            const uint4 tq = np[1];
+            const uint4 hq = np[2];
+            const float f0 = win[o.x];
+            const bool lt0 = f0 < __uint_as_float(tq.x);
+            const float fc = win[lt0 ? o.y : o.z];
+            const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+            const bool lt1 = fc < th1;
+            hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
+        }
+        float m = h; // running minimum of the prefix scores
+        if (nt == 64)
+        {
+#pragma unroll
+            for (int q = 0; q < 64; q++)
+            {
+                h = h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), q));
+                asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+            }
+        }
+        else
+        {
+            for (int q = 0; q < nt; q++)
+            {
+                h = h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), q));
+                asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+            }
+        }
+        if (!(m > thrC) || !(h > thrC))
+        {
+            return false;
+        }
+    }
+    return true;
+}
+
+
+// Emit one wave's surviving lanes: hits if the model has no more trees, else
+// entries of the frame's tail queue.  One global atomic per wave.
+__device__ __forceinline__ void tile_emit(const TileArgs& a, bool final_, int frame, bool alive, int lvl, int n, int nWinR, float h)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (!mask)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0)
+    {
+        base = atomicAdd((final_ ? a.counts : a.qcount) + frame, __popcll(mask));
+    }
+    base = __shfl(base, 0);
+    if (alive)
+    {
+        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (final_)
+        {
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = n / nWinR;
+                hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+        else if (idx < a.qcap)
+        {
+            a.q[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
+        }
+    }
+}
+
+// Survivors of a tile stage -> LDS list {thread id in tile, h bits}.
+__device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2* list, int* cnt)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (!mask)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0)
+    {
+        base = atomicAdd(cnt, __popcll(mask)); // LDS atomic
+    }
+    base = __shfl(base, 0);
+    if (alive)
+    {
+        list[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(tag), __float_as_uint(h));
+    }
+}
+
+#define TILE_STAMP(k)                                                          \
+    if ((a.debug & 4) && threadIdx.x == 0)                                      \
+    {                                                                          \
+        a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    }
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
+{
+    extern __shared__ float lds[];
+    __shared__ int s_cnt[4];
+    float* tileF = lds;
+    uint2* list = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
+    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64); // trees [0, b2): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // Block -> (frame, tile).  Hardware block b runs on XCD b % 8: give every XCD
+    // one contiguous range of (frame-major) tiles, so tiles that share halo rows
+    // and columns — neighbours in this order — hit the same XCD's L2.
+    const int64_t total = int64_t(a.nTiles) * a.nFrames;
+    const int64_t perX = (total + 7) >> 3;
+    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
+    if (id >= total || (blockIdx.x >> 3) >= perX)
+    {
+        return;
+    }
+    const int frame = int(id / a.nTiles);
+    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+    const int lvl = T.level;
+    const CascLevel L = a.levels[lvl];
+    const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
+    const int gr0 = T.r0 * step, gc0 = T.c0 * step;
+    const int area = L.hP * L.wP;
+    const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+    const int colsValid = min(colsT, L.wP - gc0);
+
+    if (tid < 4)
+    {
+        s_cnt[tid] = 0;
+    }
+    for (int i = tid; i < 3 * a.g.b[2]; i += NW * 64)
+    {
+        nodesL[i] = reinterpret_cast<const uint4*>(a.tileNodes)[i];
+    }
+    TILE_STAMP(0);
+    // ---- fill.  The tile is nChns*colsT column segments of rowsP floats = rowsP/4
+    // 16-byte chunks each; chunk q lives at LDS float 4q.  One global_load_lds_dwordx4
+    // moves 64 chunks (1 KB) from 64 per-lane global addresses straight into LDS
+    // (LDS address = M0 + 16*lane: no VGPR round trip, no ds_write) — measured 4-byte
+    // LDS-DMA kept the LDS busy ~12k cycles per tile and starved the co-resident
+    // workgroup's feature reads; 16-byte chunks cut that four-fold.  Nothing waits
+    // between instructions, so a wave's ~9 requests are all in flight.  A segment's
+    // last chunk may run up to 3 floats past the rows the tile needs (into the next
+    // column / plane; the pyramid allocation is padded): those cells, like cells of
+    // columns beyond the plane (address clamped), are only reachable from windows
+    // outside the grid, whose lanes never contribute.
+    if (!(a.debug & 1))
+    {
+        const uint32_t cps = uint32_t(rowsP) >> 2;
+        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
+        const int ccMax = colsValid - 1;
+        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
+        {
+            const uint32_t q = q0 + lane;
+            if (q < nChunks)
+            {
+                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                const uint32_t j = q - seg * cps;
+                const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                const int cc = int(seg - z * uint32_t(colsT));
+                // level planes are < 2^31 floats (checked at plan time): 32-bit offsets
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(L.hP) + 4u * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    TILE_STAMP(1);
+    if (a.debug & 2)
+    {
+        return;
+    }
+
+    const float thrC = a.cascThr;
+    const int tEnd = a.g.b[4];
+    const bool lastAll = tEnd == a.nTrees;
+    // ---- stage A: lanes = windows
+    const int r_l = tid % a.g.TR, c_l = tid / a.g.TR;
+    const int wr = T.r0 + r_l, wc = T.c0 + c_l;
+    bool alive = wr < L.nWinR && wc < L.nWinC;
+    float h = 0.f;
+    if (a.g.b[1] <= a.g.b[2])
+    {
+        tile_eval_lds(tileF + (c_l * step) * rowsP + r_l * step, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
+    }
+    if (a.g.b[1] == tEnd)
+    {
+        tile_emit(a, lastAll, frame, alive, lvl, wc * L.nWinR + wr, L.nWinR, h);
+        return;
+    }
+    tile_compact(alive, tid, h, list, &s_cnt[0]);
+    __syncthreads();
+    TILE_STAMP(2);
+    // ---- stages B, C: dense lanes over the survivor list.  The list is compacted in
+    // place: every thread reads its entry, a barrier, then the survivors are rewritten.
+    int nIn = s_cnt[0];
+    for (int stage = 1; stage <= 2; stage++)
+    {
+        const int t0 = a.g.b[stage], t1 = a.g.b[stage + 1];
+        if (t0 == t1)
+        {
+            continue;
+        }
+        bool al = tid < nIn;
+        const uint2 e = al ? list[tid] : make_uint2(0u, 0u);
+        __syncthreads();
+        const int rl = int(e.x) % a.g.TR, cl = int(e.x) / a.g.TR;
+        float hh = __uint_as_float(e.y);
+        if (t1 <= a.g.b[2])
+        {
+            tile_eval_lds(tileF + (cl * step) * rowsP + rl * step, nodesL, t0, t1, thrC, hh, al);
+        }
+        else
+        {
+            tile_eval(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh, al);
+        }
+        if (t1 == tEnd)
+        {
+            tile_emit(a, lastAll, frame, al, lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh);
+            return;
+        }
+        tile_compact(al, int(e.x), hh, list, &s_cnt[stage]);
+        __syncthreads();
+        nIn = s_cnt[stage];
+    }
+    TILE_STAMP(3);
+    // ---- stage D: one wave per surviving window, lanes = trees
+    {
+        const int t0 = a.g.b[3], t1 = a.g.b[4];
+        for (int i = wv; i < nIn; i += NW)
+        {
+            const uint2 e = list[i];
+            const int rl = int(e.x) % a.g.TR, cl = int(e.x) / a.g.TR;
+            float hh = __uint_as_float(e.y);
+            const bool ok = wave_eval_trees(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh);
+            tile_emit(a, lastAll, frame, ok && lane == 0, lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh);
+        }
+    }
+    TILE_STAMP(4);
+}
+
+// Tail stage [tEnd, nTrees) of the tiled path: the few windows still alive each
+// need thousands of feature reads scattered over their own modelDsPad footprint.
+// One WAVE owns one window: the footprint (nChns*mW*mH floats — exactly the
+// cids[] index space, acfDetect1.cpp:390-406, so a feature id addresses it
+// directly) is copied to the wave's LDS slab, then wave_eval_trees runs the
+// remaining trees 64 at a time.  Waves pull windows from the frame's queue with
+// an atomic head counter, so long-lived windows do not stall a fixed partition.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* win = lds + wv * a.g.winFloats;
+    const int frame = blockIdx.x % a.nFrames;
+    const int cnt = min(a.qcount[frame], a.qcap);
+    const int mH = a.mH, mW = a.mW;
+    const int tEnd = a.g.b[4];
+    // lane -> (sub-row of this pass, row offset) for the footprint copy: SUB runs of mH floats per pass
+    const int SUB = max(1, min(64 / mH, mW)); // <= mW: one conditional wrap per step
+    const int sub = lane / mH, rr = lane - sub * mH;
+    const bool lact = sub < SUB;
+    const int rrc = lact ? rr : 0;
+    const int nRuns = a.nChns * mW;
+    for (;;)
+    {
+        int i = 0;
+        if (lane == 0)
+        {
+            i = atomicAdd(a.qhead + frame, 1);
+        }
+        i = __shfl(i, 0);
+        if (i >= cnt)
+        {
+            break;
+        }
+        const uint2 e = a.q[int64_t(frame) * a.qcap + i];
+        const int lvl = int(e.x >> 24);
+        const int n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR;
+        const int r = n - c * L.nWinR;
+        const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
+        const int area = L.hP * L.wP;
+        // copy: run = z * mW + cc  ->  win[run * mH + rr].  SUB consecutive runs (SUB*mH <= 64 lanes) per
+        // instruction, straight into LDS (global_load_lds_dword: LDS address = M0 + 4*lane); nothing waits
+        // between instructions, so the whole footprint is in flight at once.
+        if (mH <= 64)
+        {
+            int z = 0, cc = lact ? sub : 0;
+            const int zMax = a.nChns - 1;
+            for (int base = 0; base < nRuns; base += SUB) // wave-uniform trip count
+            {
+                if (lact && base + sub < nRuns)
+                {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(chn + (uint32_t(min(z, zMax)) * uint32_t(area) + uint32_t(cc * L.hP + rrc))),
+                        (lptr_t)(win + base * mH), 4, 0, 0);
+                }
+                cc += SUB;
+                if (cc >= mW)
+                {
+                    cc -= mW;
+                    z++;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        else
+        {
+            for (int f = lane; f < a.g.winFloats; f += 64)
+            {
+                const int run = f / mH, r2 = f - run * mH;
+                const int z = run / mW, cc = run - z * mW;
+                win[f] = chn[int64_t(z) * area + cc * L.hP + r2];
+            }
+        }
+        // the wave's own writes, read back by its own lanes: LDS ops of one wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        float h = __uint_as_float(e.y);
+        const bool ok = wave_eval_trees(win, a.tailNodes, tEnd, a.nTrees, a.cascThr, h);
+        if (ok && lane == 0)
+        {
+            const int idx = atomicAdd(a.counts + frame, 1);
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = c;
+                hit.r = r;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Sort each frame's hits into the reference's order (level, then c, then r:
 // ACF.cpp:326-329, acfDetect1.cpp:86-96) by rank counting, and map them to
 // image boxes (ACF.cpp:302-312).  Hit lists are small (<= maxHits), the keys

@@ -169,11 +169,15 @@ def test_rgb2luv(dev, oracle, h, w):
     assert np.array_equal(bits(g), bits(wg))
 
 
+@pytest.mark.parametrize("tiles", [1, 0])
 @pytest.mark.parametrize("depth", [2, 1, 3, 0])
-@pytest.mark.parametrize("nTrees", [128, 300, 20])
-def test_acf_detect1(dev, oracle, depth, nTrees):
+@pytest.mark.parametrize("nTrees", [128, 300, 20, 40, 70])
+def test_acf_detect1(dev, oracle, depth, nTrees, tiles):
     """The cascade on a random channel buffer: hits identical in number, order, position and score bits.
-    nTrees 20 / 128 / 300 end in the first / a queue / the LDS tail stage of the staged cascade."""
+    tiles=1: the LDS-tiled path (depth 2; its stages end at 16/32/64/128 trees, then the wave-per-window tail);
+    tiles=0 and the other depths: the global-memory staged path (first / queue / LDS tail kernels)."""
+    if tiles and depth != 2:
+        pytest.skip("tiled path is depth-2 only")
     nC, wP, hP = 10, 60, 44
     chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
     kw = dict(treeDepth=depth)
@@ -183,6 +187,50 @@ def test_acf_detect1(dev, oracle, depth, nTrees):
     m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
     m["hs"] = rnd(6, m["hs"].shape, -0.25, 0.2)
     m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
+    dev.set_option("cascade_tiles", tiles)
+    dev.set_model(m)
+    try:
+        got = dev.op_acf_detect1(chns)
+    finally:
+        dev.set_option("cascade_tiles", 1)
+    params, keep = capi.make_params(m)
+    want = np.zeros(1 << 16, dtype=capi.HIT_DTYPE)
+    n = oracle.lib().acfo_acf_detect1(chns.ctypes.data_as(C.c_void_p), 0, keep["thrs"].ctypes.data_as(C.c_void_p), hP, wP, nC,
+                                      C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
+    want = want[:n]
+    assert n > 0 and n < (wP - 3) * (hP - 3), n
+    assert len(got) == n
+    for k in ("scale", "c", "r"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(bits(got["score"]), bits(want["score"]))
+
+
+@pytest.mark.parametrize("case", ["stride8", "wide_model", "tall_plane", "one_window", "permissive"])
+def test_acf_detect1_tiled_geometries(dev, oracle, case):
+    """Tile edge cases of the LDS-tiled cascade: step 2 between windows, a non-square model, a plane with
+    many tiles along r, a plane that holds exactly one window, and a threshold nothing is rejected by
+    (every window reaches the tail queue)."""
+    nC = 10
+    kw = dict(name="TINY", nTrees=160, cascThr=-3.0)
+    wP, hP = 70, 50
+    if case == "stride8":
+        kw.update(stride=8)
+    elif case == "wide_model":
+        kw.update(modelDs_h=16, modelDs_w=40, modelDsPad_h=16, modelDsPad_w=40)
+    elif case == "tall_plane":
+        wP, hP = 24, 300
+    elif case == "one_window":
+        wP, hP = 4, 4
+        kw.update(cascThr=-50.0)
+    elif case == "permissive":
+        wP, hP = 40, 45
+        kw.update(cascThr=-50.0)
+    m = synth.make_model(seed=21, **kw)
+    mh, mw = m["modelDsPad_h"] // 4, m["modelDsPad_w"] // 4
+    chns = rnd(123, (nC, wP, hP), 0.0, 0.6)
+    m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
+    m["hs"] = rnd(6, m["hs"].shape, -0.25, 0.2)
+    m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * mh * mw)).astype(np.uint32).reshape(m["fids"].shape)
     dev.set_model(m)
     got = dev.op_acf_detect1(chns)
     params, keep = capi.make_params(m)
@@ -190,7 +238,7 @@ def test_acf_detect1(dev, oracle, depth, nTrees):
     n = oracle.lib().acfo_acf_detect1(chns.ctypes.data_as(C.c_void_p), 0, keep["thrs"].ctypes.data_as(C.c_void_p), hP, wP, nC,
                                       C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
     want = want[:n]
-    assert n > 0 and n < (wP - 3) * (hP - 3), n
+    assert n > 0, n
     assert len(got) == n
     for k in ("scale", "c", "r"):
         assert np.array_equal(got[k], want[k]), k
