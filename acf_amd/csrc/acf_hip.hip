@@ -65,6 +65,11 @@ struct acf_hip_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
+    // side streams: independent launches of one stage (the level groups) run concurrently, forked from and
+    // joined back into `stream` with events, so the stage costs its longest launch instead of their sum
+    std::vector<hipStream_t> side;
+    hipEvent_t evFork = nullptr;
+    std::vector<hipEvent_t> evJoin;
     mutable std::string err;
     bool hasModel = false, hasPlan = false;
     int taps = 0;
@@ -95,6 +100,17 @@ struct acf_hip_ctx
     float* d_ft = nullptr;
     SmoothJob* d_realJobs = nullptr; // one per real scale
     SmoothJob* d_finalJobs = nullptr;
+    LevelJob* d_levelJobs = nullptr;
+    float* d_dump = nullptr; // 64 floats nobody reads: target of stores from lanes past the end of a plane (keeps kernels branch-free)
+    LevelJob* d_levelJobsRaw = nullptr; // same levels, every one read from its raw channels (after a separate resample launch)
+    struct LevelGroup
+    {
+        int R, mode, first, count;
+    };
+    std::vector<LevelGroup> levelGroups, levelGroupsRaw; // jobs sorted into runs of equal (R, mode)
+    int levelMode = 1;                  // option "fused_levels": 1 fused resample+smooth, 2 separate resample + wave-per-plane smooth, 0 separate launches
+    bool fusedOk = false;      // the fused resample+smooth level kernel covers this plan
+    int noFused = 0;           // option "fused_levels" = 0: separate resample and smoothing launches
     PadJob* d_padJobs = nullptr;
     int finalMaxH = 0;
     int approxMaxBlocks = 0;
@@ -513,6 +529,17 @@ int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
         }
         c->ownStream = true;
     }
+    for (int i = 0; i < 6; i++)
+    {
+        hipStream_t st;
+        hipEvent_t ev;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
+        {
+            c->side.push_back(st);
+            c->evJoin.push_back(ev);
+        }
+    }
+    (void)hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
     *out = c;
     return ACF_HIP_OK;
 }
@@ -529,6 +556,18 @@ int acf_hip_destroy(acf_hip_ctx* c)
     for (hipEvent_t e : c->evPool)
     {
         (void)hipEventDestroy(e);
+    }
+    for (hipStream_t st : c->side)
+    {
+        (void)hipStreamDestroy(st);
+    }
+    for (hipEvent_t e : c->evJoin)
+    {
+        (void)hipEventDestroy(e);
+    }
+    if (c->evFork)
+    {
+        (void)hipEventDestroy(c->evFork);
     }
     if (c->ownStream)
     {
@@ -558,6 +597,12 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     {
         c->profile = value != 0;
         c->evUsed = 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "fused_levels"))
+    {
+        c->noFused = value == 0;
+        c->levelMode = value;
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "cascade_tiles"))
@@ -1148,6 +1193,67 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         padJobs.push_back(q);
         c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * l.hP * l.wP);
     }
+    // level jobs (k_level): every level, real ones read their raw channels, approximated ones resample on the
+    // fly; sorted into runs of equal (rows-per-lane R, mode) because both are template parameters of the kernel
+    {
+        struct Keyed
+        {
+            int key;
+            LevelJob j;
+        };
+        std::vector<Keyed> fusedJobs, rawJobs;
+        c->fusedOk = p.smooth > 0 && c->finalMaxH <= 64 * 8;
+        int ai = 0;
+        for (size_t i = 0; i < pl.levels.size(); i++)
+        {
+            const acf_hip_level& l = pl.levels[i];
+            LevelJob j{};
+            j.hC = l.hC;
+            j.wC = l.wC;
+            j.out_cs = l.hP;
+            j.in_off = pl.raw_off[i];
+            j.raw_off = pl.raw_off[i];
+            j.out_off = l.offset + int64_t(px) * l.hP + py;
+            j.in_ps = int64_t(l.hC) * l.wC;
+            j.out_ps = int64_t(l.hP) * l.wP;
+            j.desc = -1;
+            const int R = (l.hC + 63) / 64;
+            int mode = LM_REAL;
+            rawJobs.push_back({ R * 8 + LM_REAL, j });
+            if (!l.isReal)
+            {
+                j.desc = ai;
+                const ResampleDesc& dd = c->h_descs[size_t(c->nImgDescs + ai)];
+                if ((dd.ymode == RS_DOWN && dd.ybd0 > 3) || (dd.xmode == RS_DOWN && dd.xbd0 > 3) || dd.ymode == RS_EXACT || dd.xmode == RS_EXACT)
+                {
+                    c->fusedOk = false; // more than three taps on an axis or an exact 1/k ratio: separate launches
+                }
+                mode = dd.xmode == RS_DOWN ? (dd.ymode == RS_DOWN ? LM_DD : LM_DU) : (dd.ymode == RS_DOWN ? LM_UD : LM_UU);
+                ai++;
+            }
+            fusedJobs.push_back({ R * 8 + mode, j });
+        }
+        auto pack = [&](std::vector<Keyed>& v, std::vector<acf_hip_ctx::LevelGroup>& groups, LevelJob** dst) {
+            std::stable_sort(v.begin(), v.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+            std::vector<LevelJob> flat;
+            groups.clear();
+            for (const auto& k : v)
+            {
+                if (groups.empty() || groups.back().R * 8 + groups.back().mode != k.key)
+                {
+                    groups.push_back({ k.key / 8, k.key % 8, int(flat.size()), 0 });
+                }
+                groups.back().count++;
+                flat.push_back(k.j);
+            }
+            return devUpload(c, dst, flat);
+        };
+        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw)) ||
+            (rc = devAlloc(c, &c->d_dump, 64)))
+        {
+            return rc;
+        }
+    }
     if ((rc = devUpload(c, &c->d_descs, c->h_descs)) || (rc = devUpload(c, &c->d_it, arena.ints)) || (rc = devUpload(c, &c->d_ft, arena.floats)) ||
         (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)))
     {
@@ -1394,18 +1500,83 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         }
     }
 
-    // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
-    if (c->nApproxDescs > 0)
+    const int nL = int(pl.levels.size());
+    const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * 8 && c->levelMode != 0;
+    const bool fused = waveSmooth && c->fusedOk && c->levelMode == 1;
+    if (!fused && c->nApproxDescs > 0)
     {
+        // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
         prof(c, "k_resample(approx)");
         hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nF), dim3(64, 4), 0, c->stream,
             (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft);
         LAUNCHCHK(c, "k_resample(approx)");
     }
-
+    if (waveSmooth)
+    {
+        // ---- (approximated-scale resample +) smoothing + placement in the padded pyramid: one wave per plane (k_level)
+        const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
+        float* rawOut = (fused && c->taps) ? c->d_chns : nullptr;
+        const LevelJob* ljobs = fused ? c->d_levelJobs : c->d_levelJobsRaw;
+        const auto& groups = fused ? c->levelGroups : c->levelGroupsRaw;
+        const ResampleDesc* dd = c->d_descs + c->nImgDescs;
+        prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
+        // fork: every group is an independent launch (disjoint outputs); biggest planes first
+        const size_t nSide = c->side.size();
+        if (nSide && c->evFork)
+        {
+            HIPCHK(c, hipEventRecord(c->evFork, c->stream));
+            for (size_t k = 0; k < nSide; k++)
+            {
+                HIPCHK(c, hipStreamWaitEvent(c->side[k], c->evFork, 0));
+            }
+        }
+        size_t gi = 0;
+        for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
+        {
+            const auto& g = *git;
+            hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
+            dim3 grid(cdiv(pl.nChns, 4), g.count, nF), block(256);
+#define LV_LAUNCH(RR, MM)                                                                                                         \
+    hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs + g.first, dd, \
+        (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+#define LV_MODES(RR)                                  \
+    switch (g.mode)                                   \
+    {                                                 \
+        case LM_REAL: LV_LAUNCH(RR, LM_REAL); break;  \
+        case LM_DD: LV_LAUNCH(RR, LM_DD); break;      \
+        case LM_DU: LV_LAUNCH(RR, LM_DU); break;      \
+        case LM_UD: LV_LAUNCH(RR, LM_UD); break;      \
+        default: LV_LAUNCH(RR, LM_UU); break;         \
+    }
+            switch (g.R)
+            {
+                case 1: LV_MODES(1); break;
+                case 2: LV_MODES(2); break;
+                case 3: LV_MODES(3); break;
+                case 4: LV_MODES(4); break;
+                case 5: LV_MODES(5); break;
+                case 6: LV_MODES(6); break;
+                case 7: LV_MODES(7); break;
+                default: LV_MODES(8); break;
+            }
+#undef LV_MODES
+#undef LV_LAUNCH
+            LAUNCHCHK(c, "k_level");
+        }
+        if (nSide && c->evFork)
+        {
+            for (size_t k = 0; k < std::min(nSide, groups.size()); k++)
+            {
+                HIPCHK(c, hipEventRecord(c->evJoin[k], c->side[k]));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->evJoin[k], 0));
+            }
+        }
+    }
     // ---- smooth every plane of every level into the fused, padded pyramid (chnsPyramid.cpp:399-435)
-    const int nL = int(pl.levels.size());
-    if (p.smooth > 0)
+    if (waveSmooth)
+    {
+    }
+    else if (p.smooth > 0)
     {
         const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
         if ((rc = launchSmooth(c, c->d_chns, c->d_pyr, c->d_finalJobs, nL, pl.nChns, c->finalMaxH, pl.raw_floats, pl.pyr_floats, nF, pS, true)))

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <limits>
 
 namespace acfhip
@@ -239,6 +240,49 @@ int buildResample(int ha, int wa, int hb, int wb, ResampleDesc& d, TableArena& a
         arena.ints.insert(arena.ints.end(), cy.src.begin(), cy.src.end());
         d.y_wt = int(arena.floats.size());
         arena.floats.insert(arena.floats.end(), cy.wt.begin(), cy.wt.end());
+    }
+    // One 32-byte record per output column with everything the x pass of that column needs (first source
+    // column, tap count, first four weights): the fused level kernel fetches it with a single scalar load
+    // instead of chasing start[] -> src[] -> wt[].
+    while (arena.ints.size() % 8)
+    {
+        arena.ints.push_back(0);
+    }
+    d.x_col = int(arena.ints.size());
+    auto fbits = [](float f) {
+        int32_t b;
+        std::memcpy(&b, &f, 4);
+        return b;
+    };
+    for (int x = 0; x < wb; x++)
+    {
+        int32_t rec[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (d.xmode == RS_EXACT)
+        {
+            rec[0] = arena.ints[size_t(d.x_src) + x];
+            rec[1] = d.xk;
+        }
+        else if (d.xmode == RS_DOWN)
+        {
+            const int s0 = cx.start[size_t(x)], s1 = cx.start[size_t(x) + 1];
+            rec[0] = cx.src[size_t(s0)];
+            rec[1] = s1 - s0;
+            rec[2] = d.x_wt + s0;
+            for (int j = 0; j < 4 && j < s1 - s0; j++)
+            {
+                rec[4 + j] = fbits(cx.wt[size_t(s0 + j)]);
+            }
+        }
+        else
+        {
+            rec[0] = cx.src[size_t(x)];
+            rec[1] = 2;
+            rec[3] = (x < d.xbd0 || x >= wb - d.xbd1) ? 1 : 0;
+            const float w0 = cx.wt[size_t(x)];
+            rec[4] = fbits(w0);
+            rec[5] = fbits(1 - w0);
+        }
+        arena.ints.insert(arena.ints.end(), rec, rec + 8);
     }
     return ACF_HIP_OK;
 }

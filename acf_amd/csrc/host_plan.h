@@ -61,7 +61,7 @@ struct ResampleDesc
     float r[3];        // gain after the reference's /k and /(1+1e-6) (imResampleMex.cpp:145-157)
     float rk[3];       // r / yk for the exact y path (:286,:309,:316)
     int32_t nplanes;
-    int32_t pad_;
+    int32_t x_col;     // int-arena offset (multiple of 8) of the per-output-column records {xa, m, wofs, border, w0..w3 bits}
     int64_t src_off, dst_off; // float offsets inside the per-frame source / destination buffers
     int64_t src_frame_stride, dst_frame_stride;
 };

@@ -1040,6 +1040,343 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
     }
 }
 
+// ------------------------------------------------------------------------
+// Fused level kernel: approximated-scale resample (chnsPyramid.cpp:385-397) +
+// final convTri1 smoothing with the in-place aliasing (:399-407) + placement in
+// the padded, fused pyramid (:410-435), one pass, no intermediate plane.
+//
+// ONE WAVE owns one (level, channel) plane.  Lane l holds rows l, l+64, ... (R
+// per lane), so a column is R coalesced 256-byte accesses.  The smoothing
+// recursion along image-x needs T[y-1] and T[y+1] every column: with the rows
+// interleaved by 64 those live in the neighbouring LANES of the same register,
+// fetched with DPP wave rotates (lane 0 / 63 take the wrap-around value from the
+// adjacent register) — no LDS, no barrier, so a CU runs as many planes
+// concurrently as it has wave slots instead of one barrier-synchronised
+// workgroup per plane.  The column fed to the recursion is produced on the fly:
+// for a real level it is read from the raw channels, for an approximated level it
+// is resampled from the real level's raw channels with exactly the arithmetic of
+// k_resample (x pass then y pass, reference association order); the column two
+// steps ahead is requested while the current one is filtered.
+// ------------------------------------------------------------------------
+struct LevelJob
+{
+    int32_t hC, wC, out_cs, desc; // desc: index of the ResampleDesc of an approximated level, -1 for a real level
+    int64_t in_off;               // real level: float offset of its raw channels in the per-frame channel buffer
+    int64_t raw_off;              // where the level's raw (unsmoothed) channels go when taps are kept
+    int64_t out_off;              // float offset of the level's interior in the per-frame pyramid
+    int64_t in_ps, out_ps;        // plane strides
+};
+
+__device__ __forceinline__ float wave_rol1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false)); // lane l <- lane l+1 (63 <- 0)
+}
+__device__ __forceinline__ float wave_ror1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // lane l <- lane l-1 (0 <- 63)
+}
+
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) u32x8* cptr8_t;
+
+// LM_*: which column source a wave uses.  Levels are launched in groups of equal
+// (R, mode), so both are compile-time: R = ceil(h/64) exactly (every register but
+// the last holds 64 valid rows: no per-register guards) and only the arithmetic of
+// one resampling mode is in the instruction stream.  The code is written
+// branch-free on purpose — loads are unconditional on clamped addresses and
+// conditions are applied with selects afterwards — because a conditional load
+// becomes its own basic block with a full memory wait, which serialises every
+// access of the column (measured: 5x slower than the barrier kernel it replaces).
+enum
+{
+    LM_REAL = 0, // raw channels of a real level
+    LM_DD = 1,   // approximated level: x down, y down
+    LM_DU = 2,   // x down, y up
+    LM_UD = 3,   // x up, y down
+    LM_UU = 4
+};
+
+template <int R>
+struct LaneTaps
+{
+    uint32_t roff[R][3]; // clamped source row of y tap o (floats)
+    float wy[R][3];      // y weights, gain folded in (imResampleMex.cpp:158-161)
+    uint32_t bad[R];     // bit o: tap row >= ha (reads the zeroed tail of the column buffer, :133-137)
+    uint32_t one[R];     // y up: a clamped border row uses one tap only
+};
+
+// One column of an approximated level: x pass then y pass, reference association order
+// (imResampleMex.cpp:198-280, 319-373).
+template <int R, int MODE>
+__device__ __forceinline__ void level_column(float (&v)[R], int xb, const float* __restrict__ A, int h, const uint32_t (&yoff)[R],
+    int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, float* __restrict__ raw, bool lastOk)
+{
+    if (MODE == LM_REAL)
+    {
+        const float* __restrict__ col = A + int64_t(xb) * h;
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            v[k] = col[yoff[k]];
+        }
+        return;
+    }
+    constexpr bool XDOWN = MODE == LM_DD || MODE == LM_DU;
+    constexpr bool YDOWN = MODE == LM_DD || MODE == LM_UD;
+    // An approximated level is within a factor 2^(+-1/2) of its real level, so an output has at most three
+    // taps per axis when down-sampling and two when up-sampling (the plan falls back to separate launches
+    // otherwise).  All JX*NY source values of every register are requested before any is used.
+    constexpr int NY = YDOWN ? 3 : 2;
+    constexpr int JX = XDOWN ? 3 : 2;
+    const int xa = int(xr[0]), m = int(xr[1]);
+    const bool border = xr[3] != 0;
+    const float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
+    float a[JX][R][NY];
+#pragma unroll
+    for (int j = 0; j < JX; j++)
+    {
+        const float* __restrict__ col = A + int64_t(min(xa + j, wa - 1)) * ha;
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+#pragma unroll
+            for (int o = 0; o < NY; o++)
+            {
+                a[j][k][o] = col[tp.roff[k][o]];
+            }
+        }
+    }
+    // x pass: taps accumulate left to right (imResampleMex.cpp:198-280); y pass (:319-373)
+#pragma unroll
+    for (int k = 0; k < R; k++)
+    {
+        float c[NY];
+#pragma unroll
+        for (int o = 0; o < NY; o++)
+        {
+            float C;
+            if (XDOWN)
+            {
+                C = a[0][k][o] * w[0];
+                const float C2 = C + a[1][k][o] * w[1];
+                C = (m > 1) ? C2 : C;
+                const float C3 = C + a[2][k][o] * w[2];
+                C = (m > 2) ? C3 : C;
+            }
+            else
+            {
+                // up: A0*wt + A1*(1-wt); a clamped border column is copied (:264-280)
+                C = border ? a[0][k][o] : a[0][k][o] * w[0] + a[1][k][o] * w[1];
+            }
+            c[o] = ((tp.bad[k] >> o) & 1u) ? 0.f : C; // rows >= ha read the zeroed tail of the column buffer (:133-137)
+        }
+        float o_;
+        if (YDOWN)
+        {
+            // U(0)+U(1)(+U(2)) with exactly ybd0 terms (:324-348)
+            o_ = c[0] * tp.wy[k][0];
+            o_ = o_ + c[1] * tp.wy[k][1];
+            const float o3 = o_ + c[2] * tp.wy[k][2];
+            o_ = (ny > 2) ? o3 : o_;
+        }
+        else
+        {
+            const float o1 = c[0] * tp.wy[k][0];
+            const float o2 = o1 + c[1] * tp.wy[k][1];
+            o_ = tp.one[k] ? o1 : o2;
+        }
+        v[k] = o_;
+    }
+    if (raw)
+    {
+        float* __restrict__ rc = raw + int64_t(xb) * h;
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            if (k < R - 1 || lastOk)
+            {
+                rc[yoff[k]] = v[k];
+            }
+        }
+    }
+}
+
+template <int R, int MODE>
+__global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+    const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+{
+    const LevelJob J = jobs[blockIdx.y];
+    const int z = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (z >= nChns)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int h = J.hC, w = J.wC;
+    const int64_t f = blockIdx.z;
+    float* __restrict__ O = pyr + f * pyr_fs + J.out_off + int64_t(z) * J.out_ps;
+    const float* __restrict__ A;
+    float* __restrict__ raw = nullptr;
+    int ha = 0, wa = 0, ny = 0;
+    LaneTaps<R> tp;
+    uint32_t yoff[R];
+#pragma unroll
+    for (int k = 0; k < R; k++)
+    {
+        yoff[k] = uint32_t(min(lane + 64 * k, h - 1));
+    }
+    const bool lastOk = lane + 64 * (R - 1) < h; // rows of the last register beyond the plane are clamped duplicates: never stored
+    const int32_t* xcol = it;
+    if (MODE == LM_REAL)
+    {
+        A = chns + f * chns_fs + J.in_off + int64_t(z) * J.in_ps;
+    }
+    else
+    {
+        const ResampleDesc& d = descs[J.desc];
+        A = chns + f * chns_fs + d.src_off + int64_t(z) * d.ha * d.wa;
+        raw = rawOut ? rawOut + f * chns_fs + J.raw_off + int64_t(z) * J.in_ps : nullptr;
+        const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+        const float r = d.r[ty];
+        const int hb = d.hb;
+        ha = d.ha;
+        wa = d.wa;
+        xcol = it + d.x_col;
+        constexpr bool YDOWN = MODE == LM_DD || MODE == LM_UD;
+        ny = YDOWN ? d.ybd0 : 2;
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            const int ybc = int(yoff[k]); // == min(yb, hb - 1)
+            int ya;
+            tp.wy[k][0] = tp.wy[k][1] = tp.wy[k][2] = 0.f;
+            tp.one[k] = 0;
+            if (YDOWN)
+            {
+                const int q0 = it[d.y_start + ybc];
+                ya = it[d.y_src + q0];
+#pragma unroll
+                for (int o = 0; o < 3; o++)
+                {
+                    if (o < d.ybd0)
+                    {
+                        tp.wy[k][o] = ft[d.y_wt + q0 + o] * r;
+                    }
+                }
+            }
+            else
+            {
+                ya = it[d.y_src + ybc];
+                tp.wy[k][0] = ft[d.y_wt + ybc] * r;
+                tp.wy[k][1] = r - tp.wy[k][0];
+                tp.one[k] = (ybc < d.ybd0 || ybc >= hb - d.ybd1) ? 1u : 0u;
+            }
+            tp.bad[k] = 0;
+#pragma unroll
+            for (int o = 0; o < 3; o++)
+            {
+                tp.roff[k][o] = uint32_t(min(ya + o, ha - 1));
+                tp.bad[k] |= (ya + o >= ha) ? (1u << o) : 0u;
+            }
+        }
+    }
+    const float nrm = 1.0f / ((p + 2) * (p + 2));
+    const float p1 = 1 + p;
+    // Column records come through the scalar unit (constant address space) ahead of the column loads
+    // they drive; column loads are issued three steps before the recursion consumes them.  Four column
+    // buffers rotate through the roles (loop unrolled 4x) so no register is copied — a copy would force
+    // the wait for the load that feeds it.  The loop starts at i = -3: the first three steps only load.
+    cptr8_t xrec = (cptr8_t)(uintptr_t)xcol;
+    const u32x8 zrec = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    float b0[R], b1[R], b2[R], b3[R], prev[R];
+#pragma unroll
+    for (int k = 0; k < R; k++)
+    {
+        b0[k] = b1[k] = b2[k] = b3[k] = prev[k] = 0.f;
+    }
+    // The main loop body is straight-line code (no branch, not even a wave-uniform one): column indices
+    // are clamped instead of guarded and the last register's rows beyond the plane are stored to a dump
+    // slot instead of being masked.  vmcnt completes in order, and the compiler can only leave older
+    // loads in flight across a step if it sees the whole step as one basic block — with a branch per
+    // store it waited for the loads it had just issued, every step.
+    u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
+    u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
+    const int64_t lastRow = lane + 64 * (R - 1);
+#define LV_LOAD(FAR, COL)                                                                                           \
+    {                                                                                                               \
+        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, lastOk);                 \
+        xr = xrn;                                                                                                   \
+        xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
+    }
+#define LV_FILTER(I, CUR, NXT)                                                                                      \
+    {                                                                                                               \
+        const int i_ = (I);                                                                                         \
+        float T[R], up[R], dn[R];                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            const float Im = CUR[k];                                                                                \
+            const float Ir = (i_ < w - 1) ? NXT[k] : Im;                                                            \
+            const float Il = (i_ == 0) ? Im : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507) */              \
+            T[k] = nrm * (Il + p * Im + Ir);                                                                        \
+            up[k] = wave_ror1(T[k]); /* T[y-1] for lanes 1..63 */                                                   \
+            dn[k] = wave_rol1(T[k]); /* T[y+1] for lanes 0..62 */                                                   \
+        }                                                                                                           \
+        float* __restrict__ oc = O + int64_t(i_) * J.out_cs;                                                        \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            const int y = lane + 64 * k;                                                                            \
+            const float tm = (lane == 0) ? up[k > 0 ? k - 1 : 0] : up[k];       /* row y-1 */                       \
+            const float tpv = (lane == 63) ? dn[k + 1 < R ? k + 1 : k] : dn[k]; /* row y+1 */                       \
+            const float mid = tm + p * T[k] + tpv;                                                                  \
+            const float top = p1 * T[k] + tpv;                                                                      \
+            const float bot = tm + p1 * T[k];                                                                       \
+            const float o = (y == 0) ? top : ((y == h - 1) ? bot : mid);                                            \
+            prev[k] = o;                                                                                            \
+            if (k < R - 1)                                                                                          \
+            {                                                                                                       \
+                oc[y] = o;                                                                                          \
+            }                                                                                                       \
+            else                                                                                                    \
+            {                                                                                                       \
+                float* __restrict__ dst = lastOk ? (oc + lastRow) : (dump + lane);                                  \
+                *dst = o;                                                                                           \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
+    LV_LOAD(b0, 0);
+    LV_LOAD(b1, 1);
+    LV_LOAD(b2, 2);
+    int i = 0;
+    for (; i + 3 < w; i += 4)
+    {
+        LV_LOAD(b3, i + 3);
+        LV_FILTER(i, b0, b1);
+        LV_LOAD(b0, i + 4);
+        LV_FILTER(i + 1, b1, b2);
+        LV_LOAD(b1, i + 5);
+        LV_FILTER(i + 2, b2, b3);
+        LV_LOAD(b2, i + 6);
+        LV_FILTER(i + 3, b3, b0);
+    }
+    // tail: up to three columns; their inputs are already in b0, b1, b2
+    if (i < w)
+    {
+        LV_FILTER(i, b0, b1);
+    }
+    if (i + 1 < w)
+    {
+        LV_FILTER(i + 1, b1, b2);
+    }
+    if (i + 2 < w)
+    {
+        LV_FILTER(i + 2, b2, b2);
+    }
+#undef LV_LOAD
+#undef LV_FILTER
+}
+
 // grid.x needed for one descriptor
 static inline int resampleBlocks(const ResampleDesc& d)
 {

@@ -122,6 +122,8 @@ def main():
     det = HipDetector(model, H, W, 3, max_batch=B, max_hits=8192, device=local, stream=stream)
     if not args.no_profile:
         det.set_option("profile", 1)
+    if os.environ.get("ACF_BENCH_LEVEL_MODE"):  # A/B knob (profiles/ab_levels.sh)
+        det.set_option("fused_levels", int(os.environ["ACF_BENCH_LEVEL_MODE"]))
     rec = torch.zeros((B, 1 + 6 * args.cap), dtype=torch.int32, device=dev)
 
     def step():

@@ -34,10 +34,15 @@ def build(cfg, batch=1, taps=True):
     return det, model, (H, W, kind, d_in)
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("cfg", list(CONFIGS))
-def test_pipeline_bit_exact(oracle, cfg):
+def test_pipeline_bit_exact(oracle, cfg, fused):
+    """fused=1: approximated-scale resample + final smoothing in one wave-per-plane kernel (k_level_fused),
+    tiled cascade; fused=0: the separate resample / smoothing launches and the global-memory staged cascade."""
     import torch
     det, model, (H, W, kind, d_in) = build(cfg)
+    det.set_option("fused_levels", fused)
+    det.set_option("cascade_tiles", fused)
     frame = synth.make_frame(17, H, W, kind)
     plan = oracle.Plan(model, H, W, d_in)
     # plan geometry agrees (host_plan.cpp vs the oracle's independent restatement)
