@@ -387,17 +387,7 @@ float shrinkGainY(int S)
 int launchChns(acf_hip_ctx* c, const ChnsArgs& a, int shrink, int nFrames)
 {
     const int hc = a.h / shrink, wc = a.w / shrink;
-    dim3 grid(cdiv(hc, 256), wc, nFrames), block(256);
-    if (hc <= 64)
-    {
-        block = dim3(64);
-        grid = dim3(cdiv(hc, 64), wc, nFrames);
-    }
-    else if (hc <= 128)
-    {
-        block = dim3(128);
-        grid = dim3(cdiv(hc, 128), wc, nFrames);
-    }
+    dim3 grid(cdiv(int64_t(hc) * wc, 256), 1, nFrames), block(256);
     prof(c, "k_chns");
     if (shrink == 4)
     {
@@ -1462,8 +1452,14 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         if (p.gradMagEnabled || p.gradHistEnabled)
         {
             prof(c, "k_grad_mag");
-            hipLaunchKernelGGL(k_grad_mag, dim3(cdiv(rs.h, 256), rs.w, nF), dim3(256), 0, c->stream,
-                (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)(c->d_acos + 10010), rs.h, rs.w, p.full, int64_t(d) * np, np);
+            {
+                // enough workgroups to fill the chip twice over, each long enough to amortise its 80 KB table copy
+                const int rowBlocks = cdiv(rs.h, GM_ROWS), nStrips = cdiv(rs.w, GM_XT);
+                const int want = std::max(1, cdiv(1024, rowBlocks * nF));
+                const int spb = std::max(8, cdiv(nStrips, want));
+                hipLaunchKernelGGL(k_grad_mag_strip, dim3(rowBlocks, cdiv(nStrips, spb), nF), dim3(GM_ROWS), 0, c->stream,
+                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb);
+            }
             LAUNCHCHK(c, "k_grad_mag");
             if (p.normRad)
             {
@@ -2330,7 +2326,7 @@ int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O,
     {
         return fail(c, ACF_HIP_E_HIP, "op_gradient_mag: allocation");
     }
-    hipLaunchKernelGGL(k_grad_mag, dim3(cdiv(h, 256), w, 1), dim3(256), 0, c->stream, (const float*)di, dM, dO, (const float*)(c->d_acos + 10010), h, w, full, int64_t(0), int64_t(0));
+    hipLaunchKernelGGL(k_grad_mag_strip, dim3(cdiv(h, GM_ROWS), 1, 1), dim3(GM_ROWS), 0, c->stream, (const float*)di, dM, dO, (const float*)c->d_acos, h, w, full, int64_t(0), int64_t(0), cdiv(w, GM_XT));
     LAUNCHCHK(c, "k_grad_mag");
     if (normRad)
     {

@@ -353,6 +353,82 @@ __global__ void __launch_bounds__(256) k_grad_mag(const float* __restrict__ in, 
     O[o] = ov;
 }
 
+// Same arithmetic as k_grad_mag, organised for throughput.  A workgroup owns GM_ROWS
+// image rows of one frame and walks along image-x in strips of GM_XT columns:
+//  - the 20020-entry acos table (80 KB) is copied into LDS once per workgroup.  From
+//    global memory the lookup is a 4-byte gather in which every lane pulls its own
+//    128-byte line through a 32 KB L1 — on noise-like gradients that moved ~50x the
+//    useful bytes and made the lookup, not the image, the kernel's traffic;
+//  - the three x taps slide through registers (one row load per column instead of
+//    three), every load of a strip is issued before its first use, and border cases
+//    are clamped indices + selects (no branch around a load).
+#define GM_XT 8
+#define GM_ROWS 384
+#define GM_ACOS_N 20020
+__global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
+    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int stripsPerBlock)
+{
+    __shared__ float acosL[GM_ACOS_N];
+    for (int i = threadIdx.x; i < GM_ACOS_N; i += GM_ROWS)
+    {
+        acosL[i] = acosBase[i];
+    }
+    __syncthreads();
+    const float* acosT = acosL + 10010; // index 0 = centre of the table
+    const int y = blockIdx.x * GM_ROWS + threadIdx.x;
+    const int yc = min(y, h - 1);
+    const float* __restrict__ I = in + int64_t(blockIdx.z) * in_fs;
+    const int yu = max(yc - 1, 0), yd = min(yc + 1, h - 1);
+    const float ry = (yc == 0 || yc == h - 1) ? 1.f : .5f;
+    const int nStrips = (w + GM_XT - 1) / GM_XT;
+    const int s0 = blockIdx.y * stripsPerBlock, s1 = min(nStrips, s0 + stripsPerBlock);
+    for (int s = s0; s < s1; s++)
+    {
+        const int x0 = s * GM_XT;
+        float c[GM_XT + 2], up[GM_XT], dn[GM_XT];
+#pragma unroll
+        for (int j = 0; j < GM_XT + 2; j++)
+        {
+            const int x = min(max(x0 + j - 1, 0), w - 1);
+            c[j] = I[int64_t(x) * h + yc];
+        }
+#pragma unroll
+        for (int j = 0; j < GM_XT; j++)
+        {
+            const int x = min(x0 + j, w - 1);
+            up[j] = I[int64_t(x) * h + yu];
+            dn[j] = I[int64_t(x) * h + yd];
+        }
+#pragma unroll
+        for (int j = 0; j < GM_XT; j++)
+        {
+            const int x = x0 + j;
+            // grad1 :22-53 — one-sided differences with r = 1 at the first / last column, central * .5 inside
+            const float rx = (x == 0 || x == w - 1) ? 1.f : .5f;
+            const float gx = (c[j + 2] - c[j]) * rx;
+            const float gy = (dn[j] - up[j]) * ry;
+            const float m2 = gx * gx + gy * gy;
+            float m = 1.0f / sqrtf(m2);
+            m = m < 1e10f ? m : 1e10f;
+            float g = (gx * m) * 10000.0f;
+            g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
+            g = g < 10009.0f ? g : 10009.0f;
+            g = g > -10009.0f ? g : -10009.0f;
+            float ov = acosT[(int)g];
+            if (full)
+            {
+                ov += (gy < 0) * 3.14159265f;
+            }
+            if (x < w && y < h)
+            {
+                const int64_t o = int64_t(blockIdx.z) * out_fs + int64_t(x) * h + y;
+                M[o] = 1.0f / m;
+                O[o] = ov;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------
 // convTri radius r, x pass (toolbox/convConst.cpp:347-442): second-order
 // running sums along image-x, one thread per image row.  Writes U (the
@@ -390,26 +466,44 @@ __global__ void __launch_bounds__(256) k_tri_x(const float* __restrict__ in, flo
         U += nrm * T;
         Uc[int64_t(i) * h] = U;
     }
-    // body: r < i <= w - r, loads independent of the recurrence (TX_CH columns = 3*TX_CH loads in flight)
+    // body: r < i <= w - r.  Loads do not depend on the recurrence: TX_CH columns (3*TX_CH loads) are
+    // requested one whole chunk ahead of the chunk being summed, in two register sets that swap roles
+    // (loop unrolled 2x: no copies, so no wait for the set still in flight).
     constexpr int TX_CH = 8;
-    for (; i + TX_CH - 1 <= w - r; i += TX_CH)
+#define TX_LOAD(A_, B_, C_, I0)                                  \
+    _Pragma("unroll") for (int j = 0; j < TX_CH; j++)            \
+    {                                                            \
+        const int ii = min((I0) + j, w - r); /* clamped: a chunk past the body re-reads valid columns, unused */ \
+        A_[j] = I[int64_t(ii - 1 - r) * h];                      \
+        B_[j] = I[int64_t(ii - 1 + r) * h];                      \
+        C_[j] = I[int64_t(ii - 1) * h];                          \
+    }
+#define TX_SUM(A_, B_, C_, I0)                                   \
+    _Pragma("unroll") for (int j = 0; j < TX_CH; j++)            \
+    {                                                            \
+        T += A_[j] + B_[j] - 2 * C_[j];                          \
+        U += nrm * T;                                            \
+        Uc[int64_t((I0) + j) * h] = U;                           \
+    }
+    if (i + TX_CH - 1 <= w - r)
     {
-        float a[TX_CH], b[TX_CH], c[TX_CH];
-#pragma unroll
-        for (int j = 0; j < TX_CH; j++)
+        float a0[TX_CH], b0[TX_CH], c0[TX_CH], a1[TX_CH], b1[TX_CH], c1[TX_CH];
+        TX_LOAD(a0, b0, c0, i);
+        for (; i + 2 * TX_CH - 1 <= w - r; i += 2 * TX_CH)
         {
-            a[j] = I[int64_t(i + j - 1 - r) * h];
-            b[j] = I[int64_t(i + j - 1 + r) * h];
-            c[j] = I[int64_t(i + j - 1) * h];
+            TX_LOAD(a1, b1, c1, i + TX_CH);
+            TX_SUM(a0, b0, c0, i);
+            TX_LOAD(a0, b0, c0, i + 2 * TX_CH);
+            TX_SUM(a1, b1, c1, i + TX_CH);
         }
-#pragma unroll
-        for (int j = 0; j < TX_CH; j++)
+        if (i + TX_CH - 1 <= w - r)
         {
-            T += a[j] + b[j] - 2 * c[j];
-            U += nrm * T;
-            Uc[int64_t(i + j) * h] = U;
+            TX_SUM(a0, b0, c0, i);
+            i += TX_CH;
         }
     }
+#undef TX_LOAD
+#undef TX_SUM
     for (; i < w; i++)
     {
         const float Il = (i <= r) ? I[int64_t(r - i) * h] : I[int64_t(i - 1 - r) * h];
@@ -655,14 +749,17 @@ template <int S>
 __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
 {
     const int hc = a.h / S, wc = a.w / S;
-    const int yc = blockIdx.x * blockDim.x + threadIdx.x;
-    const int xc = blockIdx.y;
-    if (yc >= hc)
+    // cells are numbered column-major (yc fastest) and dealt to threads linearly, so every wave is full
+    // and its 64 cells are (mostly) one contiguous run of a cell column: 16-byte loads per lane, 1 KB per wave
+    const int64_t cells = int64_t(hc) * wc;
+    const int64_t cell = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (cell >= cells)
     {
         return;
     }
+    const int xc = int(cell / hc);
+    const int yc = int(cell - int64_t(xc) * hc);
     const int64_t f = blockIdx.z;
-    const int64_t cells = int64_t(hc) * wc;
     float* out = a.chns + f * a.chns_fs + int64_t(xc) * hc + yc;
     const int64_t pbase = int64_t(xc * S) * a.h + yc * S;
     int ch = 0;
