@@ -1657,6 +1657,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * 64 * 8 + size_t(48) * g.b[2];
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
+        prof(c, "k_cascade_tile");
 #define TILE_LAUNCH(N)                                                        \
     if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N>), lds)))                           \
         return rc;                                                            \
@@ -1704,6 +1705,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         {
             const size_t tl = size_t(cs.tailWaves) * g.winFloats * 4;
             dim3 tgrid(std::max(1, 512 / nF) * nF), tblock(cs.tailWaves * 64);
+            prof(c, "k_cascade_tail2");
 #define TAIL_LAUNCH(N)                                                        \
     if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail2<N>), tl)))                           \
         return rc;                                                            \

@@ -33,16 +33,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 
 def kernel_bytes_per_frame(det, model):
-    """Algorithmic (compulsory in+out) bytes per frame of each kernel, from the plan."""
+    """Algorithmic (compulsory in+out) bytes per frame of each kernel, from the plan (DESIGN.md §3)."""
     lv = det.levels
     nC = det.nChns
     d = 1 if model["colorSpace"] == 0 else 3
     sh = model["shrink"]
     real = [l for l in lv if l.isReal]
     np_real = [l.hC * sh * l.wC * sh for l in real]
-    cells = [l.hC * l.wC for l in lv]
-    raw = 4 * nC * sum(cells)
+    raw_real = 4 * nC * sum(l.hC * l.wC for l in real)
     pyr = 4 * det.pyr_floats
+    mh, mw = model["modelDsPad_h"] // sh, model["modelDsPad_w"] // sh
     b = {}
     b["k_smooth_tri1(image)"] = sum(2 * d * n * 4 for n in np_real)
     b["k_grad_mag"] = sum(3 * n * 4 for n in np_real)
@@ -50,13 +50,28 @@ def kernel_bytes_per_frame(det, model):
     b["k_tri_y"] = sum(2 * n * 4 for n in np_real)
     b["k_chns"] = sum((d + 3) * n * 4 + nC * (n // (sh * sh)) * 4 for n in np_real)
     b["k_resample(image)"] = sum(d * 4 * (np_real[0] if i == 1 else np_real[1]) + d * 4 * np_real[i] for i in range(1, len(np_real))) if len(np_real) > 1 else 0
-    b["k_resample(approx)"] = raw
-    b["k_smooth_tri1(levels)"] = raw + pyr
+    b["k_level(fused)"] = raw_real + pyr          # real levels' raw channels in, padded pyramid out
+    b["k_level(smooth)"] = 2 * pyr
+    b["k_resample(approx)"] = raw_real + pyr
+    b["k_smooth_tri1(levels)"] = 2 * pyr
+    b["k_cascade_tile"] = pyr                     # every pyramid cell read once (halo re-reads are L2 hits)
     b["k_cascade"] = pyr
+    b["k_cascade_tail2"] = 0                      # data dependent: (survivors of 128 trees) x 4*nC*mh*mw bytes, ~15 MB/frame here
     b["k_sort_map"] = 0
-    b["k_pad_reflect"] = 0
-    b["k_colour"] = 0
     return b
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("frames_per_step") != batch:
+            return None
+        return t["kernels"].get(kernel)
+    except Exception:
+        return None
 
 
 def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
@@ -172,25 +187,29 @@ def main():
                        "frames_per_gpu_per_step": B, "levels": len(det.levels), "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in det.levels)),
                        "mean_detections_per_frame": float(counts.mean()), "parallelism": "frames sharded, %d rank(s)" % world},
         }
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "bytes_per_frame": b_frame}
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if prof:
             tot_ms = sum(v[0] for v in prof.values())
             kb = kernel_bytes_per_frame(det, model)
             dom = max(prof, key=lambda k: prof[k][0])
-            # whole path: algorithmic bytes of all frames of all timed steps / summed kernel time (HIP events on the launch stream)
-            ach = b_frame * B * args.steps / (tot_ms * 1e-3) / 1e9
+            launches = max(prof[dom][1], 1)
+            avg_ms = prof[dom][0] / launches
+            frames_per_launch = B * args.steps / launches
+            # dominant kernel: its algorithmic bytes per launch / its average launch duration (HIP events on the launch stream)
+            ach = kb.get(dom, 0) * frames_per_launch / (avg_ms * 1e-3) / 1e9
+            path = b_frame * B * args.steps / (tot_ms * 1e-3) / 1e9
             roof.update({
-                "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                "scope": "whole hot path per step (all kernels); dominant kernel below",
-                "kernel": dom, "kernel_share": prof[dom][0] / tot_ms,
-                "kernel_avg_ms": prof[dom][0] / max(prof[dom][1], 1),
-                "kernel_achieved": (kb.get(dom, 0) * B * args.steps / (prof[dom][0] * 1e-3) / 1e9) if prof[dom][0] > 0 else None,
+                "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
+                "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_share": prof[dom][0] / tot_ms,
+                "kernel_bytes_per_launch": kb.get(dom, 0) * frames_per_launch,
+                # whole hot path on the same clock: B = B_in + 2*B_pyr per frame over the summed kernel time
+                "path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
                 "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             })
         else:
-            ach = b_frame * fps / world / 1e9
-            roof.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "scope": "whole hot path, wall clock"})
+            path = b_frame * fps / world / 1e9
+            roof.update({"path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
+                         "note": "per-kernel events disabled: whole path on the wall clock only"})
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, base_np, H, W)
