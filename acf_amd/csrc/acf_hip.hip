@@ -217,6 +217,7 @@ void freeAll(acf_hip_ctx* c)
     c->allocs.clear();
     c->hasPlan = false;
     c->d_lTable = c->d_acos = nullptr;
+    c->d_dump = nullptr;
 }
 
 // rgb2luv_setup's table (toolbox/rgbConvertMex.cpp:39-58)
@@ -302,7 +303,11 @@ int ensureConstTables(acf_hip_ctx* c)
     {
         return rc;
     }
-    return devUpload(c, &c->d_acos, makeAcosTable());
+    if ((rc = devUpload(c, &c->d_acos, makeAcosTable())))
+    {
+        return rc;
+    }
+    return devAlloc(c, &c->d_dump, 64);
 }
 
 inline int cdiv(int64_t a, int64_t b)
@@ -315,22 +320,33 @@ inline int cdiv(int64_t a, int64_t b)
 int launchSmooth(acf_hip_ctx* c, const float* in, float* out, const SmoothJob* d_jobs, int nJobs, int maxPlanes, int maxH,
     int64_t in_fs, int64_t out_fs, int nFrames, float p, bool aliased)
 {
-    // threads along y; up to 1024 per workgroup, R interleaved rows per thread
-    int nt = std::min(1024, ((maxH + 63) / 64) * 64);
-    if (maxH <= 512)
+    // threads along y, R interleaved rows per thread: the (nt, R) with the fewest idle row slots (every slot
+    // is computed: the kernel clamps instead of branching), fewer rows per thread on a tie
+    int nt = 64, R = 0;
+    int64_t best = -1;
+    for (int r = 1; r <= 4; r++)
     {
-        nt = std::min(nt, 256);
+        const int t = ((maxH + 64 * r - 1) / (64 * r)) * 64;
+        if (t <= 1024 && (best < 0 || int64_t(t) * r < best))
+        {
+            best = int64_t(t) * r;
+            nt = t;
+            R = r;
+        }
     }
-    const int R = (maxH + nt - 1) / nt;
+    if (!R)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "smooth: plane taller than 4096 rows");
+    }
     const int ldsStride = maxH + 1;
     prof(c, nJobs > 1 ? "k_smooth_tri1(levels)" : "k_smooth_tri1(image)");
     const size_t lds = 2 * size_t(ldsStride) * sizeof(float);
     dim3 grid(maxPlanes, nJobs, nFrames), block(nt);
 #define SM_LAUNCH(RR)                                                                                                    \
     if (aliased)                                                                                                         \
-        hipLaunchKernelGGL((k_smooth_tri1<RR, true>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride); \
+        hipLaunchKernelGGL((k_smooth_tri1<RR, true>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride, c->d_dump); \
     else                                                                                                                 \
-        hipLaunchKernelGGL((k_smooth_tri1<RR, false>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride);
+        hipLaunchKernelGGL((k_smooth_tri1<RR, false>), grid, block, lds, c->stream, in, out, d_jobs, in_fs, out_fs, p, ldsStride, c->d_dump);
     switch (R)
     {
         case 1:
@@ -1238,8 +1254,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             }
             return devUpload(c, dst, flat);
         };
-        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw)) ||
-            (rc = devAlloc(c, &c->d_dump, 64)))
+        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw)))
         {
             return rc;
         }

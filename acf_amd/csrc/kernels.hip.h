@@ -130,13 +130,17 @@ struct SmoothJob
     int64_t in_ps, out_ps;         // plane strides
 };
 
-// Columns are loaded SM_CH at a time, one chunk ahead of the recursion, so SM_CH
-// column loads per thread are in flight while a chunk is being filtered.
+// Columns are loaded SM_CH at a time, one whole chunk ahead of the chunk being
+// filtered, into two register sets that swap roles (main loop unrolled over two
+// chunks: no copies).  The main loop is straight-line code: row and column indices
+// are clamped instead of guarded and rows beyond the plane store to a dump slot,
+// because vmcnt completes in order and the compiler only keeps the next chunk's loads
+// in flight across a column step when it sees no branch between them.
 #define SM_CH 8
 
 template <int R, bool ALIASED>
 __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ in, float* __restrict__ out,
-    const SmoothJob* __restrict__ jobs, int64_t in_fs, int64_t out_fs, float p, int ldsStride)
+    const SmoothJob* __restrict__ jobs, int64_t in_fs, int64_t out_fs, float p, int ldsStride, float* __restrict__ dump)
 {
     extern __shared__ float lds[]; // 2 * ldsStride floats
     const SmoothJob job = jobs[blockIdx.y];
@@ -145,113 +149,135 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
         return;
     }
     const int h = job.h, w = job.w;
-    const float* I = in + int64_t(blockIdx.z) * in_fs + job.in_off + int64_t(blockIdx.x) * job.in_ps;
-    float* O = out + int64_t(blockIdx.z) * out_fs + job.out_off + int64_t(blockIdx.x) * job.out_ps;
+    const float* __restrict__ I = in + int64_t(blockIdx.z) * in_fs + job.in_off + int64_t(blockIdx.x) * job.in_ps;
+    float* __restrict__ O = out + int64_t(blockIdx.z) * out_fs + job.out_off + int64_t(blockIdx.x) * job.out_ps;
     const int tid = threadIdx.x, nt = blockDim.x;
     const float nrm = 1.0f / ((p + 2) * (p + 2));
     const float p1 = 1 + p;
-
-    float c[SM_CH][R], nx[SM_CH][R], prev[R];
+    int yk[R], ym[R], yp[R]; // this thread's rows (clamped) and their neighbours
+    bool ok[R];
 #pragma unroll
-    for (int j = 0; j < SM_CH; j++)
+    for (int k = 0; k < R; k++)
     {
-#pragma unroll
-        for (int k = 0; k < R; k++)
-        {
-            const int y = tid + k * nt;
-            c[j][k] = (j < w && y < h) ? I[int64_t(j) * h + y] : 0.f;
-        }
+        const int y = tid + k * nt;
+        ok[k] = y < h;
+        yk[k] = min(y, h - 1);
+        ym[k] = max(yk[k] - 1, 0);
+        yp[k] = min(yk[k] + 1, h - 1);
+    }
+    float c0[SM_CH][R], c1[SM_CH][R], prev[R], lastIn[R];
+#define SM_LOAD(BUF, I0)                                                          \
+    _Pragma("unroll") for (int j = 0; j < SM_CH; j++)                             \
+    {                                                                             \
+        const float* __restrict__ col = I + int64_t(min((I0) + j, w - 1)) * h;    \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                             \
+        {                                                                         \
+            BUF[j][k] = col[yk[k]];                                               \
+        }                                                                         \
+    }
+    // one column: CUR = column i, NXT = column i+1 (already clamped to w-1 by the loads)
+#define SM_COL(I_, CUR, NXT)                                                      \
+    {                                                                             \
+        const int i_ = (I_);                                                      \
+        float* Tb = lds + (i_ & 1) * ldsStride;                                   \
+        float T[R];                                                               \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                             \
+        {                                                                         \
+            const float Im = CUR[k];                                              \
+            const float Ir = NXT[k]; /* column min(i+1, w-1): Ir = Im at the last column (:508-512) */ \
+            const float Il = ALIASED ? ((i_ == 0) ? Im : prev[k]) : ((i_ == 0) ? Im : lastIn[k]);     \
+            T[k] = nrm * (Il + p * Im + Ir);                                      \
+            lastIn[k] = Im;                                                       \
+            Tb[yk[k]] = T[k]; /* rows beyond the plane rewrite row h-1 with its own value */          \
+        }                                                                         \
+        __syncthreads();                                                          \
+        float* __restrict__ oc = O + int64_t(i_) * job.out_cs;                    \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                             \
+        {                                                                         \
+            const float tm = Tb[ym[k]], tp = Tb[yp[k]];                           \
+            const float mid = tm + p * T[k] + tp;                                 \
+            const float top = p1 * T[k] + tp;                                     \
+            const float bot = tm + p1 * T[k];                                     \
+            const float o = (yk[k] == 0) ? top : ((yk[k] == h - 1) ? bot : mid);  \
+            prev[k] = o;                                                          \
+            float* __restrict__ dst = ok[k] ? (oc + yk[k]) : (dump + (tid & 63)); \
+            *dst = o;                                                             \
+        }                                                                         \
     }
 #pragma unroll
     for (int k = 0; k < R; k++)
     {
-        prev[k] = c[0][k]; // Il = Im at i == 0 (:503-507)
+        prev[k] = lastIn[k] = 0.f;
     }
-    int buf = 0;
-    for (int i0 = 0; i0 < w; i0 += SM_CH)
+    SM_LOAD(c0, 0);
+    int i = 0;
+    // main loop: two full chunks per iteration; needs columns i .. i + 2*SM_CH (the lookahead column is clamped)
+    for (; i + 2 * SM_CH <= w; i += 2 * SM_CH)
     {
+        SM_LOAD(c1, i + SM_CH);
 #pragma unroll
         for (int j = 0; j < SM_CH; j++)
         {
-#pragma unroll
-            for (int k = 0; k < R; k++)
+            if (j < SM_CH - 1)
             {
-                const int y = tid + k * nt;
-                const int col = i0 + SM_CH + j;
-                nx[j][k] = (col < w && y < h) ? I[int64_t(col) * h + y] : 0.f;
+                SM_COL(i + j, c0[j], c0[j + 1]);
+            }
+            else
+            {
+                SM_COL(i + j, c0[j], c1[0]);
             }
         }
+        SM_LOAD(c0, i + 2 * SM_CH);
 #pragma unroll
         for (int j = 0; j < SM_CH; j++)
         {
-            const int i = i0 + j;
-            if (i < w) // uniform across the workgroup
+            if (j < SM_CH - 1)
             {
-                float* Tb = lds + buf * ldsStride;
-                float T[R];
-#pragma unroll
-                for (int k = 0; k < R; k++)
-                {
-                    const int y = tid + k * nt;
-                    const float Im = c[j][k];
-                    const float Irn = (j < SM_CH - 1) ? c[(j + 1) % SM_CH][k] : nx[0][k];
-                    const float Ir = (i < w - 1) ? Irn : Im;
-                    const float Il = ALIASED ? prev[k] : ((i > 0) ? ((j > 0) ? c[(j + SM_CH - 1) % SM_CH][k] : prev[k]) : Im);
-                    T[k] = nrm * (Il + p * Im + Ir);
-                    if (y < h)
-                    {
-                        Tb[y] = T[k];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < R; k++)
-                {
-                    const int y = tid + k * nt;
-                    if (y < h)
-                    {
-                        float o;
-                        if (y == 0)
-                        {
-                            o = p1 * T[k] + Tb[1];
-                        }
-                        else if (y == h - 1)
-                        {
-                            o = Tb[y - 1] + p1 * T[k];
-                        }
-                        else
-                        {
-                            o = Tb[y - 1] + p * T[k] + Tb[y + 1];
-                        }
-                        O[int64_t(i) * job.out_cs + y] = o;
-                        if (ALIASED)
-                        {
-                            prev[k] = o;
-                        }
-                    }
-                }
-                buf ^= 1;
+                SM_COL(i + SM_CH + j, c1[j], c1[j + 1]);
             }
-        }
-        if (!ALIASED)
-        {
-            // non-aliased: Il of the next chunk's first column is this chunk's last input column
-#pragma unroll
-            for (int k = 0; k < R; k++)
+            else
             {
-                prev[k] = c[SM_CH - 1][k];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < SM_CH; j++)
-        {
-#pragma unroll
-            for (int k = 0; k < R; k++)
-            {
-                c[j][k] = nx[j][k];
+                SM_COL(i + SM_CH + j, c1[j], c0[0]);
             }
         }
     }
+    // tail: fewer than 2*SM_CH columns left; c0 holds columns i .. i+SM_CH-1 (clamped)
+    if (i < w)
+    {
+        SM_LOAD(c1, i + SM_CH);
+#pragma unroll
+        for (int j = 0; j < SM_CH; j++)
+        {
+            if (i + j < w) // uniform
+            {
+                if (j < SM_CH - 1)
+                {
+                    SM_COL(i + j, c0[j], c0[j + 1]);
+                }
+                else
+                {
+                    SM_COL(i + j, c0[j], c1[0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SM_CH; j++)
+        {
+            if (i + SM_CH + j < w) // uniform
+            {
+                if (j < SM_CH - 1)
+                {
+                    SM_COL(i + SM_CH + j, c1[j], c1[j + 1]);
+                }
+                else
+                {
+                    SM_COL(i + SM_CH + j, c1[j], c1[j]);
+                }
+            }
+        }
+    }
+#undef SM_LOAD
+#undef SM_COL
 }
 
 // cv::copyMakeBorder(BORDER_REFLECT) of the interior already written by the
