@@ -1219,28 +1219,50 @@ enum
     LM_UU = 4
 };
 
+// Buffer addressing (SRD in SGPRs + 32-bit per-lane byte offset + scalar byte offset): every access of the level
+// kernel is `buffer_load/store v, voff, srd, soff offen`, with no per-access VALU address arithmetic.  The
+// descriptor inputs are made provably wave-uniform with readfirstlane (cdna_hip_programming.md T20).
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, int64_t bytes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(a)), hi = __builtin_amdgcn_readfirstlane(uint32_t(a >> 32));
+    const uint32_t n = __builtin_amdgcn_readfirstlane(uint32_t(bytes > 0xffffffffll ? 0xffffffffll : bytes));
+    void* p = reinterpret_cast<void*>((uint64_t(hi) << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, int(n), 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(srd_t r, uint32_t voff, uint32_t soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st(srd_t r, uint32_t voff, uint32_t soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
 template <int R>
 struct LaneTaps
 {
-    uint32_t roff[R][3]; // clamped source row of y tap o (floats)
+    uint32_t roff[R][3]; // clamped source row of y tap o, as a BYTE offset in a source column
     float wy[R][3];      // y weights, gain folded in (imResampleMex.cpp:158-161)
     uint32_t bad[R];     // bit o: tap row >= ha (reads the zeroed tail of the column buffer, :133-137)
     uint32_t one[R];     // y up: a clamped border row uses one tap only
+    bool anyBad;         // wave-uniform: some lane has a tap row >= ha
 };
 
 // One column of an approximated level: x pass then y pass, reference association order
 // (imResampleMex.cpp:198-280, 319-373).
 template <int R, int MODE>
-__device__ __forceinline__ void level_column(float (&v)[R], int xb, const float* __restrict__ A, int h, const uint32_t (&yoff)[R],
-    int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, float* __restrict__ raw, bool lastOk)
+__device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int h, const uint32_t (&yoff)[R],
+    int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, srd_t raw, bool haveRaw, bool lastOk)
 {
     if (MODE == LM_REAL)
     {
-        const float* __restrict__ col = A + int64_t(xb) * h;
+        const uint32_t col = uint32_t(xb) * uint32_t(h) * 4u; // planes are < 2^30 floats: byte offsets fit 32 bits
 #pragma unroll
         for (int k = 0; k < R; k++)
         {
-            v[k] = col[yoff[k]];
+            v[k] = buf_ld(A, yoff[k], col);
         }
         return;
     }
@@ -1258,67 +1280,139 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, const float*
 #pragma unroll
     for (int j = 0; j < JX; j++)
     {
-        const float* __restrict__ col = A + int64_t(min(xa + j, wa - 1)) * ha;
+        const uint32_t col = uint32_t(min(xa + j, wa - 1)) * uint32_t(ha) * 4u;
 #pragma unroll
         for (int k = 0; k < R; k++)
         {
 #pragma unroll
             for (int o = 0; o < NY; o++)
             {
-                a[j][k][o] = col[tp.roff[k][o]];
+                a[j][k][o] = buf_ld(A, tp.roff[k][o], col);
             }
         }
     }
-    // x pass: taps accumulate left to right (imResampleMex.cpp:198-280); y pass (:319-373)
-#pragma unroll
-    for (int k = 0; k < R; k++)
+    // x pass: taps accumulate left to right (imResampleMex.cpp:198-280).  The tap count m and the border flag are
+    // wave-uniform per column: branch on them once (around arithmetic only — all loads are already in flight)
+    // instead of selecting per value.
+    float C[R][NY];
+    if (XDOWN)
     {
-        float c[NY];
+        if (m == 2)
+        {
 #pragma unroll
-        for (int o = 0; o < NY; o++)
-        {
-            float C;
-            if (XDOWN)
+            for (int k = 0; k < R; k++)
             {
-                C = a[0][k][o] * w[0];
-                const float C2 = C + a[1][k][o] * w[1];
-                C = (m > 1) ? C2 : C;
-                const float C3 = C + a[2][k][o] * w[2];
-                C = (m > 2) ? C3 : C;
+#pragma unroll
+                for (int o = 0; o < NY; o++)
+                {
+                    C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1];
+                }
             }
-            else
-            {
-                // up: A0*wt + A1*(1-wt); a clamped border column is copied (:264-280)
-                C = border ? a[0][k][o] : a[0][k][o] * w[0] + a[1][k][o] * w[1];
-            }
-            c[o] = ((tp.bad[k] >> o) & 1u) ? 0.f : C; // rows >= ha read the zeroed tail of the column buffer (:133-137)
         }
-        float o_;
-        if (YDOWN)
+        else if (m >= 3)
         {
-            // U(0)+U(1)(+U(2)) with exactly ybd0 terms (:324-348)
-            o_ = c[0] * tp.wy[k][0];
-            o_ = o_ + c[1] * tp.wy[k][1];
-            const float o3 = o_ + c[2] * tp.wy[k][2];
-            o_ = (ny > 2) ? o3 : o_;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+            {
+#pragma unroll
+                for (int o = 0; o < NY; o++)
+                {
+                    C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1] + a[2][k][o] * w[2];
+                }
+            }
         }
         else
         {
-            const float o1 = c[0] * tp.wy[k][0];
-            const float o2 = o1 + c[1] * tp.wy[k][1];
-            o_ = tp.one[k] ? o1 : o2;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+            {
+#pragma unroll
+                for (int o = 0; o < NY; o++)
+                {
+                    C[k][o] = a[0][k][o] * w[0];
+                }
+            }
         }
-        v[k] = o_;
     }
-    if (raw)
+    else if (border)
     {
-        float* __restrict__ rc = raw + int64_t(xb) * h;
+        // up: a clamped border column is copied (:264-280)
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+#pragma unroll
+            for (int o = 0; o < NY; o++)
+            {
+                C[k][o] = a[0][k][o];
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+#pragma unroll
+            for (int o = 0; o < NY; o++)
+            {
+                C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1]; // A0*wt + A1*(1-wt)
+            }
+        }
+    }
+    // rows >= ha read the zeroed tail of the reference's column buffer (:133-137): only the lanes of the plane's last
+    // rows can have such taps, so the select is skipped when no lane of the wave has one (tp.anyBad, wave-uniform)
+    if (tp.anyBad)
+    {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+#pragma unroll
+            for (int o = 0; o < NY; o++)
+            {
+                C[k][o] = ((tp.bad[k] >> o) & 1u) ? 0.f : C[k][o];
+            }
+        }
+    }
+    // y pass (:319-373)
+    if (YDOWN)
+    {
+        // U(0)+U(1)(+U(2)) with exactly ybd0 terms (:324-348); ny is wave-uniform
+        if (ny > 2)
+        {
+#pragma unroll
+            for (int k = 0; k < R; k++)
+            {
+                v[k] = C[k][0] * tp.wy[k][0] + C[k][1] * tp.wy[k][1] + C[k][2] * tp.wy[k][2];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < R; k++)
+            {
+                v[k] = C[k][0] * tp.wy[k][0] + C[k][1] * tp.wy[k][1];
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            const float o1 = C[k][0] * tp.wy[k][0];
+            const float o2 = o1 + C[k][1] * tp.wy[k][1];
+            v[k] = tp.one[k] ? o1 : o2;
+        }
+    }
+    if (haveRaw)
+    {
+        const uint32_t rc = uint32_t(xb) * uint32_t(h) * 4u;
 #pragma unroll
         for (int k = 0; k < R; k++)
         {
             if (k < R - 1 || lastOk)
             {
-                rc[yoff[k]] = v[k];
+                buf_st(raw, yoff[k], rc, v[k]);
             }
         }
     }
@@ -1330,7 +1424,9 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
     const LevelJob J = jobs[blockIdx.y];
-    const int z = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the plane index is the same for the 64 lanes of a wave; say so (readfirstlane), or every plane pointer is
+    // treated as per-lane and all address arithmetic lands on the VALU in 64 bits
+    const int z = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (z >= nChns)
     {
         return;
@@ -1338,28 +1434,32 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
     const int lane = threadIdx.x & 63;
     const int h = J.hC, w = J.wC;
     const int64_t f = blockIdx.z;
-    float* __restrict__ O = pyr + f * pyr_fs + J.out_off + int64_t(z) * J.out_ps;
-    const float* __restrict__ A;
-    float* __restrict__ raw = nullptr;
+    const srd_t Osrd = make_srd(pyr + f * pyr_fs + J.out_off + int64_t(z) * J.out_ps, (int64_t(w - 1) * J.out_cs + h) * 4);
+    srd_t A, raw = Osrd;
+    bool haveRaw = false;
     int ha = 0, wa = 0, ny = 0;
     LaneTaps<R> tp;
     uint32_t yoff[R];
 #pragma unroll
     for (int k = 0; k < R; k++)
     {
-        yoff[k] = uint32_t(min(lane + 64 * k, h - 1));
+        yoff[k] = 4u * uint32_t(min(lane + 64 * k, h - 1)); // byte offset of the lane's (clamped) row in a column
     }
     const bool lastOk = lane + 64 * (R - 1) < h; // rows of the last register beyond the plane are clamped duplicates: never stored
     const int32_t* xcol = it;
     if (MODE == LM_REAL)
     {
-        A = chns + f * chns_fs + J.in_off + int64_t(z) * J.in_ps;
+        A = make_srd(chns + f * chns_fs + J.in_off + int64_t(z) * J.in_ps, J.in_ps * 4);
     }
     else
     {
         const ResampleDesc& d = descs[J.desc];
-        A = chns + f * chns_fs + d.src_off + int64_t(z) * d.ha * d.wa;
-        raw = rawOut ? rawOut + f * chns_fs + J.raw_off + int64_t(z) * J.in_ps : nullptr;
+        A = make_srd(chns + f * chns_fs + d.src_off + int64_t(z) * d.ha * d.wa, int64_t(d.ha) * d.wa * 4);
+        haveRaw = rawOut != nullptr;
+        if (haveRaw)
+        {
+            raw = make_srd(rawOut + f * chns_fs + J.raw_off + int64_t(z) * J.in_ps, J.in_ps * 4);
+        }
         const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
         const float r = d.r[ty];
         const int hb = d.hb;
@@ -1371,7 +1471,7 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
 #pragma unroll
         for (int k = 0; k < R; k++)
         {
-            const int ybc = int(yoff[k]); // == min(yb, hb - 1)
+            const int ybc = int(yoff[k] >> 2); // == min(yb, hb - 1)
             int ya;
             tp.wy[k][0] = tp.wy[k][1] = tp.wy[k][2] = 0.f;
             tp.one[k] = 0;
@@ -1399,10 +1499,17 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
 #pragma unroll
             for (int o = 0; o < 3; o++)
             {
-                tp.roff[k][o] = uint32_t(min(ya + o, ha - 1));
+                tp.roff[k][o] = 4u * uint32_t(min(ya + o, ha - 1));
                 tp.bad[k] |= (ya + o >= ha) ? (1u << o) : 0u;
             }
         }
+        uint32_t anyb = 0;
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            anyb |= tp.bad[k];
+        }
+        tp.anyBad = __any(anyb != 0);
     }
     const float nrm = 1.0f / ((p + 2) * (p + 2));
     const float p1 = 1 + p;
@@ -1425,10 +1532,10 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
     // store it waited for the loads it had just issued, every step.
     u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
     u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
-    const int64_t lastRow = lane + 64 * (R - 1);
+    const int lastLane = (h - 1) & 63; // lane holding row h-1 in the last register
 #define LV_LOAD(FAR, COL)                                                                                           \
     {                                                                                                               \
-        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, lastOk);                 \
+        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, haveRaw, lastOk);        \
         xr = xrn;                                                                                                   \
         xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
     }
@@ -1445,7 +1552,7 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
             up[k] = wave_ror1(T[k]); /* T[y-1] for lanes 1..63 */                                                   \
             dn[k] = wave_rol1(T[k]); /* T[y+1] for lanes 0..62 */                                                   \
         }                                                                                                           \
-        float* __restrict__ oc = O + int64_t(i_) * J.out_cs;                                                        \
+        const uint32_t oc = uint32_t(i_) * uint32_t(J.out_cs) * 4u;                                                 \
         _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
         {                                                                                                           \
             const int y = lane + 64 * k;                                                                            \
@@ -1456,15 +1563,10 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
             const float bot = tm + p1 * T[k];                                                                       \
             const float o = (y == 0) ? top : ((y == h - 1) ? bot : mid);                                            \
             prev[k] = o;                                                                                            \
-            if (k < R - 1)                                                                                          \
-            {                                                                                                       \
-                oc[y] = o;                                                                                          \
-            }                                                                                                       \
-            else                                                                                                    \
-            {                                                                                                       \
-                float* __restrict__ dst = lastOk ? (oc + lastRow) : (dump + lane);                                  \
-                *dst = o;                                                                                           \
-            }                                                                                                       \
+            /* lanes past the end of the plane (last register only) are clamped to row h-1: they store row h-1's */ \
+            /* value to row h-1's address, so every store is unconditional and base + 32-bit offset             */ \
+            const float ov = (k < R - 1 || lastOk) ? o : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o), lastLane)); \
+            buf_st(Osrd, yoff[k], oc, ov);                                                                          \
         }                                                                                                           \
     }
     // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
