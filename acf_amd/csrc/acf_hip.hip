@@ -926,7 +926,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 const uint32_t cps = uint32_t(g.rowsP / 4), nSeg = uint32_t(nChns * g.colsT);
                 for (uint32_t q = 0; q < nSeg * cps && ok; q++)
                 {
-                    const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32);
+                    const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32); // a divisor of 1 has magic 2^32 = 0 in 32 bits: caught here
                     ok = seg == q / cps && uint32_t((uint64_t(seg) * g.colsMagic) >> 32) == seg / uint32_t(g.colsT);
                 }
             }

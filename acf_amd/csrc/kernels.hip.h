@@ -2275,25 +2275,46 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, const uint4* nod
 // wave-uniform chain of v_readlane + add); the window is rejected if any prefix
 // falls to cascThr or below — exactly evaluate()'s early exit.  Returns whether
 // the window is still alive after t1; h is exact for windows that are.
-__device__ __forceinline__ bool wave_eval_trees(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h)
+struct LaneNode
+{
+    uint4 o, tq, hq;
+};
+
+// lane's tree of the 64-tree batch starting at tb (clamped to the last tree: lanes past the end are masked by the caller)
+__device__ __forceinline__ LaneNode lane_node(const TreeNode* __restrict__ nodes, int tb, int t1)
+{
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + min(tb + int(threadIdx.x & 63), t1 - 1));
+    LaneNode n;
+    n.o = np[0];
+    n.tq = np[1];
+    n.hq = np[2];
+    return n;
+}
+
+// `first`: the batch at t0 already in registers (a wave that evaluates the same tree range for many windows loads
+// it once).  The next batch's nodes are requested before the current batch is scanned.
+__device__ __forceinline__ bool wave_eval_trees(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h,
+    const LaneNode& first)
 {
     const int lane = threadIdx.x & 63;
+    LaneNode cur = first;
     for (int tb = t0; tb < t1; tb += 64)
     {
         const int nt = min(64, t1 - tb);
-        float hv = 0.f;
-        if (lane < nt)
+        LaneNode nxt = cur;
+        if (tb + 64 < t1)
         {
-            const uint4* np = reinterpret_cast<const uint4*>(nodes + tb + lane);
-            const uint4 o = np[0];
-            const uint4 tq = np[1];
-            const uint4 hq = np[2];
-            const float f0 = win[o.x];
-            const bool lt0 = f0 < __uint_as_float(tq.x);
-            const float fc = win[lt0 ? o.y : o.z];
-            const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+            nxt = lane_node(nodes, tb + 64, t1);
+        }
+        float hv = 0.f;
+        {
+            const float f0 = win[cur.o.x];
+            const bool lt0 = f0 < __uint_as_float(cur.tq.x);
+            const float fc = win[lt0 ? cur.o.y : cur.o.z];
+            const float th1 = __uint_as_float(lt0 ? cur.tq.y : cur.tq.z);
             const bool lt1 = fc < th1;
-            hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
+            const float leaf = __uint_as_float(lt0 ? (lt1 ? cur.hq.x : cur.hq.y) : (lt1 ? cur.hq.z : cur.hq.w));
+            hv = (lane < nt) ? leaf : 0.f;
         }
         float m = h; // running minimum of the prefix scores
         if (nt == 64)
@@ -2317,6 +2338,7 @@ __device__ __forceinline__ bool wave_eval_trees(const float* win, const TreeNode
         {
             return false;
         }
+        cur = nxt;
     }
     return true;
 }
@@ -2521,12 +2543,13 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     // ---- stage D: one wave per surviving window, lanes = trees
     {
         const int t0 = a.g.b[3], t1 = a.g.b[4];
+        const LaneNode first = lane_node(a.tileNodes, t0, t1); // same trees for every survivor this wave takes
         for (int i = wv; i < nIn; i += NW)
         {
             const uint2 e = list[i];
             const int rl = int(e.x) % a.g.TR, cl = int(e.x) / a.g.TR;
             float hh = __uint_as_float(e.y);
-            const bool ok = wave_eval_trees(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh);
+            const bool ok = wave_eval_trees(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh, first);
             tile_emit(a, lastAll, frame, ok && lane == 0, lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh);
         }
     }
@@ -2556,6 +2579,9 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
     const bool lact = sub < SUB;
     const int rrc = lact ? rr : 0;
     const int nRuns = a.nChns * mW;
+    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees); // first tail batch: same trees for every window
+    const uint32_t cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(max(mH >> 2, 1)) - 1) / uint32_t(max(mH >> 2, 1)));
+    const uint32_t mwMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(mW) - 1) / uint32_t(mW));
     for (;;)
     {
         int i = 0;
@@ -2576,10 +2602,27 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
         const int r = n - c * L.nWinR;
         const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
         const int area = L.hP * L.wP;
-        // copy: run = z * mW + cc  ->  win[run * mH + rr].  SUB consecutive runs (SUB*mH <= 64 lanes) per
-        // instruction, straight into LDS (global_load_lds_dword: LDS address = M0 + 4*lane); nothing waits
-        // between instructions, so the whole footprint is in flight at once.
-        if (mH <= 64)
+        // copy: run = z * mW + cc  ->  win[run * mH + rr], straight into LDS by LDS-DMA (no VGPR round trip); nothing
+        // waits between instructions, so the whole footprint is in flight at once
+        if ((mH & 3) == 0)
+        {
+            // 16-byte chunks: chunk q = floats [4q, 4q+4) of the window; 64 chunks (1 KB) per instruction
+            const uint32_t cps = uint32_t(mH) >> 2, nChunks = uint32_t(nRuns) * cps;
+            for (uint32_t q0 = 0; q0 < nChunks; q0 += 64u)
+            {
+                const uint32_t q = q0 + lane;
+                if (q < nChunks)
+                {
+                    const uint32_t run = cps == 1 ? q : __umulhi(q, cpsMagic); // exact for q, cps < 2^16 (the magic of 1 is 2^32)
+                    const uint32_t j = q - run * cps;
+                    const uint32_t z = mW == 1 ? run : __umulhi(run, mwMagic);
+                    const uint32_t cc = run - z * uint32_t(mW);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(chn + (z * uint32_t(area) + cc * uint32_t(L.hP) + 4u * j)), (lptr_t)(win + 4u * q0), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        else if (mH <= 64)
         {
             int z = 0, cc = lact ? sub : 0;
             const int zMax = a.nChns - 1;
@@ -2611,7 +2654,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
         // the wave's own writes, read back by its own lanes: LDS ops of one wave complete in order
         __builtin_amdgcn_wave_barrier();
         float h = __uint_as_float(e.y);
-        const bool ok = wave_eval_trees(win, a.tailNodes, tEnd, a.nTrees, a.cascThr, h);
+        const bool ok = wave_eval_trees(win, a.tailNodes, tEnd, a.nTrees, a.cascThr, h, firstTail);
         if (ok && lane == 0)
         {
             const int idx = atomicAdd(a.counts + frame, 1);
