@@ -881,18 +881,23 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         }
         // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for two
         // workgroups per CU (160 KiB LDS), else one
+        int W = 1; // windows per lane in stage A (kernels.hip.h): node reads and address math shared by W windows
+        if (const char* e = getenv("ACF_HIP_CASC_W"))
+        {
+            W = atoi(e) == 2 ? 2 : 1; // measured: W = 2 halves the LDS node traffic but stage A is chain-latency bound, and fewer waves slow stage D
+        }
         auto ldsBytes = [&](int nw) {
-            const int tc = nw * 64 / g.TR;
+            const int tc = nw * W * 64 / g.TR;
             const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
             const int64_t rowsP = (rows + 3) / 4 * 4;
-            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * 64 * 8 + int64_t(48) * std::min(32, p.nTrees);
+            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * W * 64 * 8 + int64_t(48) * std::min(32, p.nTrees);
         };
         int nw = 0;
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
         {
-            for (int cand : { 8, 4, 2, 1 })
+            for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
             {
-                if (!nw && ldsBytes(cand) <= limit)
+                if (!nw && cand >= 1 && ldsBytes(cand) <= limit)
                 {
                     nw = cand;
                 }
@@ -912,7 +917,8 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         if (nw && tw)
         {
             g.NW = nw;
-            g.TC = nw * 64 / g.TR;
+            g.W = W;
+            g.TC = nw * W * 64 / g.TR;
             g.rowsT = (g.TR - 1) * g.step + mH;
             g.colsT = (g.TC - 1) * g.step + mW;
             g.rowsP = (g.rowsT + 3) / 4 * 4;
@@ -1669,28 +1675,23 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         const int64_t total = int64_t(cs.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * 64 * 8 + size_t(48) * g.b[2];
+        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[2];
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");
-#define TILE_LAUNCH(N)                                                        \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N>), lds)))                           \
-        return rc;                                                            \
-    hipLaunchKernelGGL(k_cascade_tile<N>, grid, block, lds, c->stream, a);
-        switch (g.NW)
+#define TILE_LAUNCH(N, WW)                                                                           \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N, WW>), lds)))              \
+        return rc;                                                                                   \
+    hipLaunchKernelGGL((k_cascade_tile<N, WW>), grid, block, lds, c->stream, a);
+        switch (g.NW * 4 + g.W)
         {
-            case 8:
-                TILE_LAUNCH(8);
-                break;
-            case 4:
-                TILE_LAUNCH(4);
-                break;
-            case 2:
-                TILE_LAUNCH(2);
-                break;
-            default:
-                TILE_LAUNCH(1);
-                break;
+            case 8 * 4 + 1: TILE_LAUNCH(8, 1); break;
+            case 4 * 4 + 1: TILE_LAUNCH(4, 1); break;
+            case 2 * 4 + 1: TILE_LAUNCH(2, 1); break;
+            case 1 * 4 + 1: TILE_LAUNCH(1, 1); break;
+            case 4 * 4 + 2: TILE_LAUNCH(4, 2); break;
+            case 2 * 4 + 2: TILE_LAUNCH(2, 2); break;
+            default: TILE_LAUNCH(1, 2); break;
         }
 #undef TILE_LAUNCH
         LAUNCHCHK(c, "k_cascade_tile");

@@ -2055,7 +2055,7 @@ struct __attribute__((aligned(16))) TreeNode
 
 struct TileGeom
 {
-    int32_t TR, TC, NW;        // window rows / columns per tile (TR * TC == 64 * NW), waves per workgroup
+    int32_t TR, TC, NW, W;     // window rows / columns per tile (TR * TC == 64 * NW * W), waves per workgroup, windows per lane
     int32_t step;              // stride / shrink, cells between adjacent windows
     int32_t rowsT, colsT;      // footprint rows / columns
     int32_t rowsP;             // LDS column stride: rowsT rounded up to 4 floats (16-byte fill chunks)
@@ -2196,76 +2196,101 @@ __device__ __forceinline__ void tile_eval(const float* win, const TreeNode* __re
     }
 }
 
-// Same, with the node table staged in LDS (three wave-uniform ds_read_b128 per
-// tree: every lane the same address, served as a broadcast).  Measured against the
-// scalar-load version above the per-batch latency drops from ~1700 to a few hundred
-// cycles: scalar-cache loads of a 192-byte batch were the slowest link of the
-// per-tile dependency chain.
-__device__ __forceinline__ void tile_eval_lds(const float* win, const uint4* nodesL, int t0, int t1, float thrC, float& h, bool& alive)
+// Same, with the node table staged in LDS and W windows per lane.  A node is packed as
+// {off0, off1, off2, thr0} {thr1, thr2, hs0, hs1} {hs2, hs3}: two ds_read_b128 and one
+// ds_read_b64, every lane the same address (served as a broadcast) — 10 LDS cycles per
+// tree instead of the 20 of three 12/16-byte reads of the unpacked layout.  Stage A is
+// LDS-bandwidth bound (every wave of the tile repeats the node reads), so with W > 1 a
+// lane evaluates W windows dW floats apart with ONE set of node reads and ONE set of
+// address computations per tree.
+template <int W>
+__device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const uint4* nodesL, int t0, int t1, float thrC, float (&h)[W], bool (&alive)[W])
 {
     constexpr int TG = 4;
     int t = t0;
+    // (requesting the next batch's nodes one iteration early was measured: no gain — the node reads are not on the
+    // critical path of a batch)
     for (; t + TG <= t1; t += TG)
     {
-        if (!__any(alive))
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < W; u++)
+        {
+            any = any || alive[u];
+        }
+        if (!__any(any))
         {
             return;
         }
-        uint4 o[TG], tq[TG], hq[TG];
+        uint4 q0[TG], q1[TG];
+        uint2 q2[TG];
 #pragma unroll
         for (int g = 0; g < TG; g++)
         {
-            o[g] = nodesL[3 * (t + g) + 0];
-            tq[g] = nodesL[3 * (t + g) + 1];
-            hq[g] = nodesL[3 * (t + g) + 2];
+            q0[g] = nodesL[3 * (t + g) + 0];
+            q1[g] = nodesL[3 * (t + g) + 1];
+            q2[g] = *reinterpret_cast<const uint2*>(nodesL + 3 * (t + g) + 2);
         }
-        float f0[TG], f1[TG], f2[TG];
+        float f0[W][TG], f1[W][TG], f2[W][TG];
 #pragma unroll
         for (int g = 0; g < TG; g++)
         {
-            f0[g] = win[o[g].x];
-            f1[g] = win[o[g].y];
-            f2[g] = win[o[g].z];
-        }
 #pragma unroll
-        for (int g = 0; g < TG; g++)
-        {
-            ACF_PIN_V(f0[g]);
-            ACF_PIN_V(f1[g]);
-            ACF_PIN_V(f2[g]);
+            for (int u = 0; u < W; u++)
+            {
+                f0[u][g] = win[q0[g].x + u * dW];
+                f1[u][g] = win[q0[g].y + u * dW];
+                f2[u][g] = win[q0[g].z + u * dW];
+            }
         }
 #pragma unroll
         for (int g = 0; g < TG; g++)
         {
-            const bool lt0 = f0[g] < __uint_as_float(tq[g].x);
-            const float fc = lt0 ? f1[g] : f2[g];
-            const float th1 = __uint_as_float(lt0 ? tq[g].y : tq[g].z);
-            const bool lt1 = fc < th1;
-            const float hv = __uint_as_float(lt0 ? (lt1 ? hq[g].x : hq[g].y) : (lt1 ? hq[g].z : hq[g].w));
-            const float hn = h + hv;
-            h = alive ? hn : h;
-            alive = alive && (hn > thrC);
+#pragma unroll
+            for (int u = 0; u < W; u++)
+            {
+                ACF_PIN_V(f0[u][g]);
+                ACF_PIN_V(f1[u][g]);
+                ACF_PIN_V(f2[u][g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < TG; g++)
+        {
+#pragma unroll
+            for (int u = 0; u < W; u++)
+            {
+                const bool lt0 = f0[u][g] < __uint_as_float(q0[g].w);
+                const float fc = lt0 ? f1[u][g] : f2[u][g];
+                const float th1 = __uint_as_float(lt0 ? q1[g].x : q1[g].y);
+                const bool lt1 = fc < th1;
+                const float hv = __uint_as_float(lt0 ? (lt1 ? q1[g].z : q1[g].w) : (lt1 ? q2[g].x : q2[g].y));
+                const float hn = h[u] + hv;
+                h[u] = alive[u] ? hn : h[u]; // a rejected window keeps the score it was rejected with
+                alive[u] = alive[u] && (hn > thrC);
+            }
         }
     }
     for (; t < t1; t++)
     {
-        if (!__any(alive))
+        const uint4 q0 = nodesL[3 * t + 0], q1 = nodesL[3 * t + 1];
+        const uint2 q2 = *reinterpret_cast<const uint2*>(nodesL + 3 * t + 2);
+#pragma unroll
+        for (int u = 0; u < W; u++)
         {
-            return;
+            float f0 = win[q0.x + u * dW], f1 = win[q0.y + u * dW], f2 = win[q0.z + u * dW];
+            ACF_PIN_V(f0);
+            ACF_PIN_V(f1);
+            ACF_PIN_V(f2);
+            const bool lt0 = f0 < __uint_as_float(q0.w);
+            const float fc = lt0 ? f1 : f2;
+            const float th1 = __uint_as_float(lt0 ? q1.x : q1.y);
+            const bool lt1 = fc < th1;
+            const float hv = __uint_as_float(lt0 ? (lt1 ? q1.z : q1.w) : (lt1 ? q2.x : q2.y));
+            const float hn = h[u] + hv;
+            h[u] = alive[u] ? hn : h[u];
+            alive[u] = alive[u] && (hn > thrC);
         }
-        const uint4 o = nodesL[3 * t + 0], tq = nodesL[3 * t + 1], hq = nodesL[3 * t + 2];
-        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
-        ACF_PIN_V(f0);
-        ACF_PIN_V(f1);
-        ACF_PIN_V(f2);
-        const bool lt0 = f0 < __uint_as_float(tq.x);
-        const float fc = lt0 ? f1 : f2;
-        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
-        const bool lt1 = fc < th1;
-        const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
-        const float hn = h + hv;
-        h = alive ? hn : h;
-        alive = alive && (hn > thrC);
     }
 }
 
@@ -2409,14 +2434,15 @@ __device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2
         a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     }
 
-template <int NW>
+// NW waves per tile, W windows per lane in stage A: the tile holds TR x TC = 64 * NW * W windows
+template <int NW, int W>
 __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
 {
     extern __shared__ float lds[];
     __shared__ int s_cnt[4];
     float* tileF = lds;
     uint2* list = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
-    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64); // trees [0, b2): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
+    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64 * W); // trees [0, b2): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // Block -> (frame, tile).  Hardware block b runs on XCD b % 8: give every XCD
@@ -2443,9 +2469,14 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     {
         s_cnt[tid] = 0;
     }
-    for (int i = tid; i < 3 * a.g.b[2]; i += NW * 64)
+    for (int t = tid; t < a.g.b[2]; t += NW * 64)
     {
-        nodesL[i] = reinterpret_cast<const uint4*>(a.tileNodes)[i];
+        // repack {off[4]} {thr[4]} {hs[4]} -> {off0, off1, off2, thr0} {thr1, thr2, hs0, hs1} {hs2, hs3, -, -}
+        const uint4* gp = reinterpret_cast<const uint4*>(a.tileNodes + t);
+        const uint4 o = gp[0], tq = gp[1], hq = gp[2];
+        nodesL[3 * t + 0] = make_uint4(o.x, o.y, o.z, tq.x);
+        nodesL[3 * t + 1] = make_uint4(tq.y, tq.z, hq.x, hq.y);
+        nodesL[3 * t + 2] = make_uint4(hq.z, hq.w, 0u, 0u);
     }
     TILE_STAMP(0);
     // ---- fill.  The tile is nChns*colsT column segments of rowsP floats = rowsP/4
@@ -2490,25 +2521,37 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     const float thrC = a.cascThr;
     const int tEnd = a.g.b[4];
     const bool lastAll = tEnd == a.nTrees;
-    // ---- stage A: lanes = windows
+    // ---- stage A: lanes = windows, W per lane (tile columns c_l + u * TC/W)
     const int r_l = tid % a.g.TR, c_l = tid / a.g.TR;
-    const int wr = T.r0 + r_l, wc = T.c0 + c_l;
-    bool alive = wr < L.nWinR && wc < L.nWinC;
-    float h = 0.f;
-    if (a.g.b[1] <= a.g.b[2])
+    const int cStep = a.g.TC / W;
+    const int wr = T.r0 + r_l;
+    bool alive[W];
+    float h[W];
+#pragma unroll
+    for (int u = 0; u < W; u++)
     {
-        tile_eval_lds(tileF + (c_l * step) * rowsP + r_l * step, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
+        alive[u] = wr < L.nWinR && (T.c0 + c_l + u * cStep) < L.nWinC;
+        h[u] = 0.f;
     }
+    tile_eval_lds<W>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
     if (a.g.b[1] == tEnd)
     {
-        tile_emit(a, lastAll, frame, alive, lvl, wc * L.nWinR + wr, L.nWinR, h);
+#pragma unroll
+        for (int u = 0; u < W; u++)
+        {
+            tile_emit(a, lastAll, frame, alive[u], lvl, (T.c0 + c_l + u * cStep) * L.nWinR + wr, L.nWinR, h[u]);
+        }
         return;
     }
-    tile_compact(alive, tid, h, list, &s_cnt[0]);
+#pragma unroll
+    for (int u = 0; u < W; u++)
+    {
+        tile_compact(alive[u], (c_l + u * cStep) * a.g.TR + r_l, h[u], list, &s_cnt[0]);
+    }
     __syncthreads();
     TILE_STAMP(2);
-    // ---- stages B, C: dense lanes over the survivor list.  The list is compacted in
-    // place: every thread reads its entry, a barrier, then the survivors are rewritten.
+    // ---- stages B, C: dense lanes over the survivor list (tag = c * TR + r).  The list is compacted in
+    // place: every thread reads its entries, a barrier, then the survivors are rewritten.
     int nIn = s_cnt[0];
     for (int stage = 1; stage <= 2; stage++)
     {
@@ -2517,25 +2560,50 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
         {
             continue;
         }
-        bool al = tid < nIn;
-        const uint2 e = al ? list[tid] : make_uint2(0u, 0u);
-        __syncthreads();
-        const int rl = int(e.x) % a.g.TR, cl = int(e.x) / a.g.TR;
-        float hh = __uint_as_float(e.y);
-        if (t1 <= a.g.b[2])
+        bool al[W];
+        uint2 e[W];
+        float hh[W];
+#pragma unroll
+        for (int u = 0; u < W; u++)
         {
-            tile_eval_lds(tileF + (cl * step) * rowsP + rl * step, nodesL, t0, t1, thrC, hh, al);
+            const int idx = tid + u * NW * 64;
+            al[u] = idx < nIn;
+            e[u] = al[u] ? list[idx] : make_uint2(0u, 0u);
+            hh[u] = __uint_as_float(e[u].y);
         }
-        else
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < W; u++)
         {
-            tile_eval(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh, al);
+            const int rl = int(e[u].x) % a.g.TR, cl = int(e[u].x) / a.g.TR;
+            float h1[1] = { hh[u] };
+            bool a1[1] = { al[u] };
+            if (t1 <= a.g.b[2])
+            {
+                tile_eval_lds<1>(tileF + (cl * step) * rowsP + rl * step, 0, nodesL, t0, t1, thrC, h1, a1);
+            }
+            else
+            {
+                tile_eval(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, h1[0], a1[0]);
+            }
+            hh[u] = h1[0];
+            al[u] = a1[0];
         }
         if (t1 == tEnd)
         {
-            tile_emit(a, lastAll, frame, al, lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh);
+#pragma unroll
+            for (int u = 0; u < W; u++)
+            {
+                const int rl = int(e[u].x) % a.g.TR, cl = int(e[u].x) / a.g.TR;
+                tile_emit(a, lastAll, frame, al[u], lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh[u]);
+            }
             return;
         }
-        tile_compact(al, int(e.x), hh, list, &s_cnt[stage]);
+#pragma unroll
+        for (int u = 0; u < W; u++)
+        {
+            tile_compact(al[u], int(e[u].x), hh[u], list, &s_cnt[stage]);
+        }
         __syncthreads();
         nIn = s_cnt[stage];
     }
