@@ -68,6 +68,12 @@ struct acf_hip_ctx
     // side streams: independent launches of one stage (the level groups) run concurrently, forked from and
     // joined back into `stream` with events, so the stage costs its longest launch instead of their sum
     std::vector<hipStream_t> side;
+    // Sub-batch contexts (option "streams" = K > 1): the batch is cut into K contiguous chunks, each run by a child
+    // context with its own buffers and stream, forked from / joined into `stream` by events.  The path is a chain of
+    // kernels several of which are latency-bound inside a frame (column recursions, per-tile dependency chains):
+    // chunks at different stages of the chain fill each other's idle issue slots and memory time.
+    std::vector<acf_hip_ctx*> kids;
+    int nStreams = 1, kidChunk = 0;
     hipEvent_t evFork = nullptr;
     std::vector<hipEvent_t> evJoin;
     mutable std::string err;
@@ -493,7 +499,41 @@ __global__ void __launch_bounds__(256) k_copy_planes(const float* __restrict__ i
         in[int64_t(blockIdx.z) * in_fs + j.in_off + int64_t(z) * j.in_ps + rem];
 }
 
+
+namespace
+{
+int kidsFork(acf_hip_ctx* c)
+{
+    HIPCHK(c, hipEventRecord(c->evFork, c->stream));
+    for (acf_hip_ctx* k : c->kids)
+    {
+        HIPCHK(c, hipStreamWaitEvent(k->stream, c->evFork, 0));
+    }
+    return ACF_HIP_OK;
+}
+int kidsJoin(acf_hip_ctx* c)
+{
+    for (size_t i = 0; i < c->kids.size(); i++)
+    {
+        HIPCHK(c, hipEventRecord(c->evJoin[i], c->kids[i]->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evJoin[i], 0));
+    }
+    return ACF_HIP_OK;
+}
+int kidFail(acf_hip_ctx* c, acf_hip_ctx* k, int rc)
+{
+    c->err = k->err;
+    return rc;
+}
+// frames of the last batch owned by child i: [i * chunk, min(n, (i+1) * chunk))
+int kidCount(const acf_hip_ctx* c, size_t i, int n)
+{
+    return std::max(0, std::min(n, int(i + 1) * c->kidChunk) - int(i) * c->kidChunk);
+}
+} // namespace
+
 extern "C" {
+
 
 int acf_hip_abi_version(void)
 {
@@ -552,6 +592,14 @@ int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
 
 int acf_hip_destroy(acf_hip_ctx* c)
 {
+    if (c)
+    {
+        for (acf_hip_ctx* k : c->kids)
+        {
+            (void)acf_hip_destroy(k);
+        }
+        c->kids.clear();
+    }
     if (!c)
     {
         return ACF_HIP_E_INVALID;
@@ -593,6 +641,19 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!c || !key)
     {
         return ACF_HIP_E_INVALID;
+    }
+    if (!strcmp(key, "streams"))
+    {
+        if (value < 1 || value > 6)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "streams: 1..6");
+        }
+        c->nStreams = value; // takes effect at the next acf_hip_plan
+        return ACF_HIP_OK;
+    }
+    for (acf_hip_ctx* k : c->kids)
+    {
+        (void)acf_hip_set_option(k, key, value);
     }
     if (!strcmp(key, "taps"))
     {
@@ -673,6 +734,14 @@ int acf_hip_plan_levels(const acf_hip_params* p, int h, int w, int d, acf_hip_le
 
 int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
 {
+    if (c)
+    {
+        for (acf_hip_ctx* k : c->kids)
+        {
+            (void)acf_hip_destroy(k);
+        }
+        c->kids.clear();
+    }
     if (!c || !p)
     {
         return ACF_HIP_E_INVALID;
@@ -1016,6 +1085,40 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     if (rc)
     {
         return rc;
+    }
+    for (acf_hip_ctx* k : c->kids)
+    {
+        (void)acf_hip_destroy(k);
+    }
+    c->kids.clear();
+    if (c->nStreams > 1 && max_batch >= 2 * c->nStreams && c->evFork && int(c->evJoin.size()) >= c->nStreams)
+    {
+        // sub-batch contexts: this context keeps only the plan's geometry; every device buffer lives in a child
+        c->kidChunk = (max_batch + c->nStreams - 1) / c->nStreams;
+        for (int i = 0; i < c->nStreams; i++)
+        {
+            acf_hip_ctx* k = nullptr;
+            if ((rc = acf_hip_create(c->device, nullptr, &k)))
+            {
+                return fail(c, rc, "plan: cannot create a sub-batch context");
+            }
+            c->kids.push_back(k);
+            k->taps = c->taps;
+            k->profile = c->profile;
+            k->noTiles = c->noTiles;
+            k->noFused = c->noFused;
+            k->levelMode = c->levelMode;
+            if ((rc = acf_hip_set_model(k, &c->p)) || (rc = acf_hip_plan(k, H, W, d_in, c->kidChunk, max_hits)))
+            {
+                return kidFail(c, k, rc);
+            }
+        }
+        c->maxBatch = max_batch;
+        c->maxHits = max_hits;
+        c->hasPlan = true;
+        c->pyramidValid = c->detectValid = false;
+        c->lastBatch = 0;
+        return ACF_HIP_OK;
     }
     Plan& pl = c->plan;
     // smoothing radii the recursion kernel implements (convTri.cpp:215-218)
@@ -1365,6 +1468,27 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
 
 int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
 {
+    if (c && !c->kids.empty())
+    {
+        if (!frames || nF <= 0 || nF > c->maxBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
+        }
+        const size_t per = size_t(c->plan.d_in) * c->plan.H * c->plan.W;
+        int rc = kidsFork(c);
+        for (size_t i = 0; i < c->kids.size() && !rc; i++)
+        {
+            const int n = kidCount(c, i, nF);
+            if (n > 0 && (rc = acf_hip_pyramid(c->kids[i], frames + i * size_t(c->kidChunk) * per, n)))
+            {
+                return kidFail(c, c->kids[i], rc);
+            }
+        }
+        c->lastBatch = nF;
+        c->pyramidValid = true;
+        c->detectValid = false;
+        return rc ? rc : kidsJoin(c);
+    }
     if (!c || !c->hasPlan)
     {
         return c ? fail(c, ACF_HIP_E_NOPLAN, "pyramid: plan first") : ACF_HIP_E_INVALID;
@@ -1884,6 +2008,23 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
 
 int acf_hip_detect(acf_hip_ctx* c)
 {
+    if (c && !c->kids.empty())
+    {
+        if (!c->pyramidValid)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "detect: no pyramid (call acf_hip_pyramid)");
+        }
+        int rc = kidsFork(c);
+        for (size_t i = 0; i < c->kids.size() && !rc; i++)
+        {
+            if (kidCount(c, i, c->lastBatch) > 0 && (rc = acf_hip_detect(c->kids[i])))
+            {
+                return kidFail(c, c->kids[i], rc);
+            }
+        }
+        c->detectValid = true;
+        return rc ? rc : kidsJoin(c);
+    }
     if (!c || !c->hasPlan)
     {
         return c ? fail(c, ACF_HIP_E_NOPLAN, "detect: plan first") : ACF_HIP_E_INVALID;
@@ -1904,6 +2045,26 @@ int acf_hip_detect(acf_hip_ctx* c)
 
 int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
 {
+    if (c && !c->kids.empty())
+    {
+        if (!frames || nF <= 0 || nF > c->maxBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "run: n_frames out of range");
+        }
+        const size_t per = size_t(c->plan.d_in) * c->plan.H * c->plan.W;
+        int rc = kidsFork(c);
+        for (size_t i = 0; i < c->kids.size() && !rc; i++)
+        {
+            const int n = kidCount(c, i, nF);
+            if (n > 0 && (rc = acf_hip_run(c->kids[i], frames + i * size_t(c->kidChunk) * per, n)))
+            {
+                return kidFail(c, c->kids[i], rc);
+            }
+        }
+        c->lastBatch = nF;
+        c->pyramidValid = c->detectValid = true;
+        return rc ? rc : kidsJoin(c);
+    }
     int rc = acf_hip_pyramid(c, frames, nF);
     if (rc)
     {
@@ -1914,6 +2075,26 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
 
 int acf_hip_run_host(acf_hip_ctx* c, const float* frames_host, int nF)
 {
+    if (c && !c->kids.empty())
+    {
+        if (!frames_host || nF <= 0 || nF > c->maxBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "run_host: n_frames out of range");
+        }
+        const size_t per = size_t(c->plan.d_in) * c->plan.H * c->plan.W;
+        int rc = kidsFork(c);
+        for (size_t i = 0; i < c->kids.size() && !rc; i++)
+        {
+            const int n = kidCount(c, i, nF);
+            if (n > 0 && (rc = acf_hip_run_host(c->kids[i], frames_host + i * size_t(c->kidChunk) * per, n)))
+            {
+                return kidFail(c, c->kids[i], rc);
+            }
+        }
+        c->lastBatch = nF;
+        c->pyramidValid = c->detectValid = true;
+        return rc ? rc : kidsJoin(c);
+    }
     if (!c || !c->hasPlan)
     {
         return c ? fail(c, ACF_HIP_E_NOPLAN, "run_host: plan first") : ACF_HIP_E_INVALID;
@@ -1942,6 +2123,10 @@ int acf_hip_synchronize(acf_hip_ctx* c)
     {
         return ACF_HIP_E_INVALID;
     }
+    for (acf_hip_ctx* k : c->kids)
+    {
+        HIPCHK(c, hipStreamSynchronize(k->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ACF_HIP_OK;
 }
@@ -1951,6 +2136,48 @@ int acf_hip_profile_get(acf_hip_ctx* c, int* n, const char** names, float* ms, i
     if (!c || !n)
     {
         return ACF_HIP_E_INVALID;
+    }
+    if (!c->kids.empty())
+    {
+        // sum over the sub-batch contexts (their kernels overlap in time: the sum exceeds the wall clock)
+        std::vector<const char*> nm;
+        std::vector<float> tot;
+        std::vector<int> cnt;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            int kn = 0;
+            const char* knames[64];
+            float kms[64];
+            int kl[64];
+            int rc = acf_hip_profile_get(k, &kn, knames, kms, kl, 64);
+            if (rc)
+            {
+                return kidFail(c, k, rc);
+            }
+            for (int i = 0; i < std::min(kn, 64); i++)
+            {
+                size_t j = 0;
+                for (; j < nm.size() && strcmp(nm[j], knames[i]); j++)
+                {
+                }
+                if (j == nm.size())
+                {
+                    nm.push_back(knames[i]);
+                    tot.push_back(0.f);
+                    cnt.push_back(0);
+                }
+                tot[j] += kms[i];
+                cnt[j] += kl[i];
+            }
+        }
+        *n = int(nm.size());
+        for (int i = 0; i < std::min(*n, cap); i++)
+        {
+            if (names) names[i] = nm[size_t(i)];
+            if (ms) ms[i] = tot[size_t(i)];
+            if (launches) launches[i] = cnt[size_t(i)];
+        }
+        return ACF_HIP_OK;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<const char*> nm;
@@ -2022,6 +2249,16 @@ static int fetchCounts(acf_hip_ctx* c)
 
 int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, int cap, int* count)
 {
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_get_detections(k, frame % c->kidChunk, out, cap, count);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
     if (!c || !c->hasPlan)
     {
         return ACF_HIP_E_NOPLAN;
@@ -2054,6 +2291,16 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
 
 int acf_hip_get_hits(acf_hip_ctx* c, int frame, acf_hip_hit* out, int cap, int* count)
 {
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_get_hits(k, frame % c->kidChunk, out, cap, count);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
     if (!c || !c->hasPlan)
     {
         return ACF_HIP_E_NOPLAN;
@@ -2086,6 +2333,23 @@ int acf_hip_get_hits(acf_hip_ctx* c, int frame, acf_hip_hit* out, int cap, int* 
 
 int acf_hip_export_detections(acf_hip_ctx* c, int32_t* dst_dev, int cap)
 {
+    if (c && !c->kids.empty())
+    {
+        if (!c->detectValid || !dst_dev || cap <= 0)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "export_detections: nothing to export");
+        }
+        int rc = kidsFork(c);
+        for (size_t i = 0; i < c->kids.size() && !rc; i++)
+        {
+            if (kidCount(c, i, c->lastBatch) > 0 &&
+                (rc = acf_hip_export_detections(c->kids[i], dst_dev + i * size_t(c->kidChunk) * (1 + 6 * size_t(cap)), cap)))
+            {
+                return kidFail(c, c->kids[i], rc);
+            }
+        }
+        return rc ? rc : kidsJoin(c);
+    }
     if (!c || !c->hasPlan)
     {
         return ACF_HIP_E_NOPLAN;
@@ -2103,6 +2367,16 @@ int acf_hip_export_detections(acf_hip_ctx* c, int32_t* dst_dev, int cap)
 
 int acf_hip_read_level(acf_hip_ctx* c, int frame, int level, float* host_out)
 {
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_read_level(k, frame % c->kidChunk, level, host_out);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
     if (!c || !c->hasPlan)
     {
         return ACF_HIP_E_NOPLAN;
@@ -2119,6 +2393,16 @@ int acf_hip_read_level(acf_hip_ctx* c, int frame, int level, float* host_out)
 
 int acf_hip_read_tap(acf_hip_ctx* c, int frame, int tap, int index, float* host_out, int64_t cap)
 {
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_read_tap(k, frame % c->kidChunk, tap, index, host_out, cap);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
     if (!c || !c->hasPlan)
     {
         return ACF_HIP_E_NOPLAN;

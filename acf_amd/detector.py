@@ -27,7 +27,7 @@ def _dev_ptr(x):
 
 
 class HipDetector:
-    def __init__(self, model=None, H=0, W=0, d_in=3, max_batch=1, max_hits=4096, device=0, stream=None, taps=False):
+    def __init__(self, model=None, H=0, W=0, d_in=3, max_batch=1, max_hits=4096, device=0, stream=None, taps=False, streams=1):
         self.lib = capi.load()
         self.ctx = C.c_void_p()
         rc = self.lib.acf_hip_create(device, C.c_void_p(stream or 0), C.byref(self.ctx))
@@ -38,6 +38,9 @@ class HipDetector:
         self.nChns = 0
         if taps:
             self._chk(self.lib.acf_hip_set_option(self.ctx, b"taps", 1))
+        if streams > 1:
+            # sub-batch contexts on their own streams (takes effect at plan time)
+            self._chk(self.lib.acf_hip_set_option(self.ctx, b"streams", streams))
         if model is not None:
             self.set_model(model)
             if H and W:

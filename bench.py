@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cap", type=int, default=1024, help="detections exported per frame (gather record capacity)")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     args = ap.parse_args()
@@ -134,7 +135,7 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
-    det = HipDetector(model, H, W, 3, max_batch=B, max_hits=8192, device=local, stream=stream)
+    det = HipDetector(model, H, W, 3, max_batch=B, max_hits=8192, device=local, stream=stream, streams=args.streams)
     if not args.no_profile:
         det.set_option("profile", 1)
     if os.environ.get("ACF_BENCH_LEVEL_MODE"):  # A/B knob (profiles/ab_levels.sh)

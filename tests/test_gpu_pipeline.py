@@ -148,3 +148,37 @@ def test_export_detections_layout(oracle):
         assert np.array_equal(body[:n, 4].view(np.float32), got["score"][:n])
         assert np.all(body[n:] == 0)
     det.close()
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_sub_batch_streams(oracle, streams):
+    """Option "streams": the batch is cut into chunks run by child contexts on their own streams.  Every frame's
+    pyramid, hits, boxes and export record must equal the single-stream (oracle) result, including an uneven split."""
+    import torch
+    from acf_amd.detector import HipDetector
+    from acf_amd.dist import records_to_detections
+    H, W = 96, 128
+    model = synth.make_model(seed=3, name="TINY", nTrees=160)
+    n = 7
+    det = HipDetector(model, H, W, 3, max_batch=n, max_hits=1 << 14, streams=streams)
+    frames = np.stack([synth.make_frame(60 + i, H, W, "luv") for i in range(n)])
+    fr = torch.from_numpy(frames).cuda()
+    plan = oracle.Plan(model, H, W, 3)
+    cap = 256
+    rec = torch.zeros((n, 1 + 6 * cap), dtype=torch.int32, device="cuda")
+    for nrun in (n, n - 2):  # a full batch, then a shorter one that leaves the last child with fewer frames
+        det.run(fr, nrun)
+        det.export_detections(rec, cap)
+        torch.cuda.synchronize()
+        r = rec.cpu().numpy()
+        for f in range(nrun):
+            pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+            want, wh = oracle.detect(plan, pyr)
+            assert np.array_equal(bits(det.read_pyramid(f)), bits(pyr)), f
+            got, gh = det.detections(f)
+            assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes(), f
+            dec = records_to_detections(r[f], cap)
+            assert len(dec) == min(len(want), cap) and r[f, 0] == len(want)
+            for a, b in zip(dec, want):
+                assert a[:4] == (int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])) and np.float32(a[4]) == b["score"]
+    det.close()
