@@ -931,8 +931,10 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         g.step = p.stride / p.shrink;
         g.TR = 32;
         g.winFloats = nChns * mW * mH;
-        // stage boundaries (kernels.hip.h): A [0,16) and B [16,32) one lane per window; no stage C; D [32,128) one wave per window
-        int bounds[5] = { 0, 16, 32, 32, 128 };
+        // stage boundaries (kernels.hip.h): A [0,16), B [16,32), C [32,64) one lane per window (node table in LDS);
+        // D [64,128) one wave per window.  PMC (SQ_INSTS_VALU) showed stage D's ordered 64-step scans were 2/3 of the
+        // kernel's VALU work when ~40 windows per tile reached it at tree 32; at tree 64 only ~2.5 do.
+        int bounds[5] = { 0, 16, 32, 64, 128 };
         if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
         {
             int v1, v2, v3, v4;
@@ -959,7 +961,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             const int tc = nw * W * 64 / g.TR;
             const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
             const int64_t rowsP = (rows + 3) / 4 * 4;
-            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * W * 64 * 8 + int64_t(48) * std::min(32, p.nTrees);
+            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * W * 64 * 8 + int64_t(48) * g.b[3];
         };
         int nw = 0;
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
@@ -1597,6 +1599,15 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         if (p.gradMagEnabled || p.gradHistEnabled)
         {
             prof(c, "k_grad_mag");
+            if (rs.h % 4 == 0 && np % 4 == 0)
+            {
+                // 16 bytes per lane, persistent grid (2 workgroups per CU: the 80 KB LDS table), grid-stride over (frame, strip, row quad)
+                const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
+                const int blocks = int(std::min<int64_t>(512, (items + 255) / 256));
+                hipLaunchKernelGGL(k_grad_mag_vec, dim3(blocks), dim3(256), 0, c->stream,
+                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF);
+            }
+            else
             {
                 // enough workgroups to fill the chip twice over, each long enough to amortise its 80 KB table copy
                 const int rowBlocks = cdiv(rs.h, GM_ROWS), nStrips = cdiv(rs.w, GM_XT);
@@ -1799,7 +1810,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         const int64_t total = int64_t(cs.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[2];
+        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[3];
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");

@@ -455,6 +455,97 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
     }
 }
 
+// gradMag with 16 bytes per lane (h % 4 == 0) and the acos table in LDS.  A work item is (frame, strip of
+// GMV_XT columns, quad of 4 consecutive rows); items are numbered quad-fastest and dealt to a persistent grid
+// (2 workgroups per CU, grid-stride), so a wave reads 1 KB contiguous per column and a workgroup amortises its
+// one 80 KB table copy over ~60 items per thread.  The x taps slide through registers as float4, the two
+// y-neighbour rows outside the thread's own four come from one scalar load each, M / O leave as float4.
+// Measured: with the table in global memory the 4-byte lookups (every lane its own 128-byte line through a
+// 32 KB L1) were more than half of the kernel.  Same arithmetic as k_grad_mag per pixel.
+#define GMV_XT 4
+__global__ void __launch_bounds__(256) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
+    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames)
+{
+    __shared__ float acosL[GM_ACOS_N];
+    for (int i = threadIdx.x; i < GM_ACOS_N; i += 256)
+    {
+        acosL[i] = acosBase[i];
+    }
+    __syncthreads();
+    const float* acosT = acosL + 10010; // index 0 = centre of the table
+    const int h4 = h >> 2;
+    const int nStrips = (w + GMV_XT - 1) / GMV_XT;
+    const int64_t perFrame = int64_t(nStrips) * h4;
+    const int64_t total = perFrame * nFrames;
+    for (int64_t item = int64_t(blockIdx.x) * 256 + threadIdx.x; item < total; item += int64_t(gridDim.x) * 256)
+    {
+        const int f = int(item / perFrame);
+        const int rem = int(item - int64_t(f) * perFrame);
+        const int strip = rem / h4;
+        const int q = rem - strip * h4;
+        const int x0 = strip * GMV_XT;
+        const int y0 = q * 4;
+        const float* __restrict__ I = in + int64_t(f) * in_fs;
+        const int yu = max(y0 - 1, 0), yd = min(y0 + 4, h - 1);
+        float4 c[GMV_XT + 2];
+        float up[GMV_XT], dn[GMV_XT];
+#pragma unroll
+        for (int j = 0; j < GMV_XT + 2; j++)
+        {
+            const int x = min(max(x0 + j - 1, 0), w - 1);
+            c[j] = *reinterpret_cast<const float4*>(I + int64_t(x) * h + y0);
+        }
+#pragma unroll
+        for (int j = 0; j < GMV_XT; j++)
+        {
+            const int x = min(x0 + j, w - 1);
+            up[j] = I[int64_t(x) * h + yu];
+            dn[j] = I[int64_t(x) * h + yd];
+        }
+#pragma unroll
+        for (int j = 0; j < GMV_XT; j++)
+        {
+            const int x = x0 + j;
+            const float rx = (x == 0 || x == w - 1) ? 1.f : .5f;
+            const float cur[4] = { c[j + 1].x, c[j + 1].y, c[j + 1].z, c[j + 1].w };
+            const float lft[4] = { c[j].x, c[j].y, c[j].z, c[j].w };
+            const float rgt[4] = { c[j + 2].x, c[j + 2].y, c[j + 2].z, c[j + 2].w };
+            float mo[4], oo[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int y = y0 + k;
+                // grad1 :22-58 — one-sided differences (factor 1) at the borders, central * .5 inside
+                const float ry = (y == 0 || y == h - 1) ? 1.f : .5f;
+                const float a = (k == 0) ? ((y == 0) ? cur[0] : up[j]) : cur[k - 1];
+                const float b = (k == 3) ? ((y == h - 1) ? cur[3] : dn[j]) : cur[k + 1];
+                const float gx = (rgt[k] - lft[k]) * rx;
+                const float gy = (b - a) * ry;
+                const float m2 = gx * gx + gy * gy;
+                float m = 1.0f / sqrtf(m2);
+                m = m < 1e10f ? m : 1e10f;
+                float g = (gx * m) * 10000.0f;
+                g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
+                g = g < 10009.0f ? g : 10009.0f;
+                g = g > -10009.0f ? g : -10009.0f;
+                float ov = acosT[(int)g];
+                if (full)
+                {
+                    ov += (gy < 0) * 3.14159265f;
+                }
+                mo[k] = 1.0f / m;
+                oo[k] = ov;
+            }
+            if (x < w)
+            {
+                const int64_t o = int64_t(f) * out_fs + int64_t(x) * h + y0;
+                *reinterpret_cast<float4*>(M + o) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+                *reinterpret_cast<float4*>(O + o) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------
 // convTri radius r, x pass (toolbox/convConst.cpp:347-442): second-order
 // running sums along image-x, one thread per image row.  Writes U (the
@@ -2442,7 +2533,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     __shared__ int s_cnt[4];
     float* tileF = lds;
     uint2* list = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
-    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64 * W); // trees [0, b2): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
+    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64 * W); // trees [0, b3): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // Block -> (frame, tile).  Hardware block b runs on XCD b % 8: give every XCD
@@ -2469,7 +2560,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     {
         s_cnt[tid] = 0;
     }
-    for (int t = tid; t < a.g.b[2]; t += NW * 64)
+    for (int t = tid; t < a.g.b[3]; t += NW * 64)
     {
         // repack {off[4]} {thr[4]} {hs[4]} -> {off0, off1, off2, thr0} {thr1, thr2, hs0, hs1} {hs2, hs3, -, -}
         const uint4* gp = reinterpret_cast<const uint4*>(a.tileNodes + t);
@@ -2578,7 +2669,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
             const int rl = int(e[u].x) % a.g.TR, cl = int(e[u].x) / a.g.TR;
             float h1[1] = { hh[u] };
             bool a1[1] = { al[u] };
-            if (t1 <= a.g.b[2])
+            if (t1 <= a.g.b[3])
             {
                 tile_eval_lds<1>(tileF + (cl * step) * rowsP + rl * step, 0, nodesL, t0, t1, thrC, h1, a1);
             }

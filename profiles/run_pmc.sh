@@ -22,4 +22,6 @@ print("kernel," + ",".join(names))
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get(names[0], 0))):
     print(k + "," + ",".join("%.4g" % (d[n] / max(cnt[(k, n)], 1)) for n in names))
 PY
-find $OUT -name '*.csv' -size +30M -delete
+
+[ -n "$F" ] && python $GRAFT_REPO_ROOT/profiles/pmc_dispatches.py "$F" > $OUT/largest_dispatch.csv
+find $OUT -name "*counter_collection.csv" -size +30M -delete
