@@ -382,7 +382,14 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
         return fail(c, ACF_HIP_E_UNSUPPORTED, "convTri: radius > 15");
     }
     prof(c, "k_tri_x");
-    hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
+    if (rad == 5 && h % 4 == 0 && w >= 48 && fs % 4 == 0 && ((uintptr_t(in) | uintptr_t(U)) & 15) == 0)
+    {
+        hipLaunchKernelGGL(k_tri_x5v, dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, fs);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
+    }
     LAUNCHCHK(c, "k_tri_x");
     prof(c, "k_tri_y");
     if (rad == 5 && h % 4 == 0 && h >= 48 && fs % 4 == 0 && ((uintptr_t(U) | uintptr_t(S)) & 15) == 0)

@@ -632,6 +632,128 @@ __global__ void __launch_bounds__(256) k_tri_x(const float* __restrict__ in, flo
     }
 }
 
+// convTri x pass for radius 5, h % 4 == 0, w >= 48: 16 bytes per lane.  A thread owns 4 consecutive image rows
+// (four independent running-sum chains) and walks along image-x; columns enter a 16-slot register ring of
+// float4 exactly once (step i needs columns i-7, i-1, i+5: with the loop unrolled 16x every ring index is
+// static), and the 16 columns of the next iteration are requested one iteration ahead into a second register
+// set that swaps roles with the first.  Per chain the arithmetic is k_tri_x's: T += Il + Ir - 2*Im; U += nrm*T.
+__global__ void __launch_bounds__(64) k_tri_x5v(const float* __restrict__ in, float* __restrict__ Uo, int h, int w, int64_t fs)
+{
+    const int h4 = h >> 2;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= h4)
+    {
+        return;
+    }
+    const float* __restrict__ I = in + int64_t(blockIdx.z) * fs + 4 * q;
+    float* __restrict__ Uc = Uo + int64_t(blockIdx.z) * fs + 4 * q;
+    constexpr int r = 6;
+    const float nrm = 1.0f / (r * r * r * r);
+#define TXV_LD(col) (*reinterpret_cast<const float4*>(I + int64_t(col) * h))
+#define TXV_ST(col, v) (*reinterpret_cast<float4*>(Uc + int64_t(col) * h) = (v))
+    float T[4], U[4];
+    {
+        const float4 v0 = TXV_LD(0);
+        U[0] = T[0] = v0.x, U[1] = T[1] = v0.y, U[2] = T[2] = v0.z, U[3] = T[3] = v0.w;
+#pragma unroll
+        for (int i = 1; i < r; i++)
+        {
+            const float4 v = TXV_LD(i);
+            const float e[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                T[k] += e[k];
+                U[k] += T[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            U[k] = nrm * (2 * U[k] - T[k]);
+            T[k] = 0;
+        }
+        TXV_ST(0, make_float4(U[0], U[1], U[2], U[3]));
+    }
+#define TXV_STEP(A_, B_, C_, col)                                  \
+    {                                                              \
+        const float a_[4] = { A_.x, A_.y, A_.z, A_.w };            \
+        const float b_[4] = { B_.x, B_.y, B_.z, B_.w };            \
+        const float c_[4] = { C_.x, C_.y, C_.z, C_.w };            \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)              \
+        {                                                          \
+            T[k] += a_[k] + b_[k] - 2 * c_[k];                     \
+            U[k] += nrm * T[k];                                    \
+        }                                                          \
+        TXV_ST(col, make_float4(U[0], U[1], U[2], U[3]));          \
+    }
+    // head: i = 1 .. 15 straight from memory (reflected left taps for i <= r)
+#pragma unroll
+    for (int i = 1; i < 16; i++)
+    {
+        const float4 a = (i <= r) ? TXV_LD(r - i) : TXV_LD(i - 1 - r);
+        const float4 c = TXV_LD(i - 1);
+        const float4 b = TXV_LD(i - 1 + r);
+        TXV_STEP(a, b, c, i);
+    }
+    // ring: slot (column & 15); holds columns J-8 .. J+7 at the top of an iteration
+    float4 ring[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++)
+    {
+        ring[(8 + m) & 15] = TXV_LD(8 + m);
+    }
+    int J = 16;
+    const int lastFast = w - 24; // J + 23 <= w - 1 and every i <= J + 15 is a body column (i <= w - r)
+    float4 nx[16], ny[16];
+#define TXV_FETCH(SET, J0)                                         \
+    _Pragma("unroll") for (int m = 0; m < 16; m++)                 \
+    {                                                              \
+        SET[m] = TXV_LD(min((J0) + 8 + m, w - 1));                 \
+    }
+#define TXV_ITER(SET, J0)                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 16; jj++)              \
+    {                                                              \
+        if (jj >= 3)                                               \
+        {                                                          \
+            ring[(8 + jj - 3) & 15] = SET[jj - 3]; /* column J+8+m enters before step m+3; its slot's old column was last read at step m-1 */ \
+        }                                                          \
+        TXV_STEP(ring[(jj - 7) & 15], ring[(jj + 5) & 15], ring[(jj - 1) & 15], (J0) + jj); \
+    }                                                              \
+    ring[(8 + 13) & 15] = SET[13];                                 \
+    ring[(8 + 14) & 15] = SET[14];                                 \
+    ring[(8 + 15) & 15] = SET[15];
+    if (J <= lastFast)
+    {
+        TXV_FETCH(nx, J);
+        for (; J + 16 <= lastFast; J += 32)
+        {
+            TXV_FETCH(ny, J + 16);
+            TXV_ITER(nx, J);
+            TXV_FETCH(nx, J + 32); // clamped: past the body this re-reads valid columns that are not used
+            TXV_ITER(ny, J + 16);
+        }
+        if (J <= lastFast)
+        {
+            TXV_ITER(nx, J);
+            J += 16;
+        }
+    }
+    // tail: remaining columns from memory (reflected right taps for i > w - r)
+    for (int i = J; i < w; i++)
+    {
+        const float4 a = TXV_LD(i - 1 - r);
+        const float4 c = TXV_LD(i - 1);
+        const float4 b = (i > w - r) ? TXV_LD(2 * w - r - i) : TXV_LD(i - 1 + r);
+        TXV_STEP(a, b, c, i);
+    }
+#undef TXV_LD
+#undef TXV_ST
+#undef TXV_STEP
+#undef TXV_FETCH
+#undef TXV_ITER
+}
+
 // ------------------------------------------------------------------------
 // convTriY (toolbox/convConst.cpp:269-297): second-order running sums down
 // each column.  One wave owns 64 columns; 64-row slabs are staged through LDS

@@ -87,6 +87,17 @@ def test_conv_tri_r5_streaming_boundaries(dev, oracle, h):
     assert np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("w", [44, 48, 49, 55, 56, 63, 64, 65, 71, 72, 79, 80, 81, 95, 96, 97, 112, 113, 480])
+def test_conv_tri_r5_x_streaming_boundaries(dev, oracle, w):
+    """Every residue of the 16-column unrolled, two-set x-pass kernel (k_tri_x5v) and its head / tail hand-over."""
+    h = 64
+    a = rnd(w * 11 + 3, (1, w, h))
+    got = dev.op_conv_tri(a, 5.0, aliased=False)
+    want = np.zeros_like(a)
+    assert oracle.lib().acfo_conv_tri(oracle.F(a), oracle.F(want), h, w, 1, 5, 1) == 0
+    assert np.array_equal(bits(got), bits(want))
+
+
 @pytest.mark.parametrize("h,w", SIZES)
 @pytest.mark.parametrize("full", [0, 1])
 def test_gradient_mag(dev, oracle, h, w, full):
