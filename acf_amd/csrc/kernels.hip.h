@@ -1752,7 +1752,7 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
         xr = xrn;                                                                                                   \
         xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
     }
-#define LV_FILTER(I, CUR, NXT)                                                                                      \
+#define LV_FILTER(I, CUR, NXT, OB)                                                                                  \
     {                                                                                                               \
         const int i_ = (I);                                                                                         \
         float T[R], up[R], dn[R];                                                                                   \
@@ -1765,7 +1765,6 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
             up[k] = wave_ror1(T[k]); /* T[y-1] for lanes 1..63 */                                                   \
             dn[k] = wave_rol1(T[k]); /* T[y+1] for lanes 0..62 */                                                   \
         }                                                                                                           \
-        const uint32_t oc = uint32_t(i_) * uint32_t(J.out_cs) * 4u;                                                 \
         _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
         {                                                                                                           \
             const int y = lane + 64 * k;                                                                            \
@@ -1779,9 +1778,22 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
             /* lanes past the end of the plane (last register only) are clamped to row h-1: they store row h-1's */ \
             /* value to row h-1's address, so every store is unconditional and base + 32-bit offset             */ \
             const float ov = (k < R - 1 || lastOk) ? o : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o), lastLane)); \
-            buf_st(Osrd, yoff[k], oc, ov);                                                                          \
+            OB[k] = ov;                                                                                             \
         }                                                                                                           \
     }
+    // Outputs are kept in registers and stored four columns at a time.  vmcnt completes IN ORDER over loads and
+    // stores alike: waiting for a load also waits for every store issued before it, and a store is only done
+    // when L2 acknowledges it (~2 us here).  With a store after every column each step paid that; batched, the
+    // first load after a batch pays it once per four columns.
+#define LV_STORE(I, OB)                                                                                             \
+    {                                                                                                               \
+        const uint32_t oc = uint32_t(I) * uint32_t(J.out_cs) * 4u;                                                  \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            buf_st(Osrd, yoff[k], oc, OB[k]);                                                                       \
+        }                                                                                                           \
+    }
+    float o0[R], o1[R], o2[R], o3[R];
     // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
     LV_LOAD(b0, 0);
     LV_LOAD(b1, 1);
@@ -1790,27 +1802,35 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
     for (; i + 3 < w; i += 4)
     {
         LV_LOAD(b3, i + 3);
-        LV_FILTER(i, b0, b1);
+        LV_FILTER(i, b0, b1, o0);
         LV_LOAD(b0, i + 4);
-        LV_FILTER(i + 1, b1, b2);
+        LV_FILTER(i + 1, b1, b2, o1);
         LV_LOAD(b1, i + 5);
-        LV_FILTER(i + 2, b2, b3);
+        LV_FILTER(i + 2, b2, b3, o2);
         LV_LOAD(b2, i + 6);
-        LV_FILTER(i + 3, b3, b0);
+        LV_FILTER(i + 3, b3, b0, o3);
+        LV_STORE(i, o0);
+        LV_STORE(i + 1, o1);
+        LV_STORE(i + 2, o2);
+        LV_STORE(i + 3, o3);
     }
     // tail: up to three columns; their inputs are already in b0, b1, b2
     if (i < w)
     {
-        LV_FILTER(i, b0, b1);
+        LV_FILTER(i, b0, b1, o0);
+        LV_STORE(i, o0);
     }
     if (i + 1 < w)
     {
-        LV_FILTER(i + 1, b1, b2);
+        LV_FILTER(i + 1, b1, b2, o1);
+        LV_STORE(i + 1, o1);
     }
     if (i + 2 < w)
     {
-        LV_FILTER(i + 2, b2, b2);
+        LV_FILTER(i + 2, b2, b2, o2);
+        LV_STORE(i + 2, o2);
     }
+#undef LV_STORE
 #undef LV_LOAD
 #undef LV_FILTER
 }
