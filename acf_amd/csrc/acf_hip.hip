@@ -1576,8 +1576,20 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
                 return fail(c, ACF_HIP_E_INVALID, "pyramid: internal frame-stride mismatch");
             }
             prof(c, "k_resample(image)");
-            hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(c->h_descs[rs.descIndex]), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
-                (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
+            const ResampleDesc& hd = c->h_descs[rs.descIndex];
+            if (hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
+                hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&
+                (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0)
+            {
+                const int64_t items = int64_t(hd.hb / 2) * hd.wb * hd.nplanes;
+                hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
+                    (const ResampleDesc*)(c->d_descs + rs.descIndex));
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
+                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
+            }
             LAUNCHCHK(c, "k_resample(image)");
             img = rs.img;
             img_fs = int64_t(d) * np;

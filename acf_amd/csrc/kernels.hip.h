@@ -1284,42 +1284,21 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
         {
             break;
         }
+        // the column's x taps: one 32-byte record (host_plan.cpp) through the scalar unit instead of chasing
+        // start[] -> src[] -> wt[] with dependent loads
         RsX X;
-        X.wofs = 0;
-        X.border = false;
-        X.w[0] = X.w[1] = X.w[2] = X.w[3] = 0.f;
-        if (xmode == RS_EXACT)
         {
-            X.xa = it[d.x_src + xb];
-            X.m = d.xk;
-        }
-        else if (xmode == RS_DOWN)
-        {
-            const int s0 = it[d.x_start + xb], s1 = it[d.x_start + xb + 1];
-            X.xa = it[d.x_src + s0];
-            X.m = s1 - s0;
-            X.wofs = d.x_wt + s0;
-            X.w[0] = ft[X.wofs];
-            if (X.m > 1)
-            {
-                X.w[1] = ft[X.wofs + 1];
-            }
-            if (X.m > 2)
-            {
-                X.w[2] = ft[X.wofs + 2];
-            }
-            if (X.m > 3)
-            {
-                X.w[3] = ft[X.wofs + 3];
-            }
-        }
-        else
-        {
-            X.xa = it[d.x_src + xb];
-            X.m = 2;
-            X.border = xb < d.xbd0 || xb >= wb - d.xbd1;
-            X.w[0] = ft[d.x_wt + xb];
-            X.w[1] = 1 - X.w[0];
+            typedef uint32_t rs_u32x8 __attribute__((ext_vector_type(8)));
+            typedef const __attribute__((address_space(4))) rs_u32x8* rs_cptr8;
+            const rs_u32x8 xr = ((rs_cptr8)(uintptr_t)(it + d.x_col))[xb];
+            X.xa = int(xr[0]);
+            X.m = int(xr[1]);
+            X.wofs = int(xr[2]);
+            X.border = xr[3] != 0;
+            X.w[0] = __uint_as_float(xr[4]);
+            X.w[1] = __uint_as_float(xr[5]);
+            X.w[2] = __uint_as_float(xr[6]);
+            X.w[3] = __uint_as_float(xr[7]);
         }
         float v;
         if (ymode == RS_EXACT)
@@ -1833,6 +1812,36 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
 #undef LV_STORE
 #undef LV_LOAD
 #undef LV_FILTER
+}
+
+// imResample, exact 1/2 in both axes (imResampleMex.cpp:198-215, 284-288), ha % 4 == 0: 16 bytes per lane.
+// A thread reads 4 source rows of the two source columns of its output column as float4 and writes 2 output
+// rows as float2: out[y] = ((A[2x][2y] + A[2x+1][2y]) + (A[2x][2y+1] + A[2x+1][2y+1])) * rk — x pass then y pass,
+// the association of the generic kernel's RS_EXACT path.
+__global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__ src, float* __restrict__ dst, const ResampleDesc* __restrict__ descs)
+{
+    const ResampleDesc& d = descs[0];
+    const int ha = d.ha, hb = d.hb, wb = d.wb;
+    const int hq = hb >> 1; // output row pairs
+    const int64_t item = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t perPlane = int64_t(hq) * wb;
+    if (item >= perPlane * d.nplanes)
+    {
+        return;
+    }
+    const int z = int(item / perPlane);
+    const int rem = int(item - int64_t(z) * perPlane);
+    const int xb = rem / hq, q = rem - xb * hq;
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float rk = d.rk[ty];
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * d.wa + int64_t(2 * xb) * ha + 4 * q;
+    const float4 p0 = *reinterpret_cast<const float4*>(A);
+    const float4 p1 = *reinterpret_cast<const float4*>(A + ha);
+    float2 o;
+    o.x = ((p0.x + p1.x) + (p0.y + p1.y)) * rk;
+    o.y = ((p0.z + p1.z) + (p0.w + p1.w)) * rk;
+    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb + int64_t(xb) * hb + 2 * q;
+    *reinterpret_cast<float2*>(B) = o;
 }
 
 // grid.x needed for one descriptor
