@@ -1587,8 +1587,10 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
             }
             else
             {
-                hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
-                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
+                // small planes: fewer columns per wave, more waves
+                const int xt = int64_t(resampleBlocks(hd)) * nF < 4096 ? 2 : RS_XT;
+                hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd, xt), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
+                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, xt);
             }
             LAUNCHCHK(c, "k_resample(image)");
             img = rs.img;
@@ -1679,7 +1681,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
         prof(c, "k_resample(approx)");
         hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nF), dim3(64, 4), 0, c->stream,
-            (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft);
+            (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
         LAUNCHCHK(c, "k_resample(approx)");
     }
     if (waveSmooth)
@@ -2752,7 +2754,7 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
         return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
     }
     hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(dd), 1, 1), dim3(64, 4), 0, c->stream, (const float*)di, dout,
-        (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft);
+        (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, RS_XT);
     LAUNCHCHK(c, "k_resample");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout, sizeof(float) * d * hb * wb, hipMemcpyDeviceToHost));

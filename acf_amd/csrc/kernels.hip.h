@@ -1213,12 +1213,13 @@ __device__ __forceinline__ float rs_C(int xmode, int ha, const RsX& X, const flo
 #define RS_XT 8
 
 __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src, float* __restrict__ dst,
-    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft)
+    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int xt)
 {
+    // xt: output columns per wave (the lane's y taps are reused across them); small launches use fewer for more waves
     const ResampleDesc& d = descs[blockIdx.y];
     const int ha = d.ha, hb = d.hb, wb = d.wb;
     const int ntY = (hb + 63) >> 6;
-    const int ntX = (wb + 4 * RS_XT - 1) / (4 * RS_XT);
+    const int ntX = (wb + 4 * xt - 1) / (4 * xt);
     int t = blockIdx.x;
     const int ytile = t % ntY;
     t /= ntY;
@@ -1229,7 +1230,7 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
         return;
     }
     const int yb = ytile * 64 + threadIdx.x;
-    const int xb0 = __builtin_amdgcn_readfirstlane((xtile * 4 + (int)threadIdx.y) * RS_XT);
+    const int xb0 = __builtin_amdgcn_readfirstlane((xtile * 4 + (int)threadIdx.y) * xt);
     if (xb0 >= wb)
     {
         return;
@@ -1277,7 +1278,7 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
         ny = (ybc < d.ybd0 || ybc >= hb - d.ybd1) ? 1 : 2;
     }
 
-    for (int xi = 0; xi < RS_XT; xi++)
+    for (int xi = 0; xi < xt; xi++)
     {
         const int xb = xb0 + xi;
         if (xb >= wb)
@@ -1845,9 +1846,9 @@ __global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__
 }
 
 // grid.x needed for one descriptor
-static inline int resampleBlocks(const ResampleDesc& d)
+static inline int resampleBlocks(const ResampleDesc& d, int xt = RS_XT)
 {
-    return ((d.hb + 63) / 64) * ((d.wb + 4 * RS_XT - 1) / (4 * RS_XT)) * d.nplanes;
+    return ((d.hb + 63) / 64) * ((d.wb + 4 * xt - 1) / (4 * xt)) * d.nplanes;
 }
 
 // ------------------------------------------------------------------------
