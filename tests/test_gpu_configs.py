@@ -1,0 +1,69 @@
+"""BASELINE.json's configurations at FULL size, one frame each, bit-exact against the oracle (the oracle needs
+0.1-2 s per frame at these sizes): every level of the fused pyramid, hit positions, score bits and mapped boxes.
+
+ cfg 1  640x480 gray, FACE64 (7 channels, colour disabled), 2048 trees
+ cfg 2  1920x1080 planar LUV, FACE80, 2048 trees (the benchmark workload)
+ cfg 3  a batch of cfg-2 frames (8 here): per-frame results independent of batch position
+ cfg 4  640x480 RGB, INRIA 128x64 model, pad [16 12], nOctUp 1 (RGB->LUV on the device, up-sampled real scale)
+ cfg 5  3840x2160 planar LUV, 12 scales/octave, nApprox 11, FACE80 (LDCF has no reference counterpart: not covered)
+"""
+import numpy as np
+import pytest
+
+from acf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+CFG = {
+    "cfg1_vga_gray_face64": (480, 640, "gray", 1, dict(name="FACE64")),
+    "cfg2_1080p_luv_face80": (1080, 1920, "luv", 3, dict(name="FACE80")),
+    "cfg4_vga_rgb_inria": (480, 640, "rgb", 3, dict(name="INRIA")),
+    "cfg5_4k_luv_face80_12perOct": (2160, 3840, "luv", 3, dict(name="FACE80", nPerOct=12, nApprox=11)),
+}
+
+
+@pytest.mark.parametrize("cfg", list(CFG))
+def test_full_size_config_bit_exact(oracle, cfg):
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W, kind, d_in, kw = CFG[cfg]
+    model = synth.make_model(seed=1, **kw)
+    frame = synth.make_frame(2, H, W, kind)
+    det = HipDetector(model, H, W, d_in, max_batch=1, max_hits=1 << 16)
+    plan = oracle.Plan(model, H, W, d_in)
+    assert len(det.levels) == plan.nScales
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    want, wh = oracle.detect(plan, pyr)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    for i in range(plan.nScales):
+        l = plan.levels[i]
+        n = plan.nChns * l.hP * l.wP
+        assert np.array_equal(bits(det.read_level(0, i)).ravel(), bits(pyr[l.offset:l.offset + n])), (cfg, "level", i)
+    got, gh = det.detections(0)
+    assert len(want) > 0, "the synthetic model should fire on this frame"
+    assert gh.tobytes() == wh.tobytes()
+    assert got.tobytes() == want.tobytes()
+    det.close()
+
+
+def test_cfg3_batch_of_1080p_frames(oracle):
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 1080, 1920
+    model = synth.make_model(seed=1, name="FACE80")
+    n = 8
+    frames = np.stack([synth.make_frame(100 + i, H, W, "luv") for i in range(n)])
+    det = HipDetector(model, H, W, 3, max_batch=n, max_hits=1 << 15)
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    for f in (0, 3, 7):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want, wh = oracle.detect(plan, pyr)
+        got, gh = det.detections(f)
+        assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes(), f
+    det.close()
