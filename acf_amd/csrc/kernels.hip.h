@@ -2446,10 +2446,14 @@ __device__ __forceinline__ void tile_eval(const float* win, const TreeNode* __re
 // LDS-bandwidth bound (every wave of the tile repeats the node reads), so with W > 1 a
 // lane evaluates W windows dW floats apart with ONE set of node reads and ONE set of
 // address computations per tree.
-template <int W>
+// trees per batch in the list stages (B, C): few waves are active there and a batch is one chain of two LDS round
+// trips, so larger batches shorten the tile's critical path
+#ifndef CASC_TG_LIST
+#define CASC_TG_LIST 8
+#endif
+template <int W, int TG = 4>
 __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const uint4* nodesL, int t0, int t1, float thrC, float (&h)[W], bool (&alive)[W])
 {
-    constexpr int TG = 4;
     int t = t0;
     // (requesting the next batch's nodes one iteration early was measured: no gain — the node reads are not on the
     // critical path of a batch)
@@ -2823,7 +2827,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
             bool a1[1] = { al[u] };
             if (t1 <= a.g.b[3])
             {
-                tile_eval_lds<1>(tileF + (cl * step) * rowsP + rl * step, 0, nodesL, t0, t1, thrC, h1, a1);
+                tile_eval_lds<1, CASC_TG_LIST>(tileF + (cl * step) * rowsP + rl * step, 0, nodesL, t0, t1, thrC, h1, a1);
             }
             else
             {
