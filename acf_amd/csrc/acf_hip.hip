@@ -80,6 +80,7 @@ struct acf_hip_ctx
     bool hasModel = false, hasPlan = false;
     int taps = 0;
     int profile = 0;
+    int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     std::vector<hipEvent_t> evPool;
     std::vector<const char*> evName;
@@ -313,7 +314,7 @@ int ensureConstTables(acf_hip_ctx* c)
     {
         return rc;
     }
-    return devAlloc(c, &c->d_dump, 64);
+    return devAlloc(c, &c->d_dump, 1024);
 }
 
 inline int cdiv(int64_t a, int64_t b)
@@ -677,6 +678,11 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     {
         c->noFused = value == 0;
         c->levelMode = value;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "fused_smooth"))
+    {
+        c->noFusedSmooth = value == 0;
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "cascade_tiles"))
@@ -1115,6 +1121,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->taps = c->taps;
             k->profile = c->profile;
             k->noTiles = c->noTiles;
+            k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
             if ((rc = acf_hip_set_model(k, &c->p)) || (rc = acf_hip_plan(k, H, W, d_in, c->kidChunk, max_hits)))
@@ -1559,6 +1566,21 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
 
     // ---- real scales, in order (chnsPyramid.cpp:297-338 + chnsCompute.cpp:146-338)
     const float pColor = p.colorSmooth > 0 ? float(12.0 / p.colorSmooth / (p.colorSmooth + 2.0) - 2.0) : 0.f;
+    // which real scale's smoothed image each real scale is resampled from (-1: the input frame), following the
+    // reference's I = I1 adoption (chnsPyramid.cpp:313-316)
+    std::vector<int> srcIdx(c->real.size(), -1);
+    std::vector<char> halfDone(c->real.size(), 0);
+    {
+        int curIdx = -1;
+        for (size_t k = 0; k < c->real.size(); k++)
+        {
+            srcIdx[k] = curIdx;
+            if (c->real[k].adoptAsI)
+            {
+                curIdx = int(k);
+            }
+        }
+    }
     for (size_t k = 0; k < c->real.size(); k++)
     {
         RealScale& rs = c->real[k];
@@ -1577,7 +1599,11 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
             }
             prof(c, "k_resample(image)");
             const ResampleDesc& hd = c->h_descs[rs.descIndex];
-            if (hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
+            if (halfDone[k])
+            {
+                // already produced by the previous scale's k_smooth_vec
+            }
+            else if (hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
                 hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&
                 (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0)
             {
@@ -1597,7 +1623,84 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
             img_fs = int64_t(d) * np;
         }
         // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
-        if (p.colorSmooth > 0)
+        bool colorDone = false;
+        const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 8 == 0 &&
+            rs.h / 4 <= 512 && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
+        if (fuseSm)
+        {
+            // k_smooth_vec: smoothing + the level's colour channels (+ the next real scale's image when it is an exact half
+            // of this one) from registers; full-resolution smoothed planes are written only where something still reads them
+            const bool halfNext = k + 1 < c->real.size() && srcIdx[k + 1] == int(k) && c->real[k + 1].resampled &&
+                [&] { const ResampleDesc& nd = c->h_descs[c->real[k + 1].descIndex];
+                      return nd.xmode == RS_EXACT && nd.ymode == RS_EXACT && nd.xk == 2 && nd.yk == 2 && nd.ha == rs.h && nd.wa == rs.w; }();
+            bool needFullAll = false;
+            for (size_t m = k + 1; m < c->real.size(); m++)
+            {
+                if (srcIdx[m] == int(k) && !(m == k + 1 && halfNext))
+                {
+                    needFullAll = true;
+                }
+            }
+            SmoothVecArgs sa{};
+            sa.in = img;
+            sa.in_fs = img_fs;
+            sa.in_ps = np;
+            sa.sm = rs.sm;
+            sa.sm_fs = int64_t(d) * np;
+            sa.sm_ps = np;
+            sa.chns = c->d_chns + pl.raw_off[rs.level];
+            sa.chns_fs = pl.raw_floats;
+            sa.cells = int64_t(rs.h / 4) * (rs.w / 4);
+            sa.h = rs.h;
+            sa.w = rs.w;
+            sa.p = pColor;
+            sa.rq_y = shrinkGainY(shrink);
+            sa.dump = c->d_dump;
+            if (halfNext)
+            {
+                const RealScale& nx = c->real[k + 1];
+                const ResampleDesc& nd = c->h_descs[nx.descIndex];
+                sa.half = nx.img;
+                sa.half_ps = int64_t(nx.h) * nx.w;
+                sa.half_fs = int64_t(d) * sa.half_ps;
+                sa.rkHalf = nd.rk[0];
+                halfDone[k + 1] = true;
+            }
+            prof(c, "k_smooth_vec");
+            const int nq = rs.h / 4, nt = ((nq + 63) / 64) * 64;
+            const size_t ldsB = size_t(4) * nq * sizeof(float);
+            for (int z0 = 0; z0 < d;)
+            {
+                const bool full0 = needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z0 == p.colorChn);
+                int z1 = z0 + 1;
+                while (z1 < d && (needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z1 == p.colorChn)) == full0)
+                {
+                    z1++;
+                }
+                sa.plane0 = z0;
+                dim3 grid(z1 - z0, 1, nF), block(nt);
+                if (full0 && halfNext)
+                {
+                    hipLaunchKernelGGL((k_smooth_vec<true, true, true>), grid, block, ldsB, c->stream, sa);
+                }
+                else if (full0)
+                {
+                    hipLaunchKernelGGL((k_smooth_vec<true, false, true>), grid, block, ldsB, c->stream, sa);
+                }
+                else if (halfNext)
+                {
+                    hipLaunchKernelGGL((k_smooth_vec<false, true, true>), grid, block, ldsB, c->stream, sa);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((k_smooth_vec<false, false, true>), grid, block, ldsB, c->stream, sa);
+                }
+                LAUNCHCHK(c, "k_smooth_vec");
+                z0 = z1;
+            }
+            colorDone = true;
+        }
+        else if (p.colorSmooth > 0)
         {
             if ((rc = launchSmooth(c, img, rs.sm, c->d_realJobs + k, 1, d, rs.h, img_fs, int64_t(d) * np, nF, pColor, true)))
             {
@@ -1660,6 +1763,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
         a.w = rs.w;
         a.d = d;
         a.colorEnabled = p.colorEnabled;
+        a.colorDone = colorDone ? 1 : 0;
         a.magEnabled = p.gradMagEnabled;
         a.histEnabled = p.gradHistEnabled;
         a.nOrients = p.nOrients;

@@ -280,6 +280,142 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
 #undef SM_COL
 }
 
+// ------------------------------------------------------------------------
+// Image smoothing with 16 bytes per lane and fused consumers (h % 4 == 0, w % 8 == 0).
+// A thread owns 4 consecutive image rows of one plane; the recursion along image-x
+// is k_smooth_tri1's.  Of the two y neighbours a row needs, three of four are the
+// thread's own registers; the first / last row's come from the adjacent threads
+// through two LDS floats per thread and one barrier per column.
+//
+// Because a thread's four rows are exactly one shrink-4 cell row and two
+// half-resolution row pairs, the consumers of the smoothed image are produced here,
+// from registers, instead of re-reading the full-resolution planes:
+//   SHRINK  the colour channels of the level: addChn's exact 1/4 resample
+//           (chnsCompute.cpp:253-256,346-351; imResampleMex.cpp:210-215,312-317):
+//           (((A0+A1)+A2)+A3) along x, then the 4-row sum, * r/4 — k_chns's colour branch;
+//   HALF    the next real scale's image when it is an exact half (chnsPyramid.cpp:300-316;
+//           imResampleMex.cpp:198-215,284-288): ((Ae[2y]+Ao[2y]) + (Ae[2y+1]+Ao[2y+1])) * rk
+//           — k_resample_half;
+//   FULL    the full-resolution smoothed plane itself, only where something still reads
+//           it (the gradient plane; every plane of a scale later scales are resampled from).
+// All three are compile-time per launch, so the column loop has no branch.
+// ------------------------------------------------------------------------
+struct SmoothVecArgs
+{
+    const float* in;  // [planes][w][h]
+    float* sm;        // FULL: smoothed planes, same layout
+    float* half;      // HALF: [planes][w/2][h/2]
+    float* chns;      // SHRINK: channel z at chns + z * cells
+    int64_t in_fs, in_ps, sm_fs, sm_ps, half_fs, half_ps, chns_fs, cells;
+    int32_t h, w, plane0; // plane0: first plane of this launch (blockIdx.x is relative to it)
+    float p, rkHalf, rq_y;
+    float* dump;      // >= 256 floats nobody reads
+};
+
+#define SV_CH 8
+template <bool FULL, bool HALF, bool SHRINK>
+__global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a)
+{
+    extern __shared__ float lds[]; // [2 parities][lo, hi][nq]
+    const int h = a.h, w = a.w, nq = h >> 2;
+    const int q = threadIdx.x;
+    const bool valid = q < nq;
+    const int qc = valid ? q : nq - 1;
+    const int z = a.plane0 + blockIdx.x;
+    const int64_t f = blockIdx.z;
+    const float* __restrict__ I = a.in + f * a.in_fs + int64_t(z) * a.in_ps + 4 * qc;
+    float* __restrict__ Of = FULL ? a.sm + f * a.sm_fs + int64_t(z) * a.sm_ps + 4 * qc : nullptr;
+    float* __restrict__ Oh = HALF ? a.half + f * a.half_fs + int64_t(z) * a.half_ps + 2 * qc : nullptr;
+    float* __restrict__ Oc = SHRINK ? a.chns + f * a.chns_fs + int64_t(z) * a.cells + qc : nullptr;
+    const int hb = h >> 1, hc = h >> 2;
+    const float p = a.p, nrm = 1.0f / ((p + 2) * (p + 2)), p1 = 1 + p;
+    const bool first = qc == 0, last = qc == nq - 1;
+    const int qm = max(qc - 1, 0), qp = min(qc + 1, nq - 1);
+    float prev[4] = { 0.f, 0.f, 0.f, 0.f }, acc[4] = { 0.f, 0.f, 0.f, 0.f };
+    float4 c0[SV_CH], c1[SV_CH];
+#define SV_LOAD(BUF, I0)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < SV_CH; j++)                                             \
+    {                                                                                             \
+        BUF[j] = *reinterpret_cast<const float4*>(I + int64_t(min((I0) + j, w - 1)) * h);         \
+    }
+    // column i = I0 + JJ (JJ compile-time, I0 % 8 == 0): CUR = column i, NXT = column min(i+1, w-1)
+#define SV_COL(I0, JJ, CUR, NXT)                                                                  \
+    {                                                                                             \
+        const int i_ = (I0) + (JJ);                                                               \
+        float* tl = lds + (i_ & 1) * 2 * nq;                                                      \
+        const float im[4] = { CUR.x, CUR.y, CUR.z, CUR.w };                                       \
+        const float ir[4] = { NXT.x, NXT.y, NXT.z, NXT.w };                                       \
+        float T[4];                                                                               \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
+        {                                                                                         \
+            const float il = (i_ == 0) ? im[k] : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507) */ \
+            T[k] = nrm * (il + p * im[k] + ir[k]);                                                \
+        }                                                                                         \
+        tl[qc] = T[0];                                                                            \
+        tl[nq + qc] = T[3];                                                                       \
+        __syncthreads();                                                                          \
+        const float up = tl[nq + qm], dn = tl[qp];                                                \
+        float o[4];                                                                               \
+        {                                                                                         \
+            const float mid0 = up + p * T[0] + T[1], top0 = p1 * T[0] + T[1];                     \
+            o[0] = first ? top0 : mid0;                                                           \
+            o[1] = T[0] + p * T[1] + T[2];                                                        \
+            o[2] = T[1] + p * T[2] + T[3];                                                        \
+            const float mid3 = T[2] + p * T[3] + dn, bot3 = T[2] + p1 * T[3];                     \
+            o[3] = last ? bot3 : mid3;                                                            \
+        }                                                                                         \
+        if (FULL)                                                                                 \
+        {                                                                                         \
+            float* dst = valid ? Of + int64_t(i_) * h : a.dump + 4 * (q & 63);                    \
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);                \
+        }                                                                                         \
+        if (HALF && ((JJ) & 1))                                                                   \
+        {                                                                                         \
+            float2 hv;                                                                            \
+            hv.x = ((prev[0] + o[0]) + (prev[1] + o[1])) * a.rkHalf;                              \
+            hv.y = ((prev[2] + o[2]) + (prev[3] + o[3])) * a.rkHalf;                              \
+            float* dst = valid ? Oh + int64_t(i_ >> 1) * hb : a.dump + 2 * (q & 63);              \
+            *reinterpret_cast<float2*>(dst) = hv;                                                 \
+        }                                                                                         \
+        if (SHRINK)                                                                               \
+        {                                                                                         \
+            _Pragma("unroll") for (int k = 0; k < 4; k++)                                         \
+            {                                                                                     \
+                acc[k] = (((JJ) & 3) == 0) ? o[k] : acc[k] + o[k];                                \
+            }                                                                                     \
+            if (((JJ) & 3) == 3)                                                                  \
+            {                                                                                     \
+                float* dst = valid ? Oc + int64_t(i_ >> 2) * hc : a.dump + (q & 63);              \
+                *dst = (((acc[0] + acc[1]) + acc[2]) + acc[3]) * a.rq_y;                          \
+            }                                                                                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
+        {                                                                                         \
+            prev[k] = o[k];                                                                       \
+        }                                                                                         \
+    }
+#define SV_CHUNK(I0, A_, B_)                                                                      \
+    SV_COL(I0, 0, A_[0], A_[1]) SV_COL(I0, 1, A_[1], A_[2]) SV_COL(I0, 2, A_[2], A_[3]) SV_COL(I0, 3, A_[3], A_[4]) \
+    SV_COL(I0, 4, A_[4], A_[5]) SV_COL(I0, 5, A_[5], A_[6]) SV_COL(I0, 6, A_[6], A_[7]) SV_COL(I0, 7, A_[7], B_[0])
+    SV_LOAD(c0, 0);
+    int i = 0;
+    for (; i + 2 * SV_CH <= w; i += 2 * SV_CH)
+    {
+        SV_LOAD(c1, i + SV_CH);
+        SV_CHUNK(i, c0, c1);
+        SV_LOAD(c0, i + 2 * SV_CH); // clamped to the last column past the end
+        SV_CHUNK(i + SV_CH, c1, c0);
+    }
+    if (i < w) // one chunk left (w % 16 == 8)
+    {
+        SV_LOAD(c1, i + SV_CH);
+        SV_CHUNK(i, c0, c1);
+    }
+#undef SV_LOAD
+#undef SV_COL
+#undef SV_CHUNK
+}
+
 // cv::copyMakeBorder(BORDER_REFLECT) of the interior already written by the
 // smoothing kernel (chnsPyramid.cpp:410-424): fills only the border cells.
 struct PadJob
@@ -980,6 +1116,7 @@ struct ChnsArgs
     int64_t sm_fs, m_fs, chns_fs;
     int32_t h, w, d;
     int32_t colorEnabled, magEnabled, histEnabled, nOrients, doNorm, full;
+    int32_t colorDone; // the colour channels were already written by k_smooth_vec: skip them, keep their slots
     float normConst, rq; // rq = (1/S)/(1+1e-6) then /S in the y pass (imResampleMex.cpp:145-157,316)
     float rq_y;
 };
@@ -1002,7 +1139,11 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
     float* out = a.chns + f * a.chns_fs + int64_t(xc) * hc + yc;
     const int64_t pbase = int64_t(xc * S) * a.h + yc * S;
     int ch = 0;
-    if (a.colorEnabled)
+    if (a.colorEnabled && a.colorDone)
+    {
+        ch = a.d;
+    }
+    else if (a.colorEnabled)
     {
         for (int z = 0; z < a.d; z++)
         {

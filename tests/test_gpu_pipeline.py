@@ -182,3 +182,31 @@ def test_sub_batch_streams(oracle, streams):
             for a, b in zip(dec, want):
                 assert a[:4] == (int(b["x"]), int(b["y"]), int(b["w"]), int(b["h"])) and np.float32(a[4]) == b["score"]
     det.close()
+
+
+@pytest.mark.parametrize("fused_smooth", [1, 0])
+@pytest.mark.parametrize("H,W,kw", [
+    (256, 384, dict(name="TINY", nTrees=96)),                       # fused: exact-half next scale, colour channels from registers
+    (480, 640, dict(name="FACE80", nTrees=256)),
+    (200, 264, dict(name="TINY", nTrees=96)),                       # sz != sz1 at scale 1 (image resampled first), generic next-scale resample
+    (96, 132, dict(name="TINY", nTrees=96)),                        # w % 8 != 0 at some scale: falls back per scale
+    (240, 320, dict(name="TINY", nTrees=96, nApprox=0, minDs_h=32, minDs_w=32)),  # every scale real
+])
+def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
+    """k_smooth_vec (smoothing + colour channels + exact-half next image, taps off) against the oracle, and the
+    separate-kernel path on the same inputs."""
+    import torch
+    from acf_amd.detector import HipDetector
+    model = synth.make_model(seed=3, **kw)
+    frame = synth.make_frame(23, H, W, "luv")
+    det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
+    det.set_option("fused_smooth", fused_smooth)
+    det.run(torch.from_numpy(np.stack([frame, frame])).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    want, wh = oracle.detect(plan, pyr)
+    for f in (0, 1):
+        assert np.array_equal(bits(det.read_pyramid(f)), bits(pyr))
+        got, gh = det.detections(f)
+        assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes()
+    det.close()
