@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cap", type=int, default=1024, help="detections exported per frame (gather record capacity)")

@@ -76,7 +76,7 @@ def test_conv_tri_running_sums(dev, oracle, h, w, r):
     assert np.array_equal(bits(got), bits(want))
 
 
-@pytest.mark.parametrize("h", [44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 100, 540])
+@pytest.mark.parametrize("h", [44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 92, 96, 100, 104, 124, 128, 132, 136, 156, 160, 164, 272, 540])
 def test_conv_tri_r5_streaming_boundaries(dev, oracle, h):
     """Every residue of the 16-row unrolled streaming column kernel (k_tri_y5) and its head / tail hand-over."""
     w = 70
