@@ -459,63 +459,7 @@ __global__ void __launch_bounds__(256) k_pad_reflect(float* __restrict__ pyr, co
 // gradMag, d == 1 (toolbox/gradientMex.cpp:17-87,168-251).  acosT points at
 // the table's centre (index 0).
 // ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_grad_mag(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
-    const float* __restrict__ acosT, int h, int w, int full, int64_t in_fs, int64_t out_fs)
-{
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = blockIdx.y;
-    if (y >= h)
-    {
-        return;
-    }
-    const float* I = in + int64_t(blockIdx.z) * in_fs + int64_t(x) * h;
-    // grad1 :22-53
-    const float* Ip = I - h;
-    const float* In = I + h;
-    float r = .5f;
-    if (x == 0)
-    {
-        r = 1;
-        Ip += h;
-    }
-    else if (x == w - 1)
-    {
-        r = 1;
-        In -= h;
-    }
-    const float gx = (In[y] - Ip[y]) * r;
-    // :58
-    float gy;
-    if (y == 0)
-    {
-        gy = (I[1] - I[0]) * 1;
-    }
-    else if (y == h - 1)
-    {
-        gy = (I[h - 1] - I[h - 2]) * 1;
-    }
-    else
-    {
-        gy = (I[y + 1] - I[y - 1]) * .5f;
-    }
-    const float m2 = gx * gx + gy * gy;
-    float m = 1.0f / sqrtf(m2);
-    m = m < 1e10f ? m : 1e10f;
-    const int64_t o = int64_t(blockIdx.z) * out_fs + int64_t(x) * h + y;
-    M[o] = 1.0f / m;
-    float g = (gx * m) * 10000.0f;
-    g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
-    g = g < 10009.0f ? g : 10009.0f;
-    g = g > -10009.0f ? g : -10009.0f;
-    float ov = acosT[(int)g];
-    if (full)
-    {
-        ov += (gy < 0) * 3.14159265f;
-    }
-    O[o] = ov;
-}
-
-// Same arithmetic as k_grad_mag, organised for throughput.  A workgroup owns GM_ROWS
+// A workgroup owns GM_ROWS
 // image rows of one frame and walks along image-x in strips of GM_XT columns:
 //  - the 20020-entry acos table (80 KB) is copied into LDS once per workgroup.  From
 //    global memory the lookup is a 4-byte gather in which every lane pulls its own
@@ -597,7 +541,7 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
 // one 80 KB table copy over ~60 items per thread.  The x taps slide through registers as float4, the two
 // y-neighbour rows outside the thread's own four come from one scalar load each, M / O leave as float4.
 // Measured: with the table in global memory the 4-byte lookups (every lane its own 128-byte line through a
-// 32 KB L1) were more than half of the kernel.  Same arithmetic as k_grad_mag per pixel.
+// 32 KB L1) were more than half of the kernel.  Same arithmetic as k_grad_mag_strip per pixel.
 #define GMV_XT 4
 __global__ void __launch_bounds__(256) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
     const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames)
