@@ -45,11 +45,15 @@ def kernel_bytes_per_frame(det, model):
     mh, mw = model["modelDsPad_h"] // sh, model["modelDsPad_w"] // sh
     b = {}
     b["k_smooth_tri1(image)"] = sum(2 * d * n * 4 for n in np_real)
+    # fused smoothing: every plane read; the gradient plane written at every scale, all planes at the scale later scales are
+    # resampled from (index 1 here); the colour channels (1/16) and, from scale 0, the half-resolution next image (1/4)
+    b["k_smooth_vec"] = sum(4 * (d * n + n + d * n // 16) for n in np_real) + (4 * (d - 1) * np_real[1] if len(np_real) > 1 else 0) + \
+        (4 * d * np_real[0] // 4 if len(np_real) > 1 else 0)
     b["k_grad_mag"] = sum(3 * n * 4 for n in np_real)
     b["k_tri_x"] = sum(2 * n * 4 for n in np_real)
     b["k_tri_y"] = sum(2 * n * 4 for n in np_real)
-    b["k_chns"] = sum((d + 3) * n * 4 + nC * (n // (sh * sh)) * 4 for n in np_real)
-    b["k_resample(image)"] = sum(d * 4 * (np_real[0] if i == 1 else np_real[1]) + d * 4 * np_real[i] for i in range(1, len(np_real))) if len(np_real) > 1 else 0
+    b["k_chns"] = sum(3 * n * 4 + (nC - d) * (n // (sh * sh)) * 4 for n in np_real)  # M, S, O in; magnitude + histogram channels out
+    b["k_resample(image)"] = sum(d * 4 * np_real[1] + d * 4 * np_real[i] for i in range(2, len(np_real))) if len(np_real) > 2 else 0
     b["k_level(fused)"] = raw_real + pyr          # real levels' raw channels in, padded pyramid out
     b["k_level(smooth)"] = 2 * pyr
     b["k_resample(approx)"] = raw_real + pyr
