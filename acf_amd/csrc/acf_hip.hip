@@ -1925,8 +1925,9 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         a.debug = atoi(e);
     }
-    if (a.debug & 4)
+    if (a.debug & 12)
     {
+        a.debug |= 4;
         const int64_t total = int64_t(cs.nTiles) * nF;
         HIPCHK(c, hipMalloc(&a.stamps, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long)));
         HIPCHK(c, hipMemsetAsync(a.stamps, 0, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long), c->stream));
@@ -1961,7 +1962,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             HIPCHK(c, hipStreamSynchronize(c->stream));
             std::vector<long long> st(size_t(grid.x) * 8);
             HIPCHK(c, hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
-            double acc[4] = { 0, 0, 0, 0 };
+            double acc[4] = { 0, 0, 0, 0 }, sub[3] = { 0, 0, 0 };
             long long nb = 0;
             for (size_t b = 0; b < size_t(grid.x); b++)
             {
@@ -1971,10 +1972,15 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
                     {
                         acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
                     }
+                    for (int k = 0; k < 3; k++)
+                    {
+                        sub[k] += double(st[b * 8 + 5 + k]);
+                    }
                     nb++;
                 }
             }
-            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles\n", nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb);
+            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles   (stage A wave 0: node reads %.0f, feature reads %.0f, resolve %.0f)\n", nb,
+                acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
             (void)hipFree(a.stamps);
         }
         if (g.b[4] < p.nTrees)

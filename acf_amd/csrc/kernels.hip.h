@@ -2536,8 +2536,9 @@ __device__ __forceinline__ void tile_eval(const float* win, const TreeNode* __re
 #ifndef CASC_TG_LIST
 #define CASC_TG_LIST 8
 #endif
-template <int W, int TG = 4>
-__device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const uint4* nodesL, int t0, int t1, float thrC, float (&h)[W], bool (&alive)[W])
+template <int W, int TG = 4, bool TIMED = false>
+__device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const uint4* nodesL, int t0, int t1, float thrC, float (&h)[W], bool (&alive)[W],
+    long long* tacc = nullptr)
 {
     int t = t0;
     // (requesting the next batch's nodes one iteration early was measured: no gain — the node reads are not on the
@@ -2554,6 +2555,11 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const ui
         {
             return;
         }
+        long long tA = 0, tB = 0, tC = 0;
+        if (TIMED)
+        {
+            tA = __builtin_amdgcn_s_memtime();
+        }
         uint4 q0[TG], q1[TG];
         uint2 q2[TG];
 #pragma unroll
@@ -2562,6 +2568,15 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const ui
             q0[g] = nodesL[3 * (t + g) + 0];
             q1[g] = nodesL[3 * (t + g) + 1];
             q2[g] = *reinterpret_cast<const uint2*>(nodesL + 3 * (t + g) + 2);
+        }
+        if (TIMED)
+        {
+#pragma unroll
+            for (int g = 0; g < TG; g++)
+            {
+                asm volatile("" ::"v"(q0[g].x), "v"(q1[g].x), "v"(q2[g].x));
+            }
+            tB = __builtin_amdgcn_s_memtime();
         }
         float f0[W][TG], f1[W][TG], f2[W][TG];
 #pragma unroll
@@ -2586,6 +2601,10 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const ui
                 ACF_PIN_V(f2[u][g]);
             }
         }
+        if (TIMED)
+        {
+            tC = __builtin_amdgcn_s_memtime();
+        }
 #pragma unroll
         for (int g = 0; g < TG; g++)
         {
@@ -2598,9 +2617,17 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const ui
                 const bool lt1 = fc < th1;
                 const float hv = __uint_as_float(lt0 ? (lt1 ? q1[g].z : q1[g].w) : (lt1 ? q2[g].x : q2[g].y));
                 const float hn = h[u] + hv;
-                h[u] = alive[u] ? hn : h[u]; // a rejected window keeps the score it was rejected with
+                h[u] = hn; // a rejected window's score is never read again: no select to freeze it
                 alive[u] = alive[u] && (hn > thrC);
             }
+        }
+        if (TIMED && tacc)
+        {
+            asm volatile("" ::"v"(h[0]));
+            const long long tD = __builtin_amdgcn_s_memtime();
+            tacc[0] += tB - tA; // node reads
+            tacc[1] += tC - tB; // feature reads
+            tacc[2] += tD - tC; // resolve
         }
     }
     for (; t < t1; t++)
@@ -2620,7 +2647,7 @@ __device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const ui
             const bool lt1 = fc < th1;
             const float hv = __uint_as_float(lt0 ? (lt1 ? q1.z : q1.w) : (lt1 ? q2.x : q2.y));
             const float hn = h[u] + hv;
-            h[u] = alive[u] ? hn : h[u];
+            h[u] = hn;
             alive[u] = alive[u] && (hn > thrC);
         }
     }
@@ -2865,7 +2892,21 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
         alive[u] = wr < L.nWinR && (T.c0 + c_l + u * cStep) < L.nWinC;
         h[u] = 0.f;
     }
-    tile_eval_lds<W>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
+    if (a.debug & 8)
+    {
+        long long tacc[3] = { 0, 0, 0 };
+        tile_eval_lds<W, 4, true>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive, tacc);
+        if (threadIdx.x == 0)
+        {
+            a.stamps[int64_t(blockIdx.x) * 8 + 5] = tacc[0];
+            a.stamps[int64_t(blockIdx.x) * 8 + 6] = tacc[1];
+            a.stamps[int64_t(blockIdx.x) * 8 + 7] = tacc[2];
+        }
+    }
+    else
+    {
+        tile_eval_lds<W>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
+    }
     if (a.g.b[1] == tEnd)
     {
 #pragma unroll
