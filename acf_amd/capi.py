@@ -123,6 +123,9 @@ def make_params(model):
     return p, keep
 
 
+PIX_RGB, PIX_BGR, PIX_RGBA, PIX_BGRA, PIX_GRAY = range(5)
+PIX_CPP = {PIX_RGB: 3, PIX_BGR: 3, PIX_RGBA: 4, PIX_BGRA: 4, PIX_GRAY: 1}
+
 _lib = None
 
 
@@ -162,6 +165,14 @@ def load():
         "acf_hip_detect": ([ctx], C.c_int),
         "acf_hip_run": ([ctx, C.c_void_p, C.c_int], C.c_int),
         "acf_hip_run_host": ([ctx, fp, C.c_int], C.c_int),
+        "acf_hip_pyramid_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+        "acf_hip_run_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+        "acf_hip_stream_open": ([ctx, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+        "acf_hip_stream_submit": ([ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "acf_hip_stream_collect": ([ctx, C.c_int, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int)], C.c_int),
+        "acf_hip_stream_close": ([ctx], C.c_int),
+        "acf_hip_host_alloc": ([C.c_size_t, C.POINTER(C.c_void_p)], C.c_int),
+        "acf_hip_host_free": ([C.c_void_p], C.c_int),
         "acf_hip_get_detections": ([ctx, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_hits": ([ctx, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_export_detections": ([ctx, C.c_void_p, C.c_int], C.c_int),
@@ -190,6 +201,8 @@ DECLARED_SYMBOLS = [
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_pyramid_floats", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_get_detections", "acf_hip_get_hits",
+    "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
+    "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",
     "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_op_gradient_hist",
     "acf_hip_op_im_resample", "acf_hip_op_acf_detect1",

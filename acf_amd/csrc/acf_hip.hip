@@ -127,7 +127,19 @@ struct acf_hip_ctx
     float* d_chns = nullptr;
     float* d_pyr = nullptr;
     const float* lastFrames = nullptr;
-    float* d_stage = nullptr; // H2D staging for run_host
+    float* d_stage = nullptr; // H2D staging for run_host; planar f32 target of the 8-bit ingest when no colour conversion follows
+    // streaming front end (acf_hip_stream_*)
+    struct StreamSlot
+    {
+        uint8_t* d_in = nullptr;   // device copy of the packed 8-bit batch
+        int32_t* d_rec = nullptr;  // device records (acf_hip_export_detections layout)
+        int32_t* h_rec = nullptr;  // pinned host records
+        hipEvent_t evH2D = nullptr, evDone = nullptr;
+        int ticket = -1, nFrames = 0;
+    };
+    std::vector<StreamSlot> slots;
+    hipStream_t copyStream = nullptr;
+    int stPix = 0, stStride = 0, stCap = 0, nextTicket = 0, nextCollect = 0;
     // cascade (tables, model arrays, work queues, outputs): one value so that
     // acf_hip_op_acf_detect1 can swap in a temporary set and restore the plan's
     CascState cs;
@@ -225,6 +237,9 @@ void freeAll(acf_hip_ctx* c)
     c->hasPlan = false;
     c->d_lTable = c->d_acos = nullptr;
     c->d_dump = nullptr;
+    c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
+    c->lastFrames = nullptr;
+    c->pyramidValid = c->detectValid = false;
 }
 
 // rgb2luv_setup's table (toolbox/rgbConvertMex.cpp:39-58)
@@ -614,6 +629,7 @@ int acf_hip_destroy(acf_hip_ctx* c)
     }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)acf_hip_stream_close(c);
     freeAll(c);
     for (hipEvent_t e : c->evPool)
     {
@@ -1094,6 +1110,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)acf_hip_stream_close(c); // its slots are sized by the plan
     freeAll(c);
     const acf_hip_params& p = c->p;
     int rc = buildPlan(p, H, W, d_in, c->plan, c->err);
@@ -1482,10 +1499,108 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
     return ACF_HIP_OK;
 }
 
+namespace
+{
+// packed 8-bit source of a batch (acf_hip_pyramid_u8)
+struct PackedSrc
+{
+    const uint8_t* frames;
+    int pix, rowStride;
+};
+int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF);
+} // namespace
+
 int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
+{
+    return pyramidImpl(c, frames, nullptr, nF);
+}
+
+namespace
+{
+int launchIngest(acf_hip_ctx* c, const PackedSrc& u, int nF, float* dst, int64_t out_fs, bool convert)
+{
+    const acf_hip_params& p = c->p;
+    const Plan& pl = c->plan;
+    IngestArgs a{};
+    a.in = u.frames;
+    a.out = dst;
+    a.lTable = c->d_lTable;
+    a.k = makeLuvConsts();
+    a.mr = (float).2989360213 * 1.0f;
+    a.mg = (float).5870430745 * 1.0f;
+    a.mb = (float).1140209043 * 1.0f;
+    a.H = pl.H;
+    a.W = pl.W;
+    switch (u.pix)
+    {
+        case ACF_HIP_PIX_RGB: a.cpp = 3, a.ro = 0, a.go = 1, a.bo = 2; break;
+        case ACF_HIP_PIX_BGR: a.cpp = 3, a.ro = 2, a.go = 1, a.bo = 0; break;
+        case ACF_HIP_PIX_RGBA: a.cpp = 4, a.ro = 0, a.go = 1, a.bo = 2; break;
+        case ACF_HIP_PIX_BGRA: a.cpp = 4, a.ro = 2, a.go = 1, a.bo = 0; break;
+        case ACF_HIP_PIX_GRAY: a.cpp = 1, a.ro = 0, a.go = 0, a.bo = 0; break;
+        default: return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: pixel layout");
+    }
+    if ((a.cpp == 1) != (pl.d_in == 1))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: the plan's input planes (d) must be 3 for colour layouts and 1 for GRAY");
+    }
+    a.rowStride = u.rowStride > 0 ? u.rowStride : pl.W * a.cpp;
+    if (a.rowStride < pl.W * a.cpp)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: row stride smaller than a row");
+    }
+    a.in_fs = int64_t(a.rowStride) * pl.H;
+    a.out_fs = out_fs;
+    a.vecStore = (pl.H % 4 == 0) && (out_fs % 4 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+    const bool aligned = (reinterpret_cast<uintptr_t>(u.frames) % 4 == 0) && (a.rowStride % 4 == 0);
+    const int64_t np0 = int64_t(pl.H) * pl.W;
+    int mode = IG_PLANAR;
+    a.nOut = pl.d_in;
+    if (convert)
+    {
+        if (p.colorSpace == ACF_HIP_CS_LUV)
+        {
+            mode = (np0 % 4 == 0) ? IG_LUV_VEC : IG_LUV; // rgbConvertMex.cpp:92,343
+        }
+        else if (p.colorSpace == ACF_HIP_CS_GRAY)
+        {
+            mode = IG_GRAY; // a 1-plane input is replicated first (chnsPyramid.cpp:234-244): r == g == b
+        }
+        else
+        {
+            a.nOut = 3; // ORIG / RGB with a 1-plane input: replicate (chnsPyramid.cpp:242-243)
+        }
+    }
+    dim3 grid(cdiv(pl.W, IG_T), cdiv(pl.H, IG_T), nF), block(256);
+#define IG_LAUNCH(M)                                                                  \
+    if (aligned)                                                                      \
+    {                                                                                 \
+        hipLaunchKernelGGL((k_ingest_u8<M, true>), grid, block, 0, c->stream, a);     \
+    }                                                                                 \
+    else                                                                              \
+    {                                                                                 \
+        hipLaunchKernelGGL((k_ingest_u8<M, false>), grid, block, 0, c->stream, a);    \
+    }
+    switch (mode)
+    {
+        case IG_LUV_VEC: IG_LAUNCH(IG_LUV_VEC) break;
+        case IG_LUV: IG_LAUNCH(IG_LUV) break;
+        case IG_GRAY: IG_LAUNCH(IG_GRAY) break;
+        default: IG_LAUNCH(IG_PLANAR) break;
+    }
+#undef IG_LAUNCH
+    LAUNCHCHK(c, "k_ingest_u8");
+    return ACF_HIP_OK;
+}
+
+int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF)
 {
     if (c && !c->kids.empty())
     {
+        if (u8)
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "pyramid_u8: not available with option \"streams\" > 1");
+        }
         if (!frames || nF <= 0 || nF > c->maxBatch)
         {
             return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
@@ -1509,7 +1624,7 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     {
         return c ? fail(c, ACF_HIP_E_NOPLAN, "pyramid: plan first") : ACF_HIP_E_INVALID;
     }
-    if (!frames || nF <= 0 || nF > c->maxBatch)
+    if ((!frames && !u8) || (u8 && !u8->frames) || nF <= 0 || nF > c->maxBatch)
     {
         return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
     }
@@ -1519,14 +1634,44 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     const int H = pl.H, W = pl.W, d = pl.d, d_in = pl.d_in, shrink = p.shrink;
     const int64_t np0 = int64_t(H) * W;
     c->pyramidValid = c->detectValid = false;
-    c->lastFrames = frames;
     int rc;
+    if (u8)
+    {
+        // 8-bit ingest (ACF.cpp:114-119,137; MatP.cpp:51-73), fused with the colour conversion below when there is one
+        prof(c, "k_ingest_u8");
+        if (c->d_color)
+        {
+            if ((rc = launchIngest(c, *u8, nF, c->d_color, int64_t(d) * np0, true)))
+            {
+                return rc;
+            }
+            frames = nullptr;
+        }
+        else
+        {
+            if (!c->d_stage && (rc = devAlloc(c, &c->d_stage, size_t(c->maxBatch) * d_in * np0)))
+            {
+                return rc;
+            }
+            if ((rc = launchIngest(c, *u8, nF, c->d_stage, int64_t(d_in) * np0, false)))
+            {
+                return rc;
+            }
+            frames = c->d_stage;
+        }
+    }
+    c->lastFrames = frames;
 
     // ---- colour conversion, once at full resolution (chnsPyramid.cpp:230-263)
     const float* cur = frames; // "I"
     int64_t cur_fs = int64_t(d_in) * np0;
     int curH = H, curW = W;
-    if (c->d_color)
+    if (c->d_color && u8)
+    {
+        cur = c->d_color;
+        cur_fs = int64_t(d) * np0;
+    }
+    else if (c->d_color)
     {
         prof(c, "k_colour");
         dim3 grid(cdiv(np0, 256), 1, nF), block(256);
@@ -1882,6 +2027,17 @@ int acf_hip_pyramid(acf_hip_ctx* c, const float* frames, int nF)
     c->lastBatch = nF;
     c->pyramidValid = true;
     return ACF_HIP_OK;
+}
+} // namespace
+
+int acf_hip_pyramid_u8(acf_hip_ctx* c, const uint8_t* frames, int nF, int pix, int rowStride)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    PackedSrc u{ frames, pix, rowStride };
+    return pyramidImpl(c, nullptr, &u, nF);
 }
 
 static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes)
@@ -2257,6 +2413,194 @@ int acf_hip_run_host(acf_hip_ctx* c, const float* frames_host, int nF)
     }
     HIPCHK(c, hipMemcpyAsync(c->d_stage, frames_host, per * nF * sizeof(float), hipMemcpyHostToDevice, c->stream));
     return acf_hip_run(c, c->d_stage, nF);
+}
+
+int acf_hip_run_u8(acf_hip_ctx* c, const uint8_t* frames, int nF, int pix, int rowStride)
+{
+    int rc = acf_hip_pyramid_u8(c, frames, nF, pix, rowStride);
+    if (rc)
+    {
+        return rc;
+    }
+    return acf_hip_detect(c);
+}
+
+// ---------------------------------------------------------------------------
+// streaming front end: copy stream + per-slot events; see include/acf_hip.h
+// ---------------------------------------------------------------------------
+int acf_hip_stream_close(acf_hip_ctx* c)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    (void)hipSetDevice(c->device);
+    if (c->copyStream)
+    {
+        (void)hipStreamSynchronize(c->copyStream);
+    }
+    if (c->stream)
+    {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    for (auto& s : c->slots)
+    {
+        if (s.d_in)
+        {
+            (void)hipFree(s.d_in);
+        }
+        if (s.d_rec)
+        {
+            (void)hipFree(s.d_rec);
+        }
+        if (s.h_rec)
+        {
+            (void)hipHostFree(s.h_rec);
+        }
+        if (s.evH2D)
+        {
+            (void)hipEventDestroy(s.evH2D);
+        }
+        if (s.evDone)
+        {
+            (void)hipEventDestroy(s.evDone);
+        }
+    }
+    c->slots.clear();
+    if (c->copyStream)
+    {
+        (void)hipStreamDestroy(c->copyStream);
+        c->copyStream = nullptr;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_stream_open(acf_hip_ctx* c, int pix, int rowStride, int cap, int depth)
+{
+    if (!c || !c->hasPlan)
+    {
+        return c ? fail(c, ACF_HIP_E_NOPLAN, "stream_open: plan first") : ACF_HIP_E_INVALID;
+    }
+    if (!c->kids.empty())
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "stream_open: not available with option \"streams\" > 1");
+    }
+    if (depth < 2 || depth > 8 || cap <= 0 || pix < ACF_HIP_PIX_RGB || pix > ACF_HIP_PIX_GRAY)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "stream_open: depth must be 2..8, cap > 0, pix one of ACF_HIP_PIX_*");
+    }
+    const int cpp = (pix == ACF_HIP_PIX_GRAY) ? 1 : (pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3;
+    if ((cpp == 1) != (c->plan.d_in == 1))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "stream_open: the plan's input planes (d) must be 3 for colour layouts and 1 for GRAY");
+    }
+    const int stride = rowStride > 0 ? rowStride : c->plan.W * cpp;
+    if (stride < c->plan.W * cpp)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "stream_open: row stride smaller than a row");
+    }
+    acf_hip_stream_close(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    c->stPix = pix;
+    c->stStride = stride;
+    c->stCap = cap;
+    c->nextTicket = c->nextCollect = 0;
+    c->slots.resize(size_t(depth));
+    const size_t inBytes = size_t(c->maxBatch) * stride * c->plan.H;
+    const size_t recBytes = size_t(c->maxBatch) * (1 + 6 * size_t(cap)) * sizeof(int32_t);
+    for (auto& s : c->slots)
+    {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&s.d_in), inBytes));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&s.d_rec), recBytes));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&s.h_rec), recBytes, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&s.evH2D, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&s.evDone, hipEventDisableTiming));
+        s.ticket = -1;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_stream_submit(acf_hip_ctx* c, const uint8_t* frames_host, int nF, int* ticket)
+{
+    if (!c || c->slots.empty())
+    {
+        return c ? fail(c, ACF_HIP_E_INVALID, "stream_submit: stream_open first") : ACF_HIP_E_INVALID;
+    }
+    if (!frames_host || nF <= 0 || nF > c->maxBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "stream_submit: n_frames out of range");
+    }
+    const int depth = int(c->slots.size());
+    if (c->nextTicket - c->nextCollect >= depth)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "stream_submit: every slot is in flight; collect the oldest ticket first");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    acf_hip_ctx::StreamSlot& s = c->slots[size_t(c->nextTicket % depth)];
+    // The slot's previous batch was collected (checked above), so its device input and host records are free.
+    const size_t bytes = size_t(nF) * c->stStride * c->plan.H;
+    HIPCHK(c, hipMemcpyAsync(s.d_in, frames_host, bytes, hipMemcpyHostToDevice, c->copyStream));
+    HIPCHK(c, hipEventRecord(s.evH2D, c->copyStream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.evH2D, 0));
+    int rc = acf_hip_run_u8(c, s.d_in, nF, c->stPix, c->stStride);
+    if (rc)
+    {
+        return rc;
+    }
+    if ((rc = acf_hip_export_detections(c, s.d_rec, c->stCap)))
+    {
+        return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(s.h_rec, s.d_rec, size_t(nF) * (1 + 6 * size_t(c->stCap)) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(s.evDone, c->stream));
+    s.ticket = c->nextTicket;
+    s.nFrames = nF;
+    if (ticket)
+    {
+        *ticket = s.ticket;
+    }
+    c->nextTicket++;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_stream_collect(acf_hip_ctx* c, int ticket, const int32_t** records, int* nFrames)
+{
+    if (!c || c->slots.empty())
+    {
+        return c ? fail(c, ACF_HIP_E_INVALID, "stream_collect: stream_open first") : ACF_HIP_E_INVALID;
+    }
+    if (ticket != c->nextCollect || ticket >= c->nextTicket)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "stream_collect: tickets are collected in submission order");
+    }
+    acf_hip_ctx::StreamSlot& s = c->slots[size_t(ticket % int(c->slots.size()))];
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(s.evDone));
+    if (records)
+    {
+        *records = s.h_rec;
+    }
+    if (nFrames)
+    {
+        *nFrames = s.nFrames;
+    }
+    c->nextCollect++;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? ACF_HIP_OK : ACF_HIP_E_HIP;
+}
+
+int acf_hip_host_free(void* p)
+{
+    return (!p || hipHostFree(p) == hipSuccess) ? ACF_HIP_OK : ACF_HIP_E_HIP;
 }
 
 int acf_hip_synchronize(acf_hip_ctx* c)

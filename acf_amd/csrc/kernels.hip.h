@@ -35,18 +35,8 @@ struct LuvConsts
 // reference picks VEC iff n % 4 == 0.  lTable: 1064 floats built on the host
 // exactly as rgb2luv_setup does (:39-58).
 template <bool VEC>
-__global__ void __launch_bounds__(256) k_rgb2luv(const float* __restrict__ in, float* __restrict__ out,
-    const float* __restrict__ lTable, LuvConsts k, int n, int64_t in_fs, int64_t out_fs)
+__device__ __forceinline__ void luv_px(float r, float g, float b, const float* __restrict__ lTable, const LuvConsts& k, float& L, float& U, float& V)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-    {
-        return;
-    }
-    const float* I = in + int64_t(blockIdx.z) * in_fs;
-    float* J = out + int64_t(blockIdx.z) * out_fs;
-    const float r = I[i], g = I[i + n], b = I[i + 2 * int64_t(n)];
-    float L, U, V;
     if (VEC)
     {
         const float x = (r * k.mr[0] + g * k.mg[0]) + b * k.mb[0];
@@ -70,6 +60,22 @@ __global__ void __launch_bounds__(256) k_rgb2luv(const float* __restrict__ in, f
         U = L * (13 * 4 * x * z - 13 * k.un) - k.minu;
         V = L * (13 * 9 * y * z - 13 * k.vn) - k.minv;
     }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_rgb2luv(const float* __restrict__ in, float* __restrict__ out,
+    const float* __restrict__ lTable, LuvConsts k, int n, int64_t in_fs, int64_t out_fs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const float* I = in + int64_t(blockIdx.z) * in_fs;
+    float* J = out + int64_t(blockIdx.z) * out_fs;
+    const float r = I[i], g = I[i + n], b = I[i + 2 * int64_t(n)];
+    float L, U, V;
+    luv_px<VEC>(r, g, b, lTable, k, L, U, V);
     J[i] = L;
     J[i + n] = U;
     J[i + 2 * int64_t(n)] = V;
@@ -106,6 +112,151 @@ __global__ void __launch_bounds__(256) k_replicate3(const float* __restrict__ in
     J[i] = v;
     J[i + n] = v;
     J[i + 2 * int64_t(n)] = v;
+}
+
+// ------------------------------------------------------------------------
+// Packed 8-bit upright frames -> transposed planar f32.
+//
+// Restates the image entry of the detector: cvt8UC3To32FC3 = convertTo(CV_32FC3, 1/255) (ACF.cpp:114-119; OpenCV's
+// 8u->32f cvtScale works in f32: float(v) * float(1/255.0)), I.t() (ACF.cpp:137,149) and the MatP plane split
+// (MatP.cpp:51-73).  The colour conversion of chnsPyramid.cpp:230-263 is applied in registers when MODE asks for it,
+// so the planar f32 RGB image never goes to HBM.
+//
+// A workgroup moves one 64 x 64 pixel tile: rows are read as dwords (coalesced along image-x) into LDS, then every
+// lane takes 4 consecutive image-y of one image-x and writes one float4 per output plane (coalesced along image-y).
+// The LDS row pitch is 65 dwords, so the 16 row-quads of a wave hit 16 distinct banks.
+// ------------------------------------------------------------------------
+enum
+{
+    IG_PLANAR = 0, // nOut planes, plane c = component c (after the ro/go/bo swizzle)
+    IG_LUV_VEC = 1, // rgb2luv_sse body
+    IG_LUV = 2,     // scalar rgb2luv
+    IG_GRAY = 3     // rgb2gray
+};
+
+struct IngestArgs
+{
+    const uint8_t* in;
+    float* out;
+    const float* lTable;
+    LuvConsts k;
+    float mr, mg, mb;
+    int H, W;        // upright rows, columns
+    int cpp;         // bytes per pixel (1, 3, 4)
+    int ro, go, bo;  // byte offsets of r, g, b inside a pixel
+    int rowStride;   // bytes between image rows
+    int64_t in_fs;   // bytes between frames
+    int64_t out_fs;  // floats between output frames
+    int nOut;        // IG_PLANAR: 1 or 3 planes
+    int vecStore;    // H % 4 == 0: float4 stores
+};
+
+constexpr int IG_T = 64;
+constexpr int IG_PITCH = 260; // bytes; 65 dwords
+
+template <int MODE, bool ALIGNED>
+__global__ void __launch_bounds__(256) k_ingest_u8(IngestArgs a)
+{
+    __shared__ uint32_t tileW[IG_T * IG_PITCH / 4];
+    uint8_t* tile = reinterpret_cast<uint8_t*>(tileW);
+    const int x0 = blockIdx.x * IG_T, y0 = blockIdx.y * IG_T;
+    const int nx = min(IG_T, a.W - x0), ny = min(IG_T, a.H - y0);
+    const uint8_t* src = a.in + int64_t(blockIdx.z) * a.in_fs + int64_t(y0) * a.rowStride + int64_t(x0) * a.cpp;
+    const int nb = nx * a.cpp;
+    if (ALIGNED)
+    {
+        // base, row stride and frame stride are multiples of 4 (host-checked) and x0 * cpp is a multiple of 64
+        const int nd = (nb + 3) >> 2; // the last dword of a row may run into the next row: still inside the frame
+        const int lastOk = (y0 + ny == a.H && blockIdx.z == gridDim.z - 1) ? (nb >> 2) : nd; // ... except at the very end
+        for (int i = threadIdx.x; i < ny * 64; i += 256)
+        {
+            const int yy = i >> 6, j = i & 63;
+            if (j < nd)
+            {
+                const uint8_t* rp = src + int64_t(yy) * a.rowStride;
+                uint32_t v;
+                if (j < lastOk || yy + 1 < ny)
+                {
+                    v = reinterpret_cast<const uint32_t*>(rp)[j];
+                }
+                else
+                {
+                    v = 0;
+                    for (int b = 0; b < nb - 4 * j; b++)
+                    {
+                        v |= uint32_t(rp[4 * j + b]) << (8 * b);
+                    }
+                }
+                tileW[yy * (IG_PITCH / 4) + j] = v;
+            }
+        }
+    }
+    else
+    {
+        for (int i = threadIdx.x; i < ny * 256; i += 256)
+        {
+            const int yy = i >> 8, j = i & 255;
+            if (j < nb)
+            {
+                tile[yy * IG_PITCH + j] = src[int64_t(yy) * a.rowStride + j];
+            }
+        }
+    }
+    __syncthreads();
+    const int yq = (threadIdx.x & 15) * 4;
+    const float sc = float(1.0 / 255.0);
+    float* outF = a.out + int64_t(blockIdx.z) * a.out_fs;
+    const int64_t np = int64_t(a.H) * a.W;
+    for (int xx = threadIdx.x >> 4; xx < nx; xx += 16)
+    {
+        float o[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int yy = min(yq + j, IG_T - 1);
+            const uint8_t* px = tile + yy * IG_PITCH + xx * a.cpp;
+            const float r = float(px[a.ro]) * sc, g = float(px[a.go]) * sc, b = float(px[a.bo]) * sc;
+            if (MODE == IG_PLANAR)
+            {
+                o[0][j] = r;
+                o[1][j] = g;
+                o[2][j] = b;
+            }
+            else if (MODE == IG_GRAY)
+            {
+                o[0][j] = r * a.mr + g * a.mg + b * a.mb; // rgbConvertMex.cpp:241-252
+            }
+            else
+            {
+                luv_px<MODE == IG_LUV_VEC>(r, g, b, a.lTable, a.k, o[0][j], o[1][j], o[2][j]);
+            }
+        }
+        const int nPl = (MODE == IG_PLANAR) ? a.nOut : (MODE == IG_GRAY ? 1 : 3);
+        const int64_t at = int64_t(x0 + xx) * a.H + y0 + yq;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+        {
+            if (c < nPl)
+            {
+                float* d = outF + c * np + at;
+                if (a.vecStore && yq + 3 < ny)
+                {
+                    *reinterpret_cast<float4*>(d) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+                }
+                else
+                {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        if (yq + j < ny)
+                        {
+                            d[j] = o[c][j];
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1697,7 +1848,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 }
 
 template <int R, int MODE>
-__global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
@@ -1817,7 +1968,7 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
         xr = xrn;                                                                                                   \
         xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
     }
-#define LV_FILTER(I, CUR, NXT, OB)                                                                                  \
+#define LV_FILTER(I, CUR, NXT)                                                                                      \
     {                                                                                                               \
         const int i_ = (I);                                                                                         \
         float T[R], up[R], dn[R];                                                                                   \
@@ -1843,22 +1994,10 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
             /* lanes past the end of the plane (last register only) are clamped to row h-1: they store row h-1's */ \
             /* value to row h-1's address, so every store is unconditional and base + 32-bit offset             */ \
             const float ov = (k < R - 1 || lastOk) ? o : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o), lastLane)); \
-            OB[k] = ov;                                                                                             \
+            buf_st(Osrd, yoff[k], uint32_t(i_) * uint32_t(J.out_cs) * 4u, ov);                                      \
         }                                                                                                           \
     }
-    // Outputs are kept in registers and stored four columns at a time.  vmcnt completes IN ORDER over loads and
-    // stores alike: waiting for a load also waits for every store issued before it, and a store is only done
-    // when L2 acknowledges it (~2 us here).  With a store after every column each step paid that; batched, the
-    // first load after a batch pays it once per four columns.
-#define LV_STORE(I, OB)                                                                                             \
-    {                                                                                                               \
-        const uint32_t oc = uint32_t(I) * uint32_t(J.out_cs) * 4u;                                                  \
-        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
-        {                                                                                                           \
-            buf_st(Osrd, yoff[k], oc, OB[k]);                                                                       \
-        }                                                                                                           \
-    }
-    float o0[R], o1[R], o2[R], o3[R];
+    // (storing four columns at a time instead of one was measured: no gain, 16 more VGPRs)
     // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
     LV_LOAD(b0, 0);
     LV_LOAD(b1, 1);
@@ -1867,35 +2006,27 @@ __global__ void __launch_bounds__(256) k_level(const float* __restrict__ chns, f
     for (; i + 3 < w; i += 4)
     {
         LV_LOAD(b3, i + 3);
-        LV_FILTER(i, b0, b1, o0);
+        LV_FILTER(i, b0, b1);
         LV_LOAD(b0, i + 4);
-        LV_FILTER(i + 1, b1, b2, o1);
+        LV_FILTER(i + 1, b1, b2);
         LV_LOAD(b1, i + 5);
-        LV_FILTER(i + 2, b2, b3, o2);
+        LV_FILTER(i + 2, b2, b3);
         LV_LOAD(b2, i + 6);
-        LV_FILTER(i + 3, b3, b0, o3);
-        LV_STORE(i, o0);
-        LV_STORE(i + 1, o1);
-        LV_STORE(i + 2, o2);
-        LV_STORE(i + 3, o3);
+        LV_FILTER(i + 3, b3, b0);
     }
     // tail: up to three columns; their inputs are already in b0, b1, b2
     if (i < w)
     {
-        LV_FILTER(i, b0, b1, o0);
-        LV_STORE(i, o0);
+        LV_FILTER(i, b0, b1);
     }
     if (i + 1 < w)
     {
-        LV_FILTER(i + 1, b1, b2, o1);
-        LV_STORE(i + 1, o1);
+        LV_FILTER(i + 1, b1, b2);
     }
     if (i + 2 < w)
     {
-        LV_FILTER(i + 2, b2, b2, o2);
-        LV_STORE(i + 2, o2);
+        LV_FILTER(i + 2, b2, b2);
     }
-#undef LV_STORE
 #undef LV_LOAD
 #undef LV_FILTER
 }

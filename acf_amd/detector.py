@@ -26,6 +26,36 @@ def _dev_ptr(x):
     return x.data_ptr()
 
 
+def _dev_ptr_u8(x):
+    if isinstance(x, int):
+        return x
+    assert x.is_cuda and x.is_contiguous() and x.element_size() == 1
+    return x.data_ptr()
+
+
+class PinnedBuffer:
+    """Page-locked host memory from the library (acf_hip_host_alloc), viewed as a numpy uint8 array."""
+
+    def __init__(self, nbytes):
+        self.lib = capi.load()
+        self.ptr = C.c_void_p()
+        if self.lib.acf_hip_host_alloc(nbytes, C.byref(self.ptr)):
+            raise HipError(5, "acf_hip_host_alloc failed")
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.lib.acf_hip_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipDetector:
     def __init__(self, model=None, H=0, W=0, d_in=3, max_batch=1, max_hits=4096, device=0, stream=None, taps=False, streams=1):
         self.lib = capi.load()
@@ -94,6 +124,36 @@ class HipDetector:
     def run_host(self, frames):
         frames = np.ascontiguousarray(frames, dtype=np.float32)
         self._chk(self.lib.acf_hip_run_host(self.ctx, capi.fptr(frames), frames.shape[0]))
+
+    def pyramid_u8(self, frames, pix=capi.PIX_RGB, row_stride=0, n=None):
+        """frames: torch uint8 CUDA tensor [n][H][W][cpp] (upright, packed) or a raw device pointer."""
+        n = n if n is not None else frames.shape[0]
+        self._chk(self.lib.acf_hip_pyramid_u8(self.ctx, C.c_void_p(_dev_ptr_u8(frames)), n, pix, row_stride))
+
+    def run_u8(self, frames, pix=capi.PIX_RGB, row_stride=0, n=None):
+        n = n if n is not None else frames.shape[0]
+        self._chk(self.lib.acf_hip_run_u8(self.ctx, C.c_void_p(_dev_ptr_u8(frames)), n, pix, row_stride))
+
+    # ---- streaming front end (pinned host frames in, pinned host records out)
+    def stream_open(self, pix=capi.PIX_RGB, row_stride=0, cap=1024, depth=2):
+        self._chk(self.lib.acf_hip_stream_open(self.ctx, pix, row_stride, cap, depth))
+        self._stream_cap = cap
+
+    def stream_submit(self, host_ptr, n):
+        t = C.c_int()
+        self._chk(self.lib.acf_hip_stream_submit(self.ctx, C.c_void_p(host_ptr), n, C.byref(t)))
+        return t.value
+
+    def stream_collect(self, ticket):
+        """-> int32 array [n][1 + 6*cap] (a copy of the pinned records: count, then {x,y,w,h,score bits,scale})."""
+        rec = C.POINTER(C.c_int32)()
+        n = C.c_int()
+        self._chk(self.lib.acf_hip_stream_collect(self.ctx, ticket, C.byref(rec), C.byref(n)))
+        per = 1 + 6 * self._stream_cap
+        return np.ctypeslib.as_array(rec, shape=(n.value, per)).copy()
+
+    def stream_close(self):
+        self._chk(self.lib.acf_hip_stream_close(self.ctx))
 
     def synchronize(self):
         self._chk(self.lib.acf_hip_synchronize(self.ctx))

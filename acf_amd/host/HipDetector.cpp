@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace acf
@@ -28,6 +29,10 @@ HipDetector::~HipDetector()
     if (m_ctx && m_api)
     {
         m_api->acf_hip_destroy(m_ctx);
+    }
+    if (m_pin && m_api)
+    {
+        m_api->acf_hip_host_free(m_pin);
     }
 }
 
@@ -157,6 +162,7 @@ void HipDetector::ensurePlan(int imgH, int imgW, int d, int batch)
         m_planW = imgW;
         m_planD = d;
         m_planBatch = batch;
+        m_streamCap = 0; // a re-plan closes the stream (its slots are sized by the plan)
         int n = 0;
         check(m_api->acf_hip_num_levels(m_ctx, &n, &m_nChns), "acf_hip_num_levels");
         m_levels.resize(size_t(n));
@@ -275,6 +281,11 @@ void HipDetector::fetch(int frame, RectVec& objects, RealVec* scores)
         bbs[size_t(i)].roi = Rect(d[size_t(i)].x, d[size_t(i)].y, d[size_t(i)].w, d[size_t(i)].h);
         bbs[size_t(i)].score = double(d[size_t(i)].score);
     }
+    finish(bbs, objects, scores);
+}
+
+void HipDetector::finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const
+{
     if (m_doNms)
     {
         // ACF.cpp:332-353
@@ -347,6 +358,116 @@ int HipDetector::operator()(const float* rgb, int rows, int cols, RectVec& objec
         }
     }
     return (*this)(Ip, objects, scores);
+}
+
+int HipDetector::operator()(const uint8_t* packed, int rows, int cols, int pix, int rowStrideBytes, RectVec& objects, RealVec* scores)
+{
+    if (!packed || rows <= 0 || cols <= 0)
+    {
+        throw Exception(ACF_HIP_E_INVALID, "operator()(packed): empty image");
+    }
+    if (m_isTranspose)
+    {
+        throw Exception(ACF_HIP_E_UNSUPPORTED, "operator()(packed): 8-bit input must be upright (setIsTranspose(false))");
+    }
+    const int cpp = pix == ACF_HIP_PIX_GRAY ? 1 : (pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3;
+    const int stride = rowStrideBytes > 0 ? rowStrideBytes : cols * cpp;
+    // one-frame stream: H2D on the copy stream, ingest + pyramid + cascade on the context's stream
+    if (m_streamCap == 0 || m_planH != rows || m_planW != cols || m_planD != (cpp == 1 ? 1 : 3) || m_dirty || pix != m_streamPix ||
+        stride != m_streamStride)
+    {
+        streamOpen(rows, cols, pix, stride, std::max(1, m_planBatch), 2);
+    }
+    const size_t bytes = size_t(stride) * rows;
+    if (bytes > m_pinBytes)
+    {
+        pinnedFree(m_pin);
+        m_pin = pinnedAlloc(bytes);
+        m_pinBytes = bytes;
+    }
+    std::memcpy(m_pin, packed, bytes);
+    const int t = streamSubmit(static_cast<const uint8_t*>(m_pin), 1);
+    const int32_t* rec = nullptr;
+    int n = 0;
+    check(m_api->acf_hip_stream_collect(m_ctx, t, &rec, &n), "acf_hip_stream_collect");
+    fetch(0, objects, scores); // every detection, not only the first `cap` of the record
+    return 0;
+}
+
+void HipDetector::streamOpen(int rows, int cols, int pix, int rowStrideBytes, int maxBatch, int depth, int maxDetectionsPerFrame)
+{
+    const int d = pix == ACF_HIP_PIX_GRAY ? 1 : 3;
+    ensurePlan(rows, cols, d, maxBatch);
+    check(m_api->acf_hip_stream_open(m_ctx, pix, rowStrideBytes, maxDetectionsPerFrame, depth), "acf_hip_stream_open");
+    m_streamCap = maxDetectionsPerFrame;
+    m_streamPix = pix;
+    m_streamStride = rowStrideBytes > 0 ? rowStrideBytes : cols * (pix == ACF_HIP_PIX_GRAY ? 1 : (pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3);
+}
+
+int HipDetector::streamSubmit(const uint8_t* frames, int nFrames)
+{
+    int t = -1;
+    check(m_api->acf_hip_stream_submit(m_ctx, frames, nFrames, &t), "acf_hip_stream_submit");
+    ++m_generation; // any Pyramid handed out earlier is no longer the resident one
+    return t;
+}
+
+void HipDetector::streamCollect(int ticket, std::vector<RectVec>& objects, std::vector<RealVec>* scores)
+{
+    const int32_t* rec = nullptr;
+    int n = 0;
+    check(m_api->acf_hip_stream_collect(m_ctx, ticket, &rec, &n), "acf_hip_stream_collect");
+    objects.assign(size_t(n), RectVec());
+    if (scores)
+    {
+        scores->assign(size_t(n), RealVec());
+    }
+    const size_t per = 1 + 6 * size_t(m_streamCap);
+    for (int f = 0; f < n; f++)
+    {
+        const int32_t* r = rec + size_t(f) * per;
+        if (r[0] > m_streamCap)
+        {
+            throw Exception(ACF_HIP_E_CAPACITY, "streamCollect: more detections than maxDetectionsPerFrame");
+        }
+        DetectionVec bbs(static_cast<size_t>(r[0]));
+        for (int i = 0; i < r[0]; i++)
+        {
+            const int32_t* q = r + 1 + 6 * size_t(i);
+            bbs[size_t(i)].roi = Rect(q[0], q[1], q[2], q[3]);
+            float sc;
+            std::memcpy(&sc, &q[4], sizeof(float));
+            bbs[size_t(i)].score = double(sc);
+        }
+        finish(bbs, objects[size_t(f)], scores ? &(*scores)[size_t(f)] : nullptr);
+    }
+}
+
+void HipDetector::streamClose()
+{
+    if (m_ctx)
+    {
+        check(m_api->acf_hip_stream_close(m_ctx), "acf_hip_stream_close");
+    }
+    m_streamCap = 0;
+}
+
+void* HipDetector::pinnedAlloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hip::load().acf_hip_host_alloc(bytes, &p))
+    {
+        throw Exception(ACF_HIP_E_HIP, "acf_hip_host_alloc");
+    }
+    return p;
+}
+
+void HipDetector::pinnedFree(void* p)
+{
+    if (p)
+    {
+        hip::load().acf_hip_host_free(p);
+    }
 }
 
 int HipDetector::detectBatch(const float* frames, int nFrames, int rows, int cols, int channels,

@@ -221,11 +221,28 @@ public:
     int operator()(const MatP& IpTranspose, RectVec& objects, RealVec* scores = nullptr);
     // Packed interleaved RGB f32 in [0,1], upright rows x cols x 3 unless setIsTranspose(true) (ACF.cpp:135-141).
     int operator()(const float* rgbInterleaved, int rows, int cols, RectVec& objects, RealVec* scores = nullptr);
+    // Packed 8-bit image (CV_8UC3 RGB / CV_8UC4 / CV_8UC1 of the reference's cv::Mat entry, ACF.cpp:135-141), upright
+    // rows x cols, `pix` = ACF_HIP_PIX_*, `rowStrideBytes` 0 = tight.  /255, transpose, plane split and the colour
+    // conversion all happen on the device (acf_hip_run_u8).
+    int operator()(const uint8_t* packed, int rows, int cols, int pix, int rowStrideBytes, RectVec& objects, RealVec* scores = nullptr);
     // Multi-scale search on a pyramid (ACF.cpp:268-367).
     int operator()(const Pyramid& P, RectVec& objects, RealVec* scores = nullptr);
     // Batch of frames (no reference precedent; frames are independent): per-frame outputs.
     int detectBatch(const float* framesTransposedPlanar, int nFrames, int rows, int cols, int channels,
         std::vector<RectVec>& objects, std::vector<RealVec>* scores = nullptr);
+
+    // Streaming front end (the role of GPUDetectionPipeline::runFast's two-frame FIFO, GPUDetectionPipeline.cpp:357-437):
+    // batches of packed 8-bit frames are copied to the device while the previous batch computes.
+    //   streamOpen(rows, cols, pix, stride, maxBatch, depth); t = streamSubmit(frames, n); streamCollect(t, objects, &scores);
+    // `frames` should be page-locked (pinnedAlloc) and stay untouched until its ticket is collected; tickets are
+    // collected in submission order.  At most maxDetectionsPerFrame (streamOpen) boxes per frame come back, in the
+    // reference's order, before NMS/prune are applied exactly as in operator().
+    void streamOpen(int rows, int cols, int pix, int rowStrideBytes, int maxBatch, int depth = 2, int maxDetectionsPerFrame = 4096);
+    int streamSubmit(const uint8_t* frames, int nFrames);
+    void streamCollect(int ticket, std::vector<RectVec>& objects, std::vector<RealVec>* scores = nullptr);
+    void streamClose();
+    static void* pinnedAlloc(size_t bytes);
+    static void pinnedFree(void* p);
 
     void computePyramid(const MatP& Ip, Pyramid& P); // ACF.cpp:147-159
     int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false); // chnsPyramid.cpp:160-456
@@ -252,6 +269,7 @@ private:
     void fillParams(acf_hip_params& p) const;
     void ensurePlan(int imgH, int imgW, int d, int batch);
     void fetch(int frame, RectVec& objects, RealVec* scores);
+    void finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const; // ACF.cpp:332-364
 
     const hip::Api* m_api = nullptr;
     acf_hip_ctx* m_ctx = nullptr;
@@ -264,6 +282,9 @@ private:
     std::vector<acf_hip_level> m_levels;
     int m_nChns = 0;
     std::vector<float> m_upright; // scratch for operator()(interleaved)
+    int m_streamCap = 0, m_streamPix = -1, m_streamStride = 0;
+    void* m_pin = nullptr; // pinned scratch of operator()(packed 8-bit)
+    size_t m_pinBytes = 0;
 };
 
 } // namespace acf

@@ -3,6 +3,8 @@
 //
 //   acf_hip_detect --model m.acfm --frames f.raw --rows W --cols H --channels d --count N
 //                  [--luv] [--nms] [--batch] [--via-pyramid] [--max-count K] [--prune-ratio R]
+//   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] ...
+//                  packed 8-bit upright frames; --stream B: batches of B frames through streamSubmit/streamCollect
 //   acf_hip_detect --nms-only boxes.txt [--type maxg] [--overlap .65] [--ovrdnm min]   (host logic only, no GPU)
 //
 // Model file ("ACFHIPM1", written by acf_amd/modelio.py): text header of
@@ -176,6 +178,69 @@ int main(int argc, char** argv)
             m.has_cascCal = true;
             m.cascCal = std::stod(a["casc-cal"]);
             det.acfModify(m);
+        }
+        if (a.count("u8"))
+        {
+            static const std::map<std::string, int> kPix = { { "rgb", ACF_HIP_PIX_RGB }, { "bgr", ACF_HIP_PIX_BGR }, { "rgba", ACF_HIP_PIX_RGBA },
+                { "bgra", ACF_HIP_PIX_BGRA }, { "gray", ACF_HIP_PIX_GRAY } };
+            const int pix = kPix.at(a["u8"]);
+            const int cpp = pix == ACF_HIP_PIX_GRAY ? 1 : (pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3;
+            const int H = std::stoi(a.at("rows")), W = std::stoi(a.at("cols")), cnt = std::stoi(a.at("count"));
+            const size_t per = size_t(H) * W * cpp;
+            std::vector<uint8_t> frames(per * size_t(cnt));
+            std::ifstream is(a.at("frames"), std::ios::binary);
+            is.read(reinterpret_cast<char*>(frames.data()), std::streamsize(frames.size()));
+            if (!is)
+            {
+                std::fprintf(stderr, "short frames file\n");
+                return 2;
+            }
+            if (a.count("stream"))
+            {
+                const int B = std::stoi(a["stream"]), depth = 2;
+                det.streamOpen(H, W, pix, 0, B, depth, 8192);
+                uint8_t* pin[2] = { static_cast<uint8_t*>(HipDetector::pinnedAlloc(per * size_t(B))), static_cast<uint8_t*>(HipDetector::pinnedAlloc(per * size_t(B))) };
+                std::vector<std::pair<int, int>> inflight; // ticket, first frame
+                auto drain = [&]() {
+                    std::vector<HipDetector::RectVec> objs;
+                    std::vector<HipDetector::RealVec> scores;
+                    det.streamCollect(inflight.front().first, objs, &scores);
+                    for (size_t f = 0; f < objs.size(); f++)
+                    {
+                        printFrame(inflight.front().second + int(f), objs[f], scores[f]);
+                    }
+                    inflight.erase(inflight.begin());
+                };
+                int k = 0;
+                for (int f0 = 0; f0 < cnt; f0 += B, k++)
+                {
+                    if (int(inflight.size()) == depth)
+                    {
+                        drain();
+                    }
+                    const int n = std::min(B, cnt - f0);
+                    std::memcpy(pin[k % 2], frames.data() + per * size_t(f0), per * size_t(n));
+                    inflight.emplace_back(det.streamSubmit(pin[k % 2], n), f0);
+                }
+                while (!inflight.empty())
+                {
+                    drain();
+                }
+                det.streamClose();
+                HipDetector::pinnedFree(pin[0]);
+                HipDetector::pinnedFree(pin[1]);
+            }
+            else
+            {
+                for (int f = 0; f < cnt; f++)
+                {
+                    HipDetector::RectVec objs;
+                    HipDetector::RealVec scores;
+                    det(frames.data() + per * size_t(f), H, W, pix, 0, objs, &scores);
+                    printFrame(f, objs, scores);
+                }
+            }
+            return 0;
         }
         const int rows = std::stoi(a.at("rows")), cols = std::stoi(a.at("cols")), ch = std::stoi(a.at("channels")), cnt = std::stoi(a.at("count"));
         std::vector<float> frames(size_t(rows) * cols * ch * cnt);

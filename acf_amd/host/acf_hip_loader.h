@@ -36,6 +36,14 @@ struct Api
     ACF_HIP_FN(acf_hip_detect)
     ACF_HIP_FN(acf_hip_run)
     ACF_HIP_FN(acf_hip_run_host)
+    ACF_HIP_FN(acf_hip_pyramid_u8)
+    ACF_HIP_FN(acf_hip_run_u8)
+    ACF_HIP_FN(acf_hip_stream_open)
+    ACF_HIP_FN(acf_hip_stream_submit)
+    ACF_HIP_FN(acf_hip_stream_collect)
+    ACF_HIP_FN(acf_hip_stream_close)
+    ACF_HIP_FN(acf_hip_host_alloc)
+    ACF_HIP_FN(acf_hip_host_free)
     ACF_HIP_FN(acf_hip_get_detections)
     ACF_HIP_FN(acf_hip_get_hits)
     ACF_HIP_FN(acf_hip_export_detections)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 1
+#define ACF_HIP_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -202,6 +202,50 @@ ACF_HIP_API int acf_hip_run(acf_hip_ctx* ctx, const float* frames_dev, int n_fra
 
 /* Same with frames in host memory (H2D copy included). */
 ACF_HIP_API int acf_hip_run_host(acf_hip_ctx* ctx, const float* frames_host, int n_frames);
+
+/* Pixel layouts of packed 8-bit frames: the cv::Mat inputs of the image entry
+ * Detector::operator()(const cv::Mat&) (CV_8UC3 RGB, ACF.cpp:135-141) and the
+ * BGR/BGRA/grey video frames the apps convert before calling it (acf.cpp:117-148,
+ * GPUDetectionPipeline.cpp:250-266).  Alpha is ignored. */
+enum {
+    ACF_HIP_PIX_RGB = 0,
+    ACF_HIP_PIX_BGR = 1,
+    ACF_HIP_PIX_RGBA = 2,
+    ACF_HIP_PIX_BGRA = 3,
+    ACF_HIP_PIX_GRAY = 4
+};
+
+/* The image entry for 8-bit input: cvt8UC3To32FC3 = convertTo(CV_32F, 1/255)
+ * (ACF.cpp:114-119), I.t() (ACF.cpp:137) and the MatP plane split
+ * (MatP.cpp:51-73) in one kernel, fused with the colour conversion of
+ * chnsPyramid.cpp:230-263 when the model asks for one; then as acf_hip_pyramid.
+ * `frames_dev`: n_frames upright images of h rows x w pixels, `row_stride_bytes`
+ * between rows (0 = tightly packed), frames back to back (h * stride bytes
+ * apart).  The plan's `d` must be 3 for the colour layouts and 1 for GRAY. */
+ACF_HIP_API int acf_hip_pyramid_u8(acf_hip_ctx* ctx, const uint8_t* frames_dev, int n_frames, int pix, int row_stride_bytes);
+ACF_HIP_API int acf_hip_run_u8(acf_hip_ctx* ctx, const uint8_t* frames_dev, int n_frames, int pix, int row_stride_bytes);
+
+/* ---- streaming front end ---------------------------------------------
+ * The overlap of transfer and compute that GPUDetectionPipeline::runFast gets
+ * from its two-frame texture FIFO (GPUDetectionPipeline.cpp:357-437), expressed
+ * with HIP streams and events: batch k+1 is copied host->device on a copy
+ * stream while batch k runs on the context's stream; results come back as the
+ * fixed-capacity records of acf_hip_export_detections in pinned host memory.
+ *
+ *   acf_hip_stream_open(ctx, pix, stride, cap, depth)   depth = batches in flight (2..8)
+ *   acf_hip_stream_submit(ctx, frames_host, n, &ticket)  returns at once (frames_host pinned: see acf_hip_host_alloc)
+ *   acf_hip_stream_collect(ctx, ticket, &records, &n)    waits for that batch only
+ *
+ * Tickets must be collected in order; `records` stays valid until `depth` more
+ * batches have been submitted.  `frames_host` must stay untouched until its
+ * ticket is collected. */
+ACF_HIP_API int acf_hip_stream_open(acf_hip_ctx* ctx, int pix, int row_stride_bytes, int cap, int depth);
+ACF_HIP_API int acf_hip_stream_submit(acf_hip_ctx* ctx, const uint8_t* frames_host, int n_frames, int* ticket);
+ACF_HIP_API int acf_hip_stream_collect(acf_hip_ctx* ctx, int ticket, const int32_t** records, int* n_frames);
+ACF_HIP_API int acf_hip_stream_close(acf_hip_ctx* ctx);
+/* Page-locked host memory for acf_hip_stream_submit / acf_hip_run_host callers that do not link HIP. */
+ACF_HIP_API int acf_hip_host_alloc(size_t bytes, void** out);
+ACF_HIP_API int acf_hip_host_free(void* p);
 
 /* Wait for the stream, then return frame `frame`'s detections in the
  * reference's order (level ascending, then c, then r; ACF.cpp:326-329,

@@ -569,6 +569,32 @@ ACFO_API void acfo_rgb2gray(const float* I, float* J, int n)
 }
 
 /* ------------------------------------------------------------------------
+ * Image entry for 8-bit input — L/ACF.cpp:114-119 (cvt8UC3To32FC3 =
+ * convertTo(CV_32FC3, 1/255)), :137,149 (I.t()), L/MatP.cpp:51-73 (plane split).
+ * `in` is an upright image of H rows x W pixels, cpp bytes per pixel, rowStride
+ * bytes between rows; r/g/b sit at byte offsets ro/go/bo of a pixel (the apps
+ * swizzle BGR(A) to RGB before the call, A/acf/acf.cpp).  Output: nOut planes
+ * float[W][H].  OpenCV's 8u->32f cvtScale works in float: float(v) * (float)(1/255.0)
+ * (third-party arithmetic, SURVEY.md 8c: parity unpinned for this one product).
+ * ---------------------------------------------------------------------- */
+ACFO_API void acfo_ingest_u8(const uint8_t* in, int H, int W, int cpp, int ro, int go, int bo, int rowStride, float* out, int nOut)
+{
+    const float sc = (float)(1.0 / 255.0);
+    const int off[3] = { ro, go, bo };
+    for (int c = 0; c < nOut; c++)
+    {
+        float* P = out + (size_t)c * H * W;
+        for (int x = 0; x < W; x++)
+        {
+            for (int y = 0; y < H; y++)
+            {
+                P[(size_t)x * H + y] = (float)in[(size_t)y * rowStride + (size_t)x * cpp + off[c]] * sc;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
  * a4  convTri1 / convTri1Y (s == 1) — T/convConst.cpp:445-525.
  * O may alias I: that is how the pyramid calls it (chnsCompute.cpp:239,
  * chnsPyramid.cpp:404; MatP::create is a no-op for an equal shape,

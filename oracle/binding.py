@@ -46,6 +46,8 @@ def lib():
         o.acfo_acos_table.restype = fp
         o.acfo_rgb2luv.argtypes = [fp, fp, C.c_int]
         o.acfo_rgb2gray.argtypes = [fp, fp, C.c_int]
+        o.acfo_ingest_u8.argtypes = [C.c_void_p] + [C.c_int] * 7 + [fp, C.c_int]
+        o.acfo_ingest_u8.restype = None
         o.acfo_conv_tri1.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
         o.acfo_conv_tri1.restype = C.c_int
         o.acfo_conv_tri.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -115,6 +117,24 @@ def aligned_copy(a):
 F = capi.fptr
 
 # ---------------------------------------------------------------- high level
+
+
+_PIX = {0: (3, 0, 1, 2), 1: (3, 2, 1, 0), 2: (4, 0, 1, 2), 3: (4, 2, 1, 0), 4: (1, 0, 0, 0)}  # ACF_HIP_PIX_* -> cpp, ro, go, bo
+
+
+def ingest_u8(img, pix, row_stride=0):
+    """Packed upright uint8 image [H][stride bytes] or [H][W][cpp] -> planar transposed f32 [d][W][H] (acfo_ingest_u8)."""
+    cpp, ro, go, bo = _PIX[pix]
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H = img.shape[0]
+    stride = row_stride or int(np.prod(img.shape[1:]))
+    W = img.shape[1] if img.ndim == 3 or cpp == 1 and not row_stride else None
+    if W is None:
+        raise ValueError("pass [H][W][cpp] images, or [H][W] for GRAY")
+    n_out = 1 if cpp == 1 else 3
+    out = aligned((n_out, W, H))
+    lib().acfo_ingest_u8(img.ctypes.data, H, W, cpp, ro, go, bo, stride, F(out), n_out)
+    return out
 
 
 class Plan:

@@ -1,0 +1,185 @@
+"""Packed 8-bit image entry and the streaming front end (include/acf_hip.h:
+acf_hip_pyramid_u8 / acf_hip_run_u8 / acf_hip_stream_*).
+
+The oracle restates the reference's image entry for CV_8U input — convertTo(1/255),
+I.t(), plane split (ACF.cpp:114-119,137; MatP.cpp:51-73; oracle acfo_ingest_u8) — and
+then runs the usual chnsPyramid + acfDetect; the HIP path does ingest and colour
+conversion in one kernel.  Everything is compared bit for bit.
+"""
+import numpy as np
+import pytest
+
+from acf_amd import capi, synth
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def make_u8(seed, H, W, pix, pad_bytes=0):
+    """Upright packed uint8 frame [H][stride] for layout `pix`, plus the [H][W][cpp] view the oracle reads."""
+    cpp = capi.PIX_CPP[pix]
+    if pix == capi.PIX_GRAY:
+        f = synth.make_frame(seed, H, W, "gray")          # [1][W][H]
+        rgb = np.repeat(f, 3, axis=0)
+    else:
+        rgb = synth.make_frame(seed, H, W, "rgb")         # [3][W][H]
+    up = np.clip(np.rint(rgb.transpose(2, 1, 0) * 255.0), 0, 255).astype(np.uint8)  # [H][W][3] RGB
+    img = np.zeros((H, W, cpp), np.uint8)
+    if pix == capi.PIX_GRAY:
+        img[..., 0] = up[..., 0]
+    elif pix in (capi.PIX_RGB, capi.PIX_RGBA):
+        img[..., :3] = up
+    else:
+        img[..., :3] = up[..., ::-1]
+    if cpp == 4:
+        img[..., 3] = (synth.uniform(seed, H * W, 77).reshape(H, W) * 255).astype(np.uint8)  # alpha: must be ignored
+    stride = W * cpp + pad_bytes
+    buf = np.zeros((H, stride), np.uint8)
+    buf[:, :W * cpp] = img.reshape(H, W * cpp)
+    buf[:, W * cpp:] = 0xA5
+    return buf, stride
+
+
+def _oracle_planar(oracle, buf, stride, H, W, pix):
+    cpp, ro, go, bo = oracle._PIX[pix]
+    out = oracle.aligned((1 if cpp == 1 else 3, W, H))
+    oracle.lib().acfo_ingest_u8(buf.ctypes.data, H, W, cpp, ro, go, bo, stride, oracle.F(out), out.shape[0])
+    return out
+
+
+def test_oracle_ingest_layout_and_scale(oracle):
+    """CPU: the restated entry equals float(v) * float(1/255) on the transposed planes, for every layout."""
+    H, W = 19, 23
+    for pix in range(5):
+        buf, stride = make_u8(5, H, W, pix, pad_bytes=3)
+        cpp = capi.PIX_CPP[pix]
+        img = buf[:, :W * cpp].reshape(H, W, cpp)
+        _, ro, go, bo = oracle._PIX[pix]
+        out = _oracle_planar(oracle, buf, stride, H, W, pix)
+        sc = np.float32(1.0 / 255.0)
+        order = [ro, go, bo][:out.shape[0]]
+        for c, off in enumerate(order):
+            want = (img[..., off].astype(np.float32) * sc).T
+            assert np.array_equal(bits(out[c]), bits(want)), (pix, c)
+
+
+INGEST_CASES = [
+    # name, H, W, pix, pad bytes, model kwargs, d_in
+    ("rgb_luv_vec", 240, 320, capi.PIX_RGB, 0, dict(name="INRIA", nTrees=128, cascThr=-2.5), 3),       # fused rgb2luv_sse body
+    ("bgra_luv_vec", 240, 320, capi.PIX_BGRA, 64, dict(name="INRIA", nTrees=128, cascThr=-2.5), 3),    # swizzle, alpha ignored, padded rows
+    ("bgr_luv_scalar_unaligned", 131, 175, capi.PIX_BGR, 1, dict(name="INRIA", nTrees=64, cascThr=-2.5, nOctUp=0), 3),  # n % 4 != 0 -> scalar rgb2luv; odd stride -> byte loads
+    ("gray_gray", 240, 320, capi.PIX_GRAY, 0, dict(name="FACE64", nTrees=128, cascThr=-2.5), 1),                     # 1 plane, rgb2gray of the replicated plane
+    ("rgb_to_gray", 120, 160, capi.PIX_RGB, 0, dict(name="FACE64", nTrees=128, cascThr=-4.0, minDs_h=32, minDs_w=32), 3),
+    ("rgba_passthrough", 96, 128, capi.PIX_RGBA, 0, dict(name="TINY", nTrees=96, cascThr=-3.0), 3),     # isLuv model: planes taken as they are
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", INGEST_CASES, ids=[c[0] for c in INGEST_CASES])
+def test_run_u8_bit_exact(oracle, case):
+    import torch
+    from acf_amd.detector import HipDetector
+    name, H, W, pix, pad, kw, d_in = case
+    model = synth.make_model(seed=3, **kw)
+    nF = 3
+    det = HipDetector(model, H, W, d_in, max_batch=nF, max_hits=1 << 16)
+    plan = oracle.Plan(model, H, W, d_in)
+    bufs = [make_u8(30 + i, H, W, pix, pad) for i in range(nF)]
+    stride = bufs[0][1]
+    batch = np.stack([b for b, _ in bufs])
+    det.run_u8(torch.from_numpy(batch).cuda(), pix, stride)
+    total = 0
+    for f in range(nF):
+        planar = _oracle_planar(oracle, bufs[f][0], stride, H, W, pix)
+        pyr, _, _ = oracle.chns_pyramid(plan, planar)
+        for i in range(plan.nScales):
+            assert np.array_equal(bits(det.read_level(f, i)), bits(plan.level_view(pyr, i))), (name, f, "level", i)
+        want, want_hits = oracle.detect(plan, pyr)
+        got, got_hits = det.detections(f)
+        assert len(got) == len(want)
+        for k in ("x", "y", "w", "h", "scale"):
+            assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(bits(got["score"]), bits(want["score"]))
+        total += len(want)
+    assert total > 0, "no detections: the cascade comparison would be vacuous"
+    det.close()
+
+
+@pytest.mark.gpu
+def test_u8_entry_argument_checks():
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    model = synth.make_model(seed=3, name="TINY", nTrees=16)
+    det = HipDetector(model, 96, 128, 3, max_batch=1)
+    x = torch.zeros((1, 96, 128, 3), dtype=torch.uint8).cuda()
+    with pytest.raises(HipError):
+        det.run_u8(x, capi.PIX_GRAY)            # 3-plane plan, 1-plane layout
+    with pytest.raises(HipError):
+        det.run_u8(x, 9)                        # unknown layout
+    with pytest.raises(HipError):
+        det.run_u8(x, capi.PIX_RGB, row_stride=100)  # shorter than a row
+    with pytest.raises(HipError):
+        det.stream_submit(0, 1)                 # stream not open
+    det.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [2, 3])
+def test_stream_matches_blocking_calls(oracle, depth):
+    """5 batches through submit/collect (copy stream + events) give the records of run_u8 + export of each batch."""
+    import torch
+    from acf_amd.detector import HipDetector, HipError, PinnedBuffer
+    H, W, pix, cap, nB = 120, 160, capi.PIX_RGB, 256, 4
+    model = synth.make_model(seed=3, name="INRIA", nTrees=64, cascThr=-3.0, nOctUp=0)
+    det = HipDetector(model, H, W, 3, max_batch=nB, max_hits=4096)
+    per = H * W * 3
+    batches = []
+    for b in range(5):
+        n = nB if b != 3 else 2  # one short batch
+        batches.append(np.stack([make_u8(100 + 10 * b + i, H, W, pix)[0] for i in range(n)]))
+    # blocking reference through the same library
+    want = []
+    for x in batches:
+        det.run_u8(torch.from_numpy(x).cuda(), pix)
+        dst = torch.zeros((x.shape[0], 1 + 6 * cap), dtype=torch.int32, device="cuda")
+        det.export_detections(dst, cap)
+        det.synchronize()
+        want.append(dst.cpu().numpy())
+    assert sum(int(w[:, 0].sum()) for w in want) > 0
+    # and the first frame against the oracle, so the reference above is not self-referential
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, _, _ = oracle.chns_pyramid(plan, _oracle_planar(oracle, batches[0][0], W * 3, H, W, pix))
+    odet, _ = oracle.detect(plan, pyr)
+    assert want[0][0, 0] == len(odet)
+    assert np.array_equal(want[0][0, 1:1 + 6 * len(odet)].reshape(-1, 6)[:, 4].view(np.uint32), bits(odet["score"]))
+
+    pins = [PinnedBuffer(nB * per) for _ in range(depth)]
+    det.stream_open(pix, 0, cap, depth)
+    got = []
+    inflight = []
+    for b, x in enumerate(batches):
+        if len(inflight) == depth:
+            got.append(det.stream_collect(inflight.pop(0)))
+        pin = pins[b % depth]
+        pin.array[:x.size] = x.ravel()
+        inflight.append(det.stream_submit(pin.ptr.value, x.shape[0]))
+    with pytest.raises(HipError):
+        det.stream_collect(inflight[-1] + 5)   # unknown ticket
+    while inflight:
+        got.append(det.stream_collect(inflight.pop(0)))
+    for b in range(5):
+        assert got[b].shape == want[b].shape, b
+        for f in range(want[b].shape[0]):
+            n = want[b][f, 0]
+            assert got[b][f, 0] == n
+            assert np.array_equal(got[b][f, :1 + 6 * n], want[b][f, :1 + 6 * n]), (b, f)
+    # all slots in flight -> submit refuses instead of overwriting
+    for k in range(depth):
+        det.stream_submit(pins[k].ptr.value, 1)
+    with pytest.raises(HipError):
+        det.stream_submit(pins[0].ptr.value, 1)
+    det.stream_close()
+    det.close()
+    for p in pins:
+        p.close()

@@ -170,3 +170,37 @@ def test_cli_nms_and_calibration(cli, oracle, tmp_path):
     wb, ws = prune_ref(wb, ws, 5, 0.0)
     assert len(got) > 0
     assert [g[:4] for g in got] == [tuple(b) for b in wb]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--stream", "2"], ["--stream", "2", "--nms"]])
+def test_cli_packed_u8_and_stream(cli, oracle, tmp_path, mode):
+    """The CV_8UC3 image entry and the streaming front end of acf::HipDetector against the oracle's
+    restated entry (acfo_ingest_u8 -> chnsPyramid -> acfDetect [-> restated NMS + prune])."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_ingest import make_u8, _oracle_planar
+    H, W, pix = 120, 160, capi.PIX_BGR
+    model = synth.make_model(seed=3, name="INRIA", nTrees=64, cascThr=-3.0, nOctUp=0)
+    write_model(str(tmp_path / "m.acfm"), model)
+    bufs = [make_u8(60 + i, H, W, pix)[0] for i in range(5)]
+    (tmp_path / "f.u8").write_bytes(np.stack(bufs).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.u8"), "--u8", "bgr", "--rows", str(H), "--cols", str(W),
+                  "--count", "5", "--max-count", "6"] + mode)
+    got = parse(p.stdout)
+    plan = oracle.Plan(model, H, W, 3)
+    assert len(got) == 5
+    total = 0
+    for f in range(5):
+        pyr, _, _ = oracle.chns_pyramid(plan, _oracle_planar(oracle, bufs[f], W * 3, H, W, pix))
+        det, _ = oracle.detect(plan, pyr)
+        want = [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det]
+        if "--nms" in mode:
+            scores = [float(np.uint32(w[4]).view(np.float32)) for w in want]
+            wb, ws = nms_ref([w[:4] for w in want], scores, 0.65, True, False)
+            wb, ws = prune_ref(wb, ws, 6, 0.0)
+            assert [g[:4] for g in got[f]] == [tuple(b) for b in wb], f
+        else:
+            assert got[f] == want, f
+        total += len(want)
+    assert total > 0
