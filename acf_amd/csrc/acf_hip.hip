@@ -3215,7 +3215,60 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
     return ACF_HIP_OK;
 }
 
+// thrs.convertTo(thrsU8, CV_8UC1, 255.0f) (ACFIOArchive.h:96-99): OpenCV's 32f->8u cvtScale works in f32 and rounds
+// with cvRound (to nearest even), then saturates.
+int acf_hip_thrs_u8(const float* thrs, int n, uint8_t* out)
+{
+    if (!thrs || !out || n < 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        const float v = thrs[i] * 255.0f;
+        // cvRound is cvtss2si: half to even; NaN and |v| >= 2^31 convert to INT_MIN, which saturate_cast<uchar> maps to 0
+        const bool inRange = v > -2147483648.0f && v < 2147483648.0f;
+        const float r = inRange ? std::nearbyint(v) : -1.0f;
+        out[i] = uint8_t(r < 0.f ? 0 : (r > 255.f ? 255 : int(r)));
+    }
+    return ACF_HIP_OK;
+}
+
+static int opAcfDetect1(acf_hip_ctx* c, const void* chns, bool u8, int hP, int wP, int nChns, acf_hip_hit* out, int cap, int* count);
+
 int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, int nChns, acf_hip_hit* out, int cap, int* count)
+{
+    return opAcfDetect1(c, chns, false, hP, wP, nChns, out, cap, count);
+}
+
+// The uint8_t body of acfDetect1 (acfDetect1.cpp:157-166,187-192): features and thresholds are bytes, compared after
+// promotion to float (`float ftr = chns1[...]; ftr < thrs[k]`).  Bytes widen to f32 exactly, so the planes are widened
+// on the device and the f32 cascade runs on them with the widened thresholds: same comparisons, same sums.
+int acf_hip_op_acf_detect1_u8(acf_hip_ctx* c, const uint8_t* chns, int hP, int wP, int nChns, const uint8_t* thrsU8, acf_hip_hit* out, int cap, int* count)
+{
+    if (!c || !c->hasModel)
+    {
+        return c ? fail(c, ACF_HIP_E_NOMODEL, "op_acf_detect1_u8: set_model first") : ACF_HIP_E_INVALID;
+    }
+    std::vector<uint8_t> derived;
+    if (!thrsU8)
+    {
+        derived.resize(c->thrs.size());
+        acf_hip_thrs_u8(c->thrs.data(), int(c->thrs.size()), derived.data());
+        thrsU8 = derived.data();
+    }
+    std::vector<float> wide(c->thrs.size());
+    for (size_t i = 0; i < wide.size(); i++)
+    {
+        wide[i] = float(thrsU8[i]);
+    }
+    c->thrs.swap(wide);
+    const int rc = opAcfDetect1(c, chns, true, hP, wP, nChns, out, cap, count);
+    c->thrs.swap(wide);
+    return rc;
+}
+
+static int opAcfDetect1(acf_hip_ctx* c, const void* chns, bool u8, int hP, int wP, int nChns, acf_hip_hit* out, int cap, int* count)
 {
     OP_PROLOGUE(c);
     if (!c->hasModel)
@@ -3314,9 +3367,27 @@ int acf_hip_op_acf_detect1(acf_hip_ctx* c, const float* chns, int hP, int wP, in
     {
         rc = devAlloc(c, &dChn, size_t(nChns) * hP * wP + 64);
     }
-    if (!rc && hipMemcpy(dChn, chns, sizeof(float) * nChns * hP * wP, hipMemcpyHostToDevice) != hipSuccess)
+    if (!rc && !u8 && hipMemcpy(dChn, chns, sizeof(float) * nChns * hP * wP, hipMemcpyHostToDevice) != hipSuccess)
     {
         rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1: upload");
+    }
+    if (!rc && u8)
+    {
+        uint8_t* dBytes = nullptr;
+        const size_t n = size_t(nChns) * hP * wP;
+        rc = devAlloc(c, &dBytes, n);
+        if (!rc && hipMemcpy(dBytes, chns, n, hipMemcpyHostToDevice) != hipSuccess)
+        {
+            rc = fail(c, ACF_HIP_E_HIP, "op_acf_detect1_u8: upload");
+        }
+        if (!rc)
+        {
+            hipLaunchKernelGGL(k_widen_u8, dim3(cdiv(int64_t(n), 256)), dim3(256), 0, c->stream, (const uint8_t*)dBytes, dChn, int64_t(n));
+            if (hipGetLastError() != hipSuccess)
+            {
+                rc = fail(c, ACF_HIP_E_HIP, "launch k_widen_u8");
+            }
+        }
     }
     if (!rc)
     {

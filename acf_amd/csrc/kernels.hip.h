@@ -114,6 +114,16 @@ __global__ void __launch_bounds__(256) k_replicate3(const float* __restrict__ in
     J[i + 2 * int64_t(n)] = v;
 }
 
+// uint8_t channel planes -> f32 (exact), for the uint8_t cascade body (acfDetect1.cpp:157-166)
+__global__ void __launch_bounds__(256) k_widen_u8(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        out[i] = float(in[i]);
+    }
+}
+
 // ------------------------------------------------------------------------
 // Packed 8-bit upright frames -> transposed planar f32.
 //

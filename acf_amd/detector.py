@@ -241,3 +241,14 @@ class HipDetector:
         n = C.c_int()
         self._chk(self.lib.acf_hip_op_acf_detect1(self.ctx, capi.fptr(chns), hP, wP, nC, hits.ctypes.data_as(C.POINTER(capi.Hit)), cap, C.byref(n)))
         return hits[:n.value].copy()
+
+    def op_acf_detect1_u8(self, chns, thrs_u8=None, cap=1 << 16):
+        """uint8 channel planes [nC][wP][hP]; thrs_u8 None: derived from the model's thrs (ACFIOArchive.h:96-99)."""
+        chns = np.ascontiguousarray(chns, dtype=np.uint8)
+        nC, wP, hP = chns.shape
+        hits = np.zeros(cap, dtype=capi.HIT_DTYPE)
+        n = C.c_int()
+        t = None if thrs_u8 is None else np.ascontiguousarray(thrs_u8, dtype=np.uint8)
+        self._chk(self.lib.acf_hip_op_acf_detect1_u8(self.ctx, chns.ctypes.data, hP, wP, nC, None if t is None else t.ctypes.data,
+                                                     hits.ctypes.data_as(C.POINTER(capi.Hit)), cap, C.byref(n)))
+        return hits[:n.value].copy()

@@ -599,6 +599,17 @@ int HipDetector::operator()(const Pyramid& P, RectVec& objects, RealVec* scores)
 void HipDetector::acfDetect1(const MatP& chns, int, const Size&, int, double, DetectionVec& objects)
 {
     // chns: fused level buffer, rows = nChns * wP, cols = hP
+    detect1(chns.data(), nullptr, chns.rows(), chns.cols(), objects);
+}
+
+void HipDetector::acfDetect1(const uint8_t* chnsU8, int rows, int cols, DetectionVec& objects)
+{
+    // the CV_8UC1 case of allocDetector (acfDetect1.cpp:187-192) with Classifier::thrsU8 (getScaledThresholds :168-182)
+    detect1(nullptr, chnsU8, rows, cols, objects);
+}
+
+void HipDetector::detect1(const float* f32, const uint8_t* u8, int rows, int cols, DetectionVec& objects)
+{
     if (!m_good)
     {
         throw Exception(ACF_HIP_E_NOMODEL, "acfDetect1: no model");
@@ -614,11 +625,24 @@ void HipDetector::acfDetect1(const MatP& chns, int, const Size&, int, double, De
     const auto& ch = opts.pPyramid.pChns;
     const int nColor = ch.pColor.enabled ? (ch.pColor.colorSpace == "gray" ? 1 : 3) : 0;
     const int nC = nColor + (ch.pGradMag.enabled ? 1 : 0) + (ch.pGradHist.enabled ? ch.pGradHist.nOrients : 0);
-    const int wP = chns.rows() / nC, hP = chns.cols();
+    const int wP = rows / nC, hP = cols;
     const int cap = std::max(1, wP * hP);
     std::vector<acf_hip_hit> hits(static_cast<size_t>(cap));
     int n = 0;
-    check(m_api->acf_hip_op_acf_detect1(m_ctx, chns.data(), hP, wP, nC, hits.data(), cap, &n), "acf_hip_op_acf_detect1");
+    if (u8)
+    {
+        if (clf.thrsU8.empty())
+        {
+            // what the loader does once (ACFIOArchive.h:96-99)
+            clf.thrsU8.resize(clf.thrs.size());
+            check(m_api->acf_hip_thrs_u8(clf.thrs.data(), int(clf.thrs.size()), clf.thrsU8.data()), "acf_hip_thrs_u8");
+        }
+        check(m_api->acf_hip_op_acf_detect1_u8(m_ctx, u8, hP, wP, nC, clf.thrsU8.data(), hits.data(), cap, &n), "acf_hip_op_acf_detect1_u8");
+    }
+    else
+    {
+        check(m_api->acf_hip_op_acf_detect1(m_ctx, f32, hP, wP, nC, hits.data(), cap, &n), "acf_hip_op_acf_detect1");
+    }
     for (int i = 0; i < n; i++)
     {
         Detection d;

@@ -149,6 +149,7 @@ public:
         int nTrees = 0, nTreeNodes = 0, treeDepth = 0;
         std::vector<uint32_t> fids, child;
         std::vector<float> thrs, hs;
+        std::vector<uint8_t> thrsU8; // prescaled thresholds (x255) for uint8_t channels (ACF.h:305); filled on first use if empty
     };
 
     // Detector::Modify (ACF.h:391-408): the subset acfModify may override (acfModify.cpp:83-152).
@@ -252,6 +253,8 @@ public:
 
     // acfDetect1.cpp:309-335: one level; rois unused on this path (fused buffers only)
     void acfDetect1(const MatP& chns, int shrink, const Size& modelDsPad, int stride, double cascThr, DetectionVec& objects);
+    // the same on uint8_t channels ([nChns * wP rows][hP cols] bytes), the CV_8UC1 branch of allocDetector (acfDetect1.cpp:187-192)
+    void acfDetect1(const uint8_t* chnsU8, int rows, int cols, DetectionVec& objects);
     // bbNms.cpp:229-304 (max / maxg / none), ObjectDetector.cpp:28-44
     static int bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, DetectionVec& bbs);
     void prune(RectVec& objects, RealVec& scores) const;
@@ -269,6 +272,7 @@ private:
     void fillParams(acf_hip_params& p) const;
     void ensurePlan(int imgH, int imgW, int d, int batch);
     void fetch(int frame, RectVec& objects, RealVec* scores);
+    void detect1(const float* f32, const uint8_t* u8, int rows, int cols, DetectionVec& objects);
     void finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const; // ACF.cpp:332-364
 
     const hip::Api* m_api = nullptr;

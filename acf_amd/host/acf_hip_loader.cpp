@@ -73,6 +73,8 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_op_gradient_hist)
     ACF_HIP_FN(acf_hip_op_im_resample)
     ACF_HIP_FN(acf_hip_op_acf_detect1)
+    ACF_HIP_FN(acf_hip_op_acf_detect1_u8)
+    ACF_HIP_FN(acf_hip_thrs_u8)
 #undef ACF_HIP_FN
     if (g_api.acf_hip_abi_version() != ACF_HIP_ABI_VERSION)
     {

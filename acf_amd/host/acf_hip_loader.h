@@ -57,6 +57,8 @@ struct Api
     ACF_HIP_FN(acf_hip_op_gradient_hist)
     ACF_HIP_FN(acf_hip_op_im_resample)
     ACF_HIP_FN(acf_hip_op_acf_detect1)
+    ACF_HIP_FN(acf_hip_op_acf_detect1_u8)
+    ACF_HIP_FN(acf_hip_thrs_u8)
 #undef ACF_HIP_FN
 };
 

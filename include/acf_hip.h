@@ -306,6 +306,15 @@ ACF_HIP_API int acf_hip_op_im_resample(acf_hip_ctx* ctx, const float* in, float*
 ACF_HIP_API int acf_hip_op_acf_detect1(acf_hip_ctx* ctx, const float* chns, int hP, int wP, int nChns,
     acf_hip_hit* out, int cap, int* count);
 
+/* The uint8_t body of acfDetect1 (ParallelDetectionBody<uint8_t,...>, acfDetect1.cpp:157-166,187-192) on one host
+ * channel buffer of bytes [nChns][wP][hP], the format the reference's GL backend feeds the cascade (GPUACF.cpp:790).
+ * `thrsU8`: Classifier::thrsU8 ([nTrees][nTreeNodes] bytes), or NULL to derive it from the model's thrs as the
+ * loader does (ACFIOArchive.h:96-99, acf_hip_thrs_u8). */
+ACF_HIP_API int acf_hip_op_acf_detect1_u8(acf_hip_ctx* ctx, const uint8_t* chns, int hP, int wP, int nChns, const uint8_t* thrsU8,
+    acf_hip_hit* out, int cap, int* count);
+/* thrs.convertTo(thrsU8, CV_8UC1, 255.0f) (ACFIOArchive.h:96-99): host only, no context. */
+ACF_HIP_API int acf_hip_thrs_u8(const float* thrs, int n, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1488,6 +1488,20 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
     return rc;
 }
 
+/* Classifier::thrsU8 — L/ACFIOArchive.h:96-99: thrs.convertTo(thrsU8, CV_8UC1, 255.0f).  OpenCV's 32f->8u
+ * cvtScale: saturate_cast<uchar>(src * (float)alpha + 0) with cvRound (round half to even).  Third-party
+ * arithmetic: parity unpinned for this one conversion. */
+ACFO_API void acfo_thrs_u8(const float* thrs, int n, uint8_t* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        float v = thrs[i] * 255.0f;
+        /* cvRound = cvtss2si: round half to even; NaN and |v| >= 2^31 give INT_MIN, which saturates to 0 */
+        long r = (v > -2147483648.0f && v < 2147483648.0f) ? lrintf(v) : -2147483647L - 1;
+        out[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
 /* ------------------------------------------------------------------------
  * a13-a15  createDetector / ParallelDetectionBody / acfDetect1 —
  * T/acfDetect1.cpp:72-166, 231-335, 390-406 (column-major, no rois).

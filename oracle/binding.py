@@ -69,6 +69,8 @@ def lib():
         o.acfo_acf_detect1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, P,
                                        C.POINTER(capi.Hit), C.c_int, C.c_int]
         o.acfo_acf_detect1.restype = C.c_int
+        o.acfo_thrs_u8.argtypes = [fp, C.c_int, C.c_void_p]
+        o.acfo_thrs_u8.restype = None
         o.acfo_mean_trees.argtypes = [fp, C.c_int, C.c_int, C.c_int, P]
         o.acfo_mean_trees.restype = C.c_double
         o.acfo_detect.argtypes = [fp, P, L, C.c_int, C.c_int, C.POINTER(capi.Detection), C.POINTER(capi.Hit), C.c_int]
@@ -199,6 +201,24 @@ def detect(plan, pyr, cap=1 << 16):
     if n > cap:
         raise RuntimeError("capacity %d < %d" % (cap, n))
     return det[:n].copy(), hits[:n].copy()
+
+
+def thrs_u8(thrs):
+    t = np.ascontiguousarray(thrs, dtype=np.float32)
+    out = np.zeros(t.shape, np.uint8)
+    lib().acfo_thrs_u8(F(t), t.size, out.ctypes.data)
+    return out
+
+
+def acf_detect1_u8(plan, chns_u8, thrs_u8_arr, cap=1 << 16):
+    """The uint8_t cascade body on one level's byte planes [nC][wP][hP] (acfo_acf_detect1 with u8 = 1)."""
+    chns_u8 = np.ascontiguousarray(chns_u8, dtype=np.uint8)
+    t = np.ascontiguousarray(thrs_u8_arr, dtype=np.uint8)
+    nC, wP, hP = chns_u8.shape
+    hits = np.zeros(cap, dtype=capi.HIT_DTYPE)
+    n = lib().acfo_acf_detect1(chns_u8.ctypes.data, 1, t.ctypes.data, hP, wP, nC, C.byref(plan.params),
+                               hits.ctypes.data_as(C.POINTER(capi.Hit)), cap, 0)
+    return hits[:min(n, cap)].copy(), n
 
 
 def mean_trees(plan, pyr):

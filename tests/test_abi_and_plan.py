@@ -120,3 +120,18 @@ def test_plan_rejects_unsupported():
         assert lib.acf_hip_plan_levels(C.byref(params), 96, 128, 3, lv, 8, C.byref(n), C.byref(nc)) == code, over
     params, keep = capi.make_params(synth.make_model(name="FACE80", nTrees=4))
     assert lib.acf_hip_plan_levels(C.byref(params), 40, 40, 3, lv, 8, C.byref(n), C.byref(nc)) == 1  # smaller than minDs: no scales
+
+
+def test_thrs_u8_host_entry_matches_oracle(oracle):
+    """acf_hip_thrs_u8 (host only) vs the oracle's restatement of thrs.convertTo(thrsU8, CV_8UC1, 255.0f)
+    (ACFIOArchive.h:96-99): halves round to even, values saturate, NaN -> 0."""
+    lib = capi.load()
+    halves = (np.arange(0, 256, dtype=np.float32) + np.float32(0.5)) / np.float32(255.0)
+    t = np.concatenate([synth.uniform(3, 4000, 0).astype(np.float32) * 1.4 - 0.2, halves,
+                        np.array([0.0, 1.0, -1.0, 2.0, 1e30, -1e30, np.nan, 0.5 / 255, 1.5 / 255, 2.5 / 255], np.float32)]).astype(np.float32)
+    got = np.zeros(t.size, np.uint8)
+    assert lib.acf_hip_thrs_u8(capi.fptr(t), t.size, got.ctypes.data) == 0
+    want = oracle.thrs_u8(t)
+    assert np.array_equal(got, want)
+    assert want[-4] == 0 and want[-5] == 0 and want[-6] == 0 and want[-7] == 255  # NaN, -1e30, 1e30 (cvtss2si overflow -> INT_MIN -> 0), 2.0
+    assert list(oracle.thrs_u8(np.array([0.5, 1.5, 2.5, 3.5], np.float32))) == [128, 255, 255, 255]

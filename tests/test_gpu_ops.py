@@ -216,6 +216,32 @@ def test_acf_detect1(dev, oracle, depth, nTrees, tiles):
     assert np.array_equal(bits(got["score"]), bits(want["score"]))
 
 
+@pytest.mark.parametrize("explicit_thrs", [False, True])
+@pytest.mark.parametrize("depth", [2, 0, 3])
+def test_acf_detect1_u8(dev, oracle, depth, explicit_thrs):
+    """The uint8_t cascade body (acfDetect1.cpp:157-166,187-192): byte planes + Classifier::thrsU8.  Ties between a
+    byte feature and a byte threshold are common here (256 levels), so `<` vs `<=` mistakes cannot hide."""
+    nC, wP, hP = 10, 60, 44
+    chns = (rnd(77 + depth, (nC, wP, hP), 0.0, 0.6) * 255.0).astype(np.uint8)
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=128, cascThr=-1.0, treeDepth=depth)
+    m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
+    m["hs"] = rnd(6, m["hs"].shape, -0.25, 0.2)
+    m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
+    dev.set_model(m)
+    tu = oracle.thrs_u8(m["thrs"])
+    got = dev.op_acf_detect1_u8(chns, tu if explicit_thrs else None)
+    params, keep = capi.make_params(m)
+    want = np.zeros(1 << 16, dtype=capi.HIT_DTYPE)
+    n = oracle.lib().acfo_acf_detect1(chns.ctypes.data_as(C.c_void_p), 1, tu.ctypes.data_as(C.c_void_p), hP, wP, nC,
+                                      C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
+    want = want[:n]
+    assert n > 0 and n < (wP - 3) * (hP - 3), n
+    assert len(got) == n
+    for k in ("scale", "c", "r"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(bits(got["score"]), bits(want["score"]))
+
+
 @pytest.mark.parametrize("case", ["stride8", "wide_model", "tall_plane", "one_window", "permissive"])
 def test_acf_detect1_tiled_geometries(dev, oracle, case):
     """Tile edge cases of the LDS-tiled cascade: step 2 between windows, a non-square model, a plane with
