@@ -1,4 +1,5 @@
 #include "HipDetector.h"
+#include "ModelIO.h"
 
 #include <algorithm>
 #include <cmath>
@@ -22,6 +23,46 @@ static int colorSpaceFlag(const std::string& s)
 HipDetector::HipDetector(const Options& o, const Classifier& c, int device)
 {
     setModel(o, c, device);
+}
+
+// Detector(const std::string& filename) / Detector(std::istream&, hint) (ACF.cpp:38-46): good() reports the load status
+HipDetector::HipDetector(const std::string& filename, int device)
+{
+    Options o;
+    Classifier c;
+    try
+    {
+        if (loadModelAny(filename, o, c) == 0)
+        {
+            setModel(o, c, device);
+        }
+    }
+    catch (const Exception&)
+    {
+        m_good = false; // malformed file: like a failed deserialize
+    }
+}
+
+HipDetector::HipDetector(std::istream& is, const std::string& hint, int device)
+{
+    Options o;
+    Classifier c;
+    try
+    {
+        if (hint.empty() || hint.find(".cpb") != std::string::npos) // ACFIO.cpp:218-231
+        {
+            loadCpb(is, o, c);
+            setModel(o, c, device);
+        }
+        else if (loadAcfm(is, o, c))
+        {
+            setModel(o, c, device);
+        }
+    }
+    catch (const Exception&)
+    {
+        m_good = false;
+    }
 }
 
 HipDetector::~HipDetector()

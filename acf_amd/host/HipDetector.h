@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <functional>
 #include <stdexcept>
+#include <iosfwd>
 #include <string>
 #include <vector>
 
@@ -196,6 +197,9 @@ public:
 
     HipDetector() = default; // !good() until a model is supplied
     HipDetector(const Options& o, const Classifier& c, int device = 0);
+    // Detector(filename) / Detector(istream, hint) (ACF.h:59-66): "*.cpb" = the reference's cereal files (ModelIO.h)
+    explicit HipDetector(const std::string& filename, int device = 0);
+    HipDetector(std::istream& is, const std::string& hint = {}, int device = 0);
     ~HipDetector();
     HipDetector(const HipDetector&) = delete;
     HipDetector& operator=(const HipDetector&) = delete;

@@ -5,6 +5,7 @@
 //                  [--luv] [--nms] [--batch] [--via-pyramid] [--max-count K] [--prune-ratio R]
 //   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] ...
 //                  packed 8-bit upright frames; --stream B: batches of B frames through streamSubmit/streamCollect
+//   acf_hip_detect --convert in.acfm|in.cpb --out out.cpb                                  (model file conversion, no GPU)
 //   acf_hip_detect --nms-only boxes.txt [--type maxg] [--overlap .65] [--ovrdnm min]   (host logic only, no GPU)
 //
 // Model file ("ACFHIPM1", written by acf_amd/modelio.py): text header of
@@ -13,6 +14,7 @@
 // Frames: raw f32, transposed planar [count][channels][rows=W][cols=H].
 // Output: "frame i n" then n lines "x y w h score scorebits".
 #include "HipDetector.h"
+#include "ModelIO.h"
 
 #include <cstdio>
 #include <cstring>
@@ -25,70 +27,7 @@ using acf::HipDetector;
 
 static bool loadModel(const std::string& path, HipDetector::Options& o, HipDetector::Classifier& c)
 {
-    std::ifstream is(path, std::ios::binary);
-    std::string line;
-    if (!std::getline(is, line) || line != "ACFHIPM1")
-    {
-        return false;
-    }
-    std::map<std::string, std::string> kv;
-    while (std::getline(is, line) && line != "END")
-    {
-        const size_t sp = line.find(' ');
-        if (sp != std::string::npos)
-        {
-            kv[line.substr(0, sp)] = line.substr(sp + 1);
-        }
-    }
-    auto I = [&](const char* k) { return std::stoi(kv.at(k)); };
-    auto D = [&](const char* k) { return std::stod(kv.at(k)); };
-    c.nTrees = I("nTrees");
-    c.nTreeNodes = I("nTreeNodes");
-    c.treeDepth = I("treeDepth");
-    o.modelDs = acf::Size(I("modelDs_h"), I("modelDs_w")); // {width = image-height axis}
-    o.modelDsPad = acf::Size(I("modelDsPad_h"), I("modelDsPad_w"));
-    o.stride = I("stride");
-    o.cascThr = D("cascThr");
-    auto& p = o.pPyramid;
-    p.nPerOct = I("nPerOct");
-    p.nOctUp = I("nOctUp");
-    p.nApprox = I("nApprox");
-    p.lambdas.clear();
-    {
-        std::istringstream ls(kv["lambdas"]);
-        double v;
-        while (ls >> v)
-        {
-            p.lambdas.push_back(v);
-        }
-    }
-    p.pad = acf::Size(I("pad_h"), I("pad_w"));
-    p.minDs = acf::Size(I("minDs_h"), I("minDs_w"));
-    p.smooth = D("smooth");
-    p.pChns.shrink = I("shrink");
-    p.pChns.pColor.enabled = I("colorEnabled");
-    p.pChns.pColor.smooth = D("colorSmooth");
-    const char* cs[] = { "gray", "rgb", "luv", "hsv", "orig" };
-    p.pChns.pColor.colorSpace = cs[I("colorSpace")];
-    p.pChns.pGradMag.enabled = I("gradMagEnabled");
-    p.pChns.pGradMag.colorChn = I("colorChn");
-    p.pChns.pGradMag.normRad = I("normRad");
-    p.pChns.pGradMag.normConst = D("normConst");
-    p.pChns.pGradMag.full = I("full");
-    p.pChns.pGradHist.enabled = I("gradHistEnabled");
-    p.pChns.pGradHist.binSize = I("binSize");
-    p.pChns.pGradHist.nOrients = I("nOrients");
-    p.pChns.pGradHist.softBin = I("softBin");
-    const size_t n = size_t(c.nTrees) * c.nTreeNodes;
-    c.fids.resize(n);
-    c.thrs.resize(n);
-    c.hs.resize(n);
-    c.child.resize(n);
-    is.read(reinterpret_cast<char*>(c.fids.data()), std::streamsize(n * 4));
-    is.read(reinterpret_cast<char*>(c.thrs.data()), std::streamsize(n * 4));
-    is.read(reinterpret_cast<char*>(c.hs.data()), std::streamsize(n * 4));
-    is.read(reinterpret_cast<char*>(c.child.data()), std::streamsize(n * 4));
-    return bool(is);
+    return acf::loadModelAny(path, o, c) == 0; // "*.cpb": the reference's cereal files; otherwise the ACFHIPM1 container
 }
 
 static void printFrame(int f, const HipDetector::RectVec& objs, const HipDetector::RealVec& scores)
@@ -157,12 +96,19 @@ int main(int argc, char** argv)
         }
         HipDetector::Options o;
         HipDetector::Classifier c;
-        if (!loadModel(a.at("model"), o, c))
+        if (a.count("convert"))
         {
-            std::fprintf(stderr, "cannot read model %s\n", a["model"].c_str());
-            return 2;
+            // acf_hip_detect --convert in.{acfm,cpb} --out out.cpb : host only
+            if (!loadModel(a["convert"], o, c))
+            {
+                std::fprintf(stderr, "cannot read model %s\n", a["convert"].c_str());
+                return 2;
+            }
+            std::ofstream os(a.at("out"), std::ios::binary);
+            acf::saveCpb(os, o, c);
+            return os ? 0 : 2;
         }
-        HipDetector det(o, c);
+        HipDetector det(a.at("model")); // Detector(filename): "*.cpb" or the ACFHIPM1 container
         if (!det.good())
         {
             std::fprintf(stderr, "detector not good (no device / bad model)\n");
