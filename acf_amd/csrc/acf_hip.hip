@@ -58,6 +58,8 @@ struct CascState
     TreeNode* d_tailNodes = nullptr; // offsets = feature ids (window-local layout), all trees
     TileGeom geom{};
     int tailWaves = 0;
+    float* d_tailScratch = nullptr; // k_cascade_tail3 leaf matrices: [blocks][tailWaves][TAIL_G][tailPad]
+    int tailPad = 0, tailSlab = 0, tailBlocks = 0, tailNodesLds = 0;
 };
 
 struct acf_hip_ctx
@@ -113,8 +115,11 @@ struct acf_hip_ctx
     struct LevelGroup
     {
         int R, mode, first, count;
+        double cost; // ~ column steps x work per step of the group's longest plane chain and of all its planes (see pack)
+        int lane;    // side stream the launch goes to (longest-processing-time-first over the hardware queues)
     };
     std::vector<LevelGroup> levelGroups, levelGroupsRaw; // jobs sorted into runs of equal (R, mode)
+    int nAllJobs = 0, nAllJobsRaw = 0; // leading jobs of d_levelJobs(/Raw) that go to the single k_level_all launch
     int levelMode = 1;                  // option "fused_levels": 1 fused resample+smooth, 2 separate resample + wave-per-plane smooth, 0 separate launches
     bool fusedOk = false;      // the fused resample+smooth level kernel covers this plan
     int noFused = 0;           // option "fused_levels" = 0: separate resample and smoothing launches
@@ -1004,11 +1009,12 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             }
         }
         int tw = 0;
+        const int tailSlab = (std::max(g.winFloats, TAIL_G * TAIL_PITCH) + 3) / 4 * 4; // footprint, reused as phase 2's transposition tile (16-byte rows)
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
         {
             for (int cand : { 4, 2, 1 })
             {
-                if (!tw && int64_t(cand) * g.winFloats * 4 <= limit)
+                if (!tw && int64_t(cand) * tailSlab * 4 <= limit)
                 {
                     tw = cand;
                 }
@@ -1082,6 +1088,26 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 }
                 cs.geom = g;
                 cs.tailWaves = tw;
+                cs.tailSlab = tailSlab;
+                cs.tailPad = (std::max(p.nTrees - g.b[4], 1) + 63) / 64 * 64;
+                cs.tailBlocks = std::max(512, c->maxBatch);
+                {
+                    // node table of the tail in LDS if it fits beside the footprint slabs (TreeNode = 12 dwords)
+                    const int64_t nodeFloats = int64_t(std::max(p.nTrees - g.b[4], 0)) * 12;
+                    cs.tailNodesLds = 0;
+                    for (int cand : { 4, 2 })
+                    {
+                        if (!cs.tailNodesLds && cand <= tw && nodeFloats > 0 && (nodeFloats + int64_t(cand) * tailSlab) * 4 <= int64_t(159) * 1024)
+                        {
+                            cs.tailNodesLds = int(nodeFloats);
+                            cs.tailWaves = cand;
+                        }
+                    }
+                }
+                if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
+                {
+                    return rc;
+                }
                 cs.nTiles = int(tiles.size());
                 if ((rc = devUpload(c, &cs.d_tiles, tiles)) || (rc = devUpload(c, &cs.d_tileNodes, tileNodes)) || (rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
                 {
@@ -1381,22 +1407,46 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             }
             fusedJobs.push_back({ R * 8 + mode, j });
         }
-        auto pack = [&](std::vector<Keyed>& v, std::vector<acf_hip_ctx::LevelGroup>& groups, LevelJob** dst) {
-            std::stable_sort(v.begin(), v.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
-            std::vector<LevelJob> flat;
-            groups.clear();
+        auto pack = [&](std::vector<Keyed>& v, std::vector<acf_hip_ctx::LevelGroup>& groups, LevelJob** dst, int* nAll) {
+            auto jobCost = [](const Keyed& k) {
+                // one wave walks wC column steps; a step costs ~R row registers x (1 for a copy, 3 for a resampled column) + the recursion
+                const int R = k.key / 8, mode = k.key % 8;
+                return double(k.j.wC) * (R * (mode == LM_REAL ? 1.0 : 3.0) + 2.0);
+            };
+            for (auto& k : v)
+            {
+                k.j.kind = k.key;
+            }
+            // k_level_all takes every job whose specialisation fits 128 VGPRs, longest chain first; the rest go out as
+            // one launch per (R, mode) run on the side streams
+            std::vector<Keyed> all, rest;
             for (const auto& k : v)
+            {
+                const int R = k.key / 8, mode = k.key % 8;
+                ((R <= 4 || (mode == LM_REAL && R <= 8)) && !getenv("ACF_HIP_LEVEL_GROUPS") ? all : rest).push_back(k);
+            }
+            std::stable_sort(all.begin(), all.end(), [&](const Keyed& a, const Keyed& b) { return jobCost(a) > jobCost(b); });
+            std::stable_sort(rest.begin(), rest.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+            std::vector<LevelJob> flat;
+            for (const auto& k : all)
+            {
+                flat.push_back(k.j);
+            }
+            *nAll = int(all.size());
+            groups.clear();
+            for (const auto& k : rest)
             {
                 if (groups.empty() || groups.back().R * 8 + groups.back().mode != k.key)
                 {
-                    groups.push_back({ k.key / 8, k.key % 8, int(flat.size()), 0 });
+                    groups.push_back({ k.key / 8, k.key % 8, int(flat.size()), 0, 0.0, 0 });
                 }
                 groups.back().count++;
+                groups.back().cost += jobCost(k);
                 flat.push_back(k.j);
             }
             return devUpload(c, dst, flat);
         };
-        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw)))
+        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs, &c->nAllJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw, &c->nAllJobsRaw)))
         {
             return rc;
         }
@@ -1498,6 +1548,8 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
     *n = c->plan.pyr_floats;
     return ACF_HIP_OK;
 }
+
+static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes);
 
 namespace
 {
@@ -1952,6 +2004,18 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 HIPCHK(c, hipStreamWaitEvent(c->side[k], c->evFork, 0));
             }
         }
+        const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
+        if (nAll > 0)
+        {
+            static const int occLds = getenv("ACF_HIP_LEVEL_LDS") ? atoi(getenv("ACF_HIP_LEVEL_LDS")) : 0; // experiment: cap resident workgroups per CU with an unused LDS reservation
+            if (occLds > 0 && (rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all), size_t(occLds))))
+            {
+                return rc;
+            }
+            hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nF, nAll), dim3(256), size_t(occLds), c->stream, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs, dd,
+                (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+            LAUNCHCHK(c, "k_level_all");
+        }
         size_t gi = 0;
         for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
         {
@@ -2077,6 +2141,10 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.hits = cs.d_hits;
     a.counts = cs.d_counts;
     a.maxHits = c->maxHits;
+    a.tailScratch = cs.d_tailScratch;
+    a.tailPad = cs.tailPad;
+    a.tailSlab = cs.tailSlab;
+    a.tailNodesLds = cs.tailNodesLds;
     if (const char* e = getenv("ACF_HIP_CASC_DEBUG"))
     {
         a.debug = atoi(e);
@@ -2141,13 +2209,37 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         }
         if (g.b[4] < p.nTrees)
         {
-            const size_t tl = size_t(cs.tailWaves) * g.winFloats * 4;
-            dim3 tgrid(std::max(1, 512 / nF) * nF), tblock(cs.tailWaves * 64);
+            static const bool oldTail = getenv("ACF_HIP_TAIL2") != nullptr; // A/B: the one-window-per-wave ordered scan
+            dim3 tgrid(std::min(cs.tailBlocks, std::max(1, 512 / nF) * nF)), tblock(cs.tailWaves * 64);
+            if (oldTail)
+            {
+                a.tailSlab = g.winFloats;
+                a.tailNodesLds = 0;
+            }
+            const size_t tl = (size_t(cs.tailWaves) * a.tailSlab + size_t(a.tailNodesLds)) * 4;
             prof(c, "k_cascade_tail2");
-#define TAIL_LAUNCH(N)                                                        \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail2<N>), tl)))                           \
-        return rc;                                                            \
-    hipLaunchKernelGGL(k_cascade_tail2<N>, tgrid, tblock, tl, c->stream, a);
+#define TAIL_LAUNCH(N)                                                                                              \
+    if (oldTail)                                                                                                    \
+    {                                                                                                               \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail2<N>), tl)))                             \
+            return rc;                                                                                              \
+        hipLaunchKernelGGL(k_cascade_tail2<N>, tgrid, tblock, tl, c->stream, a);                                    \
+    }                                                                                                               \
+    else                                                                                                            \
+    {                                                                                                               \
+        if (a.tailNodesLds)                                                                                         \
+        {                                                                                                           \
+            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, true>), tl)))                   \
+                return rc;                                                                                          \
+            hipLaunchKernelGGL((k_cascade_tail3<N, true>), tgrid, tblock, tl, c->stream, a);                        \
+        }                                                                                                           \
+        else                                                                                                        \
+        {                                                                                                           \
+            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, false>), tl)))                  \
+                return rc;                                                                                          \
+            hipLaunchKernelGGL((k_cascade_tail3<N, false>), tgrid, tblock, tl, c->stream, a);                       \
+        }                                                                                                           \
+    }
             switch (cs.tailWaves)
             {
                 case 4:

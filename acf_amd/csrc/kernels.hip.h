@@ -1623,6 +1623,7 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
 struct LevelJob
 {
     int32_t hC, wC, out_cs, desc; // desc: index of the ResampleDesc of an approximated level, -1 for a real level
+    int32_t kind, pad_;           // R * 8 + mode: the specialisation k_level_all dispatches to
     int64_t in_off;               // real level: float offset of its raw channels in the per-frame channel buffer
     int64_t raw_off;              // where the level's raw (unsmoothed) channels go when taps are kept
     int64_t out_off;              // float offset of the level's interior in the per-frame pyramid
@@ -1858,11 +1859,10 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 }
 
 template <int R, int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
-    const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
+__device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
-    const LevelJob J = jobs[blockIdx.y];
     // the plane index is the same for the 64 lanes of a wave; say so (readfirstlane), or every plane pointer is
     // treated as per-lane and all address arithmetic lands on the VALU in 64 bits
     const int z = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1872,7 +1872,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4
     }
     const int lane = threadIdx.x & 63;
     const int h = J.hC, w = J.wC;
-    const int64_t f = blockIdx.z;
     const srd_t Osrd = make_srd(pyr + f * pyr_fs + J.out_off + int64_t(z) * J.out_ps, (int64_t(w - 1) * J.out_cs + h) * 4);
     srd_t A, raw = Osrd;
     bool haveRaw = false;
@@ -2039,6 +2038,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4
     }
 #undef LV_LOAD
 #undef LV_FILTER
+}
+
+// One launch per run of levels with equal (R, mode): blockIdx.y = level of the run, blockIdx.z = frame.
+template <int R, int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+    const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+{
+    const LevelJob J = jobs[blockIdx.y];
+    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump);
+}
+
+// All levels whose specialisation fits 128 VGPRs (R <= 4 in any mode, real levels up to R = 8) in ONE launch:
+// blockIdx.z = level, longest plane chain first, blockIdx.y = frame.  A plane is a sequential chain of wC column
+// steps, so a launch lasts as long as its longest wave; as separate launches per (R, mode) on the 4 hardware queues
+// the stage cost max-over-queues of a sum of such tails and kept 38 % of the wave slots busy (PMC SQ_WAVE_CYCLES,
+// kernel trace).  In one grid the dispatcher starts the long chains first and back-fills slots with short ones as
+// they free up.  The specialisation is picked by a workgroup-uniform switch.
+#define ACF_LEVEL_KIND(R, M) ((R) * 8 + (M))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+    const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+{
+    const LevelJob J = jobs[blockIdx.z];
+    const int64_t f = blockIdx.y;
+#define LV_CASE(RR, MM)                                                                                    \
+    case ACF_LEVEL_KIND(RR, MM):                                                                            \
+        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump);       \
+        break;
+#define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_DU) LV_CASE(RR, LM_UD) LV_CASE(RR, LM_UU)
+    switch (J.kind)
+    {
+        LV_CASES(1)
+        LV_CASES(2)
+        LV_CASES(3)
+        LV_CASES(4)
+        LV_CASE(5, LM_REAL)
+        LV_CASE(6, LM_REAL)
+        LV_CASE(7, LM_REAL)
+        LV_CASE(8, LM_REAL)
+        default:
+            break;
+    }
+#undef LV_CASES
+#undef LV_CASE
 }
 
 // imResample, exact 1/2 in both axes (imResampleMex.cpp:198-215, 284-288), ha % 4 == 0: 16 bytes per lane.
@@ -2555,6 +2599,10 @@ struct TileArgs
     int32_t maxHits;
     int32_t debug; // timing experiments only (ACF_HIP_CASC_DEBUG): 1 = skip the tile fill, 2 = stop after the fill, 4 = phase stamps
     long long* stamps; // [block][8] s_memtime at phase boundaries (debug & 4)
+    // k_cascade_tail3: per-wave leaf matrix [TAIL_G windows][tailPad trees] in global memory, LDS floats per wave
+    float* tailScratch;
+    int32_t tailPad, tailSlab;
+    int32_t tailNodesLds; // the tail's node table fits in LDS next to the footprint slabs (floats reserved at the start of LDS, else 0)
 };
 
 // Keep scalar / vector values materialised at this point: stops the compiler from
@@ -3138,52 +3186,41 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     TILE_STAMP(4);
 }
 
-// Tail stage [tEnd, nTrees) of the tiled path: the few windows still alive each
-// need thousands of feature reads scattered over their own modelDsPad footprint.
-// One WAVE owns one window: the footprint (nChns*mW*mH floats — exactly the
-// cids[] index space, acfDetect1.cpp:390-406, so a feature id addresses it
-// directly) is copied to the wave's LDS slab, then wave_eval_trees runs the
-// remaining trees 64 at a time.  Waves pull windows from the frame's queue with
-// an atomic head counter, so long-lived windows do not stall a fixed partition.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
+// Copy one window's footprint (nChns*mW*mH floats, the cids[] index space) from the pyramid level into a wave's LDS
+// slab.  run = z * mW + cc  ->  win[run * mH + rr].
+struct TailFill
 {
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* win = lds + wv * a.g.winFloats;
-    const int frame = blockIdx.x % a.nFrames;
-    const int cnt = min(a.qcount[frame], a.qcap);
+    int SUB, sub, rr, rrc, nRuns;
+    bool lact;
+    uint32_t cpsMagic, mwMagic;
+};
+
+__device__ __forceinline__ TailFill tail_fill_setup(const TileArgs& a, int lane)
+{
+    TailFill t;
     const int mH = a.mH, mW = a.mW;
-    const int tEnd = a.g.b[4];
-    // lane -> (sub-row of this pass, row offset) for the footprint copy: SUB runs of mH floats per pass
-    const int SUB = max(1, min(64 / mH, mW)); // <= mW: one conditional wrap per step
-    const int sub = lane / mH, rr = lane - sub * mH;
-    const bool lact = sub < SUB;
-    const int rrc = lact ? rr : 0;
-    const int nRuns = a.nChns * mW;
-    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees); // first tail batch: same trees for every window
-    const uint32_t cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(max(mH >> 2, 1)) - 1) / uint32_t(max(mH >> 2, 1)));
-    const uint32_t mwMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(mW) - 1) / uint32_t(mW));
-    for (;;)
+    // lane -> (sub-row of this pass, row offset) for the 4-byte copy: SUB runs of mH floats per pass
+    t.SUB = max(1, min(64 / mH, mW)); // <= mW: one conditional wrap per step
+    t.sub = lane / mH;
+    t.rr = lane - t.sub * mH;
+    t.lact = t.sub < t.SUB;
+    t.rrc = t.lact ? t.rr : 0;
+    t.nRuns = a.nChns * mW;
+    t.cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(max(mH >> 2, 1)) - 1) / uint32_t(max(mH >> 2, 1)));
+    t.mwMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(mW) - 1) / uint32_t(mW));
+    return t;
+}
+
+__device__ __forceinline__ void tail_fill(const TileArgs& a, float* win, const float* __restrict__ chn, int hP, int area, int lane, const TailFill& t)
+{
+    const int mH = a.mH, mW = a.mW;
+    const int SUB = t.SUB, sub = t.sub, rrc = t.rrc, nRuns = t.nRuns;
+    const bool lact = t.lact;
+    const uint32_t cpsMagic = t.cpsMagic, mwMagic = t.mwMagic;
+    struct
     {
-        int i = 0;
-        if (lane == 0)
-        {
-            i = atomicAdd(a.qhead + frame, 1);
-        }
-        i = __shfl(i, 0);
-        if (i >= cnt)
-        {
-            break;
-        }
-        const uint2 e = a.q[int64_t(frame) * a.qcap + i];
-        const int lvl = int(e.x >> 24);
-        const int n = int(e.x & 0xffffffu);
-        const CascLevel L = a.levels[lvl];
-        const int c = n / L.nWinR;
-        const int r = n - c * L.nWinR;
-        const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
-        const int area = L.hP * L.wP;
+        int hP;
+    } L{ hP };
         // copy: run = z * mW + cc  ->  win[run * mH + rr], straight into LDS by LDS-DMA (no VGPR round trip); nothing
         // waits between instructions, so the whole footprint is in flight at once
         if ((mH & 3) == 0)
@@ -3233,6 +3270,48 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
                 win[f] = chn[int64_t(z) * area + cc * L.hP + r2];
             }
         }
+}
+
+// Tail stage [tEnd, nTrees) of the tiled path: the few windows still alive each
+// need thousands of feature reads scattered over their own modelDsPad footprint.
+// One WAVE owns one window: the footprint (nChns*mW*mH floats — exactly the
+// cids[] index space, acfDetect1.cpp:390-406, so a feature id addresses it
+// directly) is copied to the wave's LDS slab, then wave_eval_trees runs the
+// remaining trees 64 at a time.  Waves pull windows from the frame's queue with
+// an atomic head counter, so long-lived windows do not stall a fixed partition.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* win = lds + wv * a.g.winFloats;
+    const int frame = blockIdx.x % a.nFrames;
+    const int cnt = min(a.qcount[frame], a.qcap);
+    const int mH = a.mH, mW = a.mW;
+    const int tEnd = a.g.b[4];
+    const TailFill tf = tail_fill_setup(a, lane);
+    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees); // first tail batch: same trees for every window
+    for (;;)
+    {
+        int i = 0;
+        if (lane == 0)
+        {
+            i = atomicAdd(a.qhead + frame, 1);
+        }
+        i = __shfl(i, 0);
+        if (i >= cnt)
+        {
+            break;
+        }
+        const uint2 e = a.q[int64_t(frame) * a.qcap + i];
+        const int lvl = int(e.x >> 24);
+        const int n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR;
+        const int r = n - c * L.nWinR;
+        const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
+        const int area = L.hP * L.wP;
+        tail_fill(a, win, chn, L.hP, area, lane, tf);
         // the wave's own writes, read back by its own lanes: LDS ops of one wave complete in order
         __builtin_amdgcn_wave_barrier();
         float h = __uint_as_float(e.y);
@@ -3251,6 +3330,223 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Tail stage, two phases per wave (replaces the per-window ordered scan of k_cascade_tail2, whose 64-step
+// wave-uniform add chain was ~90 % of that kernel's instructions):
+//
+//   phase 1  lanes = trees.  The wave takes TAIL_G windows from the frame's queue; for each one it copies the
+//            footprint to its LDS slab and walks ALL remaining trees 64 at a time, writing the leaf values
+//            hs[k] to its private leaf matrix [window][tree] in global memory (256-byte rows, stays in L2 /
+//            Infinity Cache: it is rewritten by the same wave every round).  No score is involved, so the
+//            batches are independent and overlap.
+//   phase 2  lanes = windows.  Lane w adds window w's leaf values to its score strictly in tree order,
+//            h = h + hs (evaluate(), acfDetect1.cpp:123-138), 64 trees per step through a [TAIL_G][68]-float
+//            LDS transposition tile (global rows in, one ds_read_b128 per 4 trees out); a lane dies when any
+//            prefix is <= cascThr.  The add order per window is the reference's, so scores are bit-identical;
+//            trees evaluated past a window's rejection point only cost phase-1 time.
+constexpr int TAIL_G = 16;
+constexpr int TAIL_PITCH = 68;
+
+template <int NW, bool NODES_LDS>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* win = lds + a.tailNodesLds + wv * a.tailSlab;
+    const int frame = blockIdx.x % a.nFrames;
+    const int cnt = min(a.qcount[frame], a.qcap);
+    const int tEnd = a.g.b[4];
+    const int nT = a.nTrees - tEnd;
+    const int pad = a.tailPad;
+    float* __restrict__ S = a.tailScratch + (int64_t(blockIdx.x) * NW + wv) * int64_t(TAIL_G) * pad;
+    const TailFill tf = tail_fill_setup(a, lane);
+    // Node table of the tail in LDS when it fits: every window walks the same trees, and an L2 round trip per
+    // 64-tree batch (~1 us under load) was the whole cost of phase 1 when the nodes were read from global memory.
+    // (a template parameter, not a run-time flag: with both node paths in the loop the compiler put a full
+    // s_waitcnt vmcnt(0) at the top of every step, i.e. one store round trip per 64 trees)
+    constexpr bool nodesLds = NODES_LDS;
+    const TreeNode* __restrict__ nodeBase = a.tailNodes + tEnd;
+    if (nodesLds)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(nodeBase);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < nT * 3; i += NW * 64)
+        {
+            dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees);
+    const float thrC = a.cascThr;
+    for (;;)
+    {
+        int i0 = 0;
+        if (lane == 0)
+        {
+            i0 = atomicAdd(a.qhead + frame, TAIL_G);
+        }
+        i0 = __builtin_amdgcn_readfirstlane(__shfl(i0, 0));
+        if (i0 >= cnt)
+        {
+            break;
+        }
+        const int nW = min(TAIL_G, cnt - i0);
+        // lane w < nW keeps window w's queue entry for phase 2
+        const uint2 mine = a.q[int64_t(frame) * a.qcap + i0 + min(lane, nW - 1)];
+        // ---- phase 1
+        for (int k = 0; k < nW; k++)
+        {
+            const uint32_t ex = uint32_t(__builtin_amdgcn_readlane(int(mine.x), k));
+            const int lvl = int(ex >> 24);
+            const int n = int(ex & 0xffffffu);
+            const CascLevel L = a.levels[lvl];
+            const int c = n / L.nWinR;
+            const int r = n - c * L.nWinR;
+            const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
+            __builtin_amdgcn_wave_barrier(); // the previous window's feature reads are done (LDS ops of a wave are in order)
+            if (!(a.debug & 32))
+            {
+                tail_fill(a, win, chn, L.hP, L.hP * L.wP, lane, tf);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float* __restrict__ row = S + k * pad;
+            // four 64-tree batches per step: their node reads, root reads, child reads and stores are independent, so
+            // the four LDS latency chains overlap (one batch per step was 760 cycles of exposed latency per batch)
+            for (int tb = 0; tb < ((a.debug & 64) ? 0 : nT); tb += 256)
+            {
+                LaneNode nd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const int t = min(tb + 64 * j + lane, nT - 1); // batches past the end: clamped duplicates, stored into the row's padding or skipped
+                    if (nodesLds)
+                    {
+                        const uint4* np = reinterpret_cast<const uint4*>(lds) + 3 * t;
+                        nd[j].o = np[0];
+                        nd[j].tq = np[1];
+                        nd[j].hq = np[2];
+                    }
+                    else
+                    {
+                        const uint4* np = reinterpret_cast<const uint4*>(nodeBase + t);
+                        nd[j].o = np[0];
+                        nd[j].tq = np[1];
+                        nd[j].hq = np[2];
+                    }
+                }
+                float f0[4], fc[4];
+                bool lt0[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    f0[j] = win[nd[j].o.x];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    lt0[j] = f0[j] < __uint_as_float(nd[j].tq.x);
+                    fc[j] = win[lt0[j] ? nd[j].o.y : nd[j].o.z];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const float th1 = __uint_as_float(lt0[j] ? nd[j].tq.y : nd[j].tq.z);
+                    const bool lt1 = fc[j] < th1;
+                    const float leaf = __uint_as_float(lt0[j] ? (lt1 ? nd[j].hq.x : nd[j].hq.y) : (lt1 ? nd[j].hq.z : nd[j].hq.w));
+                    if (tb + 64 * j < pad)
+                    {
+                        row[tb + 64 * j + lane] = leaf;
+                    }
+                }
+            }
+        }
+        // ---- phase 2.  Other lanes of this wave wrote the rows read below.  Workgroup scope is enough: the stores went
+        // through this CU's write-through L1, which the loads below also use (an agent-scope fence would write back and
+        // invalidate the XCD's whole L2 on gfx942/950 — measured 0.3 ms per 64 frames)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (a.debug & 16)
+        {
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* tile = win;
+        float h = __uint_as_float(mine.y);
+        bool alive = lane < nW;
+        const int wl = lane & (TAIL_G - 1);
+        float nx[TAIL_G];
+#pragma unroll
+        for (int k = 0; k < TAIL_G; k++)
+        {
+            nx[k] = S[k * pad + lane];
+        }
+        for (int tb = 0; tb < nT; tb += 64)
+        {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < TAIL_G; k++)
+            {
+                tile[k * TAIL_PITCH + lane] = nx[k];
+            }
+            if (tb + 64 < nT)
+            {
+#pragma unroll
+                for (int k = 0; k < TAIL_G; k++)
+                {
+                    nx[k] = S[k * pad + tb + 64 + lane];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int nt = min(64, nT - tb);
+            float m = h;
+            if (nt == 64)
+            {
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                {
+                    const float4 x = *reinterpret_cast<const float4*>(tile + wl * TAIL_PITCH + 4 * q);
+                    h = h + x.x;
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+                    h = h + x.y;
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+                    h = h + x.z;
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+                    h = h + x.w;
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+                }
+            }
+            else
+            {
+                for (int q = 0; q < nt; q++)
+                {
+                    h = h + tile[wl * TAIL_PITCH + q];
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+                }
+            }
+            alive = alive && (m > thrC) && (h > thrC);
+            if (__ballot(alive) == 0ull)
+            {
+                break;
+            }
+        }
+        if (alive)
+        {
+            const int idx = atomicAdd(a.counts + frame, 1);
+            if (idx < a.maxHits)
+            {
+                const int lvl = int(mine.x >> 24);
+                const int n = int(mine.x & 0xffffffu);
+                const int nWinR = a.levels[lvl].nWinR;
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = n / nWinR;
+                hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
     }
 }
 
