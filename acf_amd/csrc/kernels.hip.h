@@ -1680,6 +1680,115 @@ __device__ __forceinline__ void buf_st(srd_t r, uint32_t voff, uint32_t soff, fl
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
+// Source-column window of an approximated level.  The x pass of imResample combines JX adjacent source columns per
+// output column and successive output columns move on by s = 0, 1 or 2 source columns, so instead of fetching
+// JX*NY taps per output row every step (3 source columns through the L1 per step, every one a miss with 16 planes
+// in flight per CU: the k_level experiments of round 1 put 50 % of the kernel there) the wave keeps the JX source
+// columns in registers with lanes on SOURCE rows, fetches only the s new columns per step (requested one step
+// ahead), runs the x pass once per source row, and hands the column to the y pass through a wave-private LDS
+// buffer: row r of the x-pass column at float r, gathered by each output row's y taps.  Per element the operands
+// and their order are those of k_resample (x pass then y pass), so the result is bit-identical.
+constexpr int LEVEL_LDS_WAVE = 12 * 64; // floats: the x-pass column of one wave, RS <= 12 source-row registers (R <= 8)
+
+template <int R, int MODE>
+struct LevelWindow
+{
+    static constexpr bool XDOWN = MODE == LM_DD || MODE == LM_DU;
+    static constexpr bool YDOWN = MODE == LM_DD || MODE == LM_UD;
+    static constexpr int NY = YDOWN ? 3 : 2;
+    static constexpr int JX = XDOWN ? 3 : 2;
+    static constexpr int RS = YDOWN ? (3 * R + 1) / 2 : R; // source rows per lane: ha <= 64 * RS (host-checked)
+
+    float win[JX][RS]; // source columns xaCur .. xaCur + JX - 1
+    float nw[2][RS];   // source columns xaCur + JX, xaCur + JX + 1 (requested during the previous step)
+    uint32_t srow[RS]; // byte offset of the lane's (clamped) source rows in a column
+    int xaCur;
+
+    __device__ __forceinline__ void load_col(float (&d)[RS], srd_t A, int col, int ha, int wa) const
+    {
+        const uint32_t cb = uint32_t(min(col, wa - 1)) * uint32_t(ha) * 4u;
+#pragma unroll
+        for (int r = 0; r < RS; r++)
+        {
+            d[r] = buf_ld(A, srow[r], cb);
+        }
+    }
+
+    __device__ __forceinline__ void init(srd_t A, int lane, int ha, int wa, int xa0)
+    {
+#pragma unroll
+        for (int r = 0; r < RS; r++)
+        {
+            srow[r] = 4u * uint32_t(min(lane + 64 * r, ha - 1));
+        }
+        xaCur = xa0;
+#pragma unroll
+        for (int j = 0; j < JX; j++)
+        {
+            load_col(win[j], A, xa0 + j, ha, wa);
+        }
+        load_col(nw[0], A, xa0 + JX, ha, wa);
+        load_col(nw[1], A, xa0 + JX + 1, ha, wa);
+    }
+
+    // move the window to source column xa (wave-uniform), fetching exactly the columns that enter it
+    __device__ __forceinline__ void advance(srd_t A, int xa, int ha, int wa)
+    {
+        const int sft = xa - xaCur;
+        if (sft == 0)
+        {
+            return;
+        }
+        if (sft == 1)
+        {
+#pragma unroll
+            for (int r = 0; r < RS; r++)
+            {
+#pragma unroll
+                for (int j = 0; j + 1 < JX; j++)
+                {
+                    win[j][r] = win[j + 1][r];
+                }
+                win[JX - 1][r] = nw[0][r];
+                nw[0][r] = nw[1][r];
+            }
+            load_col(nw[1], A, xa + JX + 1, ha, wa);
+        }
+        else if (sft == 2)
+        {
+#pragma unroll
+            for (int r = 0; r < RS; r++)
+            {
+                if (JX == 3)
+                {
+                    win[0][r] = win[2][r];
+                    win[1][r] = nw[0][r];
+                    win[2][r] = nw[1][r];
+                }
+                else
+                {
+                    win[0][r] = nw[0][r];
+                    win[1][r] = nw[1][r];
+                }
+            }
+            load_col(nw[0], A, xa + JX, ha, wa);
+            load_col(nw[1], A, xa + JX + 1, ha, wa);
+        }
+        else
+        {
+            // not reached for ratios within 2^(+-1/2); kept for safety (any jump, either direction)
+#pragma unroll
+            for (int j = 0; j < JX; j++)
+            {
+                load_col(win[j], A, xa + j, ha, wa);
+            }
+            load_col(nw[0], A, xa + JX, ha, wa);
+            load_col(nw[1], A, xa + JX + 1, ha, wa);
+        }
+        xaCur = xa;
+    }
+};
+
 template <int R>
 struct LaneTaps
 {
@@ -1694,7 +1803,8 @@ struct LaneTaps
 // (imResampleMex.cpp:198-280, 319-373).
 template <int R, int MODE>
 __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int h, const uint32_t (&yoff)[R],
-    int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, srd_t raw, bool haveRaw, bool lastOk)
+    int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, srd_t raw, bool haveRaw, bool lastOk,
+    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>& win, float* __restrict__ ldsCol, int lane)
 {
     if (MODE == LM_REAL)
     {
@@ -1716,61 +1826,35 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     const int xa = int(xr[0]), m = int(xr[1]);
     const bool border = xr[3] != 0;
     const float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
-    float a[JX][R][NY];
-#pragma unroll
-    for (int j = 0; j < JX; j++)
-    {
-        const uint32_t col = uint32_t(min(xa + j, wa - 1)) * uint32_t(ha) * 4u;
-#pragma unroll
-        for (int k = 0; k < R; k++)
-        {
-#pragma unroll
-            for (int o = 0; o < NY; o++)
-            {
-                a[j][k][o] = buf_ld(A, tp.roff[k][o], col);
-            }
-        }
-    }
-    // x pass: taps accumulate left to right (imResampleMex.cpp:198-280).  The tap count m and the border flag are
-    // wave-uniform per column: branch on them once (around arithmetic only — all loads are already in flight)
-    // instead of selecting per value.
-    float C[R][NY];
+    constexpr int RS = LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::RS;
+    win.advance(A, xa, ha, wa);
+    // x pass on the lane's source rows: taps accumulate left to right (imResampleMex.cpp:198-280).  The tap count m and
+    // the border flag are wave-uniform per column: branch on them once, around arithmetic only.
+    float Cr[RS];
     if (XDOWN)
     {
         if (m == 2)
         {
 #pragma unroll
-            for (int k = 0; k < R; k++)
+            for (int r = 0; r < RS; r++)
             {
-#pragma unroll
-                for (int o = 0; o < NY; o++)
-                {
-                    C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1];
-                }
+                Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1];
             }
         }
         else if (m >= 3)
         {
 #pragma unroll
-            for (int k = 0; k < R; k++)
+            for (int r = 0; r < RS; r++)
             {
-#pragma unroll
-                for (int o = 0; o < NY; o++)
-                {
-                    C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1] + a[2][k][o] * w[2];
-                }
+                Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1] + win.win[JX - 1][r] * w[2];
             }
         }
         else
         {
 #pragma unroll
-            for (int k = 0; k < R; k++)
+            for (int r = 0; r < RS; r++)
             {
-#pragma unroll
-                for (int o = 0; o < NY; o++)
-                {
-                    C[k][o] = a[0][k][o] * w[0];
-                }
+                Cr[r] = win.win[0][r] * w[0];
             }
         }
     }
@@ -1778,25 +1862,35 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     {
         // up: a clamped border column is copied (:264-280)
 #pragma unroll
-        for (int k = 0; k < R; k++)
+        for (int r = 0; r < RS; r++)
         {
-#pragma unroll
-            for (int o = 0; o < NY; o++)
-            {
-                C[k][o] = a[0][k][o];
-            }
+            Cr[r] = win.win[0][r];
         }
     }
     else
     {
 #pragma unroll
-        for (int k = 0; k < R; k++)
+        for (int r = 0; r < RS; r++)
         {
+            Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1]; // A0*wt + A1*(1-wt)
+        }
+    }
+    // hand the column to the y pass: source row q at ldsCol[q]; an output row gathers its NY taps (byte offsets
+    // tp.roff).  One wave owns the buffer and LDS operations of a wave complete in order, so the writes below cannot
+    // pass the previous step's gathers and the gathers cannot pass the writes.
 #pragma unroll
-            for (int o = 0; o < NY; o++)
-            {
-                C[k][o] = a[0][k][o] * w[0] + a[1][k][o] * w[1]; // A0*wt + A1*(1-wt)
-            }
+    for (int r = 0; r < RS; r++)
+    {
+        ldsCol[lane + 64 * r] = Cr[r];
+    }
+    float C[R][NY];
+#pragma unroll
+    for (int k = 0; k < R; k++)
+    {
+#pragma unroll
+        for (int o = 0; o < NY; o++)
+        {
+            C[k][o] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldsCol) + tp.roff[k][o]);
         }
     }
     // rows >= ha read the zeroed tail of the reference's column buffer (:133-137): only the lanes of the plane's last
@@ -1861,7 +1955,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 template <int R, int MODE>
 __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* __restrict__ ldsBlock)
 {
     // the plane index is the same for the 64 lanes of a wave; say so (readfirstlane), or every plane pointer is
     // treated as per-lane and all address arithmetic lands on the VALU in 64 bits
@@ -1970,10 +2064,17 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     // store it waited for the loads it had just issued, every step.
     u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
     u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
+    // approximated levels: the source-column window (registers) and the wave's x-pass column buffer (LDS)
+    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> lw;
+    float* __restrict__ ldsCol = ldsBlock + (threadIdx.x >> 6) * LEVEL_LDS_WAVE;
+    if (MODE != LM_REAL)
+    {
+        lw.init(A, lane, ha, wa, int(xr[0]));
+    }
     const int lastLane = (h - 1) & 63; // lane holding row h-1 in the last register
 #define LV_LOAD(FAR, COL)                                                                                           \
     {                                                                                                               \
-        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, haveRaw, lastOk);        \
+        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, haveRaw, lastOk, lw, ldsCol, lane); \
         xr = xrn;                                                                                                   \
         xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
     }
@@ -2047,7 +2148,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
     const LevelJob J = jobs[blockIdx.y];
-    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump);
+    __shared__ float ldsBlock[4 * LEVEL_LDS_WAVE];
+    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock);
 }
 
 // All levels whose specialisation fits 128 VGPRs (R <= 4 in any mode, real levels up to R = 8) in ONE launch:
@@ -2063,9 +2165,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 {
     const LevelJob J = jobs[blockIdx.z];
     const int64_t f = blockIdx.y;
-#define LV_CASE(RR, MM)                                                                                    \
-    case ACF_LEVEL_KIND(RR, MM):                                                                            \
-        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump);       \
+    __shared__ float ldsBlock[4 * LEVEL_LDS_WAVE];
+#define LV_CASE(RR, MM)                                                                                          \
+    case ACF_LEVEL_KIND(RR, MM):                                                                                  \
+        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock);   \
         break;
 #define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_DU) LV_CASE(RR, LM_UD) LV_CASE(RR, LM_UU)
     switch (J.kind)
