@@ -21,6 +21,12 @@ struct DevBuf
     size_t bytes = 0;
 };
 
+// k_resample_tile plan of a down-sampling descriptor (resampleTilePlan)
+struct ResampleTiling
+{
+    int rows = 0, cols = 0, xo = 0, tile_y = 0, tile_x = 0;
+};
+
 struct RealScale
 {
     int level = 0, h = 0, w = 0;
@@ -28,6 +34,7 @@ struct RealScale
     bool adoptAsI = false;  // after this scale, I := smoothed image of this scale
     int src_h = 0, src_w = 0;
     int descIndex = -1;
+    ResampleTiling tiling;          // k_resample_tile plan of the image resample (rows == 0: not eligible)
     float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
 };
 
@@ -1120,6 +1127,67 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     return ACF_HIP_OK;
 }
 
+// Tiling of a down-sampling descriptor for k_resample_tile: output columns per tile (the largest of 32/16/8 whose
+// source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
+// int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
+static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena)
+{
+    ResampleTiling tl;
+    if (!((dd.xmode == RS_DOWN || dd.xmode == RS_EXACT) && (dd.ymode == RS_DOWN || dd.ymode == RS_EXACT)))
+    {
+        return tl;
+    }
+    std::vector<int32_t> ty;
+    int maxR = 0;
+    {
+        const int32_t* it = arena.ints.data();
+        for (int yb0 = 0; yb0 < dd.hb; yb0 += RT_YO)
+        {
+            const int yb1 = std::min(yb0 + RT_YO, dd.hb);
+            int lo, hi;
+            if (dd.ymode == RS_EXACT)
+            {
+                lo = dd.yk * yb0;
+                hi = dd.yk * (yb1 - 1) + dd.yk - 1;
+            }
+            else
+            {
+                lo = it[dd.y_src + it[dd.y_start + yb0]];
+                hi = std::max(it[dd.y_src + it[dd.y_start + yb1 - 1]] + dd.ybd0 - 1, it[dd.y_src + it[dd.y_start + yb1] - 1]);
+            }
+            ty.push_back(lo);
+            ty.push_back(hi);
+            maxR = std::max(maxR, hi - lo + 1);
+        }
+    }
+    for (int xo : { 32, 16, 8 })
+    {
+        std::vector<int32_t> tx;
+        int maxC = 0;
+        const int32_t* it = arena.ints.data();
+        for (int xb0 = 0; xb0 < dd.wb; xb0 += xo)
+        {
+            const int xb1 = std::min(xb0 + xo, dd.wb);
+            const int lo = it[dd.x_col + 8 * xb0], hi = it[dd.x_col + 8 * (xb1 - 1)] + it[dd.x_col + 8 * (xb1 - 1) + 1] - 1;
+            tx.push_back(lo);
+            tx.push_back(hi);
+            maxC = std::max(maxC, hi - lo + 1);
+        }
+        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= int64_t(64) * 1024)
+        {
+            tl.rows = maxR;
+            tl.cols = maxC;
+            tl.xo = xo;
+            tl.tile_y = int(arena.ints.size());
+            arena.ints.insert(arena.ints.end(), ty.begin(), ty.end());
+            tl.tile_x = int(arena.ints.size());
+            arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
+            return tl;
+        }
+    }
+    return tl;
+}
+
 int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_hits)
 {
     if (!c)
@@ -1251,6 +1319,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             dd.dst_frame_stride = int64_t(d) * np;
             rs.descIndex = int(c->h_descs.size());
             c->h_descs.push_back(dd);
+            rs.tiling = resampleTilePlan(dd, arena);
             if ((rc = devAlloc(c, &rs.img, size_t(B) * d * np)))
             {
                 return rc;
@@ -1811,6 +1880,18 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 const int64_t items = int64_t(hd.hb / 2) * hd.wb * hd.nplanes;
                 hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
                     (const ResampleDesc*)(c->d_descs + rs.descIndex));
+            }
+            else if (rs.tiling.rows > 0 && !getenv("ACF_HIP_RESAMPLE_GENERIC"))
+            {
+                const ResampleTiling& tl = rs.tiling;
+                const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
+                if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes)))
+                {
+                    return rc;
+                }
+                const int nb = cdiv(hd.hb, RT_YO) * cdiv(hd.wb, tl.xo) * hd.nplanes;
+                hipLaunchKernelGGL(k_resample_tile, dim3(nb, 1, nF), dim3(256), ldsBytes, c->stream, cur, rs.img,
+                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
             }
             else
             {
@@ -3297,14 +3378,30 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
     float* di = s.upload(in, size_t(d) * ha * wa);
     float* dout = s.alloc<float>(size_t(d) * hb * wb);
     ResampleDesc* ddesc = s.upload(&dd, 1);
+    const ResampleTiling tl = resampleTilePlan(dd, arena); // appends its tile ranges to the int arena
     int32_t* dit = s.upload(arena.ints.data(), arena.ints.size());
     float* dft = s.upload(arena.floats.data(), arena.floats.size());
     if (!di || !dout || !ddesc || !dit || !dft)
     {
         return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
     }
-    hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(dd), 1, 1), dim3(64, 4), 0, c->stream, (const float*)di, dout,
-        (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, RS_XT);
+    if (tl.rows > 0 && !getenv("ACF_HIP_RESAMPLE_GENERIC"))
+    {
+        // the LDS-tiled kernel the pyramid uses for its down-sampled real scales
+        const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
+        int rc2 = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes);
+        if (rc2)
+        {
+            return rc2;
+        }
+        hipLaunchKernelGGL(k_resample_tile, dim3(cdiv(hb, RT_YO) * cdiv(wb, tl.xo) * d, 1, 1), dim3(256), ldsBytes, c->stream, (const float*)di, dout,
+            (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(dd), 1, 1), dim3(64, 4), 0, c->stream, (const float*)di, dout,
+            (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, RS_XT);
+    }
     LAUNCHCHK(c, "k_resample");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout, sizeof(float) * d * hb * wb, hipMemcpyDeviceToHost));

@@ -22,6 +22,10 @@
 namespace acfhip
 {
 
+// address-space-qualified pointers for __builtin_amdgcn_global_load_lds (LDS-DMA)
+typedef const __attribute__((address_space(1))) void* gptr_t;  // global
+typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
+
 // ------------------------------------------------------------------------
 // rgbConvert (toolbox/rgbConvertMex.cpp)
 // ------------------------------------------------------------------------
@@ -2218,6 +2222,190 @@ __global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__
     *reinterpret_cast<float2*>(B) = o;
 }
 
+// ------------------------------------------------------------------------
+// imResample for the down-sampling real scales of the image pyramid (chnsPyramid.cpp:310): a workgroup produces a
+// 64-row x `xo`-column output tile from a source tile staged once in LDS — x pass for every source row of the tile
+// into a second LDS buffer, then the y pass — instead of re-reading JX*NY taps per output through the L1 (the
+// generic k_resample: ~1 TB/s on the 960x540 -> 484x272 and -> 240x136 resamples).  Arithmetic and association order
+// are rs_C's and k_resample's (x pass then y pass), so results are bit-identical.  Modes: x and y each DOWN or EXACT.
+// ------------------------------------------------------------------------
+constexpr int RT_YO = 64;
+
+// tile_y / tile_x (int arena, written by resampleTilePlan on the host): per output-row tile {rowLo, rowHi}, per
+// output-column tile {colLo, colHi}; xo = output columns per tile.
+__global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__ src, float* __restrict__ dst,
+    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
+    int tile_y, int tile_x)
+{
+    extern __shared__ float rt_lds[];
+    const ResampleDesc& d = descs[blockIdx.y];
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int ntY = (hb + RT_YO - 1) / RT_YO;
+    const int ntX = (wb + xo - 1) / xo;
+    int t = blockIdx.x;
+    const int ytile = t % ntY;
+    t /= ntY;
+    const int xtile = t % ntX;
+    const int z = t / ntX;
+    if (z >= d.nplanes)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
+    const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty], rk = d.rk[ty];
+    const int xmode = d.xmode, ymode = d.ymode;
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
+    const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
+    const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
+    float* T = rt_lds;                             // [nCols][nRows] source tile
+    float* C = rt_lds + size_t(maxCols) * maxRows; // [xo][nRows] x-pass columns
+    // this lane's y taps (global table reads: issued before the tile load so their latency overlaps it)
+    const int yb = yb0 + lane;
+    const bool act = yb < yb1;
+    const int ybc = act ? yb : yb1 - 1;
+    int ya, q0 = 0, q1 = 0;
+    float wy[4] = { 0.f, 0.f, 0.f, 0.f };
+    const int ny = (ymode == RS_EXACT) ? d.yk : d.ybd0;
+    const bool ySlow = (ymode == RS_DOWN) && d.ybd0 > 4;
+    if (ymode == RS_EXACT)
+    {
+        ya = d.yk * ybc;
+    }
+    else
+    {
+        q0 = it[d.y_start + ybc];
+        q1 = it[d.y_start + ybc + 1];
+        ya = it[d.y_src + q0];
+        if (!ySlow)
+        {
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                if (o < ny)
+                {
+                    wy[o] = ft[d.y_wt + q0 + o] * r; // ywts[y] *= r (:158-161)
+                }
+            }
+        }
+    }
+    // source tile: a wave per source column, lanes along the rows (coalesced), straight into LDS by LDS-DMA so that the
+    // whole tile is in flight at once (a load -> ds_write loop exposed one memory round trip per 64 floats).  Rows
+    // >= ha hold clamped duplicates: the x pass zeroes those rows itself.
+    for (int cc = wv; cc < nCols; cc += 4)
+    {
+        const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
+        for (int r0 = 0; r0 < nRows; r0 += 64)
+        {
+            if (r0 + lane < nRows)
+            {
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // x pass (rs_C): a wave per output column, lanes along the source rows
+    const int32_t* xrec = it + d.x_col;
+    const int nXo = xb1 - xb0;
+    for (int c = wv; c < nXo; c += 4)
+    {
+        const int32_t* rec = xrec + 8 * (xb0 + c);
+        const int xa = rec[0], m = rec[1];
+        const float w0 = __int_as_float(rec[4]), w1 = __int_as_float(rec[5]), w2 = __int_as_float(rec[6]), w3 = __int_as_float(rec[7]);
+        const int wofs = rec[2];
+        const float* Tc = T + (xa - colLo) * nRows;
+        for (int rr = lane; rr < nRows; rr += 64)
+        {
+            const float* T0 = Tc + rr;
+            float s;
+            if (xmode == RS_EXACT)
+            {
+                s = T0[0] + T0[nRows];
+                if (m > 2)
+                {
+                    s = s + T0[2 * nRows];
+                }
+                if (m > 3)
+                {
+                    s = s + T0[3 * nRows];
+                }
+            }
+            else
+            {
+                s = T0[0] * w0;
+                if (m > 1)
+                {
+                    s = s + T0[nRows] * w1;
+                }
+                if (m > 2)
+                {
+                    s = s + T0[2 * nRows] * w2;
+                }
+                if (m > 3)
+                {
+                    s = s + T0[3 * nRows] * w3;
+                }
+                for (int j = 4; j < m; j++)
+                {
+                    s = s + T0[j * nRows] * ft[wofs + j];
+                }
+            }
+            C[c * nRows + rr] = (rowLo + rr >= ha) ? 0.f : s; // C[ha .. ha+3] = 0 (imResampleMex.cpp:133-137)
+        }
+    }
+    __syncthreads();
+    // y pass: lane = output row, a wave per output column
+    if (!act)
+    {
+        return;
+    }
+    for (int c = wv; c < nXo; c += 4)
+    {
+        const float* Cc = C + c * nRows - rowLo;
+        float v;
+        if (ymode == RS_EXACT)
+        {
+            float sacc = Cc[ya] + Cc[ya + 1];
+            if (ny > 2)
+            {
+                sacc = sacc + Cc[ya + 2];
+            }
+            if (ny > 3)
+            {
+                sacc = sacc + Cc[ya + 3];
+            }
+            v = sacc * rk;
+        }
+        else if (!ySlow)
+        {
+            v = Cc[ya] * wy[0];
+            v = v + Cc[ya + 1] * wy[1];
+            if (ny > 2)
+            {
+                v = v + Cc[ya + 2] * wy[2];
+            }
+            if (ny > 3)
+            {
+                v = v + Cc[ya + 3] * wy[3];
+            }
+        }
+        else
+        {
+            v = 0.f;
+            for (int q = q0; q < q1; q++)
+            {
+                v = v + Cc[it[d.y_src + q]] * (ft[d.y_wt + q] * r);
+            }
+        }
+        B[int64_t(xb0 + c) * hb + yb] = v;
+    }
+}
+
 // grid.x needed for one descriptor
 static inline int resampleBlocks(const ResampleDesc& d, int xt = RS_XT)
 {
@@ -2651,8 +2839,6 @@ __global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
 // every window adds the same leaves in the same order and stops at the first
 // h <= cascThr.
 // ------------------------------------------------------------------------
-typedef const __attribute__((address_space(1))) void* gptr_t;  // global
-typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4* cptr4_t; // constant: loads through it may use the scalar unit
 
