@@ -422,7 +422,15 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     prof(c, "k_tri_y");
     if (rad == 5 && h % 4 == 0 && h >= 48 && fs % 4 == 0 && ((uintptr_t(U) | uintptr_t(S)) & 15) == 0)
     {
-        hipLaunchKernelGGL(k_tri_y5, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, fs);
+        static const bool direct = getenv("ACF_HIP_TRIY_DIRECT") != nullptr; // A/B: lane-per-column accesses straight from global memory
+        if (direct)
+        {
+            hipLaunchKernelGGL(k_tri_y5, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, fs);
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_tri_y5s, dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, S, h, w, fs);
+        }
     }
     else
     {

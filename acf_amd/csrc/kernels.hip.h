@@ -1204,6 +1204,169 @@ __global__ void __launch_bounds__(64) k_tri_y5(const float* __restrict__ Ui, flo
     }
 }
 
+// k_tri_y5 with its global accesses staged through LDS.  With a lane per column every float4 load of k_tri_y5 touches
+// 64 different 128-byte lines, 8 KB of lines per wave; with ~28 waves per CU they do not survive in the L1 between the
+// eight loads that use them, so each 16-byte access re-fetched its line from L2 (PMC: 2x the algorithmic HBM traffic,
+// L2->L1 traffic ~8x).  Here a wave (64 adjacent columns) moves 16 rows at a time with lanes along image-y — 4 columns
+// x 64 contiguous bytes per instruction — through a [64 columns][20 floats] LDS buffer, and each lane then takes its
+// own column's 16 rows as four ds_read_b128 (20-float pitch: conflict-free).  Outputs go back the same way.  The
+// recurrence, the ring and every value are those of k_tri_y5.
+constexpr int TY_PITCH = 20;
+__global__ void __launch_bounds__(256) k_tri_y5s(const float* __restrict__ Ui, float* __restrict__ So, int h, int w, int64_t fs)
+{
+    __shared__ float ty_lds[4][2][64 * TY_PITCH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 4 + wv) * 64;
+    if (x0 >= w)
+    {
+        return;
+    }
+    float* inb = ty_lds[wv][0];
+    float* outb = ty_lds[wv][1];
+    const int x = min(x0 + lane, w - 1); // lanes past the last column duplicate it and never store
+    const bool own = x0 + lane < w;
+    const float* __restrict__ U0 = Ui + int64_t(blockIdx.z) * fs;
+    float* __restrict__ S0 = So + int64_t(blockIdx.z) * fs;
+    const float* __restrict__ col = U0 + int64_t(x) * h;
+    float* __restrict__ out = S0 + int64_t(x) * h;
+    // cooperative mapping: instruction q moves columns 4q + (lane >> 4), rows base + (lane & 15)
+    const int cl = lane >> 4, rl = lane & 15;
+    constexpr int r = 6, r0 = 5, r1 = 7, h0 = 7;
+    const int r2 = 2 * h - r, h1 = h - r + 1;
+    float t, u;
+    // rows 0..15: the reference's head (reflected taps), straight from memory
+    u = t = col[0];
+#pragma unroll
+    for (int q = 1; q < r; q++)
+    {
+        t += col[q];
+        u += t;
+    }
+    u = 2 * u - t;
+    t = 0;
+    float o[16];
+    o[0] = u;
+#pragma unroll
+    for (int j = 1; j < 16; j++)
+    {
+        const float a = (j < h0) ? col[r - j] : col[j - r1];
+        const float b = col[r0 + j];
+        t += a + b - 2 * col[j - 1];
+        u += t;
+        o[j] = u;
+    }
+    // store rows J..J+15 held in o[] through the LDS buffer
+#define TY_STORE(J0)                                                                                        \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            *reinterpret_cast<float4*>(outb + lane * TY_PITCH + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]); \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 16; q++)                                                      \
+        {                                                                                                   \
+            const int c_ = 4 * q + cl;                                                                      \
+            const float v_ = outb[c_ * TY_PITCH + rl];                                                      \
+            if (x0 + c_ < w)                                                                                \
+            {                                                                                               \
+                S0[int64_t(x0 + c_) * h + (J0) + rl] = v_;                                                  \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+    }
+    // request rows R0..R0+15 of the wave's 64 columns (16 coalesced loads) into g[]
+#define TY_FETCH(G, R0)                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 16; q++)                                                          \
+    {                                                                                                       \
+        G[q] = U0[int64_t(min(x0 + 4 * q + cl, w - 1)) * h + (R0) + rl];                                    \
+    }
+    // hand g[] to the owning lanes: N[q] = rows R0+4q .. R0+4q+3 of this lane's column
+#define TY_TAKE(G, N)                                                                                       \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 16; q++)                                                      \
+        {                                                                                                   \
+            inb[(4 * q + cl) * TY_PITCH + rl] = G[q];                                                       \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            N[q] = *reinterpret_cast<const float4*>(inb + lane * TY_PITCH + 4 * q);                         \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+    }
+    TY_STORE(0);
+    // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
+    float ring[16];
+    float g[16];
+    float4 nx[4];
+    {
+        TY_FETCH(g, 8);
+        TY_TAKE(g, nx); // rows 8..23
+        ring[8] = nx[0].x, ring[9] = nx[0].y, ring[10] = nx[0].z, ring[11] = nx[0].w;
+        ring[12] = nx[1].x, ring[13] = nx[1].y, ring[14] = nx[1].z, ring[15] = nx[1].w;
+        ring[0] = nx[2].x, ring[1] = nx[2].y, ring[2] = nx[2].z, ring[3] = nx[2].w;
+        ring[4] = nx[3].x, ring[5] = nx[3].y, ring[6] = nx[3].z, ring[7] = nx[3].w;
+    }
+    int J = 16;
+    const int lastFast = h - 24; // J + 23 <= h - 1 and every j <= J + 15 < h1
+    if (J <= lastFast)
+    {
+        TY_FETCH(g, J + 8);
+        TY_TAKE(g, nx); // rows J+8 .. J+23
+    }
+    for (; J <= lastFast; J += 16)
+    {
+        const bool more = J + 16 <= lastFast;
+        if (more)
+        {
+            TY_FETCH(g, J + 24); // next iteration's rows, in flight during this iteration's recurrence
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++)
+            {
+                const int jj = 4 * q + s2; // j = J + jj, J % 16 == 0
+                if (s2 == 3)
+                {
+                    // rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago)
+                    ring[(8 + 4 * q) & 15] = nx[q].x;
+                    ring[(9 + 4 * q) & 15] = nx[q].y;
+                    ring[(10 + 4 * q) & 15] = nx[q].z;
+                    ring[(11 + 4 * q) & 15] = nx[q].w;
+                }
+                const float a = ring[(jj - 7) & 15];
+                const float b = ring[(jj + 5) & 15];
+                const float cc = ring[(jj - 1) & 15];
+                t += a + b - 2 * cc;
+                u += t;
+                o[jj] = u;
+            }
+        }
+        TY_STORE(J);
+        if (more)
+        {
+            TY_TAKE(g, nx);
+        }
+    }
+#undef TY_STORE
+#undef TY_FETCH
+#undef TY_TAKE
+    // remaining rows (the reflected tail), from memory
+    if (own)
+    {
+        for (int j = J; j < h; j++)
+        {
+            const float a = col[j - r1];
+            const float b = (j < h1) ? col[r0 + j] : col[r2 - j];
+            t += a + b - 2 * col[j - 1];
+            u += t;
+            out[j] = u;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------
 // gradMagNorm + gradHist + addChn's exact 1/shrink resample, fused
 // (toolbox/gradientMex.cpp:254-275, 278-372, 451-509; chnsCompute.cpp:253-256,
