@@ -2015,10 +2015,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             prof(c, "k_grad_mag");
             if (rs.h % 4 == 0 && np % 4 == 0)
             {
-                // 16 bytes per lane, persistent grid (2 workgroups per CU: the 80 KB LDS table), grid-stride over (frame, strip, row quad)
+                // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
                 const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
-                const int blocks = int(std::min<int64_t>(512, (items + 255) / 256));
-                hipLaunchKernelGGL(k_grad_mag_vec, dim3(blocks), dim3(256), 0, c->stream,
+                const int blocks = int(std::min<int64_t>(256, (items + GMV_BLOCK - 1) / GMV_BLOCK));
+                hipLaunchKernelGGL(k_grad_mag_vec, dim3(blocks), dim3(GMV_BLOCK), 0, c->stream,
                     (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF);
             }
             else

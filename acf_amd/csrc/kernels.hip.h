@@ -708,11 +708,14 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
 // Measured: with the table in global memory the 4-byte lookups (every lane its own 128-byte line through a
 // 32 KB L1) were more than half of the kernel.  Same arithmetic as k_grad_mag_strip per pixel.
 #define GMV_XT 4
-__global__ void __launch_bounds__(256) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
+// GMV_BLOCK threads share one copy of the 80 KB table: one workgroup per CU, 16 waves (256 threads = 2 workgroups of 4
+// waves per CU left the loads of a wave exposed).
+#define GMV_BLOCK 1024
+__global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
     const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames)
 {
     __shared__ float acosL[GM_ACOS_N];
-    for (int i = threadIdx.x; i < GM_ACOS_N; i += 256)
+    for (int i = threadIdx.x; i < GM_ACOS_N; i += GMV_BLOCK)
     {
         acosL[i] = acosBase[i];
     }
@@ -722,7 +725,7 @@ __global__ void __launch_bounds__(256) k_grad_mag_vec(const float* __restrict__ 
     const int nStrips = (w + GMV_XT - 1) / GMV_XT;
     const int64_t perFrame = int64_t(nStrips) * h4;
     const int64_t total = perFrame * nFrames;
-    for (int64_t item = int64_t(blockIdx.x) * 256 + threadIdx.x; item < total; item += int64_t(gridDim.x) * 256)
+    for (int64_t item = int64_t(blockIdx.x) * GMV_BLOCK + threadIdx.x; item < total; item += int64_t(gridDim.x) * GMV_BLOCK)
     {
         const int f = int(item / perFrame);
         const int rem = int(item - int64_t(f) * perFrame);

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc $CNT -d $OUT -o pmc --output-format csv -- python bench.py "$@" --no-cpu-baseline --no-profile > $OUT/bench.log 2>&1 || true
+timeout 300 rocprofv3 --kernel-trace --pmc $CNT -d $OUT -o pmc --output-format csv -- python bench.py "$@" --no-cpu-baseline --no-profile > $OUT/bench.log 2>&1 || true
 ls $OUT | head
 F=$(find $OUT -name '*counter_collection.csv' | head -1)
 [ -n "$F" ] && python - "$F" <<'PY'
