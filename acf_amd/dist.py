@@ -30,6 +30,49 @@ def gather_records(rec, world, rank, dst=0):
     return torch.cat(out, dim=0) if rank == dst else None
 
 
+class RecordGather:
+    """The same gather, pipelined: buffers are allocated once (the destination is one [world*frames, ...] tensor whose
+    per-rank slices are the gather outputs, so nothing is concatenated), the collective is issued asynchronously and
+    waited for when the next one is issued (or at `finish`).  With two record buffers per rank the gather of batch k
+    overlaps the kernels of batch k+1; rank `dst` still sees every batch, in order."""
+
+    def __init__(self, frames, width, world, rank, device, dst=0, dtype=torch.int32):
+        self.world, self.rank, self.dst = world, rank, dst
+        self.rec = [torch.zeros((frames, width), dtype=dtype, device=device) for _ in range(2)]
+        self.out = [torch.zeros((world * frames, width), dtype=dtype, device=device) if rank == dst and world > 1 else None for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+
+    def buffer(self):
+        """Record buffer the next batch's export should write (its previous gather has completed)."""
+        i = self.k & 1
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.rec[i]
+
+    def submit(self):
+        """Start gathering the buffer returned by the last buffer() call."""
+        i = self.k & 1
+        self.k += 1
+        if self.world == 1:
+            return
+        frames = self.rec[i].shape[0]
+        outs = list(self.out[i].split(frames, dim=0)) if self.rank == self.dst else None
+        self.work[i] = dist.gather(self.rec[i], outs, dst=self.dst, async_op=True)
+
+    def finish(self):
+        """Wait for everything in flight; returns the last gathered tensor on dst (the record buffer itself when world == 1)."""
+        for i in (0, 1):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+        last = (self.k - 1) & 1
+        if self.world == 1:
+            return self.rec[last]
+        return self.out[last] if self.rank == self.dst else None
+
+
 def records_to_detections(rec_row, cap):
     """Decode one frame's record (numpy int32 row) into a list of (x, y, w, h, score, level)."""
     n = min(int(rec_row[0]), cap)

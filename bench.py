@@ -115,7 +115,7 @@ def main():
     import torch.distributed as dist
     from acf_amd import synth
     from acf_amd.detector import HipDetector
-    from acf_amd.dist import gather_records
+    from acf_amd.dist import RecordGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -144,17 +144,19 @@ def main():
         det.set_option("profile", 1)
     if os.environ.get("ACF_BENCH_LEVEL_MODE"):  # A/B knob (profiles/ab_levels.sh)
         det.set_option("fused_levels", int(os.environ["ACF_BENCH_LEVEL_MODE"]))
-    rec = torch.zeros((B, 1 + 6 * args.cap), dtype=torch.int32, device=dev)
+    # the only exchange of the path: fixed-capacity records gathered on rank 0, issued asynchronously so that the gather of
+    # one batch overlaps the kernels of the next (two record buffers); everything in flight is waited for inside the timed region
+    pipe = RecordGather(B, 1 + 6 * args.cap, world, rank, dev)
 
     def step():
+        rec = pipe.buffer()
         det.run(frames, B)
         det.export_detections(rec, args.cap)
-        if world > 1:
-            return gather_records(rec, world, rank)
-        return None
+        pipe.submit()
 
     for _ in range(args.warmup):
         step()
+    pipe.finish()
     torch.cuda.synchronize()
     if not args.no_profile:
         det.profile()  # drop warm-up events
@@ -163,7 +165,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gathered = step()
+        step()
+    gathered = pipe.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,7 +178,7 @@ def main():
     dt = float(tmax.item())
 
     prof = det.profile() if not args.no_profile else {}
-    counts = rec[:, 0].cpu().numpy()
+    counts = pipe.rec[(pipe.k - 1) & 1][:, 0].cpu().numpy()
     if rank == 0:
         frames_total = B * world * args.steps
         fps = frames_total / dt
@@ -220,7 +223,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, base_np, H, W)
         else:
             out["cpu_baseline"] = None
-        if gathered is not None:
+        if gathered is not None and world > 1:
             out["config"]["gathered_records"] = int(gathered.shape[0])
         print(json.dumps(out))
     det.close()

@@ -97,3 +97,58 @@ def test_record_roundtrip():
     out = records_to_detections(rec, 8)
     assert len(out) == 3 and out[2][:4] == (3, 6, 100, 100) and out[2][5] == 7
     assert np.float32(out[2][4]) == np.float32(26.0038)
+
+
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from acf_amd.dist import RecordGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, width = 3, 1 + 6 * 4
+        pipe = RecordGather(frames, width, world, rank, torch.device("cpu"))
+        seen = []
+        for batch in range(4):
+            rec = pipe.buffer()          # waits for this buffer's previous gather
+            if rank == 0 and batch >= 2:
+                seen.append(pipe.out[batch & 1].clone())  # the gather issued two batches ago has landed here
+            rec.copy_(torch.full((frames, width), 1000 * rank + 10 * batch, dtype=torch.int32) + torch.arange(frames, dtype=torch.int32)[:, None])
+            pipe.submit()
+        last = pipe.finish()
+        if rank == 0:
+            seen.append(pipe.out[0].clone())  # batch 2
+            seen.append(last.clone())         # batch 3
+            q.put(("ok", [s.numpy().tolist() for s in seen]))
+        else:
+            assert last is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_keeps_every_batch_in_order():
+    """RecordGather (bench.py's N>1 exchange): asynchronous gathers over two buffers deliver batches 0..3 complete and in
+    rank-major frame order on rank 0."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    tag, seen = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tag == "ok" and len(seen) == 4
+    for batch, g in enumerate(seen):
+        g = np.asarray(g)
+        assert g.shape == (6, 25)
+        for r in range(2):
+            for f in range(3):
+                assert (g[3 * r + f] == 1000 * r + 10 * batch + f).all(), (batch, r, f)
