@@ -456,11 +456,25 @@ int launchChns(acf_hip_ctx* c, const ChnsArgs& a, int shrink, int nFrames)
     prof(c, "k_chns");
     if (shrink == 4)
     {
-        hipLaunchKernelGGL(k_chns<4>, grid, block, 0, c->stream, a);
+        if (a.nOrients <= 6)
+        {
+            hipLaunchKernelGGL((k_chns<4, 6>), grid, block, 0, c->stream, a);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_chns<4, 12>), grid, block, 0, c->stream, a);
+        }
     }
     else
     {
-        hipLaunchKernelGGL(k_chns<2>, grid, block, 0, c->stream, a);
+        if (a.nOrients <= 6)
+        {
+            hipLaunchKernelGGL((k_chns<2, 6>), grid, block, 0, c->stream, a);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_chns<2, 12>), grid, block, 0, c->stream, a);
+        }
     }
     LAUNCHCHK(c, "k_chns");
     return ACF_HIP_OK;

@@ -1397,6 +1397,31 @@ struct ChnsArgs
 };
 
 template <int S>
+__device__ __forceinline__ void chns_load_vec(const float* __restrict__ p, float (&d)[S])
+{
+    if (S == 4)
+    {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+    else if (S == 2)
+    {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        d[0] = v.x, d[1] = v.y;
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < S; i++)
+        {
+            d[i] = p[i];
+        }
+    }
+}
+
+// MAXO: compile-time bound of nOrients (6 for every shipped model): the bin update is a select chain over MAXO registers,
+// 2 * MAXO * 3 VALU per pixel — half of the kernel's instructions at MAXO = 12.
+template <int S, int MAXO>
 __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
 {
     const int hc = a.h / S, wc = a.w / S;
@@ -1454,22 +1479,34 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
         const float* Mp = a.M + f * a.m_fs + pbase;
         const float* Sp = a.S + f * a.m_fs + pbase;
         const float* Op = a.O + f * a.m_fs + pbase;
+        // a cell's S rows of one image column are S consecutive floats at an S-float-aligned offset (h % S == 0, planes
+        // 256-byte aligned): one S-wide load per plane and column instead of S dword loads with the lanes 4*S bytes apart
+        float mraw[S][S], sraw[S][S];
+#pragma unroll
+        for (int xx = 0; xx < S; xx++)
+        {
+            chns_load_vec<S>(Mp + int64_t(xx) * a.h, mraw[xx]);
+            chns_load_vec<S>(Op + int64_t(xx) * a.h, ov[xx]);
+            if (a.doNorm)
+            {
+                chns_load_vec<S>(Sp + int64_t(xx) * a.h, sraw[xx]);
+            }
+        }
 #pragma unroll
         for (int xx = 0; xx < S; xx++)
         {
 #pragma unroll
             for (int yy = 0; yy < S; yy++)
             {
-                float m = Mp[int64_t(xx) * a.h + yy];
+                float m = mraw[xx][yy];
                 if (a.doNorm)
                 {
-                    const float s = Sp[int64_t(xx) * a.h + yy];
+                    const float s = sraw[xx][yy];
                     // vector body of gradMagNorm: M * rcp(S + norm); the scalar tail
                     // (last n%4 elements) divides — n%4 == 0 here since h % shrink == 0, shrink in {2,4}... see launch
                     m = m * (1.0f / (s + a.normConst));
                 }
                 mn[xx][yy] = m;
-                ov[xx][yy] = Op[int64_t(xx) * a.h + yy];
                 if (a.Mn)
                 {
                     a.Mn[f * a.m_fs + pbase + int64_t(xx) * a.h + yy] = m;
@@ -1502,7 +1539,6 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
     }
     if (a.histEnabled)
     {
-        constexpr int MAXO = 12;
         float H[MAXO];
 #pragma unroll
         for (int b = 0; b < MAXO; b++)
