@@ -1646,6 +1646,13 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
 
 static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes);
 
+// A/B knob: ACF_HIP_RESAMPLE_GENERIC forces the gather kernel for the image resamples (read once)
+static bool resampleGenericOnly()
+{
+    static const bool v = getenv("ACF_HIP_RESAMPLE_GENERIC") != nullptr;
+    return v;
+}
+
 namespace
 {
 // packed 8-bit source of a batch (acf_hip_pyramid_u8)
@@ -1903,7 +1910,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
                     (const ResampleDesc*)(c->d_descs + rs.descIndex));
             }
-            else if (rs.tiling.rows > 0 && !getenv("ACF_HIP_RESAMPLE_GENERIC"))
+            else if (rs.tiling.rows > 0 && !resampleGenericOnly())
             {
                 const ResampleTiling& tl = rs.tiling;
                 const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
@@ -2114,12 +2121,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
         if (nAll > 0)
         {
-            static const int occLds = getenv("ACF_HIP_LEVEL_LDS") ? atoi(getenv("ACF_HIP_LEVEL_LDS")) : 0; // experiment: cap resident workgroups per CU with an unused LDS reservation
-            if (occLds > 0 && (rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all), size_t(occLds))))
-            {
-                return rc;
-            }
-            hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nF, nAll), dim3(256), size_t(occLds), c->stream, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs, dd,
+            hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nF, nAll), dim3(256), 0, c->stream, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs, dd,
                 (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
             LAUNCHCHK(c, "k_level_all");
         }
@@ -2252,10 +2254,8 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.tailPad = cs.tailPad;
     a.tailSlab = cs.tailSlab;
     a.tailNodesLds = cs.tailNodesLds;
-    if (const char* e = getenv("ACF_HIP_CASC_DEBUG"))
-    {
-        a.debug = atoi(e);
-    }
+    static const int cascDebug = getenv("ACF_HIP_CASC_DEBUG") ? atoi(getenv("ACF_HIP_CASC_DEBUG")) : 0; // timing experiments (profiles/ab_*.sh)
+    a.debug = cascDebug;
     if (a.debug & 12)
     {
         a.debug |= 4;
@@ -3407,7 +3407,7 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
     {
         return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
     }
-    if (tl.rows > 0 && !getenv("ACF_HIP_RESAMPLE_GENERIC"))
+    if (tl.rows > 0 && !resampleGenericOnly())
     {
         // the LDS-tiled kernel the pyramid uses for its down-sampled real scales
         const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
