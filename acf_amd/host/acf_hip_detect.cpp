@@ -6,6 +6,7 @@
 //   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] ...
 //                  packed 8-bit upright frames; --stream B: batches of B frames through streamSubmit/streamCollect
 //   acf_hip_detect --convert in.acfm|in.cpb --out out.cpb                                  (model file conversion, no GPU)
+//   acf_hip_detect --dump-defaults                                                         (default Options tree, no GPU)
 //   acf_hip_detect --nms-only boxes.txt [--type maxg] [--overlap .65] [--ovrdnm min]   (host logic only, no GPU)
 //
 // Model file ("ACFHIPM1", written by acf_amd/modelio.py): text header of
@@ -96,6 +97,24 @@ int main(int argc, char** argv)
         }
         HipDetector::Options o;
         HipDetector::Classifier c;
+        if (a.count("dump-defaults"))
+        {
+            // the default Options tree (what Detector::initializeOpts / chnsCompute / chnsPyramid fill in, ACF.cpp:48-113,
+            // chnsCompute.cpp:161-203, chnsPyramid.cpp:183-215): host only
+            const auto& py = o.pPyramid;
+            const auto& ch = py.pChns;
+            std::printf("shrink %d\ncolor.enabled %d\ncolor.smooth %g\ncolor.colorSpace %s\n", ch.shrink, ch.pColor.enabled, ch.pColor.smooth, ch.pColor.colorSpace.c_str());
+            std::printf("gradMag.enabled %d\ngradMag.colorChn %d\ngradMag.normRad %d\ngradMag.normConst %g\ngradMag.full %d\n", ch.pGradMag.enabled,
+                ch.pGradMag.colorChn, ch.pGradMag.normRad, ch.pGradMag.normConst, ch.pGradMag.full);
+            std::printf("gradHist.enabled %d\ngradHist.binSize %d\ngradHist.nOrients %d\ngradHist.softBin %d\n", ch.pGradHist.enabled, ch.pGradHist.binSize,
+                ch.pGradHist.nOrients, ch.pGradHist.softBin);
+            std::printf("nPerOct %d\nnOctUp %d\nnApprox %d\npad %d %d\nminDs %d %d\nsmooth %g\n", py.nPerOct, py.nOctUp, py.nApprox, py.pad.width, py.pad.height,
+                py.minDs.width, py.minDs.height, py.smooth);
+            std::printf("stride %d\ncascThr %g\nnms.type %s\nnms.overlap %g\nnms.ovrDnm %s\n", o.stride, o.cascThr, o.pNms.type.c_str(), o.pNms.overlap, o.pNms.ovrDnm.c_str());
+            HipDetector det0;
+            std::printf("maxDetectionCount 10\ngood %d\n", det0.good() ? 1 : 0);
+            return 0;
+        }
         if (a.count("convert"))
         {
             // acf_hip_detect --convert in.{acfm,cpb} --out out.cpb : host only

@@ -204,3 +204,23 @@ def test_cli_packed_u8_and_stream(cli, oracle, tmp_path, mode):
             assert got[f] == want, f
         total += len(want)
     assert total > 0
+
+
+def test_default_options_match_the_references_own_tests(cli):
+    """The only values the reference's test-suite pins for this path are the default parameters
+    (src/test/test-acf-api.cpp:354-371 testChnsDefault, :444-452 pyramid defaults): acf::HipDetector::Options
+    starts from the same ones.  Known, deliberate difference: the reference leaves `lambdas` unset (estimated from the
+    image, chnsPyramid.cpp:341-374) — the device path wants them given, so Options carries the toolbox's values."""
+    p = run(cli, ["--dump-defaults"])
+    kv = dict(line.split(" ", 1) for line in p.stdout.strip().splitlines())
+    want = {
+        "shrink": "4", "color.enabled": "1", "color.smooth": "1", "color.colorSpace": "luv",
+        "gradMag.enabled": "1", "gradMag.colorChn": "0", "gradMag.normRad": "5", "gradMag.full": "0",
+        "gradHist.enabled": "1", "gradHist.binSize": "0",  # unset in the reference = shrink (chnsCompute.cpp:186-188); 0 means that here
+        "gradHist.nOrients": "6", "gradHist.softBin": "0",
+        "nPerOct": "8", "nOctUp": "0", "nApprox": "7", "pad": "0 0", "minDs": "16 16", "smooth": "1",
+        "good": "0",  # a default-constructed detector has no model (ACF.h:59, good() false)
+    }
+    for k, v in want.items():
+        assert kv[k] == v, (k, kv[k], v)
+    assert float(kv["gradMag.normConst"]) == 0.005  # toolbox default (chnsCompute.m)
