@@ -210,3 +210,44 @@ def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
         got, gh = det.detections(f)
         assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes()
     det.close()
+
+
+def test_detector_pool_concurrent_contexts_match_single(oracle):
+    """bench.py's deployment: several contexts on their own streams working on different batches at the same time.
+    Every context must return exactly what a lone context returns for the same frames (no shared mutable state)."""
+    import torch
+    from acf_amd.detector import DetectorPool, HipDetector
+    H, W, kind, d_in, kw = CONFIGS["face80_vga"]
+    model = synth.make_model(seed=3, **kw)
+    nF, C = 4, 3
+    batches = [np.stack([synth.make_frame(200 + 10 * c + i, H, W, kind) for i in range(nF)]) for c in range(C)]
+    ref = HipDetector(model, H, W, d_in, max_batch=nF, max_hits=1 << 14)
+    want = []
+    for b in batches:
+        ref.run(torch.from_numpy(b).cuda())
+        want.append([ref.detections(f)[0] for f in range(nF)])
+    ref.close()
+    pool = DetectorPool(C, model, H, W, d_in, max_batch=nF, max_hits=1 << 14)
+    dev_batches = [torch.from_numpy(b).cuda() for b in batches]
+    torch.cuda.synchronize()
+    for rep in range(3):  # several rounds in flight before anything is read back
+        for (det, stream), x in zip(pool, dev_batches):
+            with torch.cuda.stream(stream):
+                det.run(x)
+    pool.synchronize()
+    total = 0
+    for c, (det, _) in enumerate(pool):
+        for f in range(nF):
+            got = det.detections(f)[0]
+            assert len(got) == len(want[c][f])
+            for k in ("x", "y", "w", "h", "scale"):
+                assert np.array_equal(got[k], want[c][f][k]), (c, f, k)
+            assert np.array_equal(bits(got["score"]), bits(want[c][f]["score"]))
+            total += len(got)
+    assert total > 0
+    # and the oracle agrees with the lone context on one of them
+    plan = oracle.Plan(model, H, W, d_in)
+    pyr, _, _ = oracle.chns_pyramid(plan, batches[1][2])
+    odet, _ = oracle.detect(plan, pyr)
+    assert np.array_equal(bits(odet["score"]), bits(want[1][2]["score"]))
+    pool.close()
