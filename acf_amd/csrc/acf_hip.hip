@@ -1498,6 +1498,12 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                 {
                     c->fusedOk = false; // more source rows than LevelWindow's registers hold (ratio beyond 2^(1/2))
                 }
+                if (mode == LM_DU || mode == LM_UD)
+                {
+                    // one axis up, the other down: cannot happen with getScales' isotropic scales (an exhaustive scan of
+                    // 64..330 x 64..330 frames finds none), so the fused kernel is not instantiated for it
+                    c->fusedOk = false;
+                }
                 ai++;
             }
             fusedJobs.push_back({ R * 8 + mode, j });
@@ -2139,8 +2145,6 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     {                                                 \
         case LM_REAL: LV_LAUNCH(RR, LM_REAL); break;  \
         case LM_DD: LV_LAUNCH(RR, LM_DD); break;      \
-        case LM_DU: LV_LAUNCH(RR, LM_DU); break;      \
-        case LM_UD: LV_LAUNCH(RR, LM_UD); break;      \
         default: LV_LAUNCH(RR, LM_UU); break;         \
     }
             switch (g.R)

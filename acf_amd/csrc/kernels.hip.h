@@ -2376,7 +2376,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     case ACF_LEVEL_KIND(RR, MM):                                                                                  \
         level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock);   \
         break;
-#define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_DU) LV_CASE(RR, LM_UD) LV_CASE(RR, LM_UU)
+#define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_UU)
     switch (J.kind)
     {
         LV_CASES(1)
