@@ -188,6 +188,7 @@ def load():
         "acf_hip_op_acf_detect1": ([ctx, fp, C.c_int, C.c_int, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_op_acf_detect1_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_thrs_u8": ([fp, C.c_int, C.c_void_p], C.c_int),
+        "acf_hip_op_evaluate": ([ctx, fp, C.c_int, C.c_int, C.c_int, C.c_double, fp], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -207,7 +208,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",
     "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_op_gradient_hist",
-    "acf_hip_op_im_resample", "acf_hip_op_acf_detect1", "acf_hip_op_acf_detect1_u8", "acf_hip_thrs_u8",
+    "acf_hip_op_im_resample", "acf_hip_op_acf_detect1", "acf_hip_op_acf_detect1_u8", "acf_hip_thrs_u8", "acf_hip_op_evaluate",
 ]
 
 

@@ -3637,4 +3637,37 @@ static int opAcfDetect1(acf_hip_ctx* c, const void* chns, bool u8, int hP, int w
     return rc;
 }
 
+int acf_hip_op_evaluate(acf_hip_ctx* c, const float* chns, int hP, int wP, int nChns, double cascThr, float* score)
+{
+    OP_PROLOGUE(c);
+    if (!c->hasModel)
+    {
+        return fail(c, ACF_HIP_E_NOMODEL, "op_evaluate: set_model first");
+    }
+    const acf_hip_params& p = c->p;
+    const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
+    if (!chns || !score || nChns <= 0 || hP < mH || wP < mW)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_evaluate: the buffer must hold at least one window");
+    }
+    Scratch s;
+    const size_t n = size_t(nChns) * hP * wP;
+    float* dC = s.upload(chns, n);
+    uint32_t* dF = s.upload(c->fids.data(), c->fids.size());
+    float* dT = s.upload(c->thrs.data(), c->thrs.size());
+    float* dH = s.upload(c->hs.data(), c->hs.size());
+    uint32_t* dCh = c->child.empty() ? nullptr : s.upload(c->child.data(), c->child.size());
+    float* dS = s.alloc<float>(1);
+    if (!dC || !dF || !dT || !dH || !dS || (p.treeDepth == 0 && !dCh))
+    {
+        return fail(c, ACF_HIP_E_HIP, "op_evaluate: allocation");
+    }
+    hipLaunchKernelGGL(k_evaluate_window, dim3(1), dim3(64), 0, c->stream, (const float*)dC, hP, wP, mH, mW, (const uint32_t*)dF, (const float*)dT,
+        (const float*)dH, (const uint32_t*)dCh, p.nTrees, p.nTreeNodes, p.treeDepth, float(cascThr), dS);
+    LAUNCHCHK(c, "k_evaluate_window");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(score, dS, sizeof(float), hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
 } // extern "C"

@@ -4041,6 +4041,55 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
     }
 }
 
+// Detector::evaluate(const MatP&, ...) (acfDetect1.cpp:337-342): the score of the single window at (0, 0), trees added in
+// order until h <= cascThr (the reference sets cascThr = 0 for this call) — evaluate(), :113-138, with getChild (:100-107) or
+// the child-pointer walk (:146-155).  One thread: this is a probe, not a hot path.
+__global__ void k_evaluate_window(const float* __restrict__ chns, int hP, int wP, int mH, int mW, const uint32_t* __restrict__ fids,
+    const float* __restrict__ thrs, const float* __restrict__ hs, const uint32_t* __restrict__ child, int nTrees, int nTreeNodes, int depth,
+    float cascThr, float* __restrict__ score)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+    {
+        return;
+    }
+    const int area = hP * wP;
+    float h = 0.f;
+    for (int t = 0; t < nTrees; t++)
+    {
+        const uint32_t offset = uint32_t(t) * uint32_t(nTreeNodes);
+        uint32_t k = offset, k0 = depth == 0 ? k : 0u;
+        if (depth > 0)
+        {
+            for (int i = 0; i < depth; i++)
+            {
+                const uint32_t f = fids[k];
+                const uint32_t z = f / uint32_t(mW * mH), cc = (f / uint32_t(mH)) % uint32_t(mW), rr = f % uint32_t(mH); // cids[], :390-406
+                const float ftr = chns[z * uint32_t(area) + cc * uint32_t(hP) + rr];
+                k = (ftr < thrs[k]) ? 1u : 2u;
+                k0 = k += k0 * 2u;
+                k += offset;
+            }
+        }
+        else
+        {
+            while (child[k])
+            {
+                const uint32_t f = fids[k];
+                const uint32_t z = f / uint32_t(mW * mH), cc = (f / uint32_t(mH)) % uint32_t(mW), rr = f % uint32_t(mH);
+                const float ftr = chns[z * uint32_t(area) + cc * uint32_t(hP) + rr];
+                k = (ftr < thrs[k]) ? 1u : 0u;
+                k0 = k = child[k0] - k + offset;
+            }
+        }
+        h += hs[k];
+        if (h <= cascThr)
+        {
+            break;
+        }
+    }
+    *score = h;
+}
+
 // Sort each frame's hits into the reference's order (level, then c, then r:
 // ACF.cpp:326-329, acfDetect1.cpp:86-96) by rank counting, and map them to
 // image boxes (ACF.cpp:302-312).  Hit lists are small (<= maxHits), the keys

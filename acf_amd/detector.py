@@ -253,6 +253,14 @@ class HipDetector:
                                                      hits.ctypes.data_as(C.POINTER(capi.Hit)), cap, C.byref(n)))
         return hits[:n.value].copy()
 
+    def op_evaluate(self, chns, cascThr=0.0):
+        """Detector::evaluate: score of the window at (0, 0) of [nC][wP][hP] channels (acfDetect1.cpp:337-342)."""
+        chns = np.ascontiguousarray(chns, dtype=np.float32)
+        nC, wP, hP = chns.shape
+        out = np.zeros(1, np.float32)
+        self._chk(self.lib.acf_hip_op_evaluate(self.ctx, capi.fptr(chns), hP, wP, nC, float(cascThr), capi.fptr(out)))
+        return out[0]
+
 
 class DetectorPool:
     """N detector contexts on one GPU, each with its own HIP stream, plan and buffers; batches are handed to them in turn.

@@ -694,6 +694,28 @@ void HipDetector::detect1(const float* f32, const uint8_t* u8, int rows, int col
     }
 }
 
+float HipDetector::evaluate(const MatP& chns, int, const Size&, int)
+{
+    if (!m_good)
+    {
+        throw Exception(ACF_HIP_E_NOMODEL, "evaluate: no model");
+    }
+    if (m_dirty)
+    {
+        acf_hip_params p;
+        fillParams(p);
+        check(m_api->acf_hip_set_model(m_ctx, &p), "acf_hip_set_model");
+        m_dirty = false;
+        m_planH = 0;
+    }
+    const auto& ch = opts.pPyramid.pChns;
+    const int nColor = ch.pColor.enabled ? (ch.pColor.colorSpace == "gray" ? 1 : 3) : 0;
+    const int nC = nColor + (ch.pGradMag.enabled ? 1 : 0) + (ch.pGradHist.enabled ? ch.pGradHist.nOrients : 0);
+    float score = 0.f;
+    check(m_api->acf_hip_op_evaluate(m_ctx, chns.data(), chns.cols(), chns.rows() / nC, nC, 0.0, &score), "acf_hip_op_evaluate");
+    return score;
+}
+
 void HipDetector::getScales(int nPerOct, int nOctUp, const Size& minDs, int shrink, const Size& sz,
     std::vector<double>& scales, std::vector<Size2d>& scaleshw)
 {

@@ -259,6 +259,9 @@ public:
     void acfDetect1(const MatP& chns, int shrink, const Size& modelDsPad, int stride, double cascThr, DetectionVec& objects);
     // the same on uint8_t channels ([nChns * wP rows][hP cols] bytes), the CV_8UC1 branch of allocDetector (acfDetect1.cpp:187-192)
     void acfDetect1(const uint8_t* chnsU8, int rows, int cols, DetectionVec& objects);
+    // Detector::evaluate (ACF.h:543-544, acfDetect1.cpp:337-342): score of the window at (0,0) of a fused channel buffer, trees added
+    // until the score drops to 0 or below (the reference fixes cascThr = 0 for this probe)
+    float evaluate(const MatP& chns, int shrink, const Size& modelDsPad, int stride);
     // bbNms.cpp:229-304 (max / maxg / none), ObjectDetector.cpp:28-44
     static int bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, DetectionVec& bbs);
     void prune(RectVec& objects, RealVec& scores) const;

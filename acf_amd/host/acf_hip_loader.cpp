@@ -75,6 +75,7 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_op_acf_detect1)
     ACF_HIP_FN(acf_hip_op_acf_detect1_u8)
     ACF_HIP_FN(acf_hip_thrs_u8)
+    ACF_HIP_FN(acf_hip_op_evaluate)
 #undef ACF_HIP_FN
     if (g_api.acf_hip_abi_version() != ACF_HIP_ABI_VERSION)
     {

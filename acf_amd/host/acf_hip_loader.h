@@ -59,6 +59,7 @@ struct Api
     ACF_HIP_FN(acf_hip_op_acf_detect1)
     ACF_HIP_FN(acf_hip_op_acf_detect1_u8)
     ACF_HIP_FN(acf_hip_thrs_u8)
+    ACF_HIP_FN(acf_hip_op_evaluate)
 #undef ACF_HIP_FN
 };
 

@@ -312,6 +312,10 @@ ACF_HIP_API int acf_hip_op_acf_detect1(acf_hip_ctx* ctx, const float* chns, int 
  * loader does (ACFIOArchive.h:96-99, acf_hip_thrs_u8). */
 ACF_HIP_API int acf_hip_op_acf_detect1_u8(acf_hip_ctx* ctx, const uint8_t* chns, int hP, int wP, int nChns, const uint8_t* thrsU8,
     acf_hip_hit* out, int cap, int* count);
+/* Detector::evaluate(const MatP&, shrink, modelDsPad, stride) (ACF.h:543-544, acfDetect1.cpp:337-342): score of the single
+ * window at (0,0) of one host channel buffer [nChns][wP][hP]; trees are added until the score is <= cascThr (the reference
+ * passes 0 here) and the score reached is returned, whether or not the window would be a detection. */
+ACF_HIP_API int acf_hip_op_evaluate(acf_hip_ctx* ctx, const float* chns, int hP, int wP, int nChns, double cascThr, float* score);
 /* thrs.convertTo(thrsU8, CV_8UC1, 255.0f) (ACFIOArchive.h:96-99): host only, no context. */
 ACF_HIP_API int acf_hip_thrs_u8(const float* thrs, int n, uint8_t* out);
 

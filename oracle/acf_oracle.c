@@ -1605,6 +1605,28 @@ ACFO_API int acfo_acf_detect1(const void* chns, int u8, const void* thrs, int hP
     return n;
 }
 
+/* Detector::evaluate(const MatP&, shrink, modelDsPad, stride) — T/acfDetect1.cpp:337-342: createDetector, cascThr = 0,
+ * evaluate(0, 0): the score reached by the window at the origin (trees added until h <= cascThr). */
+ACFO_API float acfo_evaluate(const float* chns, int hP, int wP, int nChns, const acf_hip_params* p, float cascThr)
+{
+    const int mW = p->modelDsPad_w / p->shrink, mH = p->modelDsPad_h / p->shrink;
+    uint32_t* cids = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)nChns * mW * mH);
+    int m = 0, area = wP * hP;
+    for (int z = 0; z < nChns; z++)
+    {
+        for (int c = 0; c < mW; c++)
+        {
+            for (int r = 0; r < mH; r++)
+            {
+                cids[m++] = (uint32_t)(z * area + c * hP + r);
+            }
+        }
+    }
+    const float h = evaluate_window(chns, 0, cids, p, p->thrs, cascThr);
+    free(cids);
+    return h;
+}
+
 /* Mean number of trees evaluated per window (diagnostic for the synthetic
  * model calibration; no reference counterpart). */
 ACFO_API double acfo_mean_trees(const float* chns, int hP, int wP, int nChns, const acf_hip_params* p)

@@ -69,6 +69,8 @@ def lib():
         o.acfo_acf_detect1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, P,
                                        C.POINTER(capi.Hit), C.c_int, C.c_int]
         o.acfo_acf_detect1.restype = C.c_int
+        o.acfo_evaluate.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, C.c_float]
+        o.acfo_evaluate.restype = C.c_float
         o.acfo_thrs_u8.argtypes = [fp, C.c_int, C.c_void_p]
         o.acfo_thrs_u8.restype = None
         o.acfo_mean_trees.argtypes = [fp, C.c_int, C.c_int, C.c_int, P]

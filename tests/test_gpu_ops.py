@@ -217,6 +217,29 @@ def test_acf_detect1(dev, oracle, depth, nTrees, tiles):
     assert np.array_equal(bits(got["score"]), bits(want["score"]))
 
 
+@pytest.mark.parametrize("depth", [2, 0, 3])
+def test_evaluate_single_window(dev, oracle, depth):
+    """Detector::evaluate (acfDetect1.cpp:337-342): the score of the window at (0,0) with cascThr = 0 — the value at which
+    the tree loop stops, also for windows that are not detections."""
+    nC, wP, hP = 10, 9, 7
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=128, cascThr=-1.0, treeDepth=depth)
+    m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
+    m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
+    dev.set_model(m)
+    params, keep = capi.make_params(m)
+    seen = set()
+    for k, (lo, hi) in enumerate([(-0.25, 0.2), (-0.05, 0.3), (0.0, 0.3), (-0.3, 0.0)]):
+        m["hs"] = rnd(6 + k, m["hs"].shape, lo, hi)
+        dev.set_model(m)
+        params, keep = capi.make_params(m)
+        chns = rnd(50 + k, (nC, wP, hP), 0.0, 0.6)
+        got = dev.op_evaluate(chns)
+        want = oracle.lib().acfo_evaluate(oracle.F(chns), hP, wP, nC, C.byref(params), np.float32(0.0))
+        assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32), (k, got, want)
+        seen.add(bool(want > 0))
+    assert seen == {True, False}  # both an early stop and a full pass were exercised
+
+
 @pytest.mark.parametrize("explicit_thrs", [False, True])
 @pytest.mark.parametrize("depth", [2, 0, 3])
 def test_acf_detect1_u8(dev, oracle, depth, explicit_thrs):
