@@ -533,12 +533,19 @@ void HipDetector::computePyramid(const MatP& Ip, Pyramid& P)
     chnsPyramid(Ip, &opts.pPyramid, P, true);
 }
 
-int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& P, bool)
+int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& P, bool, const MatLoggerType& logger)
 {
     if (pPyramid && pPyramid != &opts.pPyramid)
     {
         opts.pPyramid = *pPyramid;
         m_dirty = true;
+    }
+    if (logger && !m_taps)
+    {
+        // keep the per-stage planes (one more full-resolution write per real scale); takes effect at the next plan
+        check(m_api->acf_hip_set_option(m_ctx, "taps", 1), "acf_hip_set_option(taps)");
+        m_taps = true;
+        m_planH = 0;
     }
     ensurePlan(I.cols(), I.rows(), I.channels(), 1);
     // upload + pyramid only
@@ -567,6 +574,58 @@ int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Py
         check(m_api->acf_hip_read_level(m_ctx, 0, int(i), P.data[i][0].data()), "acf_hip_read_level");
     }
     P.deviceTag = ++m_generation;
+    if (logger)
+    {
+        const auto& ch = opts.pPyramid.pChns;
+        const int d = ch.pColor.colorSpace == "gray" ? 1 : 3;
+        const int nColor = ch.pColor.enabled ? d : 0;
+        const int shrink = ch.shrink;
+        int ordinal = 0;
+        auto tag = [](const char* name, int cols, int rows) { return std::string(name) + ":" + std::to_string(cols) + "x" + std::to_string(rows); };
+        for (size_t i = 0; i < m_levels.size(); i++)
+        {
+            const acf_hip_level& l = m_levels[i];
+            if (!l.isReal)
+            {
+                continue;
+            }
+            const int h1 = l.hC * shrink, w1 = l.wC * shrink; // the real scale's image: planes are [w1 rows][h1 cols]
+            MatP sm(w1, h1, d), one(w1, h1, 1);
+            check(m_api->acf_hip_read_tap(m_ctx, 0, ACF_HIP_TAP_SMOOTHED, ordinal, sm.data(), int64_t(sm.numel())), "acf_hip_read_tap");
+            static const char* luv[3] = { "L", "U", "V" };
+            for (int z = 0; z < d; z++)
+            {
+                MatP plane(w1, h1, 1, sm[z]);
+                logger(plane, tag(d == 3 ? luv[z] : "L", h1, w1));
+            }
+            if (ch.pGradMag.enabled || ch.pGradHist.enabled)
+            {
+                for (const auto& t : { std::make_pair(int(ACF_HIP_TAP_M), "M"), std::make_pair(int(ACF_HIP_TAP_MNORM), "Mnorm"), std::make_pair(int(ACF_HIP_TAP_O), "O") })
+                {
+                    check(m_api->acf_hip_read_tap(m_ctx, 0, t.first, ordinal, one.data(), int64_t(one.numel())), "acf_hip_read_tap");
+                    logger(one, tag(t.second, h1, w1));
+                }
+            }
+            if (ch.pGradHist.enabled)
+            {
+                // cv::hconcat of the nOrients histogram planes (chnsCompute.cpp:322-329): [wC rows][nOrients * hC cols]
+                const int nO = ch.pGradHist.nOrients;
+                MatP raw(l.wC * m_nChns, l.hC, 1);
+                check(m_api->acf_hip_read_tap(m_ctx, 0, ACF_HIP_TAP_CHNS, int(i), raw.data(), int64_t(raw.numel())), "acf_hip_read_tap");
+                const int first = nColor + (ch.pGradMag.enabled ? 1 : 0);
+                MatP hc(l.wC, nO * l.hC, 1);
+                for (int b = 0; b < nO; b++)
+                {
+                    for (int r = 0; r < l.wC; r++)
+                    {
+                        std::memcpy(hc.data() + (size_t(r) * nO + b) * l.hC, raw.data() + (size_t(first + b) * l.wC + r) * l.hC, sizeof(float) * l.hC);
+                    }
+                }
+                logger(hc, tag("H", nO * l.hC, l.wC));
+            }
+            ordinal++;
+        }
+    }
     return 0;
 }
 

@@ -250,7 +250,11 @@ public:
     static void pinnedFree(void* p);
 
     void computePyramid(const MatP& Ip, Pyramid& P); // ACF.cpp:147-159
-    int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false); // chnsPyramid.cpp:160-456
+    // Detector::MatLoggerType (ACF.h:57): called with one plane and a tag "<name>:<cols>x<rows>"
+    using MatLoggerType = std::function<int(const MatP&, const std::string&)>;
+    // chnsPyramid.cpp:160-456.  With a logger, every real scale reports the planes chnsCompute hands to its logger, in its order
+    // and with its tags (chnsCompute.cpp:241-250 L,U,V; gradientMag.cpp:119-123 M; chnsCompute.cpp:285-300 Mnorm, O; :322-329 H).
+    int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false, const MatLoggerType& logger = {});
     // chnsPyramid.cpp:461-529; sz = {width = image height, height = image width}
     static void getScales(int nPerOct, int nOctUp, const Size& minDs, int shrink, const Size& sz,
         std::vector<double>& scales, std::vector<Size2d>& scaleshw);
@@ -294,6 +298,7 @@ private:
     int m_nChns = 0;
     std::vector<float> m_upright; // scratch for operator()(interleaved)
     int m_streamCap = 0, m_streamPix = -1, m_streamStride = 0;
+    bool m_taps = false; // "taps" option on: per-stage planes stay readable (needed by the logger)
     void* m_pin = nullptr; // pinned scratch of operator()(packed 8-bit)
     size_t m_pinBytes = 0;
 };

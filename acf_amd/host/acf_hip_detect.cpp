@@ -236,6 +236,22 @@ int main(int argc, char** argv)
                 acf::MatP Ip(rows, cols, ch, frames.data() + per * size_t(f));
                 HipDetector::RectVec objs;
                 HipDetector::RealVec scores;
+                if (a.count("log-taps"))
+                {
+                    // chnsPyramid with a MatLoggerType: print every tag with an FNV-1a hash of the plane's bytes
+                    HipDetector::Pyramid P;
+                    det.chnsPyramid(Ip, nullptr, P, true, [](const acf::MatP& m, const std::string& t) {
+                        uint64_t hsh = 1469598103934665603ull;
+                        const unsigned char* b = reinterpret_cast<const unsigned char*>(m.data());
+                        for (size_t i = 0; i < m.numel() * 4; i++)
+                        {
+                            hsh = (hsh ^ b[i]) * 1099511628211ull;
+                        }
+                        std::printf("tap %s %016llx\n", t.c_str(), static_cast<unsigned long long>(hsh));
+                        return 0;
+                    });
+                    continue;
+                }
                 if (a.count("via-pyramid"))
                 {
                     // computePyramid -> host Pyramid -> operator()(Pyramid) on a *copy* (forces the per-level path)

@@ -224,3 +224,39 @@ def test_default_options_match_the_references_own_tests(cli):
     for k, v in want.items():
         assert kv[k] == v, (k, kv[k], v)
     assert float(kv["gradMag.normConst"]) == 0.005  # toolbox default (chnsCompute.m)
+
+
+def _fnv1a(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+def test_chns_pyramid_logger_taps(cli, oracle, tmp_path):
+    """chnsPyramid(..., MatLoggerType): every real scale reports L,U,V / M / Mnorm / O / H with the reference's tags
+    (chnsCompute.cpp:241-250,285-300,322-329; gradientMag.cpp:119-123) and the oracle's bytes."""
+    H, W = 96, 128
+    model = synth.make_model(seed=3, name="TINY", nTrees=32)
+    frame = synth.make_frame(41, H, W, "luv")
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(frame.tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", "1", "--luv", "--log-taps"])
+    got = [tuple(l.split()[1:]) for l in p.stdout.splitlines() if l.startswith("tap ")]
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, taps, chns = oracle.chns_pyramid(plan, frame, want_taps=True, want_chns=True)
+    want = []
+    nO = model["nOrients"]
+    for k, lvl in enumerate(plan.real):
+        t = taps[k]
+        w1, h1 = t["M"].shape
+        for z, name in enumerate("LUV"):
+            want.append(("%s:%dx%d" % (name, h1, w1), "%016x" % _fnv1a(np.ascontiguousarray(t["smoothed"][z]).tobytes())))
+        for name in ("M", "Mnorm", "O"):
+            want.append(("%s:%dx%d" % (name, h1, w1), "%016x" % _fnv1a(np.ascontiguousarray(t[name]).tobytes())))
+        c = chns[lvl]                                   # [nChns][wC][hC] raw channels of the real level
+        hc = np.concatenate([c[4 + b] for b in range(nO)], axis=1)  # cv::hconcat of the histogram planes
+        want.append(("H:%dx%d" % (hc.shape[1], hc.shape[0]), "%016x" % _fnv1a(np.ascontiguousarray(hc).tobytes())))
+    assert len(want) >= 7 and got == want
