@@ -218,6 +218,8 @@ public:
     void setIsTranspose(bool flag) { m_isTranspose = flag; }
     bool getIsTranspose() const { return m_isTranspose; }
     void setDoParallel(bool) {} // scales/frames always run concurrently on the device
+    void setIsRowMajor(bool flag) { m_isRowMajor = flag; } // ACF.h:588-595: stored for callers that orient the window size by it
+    bool getIsRowMajor() const { return m_isRowMajor; }
     Size getWindowSize() const { return opts.modelDs; }
     int acfModify(const Modify& params); // acfModify.cpp:83-152
 
@@ -289,7 +291,7 @@ private:
     const hip::Api* m_api = nullptr;
     acf_hip_ctx* m_ctx = nullptr;
     bool m_good = false, m_dirty = true;
-    bool m_doNms = false, m_isLuv = false, m_isTranspose = false;
+    bool m_doNms = false, m_isLuv = false, m_isTranspose = false, m_isRowMajor = false;
     size_t m_maxDetectionCount = 10;
     double m_detectionScorePruneRatio = 0.0;
     int m_planH = 0, m_planW = 0, m_planD = 0, m_planBatch = 0;
