@@ -79,22 +79,43 @@ def pmc_traffic(kernel, batch):
 
 
 def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
-    """Oracle (oracle/acf_oracle.c, the CPU restatement) timed single-threaded on a
-    bounded sample of the same workload.  Reported baseline, not the thing measured."""
+    """Oracle (oracle/acf_oracle.c, the CPU restatement) timed on a bounded sample of the same workload: first one frame
+    single-threaded, then for `budget_s` seconds on every host core with frames dealt to threads (the reference
+    parallelises over images with one detector per thread, src/app/acf/acf.cpp:255-320; the C calls release the GIL).
+    Reported baseline, not the thing measured."""
+    import threading
     from oracle import binding as ob
     plan = ob.Plan(model, H, W, 3)
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        f = frames_np[n % len(frames_np)]
-        pyr, _, _ = ob.chns_pyramid(plan, f)
+
+    def one(i):
+        pyr, _, _ = ob.chns_pyramid(plan, frames_np[i % len(frames_np)])
         ob.detect(plan, pyr)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 200:
-            break
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic 1080p LUV frames, FACE80 synthetic model, oracle/acf_oracle.c (gcc -O2), 1 thread, %.1f s" % (n, dt)}
+
+    t0 = time.perf_counter()
+    one(0)  # also initialises the oracle's lazily built tables before any thread starts
+    single = 1.0 / (time.perf_counter() - t0)
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    done = [0] * cores
+    stop = time.perf_counter() + budget_s
+
+    def work(k):
+        i = k
+        while time.perf_counter() < stop:
+            one(i)
+            i += cores
+            done[k] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = sum(done)
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": single,
+            "sample": "%d synthetic 1080p LUV frames, FACE80 synthetic model, oracle/acf_oracle.c (gcc -O2), %d threads (one frame each at a time), %.1f s"
+                      % (n, cores, dt)}
 
 
 def main():
