@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libacf_hip.so")
 
 OK = 0
 CS_GRAY, CS_RGB, CS_LUV, CS_HSV, CS_ORIG = 0, 1, 2, 3, 4
-TAP_IMAGE, TAP_SMOOTHED, TAP_M, TAP_O, TAP_S, TAP_MNORM, TAP_CHNS = range(7)
+TAP_IMAGE, TAP_SMOOTHED, TAP_M, TAP_O, TAP_S, TAP_MNORM, TAP_CHNS, TAP_LDCF = range(8)
 
 
 class Params(C.Structure):
@@ -58,6 +58,8 @@ class Params(C.Structure):
         ("nOrients", C.c_int32),
         ("softBin", C.c_int32),
         ("isLuv", C.c_int32),
+        ("ldcfK", C.c_int32),
+        ("ldcfFilters", C.POINTER(C.c_float)),
     ]
 
 
@@ -116,6 +118,12 @@ def make_params(model):
         setattr(p, k, int(model[k]))
     for k in ("cascThr", "smooth", "colorSmooth", "normConst"):
         setattr(p, k, float(model[k]))
+    filt = model.get("ldcfFilters")
+    if filt is not None and int(model.get("ldcfK", 0)) > 0:
+        filt = np.ascontiguousarray(filt, dtype=np.float32)  # [k][nChns][5 (dx)][5 (dy)]
+        keep["ldcfFilters"] = filt
+        p.ldcfK = int(model["ldcfK"])
+        p.ldcfFilters = filt.ctypes.data_as(C.POINTER(C.c_float))
     lam = model.get("lambdas") or []
     p.nLambdas = len(lam)
     for i, v in enumerate(lam):

@@ -98,6 +98,14 @@ struct acf_hip_ctx
     acf_hip_params p{};
     std::vector<uint32_t> fids, child;
     std::vector<float> thrs, hs;
+    // LDCF post-stage (acf_hip_params::ldcfK > 0): filters, level table of the LDCF pyramid, per-level resample descriptors
+    std::vector<float> ldcfFilters;
+    std::vector<acf_hip_level> ldcfLevels;
+    int ldcfDescBase = 0;
+    int64_t ldcfFloats = 0, ldcfTmpFloats = 0;
+    float* d_ldcfFilt = nullptr;
+    float* d_ldcfTmp = nullptr;
+    float* d_ldcfPyr = nullptr;
 
     Plan plan;
     int maxBatch = 0, maxHits = 0, lastBatch = 0;
@@ -250,6 +258,7 @@ void freeAll(acf_hip_ctx* c)
     c->d_lTable = c->d_acos = nullptr;
     c->d_dump = nullptr;
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
+    c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->lastFrames = nullptr;
     c->pyramidValid = c->detectValid = false;
 }
@@ -833,8 +842,23 @@ int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
     {
         return fail(c, ACF_HIP_E_UNSUPPORTED, "set_model: nOrients must be 1..12");
     }
+    const bool ldcf = p->ldcfK > 0 && p->ldcfFilters;
+    if (ldcf && (p->ldcfK > 16 || p->modelDsPad_h % (2 * p->shrink) || p->modelDsPad_w % (2 * p->shrink)))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_model: LDCF needs 1..16 filters per channel and modelDsPad divisible by 2*shrink");
+    }
     const size_t n = size_t(p->nTrees) * p->nTreeNodes;
     c->p = *p;
+    c->ldcfFilters.clear();
+    c->p.ldcfK = ldcf ? p->ldcfK : 0;
+    c->p.ldcfFilters = nullptr;
+    if (ldcf)
+    {
+        const int dcol = p->colorSpace == ACF_HIP_CS_GRAY ? 1 : 3;
+        const int nC = (p->colorEnabled ? dcol : 0) + (p->gradMagEnabled ? 1 : 0) + (p->gradHistEnabled ? p->nOrients : 0);
+        c->ldcfFilters.assign(p->ldcfFilters, p->ldcfFilters + size_t(p->ldcfK) * nC * 25);
+        c->p.ldcfFilters = c->ldcfFilters.data();
+    }
     c->fids.assign(p->fids, p->fids + n);
     c->thrs.assign(p->thrs, p->thrs + n);
     c->hs.assign(p->hs, p->hs + n);
@@ -858,6 +882,15 @@ int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
     }
     return ACF_HIP_OK;
 }
+
+// The cascade code reads the cell size from c->p.shrink; the LDCF cascade works on cells of 2*shrink pixels.
+struct ShrinkScope
+{
+    acf_hip_ctx* c;
+    int saved;
+    ShrinkScope(acf_hip_ctx* ctx, int factor) : c(ctx), saved(ctx->p.shrink) { c->p.shrink = saved * factor; }
+    ~ShrinkScope() { c->p.shrink = saved; }
+};
 
 // Build the cascade tables for a list of level geometries (hP, wP) into the
 // context.  Shared by acf_hip_plan and acf_hip_op_acf_detect1.
@@ -1552,6 +1585,55 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             return rc;
         }
     }
+    // ---- LDCF post-stage (acf_hip_params::ldcfK): level table of the filtered, halved pyramid + one resample per level
+    c->ldcfLevels.clear();
+    c->ldcfFloats = c->ldcfTmpFloats = 0;
+    if (p.ldcfK > 0)
+    {
+        const int shrink2 = 2 * p.shrink, nCk = pl.nChns * p.ldcfK;
+        c->ldcfDescBase = int(c->h_descs.size());
+        int64_t off = 0;
+        for (size_t i = 0; i < pl.levels.size(); i++)
+        {
+            acf_hip_level l = pl.levels[i];
+            const acf_hip_level& s0 = pl.levels[i];
+            l.hP = l.hC = int(std::floor(0.5 * s0.hP + 0.5)); // imResample(C, .5): round(.5 * size)
+            l.wP = l.wC = int(std::floor(0.5 * s0.wP + 0.5));
+            if (l.hP < 1 || l.wP < 1)
+            {
+                return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: LDCF level smaller than one cell");
+            }
+            l.nWinR = std::max(0, int(std::ceil(float(l.hP * shrink2 - p.modelDsPad_h + 1) / p.stride)));
+            l.nWinC = std::max(0, int(std::ceil(float(l.wP * shrink2 - p.modelDsPad_w + 1) / p.stride)));
+            l.offset = off;
+            off += int64_t(nCk) * l.hP * l.wP;
+            c->ldcfLevels.push_back(l);
+            ResampleDesc dd;
+            if ((rc = buildResample(s0.hP, s0.wP, l.hP, l.wP, dd, arena)))
+            {
+                return fail(c, rc, "plan: degenerate LDCF resample geometry");
+            }
+            const double one[3] = { 1.0, 1.0, 1.0 };
+            setResampleGain(dd, one, nCk, nCk);
+            dd.nplanes = nCk;
+            dd.src_off = 0;
+            dd.dst_off = l.offset;
+            c->ldcfTmpFloats = std::max<int64_t>(c->ldcfTmpFloats, int64_t(nCk) * s0.hP * s0.wP);
+            c->h_descs.push_back(dd);
+        }
+        c->ldcfFloats = off;
+        for (size_t i = 0; i < c->ldcfLevels.size(); i++)
+        {
+            ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
+            dd.src_frame_stride = c->ldcfTmpFloats;
+            dd.dst_frame_stride = c->ldcfFloats;
+        }
+        if ((rc = devUpload(c, &c->d_ldcfFilt, c->ldcfFilters)) || (rc = devAlloc(c, &c->d_ldcfTmp, size_t(B) * c->ldcfTmpFloats + 64)) ||
+            (rc = devAlloc(c, &c->d_ldcfPyr, size_t(B) * c->ldcfFloats + 64)))
+        {
+            return rc;
+        }
+    }
     if ((rc = devUpload(c, &c->d_descs, c->h_descs)) || (rc = devUpload(c, &c->d_it, arena.ints)) || (rc = devUpload(c, &c->d_ft, arena.floats)) ||
         (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)))
     {
@@ -1562,9 +1644,14 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         return rc;
     }
     // cascade
-    if ((rc = buildCascadeTables(c, pl.levels, pl.nChns, c->cs)))
+    // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
+    const std::vector<acf_hip_level>& cascLevels = p.ldcfK > 0 ? c->ldcfLevels : pl.levels;
     {
-        return rc;
+        ShrinkScope ss(c, p.ldcfK > 0 ? 2 : 1);
+        if ((rc = buildCascadeTables(c, cascLevels, pl.nChns * std::max(p.ldcfK, 1), c->cs)))
+        {
+            return rc;
+        }
     }
     if ((rc = devUpload(c, &c->cs.d_thrs, c->thrs)) || (rc = devUpload(c, &c->cs.d_hs, c->hs)) || (rc = devUpload(c, &c->cs.d_child, c->child)) ||
         (rc = devUpload(c, &c->cs.d_fids, c->fids)))
@@ -1591,7 +1678,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     }
     {
         int64_t nWinTotal = 0;
-        for (const auto& l : pl.levels)
+        for (const auto& l : cascLevels)
         {
             nWinTotal += int64_t(l.nWinR) * l.nWinC;
         }
@@ -2535,7 +2622,33 @@ int acf_hip_detect(acf_hip_ctx* c)
         return fail(c, ACF_HIP_E_INVALID, "detect: no pyramid (call acf_hip_pyramid)");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_boxLevels, c->lastBatch, c->plan.nChns);
+    int rc;
+    if (c->p.ldcfK > 0)
+    {
+        // LDCF: every level is filtered (k 5x5 filters per channel) into a scratch buffer, halved into the LDCF pyramid, and the
+        // cascade runs there with cells of 2*shrink pixels (include/acf_hip.h, acf_hip_params::ldcfK)
+        const Plan& pl = c->plan;
+        const int nF = c->lastBatch, nCk = pl.nChns * c->p.ldcfK;
+        for (size_t i = 0; i < pl.levels.size(); i++)
+        {
+            const acf_hip_level& l = pl.levels[i];
+            prof(c, "k_ldcf_conv");
+            hipLaunchKernelGGL(k_ldcf_conv, dim3(cdiv(int64_t(l.hP) * l.wP, 256), nCk, nF), dim3(256), 0, c->stream, (const float*)c->d_pyr, c->d_ldcfTmp,
+                (const float*)c->d_ldcfFilt, l.hP, l.wP, pl.nChns, l.offset, pl.pyr_floats, c->ldcfTmpFloats);
+            LAUNCHCHK(c, "k_ldcf_conv");
+            const ResampleDesc& hd = c->h_descs[size_t(c->ldcfDescBase) + i];
+            prof(c, "k_resample(ldcf)");
+            hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd), 1, nF), dim3(64, 4), 0, c->stream, (const float*)c->d_ldcfTmp, c->d_ldcfPyr,
+                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase + i), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
+            LAUNCHCHK(c, "k_resample(ldcf)");
+        }
+        ShrinkScope ss(c, 2);
+        rc = runCascade(c, c->d_ldcfPyr, c->ldcfFloats, c->d_boxLevels, nF, nCk);
+    }
+    else
+    {
+        rc = runCascade(c, c->d_pyr, c->plan.pyr_floats, c->d_boxLevels, c->lastBatch, c->plan.nChns);
+    }
     if (rc)
     {
         return rc;
@@ -3103,7 +3216,17 @@ int acf_hip_read_tap(acf_hip_ctx* c, int frame, int tap, int index, float* host_
     const Plan& pl = c->plan;
     const float* src = nullptr;
     int64_t n = 0;
-    if (tap == ACF_HIP_TAP_CHNS)
+    if (tap == ACF_HIP_TAP_LDCF)
+    {
+        if (c->p.ldcfK <= 0 || !c->detectValid || index < 0 || index >= int(c->ldcfLevels.size()))
+        {
+            return fail(c, ACF_HIP_E_INVALID, "read_tap: LDCF levels exist after acf_hip_detect on a model with ldcfK > 0");
+        }
+        const acf_hip_level& l = c->ldcfLevels[size_t(index)];
+        n = int64_t(pl.nChns) * c->p.ldcfK * l.hP * l.wP;
+        src = c->d_ldcfPyr + size_t(frame) * c->ldcfFloats + l.offset;
+    }
+    else if (tap == ACF_HIP_TAP_CHNS)
     {
         if (index < 0 || index >= int(pl.levels.size()))
         {

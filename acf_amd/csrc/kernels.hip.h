@@ -2425,6 +2425,41 @@ __global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------
+// LDCF decorrelation filters (BASELINE cfg 5; no reference counterpart — definition in include/acf_hip.h): one level's
+// nChns planes convolved with k filters of 5x5 each, zero-padded 'same' true convolution:
+//   out[f*nChns + c](y, x) = sum_{dx=-2..2} sum_{dy=-2..2} in[c](y - dy, x - dx) * filt[f][c][dx + 2][dy + 2]
+// taps added in that order from 0 (f32, no contraction).  A thread produces one output cell; lanes run along image-y.
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
+    int h, int w, int nChns, int64_t lvlOff, int64_t pyr_fs, int64_t out_fs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w)
+    {
+        return;
+    }
+    const int x = i / h, y = i - x * h;
+    const int pc = blockIdx.y; // plane f*nChns + c
+    const int c = pc % nChns;
+    const float* __restrict__ in = pyr + int64_t(blockIdx.z) * pyr_fs + lvlOff + int64_t(c) * h * w;
+    const float* __restrict__ f = filt + int64_t(pc) * 25;
+    float acc = 0.f;
+#pragma unroll
+    for (int dx = -2; dx <= 2; dx++)
+    {
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++)
+        {
+            const int xx = x - dx, yy = y - dy;
+            const bool ok = xx >= 0 && xx < w && yy >= 0 && yy < h;
+            const float v = ok ? in[int64_t(min(max(xx, 0), w - 1)) * h + min(max(yy, 0), h - 1)] : 0.f;
+            acc = acc + v * f[(dx + 2) * 5 + (dy + 2)];
+        }
+    }
+    out[int64_t(blockIdx.z) * out_fs + int64_t(pc) * h * w + i] = acc;
+}
+
+// ------------------------------------------------------------------------
 // imResample for the down-sampling real scales of the image pyramid (chnsPyramid.cpp:310): a workgroup produces a
 // 64-row x `xo`-column output tile from a source tile staged once in LDS — x pass for every source row of the tile
 // into a second LDS buffer, then the y pass — instead of re-reading JX*NY taps per output through the L1 (the

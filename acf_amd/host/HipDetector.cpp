@@ -158,6 +158,9 @@ void HipDetector::fillParams(acf_hip_params& p) const
     p.nOrients = ch.pGradHist.nOrients;
     p.softBin = ch.pGradHist.softBin;
     p.isLuv = m_isLuv ? 1 : 0;
+    // LDCF post-stage (no reference counterpart; include/acf_hip.h): filters [k][nChns][5][5], MATLAB order of fs(:,:,c,f)
+    p.ldcfK = opts.ldcfFilters.empty() ? 0 : opts.ldcfK;
+    p.ldcfFilters = opts.ldcfFilters.empty() ? nullptr : opts.ldcfFilters.data();
 }
 
 int HipDetector::acfModify(const Modify& params)

@@ -139,6 +139,10 @@ public:
             double smooth = 1;
         } pPyramid;
         Size modelDs{ 16, 16 }, modelDsPad{ 16, 16 };
+        // LDCF (toolbox opts.filters, BASELINE cfg 5; not in the reference's Options tree): k filters of 5x5 per channel applied to
+        // every level before the cascade, which then runs at shrink*2.  Layout [k][nChns][5][5] = MATLAB memory order of fs(:,:,c,f).
+        int ldcfK = 0;
+        std::vector<float> ldcfFilters;
         int stride = 4;
         double cascThr = -1;
         double cascCal = 0;

@@ -149,7 +149,16 @@ def make_model(seed=1, nTrees=2048, name="FACE80", **over):
     depth = m["treeDepth"]
     nC = n_channels(m)
     mh, mw = m["modelDsPad_h"] // m["shrink"], m["modelDsPad_w"] // m["shrink"]
-    nF = nC * mh * mw
+    ldcf_k = int(m.get("ldcfK", 0))
+    if ldcf_k > 0:
+        # LDCF (BASELINE cfg 5): the cascade sees nC*k channels at shrink*2 (include/acf_hip.h, acf_hip_params::ldcfK)
+        mh, mw = m["modelDsPad_h"] // (2 * m["shrink"]), m["modelDsPad_w"] // (2 * m["shrink"])
+        fu = uniform(seed, ldcf_k * nC * 25, 31).reshape(ldcf_k, nC, 5, 5)
+        filt = (fu - 0.5) * 0.4
+        filt[0, :, 2, 2] += 1.0  # first filter close to identity, the others zero-mean-ish band filters
+        m["ldcfFilters"] = filt.astype(np.float32)
+    nCe = nC * max(ldcf_k, 1)
+    nF = nCe * mh * mw
     if depth > 0:
         nNodes = (1 << (depth + 1)) - 1
         nInternal = (1 << depth) - 1
@@ -166,6 +175,11 @@ def make_model(seed=1, nTrees=2048, name="FACE80", **over):
     if m["gradHistEnabled"]:
         qs += _CHN_Q["hist"] * m["nOrients"]
     qs = np.asarray(qs, dtype=np.float64)
+    if ldcf_k > 0:
+        # filtered channels: filter 0 keeps the channel's range, the others are centred near 0 with a fraction of its spread
+        base = qs
+        spread = (base[:, 1] - base[:, 0])[:, None] * np.array([-0.6, 0.6])
+        qs = np.concatenate([base] + [spread for _ in range(ldcf_k - 1)], axis=0)
     ch = fids // (mh * mw)
     lo, hi = qs[ch, 0], qs[ch, 1]
     thrs = (lo + u[1] * (hi - lo)).astype(np.float32)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 2
+#define ACF_HIP_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -106,6 +106,17 @@ typedef struct acf_hip_params
     int32_t nOrients;
     int32_t softBin;
     int32_t isLuv; /* Detector::setIsLuv (ACF.h:560-567) */
+
+    /* LDCF (BASELINE cfg 5: "k 5x5 filters per channel").  NO reference counterpart ("has not yet been added",
+     * README.rst:8): the definition is the upstream toolbox's acfDetectImg — for every level,
+     *   C(:,:,j) = conv2(chns(:,:,mod(j-1,nChns)+1), filters(:,:,j), 'same'),  j = 1 .. nChns*k   (zero-padded true convolution)
+     *   level    = imResample(C, .5)                                                 (size round(.5 * size))
+     * and the cascade then runs with shrink*2 over nChns*k channels (fids index nChns*k*(modelDsPad/(2*shrink))^2 cells).
+     * ldcfFilters: [k][nChns][5][5] floats in the MATLAB memory order of fs(:,:,c,f): tap (dy, dx) at dy + 5*dx.
+     * The summation order of the 25 taps (dx ascending, then dy ascending, accumulating from 0) is this repo's own.
+     * ldcfK == 0 or ldcfFilters == NULL: off. */
+    int32_t ldcfK;
+    const float* ldcfFilters;
 } acf_hip_params;
 
 /* One detection in upright image coordinates (ACF.cpp:302-312, Detection ACF.h:510-525). */
@@ -279,7 +290,8 @@ enum {
     ACF_HIP_TAP_O = 3,        /* orientation (tag O) */
     ACF_HIP_TAP_S = 4,        /* convTri(M, normRad) */
     ACF_HIP_TAP_MNORM = 5,    /* tag Mnorm */
-    ACF_HIP_TAP_CHNS = 6      /* unsmoothed, unpadded channels of a level: nChns planes [wC][hC] */
+    ACF_HIP_TAP_CHNS = 6,     /* unsmoothed, unpadded channels of a level: nChns planes [wC][hC] */
+    ACF_HIP_TAP_LDCF = 7      /* LDCF level the cascade reads: nChns*k planes [round(wP/2)][round(hP/2)] (after acf_hip_detect) */
 };
 /* `index`: real-scale ordinal for taps 0-5, level for ACF_HIP_TAP_CHNS. */
 ACF_HIP_API int acf_hip_read_tap(acf_hip_ctx* ctx, int frame, int tap, int index, float* host_out, int64_t cap_floats);

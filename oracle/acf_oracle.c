@@ -1627,6 +1627,86 @@ ACFO_API float acfo_evaluate(const float* chns, int hP, int wP, int nChns, const
     return h;
 }
 
+/* ------------------------------------------------------------------------
+ * a18  LDCF post-stage (BASELINE cfg 5).  NO REFERENCE COUNTERPART (README.rst:8): restates the upstream toolbox's
+ * acfDetectImg — per level C(:,:,j) = conv2(chns(:,:,mod(j-1,nC)+1), fs(:,:,j), 'same'); P.data{i} = imResample(C, .5);
+ * cascade with shrink*2.  Planes are [w][h] with h contiguous (= MATLAB's column-major (h, w)); filter tap (dy, dx) of
+ * filter f, channel c at filt[((f*nC + c)*5 + dx)*5 + dy].  Tap order (this repo's own choice): dx ascending, dy
+ * ascending, accumulated from 0 in f32 without contraction.  Parity unpinned by construction.
+ * ---------------------------------------------------------------------- */
+static int round_half_away(double v)
+{
+    return (int)(v < 0 ? -floor(-v + 0.5) : floor(v + 0.5));
+}
+
+ACFO_API void acfo_ldcf_conv(const float* in, float* out, int h, int w, const float* f)
+{
+    for (int x = 0; x < w; x++)
+    {
+        for (int y = 0; y < h; y++)
+        {
+            float acc = 0.f;
+            for (int dx = -2; dx <= 2; dx++)
+            {
+                for (int dy = -2; dy <= 2; dy++)
+                {
+                    const int xx = x - dx, yy = y - dy;
+                    const float v = (xx >= 0 && xx < w && yy >= 0 && yy < h) ? in[(size_t)xx * h + yy] : 0.f;
+                    acc = acc + v * f[(dx + 2) * 5 + (dy + 2)];
+                }
+            }
+            out[(size_t)x * h + y] = acc;
+        }
+    }
+}
+
+/* Level table of the LDCF pyramid: hP' = round(.5*hP) (imResample.m), window grid with shrink*2. */
+ACFO_API int64_t acfo_ldcf_plan(const acf_hip_params* p, const acf_hip_level* lv, int nScales, int nChns, acf_hip_level* out)
+{
+    int64_t off = 0;
+    const int shrink2 = 2 * p->shrink;
+    for (int i = 0; i < nScales; i++)
+    {
+        out[i] = lv[i];
+        out[i].hP = round_half_away(0.5 * lv[i].hP);
+        out[i].wP = round_half_away(0.5 * lv[i].wP);
+        out[i].hC = out[i].hP;
+        out[i].wC = out[i].wP;
+        int n1 = (int)ceilf((float)(out[i].hP * shrink2 - p->modelDsPad_h + 1) / p->stride);
+        int n2 = (int)ceilf((float)(out[i].wP * shrink2 - p->modelDsPad_w + 1) / p->stride);
+        out[i].nWinR = n1 > 0 ? n1 : 0;
+        out[i].nWinC = n2 > 0 ? n2 : 0;
+        out[i].offset = off;
+        off += (int64_t)nChns * p->ldcfK * out[i].hP * out[i].wP;
+    }
+    return off;
+}
+
+ACFO_API int acfo_ldcf_pyramid(const float* pyr, const acf_hip_params* p, const acf_hip_level* lv, const acf_hip_level* lvL, int nScales,
+    int nChns, float* out)
+{
+    for (int i = 0; i < nScales; i++)
+    {
+        const int h = lv[i].hP, w = lv[i].wP, hb = lvL[i].hP, wb = lvL[i].wP;
+        float* C = (float*)xmalloc(sizeof(float) * (size_t)h * w);
+        for (int f = 0; f < p->ldcfK; f++)
+        {
+            for (int c = 0; c < nChns; c++)
+            {
+                acfo_ldcf_conv(pyr + lv[i].offset + (size_t)c * h * w, C, h, w, p->ldcfFilters + ((size_t)f * nChns + c) * 25);
+                int rc = acfo_resample(C, out + lvL[i].offset + ((size_t)f * nChns + c) * hb * wb, h, hb, w, wb, 1, 1.0f);
+                if (rc)
+                {
+                    free(C);
+                    return rc;
+                }
+            }
+        }
+        free(C);
+    }
+    return 0;
+}
+
 /* Mean number of trees evaluated per window (diagnostic for the synthetic
  * model calibration; no reference counterpart). */
 ACFO_API double acfo_mean_trees(const float* chns, int hP, int wP, int nChns, const acf_hip_params* p)

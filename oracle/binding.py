@@ -71,6 +71,10 @@ def lib():
         o.acfo_acf_detect1.restype = C.c_int
         o.acfo_evaluate.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, C.c_float]
         o.acfo_evaluate.restype = C.c_float
+        o.acfo_ldcf_plan.argtypes = [P, L, C.c_int, C.c_int, L]
+        o.acfo_ldcf_plan.restype = C.c_int64
+        o.acfo_ldcf_pyramid.argtypes = [fp, P, L, L, C.c_int, C.c_int, fp]
+        o.acfo_ldcf_pyramid.restype = C.c_int
         o.acfo_thrs_u8.argtypes = [fp, C.c_int, C.c_void_p]
         o.acfo_thrs_u8.restype = None
         o.acfo_mean_trees.argtypes = [fp, C.c_int, C.c_int, C.c_int, P]
@@ -202,6 +206,32 @@ def detect(plan, pyr, cap=1 << 16):
                       det.ctypes.data_as(C.POINTER(capi.Detection)), hits.ctypes.data_as(C.POINTER(capi.Hit)), cap)
     if n > cap:
         raise RuntimeError("capacity %d < %d" % (cap, n))
+    return det[:n].copy(), hits[:n].copy()
+
+
+def ldcf(plan, pyr):
+    """LDCF post-stage of the pyramid (acfo_ldcf_*): -> (levels, ldcf pyramid, params with shrink*2 for the cascade)."""
+    n = plan.nScales
+    lvL = (capi.Level * len(plan.levels))()
+    k = plan.params.ldcfK
+    tot = lib().acfo_ldcf_plan(C.byref(plan.params), plan.levels, n, plan.nChns, lvL)
+    out = aligned((int(tot),))
+    rc = lib().acfo_ldcf_pyramid(F(pyr), C.byref(plan.params), plan.levels, lvL, n, plan.nChns, F(out))
+    if rc:
+        raise RuntimeError("acfo_ldcf_pyramid rc=%d" % rc)
+    return lvL, out, k
+
+
+def detect_ldcf(plan, lvL, pyrL, cap=1 << 16):
+    """Cascade + box mapping on the LDCF pyramid: shrink*2, nChns*k channels."""
+    import copy
+    p2 = capi.Params.from_buffer_copy(plan.params)
+    p2.shrink = plan.params.shrink * 2
+    det = np.zeros(cap, dtype=capi.DET_DTYPE)
+    hits = np.zeros(cap, dtype=capi.HIT_DTYPE)
+    n = lib().acfo_detect(F(pyrL), C.byref(p2), lvL, plan.nScales, plan.nChns * plan.params.ldcfK,
+                          det.ctypes.data_as(C.POINTER(capi.Detection)), hits.ctypes.data_as(C.POINTER(capi.Hit)), cap)
+    n = min(n, cap)
     return det[:n].copy(), hits[:n].copy()
 
 

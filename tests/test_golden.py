@@ -159,3 +159,45 @@ def test_hip_pipeline_matches_golden(name):
         d, h = det.detections(f)
         assert d.tobytes() == z["det"].tobytes() and h.tobytes() == z["hits"].tobytes()
     det.close()
+
+
+def test_ldcf_oracle_properties(oracle):
+    """LDCF has no reference vectors (README.rst:8): pin the oracle's restatement through properties of the definition —
+    a centre-tap filter is the identity, a one-tap filter is a zero-filled shift in the direction of a true convolution
+    (conv2, not correlation), the operator is linear in the filter, and levels are sized round(.5 * size)."""
+    import ctypes as C
+    from acf_amd import capi, synth
+    lib = oracle.lib()
+    lib.acfo_ldcf_conv.argtypes = [oracle.fp, oracle.fp, C.c_int, C.c_int, oracle.fp]
+    lib.acfo_ldcf_conv.restype = None
+    h, w = 11, 7
+    a = synth.uniform(9, h * w, 0).astype(np.float32).reshape(w, h)
+
+    def conv(f):
+        out = np.zeros_like(a)
+        f = np.ascontiguousarray(f, np.float32)  # [dx][dy]
+        lib.acfo_ldcf_conv(oracle.F(a), oracle.F(out), h, w, oracle.F(f))
+        return out
+
+    ident = np.zeros((5, 5), np.float32)
+    ident[2, 2] = 1
+    assert np.array_equal(conv(ident), a)
+    one = np.zeros((5, 5), np.float32)
+    one[2 + 1, 2 - 2] = 1          # tap (dx = +1, dy = -2): out(y, x) = in(y + 2, x - 1)
+    want = np.zeros_like(a)
+    want[1:, :h - 2] = a[:w - 1, 2:]
+    assert np.array_equal(conv(one), want)
+    f1 = (synth.uniform(4, 25, 1).reshape(5, 5) - 0.5).astype(np.float32)
+    assert np.allclose(conv(f1) + conv(ident), conv(f1 + ident), atol=1e-6)
+    # level sizes and window grid of the halved pyramid
+    m = synth.make_model(seed=3, name="TINY", nTrees=8, ldcfK=2, modelDs_h=32, modelDs_w=32, modelDsPad_h=32, modelDsPad_w=32, minDs_h=32, minDs_w=32)
+    plan = oracle.Plan(m, 131, 175, 3)
+    lvL = (capi.Level * len(plan.levels))()
+    tot = lib.acfo_ldcf_plan(C.byref(plan.params), plan.levels, plan.nScales, plan.nChns, lvL)
+    acc = 0
+    for i in range(plan.nScales):
+        assert lvL[i].hP == int(np.floor(0.5 * plan.levels[i].hP + 0.5)) and lvL[i].wP == int(np.floor(0.5 * plan.levels[i].wP + 0.5))
+        assert lvL[i].nWinR == max(0, int(np.ceil((lvL[i].hP * 8 - 32 + 1) / 4.0)))
+        assert lvL[i].offset == acc
+        acc += plan.nChns * 2 * lvL[i].hP * lvL[i].wP
+    assert tot == acc

@@ -5,7 +5,8 @@
  cfg 2  1920x1080 planar LUV, FACE80, 2048 trees (the benchmark workload)
  cfg 3  a batch of cfg-2 frames (8 here): per-frame results independent of batch position
  cfg 4  640x480 RGB, INRIA 128x64 model, pad [16 12], nOctUp 1 (RGB->LUV on the device, up-sampled real scale)
- cfg 5  3840x2160 planar LUV, 12 scales/octave, nApprox 11, FACE80 (LDCF has no reference counterpart: not covered)
+ cfg 5  3840x2160 planar LUV, 12 scales/octave, nApprox 11, FACE80 — plain, and with its LDCF post-stage (k = 4 5x5 filters per
+        channel; no reference counterpart, checked against the oracle's restatement of the toolbox definition)
 """
 import numpy as np
 import pytest
@@ -66,4 +67,31 @@ def test_cfg3_batch_of_1080p_frames(oracle):
         want, wh = oracle.detect(plan, pyr)
         got, gh = det.detections(f)
         assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes(), f
+    det.close()
+
+
+def test_cfg5_ldcf_full_size(oracle):
+    """cfg 5 as BASELINE.json names it: 4K, 12 scales/octave, FACE80 + k 5x5 filters per channel (LDCF).  58 filtered, halved levels
+    of 40 channels and the cascade over them, against oracle/acf_oracle.c's acfo_ldcf_* (the only definition there is)."""
+    import torch
+    from acf_amd import capi
+    from acf_amd.detector import HipDetector
+    H, W = 2160, 3840
+    model = synth.make_model(seed=1, name="FACE80", nPerOct=12, nApprox=11, ldcfK=4, cascThr=-2.0, nTrees=512)
+    frame = synth.make_frame(2, H, W, "luv")
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 17)
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    lvL, pyrL, k = oracle.ldcf(plan, pyr)
+    want, wh = oracle.detect_ldcf(plan, lvL, pyrL, cap=1 << 17)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    for i in range(plan.nScales):
+        l = lvL[i]
+        n = plan.nChns * k * l.hP * l.wP
+        got = det.read_tap(0, capi.TAP_LDCF, i, (plan.nChns * k, l.wP, l.hP))
+        assert np.array_equal(bits(got).ravel(), bits(pyrL[l.offset:l.offset + n])), ("LDCF level", i)
+    got, gh = det.detections(0)
+    assert len(want) > 0
+    assert gh.tobytes() == wh.tobytes()
+    assert got.tobytes() == want.tobytes()
     det.close()

@@ -251,3 +251,49 @@ def test_detector_pool_concurrent_contexts_match_single(oracle):
     odet, _ = oracle.detect(plan, pyr)
     assert np.array_equal(bits(odet["score"]), bits(want[1][2]["score"]))
     pool.close()
+
+
+LDCF_CASES = {
+    # name: (H, W, model kwargs) — BASELINE cfg 5's post-stage on small frames: k 5x5 filters per channel, halved levels, cascade at shrink*2
+    "tiny32_k3": (120, 160, dict(name="TINY", nTrees=64, ldcfK=3, modelDs_h=32, modelDs_w=32, modelDsPad_h=32, modelDsPad_w=32,
+                                 minDs_h=32, minDs_w=32, cascThr=-2.0)),
+    "tiny32_k2_stride8_odd": (131, 175, dict(name="TINY", nTrees=64, ldcfK=2, stride=8, modelDs_h=32, modelDs_w=32, modelDsPad_h=32,
+                                             modelDsPad_w=32, minDs_h=32, minDs_w=32, cascThr=-2.0)),
+    "face80_k4_vga": (480, 640, dict(name="FACE80", nTrees=256, ldcfK=4, cascThr=-2.0)),
+}
+
+
+@pytest.mark.parametrize("case", list(LDCF_CASES))
+def test_ldcf_post_stage_bit_exact(oracle, case):
+    """LDCF: no reference counterpart, so the oracle's restatement of the toolbox definition
+    (oracle/acf_oracle.c acfo_ldcf_*) is the only yardstick: filtered + halved levels and the detections on them."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W, kw = LDCF_CASES[case]
+    model = synth.make_model(seed=3, **kw)
+    nF = 2
+    det = HipDetector(model, H, W, 3, max_batch=nF, max_hits=1 << 16)
+    frames = np.stack([synth.make_frame(70 + i, H, W, "luv") for i in range(nF)])
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    total = 0
+    for f in range(nF):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        lvL, pyrL, k = oracle.ldcf(plan, pyr)
+        for i in range(plan.nScales):
+            l = lvL[i]
+            n = plan.nChns * k * l.hP * l.wP
+            want = pyrL[l.offset:l.offset + n].reshape(plan.nChns * k, l.wP, l.hP)
+            got = det.read_tap(f, capi.TAP_LDCF, i, (plan.nChns * k, l.wP, l.hP))
+            assert np.array_equal(bits(got), bits(want)), (case, f, "LDCF level", i, float(np.abs(got - want).max()))
+        want, want_hits = oracle.detect_ldcf(plan, lvL, pyrL)
+        got, got_hits = det.detections(f)
+        assert len(got) == len(want), (len(got), len(want))
+        for key in ("scale", "c", "r"):
+            assert np.array_equal(got_hits[key], want_hits[key]), key
+        for key in ("x", "y", "w", "h", "scale"):
+            assert np.array_equal(got[key], want[key]), key
+        assert np.array_equal(bits(got["score"]), bits(want["score"]))
+        total += len(want)
+    assert total > 0
+    det.close()
