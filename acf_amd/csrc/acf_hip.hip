@@ -1727,6 +1727,22 @@ int acf_hip_get_levels(const acf_hip_ctx* c, acf_hip_level* out, int cap)
     return ACF_HIP_OK;
 }
 
+int acf_hip_get_ldcf_levels(const acf_hip_ctx* c, acf_hip_level* out, int cap)
+{
+    if (!c || !c->hasPlan || !out)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    const acf_hip_ctx* src = c->kids.empty() ? c : c->kids[0];
+    if (src->p.ldcfK <= 0 || src->ldcfLevels.empty())
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    const int n = std::min(cap, int(src->ldcfLevels.size()));
+    std::copy(src->ldcfLevels.begin(), src->ldcfLevels.begin() + n, out);
+    return ACF_HIP_OK;
+}
+
 int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
 {
     if (!c || !c->hasPlan)

@@ -108,6 +108,11 @@ class HipDetector:
         tot = C.c_int64()
         self._chk(self.lib.acf_hip_pyramid_floats(self.ctx, C.byref(tot)))
         self.pyr_floats = tot.value
+        self.ldcf_levels = []
+        if int(self.params.ldcfK) > 0:
+            ll = (capi.Level * n.value)()
+            self._chk(self.lib.acf_hip_get_ldcf_levels(self.ctx, ll, n.value))
+            self.ldcf_levels = list(ll)
 
     # ---- hot path
     def pyramid(self, frames, n=None):

@@ -47,6 +47,7 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_plan)
     ACF_HIP_FN(acf_hip_num_levels)
     ACF_HIP_FN(acf_hip_get_levels)
+    ACF_HIP_FN(acf_hip_get_ldcf_levels)
     ACF_HIP_FN(acf_hip_pyramid_floats)
     ACF_HIP_FN(acf_hip_pyramid)
     ACF_HIP_FN(acf_hip_detect)

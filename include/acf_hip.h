@@ -193,6 +193,9 @@ ACF_HIP_API int acf_hip_set_model(acf_hip_ctx* ctx, const acf_hip_params* p);
 ACF_HIP_API int acf_hip_plan(acf_hip_ctx* ctx, int h, int w, int d, int max_batch, int max_hits);
 ACF_HIP_API int acf_hip_num_levels(const acf_hip_ctx* ctx, int* nScales, int* nChns);
 ACF_HIP_API int acf_hip_get_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
+/* Geometry of the LDCF levels the cascade reads when the model has ldcfK > 0 (hP, wP = round(.5 * size), window grid at
+ * shrink*2, offsets inside one frame's LDCF pyramid); same count as acf_hip_get_levels.  ACF_HIP_E_INVALID without LDCF. */
+ACF_HIP_API int acf_hip_get_ldcf_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
 /* Floats in one frame's fused pyramid (sum over levels of nChns*wP*hP). */
 ACF_HIP_API int acf_hip_pyramid_floats(const acf_hip_ctx* ctx, int64_t* n);
 

@@ -280,8 +280,11 @@ def test_ldcf_post_stage_bit_exact(oracle, case):
     for f in range(nF):
         pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
         lvL, pyrL, k = oracle.ldcf(plan, pyr)
+        assert len(det.ldcf_levels) == plan.nScales
         for i in range(plan.nScales):
             l = lvL[i]
+            for fld in ("hP", "wP", "nWinR", "nWinC", "offset"):
+                assert getattr(det.ldcf_levels[i], fld) == getattr(l, fld), (i, fld)
             n = plan.nChns * k * l.hP * l.wP
             want = pyrL[l.offset:l.offset + n].reshape(plan.nChns * k, l.wP, l.hP)
             got = det.read_tap(f, capi.TAP_LDCF, i, (plan.nChns * k, l.wP, l.hP))
