@@ -496,6 +496,14 @@ bool loadAcfm(std::istream& is, HipDetector::Options& o, HipDetector::Classifier
     is.read(reinterpret_cast<char*>(c.thrs.data()), std::streamsize(n * 4));
     is.read(reinterpret_cast<char*>(c.hs.data()), std::streamsize(n * 4));
     is.read(reinterpret_cast<char*>(c.child.data()), std::streamsize(n * 4));
+    o.ldcfK = 0;
+    o.ldcfFilters.clear();
+    if (kv.count("ldcfK") && kv.count("ldcfCount"))
+    {
+        o.ldcfK = I("ldcfK");
+        o.ldcfFilters.resize(size_t(std::stoul(kv.at("ldcfCount"))));
+        is.read(reinterpret_cast<char*>(o.ldcfFilters.data()), std::streamsize(o.ldcfFilters.size() * 4));
+    }
     return bool(is);
 }
 

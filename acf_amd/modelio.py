@@ -2,7 +2,8 @@
 (acf_amd/host/acf_hip_detect.cpp): a text header of "key value" lines, "END",
 then raw little-endian fids u32, thrs f32, hs f32, child u32 arrays
 ([nTrees][nTreeNodes] row-major, the layout after the reference's load-time
-transpose, ACFIO.cpp:61-67)."""
+transpose, ACFIO.cpp:61-67); with "ldcfK"/"ldcfCount" header keys, the LDCF
+filters [k][nChns][5][5] f32 follow."""
 import numpy as np
 
 _KEYS = ("treeDepth", "modelDs_h", "modelDs_w", "modelDsPad_h", "modelDsPad_w", "stride", "cascThr", "nPerOct", "nOctUp",
@@ -20,11 +21,16 @@ def write_model(path, model):
         for k in _KEYS:
             f.write(("%s %r\n" % (k, model[k])).encode())
         f.write(("lambdas %s\n" % " ".join(repr(float(v)) for v in (model.get("lambdas") or []))).encode())
+        filt = model.get("ldcfFilters") if int(model.get("ldcfK", 0)) > 0 else None
+        if filt is not None:
+            f.write(("ldcfK %d\nldcfCount %d\n" % (int(model["ldcfK"]), int(np.asarray(filt).size))).encode())
         f.write(b"END\n")
         f.write(fids.tobytes())
         f.write(np.ascontiguousarray(model["thrs"], dtype="<f4").tobytes())
         f.write(np.ascontiguousarray(model["hs"], dtype="<f4").tobytes())
         f.write(np.ascontiguousarray(model["child"], dtype="<u4").tobytes())
+        if filt is not None:
+            f.write(np.ascontiguousarray(filt, dtype="<f4").tobytes())  # LDCF filters [k][nChns][5][5] after the tree arrays
 
 
 # ---------------------------------------------------------------------------

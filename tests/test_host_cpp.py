@@ -260,3 +260,27 @@ def test_chns_pyramid_logger_taps(cli, oracle, tmp_path):
         hc = np.concatenate([c[4 + b] for b in range(nO)], axis=1)  # cv::hconcat of the histogram planes
         want.append(("H:%dx%d" % (hc.shape[1], hc.shape[0]), "%016x" % _fnv1a(np.ascontiguousarray(hc).tobytes())))
     assert len(want) >= 7 and got == want
+
+
+@pytest.mark.gpu
+def test_cli_ldcf_model(cli, oracle, tmp_path):
+    """acf::HipDetector with Options::ldcfK / ldcfFilters (the LDCF stage of BASELINE cfg 5) through the CLI."""
+    H, W = 120, 160
+    model = synth.make_model(seed=3, name="TINY", nTrees=64, ldcfK=3, modelDs_h=32, modelDs_w=32, modelDsPad_h=32, modelDsPad_w=32,
+                             minDs_h=32, minDs_w=32, cascThr=-2.0)
+    frames = [synth.make_frame(70 + i, H, W, "luv") for i in range(2)]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", "2", "--luv", "--batch"])
+    got = parse(p.stdout)
+    plan = oracle.Plan(model, H, W, 3)
+    total = 0
+    for f in range(2):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        lvL, pyrL, _ = oracle.ldcf(plan, pyr)
+        det, _ = oracle.detect_ldcf(plan, lvL, pyrL)
+        want = [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det]
+        assert got[f] == want
+        total += len(want)
+    assert total > 0
