@@ -104,6 +104,8 @@ struct acf_hip_ctx
     int ldcfDescBase = 0;
     int64_t ldcfFloats = 0, ldcfTmpFloats = 0;
     float* d_ldcfFilt = nullptr;
+    LdcfJob* d_ldcfJobs = nullptr;
+    int ldcfMaxCells = 0, ldcfMaxBlocks = 0;
     float* d_ldcfTmp = nullptr;
     float* d_ldcfPyr = nullptr;
 
@@ -259,6 +261,7 @@ void freeAll(acf_hip_ctx* c)
     c->d_dump = nullptr;
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
+    c->d_ldcfJobs = nullptr;
     c->lastFrames = nullptr;
     c->pyramidValid = c->detectValid = false;
 }
@@ -1592,6 +1595,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     {
         const int shrink2 = 2 * p.shrink, nCk = pl.nChns * p.ldcfK;
         c->ldcfDescBase = int(c->h_descs.size());
+        c->ldcfMaxCells = c->ldcfMaxBlocks = 0;
+        std::vector<LdcfJob> ldcfJobs;
         int64_t off = 0;
         for (size_t i = 0; i < pl.levels.size(); i++)
         {
@@ -1616,17 +1621,29 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             const double one[3] = { 1.0, 1.0, 1.0 };
             setResampleGain(dd, one, nCk, nCk);
             dd.nplanes = nCk;
-            dd.src_off = 0;
+            dd.src_off = int64_t(p.ldcfK) * s0.offset; // the filtered scratch holds every level: k planes per channel plane
             dd.dst_off = l.offset;
-            c->ldcfTmpFloats = std::max<int64_t>(c->ldcfTmpFloats, int64_t(nCk) * s0.hP * s0.wP);
             c->h_descs.push_back(dd);
+            LdcfJob j{};
+            j.h = s0.hP;
+            j.w = s0.wP;
+            j.inOff = s0.offset;
+            j.outOff = int64_t(p.ldcfK) * s0.offset;
+            ldcfJobs.push_back(j);
+            c->ldcfMaxCells = std::max(c->ldcfMaxCells, s0.hP * s0.wP);
+            c->ldcfMaxBlocks = std::max(c->ldcfMaxBlocks, resampleBlocks(dd));
         }
+        c->ldcfTmpFloats = int64_t(p.ldcfK) * pl.pyr_floats;
         c->ldcfFloats = off;
         for (size_t i = 0; i < c->ldcfLevels.size(); i++)
         {
             ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
             dd.src_frame_stride = c->ldcfTmpFloats;
             dd.dst_frame_stride = c->ldcfFloats;
+        }
+        if ((rc = devUpload(c, &c->d_ldcfJobs, ldcfJobs)))
+        {
+            return rc;
         }
         if ((rc = devUpload(c, &c->d_ldcfFilt, c->ldcfFilters)) || (rc = devAlloc(c, &c->d_ldcfTmp, size_t(B) * c->ldcfTmpFloats + 64)) ||
             (rc = devAlloc(c, &c->d_ldcfPyr, size_t(B) * c->ldcfFloats + 64)))
@@ -2645,19 +2662,15 @@ int acf_hip_detect(acf_hip_ctx* c)
         // cascade runs there with cells of 2*shrink pixels (include/acf_hip.h, acf_hip_params::ldcfK)
         const Plan& pl = c->plan;
         const int nF = c->lastBatch, nCk = pl.nChns * c->p.ldcfK;
-        for (size_t i = 0; i < pl.levels.size(); i++)
-        {
-            const acf_hip_level& l = pl.levels[i];
-            prof(c, "k_ldcf_conv");
-            hipLaunchKernelGGL(k_ldcf_conv, dim3(cdiv(int64_t(l.hP) * l.wP, 256), nCk, nF), dim3(256), 0, c->stream, (const float*)c->d_pyr, c->d_ldcfTmp,
-                (const float*)c->d_ldcfFilt, l.hP, l.wP, pl.nChns, l.offset, pl.pyr_floats, c->ldcfTmpFloats);
-            LAUNCHCHK(c, "k_ldcf_conv");
-            const ResampleDesc& hd = c->h_descs[size_t(c->ldcfDescBase) + i];
-            prof(c, "k_resample(ldcf)");
-            hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd), 1, nF), dim3(64, 4), 0, c->stream, (const float*)c->d_ldcfTmp, c->d_ldcfPyr,
-                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase + i), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
-            LAUNCHCHK(c, "k_resample(ldcf)");
-        }
+        const int nL = int(pl.levels.size());
+        prof(c, "k_ldcf_conv");
+        hipLaunchKernelGGL(k_ldcf_conv, dim3(cdiv(c->ldcfMaxCells, 256), nCk, nF * nL), dim3(256), 0, c->stream, (const float*)c->d_pyr, c->d_ldcfTmp,
+            (const float*)c->d_ldcfFilt, (const LdcfJob*)c->d_ldcfJobs, nL, pl.nChns, pl.pyr_floats, c->ldcfTmpFloats);
+        LAUNCHCHK(c, "k_ldcf_conv");
+        prof(c, "k_resample(ldcf)");
+        hipLaunchKernelGGL(k_resample, dim3(c->ldcfMaxBlocks, nL, nF), dim3(64, 4), 0, c->stream, (const float*)c->d_ldcfTmp, c->d_ldcfPyr,
+            (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
+        LAUNCHCHK(c, "k_resample(ldcf)");
         ShrinkScope ss(c, 2);
         rc = runCascade(c, c->d_ldcfPyr, c->ldcfFloats, c->d_boxLevels, nF, nCk);
     }

@@ -2430,9 +2430,20 @@ __global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__
 //   out[f*nChns + c](y, x) = sum_{dx=-2..2} sum_{dy=-2..2} in[c](y - dy, x - dx) * filt[f][c][dx + 2][dy + 2]
 // taps added in that order from 0 (f32, no contraction).  A thread produces one output cell; lanes run along image-y.
 // ------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
-    int h, int w, int nChns, int64_t lvlOff, int64_t pyr_fs, int64_t out_fs)
+struct LdcfJob
 {
+    int32_t h, w;        // padded level size (cells)
+    int64_t inOff;       // level offset in one frame's pyramid
+    int64_t outOff;      // level offset in one frame's filtered scratch (k * inOff)
+};
+
+// every level in one launch: blockIdx.z = frame * nLevels + level, blockIdx.y = output plane f*nChns + c
+__global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
+    const LdcfJob* __restrict__ jobs, int nLevels, int nChns, int64_t pyr_fs, int64_t out_fs)
+{
+    const int lvl = blockIdx.z % nLevels, frame = blockIdx.z / nLevels;
+    const LdcfJob J = jobs[lvl];
+    const int h = J.h, w = J.w;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= h * w)
     {
@@ -2441,7 +2452,7 @@ __global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr
     const int x = i / h, y = i - x * h;
     const int pc = blockIdx.y; // plane f*nChns + c
     const int c = pc % nChns;
-    const float* __restrict__ in = pyr + int64_t(blockIdx.z) * pyr_fs + lvlOff + int64_t(c) * h * w;
+    const float* __restrict__ in = pyr + int64_t(frame) * pyr_fs + J.inOff + int64_t(c) * h * w;
     const float* __restrict__ f = filt + int64_t(pc) * 25;
     float acc = 0.f;
 #pragma unroll
@@ -2456,7 +2467,7 @@ __global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr
             acc = acc + v * f[(dx + 2) * 5 + (dy + 2)];
         }
     }
-    out[int64_t(blockIdx.z) * out_fs + int64_t(pc) * h * w + i] = acc;
+    out[int64_t(frame) * out_fs + J.outOff + int64_t(pc) * h * w + i] = acc;
 }
 
 // ------------------------------------------------------------------------
