@@ -110,6 +110,9 @@ PIPELINES = {
     "rgb_inria": (112, 96, "rgb", 3, 21, dict(name="INRIA", nTrees=64, seed=5, cascThr=-0.6)),
     "gray_face64": (96, 128, "gray", 1, 23, dict(name="FACE64", nTrees=64, seed=7, modelDs_h=32, modelDs_w=32, modelDsPad_h=32, modelDsPad_w=32, minDs_h=32, minDs_w=32)),
     "depth0": (72, 96, "luv", 3, 29, dict(name="TINY", nTrees=80, seed=9, treeDepth=0)),
+    # LDCF post-stage (BASELINE cfg 5; no reference counterpart): the frozen oracle output doubles as a regression vector
+    "ldcf_k3": (96, 128, "luv", 3, 31, dict(name="TINY", nTrees=64, seed=3, ldcfK=3, modelDs_h=32, modelDs_w=32, modelDsPad_h=32, modelDsPad_w=32,
+                                           minDs_h=32, minDs_w=32, cascThr=-2.0)),
 }
 
 
@@ -121,17 +124,24 @@ def pipelines():
         frame = synth.make_frame(fseed, H, W, kind)
         plan = ob.Plan(model, H, W, d_in)
         pyr, _, _ = ob.chns_pyramid(plan, frame)
-        det, hits = ob.detect(plan, pyr)
+        extra = {}
+        if int(model.get("ldcfK", 0)) > 0:
+            lvL, pyrL, _ = ob.ldcf(plan, pyr)
+            det, hits = ob.detect_ldcf(plan, lvL, pyrL)
+            extra = dict(ldcf_filters=model["ldcfFilters"], ldcf_pyramid=pyrL,
+                         ldcf_geom=np.asarray([(lvL[i].hP, lvL[i].wP, lvL[i].nWinR, lvL[i].nWinC, lvL[i].offset) for i in range(plan.nScales)], dtype=np.int64))
+        else:
+            det, hits = ob.detect(plan, pyr)
         lv = plan.levels
         out = dict(
             H=np.int32(H), W=np.int32(W), d_in=np.int32(d_in), frame=frame,
             fids=model["fids"], thrs=model["thrs"], hs=model["hs"], child=model["child"],
-            opts_json=np.asarray(json.dumps({k: v for k, v in sorted(model.items()) if k not in ("fids", "thrs", "hs", "child")})),
+            opts_json=np.asarray(json.dumps({k: v for k, v in sorted(model.items()) if k not in ("fids", "thrs", "hs", "child", "ldcfFilters")})),
             scales=np.asarray([lv[i].scale for i in range(plan.nScales)]),
             scaleshw=np.asarray([(lv[i].scalehw_h, lv[i].scalehw_w) for i in range(plan.nScales)]),
             level_geom=np.asarray([(lv[i].isReal, lv[i].realIndex, lv[i].hC, lv[i].wC, lv[i].hP, lv[i].wP, lv[i].nWinR, lv[i].nWinC, lv[i].offset)
                                    for i in range(plan.nScales)], dtype=np.int64),
-            pyramid=pyr, det=det, hits=hits)
+            pyramid=pyr, det=det, hits=hits, **extra)
         assert len(det) > 0, name
         np.savez_compressed(os.path.join(HERE, "pipeline_%s.npz" % name), **out)
         print(name, "levels", plan.nScales, "pyramid floats", pyr.size, "detections", len(det))

@@ -17,7 +17,7 @@ from acf_amd import capi
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 F = capi.fptr
-PIPES = ["tiny_luv", "rgb_inria", "gray_face64", "depth0"]
+PIPES = ["tiny_luv", "rgb_inria", "gray_face64", "depth0", "ldcf_k3"]
 # _mm_rsqrt_ps / _mm_rcp_ps: relative error <= 1.5 * 2^-12 each (Intel SDM); gradMag chains both
 RCP = 1.5 * 2.0 ** -12
 
@@ -36,6 +36,8 @@ def load_pipeline(name):
     model = json.loads(str(z["opts_json"]))
     for k in ("fids", "thrs", "hs", "child"):
         model[k] = z[k]
+    if "ldcf_filters" in z.files:
+        model["ldcfFilters"] = z["ldcf_filters"]
     return z, model
 
 
@@ -89,7 +91,14 @@ def test_oracle_matches_pipeline_golden(oracle, name):
     assert np.array_equal(geom, z["level_geom"])
     pyr, _, _ = oracle.chns_pyramid(plan, z["frame"])
     assert np.array_equal(bits(pyr), bits(z["pyramid"]))
-    det, hits = oracle.detect(plan, pyr)
+    if "ldcf_pyramid" in z.files:
+        lvL, pyrL, _ = oracle.ldcf(plan, pyr)
+        assert np.array_equal(bits(pyrL), bits(z["ldcf_pyramid"]))
+        g = np.asarray([(lvL[i].hP, lvL[i].wP, lvL[i].nWinR, lvL[i].nWinC, lvL[i].offset) for i in range(plan.nScales)], dtype=np.int64)
+        assert np.array_equal(g, z["ldcf_geom"])
+        det, hits = oracle.detect_ldcf(plan, lvL, pyrL)
+    else:
+        det, hits = oracle.detect(plan, pyr)
     assert det.tobytes() == z["det"].tobytes() and hits.tobytes() == z["hits"].tobytes()
 
 
@@ -156,6 +165,11 @@ def test_hip_pipeline_matches_golden(name):
     det.run(fr)
     for f in (0, 1):
         assert np.array_equal(bits(det.read_pyramid(f)), bits(z["pyramid"]))
+        if "ldcf_pyramid" in z.files:
+            from acf_amd import capi
+            nCk = det.nChns * int(model["ldcfK"])
+            got = np.concatenate([det.read_tap(f, capi.TAP_LDCF, i, (nCk, int(g[1]), int(g[0]))).ravel() for i, g in enumerate(z["ldcf_geom"])])
+            assert np.array_equal(bits(got), bits(z["ldcf_pyramid"]))
         d, h = det.detections(f)
         assert d.tobytes() == z["det"].tobytes() and h.tobytes() == z["hits"].tobytes()
     det.close()
