@@ -61,12 +61,18 @@ struct CascState
     bool useTiles = false;
     CascTile* d_tiles = nullptr;
     int nTiles = 0;
-    TreeNode* d_tileNodes = nullptr; // offsets in the tile's LDS layout, trees [0, tEnd)
+    TreeNode* d_tileNodes = nullptr; // offsets in the tile's LDS layout, every tree
+    uint32_t* d_tileNodesS = nullptr; // stage A of k_cascade_tile2: 40 dwords per batch of four trees
+    bool tile2 = false;               // k_cascade_tile2 (one window per lane in stage A, two survivor lists)
+    int aTB = 4;                      // trees per stage-A batch of k_cascade_tile2
     TreeNode* d_tailNodes = nullptr; // offsets = feature ids (window-local layout), all trees
     TileGeom geom{};
     int tailWaves = 0;
     float* d_tailScratch = nullptr; // k_cascade_tail3 leaf matrices: [blocks][tailWaves][TAIL_G][tailPad]
     int tailPad = 0, tailSlab = 0, tailBlocks = 0, tailNodesLds = 0;
+    // k_tail_codes / k_tail_scan (trees stationary, windows streaming): leaf codes of the first codeCap queue entries per frame
+    uint8_t* d_tailCodes = nullptr;
+    int codeCap = 0, codePitch = 0, codeBpw = 0, codeDpw = 0;
 };
 
 struct acf_hip_ctx
@@ -1033,7 +1039,13 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         // stage boundaries (kernels.hip.h): A [0,16), B [16,32), C [32,64) one lane per window (node table in LDS);
         // D [64,128) one wave per window.  PMC (SQ_INSTS_VALU) showed stage D's ordered 64-step scans were 2/3 of the
         // kernel's VALU work when ~40 windows per tile reached it at tree 32; at tree 64 only ~2.5 do.
-        int bounds[5] = { 0, 16, 32, 64, 128 };
+        // (k_cascade_tile2, measured at cfg 2: 32 dense trees then sparse pieces [32,64) and [64,128) is 10 % faster than
+        // 16 / 32 / 64 / 128: the sparse stages are latency chains, the dense stage is VALU work)
+        int bounds[5] = { 0, 32, 32, 64, 128 };
+        if (getenv("ACF_HIP_TILE1"))
+        {
+            bounds[1] = 16;
+        }
         if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
         {
             int v1, v2, v3, v4;
@@ -1056,11 +1068,13 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         {
             W = atoi(e) == 2 ? 2 : 1; // measured: W = 2 halves the LDS node traffic but stage A is chain-latency bound, and fewer waves slow stage D
         }
+        const bool tile2 = W == 1 && !getenv("ACF_HIP_TILE1"); // A/B: ACF_HIP_TILE1 keeps round 1's k_cascade_tile
         auto ldsBytes = [&](int nw) {
             const int tc = nw * W * 64 / g.TR;
             const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
             const int64_t rowsP = (rows + 3) / 4 * 4;
-            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * W * 64 * 8 + int64_t(48) * g.b[3];
+            // k_cascade_tile2: footprint + two survivor lists; k_cascade_tile: footprint + one list + the node table of [0, b3)
+            return int64_t(nChns) * rowsP * cols * 4 + (tile2 ? int64_t(2) * nw * 64 * 8 + 64 : int64_t(nw) * W * 64 * 8 + int64_t(48) * g.b[3]);
         };
         int nw = 0;
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
@@ -1128,7 +1142,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             }
             if (ok)
             {
-                std::vector<TreeNode> tileNodes(size_t(std::max(g.b[4], 1))), tailNodes(size_t(p.nTrees));
+                std::vector<TreeNode> tileNodes(size_t(std::max(p.nTrees, 1))), tailNodes(size_t(p.nTrees));
                 for (int t = 0; t < p.nTrees; t++)
                 {
                     const size_t q = size_t(t) * p.nTreeNodes;
@@ -1145,11 +1159,34 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     {
                         a.hs[k] = b.hs[k] = c->hs[q + 3 + k];
                     }
-                    if (t < g.b[4])
-                    {
-                        tileNodes[size_t(t)] = a;
-                    }
+                    tileNodes[size_t(t)] = a;
                     tailNodes[size_t(t)] = b;
+                }
+                // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
+                const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && !getenv("ACF_HIP_TILE_TB4")) ? 8 : 4;
+                std::vector<uint32_t> nodesS(size_t(std::max(g.b[1] / aTB, 1)) * 10 * aTB, 0u);
+                for (int t = 0; t + aTB - 1 < g.b[1]; t += aTB)
+                {
+                    uint32_t* d = nodesS.data() + size_t(t / aTB) * 10 * aTB;
+                    for (int q = 0; q < aTB; q++)
+                    {
+                        const TreeNode& nd = tileNodes[size_t(t + q)];
+                        for (int k = 0; k < 3; k++)
+                        {
+                            d[3 * q + k] = nd.off[k];
+                            memcpy(&d[3 * aTB + 3 * q + k], &nd.thr[k], 4);
+                        }
+                        for (int k = 0; k < 4; k++)
+                        {
+                            memcpy(&d[6 * aTB + 4 * q + k], &nd.hs[k], 4);
+                        }
+                    }
+                }
+                cs.aTB = aTB;
+                cs.tile2 = tile2;
+                if ((rc = devUpload(c, &cs.d_tileNodesS, nodesS)))
+                {
+                    return rc;
                 }
                 cs.geom = g;
                 cs.tailWaves = tw;
@@ -1172,6 +1209,37 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
                 {
                     return rc;
+                }
+                cs.codeCap = 0;
+                if (g.b[4] < p.nTrees && (mH % 4 == 0 || tile2) && !getenv("ACF_HIP_TAIL3"))
+                {
+                    // k_tail_codes: 64-tree batches per wave (1, 2 or 4; more trees than 16 waves x 4 batches x 64 take extra
+                    // passes), LDS-DMA instructions per wave per footprint (1 KB each; footprints above 32 KB keep the old tail)
+                    const int nT = p.nTrees - g.b[4], nB = (nT + 63) / 64;
+                    const int bpw = nB <= TC_NW ? 1 : (nB <= 2 * TC_NW ? 2 : 4);
+                    const int chunks = g.winFloats / 4, dpw = (chunks + TC_NW * 64 - 1) / (TC_NW * 64);
+                    if (dpw <= 2 || tile2)
+                    {
+                        const int per = TC_NW * bpw * 64;
+                        cs.codeBpw = bpw;
+                        cs.codeDpw = dpw;
+                        cs.codePitch = (nT + per - 1) / per * per;
+                        int64_t nWinTotal = 0;
+                        for (const auto& l : lv)
+                        {
+                            nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
+                        }
+                        // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
+                        // images), at most 256 MB for the batch; whatever is beyond goes to k_cascade_tail3
+                        int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
+                        cap = std::min(cap, std::max<int64_t>((int64_t(256) << 20) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
+                        cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
+                        cs.codeCap = int(cap);
+                        if ((rc = devAlloc(c, &cs.d_tailCodes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch))))
+                        {
+                            return rc;
+                        }
+                    }
                 }
                 cs.nTiles = int(tiles.size());
                 if ((rc = devUpload(c, &cs.d_tiles, tiles)) || (rc = devUpload(c, &cs.d_tileNodes, tileNodes)) || (rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
@@ -2365,6 +2433,8 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.nTrees = p.nTrees;
     a.g = g;
     a.tileNodes = cs.d_tileNodes;
+    a.tileNodesS = cs.d_tileNodesS;
+    a.aTB = cs.aTB;
     a.tailNodes = cs.d_tailNodes;
     a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
     a.q = cs.d_queue[0];
@@ -2378,6 +2448,9 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.tailPad = cs.tailPad;
     a.tailSlab = cs.tailSlab;
     a.tailNodesLds = cs.tailNodesLds;
+    a.tailCodes = cs.d_tailCodes;
+    a.codeCap = cs.codeCap;
+    a.codePitch = cs.codePitch;
     static const int cascDebug = getenv("ACF_HIP_CASC_DEBUG") ? atoi(getenv("ACF_HIP_CASC_DEBUG")) : 0; // timing experiments (profiles/ab_*.sh)
     a.debug = cascDebug;
     if (a.debug & 12)
@@ -2391,10 +2464,27 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         const int64_t total = int64_t(cs.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[3];
+        const size_t lds = cs.tile2 ? size_t(g.tileFloats) * 4 + size_t(2) * g.NW * 64 * 8 : size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[3];
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");
+        if (cs.tile2)
+        {
+#define TILE2_LAUNCH(N)                                                                           \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N>), lds)))              \
+        return rc;                                                                                \
+    hipLaunchKernelGGL((k_cascade_tile2<N>), grid, block, lds, c->stream, a);
+            switch (g.NW)
+            {
+                case 8: TILE2_LAUNCH(8); break;
+                case 4: TILE2_LAUNCH(4); break;
+                case 2: TILE2_LAUNCH(2); break;
+                default: TILE2_LAUNCH(1); break;
+            }
+#undef TILE2_LAUNCH
+        }
+        else
+        {
 #define TILE_LAUNCH(N, WW)                                                                           \
     if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N, WW>), lds)))              \
         return rc;                                                                                   \
@@ -2410,6 +2500,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             default: TILE_LAUNCH(1, 2); break;
         }
 #undef TILE_LAUNCH
+        }
         LAUNCHCHK(c, "k_cascade_tile");
         if (a.debug & 4)
         {
@@ -2434,9 +2525,46 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
                     nb++;
                 }
             }
-            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles   (stage A wave 0: node reads %.0f, feature reads %.0f, resolve %.0f)\n", nb,
+            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles   (tile2, since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
                 acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
             (void)hipFree(a.stamps);
+        }
+        if (g.b[4] < p.nTrees && cs.codeCap > 0)
+        {
+            // first codeCap queue entries of every frame: leaf codes (trees in registers, windows streamed), then the ordered scan
+            // workgroups per frame: two per CU over the batch, and at most 1024 windows each (their descriptors live in LDS)
+            const int K = std::max(std::max(1, 512 / nF), (cs.codeCap + 1023) / 1024);
+            const size_t ldsC = size_t(TC_NBUF) * cs.codeDpw * TC_NW * 64 * 16 + size_t((cs.codeCap + K - 1) / K) * 16;
+            const void* kc = nullptr;
+            switch (cs.codeBpw * 4 + cs.codeDpw)
+            {
+                case 1 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<1, 1>); break;
+                case 2 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<2, 1>); break;
+                case 4 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<4, 1>); break;
+                case 1 * 4 + 2: kc = reinterpret_cast<const void*>(&k_tail_codes<1, 2>); break;
+                case 2 * 4 + 2: kc = reinterpret_cast<const void*>(&k_tail_codes<2, 2>); break;
+                default: kc = reinterpret_cast<const void*>(&k_tail_codes<4, 2>); break;
+            }
+            int rc = allowLds(c, kc, ldsC);
+            if (rc)
+            {
+                return rc;
+            }
+            if (!cs.tile2) // k_cascade_tile2 wrote the codes itself (stage E)
+            {
+                prof(c, "k_tail_codes");
+                void* kargs[] = { &a };
+                HIPCHK(c, hipLaunchKernel(kc, dim3(K * nF), dim3(TC_NW * 64), kargs, ldsC, c->stream));
+                LAUNCHCHK(c, "k_tail_codes");
+            }
+            const size_t ldsS = size_t(p.nTrees - g.b[4]) * 16;
+            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_tail_scan), ldsS)))
+            {
+                return rc;
+            }
+            prof(c, "k_tail_scan");
+            hipLaunchKernelGGL(k_tail_scan, dim3(nF * ((cs.codeCap + 255) / 256)), dim3(256), ldsS, c->stream, a);
+            LAUNCHCHK(c, "k_tail_scan");
         }
         if (g.b[4] < p.nTrees)
         {

@@ -3123,7 +3123,9 @@ struct TileArgs
     const CascTile* tiles;
     int32_t nTiles, nFrames, nChns, mH, mW, nTrees;
     TileGeom g;
-    const TreeNode* tileNodes;
+    const TreeNode* tileNodes;   // tile-layout offsets of every tree
+    const uint32_t* tileNodesS;  // k_cascade_tile2 stage A: 10 * aTB dwords per batch of aTB trees {off[aTB][3], thr[aTB][3], hs[aTB][4]}
+    int32_t aTB;                 // trees per stage-A batch (4 or 8)
     const TreeNode* tailNodes;
     float cascThr;
     // tail queue [frame][qcap] {(level << 24) | window, h bits}; qcount[frame], qhead[frame]
@@ -3140,6 +3142,9 @@ struct TileArgs
     float* tailScratch;
     int32_t tailPad, tailSlab;
     int32_t tailNodesLds; // the tail's node table fits in LDS next to the footprint slabs (floats reserved at the start of LDS, else 0)
+    // k_tail_codes / k_tail_scan: leaf codes [frame][codeCap][codePitch] bytes (4 * leaf index of every tail tree of a queued window)
+    uint8_t* tailCodes;
+    int32_t codeCap, codePitch;
 };
 
 // Keep scalar / vector values materialised at this point: stops the compiler from
@@ -3723,6 +3728,527 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
     TILE_STAMP(4);
 }
 
+// ------------------------------------------------------------------------
+// k_cascade_tile2: the tile kernel with (i) stage A's node records on the scalar unit, (ii) item-parallel sparse
+// stages and (iii) the tail's leaf codes computed while the tile is still in LDS.
+//
+// What the round-1 kernel (k_cascade_tile above) spent per 512-window tile, from its own phase stamps: fill 4.5k
+// cycles, stage A (16 trees, every lane) 5.9k, the list stages B+C 9.0k, stage D 2.4k.
+//  * Stage A was bound by LDS bandwidth, and 10 of its 16 LDS cycles per tree and wave were the NODE reads (every
+//    wave re-reads the same 40 bytes per tree as 64-lane broadcasts).  Here a batch of four trees is 160 contiguous
+//    bytes read with s_load (scalar cache, no LDS, no VALU); the next batch's offsets are requested while the current
+//    batch's feature reads are in flight.
+//  * B, C, D walked their trees one lane per surviving window: 2, then 1, then a fraction of a wave doing 16 + 32 + 64
+//    dependent LDS round trips while the other waves of the workgroup (and its 73 KB of LDS) idled.  A leaf does not
+//    depend on the running score, so a stage is now ITEMS = survivors x trees: TL lanes per window (TL = 16, 32, 64
+//    trees), every lane one tree, all leaves of a round in two LDS round trips.  The score is then accumulated in tree
+//    order ACROSS the TL lanes with a DPP chain (lane j takes lane j-1's prefix and adds its own leaf: the additions
+//    and their order are evaluate()'s, acfDetect1.cpp:123-138), and a window survives when every prefix stays above
+//    cascThr.
+//  * The ~930 windows per 1080p frame that outlive tree 128 used to be re-fetched from HBM as 16 KB footprints by the
+//    tail kernel (k_cascade_tail3: 11.5 us per frame; k_tail_codes: 5.5 us, bound by those 80-byte column runs).  Their
+//    features are in this tile already: stage E evaluates every remaining tree for them (lanes = trees, nodes streamed
+//    from L2 once per tile, not per window) and writes one code byte per tree; k_tail_scan finishes them.
+// ------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) uint32_t* cu32p_t;
+
+// Stage A.  tab: per batch of TB trees 10 * TB dwords {off[TB][3], thr[TB][3], hs[TB][4]} (host: buildCascadeTables).
+// All 3 * TB feature reads of a batch are issued before anything is resolved; the thresholds and leaf values arrive
+// (s_load) while those reads are in flight, and the next batch's offsets while this batch is resolved.
+template <int TB>
+__device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
+{
+    cu32p_t p = (cu32p_t)(uintptr_t)tab;
+    uint32_t o[3 * TB];
+#pragma unroll
+    for (int i = 0; i < 3 * TB; i++)
+    {
+        o[i] = p[i];
+    }
+    unsigned long long aliveM = ~0ull;
+    for (int b = 0; b < nBatches; b++)
+    {
+        float f[3 * TB];
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            f[i] = win[o[i]];
+        }
+        cu32p_t pb = p + 10 * TB * b;
+        uint32_t th[3 * TB], hv4[4 * TB];
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            th[i] = pb[3 * TB + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * TB; i++)
+        {
+            hv4[i] = pb[6 * TB + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            ACF_PIN_V(f[i]);
+        }
+        cu32p_t pn = p + 10 * TB * min(b + 1, nBatches - 1);
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            o[i] = pn[i];
+        }
+#pragma unroll
+        for (int g = 0; g < TB; g++)
+        {
+            // Thresholds are compared straight from SGPRs (one scalar operand per VALU instruction on gfx9); all three
+            // compares produce wave masks, the child's outcome is combined on the scalar unit, and the leaf is three
+            // v_cndmask with those masks: 12 VALU instructions per tree besides the three address adds.
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * g] < __uint_as_float(th[3 * g]));
+            const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * g + 1] < __uint_as_float(th[3 * g + 1]));
+            const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * g + 2] < __uint_as_float(th[3 * g + 2]));
+            const unsigned long long m1 = (m0 & mA) | (~m0 & mB);
+            float A, B, C, D, x, y, hv;
+            asm("v_mov_b32 %0, %1" : "=v"(A) : "s"(hv4[4 * g]));
+            asm("v_mov_b32 %0, %1" : "=v"(B) : "s"(hv4[4 * g + 1]));
+            asm("v_mov_b32 %0, %1" : "=v"(C) : "s"(hv4[4 * g + 2]));
+            asm("v_mov_b32 %0, %1" : "=v"(D) : "s"(hv4[4 * g + 3]));
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(B), "v"(A), "s"(m1));
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(y) : "v"(D), "v"(C), "s"(m1));
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hv) : "v"(y), "v"(x), "s"(m0));
+            h = h + hv; // a rejected window's score is never read again
+            aliveM &= __builtin_amdgcn_ballot_w64(h > thrC);
+        }
+    }
+    alive = alive && ((aliveM >> (threadIdx.x & 63)) & 1ull);
+}
+
+// one tree at a time through the TreeNode table (stage A trees beyond the last full batch of four)
+__device__ __forceinline__ void tile_eval_s1(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h, bool& alive)
+{
+    for (int t = t0; t < t1; t++)
+    {
+        cptr4_t np = (cptr4_t)(uintptr_t)(nodes + t);
+        const u32x4 o = np[0], tq = np[1], hq = np[2];
+        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
+        ACF_PIN_V(f0);
+        ACF_PIN_V(f1);
+        ACF_PIN_V(f2);
+        const bool lt0 = f0 < __uint_as_float(tq.x);
+        const float fc = lt0 ? f1 : f2;
+        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+        const bool lt1 = fc < th1;
+        const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
+        const float hn = h + hv;
+        h = hn;
+        alive = alive && (hn > thrC);
+    }
+}
+
+// Survivors of the last tile stage -> hits (model exhausted) or the frame's tail queue; returns the queue slot / hit index
+// of this lane's entry (-1: not emitted).  One global atomic per wave.
+__device__ __forceinline__ int tile_emit2(const TileArgs& a, bool final_, int frame, bool alive, int lvl, int n, int nWinR, float h)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (!mask)
+    {
+        return -1;
+    }
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0)
+    {
+        base = atomicAdd((final_ ? a.counts : a.qcount) + frame, __popcll(mask));
+    }
+    base = __shfl(base, 0);
+    int idx = -1;
+    if (alive)
+    {
+        idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (final_)
+        {
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = n / nWinR;
+                hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+        else if (idx < a.qcap)
+        {
+            a.q[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
+        }
+    }
+    return idx;
+}
+
+struct TileCtx
+{
+    const float* tileF;
+    int step, rowsP, TR;
+    float thrC;
+    int frame, lvl, r0, c0, nWinR;
+};
+
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) // lane l <- lane l - N of its 16-lane row (0 where there is none)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_bcast15(float v) // every lane of row r <- lane 15 of row r-1 (row 0 keeps its own)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xf, 0xf, false));
+}
+
+// a <- a + (leaf of lane j of this row), j = 0..15 in order, in lane 15 of every row; m <- min of the prefixes.  The DPP
+// operand is the leaf, not the running sum, so the chain is 16 dependent v_add and nothing else.
+#define ACF_ROW_STEP(N)                                                     \
+    a = a + dpp_row_shr<N>(leaf);                                           \
+    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(a));
+__device__ __forceinline__ void row_chain(float leaf, float& a, float& m)
+{
+    ACF_ROW_STEP(15) ACF_ROW_STEP(14) ACF_ROW_STEP(13) ACF_ROW_STEP(12) ACF_ROW_STEP(11) ACF_ROW_STEP(10) ACF_ROW_STEP(9) ACF_ROW_STEP(8)
+    ACF_ROW_STEP(7) ACF_ROW_STEP(6) ACF_ROW_STEP(5) ACF_ROW_STEP(4) ACF_ROW_STEP(3) ACF_ROW_STEP(2) ACF_ROW_STEP(1)
+    a = a + leaf;
+    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(a));
+}
+#undef ACF_ROW_STEP
+
+struct SparseNode
+{
+    uint32_t o0, o1, o2;
+    float t0, t1, t2, h0, h1, h2, h3;
+};
+
+// this lane's tree of a sparse stage over [t0, t0 + T) with 2^tlShift lanes per window (clamped: lanes past T are masked)
+__device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ nodes, int t0, int T, int tlShift)
+{
+    const int pos = int(threadIdx.x & 63) & ((1 << tlShift) - 1);
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + t0 + min(pos, max(T, 1) - 1));
+    const uint4 o = np[0], tq = np[1], hq = np[2];
+    SparseNode n;
+    n.o0 = o.x;
+    n.o1 = o.y;
+    n.o2 = o.z;
+    n.t0 = __uint_as_float(tq.x);
+    n.t1 = __uint_as_float(tq.y);
+    n.t2 = __uint_as_float(tq.z);
+    n.h0 = __uint_as_float(hq.x);
+    n.h1 = __uint_as_float(hq.y);
+    n.h2 = __uint_as_float(hq.z);
+    n.h3 = __uint_as_float(hq.w);
+    return n;
+}
+
+// One sparse stage over trees [t0, t0 + T), T <= 64: TL = 2^tlShift >= T lanes per listed window, every lane one tree.
+// The score is accumulated in tree order by lane 15 of each 16-lane row (row_chain), rows of one window in sequence
+// (row_bcast:15 hands the prefix to the next row).  Lanes past T contribute +0.0f: h is a sum that starts at +0.0f, so
+// it is never -0.0f and h + 0.0f == h bit for bit.  `last`: survivors go to the hit list / tail queue (their
+// {tag, slot} to lout for stage E), else {tag, h} to lout.  The caller separates stages with a barrier.
+template <int NW>
+__device__ __forceinline__ void tile_sparse_stage(const TileArgs& a, const TileCtx& X, const uint2* lin, int nIn, uint2* lout, int* cntOut, const SparseNode& nd,
+    int T, int tlShift, bool last, bool lastAll)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int TL = 1 << tlShift, G = 64 >> tlShift, K = TL >> 4;
+    const int pos = lane & (TL - 1), g = lane >> tlShift;
+    const int rowInWin = (lane >> 4) & (K - 1);
+    const bool act = pos < T;
+    // the node in registers, opaquely: otherwise `c ? nd.x : nd.y` becomes a load from a selected address of the struct,
+    // which keeps the struct in scratch memory
+    uint32_t o0 = nd.o0, o1 = nd.o1, o2 = nd.o2;
+    float t0 = nd.t0, t1 = nd.t1, t2 = nd.t2, h0 = nd.h0, h1 = nd.h1, h2 = nd.h2, h3 = nd.h3;
+    ACF_PIN_V(o0);
+    ACF_PIN_V(o1);
+    ACF_PIN_V(o2);
+    ACF_PIN_V(t0);
+    ACF_PIN_V(t1);
+    ACF_PIN_V(t2);
+    ACF_PIN_V(h0);
+    ACF_PIN_V(h1);
+    ACF_PIN_V(h2);
+    ACF_PIN_V(h3);
+    for (int base = wv * G; base < nIn; base += NW * G)
+    {
+        const int wi = base + g;
+        const bool valid = wi < nIn;
+        const uint2 e = lin[valid ? wi : base];
+        const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
+        const float* win = X.tileF + (cl * X.step) * X.rowsP + rl * X.step;
+        const float f0 = win[o0];
+        const bool lt0 = f0 < t0;
+        const float fc = win[lt0 ? o1 : o2];
+        const float th1 = lt0 ? t1 : t2;
+        const bool lt1 = fc < th1;
+        float leaf = lt0 ? (lt1 ? h0 : h1) : (lt1 ? h2 : h3);
+        leaf = act ? leaf : 0.f;
+        const float hin = __uint_as_float(e.y);
+        float acc = hin, mm = hin;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if (k < K) // wave-uniform
+            {
+                float sa = k == 0 ? hin : dpp_row_bcast15(acc);
+                float sm = k == 0 ? hin : dpp_row_bcast15(mm);
+                row_chain(leaf, sa, sm);
+                const bool mine = rowInWin == k;
+                acc = mine ? sa : acc;
+                mm = mine ? sm : mm;
+            }
+        }
+        // lane 15 of a window's last row: its final score and the minimum over all its prefixes (evaluate()'s early exit)
+        const bool emitLane = valid && (lane & 15) == 15 && rowInWin == K - 1 && (mm > X.thrC) && (acc > X.thrC);
+        if (last)
+        {
+            const int n = (X.c0 + cl) * X.nWinR + (X.r0 + rl);
+            const int slot = tile_emit2(a, lastAll, X.frame, emitLane, X.lvl, n, X.nWinR, acc);
+            if (!lastAll)
+            {
+                tile_compact(emitLane, int(e.x), __int_as_float(slot), lout, cntOut);
+            }
+        }
+        else
+        {
+            tile_compact(emitLane, int(e.x), acc, lout, cntOut);
+        }
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
+{
+    extern __shared__ float lds[];
+    __shared__ int s_cnt[8];
+    float* tileF = lds;
+    uint2* listA = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
+    uint2* listB = listA + NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
+    const int64_t total = int64_t(a.nTiles) * a.nFrames;
+    const int64_t perX = (total + 7) >> 3;
+    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
+    if (id >= total || (blockIdx.x >> 3) >= perX)
+    {
+        return;
+    }
+    const int frame = int(id / a.nTiles);
+    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+    const int lvl = T.level;
+    const CascLevel L = a.levels[lvl];
+    const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
+    const int gr0 = T.r0 * step, gc0 = T.c0 * step;
+    const int area = L.hP * L.wP;
+    const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+    const int colsValid = min(colsT, L.wP - gc0);
+    if (tid < 8)
+    {
+        s_cnt[tid] = 0;
+    }
+    TILE_STAMP(0);
+    // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
+    {
+        const uint32_t cps = uint32_t(rowsP) >> 2;
+        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
+        const int ccMax = colsValid - 1;
+        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
+        {
+            const uint32_t q = q0 + lane;
+            if (q < nChunks)
+            {
+                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                const uint32_t j = q - seg * cps;
+                const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                const int cc = int(seg - z * uint32_t(colsT));
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(L.hP) + 4u * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    TILE_STAMP(1);
+    const long long tS1 = (a.debug & 4) ? __builtin_amdgcn_s_memtime() : 0;
+#define TILE_STAMP_REL(k)                                                                  \
+    if ((a.debug & 4) && threadIdx.x == 0)                                                  \
+    {                                                                                      \
+        a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime() - tS1;       \
+    }
+
+    TileCtx X;
+    X.tileF = tileF;
+    X.step = step;
+    X.rowsP = rowsP;
+    X.TR = a.g.TR;
+    X.thrC = a.cascThr;
+    X.frame = frame;
+    X.lvl = lvl;
+    X.r0 = T.r0;
+    X.c0 = T.c0;
+    X.nWinR = L.nWinR;
+    const int tEnd = a.g.b[4];
+    const bool lastAll = tEnd == a.nTrees;
+    // nodes of the sparse stages' first pieces: requested now, used after stage A
+    int pT[3], pShift[3];
+    SparseNode pN[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+        pT[k] = min(64, a.g.b[k + 2] - a.g.b[k + 1]);
+        pShift[k] = pT[k] <= 16 ? 4 : (pT[k] <= 32 ? 5 : 6);
+        pN[k] = sparse_node(a.tileNodes, min(a.g.b[k + 1], a.nTrees - 1), pT[k], pShift[k]);
+    }
+    TILE_STAMP_REL(5);
+    // ---- stage A: lanes = windows
+    const int r_l = tid % a.g.TR, c_l = tid / a.g.TR;
+    const int wr = T.r0 + r_l;
+    bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC;
+    float h = 0.f;
+    {
+        const float* win = tileF + (c_l * step) * rowsP + r_l * step;
+        const int nb = a.g.b[1] / a.aTB;
+        if (nb > 0)
+        {
+            if (a.aTB == 8)
+            {
+                tile_eval_s<8>(win, a.tileNodesS, nb, X.thrC, h, alive);
+            }
+            else
+            {
+                tile_eval_s<4>(win, a.tileNodesS, nb, X.thrC, h, alive);
+            }
+        }
+        tile_eval_s1(win, a.tileNodes, nb * a.aTB, a.g.b[1], X.thrC, h, alive);
+    }
+    asm volatile("" ::"v"(h));
+    TILE_STAMP_REL(6);
+    const int tagA = c_l * a.g.TR + r_l;
+    if (a.g.b[1] == tEnd)
+    {
+        const int slot = tile_emit2(a, lastAll, frame, alive, lvl, (T.c0 + c_l) * L.nWinR + wr, L.nWinR, h);
+        if (lastAll)
+        {
+            return;
+        }
+        tile_compact(alive, tagA, __int_as_float(slot), listA, &s_cnt[0]);
+    }
+    else
+    {
+        tile_compact(alive, tagA, h, listA, &s_cnt[0]);
+    }
+    TILE_STAMP_REL(7);
+    __syncthreads();
+    TILE_STAMP(2);
+    // ---- sparse stages over [b1,b2) [b2,b3) [b3,b4), each cut into pieces of at most 64 trees
+    uint2* lin = listA;
+    uint2* lout = listB;
+    int nIn = s_cnt[0];
+    int ci = 1;
+    if (a.g.b[1] < tEnd)
+    {
+#pragma unroll
+        for (int stage = 1; stage <= 3; stage++)
+        {
+            for (int t0 = a.g.b[stage]; t0 < a.g.b[stage + 1]; t0 += 64)
+            {
+                const int Tn = min(64, a.g.b[stage + 1] - t0);
+                const int tlShift = Tn <= 16 ? 4 : (Tn <= 32 ? 5 : 6);
+                const bool last = t0 + Tn == tEnd;
+                if (nIn > 0)
+                {
+                    if (t0 == a.g.b[stage])
+                    {
+                        tile_sparse_stage<NW>(a, X, lin, nIn, lout, &s_cnt[ci & 7], pN[stage - 1], Tn, tlShift, last, lastAll);
+                    }
+                    else
+                    {
+                        const SparseNode nd = sparse_node(a.tileNodes, t0, Tn, tlShift);
+                        tile_sparse_stage<NW>(a, X, lin, nIn, lout, &s_cnt[ci & 7], nd, Tn, tlShift, last, lastAll);
+                    }
+                }
+                __syncthreads();
+                nIn = s_cnt[ci & 7];
+                if (tid == 0)
+                {
+                    s_cnt[(ci + 6) & 7] = 0; // counter of the piece six ahead (read long ago: barriers in between)
+                }
+                ci++;
+                uint2* tmp = lin;
+                lin = lout;
+                lout = tmp;
+            }
+        }
+    }
+    TILE_STAMP(3);
+    if (lastAll || nIn == 0 || a.codeCap <= 0)
+    {
+        TILE_STAMP(4);
+        return;
+    }
+    // ---- stage E: leaf codes of every tail tree for the nIn windows now in the tail queue (lin: {tag, queue slot}).
+    // lanes = trees; a wave takes four 64-tree batches at a time (nodes in registers, their reads of one window's
+    // features issued together), windows in the inner loop: the node stream is read once per tile, not per window.
+    {
+        const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
+        for (int b0 = wv; b0 < nB; b0 += 4 * NW)
+        {
+            uint32_t o0[4], o1[4], o2[4];
+            float t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int b = min(b0 + k * NW, nB - 1);
+                const uint4* np = reinterpret_cast<const uint4*>(a.tileNodes + tEnd + min(b * 64 + lane, nT - 1));
+                const uint4 o = np[0], tq = np[1];
+                o0[k] = o.x;
+                o1[k] = o.y;
+                o2[k] = o.z;
+                t0[k] = __uint_as_float(tq.x);
+                t1[k] = __uint_as_float(tq.y);
+                t2[k] = __uint_as_float(tq.z);
+            }
+            for (int s = 0; s < nIn; s++)
+            {
+                const uint2 e = lin[s];
+                const int slot = int(e.y);
+                if (slot < 0 || slot >= a.codeCap)
+                {
+                    continue; // no code row: k_cascade_tail3 takes this entry
+                }
+                const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
+                const float* win = tileF + (cl * step) * rowsP + rl * step;
+                uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + slot) * a.codePitch + lane;
+                float f0[4], fc[4];
+                bool lt0[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    f0[k] = win[o0[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    lt0[k] = f0[k] < t0[k];
+                    fc[k] = win[lt0[k] ? o1[k] : o2[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const bool lt1 = fc[k] < (lt0[k] ? t1[k] : t2[k]);
+                    if (b0 + k * NW < nB) // wave-uniform
+                    {
+                        row[(b0 + k * NW) * 64] = uint8_t((lt0[k] ? 0 : 8) + (lt1 ? 0 : 4));
+                    }
+                }
+            }
+        }
+    }
+    TILE_STAMP(4);
+}
+
 // Copy one window's footprint (nChns*mW*mH floats, the cids[] index space) from the pyramid level into a wave's LDS
 // slab.  run = z * mW + cc  ->  win[run * mH + rr].
 struct TailFill
@@ -3894,6 +4420,10 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
     float* win = lds + a.tailNodesLds + wv * a.tailSlab;
     const int frame = blockIdx.x % a.nFrames;
     const int cnt = min(a.qcount[frame], a.qcap);
+    if (a.qhead[frame] >= cnt) // nothing left in this frame's queue (k_tail_scan took it all): skip the node-table preload
+    {
+        return;
+    }
     const int tEnd = a.g.b[4];
     const int nT = a.nTrees - tEnd;
     const int pad = a.tailPad;
@@ -4083,6 +4613,306 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
                 hit.score = h;
                 a.hits[int64_t(frame) * a.maxHits + idx] = hit;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// Tail stage [tEnd, nTrees), trees stationary / windows streaming (replaces k_cascade_tail3 for the first codeCap
+// queue entries of a frame; k_cascade_tail3 takes whatever is beyond).
+//
+// The few windows that reach the tail (~930 of 662,799 per 1080p frame) each walk up to ~1900 more trees.  Which LEAF
+// a tree selects does not depend on the running score — only the early exit does (acfDetect1.cpp:123-138) — so the
+// tail is split into
+//   k_tail_codes   every tail tree of every queued window -> one byte, 4 * (leaf index - 3).  A workgroup of 16 waves
+//                  keeps 64 * BPW trees per wave in REGISTERS (feature offsets and thresholds of its trees, loaded
+//                  once) and streams the windows of one frame's queue through a ring of TC_NBUF footprint slabs in LDS
+//                  (LDS-DMA, 16-byte chunks, three fills in flight behind the window being evaluated: counted vmcnt,
+//                  raw s_barrier).  Per window a wave does BPW x {root read, child read, two compares, one byte store}:
+//                  no node traffic at all, every window costs the same, so the queue is dealt statically.
+//   k_tail_scan    lanes = windows: h = h + hs[leaf] strictly in tree order, 16 code bytes per 16-byte load, the leaf
+//                  values of tree t read from an LDS table at [t][code] (all lanes of a wave hit the same 16 bytes);
+//                  a lane dies at the first prefix <= cascThr.  Scores are bit-identical to evaluate()'s.
+// ------------------------------------------------------------------------
+constexpr int TC_NW = 16;
+constexpr int TC_NBUF = 4;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BPW, int DPW> // BPW: 64-tree batches per wave; DPW: LDS-DMA instructions per wave per footprint
+__global__ void __launch_bounds__(TC_NW * 64) k_tail_codes(TileArgs a)
+{
+    extern __shared__ float lds[]; // TC_NBUF slabs of DPW * TC_NW * 64 * 4 floats
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int frame = blockIdx.x % a.nFrames, j0 = blockIdx.x / a.nFrames, K = gridDim.x / a.nFrames;
+    const int cnt = min(min(a.qcount[frame], a.qcap), a.codeCap);
+    const int nMine = j0 < cnt ? (cnt - j0 + K - 1) / K : 0; // windows j0, j0 + K, ...
+    if (nMine == 0)
+    {
+        return;
+    }
+    const int tEnd = a.g.b[4], nT = a.nTrees - tEnd;
+    constexpr int slabFloats = DPW * TC_NW * 64 * 4;
+    const int mH = a.mH, mW = a.mW;
+    const uint32_t cps = uint32_t(mH) >> 2, nChunks = uint32_t(a.nChns * mW) * cps;
+    const uint32_t cpsMagic = uint32_t(((uint64_t(1) << 32) + cps - 1) / cps);
+    const uint32_t mwMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(mW) - 1) / uint32_t(mW));
+    // this lane's chunks of a footprint (the same for every window): chunk q = floats [4q, 4q+4) of the window's cids[] index
+    // space, run = q / cps = z * mW + cc.  Lanes past the last chunk re-copy the last chunk into the slab's padding.
+    uint32_t zq[DPW], ccq[DPW], jq[DPW];
+#pragma unroll
+    for (int d = 0; d < DPW; d++)
+    {
+        const uint32_t q = min(uint32_t((d * TC_NW + wv) * 64 + lane), nChunks - 1u);
+        const uint32_t run = cps == 1 ? q : __umulhi(q, cpsMagic);
+        jq[d] = q - run * cps;
+        zq[d] = mW == 1 ? run : __umulhi(run, mwMagic);
+        ccq[d] = run - zq[d] * uint32_t(mW);
+    }
+    // Per-window source descriptors {float offset of the window's first cell (64 bit), hP, area}, built once by the whole
+    // workgroup into LDS: inside the streaming loop a fill then costs one broadcast ds_read instead of a chain of two
+    // dependent memory round trips (queue entry -> level record) on every wave's critical path.
+    uint4* desc = reinterpret_cast<uint4*>(lds + TC_NBUF * slabFloats);
+    for (int m = threadIdx.x; m < nMine; m += TC_NW * 64)
+    {
+        const uint32_t ex = a.q[int64_t(frame) * a.qcap + j0 + m * K].x;
+        const CascLevel L = a.levels[ex >> 24];
+        const int n = int(ex & 0xffffffu);
+        const int c = n / L.nWinR, r = n - c * L.nWinR;
+        const int64_t off = int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
+        desc[m] = make_uint4(uint32_t(uint64_t(off)), uint32_t(uint64_t(off) >> 32), uint32_t(L.hP), uint32_t(L.hP) * uint32_t(L.wP));
+    }
+    __syncthreads();
+    auto fill = [&](int m) {
+        const uint4 d4 = desc[m];
+        const float* __restrict__ chn = a.pyr + int64_t(uint64_t(d4.x) | (uint64_t(d4.y) << 32));
+        const uint32_t hP = d4.z, area = d4.w;
+        float* slab = lds + (m % TC_NBUF) * slabFloats;
+#pragma unroll
+        for (int d = 0; d < DPW; d++)
+        {
+            __builtin_amdgcn_global_load_lds((gptr_t)(chn + (zq[d] * area + ccq[d] * hP + 4u * jq[d])),
+                (lptr_t)(slab + 4 * ((d * TC_NW + wv) * 64)), 16, 0, 0);
+        }
+    };
+    for (int tc = 0; tc < nT; tc += TC_NW * BPW * 64) // one pass unless the model has more than 1024 * BPW tail trees
+    {
+        uint32_t o0[BPW], o1[BPW], o2[BPW];
+        float t0[BPW], t1[BPW], t2[BPW];
+#pragma unroll
+        for (int b = 0; b < BPW; b++)
+        {
+            const int tb = tc + (b * TC_NW + wv) * 64;
+            const TreeNode nd = a.tailNodes[tEnd + min(tb + lane, nT - 1)];
+            o0[b] = nd.off[0];
+            o1[b] = nd.off[1];
+            o2[b] = nd.off[2];
+            t0[b] = nd.thr[0];
+            t1[b] = nd.thr[1];
+            t2[b] = nd.thr[2];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the node loads: the counted waits below see only fills and code stores
+        __builtin_amdgcn_s_barrier();                    // every wave is done with the slabs of the previous pass
+#pragma unroll
+        for (int m = 0; m < TC_NBUF - 1; m++)
+        {
+            fill(min(m, nMine - 1)); // a short queue re-copies its last window: the instruction count stays fixed
+        }
+        for (int m = 0; m < nMine; m++)
+        {
+            // fill m is done when at most the fills m+1, m+2 and the code stores of windows m-3 .. m-1 are outstanding
+            const int s = min(m, 3);
+            if (s == 0)
+            {
+                wait_vmcnt<2 * DPW>();
+            }
+            else if (s == 1)
+            {
+                wait_vmcnt<2 * DPW + BPW>();
+            }
+            else if (s == 2)
+            {
+                wait_vmcnt<2 * DPW + 2 * BPW>();
+            }
+            else
+            {
+                wait_vmcnt<2 * DPW + 3 * BPW>();
+            }
+            __builtin_amdgcn_s_barrier(); // all waves' parts of fill m have landed; everyone is done with window m-1
+            fill(min(m + TC_NBUF - 1, nMine - 1));
+            const float* win = lds + (m % TC_NBUF) * slabFloats;
+            uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + (j0 + m * K)) * a.codePitch + tc + wv * 64 + lane;
+            float f0[BPW], fc[BPW];
+            bool lt0[BPW];
+#pragma unroll
+            for (int b = 0; b < BPW; b++)
+            {
+                f0[b] = win[o0[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < BPW; b++)
+            {
+                lt0[b] = f0[b] < t0[b];
+                fc[b] = win[lt0[b] ? o1[b] : o2[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < BPW; b++)
+            {
+                const bool lt1 = fc[b] < (lt0[b] ? t1[b] : t2[b]);
+                // leaf k = 3 + code / 4: lt0 ? (lt1 ? 3 : 4) : (lt1 ? 5 : 6) (getChild, acfDetect1.cpp:100-107)
+                const uint8_t code = uint8_t((lt0[b] ? 0 : 8) + (lt1 ? 0 : 4));
+                // stored unconditionally (a fixed number of stores per window keeps the vmcnt arithmetic exact): batches past the
+                // last tree land in the row's padding
+                row[b * TC_NW * 64] = code;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tail_scan(TileArgs a)
+{
+    extern __shared__ float lds[]; // [nT][4] leaf values of the tail trees
+    const int frame = blockIdx.x % a.nFrames, chunk = blockIdx.x / a.nFrames;
+    const int cnt = min(a.qcount[frame], a.qcap);
+    const int cntC = min(cnt, a.codeCap);
+    if (chunk == 0 && threadIdx.x == 0)
+    {
+        a.qhead[frame] = cntC; // k_cascade_tail3 (launched after this kernel) starts at the first entry without codes
+    }
+    if (chunk * 256 >= cntC)
+    {
+        return;
+    }
+    const int tEnd = a.g.b[4], nT = a.nTrees - tEnd;
+    for (int t = threadIdx.x; t < nT; t += 256)
+    {
+        const float* hs = a.tailNodes[tEnd + t].hs;
+        *reinterpret_cast<float4*>(lds + 4 * t) = make_float4(hs[0], hs[1], hs[2], hs[3]);
+    }
+    __syncthreads();
+    const int i = chunk * 256 + int(threadIdx.x);
+    bool alive = i < cntC;
+    const int ic = min(i, cntC - 1);
+    const uint2 e = a.q[int64_t(frame) * a.qcap + ic];
+    const uint8_t* __restrict__ cp = a.tailCodes + (int64_t(frame) * a.codeCap + ic) * a.codePitch;
+    const float thrC = a.cascThr;
+    float h = __uint_as_float(e.y);
+    float m = h; // running minimum of the prefix scores
+    const char* leafB = reinterpret_cast<const char*>(lds);
+    // 64 trees (four 16-byte code loads) per step, two steps requested ahead: a lane's codes are its own cache lines, so
+    // every load is a full memory round trip and only distance hides it.  The three register sets swap roles in an
+    // unrolled loop: copying a set would wait for the loads that fill it.
+    int tb = 0;
+    uint4 w0[4], w1[4], w2[4];
+#define TS_LOAD(W, T0)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
+    {                                                                                         \
+        W[k] = *reinterpret_cast<const uint4*>(cp + min((T0) + 16 * k, a.codePitch - 16));    \
+    }
+#define TS_STEP(W, T0, NQ)                                                                    \
+    {                                                                                         \
+        const char* lb = leafB + (T0) * 16;                                                   \
+        _Pragma("unroll") for (int q = 0; q < (NQ); q++)                                      \
+        {                                                                                     \
+            const uint4 x = W[q >> 4];                                                        \
+            const uint32_t cw = ((q >> 2) & 3) == 0 ? x.x : (((q >> 2) & 3) == 1 ? x.y : (((q >> 2) & 3) == 2 ? x.z : x.w)); \
+            const uint32_t off = (cw >> (8 * (q & 3))) & 0xffu;                               \
+            h = h + *reinterpret_cast<const float*>(lb + q * 16 + off);                       \
+            asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));                                   \
+        }                                                                                     \
+    }
+#define TS_ROUND(CUR, FAR)                                                                    \
+    if (tb + 64 <= nT && !done)                                                               \
+    {                                                                                         \
+        TS_LOAD(FAR, tb + 128);                                                               \
+        TS_STEP(CUR, tb, 64);                                                                 \
+        alive = alive && (m > thrC) && (h > thrC);                                            \
+        done = __ballot(alive) == 0ull;                                                       \
+        tb += done ? 0 : 64;                                                                  \
+    }
+    TS_LOAD(w0, 0);
+    TS_LOAD(w1, 64);
+    bool done = false;
+    while (tb + 64 <= nT && !done)
+    {
+        TS_ROUND(w0, w2);
+        TS_ROUND(w1, w0);
+        TS_ROUND(w2, w1);
+    }
+    // the set holding the codes of [tb, tb + 64): rounds completed mod 3
+    {
+        const int rr = (tb >> 6) % 3;
+        if (rr == 1)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                w0[k] = w1[k];
+            }
+        }
+        else if (rr == 2)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                w0[k] = w2[k];
+            }
+        }
+    }
+#undef TS_ROUND
+    if (done)
+    {
+        tb = nT; // every lane of the wave is rejected: nothing left to add
+    }
+    if (tb + 64 > nT && tb < nT) // fewer than 64 trees left: w0 holds their codes
+    {
+        const int rem = nT - tb;
+        const char* lb = leafB + tb * 16;
+#pragma unroll
+        for (int q = 0; q < 64; q++)
+        {
+            if (q >= rem)
+            {
+                break;
+            }
+            const uint4 x = w0[q >> 4];
+            const uint32_t cw = ((q >> 2) & 3) == 0 ? x.x : (((q >> 2) & 3) == 1 ? x.y : (((q >> 2) & 3) == 2 ? x.z : x.w));
+            const uint32_t off = (cw >> (8 * (q & 3))) & 0xffu;
+            h = h + *reinterpret_cast<const float*>(lb + q * 16 + off);
+            asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
+        }
+    }
+#undef TS_LOAD
+#undef TS_STEP
+    alive = alive && (m > thrC) && (h > thrC);
+    const unsigned long long mask = __ballot(alive);
+    if (mask)
+    {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0)
+        {
+            base = atomicAdd(a.counts + frame, __popcll(mask));
+        }
+        base = __shfl(base, 0);
+        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (alive && idx < a.maxHits)
+        {
+            const int lvl = int(e.x >> 24);
+            const int n = int(e.x & 0xffffffu);
+            const int nWinR = a.levels[lvl].nWinR;
+            acf_hip_hit hit;
+            hit.scale = lvl;
+            hit.c = n / nWinR;
+            hit.r = n - hit.c * nWinR;
+            hit.score = h;
+            a.hits[int64_t(frame) * a.maxHits + idx] = hit;
         }
     }
 }
