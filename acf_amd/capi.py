@@ -170,6 +170,7 @@ def load():
         "acf_hip_get_levels": ([ctx, C.POINTER(Level), C.c_int], C.c_int),
         "acf_hip_get_ldcf_levels": ([ctx, C.POINTER(Level), C.c_int], C.c_int),
         "acf_hip_pyramid_floats": ([ctx, C.POINTER(C.c_int64)], C.c_int),
+        "acf_hip_get_lambdas": ([ctx, C.c_int, C.POINTER(C.c_double)], C.c_int),
         "acf_hip_pyramid": ([ctx, C.c_void_p, C.c_int], C.c_int),
         "acf_hip_detect": ([ctx], C.c_int),
         "acf_hip_run": ([ctx, C.c_void_p, C.c_int], C.c_int),
@@ -211,7 +212,7 @@ def load():
 DECLARED_SYMBOLS = [
     "acf_hip_create", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
-    "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_pyramid",
+    "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_get_lambdas", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_get_detections", "acf_hip_get_hits",
     "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",

@@ -116,6 +116,11 @@ struct acf_hip_ctx
     float* d_ldcfPyr = nullptr;
 
     Plan plan;
+    // image-specific lambdas (model without lambdas, chnsPyramid.cpp:341-374): per-frame plane sums of two real levels on
+    // the device, the lambdas of every frame of the last batch on the host
+    bool autoLambdas = false;
+    double* d_planeSums = nullptr;     // [maxBatch][2][nChns]
+    std::vector<double> h_lambdas;     // [maxBatch][3]
     int maxBatch = 0, maxHits = 0, lastBatch = 0;
     bool pyramidValid = false, detectValid = false;
 
@@ -1220,7 +1225,8 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     const int chunks = g.winFloats / 4, dpw = (chunks + TC_NW * 64 - 1) / (TC_NW * 64);
                     if (dpw <= 2 || tile2)
                     {
-                        const int per = TC_NW * bpw * 64;
+                        // row pitch: k_cascade_tile2's stage E writes 64-tree batches; k_tail_codes whole passes of 16 waves x bpw batches
+                        const int per = tile2 ? 64 : TC_NW * bpw * 64;
                         cs.codeBpw = bpw;
                         cs.codeDpw = dpw;
                         cs.codePitch = (nT + per - 1) / per * per;
@@ -1230,9 +1236,9 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                             nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
                         }
                         // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
-                        // images), at most 256 MB for the batch; whatever is beyond goes to k_cascade_tail3
+                        // images), at most 1 GB for the batch; whatever is beyond goes to k_cascade_tail3
                         int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
-                        cap = std::min(cap, std::max<int64_t>((int64_t(256) << 20) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
+                        cap = std::min(cap, std::max<int64_t>((int64_t(1) << 30) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
                         cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
                         cs.codeCap = int(cap);
                         if ((rc = devAlloc(c, &cs.d_tailCodes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch))))
@@ -1517,7 +1523,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         double ratio[3];
         for (int j = 0; j < 3; j++)
         {
-            ratio[j] = std::pow(l.scale / lr.scale, -p.lambdas[j]); // :393
+            ratio[j] = std::pow(l.scale / lr.scale, -(p.nLambdas == 3 ? p.lambdas[j] : 0.0)); // :393 (image-specific lambdas: rewritten per frame)
         }
         setResampleGain(dd, ratio, nColor, nColor + nMag);
         dd.nplanes = pl.nChns;
@@ -1529,6 +1535,12 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         c->approxMaxBlocks = std::max(c->approxMaxBlocks, resampleBlocks(dd));
     }
     c->nApproxDescs = int(c->h_descs.size()) - c->nImgDescs;
+    c->autoLambdas = p.nApprox > 0 && p.nLambdas != 3;
+    c->h_lambdas.assign(size_t(B) * 3, 0.0);
+    if (c->autoLambdas && (rc = devAlloc(c, &c->d_planeSums, size_t(B) * 2 * pl.nChns)))
+    {
+        return rc;
+    }
 
     // final smoothing + padding jobs (chnsPyramid.cpp:399-435)
     std::vector<SmoothJob> finalJobs;
@@ -1835,6 +1847,36 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
         return ACF_HIP_E_NOPLAN;
     }
     *n = c->plan.pyr_floats;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_lambdas(acf_hip_ctx* c, int frame, double out[3])
+{
+    if (!c || !out)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (!c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "get_lambdas: frame out of range");
+        }
+        const int k = frame / std::max(c->kidChunk, 1);
+        return acf_hip_get_lambdas(c->kids[size_t(k)], frame - k * c->kidChunk, out);
+    }
+    if (!c->hasPlan || !c->pyramidValid)
+    {
+        return fail(c, ACF_HIP_E_NOPLAN, "get_lambdas: no pyramid");
+    }
+    if (frame < 0 || frame >= c->lastBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "get_lambdas: frame out of range");
+    }
+    for (int j = 0; j < 3; j++)
+    {
+        out[j] = c->h_lambdas[size_t(frame) * 3 + j];
+    }
     return ACF_HIP_OK;
 }
 
@@ -2174,34 +2216,26 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             prof(c, "k_smooth_vec");
             const int nq = rs.h / 4, nt = ((nq + 63) / 64) * 64;
             const size_t ldsB = size_t(4) * nq * sizeof(float);
-            for (int z0 = 0; z0 < d;)
             {
-                const bool full0 = needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z0 == p.colorChn);
-                int z1 = z0 + 1;
-                while (z1 < d && (needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z1 == p.colorChn)) == full0)
+                uint32_t fullMask = 0;
+                for (int z = 0; z < d; z++)
                 {
-                    z1++;
+                    if (needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z == p.colorChn))
+                    {
+                        fullMask |= 1u << z;
+                    }
                 }
-                sa.plane0 = z0;
-                dim3 grid(z1 - z0, 1, nF), block(nt);
-                if (full0 && halfNext)
+                sa.plane0 = 0;
+                dim3 grid(d, 1, nF), block(nt);
+                if (halfNext)
                 {
-                    hipLaunchKernelGGL((k_smooth_vec<true, true, true>), grid, block, ldsB, c->stream, sa);
-                }
-                else if (full0)
-                {
-                    hipLaunchKernelGGL((k_smooth_vec<true, false, true>), grid, block, ldsB, c->stream, sa);
-                }
-                else if (halfNext)
-                {
-                    hipLaunchKernelGGL((k_smooth_vec<false, true, true>), grid, block, ldsB, c->stream, sa);
+                    hipLaunchKernelGGL((k_smooth_vec<true>), grid, block, ldsB, c->stream, sa, fullMask);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((k_smooth_vec<false, false, true>), grid, block, ldsB, c->stream, sa);
+                    hipLaunchKernelGGL((k_smooth_vec<false>), grid, block, ldsB, c->stream, sa, fullMask);
                 }
                 LAUNCHCHK(c, "k_smooth_vec");
-                z0 = z1;
             }
             colorDone = true;
         }
@@ -2282,111 +2316,204 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         }
     }
 
-    const int nL = int(pl.levels.size());
-    const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * 8 && c->levelMode != 0;
-    const bool fused = waveSmooth && c->fusedOk && c->levelMode == 1;
-    if (!fused && c->nApproxDescs > 0)
-    {
-        // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
-        prof(c, "k_resample(approx)");
-        hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nF), dim3(64, 4), 0, c->stream,
-            (const float*)c->d_chns, c->d_chns, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
-        LAUNCHCHK(c, "k_resample(approx)");
-    }
-    if (waveSmooth)
-    {
-        // ---- (approximated-scale resample +) smoothing + placement in the padded pyramid: one wave per plane (k_level)
-        const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
-        float* rawOut = (fused && c->taps) ? c->d_chns : nullptr;
-        const LevelJob* ljobs = fused ? c->d_levelJobs : c->d_levelJobsRaw;
-        const auto& groups = fused ? c->levelGroups : c->levelGroupsRaw;
-        const ResampleDesc* dd = c->d_descs + c->nImgDescs;
-        prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
-        // fork: every group is an independent launch (disjoint outputs); biggest planes first
-        const size_t nSide = c->side.size();
-        if (nSide && c->evFork)
+    // ---- approximated levels, smoothing and padding of frames [f0, f0 + nLF) of the batch
+    auto launchLevels = [&](int f0, int nLF) -> int {
+        float* const chnsF = c->d_chns + int64_t(f0) * pl.raw_floats;
+        float* const pyrF = c->d_pyr + int64_t(f0) * pl.pyr_floats;
+        const int nL = int(pl.levels.size());
+        const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * 8 && c->levelMode != 0;
+        const bool fused = waveSmooth && c->fusedOk && c->levelMode == 1;
+        if (!fused && c->nApproxDescs > 0)
         {
-            HIPCHK(c, hipEventRecord(c->evFork, c->stream));
-            for (size_t k = 0; k < nSide; k++)
+            // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
+            prof(c, "k_resample(approx)");
+            hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nLF), dim3(64, 4), 0, c->stream,
+                (const float*)chnsF, chnsF, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
+            LAUNCHCHK(c, "k_resample(approx)");
+        }
+        if (waveSmooth)
+        {
+            // ---- (approximated-scale resample +) smoothing + placement in the padded pyramid: one wave per plane (k_level)
+            const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
+            float* rawOut = (fused && c->taps) ? chnsF : nullptr;
+            const LevelJob* ljobs = fused ? c->d_levelJobs : c->d_levelJobsRaw;
+            const auto& groups = fused ? c->levelGroups : c->levelGroupsRaw;
+            const ResampleDesc* dd = c->d_descs + c->nImgDescs;
+            prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
+            // fork: every group is an independent launch (disjoint outputs); biggest planes first
+            const size_t nSide = c->side.size();
+            if (nSide && c->evFork)
             {
-                HIPCHK(c, hipStreamWaitEvent(c->side[k], c->evFork, 0));
+                HIPCHK(c, hipEventRecord(c->evFork, c->stream));
+                for (size_t k = 0; k < nSide; k++)
+                {
+                    HIPCHK(c, hipStreamWaitEvent(c->side[k], c->evFork, 0));
+                }
+            }
+            const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
+            if (nAll > 0)
+            {
+                hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nLF, nAll), dim3(256), 0, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,
+                    (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+                LAUNCHCHK(c, "k_level_all");
+            }
+            size_t gi = 0;
+            for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
+            {
+                const auto& g = *git;
+                hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
+                dim3 grid(cdiv(pl.nChns, 4), g.count, nLF), block(256);
+    #define LV_LAUNCH(RR, MM)                                                                                                         \
+        hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)chnsF, pyrF, rawOut, ljobs + g.first, dd, \
+            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+    #define LV_MODES(RR)                                  \
+        switch (g.mode)                                   \
+        {                                                 \
+            case LM_REAL: LV_LAUNCH(RR, LM_REAL); break;  \
+            case LM_DD: LV_LAUNCH(RR, LM_DD); break;      \
+            default: LV_LAUNCH(RR, LM_UU); break;         \
+        }
+                switch (g.R)
+                {
+                    case 1: LV_MODES(1); break;
+                    case 2: LV_MODES(2); break;
+                    case 3: LV_MODES(3); break;
+                    case 4: LV_MODES(4); break;
+                    case 5: LV_MODES(5); break;
+                    case 6: LV_MODES(6); break;
+                    case 7: LV_MODES(7); break;
+                    default: LV_MODES(8); break;
+                }
+    #undef LV_MODES
+    #undef LV_LAUNCH
+                LAUNCHCHK(c, "k_level");
+            }
+            if (nSide && c->evFork)
+            {
+                for (size_t k = 0; k < std::min(nSide, groups.size()); k++)
+                {
+                    HIPCHK(c, hipEventRecord(c->evJoin[k], c->side[k]));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evJoin[k], 0));
+                }
             }
         }
-        const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
-        if (nAll > 0)
+        // ---- smooth every plane of every level into the fused, padded pyramid (chnsPyramid.cpp:399-435)
+        if (waveSmooth)
         {
-            hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nF, nAll), dim3(256), 0, c->stream, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs, dd,
-                (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
-            LAUNCHCHK(c, "k_level_all");
         }
-        size_t gi = 0;
-        for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
+        else if (p.smooth > 0)
         {
-            const auto& g = *git;
-            hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
-            dim3 grid(cdiv(pl.nChns, 4), g.count, nF), block(256);
-#define LV_LAUNCH(RR, MM)                                                                                                         \
-    hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)c->d_chns, c->d_pyr, rawOut, ljobs + g.first, dd, \
-        (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
-#define LV_MODES(RR)                                  \
-    switch (g.mode)                                   \
-    {                                                 \
-        case LM_REAL: LV_LAUNCH(RR, LM_REAL); break;  \
-        case LM_DD: LV_LAUNCH(RR, LM_DD); break;      \
-        default: LV_LAUNCH(RR, LM_UU); break;         \
-    }
-            switch (g.R)
+            const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
+            if ((rc = launchSmooth(c, chnsF, pyrF, c->d_finalJobs, nL, pl.nChns, c->finalMaxH, pl.raw_floats, pl.pyr_floats, nLF, pS, true)))
             {
-                case 1: LV_MODES(1); break;
-                case 2: LV_MODES(2); break;
-                case 3: LV_MODES(3); break;
-                case 4: LV_MODES(4); break;
-                case 5: LV_MODES(5); break;
-                case 6: LV_MODES(6); break;
-                case 7: LV_MODES(7); break;
-                default: LV_MODES(8); break;
-            }
-#undef LV_MODES
-#undef LV_LAUNCH
-            LAUNCHCHK(c, "k_level");
-        }
-        if (nSide && c->evFork)
-        {
-            for (size_t k = 0; k < std::min(nSide, groups.size()); k++)
-            {
-                HIPCHK(c, hipEventRecord(c->evJoin[k], c->side[k]));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->evJoin[k], 0));
+                return rc;
             }
         }
-    }
-    // ---- smooth every plane of every level into the fused, padded pyramid (chnsPyramid.cpp:399-435)
-    if (waveSmooth)
+        else
+        {
+            int64_t maxE = 0;
+            for (const auto& l : pl.levels)
+            {
+                maxE = std::max<int64_t>(maxE, int64_t(pl.nChns) * l.hC * l.wC);
+            }
+            hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(maxE, 256), nL, nLF), dim3(256), 0, c->stream, (const float*)chnsF, pyrF,
+                (const SmoothJob*)c->d_finalJobs, pl.raw_floats, pl.pyr_floats);
+            LAUNCHCHK(c, "k_copy_planes(final)");
+        }
+        if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
+        {
+            prof(c, "k_pad_reflect");
+            hipLaunchKernelGGL(k_pad_reflect, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream, pyrF, (const PadJob*)c->d_padJobs, pl.pyr_floats);
+            LAUNCHCHK(c, "k_pad_reflect");
+        }
+        return ACF_HIP_OK;
+    };
+    if (!c->autoLambdas)
     {
-    }
-    else if (p.smooth > 0)
-    {
-        const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
-        if ((rc = launchSmooth(c, c->d_chns, c->d_pyr, c->d_finalJobs, nL, pl.nChns, c->finalMaxH, pl.raw_floats, pl.pyr_floats, nF, pS, true)))
+        for (int f = 0; f < nF; f++)
+        {
+            c->h_lambdas[size_t(f) * 3 + 0] = p.lambdas[0];
+            c->h_lambdas[size_t(f) * 3 + 1] = p.lambdas[1];
+            c->h_lambdas[size_t(f) * 3 + 2] = p.lambdas[2];
+        }
+        if ((rc = launchLevels(0, nF)))
         {
             return rc;
         }
     }
     else
     {
-        int64_t maxE = 0;
-        for (const auto& l : pl.levels)
+        // Image-specific lambdas (chnsPyramid.cpp:341-374): per-type means of the raw channels at two real levels (f64 plane
+        // sums on the device, k_plane_sums), lambda = -log2(f0/f1) / log2(s0/s1) on the host with the C library the
+        // oracle uses, then the approximated levels frame by frame with that frame's gains written into the descriptors
+        // (stream-ordered copies).  A fallback path for models that ship without lambdas: correctness first — it
+        // synchronises once per batch and launches per frame.
+        prof(c, "k_plane_sums");
+        const int lv0 = pl.lambdaLevel[0], lv1 = pl.lambdaLevel[1];
+        SumJob j0{ pl.raw_off[size_t(lv0)], pl.levels[size_t(lv0)].hC * pl.levels[size_t(lv0)].wC, 0 };
+        SumJob j1{ pl.raw_off[size_t(lv1)], pl.levels[size_t(lv1)].hC * pl.levels[size_t(lv1)].wC, 0 };
+        hipLaunchKernelGGL(k_plane_sums, dim3(pl.nChns, 2, nF), dim3(256), 0, c->stream, (const float*)c->d_chns, pl.raw_floats, j0, j1, pl.nChns, c->d_planeSums);
+        LAUNCHCHK(c, "k_plane_sums");
+        std::vector<double> sums(size_t(nF) * 2 * pl.nChns);
+        HIPCHK(c, hipMemcpyAsync(sums.data(), c->d_planeSums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int nColorL = p.colorEnabled ? d : 0, nMagL = p.gradMagEnabled ? 1 : 0, nHistL = p.gradHistEnabled ? p.nOrients : 0;
+        const int nTypeCh[3] = { nColorL, nMagL, nHistL };
+        // one copy of the approximated levels' descriptors per frame: each stays untouched until its stream-ordered upload is done
+        std::vector<std::vector<ResampleDesc>> descsAll(size_t(nF),
+            std::vector<ResampleDesc>(c->h_descs.begin() + c->nImgDescs, c->h_descs.begin() + c->nImgDescs + c->nApproxDescs));
+        for (int f = 0; f < nF; f++)
         {
-            maxE = std::max<int64_t>(maxE, int64_t(pl.nChns) * l.hC * l.wC);
+            std::vector<ResampleDesc>& descs = descsAll[size_t(f)];
+            double lam[3] = { 0, 0, 0 };
+            int z0 = 0;
+            for (int j = 0; j < 3; j++)
+            {
+                if (!nTypeCh[j])
+                {
+                    continue;
+                }
+                double s0 = 0, s1 = 0; // sum(MatP): the per-plane sums added in plane order (MatP.cpp:97-106)
+                for (int k = 0; k < nTypeCh[j]; k++)
+                {
+                    s0 += sums[(size_t(f) * 2 + 0) * pl.nChns + z0 + k];
+                    s1 += sums[(size_t(f) * 2 + 1) * pl.nChns + z0 + k];
+                }
+                const double f0 = s0 / (double(nTypeCh[j]) * j0.cells), f1 = s1 / (double(nTypeCh[j]) * j1.cells);
+                lam[j] = -(std::log(f0 / f1) / std::log(2.0)) / (std::log(pl.levels[size_t(lv0)].scale / pl.levels[size_t(lv1)].scale) / std::log(2.0));
+                z0 += nTypeCh[j];
+            }
+            for (int j = 0; j < 3; j++)
+            {
+                c->h_lambdas[size_t(f) * 3 + j] = lam[j];
+            }
+            size_t ai = 0;
+            for (size_t i = 0; i < pl.levels.size(); i++)
+            {
+                const acf_hip_level& l = pl.levels[i];
+                if (l.isReal)
+                {
+                    continue;
+                }
+                const acf_hip_level& lr = pl.levels[size_t(l.realIndex)];
+                double ratio[3];
+                for (int j = 0; j < 3; j++)
+                {
+                    ratio[j] = std::pow(l.scale / lr.scale, -lam[j]); // :393
+                }
+                setResampleGain(descs[ai], ratio, nColorL, nColorL + nMagL);
+                ai++;
+            }
+            if (!descs.empty())
+            {
+                HIPCHK(c, hipMemcpyAsync(c->d_descs + c->nImgDescs, descs.data(), descs.size() * sizeof(ResampleDesc), hipMemcpyHostToDevice, c->stream));
+            }
+            if ((rc = launchLevels(f, 1)))
+            {
+                return rc;
+            }
         }
-        hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(maxE, 256), nL, nF), dim3(256), 0, c->stream, (const float*)c->d_chns, c->d_pyr,
-            (const SmoothJob*)c->d_finalJobs, pl.raw_floats, pl.pyr_floats);
-        LAUNCHCHK(c, "k_copy_planes(final)");
-    }
-    if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
-    {
-        prof(c, "k_pad_reflect");
-        hipLaunchKernelGGL(k_pad_reflect, dim3(cdiv(c->padMaxElems, 256), nL, nF), dim3(256), 0, c->stream, c->d_pyr, (const PadJob*)c->d_padJobs, pl.pyr_floats);
-        LAUNCHCHK(c, "k_pad_reflect");
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // descsAll is read by the uploads above
     }
     prof(c, "(end)");
     c->lastBatch = nF;

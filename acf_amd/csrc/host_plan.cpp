@@ -346,10 +346,10 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
         err = "plan: softBin != 0";
         return ACF_HIP_E_UNSUPPORTED;
     }
-    if (p.nApprox > 0 && p.nLambdas != 3)
+    if (p.nApprox > 0 && p.nLambdas != 3 && p.nLambdas != 0)
     {
-        err = "plan: lambdas must be supplied (image-specific lambdas, chnsPyramid.cpp:341-374, are not computed)";
-        return ACF_HIP_E_UNSUPPORTED;
+        err = "plan: lambdas: none (estimated per image, chnsPyramid.cpp:341-374) or three (colour, gradMag, gradHist)";
+        return ACF_HIP_E_INVALID;
     }
     if (!(p.gradMagEnabled || p.gradHistEnabled || p.colorEnabled))
     {
@@ -453,6 +453,23 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
     }
     plan.pyr_floats = off;
     plan.raw_floats = roff;
+    plan.lambdaLevel[0] = plan.lambdaLevel[1] = -1;
+    if (p.nApprox > 0 && p.nLambdas == 0)
+    {
+        // image-specific lambdas: the two real levels they are estimated from (chnsPyramid.cpp:343-355, 1-based there)
+        std::vector<int> is;
+        for (int i = 1 + p.nOctUp * p.nPerOct; i <= n; i += p.nApprox + 1)
+        {
+            is.push_back(i - 1);
+        }
+        if (is.size() < 2)
+        {
+            err = "plan: image-specific lambdas need two real scales at or below the image size (CV_Assert(is.size() >= 2), chnsPyramid.cpp:351)";
+            return ACF_HIP_E_INVALID;
+        }
+        plan.lambdaLevel[0] = is.size() > 2 ? is[1] : is[0];
+        plan.lambdaLevel[1] = is.size() > 2 ? is[2] : is[1];
+    }
     return ACF_HIP_OK;
 }
 

@@ -88,6 +88,7 @@ struct Plan
     int64_t pyr_floats = 0;          // padded, fused (what the cascade reads)
     int64_t raw_floats = 0;          // unpadded, unsmoothed channels
     std::vector<int64_t> raw_off;    // per level
+    int lambdaLevel[2] = { -1, -1 }; // image-specific lambdas (no lambdas in the model): the two real levels they come from
 };
 
 int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err);

@@ -479,14 +479,12 @@ struct SmoothVecArgs
 
 #define SV_CH 8
 template <bool FULL, bool HALF, bool SHRINK>
-__global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a)
+__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z)
 {
-    extern __shared__ float lds[]; // [2 parities][lo, hi][nq]
     const int h = a.h, w = a.w, nq = h >> 2;
     const int q = threadIdx.x;
     const bool valid = q < nq;
     const int qc = valid ? q : nq - 1;
-    const int z = a.plane0 + blockIdx.x;
     const int64_t f = blockIdx.z;
     const float* __restrict__ I = a.in + f * a.in_fs + int64_t(z) * a.in_ps + 4 * qc;
     float* __restrict__ Of = FULL ? a.sm + f * a.sm_fs + int64_t(z) * a.sm_ps + 4 * qc : nullptr;
@@ -579,6 +577,71 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a)
 #undef SV_LOAD
 #undef SV_COL
 #undef SV_CHUNK
+}
+
+// One launch per real scale: the planes that must also be written at full resolution (bit z of fullMask: the gradient
+// plane, or every plane of a scale that later scales are resampled from) and the ones that are not run side by side as
+// workgroups of the same grid instead of as two launches back to back — a plane is a chain of w column steps, so a launch
+// lasts as long as one plane whatever the number of planes.  The flag is workgroup-uniform: each specialisation keeps
+// its branch-free column loop.
+template <bool HALF>
+__global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fullMask)
+{
+    extern __shared__ float lds[]; // [2 parities][lo, hi][nq]
+    const int z = a.plane0 + blockIdx.x;
+    if ((fullMask >> z) & 1u)
+    {
+        smooth_vec_body<true, HALF, true>(a, lds, z);
+    }
+    else
+    {
+        smooth_vec_body<false, HALF, true>(a, lds, z);
+    }
+}
+
+// ------------------------------------------------------------------------
+// Image-specific lambdas (chnsPyramid.cpp:341-374): the mean of every channel TYPE at two real scales.  The reference
+// takes sum(MatP) = the per-plane cv::sum (f32 data, f64 accumulation) added up in plane order (MatP.cpp:97-106).
+// cv::sum's own order of additions is OpenCV's SIMD blocking, which is not reproduced (OpenCV is absent from the
+// image); the order HERE, restated in oracle/acf_oracle.c:acfo_plane_sum, is: 256 partial sums over the elements
+// i = t (mod 256) in increasing i, then the binary tree partial[t] += partial[t + s], s = 128 .. 1.  Against any other
+// order of the same f64 additions the result differs by a few units in the last place of a double (relative 1e-16),
+// which moves lambda by the same relative amount.
+// One workgroup per (plane, selected level, frame); out[frame][sel][plane] (doubles).
+// ------------------------------------------------------------------------
+struct SumJob
+{
+    int64_t off;   // float offset of the level's raw channels inside a frame's channel buffer
+    int32_t cells; // hC * wC
+    int32_t pad_;
+};
+
+__global__ void __launch_bounds__(256) k_plane_sums(const float* __restrict__ chns, int64_t chns_fs, SumJob j0, SumJob j1, int nPlanes, double* __restrict__ out)
+{
+    __shared__ double part[256];
+    const int z = blockIdx.x, sel = blockIdx.y;
+    const int64_t f = blockIdx.z;
+    const SumJob J = sel ? j1 : j0;
+    const float* __restrict__ src = chns + f * chns_fs + J.off + int64_t(z) * J.cells;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < J.cells; i += 256)
+    {
+        acc += double(src[i]);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1)
+    {
+        if (int(threadIdx.x) < s)
+        {
+            part[threadIdx.x] += part[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        out[(f * 2 + sel) * nPlanes + z] = part[0];
+    }
 }
 
 // cv::copyMakeBorder(BORDER_REFLECT) of the interior already written by the

@@ -188,6 +188,12 @@ class HipDetector:
         return det[:n.value].copy(), hits[:n.value].copy()
 
     # ---- parity taps
+    def lambdas(self, frame=0):
+        """The three lambdas frame `frame` of the last pyramid was approximated with (the model's, or estimated from the image)."""
+        out = (C.c_double * 3)()
+        self._chk(self.lib.acf_hip_get_lambdas(self.ctx, frame, out))
+        return [out[0], out[1], out[2]]
+
     def read_level(self, frame, level):
         l = self.levels[level]
         out = np.zeros((self.nChns, l.wP, l.hP), dtype=np.float32)

@@ -452,7 +452,6 @@ int HipDetector::streamSubmit(const uint8_t* frames, int nFrames)
 {
     int t = -1;
     check(m_api->acf_hip_stream_submit(m_ctx, frames, nFrames, &t), "acf_hip_stream_submit");
-    ++m_generation; // any Pyramid handed out earlier is no longer the resident one
     return t;
 }
 
@@ -563,6 +562,13 @@ int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Py
     P.nTypes = (opts.pPyramid.pChns.pColor.enabled ? 1 : 0) + (opts.pPyramid.pChns.pGradMag.enabled ? 1 : 0) +
         (opts.pPyramid.pChns.pGradHist.enabled ? 1 : 0);
     P.lambdas = opts.pPyramid.lambdas;
+    if (P.lambdas.empty() && opts.pPyramid.nApprox > 0)
+    {
+        // estimated from this image (chnsPyramid.cpp:341-374)
+        double lam[3] = { 0, 0, 0 };
+        check(m_api->acf_hip_get_lambdas(m_ctx, 0, lam), "acf_hip_get_lambdas");
+        P.lambdas.assign(lam, lam + 3);
+    }
     P.data.resize(m_levels.size());
     for (size_t i = 0; i < m_levels.size(); i++)
     {
@@ -576,7 +582,6 @@ int HipDetector::chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Py
         P.data[i][0].create(l.wP * m_nChns, l.hP, 1); // fused: planes stacked along rows (ACF.h:653-672)
         check(m_api->acf_hip_read_level(m_ctx, 0, int(i), P.data[i][0].data()), "acf_hip_read_level");
     }
-    P.deviceTag = ++m_generation;
     if (logger)
     {
         const auto& ch = opts.pPyramid.pChns;
@@ -638,13 +643,10 @@ int HipDetector::operator()(const Pyramid& P, RectVec& objects, RealVec* scores)
     {
         throw Exception(ACF_HIP_E_NOPLAN, "operator()(Pyramid): pyramid was not produced by this detector");
     }
-    if (P.deviceTag == m_generation && P.deviceTag != 0)
-    {
-        // still resident: the cascade ran with it (acf_hip_run_host); results are on the device
-        fetch(0, objects, scores);
-        return 0;
-    }
-    // a host pyramid: one acfDetect1 per level + box mapping (ACF.cpp:268-367)
+    // Always the pyramid that was handed in — like the reference, which re-runs acfDetect1 on every level of P
+    // (ACF.cpp:268-367): one acfDetect1 per level + box mapping.  (Round 1 short-cut to the device-resident result of the
+    // last run when P carried a matching generation tag; another image, acfModify or an edit of P.data in between then
+    // returned detections that did not belong to P.)
     const int shift_w = (opts.modelDsPad.width - opts.modelDs.width) / 2 - opts.pPyramid.pad.width;   // image-height axis
     const int shift_h = (opts.modelDsPad.height - opts.modelDs.height) / 2 - opts.pPyramid.pad.height; // image-width axis
     DetectionVec all;

@@ -176,7 +176,6 @@ public:
         std::vector<std::vector<MatP>> data;
         std::vector<double> lambdas, scales;
         std::vector<Size2d> scaleshw;
-        uint64_t deviceTag = 0; // != 0: this pyramid is also resident on the device (generation counter)
         void clear()
         {
             data.clear();
@@ -184,7 +183,6 @@ public:
             scales.clear();
             scaleshw.clear();
             nScales = 0;
-            deviceTag = 0;
         }
     };
 
@@ -299,7 +297,6 @@ private:
     size_t m_maxDetectionCount = 10;
     double m_detectionScorePruneRatio = 0.0;
     int m_planH = 0, m_planW = 0, m_planD = 0, m_planBatch = 0;
-    uint64_t m_generation = 0;
     std::vector<acf_hip_level> m_levels;
     int m_nChns = 0;
     std::vector<float> m_upright; // scratch for operator()(interleaved)

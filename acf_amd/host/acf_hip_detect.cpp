@@ -254,12 +254,17 @@ int main(int argc, char** argv)
                 }
                 if (a.count("via-pyramid"))
                 {
-                    // computePyramid -> host Pyramid -> operator()(Pyramid) on a *copy* (forces the per-level path)
+                    // computePyramid -> host Pyramid -> another image through the detector -> operator()(Pyramid): the
+                    // detections must be P's (the reference re-runs acfDetect1 on the pyramid it is handed, ACF.cpp:268-367)
                     HipDetector::Pyramid P;
                     det.computePyramid(Ip, P);
-                    HipDetector::Pyramid Q = P;
-                    Q.deviceTag = 0;
-                    det(Q, objs, &scores);
+                    if (cnt > 1)
+                    {
+                        acf::MatP other(rows, cols, ch, frames.data() + per * size_t((f + 1) % cnt));
+                        HipDetector::RectVec o2;
+                        det(other, o2, nullptr);
+                    }
+                    det(P, objs, &scores);
                 }
                 else
                 {

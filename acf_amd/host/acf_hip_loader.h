@@ -33,6 +33,7 @@ struct Api
     ACF_HIP_FN(acf_hip_get_levels)
     ACF_HIP_FN(acf_hip_get_ldcf_levels)
     ACF_HIP_FN(acf_hip_pyramid_floats)
+    ACF_HIP_FN(acf_hip_get_lambdas)
     ACF_HIP_FN(acf_hip_pyramid)
     ACF_HIP_FN(acf_hip_detect)
     ACF_HIP_FN(acf_hip_run)

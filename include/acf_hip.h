@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 3
+#define ACF_HIP_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -85,7 +85,7 @@ typedef struct acf_hip_params
 
     /* Options::Pyramid (ACF.h:97-202) */
     int32_t nPerOct, nOctUp, nApprox;
-    int32_t nLambdas; /* 0 or 3 (colour, gradMag, gradHist); 0 is ACF_HIP_E_UNSUPPORTED on the device path */
+    int32_t nLambdas; /* 3 (colour, gradMag, gradHist), or 0: estimated from every image (chnsPyramid.cpp:341-374) */
     double lambdas[3];
     int32_t pad_h, pad_w;
     int32_t minDs_h, minDs_w;
@@ -198,6 +198,9 @@ ACF_HIP_API int acf_hip_get_levels(const acf_hip_ctx* ctx, acf_hip_level* out, i
 ACF_HIP_API int acf_hip_get_ldcf_levels(const acf_hip_ctx* ctx, acf_hip_level* out, int cap);
 /* Floats in one frame's fused pyramid (sum over levels of nChns*wP*hP). */
 ACF_HIP_API int acf_hip_pyramid_floats(const acf_hip_ctx* ctx, int64_t* n);
+/* The lambdas frame `frame` of the last acf_hip_pyramid / acf_hip_run was approximated with: the model's, or — for a
+ * model without lambdas — the ones estimated from that image (Detector::Pyramid::lambdas, chnsPyramid.cpp:341-374). */
+ACF_HIP_API int acf_hip_get_lambdas(acf_hip_ctx* ctx, int frame, double out[3]);
 
 /* ---- the hot path ---------------------------------------------------- */
 

@@ -1300,12 +1300,73 @@ static void pad_reflect(const float* src, float* dst, int h, int w, int py, int 
  * the plan).  taps: per real-scale ordinal, may be NULL.  chns_taps: per
  * level, unsmoothed/unpadded channels, may be NULL.
  * ---------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------
+ * a12  image-specific lambdas — chnsPyramid.cpp:341-374, MatP.cpp:97-111 (sum, numel), acf_math.h:20-29 (util::log2 =
+ * log(x) / log(2)).  sum(MatP) adds the per-plane cv::sum(plane)[0] in plane order; cv::sum accumulates the f32 data in
+ * f64 in OpenCV's own SIMD-blocked order, which cannot be restated without OpenCV (absent from this image): PARITY
+ * UNPINNED for that order.  The order used here and by the device (k_plane_sums) is 256 interleaved partial sums
+ * combined by a binary tree; any order of the same f64 additions agrees to a few ulp of a double (1e-16 relative).
+ * ---------------------------------------------------------------------- */
+ACFO_API double acfo_plane_sum(const float* x, int n)
+{
+    double part[256];
+    for (int t = 0; t < 256; t++)
+    {
+        double acc = 0.0;
+        for (int i = t; i < n; i += 256)
+        {
+            acc += (double)x[i];
+        }
+        part[t] = acc;
+    }
+    for (int s = 128; s >= 1; s >>= 1)
+    {
+        for (int t = 0; t < s; t++)
+        {
+            part[t] += part[t + s];
+        }
+    }
+    return part[0];
+}
+
+/* The two real levels the lambdas are estimated from (0-based), :343-355; returns 0 if there are fewer than two
+ * candidates (CV_Assert(is.size() >= 2) in the reference). */
+ACFO_API int acfo_lambda_levels(const acf_hip_params* p, int nScales, int* i0, int* i1)
+{
+    int is[3], n = 0;
+    for (int i = 1 + p->nOctUp * p->nPerOct; i <= nScales && n < 3; i += p->nApprox + 1)
+    {
+        is[n++] = i - 1;
+    }
+    if (n < 2)
+    {
+        return 0;
+    }
+    *i0 = n > 2 ? is[1] : is[0];
+    *i1 = n > 2 ? is[2] : is[1];
+    return 1;
+}
+
+/* lambda of one channel type from its plane sums at the two levels — :356-373 */
+ACFO_API double acfo_lambda(double sum0, double numel0, double sum1, double numel1, double scale0, double scale1)
+{
+    const double f0 = sum0 / numel0, f1 = sum1 / numel1;
+    return -(log(f0 / f1) / log(2.0)) / (log(scale0 / scale1) / log(2.0));
+}
+
+static __thread double g_last_lambdas[3]; /* lambdas used by the last acfo_chns_pyramid call (supplied or estimated) */
+ACFO_API void acfo_last_lambdas(double* out)
+{
+    memcpy(out, g_last_lambdas, sizeof(g_last_lambdas));
+}
+
 ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const acf_hip_params* p,
     const acf_hip_level* lv, int nScales, float* out, const acfo_taps* taps, float* const* chns_taps)
 {
-    if (p->nLambdas != 3 && p->nApprox > 0)
+    int lam0 = -1, lam1 = -1;
+    if (p->nLambdas != 3 && p->nApprox > 0 && !acfo_lambda_levels(p, nScales, &lam0, &lam1))
     {
-        return ACF_HIP_E_UNSUPPORTED; /* a12: image-specific lambdas (:341-374) depend on cv::sum order */
+        return ACF_HIP_E_INVALID; /* CV_Assert(is.size() >= 2), :351 */
     }
     if (p->softBin != 0)
     {
@@ -1436,6 +1497,34 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
         }
         realOrd++;
     }
+    /* :341-374 lambdas: the model's, or estimated from this image */
+    double lambdas[3] = { 0, 0, 0 };
+    if (p->nLambdas == 3)
+    {
+        memcpy(lambdas, p->lambdas, sizeof(lambdas));
+    }
+    else if (p->nApprox > 0 && !rc)
+    {
+        const int nTypeCh[3] = { p->colorEnabled ? d : 0, p->gradMagEnabled ? 1 : 0, p->gradHistEnabled ? p->nOrients : 0 };
+        size_t z0 = 0;
+        for (int j = 0; j < 3; j++)
+        {
+            if (!nTypeCh[j])
+            {
+                continue;
+            }
+            double s0 = 0, s1 = 0;
+            const size_t c0 = (size_t)lv[lam0].hC * lv[lam0].wC, c1 = (size_t)lv[lam1].hC * lv[lam1].wC;
+            for (int k = 0; k < nTypeCh[j]; k++) /* sum(MatP): per-plane sums added in plane order */
+            {
+                s0 += acfo_plane_sum(data[lam0] + (z0 + k) * c0, (int)c0);
+                s1 += acfo_plane_sum(data[lam1] + (z0 + k) * c1, (int)c1);
+            }
+            lambdas[j] = acfo_lambda(s0, (double)nTypeCh[j] * c0, s1, (double)nTypeCh[j] * c1, lv[lam0].scale, lv[lam1].scale);
+            z0 += nTypeCh[j];
+        }
+    }
+    memcpy(g_last_lambdas, lambdas, sizeof(lambdas));
     /* :385-397 approximated scales */
     for (int i = 0; i < nScales && !rc; i++)
     {
@@ -1453,7 +1542,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
             {
                 continue;
             }
-            double ratio = pow(lv[i].scale / lv[iR].scale, -p->lambdas[j]);
+            double ratio = pow(lv[i].scale / lv[iR].scale, -lambdas[j]);
             rc = acfo_resample(data[iR] + offA, data[i] + offB, ha, hb, wa, wb, nTypeCh[j], (float)ratio);
             offA += (size_t)nTypeCh[j] * ha * wa;
             offB += (size_t)nTypeCh[j] * hb * wb;

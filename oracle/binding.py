@@ -66,6 +66,14 @@ def lib():
         o.acfo_chns_compute.restype = C.c_int
         o.acfo_chns_pyramid.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, L, C.c_int, fp, C.POINTER(Taps), C.POINTER(fp)]
         o.acfo_chns_pyramid.restype = C.c_int
+        o.acfo_plane_sum.argtypes = [fp, C.c_int]
+        o.acfo_plane_sum.restype = C.c_double
+        o.acfo_lambda.argtypes = [C.c_double] * 6
+        o.acfo_lambda.restype = C.c_double
+        o.acfo_lambda_levels.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        o.acfo_lambda_levels.restype = C.c_int
+        o.acfo_last_lambdas.argtypes = [C.POINTER(C.c_double)]
+        o.acfo_last_lambdas.restype = None
         o.acfo_acf_detect1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, P,
                                        C.POINTER(capi.Hit), C.c_int, C.c_int]
         o.acfo_acf_detect1.restype = C.c_int
@@ -196,6 +204,13 @@ def chns_pyramid(plan, frame, want_taps=False, want_chns=False):
     if rc:
         raise RuntimeError("acfo_chns_pyramid rc=%d" % rc)
     return out, taps, chns
+
+
+def last_lambdas():
+    """The three lambdas the last chns_pyramid call on this thread used (the model's, or estimated from the image)."""
+    out = (C.c_double * 3)()
+    lib().acfo_last_lambdas(out)
+    return [out[0], out[1], out[2]]
 
 
 def detect(plan, pyr, cap=1 << 16):

@@ -217,6 +217,47 @@ def test_acf_detect1(dev, oracle, depth, nTrees, tiles):
     assert np.array_equal(bits(got["score"]), bits(want["score"]))
 
 
+def _detect1_case(dev, oracle, depth, nTrees, tiles, cascThr, hs_range, seed=0):
+    nC, wP, hP = 10, 60, 44
+    chns = rnd(99 + depth + seed, (nC, wP, hP), 0.0, 0.6)
+    m = synth.make_model(seed=11 + depth, name="TINY", nTrees=nTrees, cascThr=cascThr, treeDepth=depth)
+    m["thrs"] = rnd(5, m["thrs"].shape, 0.1, 0.5)
+    m["hs"] = rnd(6, m["hs"].shape, *hs_range)
+    m["fids"] = (synth.uniform(7, m["fids"].size, 1) * (nC * 16)).astype(np.uint32).reshape(m["fids"].shape)
+    dev.set_option("cascade_tiles", tiles)
+    dev.set_model(m)
+    try:
+        got = dev.op_acf_detect1(chns)
+    finally:
+        dev.set_option("cascade_tiles", 1)
+    params, keep = capi.make_params(m)
+    want = np.zeros(1 << 16, dtype=capi.HIT_DTYPE)
+    n = oracle.lib().acfo_acf_detect1(chns.ctypes.data_as(C.c_void_p), 0, keep["thrs"].ctypes.data_as(C.c_void_p), hP, wP, nC,
+                                      C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
+    want = want[:n]
+    assert 0 < n < (wP - 3) * (hP - 3), n
+    assert len(got) == n
+    for k in ("scale", "c", "r"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(bits(got["score"]), bits(want["score"]))
+
+
+@pytest.mark.parametrize("nTrees", [70, 300])
+@pytest.mark.parametrize("depth", [4, 5, 6, 7, 8])
+def test_acf_detect1_deep_trees(dev, oracle, depth, nTrees):
+    """acfDetect1.cpp:184-228 dispatches treeDepth 1..8 (getChild walks depth levels of a full binary tree of
+    2^(depth+1)-1 nodes): every depth above the depth-2 fast path runs the staged global-memory cascade."""
+    _detect1_case(dev, oracle, depth, nTrees, 1, -1.0 if nTrees < 300 else -4.0, (-0.25, 0.2))
+
+
+@pytest.mark.parametrize("depth,tiles", [(2, 1), (2, 0), (5, 1), (0, 1)])
+def test_acf_detect1_4096_trees(dev, oracle, depth, tiles):
+    """4096 trees (the largest detectors of the toolbox): the tile kernel's stage E and k_tail_scan then walk 3968 tail trees
+    (62 batches of 64: more than four per wave), the staged path its long last stage.  Zero-mean leaves: the score is a
+    random walk, cascThr -6 lets a small fraction through."""
+    _detect1_case(dev, oracle, depth, 4096, tiles, -6.0, (-0.2, 0.2), seed=3)
+
+
 @pytest.mark.parametrize("depth", [2, 0, 3])
 def test_evaluate_single_window(dev, oracle, depth):
     """Detector::evaluate (acfDetect1.cpp:337-342): the score of the window at (0,0) with cascThr = 0 — the value at which
