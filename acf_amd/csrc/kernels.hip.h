@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fu
 // Image-specific lambdas (chnsPyramid.cpp:341-374): the mean of every channel TYPE at two real scales.  The reference
 // takes sum(MatP) = the per-plane cv::sum (f32 data, f64 accumulation) added up in plane order (MatP.cpp:97-106).
 // cv::sum's own order of additions is OpenCV's SIMD blocking, which is not reproduced (OpenCV is absent from the
-// image); the order HERE, restated in oracle/acf_oracle.c:acfo_plane_sum, is: 256 partial sums over the elements
+// image); the order HERE (the CPU checker of the tests restates it) is: 256 partial sums over the elements
 // i = t (mod 256) in increasing i, then the binary tree partial[t] += partial[t + s], s = 128 .. 1.  Against any other
 // order of the same f64 additions the result differs by a few units in the last place of a double (relative 1e-16),
 // which moves lambda by the same relative amount.
