@@ -114,7 +114,7 @@ def test_plan_rejects_unsupported():
     lib = capi.load()
     lv = (capi.Level * 8)()
     n, nc = C.c_int(), C.c_int()
-    for over, code in ((dict(softBin=1), 2), (dict(shrink=3, modelDsPad_h=15, modelDsPad_w=15), 2), (dict(lambdas=[]), 2),
+    for over, code in ((dict(softBin=1), 2), (dict(shrink=3, modelDsPad_h=15, modelDsPad_w=15), 2), (dict(lambdas=[0.1, 0.1]), 1),
                        (dict(colorSpace=capi.CS_HSV), 2), (dict(colorChn=5), 1)):
         params, keep = capi.make_params(synth.make_model(name="TINY", nTrees=4, **over))
         assert lib.acf_hip_plan_levels(C.byref(params), 96, 128, 3, lv, 8, C.byref(n), C.byref(nc)) == code, over
