@@ -111,6 +111,9 @@ struct acf_hip_ctx
     int64_t ldcfFloats = 0, ldcfTmpFloats = 0;
     float* d_ldcfFilt = nullptr;
     LdcfJob* d_ldcfJobs = nullptr;
+    // k_ldcf_tile (filters + half resample fused): flat list of output tiles over all levels, LDS geometry
+    LdcfTileJob* d_ldcfTileJobs = nullptr;
+    int ldcfTiles = 0, ldcfTileRows = 0, ldcfTileCols = 0;
     int ldcfMaxCells = 0, ldcfMaxBlocks = 0;
     float* d_ldcfTmp = nullptr;
     float* d_ldcfPyr = nullptr;
@@ -273,6 +276,8 @@ void freeAll(acf_hip_ctx* c)
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->d_ldcfJobs = nullptr;
+    c->d_ldcfTileJobs = nullptr;
+    c->ldcfTiles = 0;
     c->lastFrames = nullptr;
     c->pyramidValid = c->detectValid = false;
 }
@@ -1262,7 +1267,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
 // Tiling of a down-sampling descriptor for k_resample_tile: output columns per tile (the largest of 32/16/8 whose
 // source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
 // int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
-static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena)
+static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena, int forceXo = 0, int64_t ldsBudget = int64_t(64) * 1024)
 {
     ResampleTiling tl;
     if (!((dd.xmode == RS_DOWN || dd.xmode == RS_EXACT) && (dd.ymode == RS_DOWN || dd.ymode == RS_EXACT)))
@@ -1294,6 +1299,10 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
     }
     for (int xo : { 32, 16, 8 })
     {
+        if (forceXo && xo != forceXo)
+        {
+            continue;
+        }
         std::vector<int32_t> tx;
         int maxC = 0;
         const int32_t* it = arena.ints.data();
@@ -1305,7 +1314,7 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
             tx.push_back(hi);
             maxC = std::max(maxC, hi - lo + 1);
         }
-        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= int64_t(64) * 1024)
+        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= ldsBudget)
         {
             tl.rows = maxR;
             tl.cols = maxC;
@@ -1715,6 +1724,49 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         }
         c->ldcfTmpFloats = int64_t(p.ldcfK) * pl.pyr_floats;
         c->ldcfFloats = off;
+        {
+            // fused path: every level tiled for k_resample_tile's passes with 16 output columns per tile
+            std::vector<LdcfTileJob> tj;
+            int maxR = 0, maxC = 0;
+            bool ok = !getenv("ACF_HIP_LDCF_UNFUSED");
+            for (size_t i = 0; i < c->ldcfLevels.size() && ok; i++)
+            {
+                const ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
+                const ResampleTiling tl = resampleTilePlan(dd, arena, 16, int64_t(40) * 1024);
+                if (tl.rows <= 0)
+                {
+                    ok = false;
+                    break;
+                }
+                maxR = std::max(maxR, tl.rows);
+                maxC = std::max(maxC, tl.cols);
+                const int ntY = cdiv(dd.hb, RT_YO), ntX = cdiv(dd.wb, 16);
+                for (int x = 0; x < ntX; x++)
+                {
+                    for (int y = 0; y < ntY; y++)
+                    {
+                        LdcfTileJob j{};
+                        j.level = int(i);
+                        j.ytile = y;
+                        j.xtile = x;
+                        j.tile_y = tl.tile_y;
+                        j.tile_x = tl.tile_x;
+                        tj.push_back(j);
+                    }
+                }
+            }
+            c->ldcfTiles = 0;
+            if (ok && !tj.empty())
+            {
+                c->ldcfTiles = int(tj.size());
+                c->ldcfTileRows = maxR;
+                c->ldcfTileCols = maxC;
+                if ((rc = devUpload(c, &c->d_ldcfTileJobs, tj)))
+                {
+                    return rc;
+                }
+            }
+        }
         for (size_t i = 0; i < c->ldcfLevels.size(); i++)
         {
             ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
@@ -1725,7 +1777,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             return rc;
         }
-        if ((rc = devUpload(c, &c->d_ldcfFilt, c->ldcfFilters)) || (rc = devAlloc(c, &c->d_ldcfTmp, size_t(B) * c->ldcfTmpFloats + 64)) ||
+        if ((rc = devUpload(c, &c->d_ldcfFilt, c->ldcfFilters)) || (c->ldcfTiles == 0 && (rc = devAlloc(c, &c->d_ldcfTmp, size_t(B) * c->ldcfTmpFloats + 64))) ||
             (rc = devAlloc(c, &c->d_ldcfPyr, size_t(B) * c->ldcfFloats + 64)))
         {
             return rc;
@@ -2918,14 +2970,33 @@ int acf_hip_detect(acf_hip_ctx* c)
         const Plan& pl = c->plan;
         const int nF = c->lastBatch, nCk = pl.nChns * c->p.ldcfK;
         const int nL = int(pl.levels.size());
-        prof(c, "k_ldcf_conv");
-        hipLaunchKernelGGL(k_ldcf_conv, dim3(cdiv(c->ldcfMaxCells, 256), nCk, nF * nL), dim3(256), 0, c->stream, (const float*)c->d_pyr, c->d_ldcfTmp,
-            (const float*)c->d_ldcfFilt, (const LdcfJob*)c->d_ldcfJobs, nL, pl.nChns, pl.pyr_floats, c->ldcfTmpFloats);
-        LAUNCHCHK(c, "k_ldcf_conv");
-        prof(c, "k_resample(ldcf)");
-        hipLaunchKernelGGL(k_resample, dim3(c->ldcfMaxBlocks, nL, nF), dim3(64, 4), 0, c->stream, (const float*)c->d_ldcfTmp, c->d_ldcfPyr,
-            (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
-        LAUNCHCHK(c, "k_resample(ldcf)");
+        if (c->ldcfTiles > 0)
+        {
+            // filters + half resample in one kernel: the filtered full-resolution planes stay in LDS
+            prof(c, "k_ldcf_tile");
+            const size_t ldsB = (size_t(c->ldcfTileCols) * c->ldcfTileRows + size_t(16) * c->ldcfTileRows +
+                                 size_t(c->ldcfTileCols + 4) * (c->ldcfTileRows + 4) + 16 * 8) * sizeof(float);
+            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_ldcf_tile), ldsB)))
+            {
+                return rc;
+            }
+            hipLaunchKernelGGL(k_ldcf_tile, dim3(c->ldcfTiles, pl.nChns, nF), dim3(256), ldsB, c->stream, (const float*)c->d_pyr, c->d_ldcfPyr,
+                (const float*)c->d_ldcfFilt, (const LdcfTileJob*)c->d_ldcfTileJobs, (const LdcfJob*)c->d_ldcfJobs,
+                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, c->ldcfTileRows, c->ldcfTileCols, 16,
+                c->p.ldcfK, pl.nChns, pl.pyr_floats);
+            LAUNCHCHK(c, "k_ldcf_tile");
+        }
+        else
+        {
+            prof(c, "k_ldcf_conv");
+            hipLaunchKernelGGL(k_ldcf_conv, dim3(cdiv(c->ldcfMaxCells, 256), nCk, nF * nL), dim3(256), 0, c->stream, (const float*)c->d_pyr, c->d_ldcfTmp,
+                (const float*)c->d_ldcfFilt, (const LdcfJob*)c->d_ldcfJobs, nL, pl.nChns, pl.pyr_floats, c->ldcfTmpFloats);
+            LAUNCHCHK(c, "k_ldcf_conv");
+            prof(c, "k_resample(ldcf)");
+            hipLaunchKernelGGL(k_resample, dim3(c->ldcfMaxBlocks, nL, nF), dim3(64, 4), 0, c->stream, (const float*)c->d_ldcfTmp, c->d_ldcfPyr,
+                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
+            LAUNCHCHK(c, "k_resample(ldcf)");
+        }
         ShrinkScope ss(c, 2);
         rc = runCascade(c, c->d_ldcfPyr, c->ldcfFloats, c->d_boxLevels, nF, nCk);
     }

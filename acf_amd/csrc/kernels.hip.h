@@ -2542,86 +2542,61 @@ __global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr
 // ------------------------------------------------------------------------
 constexpr int RT_YO = 64;
 
-// tile_y / tile_x (int arena, written by resampleTilePlan on the host): per output-row tile {rowLo, rowHi}, per
-// output-column tile {colLo, colHi}; xo = output columns per tile.
-__global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__ src, float* __restrict__ dst,
-    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
-    int tile_y, int tile_x)
+// The two passes of k_resample_tile on a source tile already in LDS (T: [nCols][nRows], source rows rowLo.. / columns colLo..;
+// C: [xo][nRows] x-pass buffer).  Shared with k_ldcf_tile, whose source tile is the 5x5-filtered level.  Must be called by
+// every thread of the (256-thread) workgroup; lanes without an output row return after the x pass.
+struct RtTaps
 {
-    extern __shared__ float rt_lds[];
-    const ResampleDesc& d = descs[blockIdx.y];
-    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
-    const int ntY = (hb + RT_YO - 1) / RT_YO;
-    const int ntX = (wb + xo - 1) / xo;
-    int t = blockIdx.x;
-    const int ytile = t % ntY;
-    t /= ntY;
-    const int xtile = t % ntX;
-    const int z = t / ntX;
-    if (z >= d.nplanes)
+    int ya, q0, q1, ny;
+    float wy[4];
+    bool act, ySlow;
+};
+
+__device__ __forceinline__ RtTaps rt_taps(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, int yb, int yb1, float r)
+{
+    RtTaps t;
+    t.act = yb < yb1;
+    const int ybc = t.act ? yb : yb1 - 1;
+    t.q0 = t.q1 = 0;
+    t.wy[0] = t.wy[1] = t.wy[2] = t.wy[3] = 0.f;
+    t.ny = (d.ymode == RS_EXACT) ? d.yk : d.ybd0;
+    t.ySlow = (d.ymode == RS_DOWN) && d.ybd0 > 4;
+    if (d.ymode == RS_EXACT)
     {
-        return;
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
-    const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
-    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
-    const float r = d.r[ty], rk = d.rk[ty];
-    const int xmode = d.xmode, ymode = d.ymode;
-    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
-    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
-    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
-    const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
-    const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
-    float* T = rt_lds;                             // [nCols][nRows] source tile
-    float* C = rt_lds + size_t(maxCols) * maxRows; // [xo][nRows] x-pass columns
-    // this lane's y taps (global table reads: issued before the tile load so their latency overlaps it)
-    const int yb = yb0 + lane;
-    const bool act = yb < yb1;
-    const int ybc = act ? yb : yb1 - 1;
-    int ya, q0 = 0, q1 = 0;
-    float wy[4] = { 0.f, 0.f, 0.f, 0.f };
-    const int ny = (ymode == RS_EXACT) ? d.yk : d.ybd0;
-    const bool ySlow = (ymode == RS_DOWN) && d.ybd0 > 4;
-    if (ymode == RS_EXACT)
-    {
-        ya = d.yk * ybc;
+        t.ya = d.yk * ybc;
     }
     else
     {
-        q0 = it[d.y_start + ybc];
-        q1 = it[d.y_start + ybc + 1];
-        ya = it[d.y_src + q0];
-        if (!ySlow)
+        t.q0 = it[d.y_start + ybc];
+        t.q1 = it[d.y_start + ybc + 1];
+        t.ya = it[d.y_src + t.q0];
+        if (!t.ySlow)
         {
 #pragma unroll
             for (int o = 0; o < 4; o++)
             {
-                if (o < ny)
+                if (o < t.ny)
                 {
-                    wy[o] = ft[d.y_wt + q0 + o] * r; // ywts[y] *= r (:158-161)
+                    t.wy[o] = ft[d.y_wt + t.q0 + o] * r; // ywts[y] *= r (:158-161)
                 }
             }
         }
     }
-    // source tile: a wave per source column, lanes along the rows (coalesced), straight into LDS by LDS-DMA so that the
-    // whole tile is in flight at once (a load -> ds_write loop exposed one memory round trip per 64 floats).  Rows
-    // >= ha hold clamped duplicates: the x pass zeroes those rows itself.
-    for (int cc = wv; cc < nCols; cc += 4)
-    {
-        const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
-        for (int r0 = 0; r0 < nRows; r0 += 64)
-        {
-            if (r0 + lane < nRows)
-            {
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ void rt_passes(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const float* T, float* C,
+    float* __restrict__ B, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int colLo, int nRows, float r, float rk,
+    const int32_t* xrecTile = nullptr) // optional: the tile's column records {8 ints per output column from xb0 on} already in LDS
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ha = d.ha, hb = d.hb;
+    const int xmode = d.xmode, ymode = d.ymode;
+    const int ya = tp.ya, q0 = tp.q0, q1 = tp.q1, ny = tp.ny;
+    const bool act = tp.act, ySlow = tp.ySlow;
+    const float wy[4] = { tp.wy[0], tp.wy[1], tp.wy[2], tp.wy[3] };
     // x pass (rs_C): a wave per output column, lanes along the source rows
-    const int32_t* xrec = it + d.x_col;
+    const int32_t* xrec = xrecTile ? xrecTile - 8 * xb0 : it + d.x_col;
     const int nXo = xb1 - xb0;
     for (int c = wv; c < nXo; c += 4)
     {
@@ -2714,6 +2689,173 @@ __global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__
             }
         }
         B[int64_t(xb0 + c) * hb + yb] = v;
+    }
+}
+
+
+// tile_y / tile_x (int arena, written by resampleTilePlan on the host): per output-row tile {rowLo, rowHi}, per
+// output-column tile {colLo, colHi}; xo = output columns per tile.
+__global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__ src, float* __restrict__ dst,
+    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
+    int tile_y, int tile_x)
+{
+    extern __shared__ float rt_lds[];
+    const ResampleDesc& d = descs[blockIdx.y];
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int ntY = (hb + RT_YO - 1) / RT_YO;
+    const int ntX = (wb + xo - 1) / xo;
+    int t = blockIdx.x;
+    const int ytile = t % ntY;
+    t /= ntY;
+    const int xtile = t % ntX;
+    const int z = t / ntX;
+    if (z >= d.nplanes)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
+    const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty], rk = d.rk[ty];
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
+    const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
+    const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
+    float* T = rt_lds;                             // [nCols][nRows] source tile
+    float* C = rt_lds + size_t(maxCols) * maxRows; // [xo][nRows] x-pass columns
+    // this lane's y taps (global table reads: issued before the tile load so their latency overlaps it)
+    const int yb = yb0 + lane;
+    const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
+    // source tile: a wave per source column, lanes along the rows (coalesced), straight into LDS by LDS-DMA so that the
+    // whole tile is in flight at once (a load -> ds_write loop exposed one memory round trip per 64 floats).  Rows
+    // >= ha hold clamped duplicates: the x pass zeroes those rows itself.
+    for (int cc = wv; cc < nCols; cc += 4)
+    {
+        const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
+        for (int r0 = 0; r0 < nRows; r0 += 64)
+        {
+            if (r0 + lane < nRows)
+            {
+                __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    rt_passes(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk);
+}
+
+// ------------------------------------------------------------------------
+// LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
+// tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
+//   C_f = conv2(plane, filter_f, 'same')  (zero padded, taps in k_ldcf_conv's order: dx then dy ascending)
+//   out_f = imResample(C_f, .5)           (k_resample_tile's x pass / y pass: rt_passes)
+// The plane tile (+2 cells of halo, zeros outside the plane) is read once into LDS, each filter's conv result is
+// written to the LDS source tile of the resample and never reaches HBM: the separate k_ldcf_conv + k_resample pair
+// wrote and re-read k full-resolution copies of the pyramid (760 MB per 4K frame at k = 4).  A job is one output tile of
+// one level (flat list built at plan time: no empty blocks); blockIdx.y = input channel, blockIdx.z = frame.
+// ------------------------------------------------------------------------
+struct LdcfTileJob
+{
+    int32_t level;          // level = LDCF descriptor index
+    int32_t ytile, xtile;   // output tile (RT_YO rows x xo columns)
+    int32_t tile_y, tile_x; // int-arena offsets of the level's {rowLo,rowHi} / {colLo,colHi} tables
+    int32_t pad_[3];
+};
+
+__global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
+    const LdcfTileJob* __restrict__ jobs, const LdcfJob* __restrict__ levels, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it,
+    const float* __restrict__ ft, int maxRows, int maxCols, int xo, int K, int nChns, int64_t pyr_fs)
+{
+    extern __shared__ float lt_lds[];
+    const LdcfTileJob J = jobs[blockIdx.x];
+    const ResampleDesc& d = descs[J.level];
+    const LdcfJob L = levels[J.level];
+    const int c = blockIdx.y;
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int lane = threadIdx.x & 63;
+    const int yb0 = J.ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
+    const int xb0 = J.xtile * xo, xb1 = min(xb0 + xo, wb);
+    const float r = d.r[0], rk = d.rk[0];
+    const int rowLo = it[J.tile_y + 2 * J.ytile], rowHi = it[J.tile_y + 2 * J.ytile + 1];
+    const int colLo = it[J.tile_x + 2 * J.xtile], colHi = it[J.tile_x + 2 * J.xtile + 1];
+    const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
+    float* T = lt_lds;                              // [nCols][nRows] filtered tile = source tile of the resample
+    float* C = lt_lds + size_t(maxCols) * maxRows;  // [xo][nRows] x-pass columns
+    float* P = C + size_t(xo) * maxRows;            // [nCols + 4][nRows + 4] plane tile with halo
+    int32_t* recL = reinterpret_cast<int32_t*>(P + size_t(maxCols + 4) * (maxRows + 4)); // [xo][8] x-pass column records of this tile
+    const int pR = nRows + 4;
+    if (int(threadIdx.x) < 8 * (xb1 - xb0))
+    {
+        recL[threadIdx.x] = it[d.x_col + 8 * xb0 + threadIdx.x]; // read once: every filter's x pass uses them
+    }
+    const int yb = yb0 + lane;
+    const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
+    const float* __restrict__ A = pyr + int64_t(blockIdx.z) * pyr_fs + L.inOff + int64_t(c) * ha * wa;
+    for (int i = threadIdx.x; i < (nCols + 4) * pR; i += 256)
+    {
+        const int cc = i / pR, rr = i - cc * pR;
+        const int x = colLo + cc - 2, y = rowLo + rr - 2;
+        const bool ok = x >= 0 && x < wa && y >= 0 && y < ha;
+        P[i] = ok ? A[int64_t(x) * ha + y] : 0.f;
+    }
+    __syncthreads();
+    for (int f = 0; f < K; f++)
+    {
+        const int pc = f * nChns + c;
+        // 25 taps through the scalar unit (wave-uniform address)
+        typedef const __attribute__((address_space(4))) float* cfp_t;
+        cfp_t fw = (cfp_t)(uintptr_t)(filt + int64_t(pc) * 25);
+        float w[25];
+#pragma unroll
+        for (int k = 0; k < 25; k++)
+        {
+            w[k] = fw[k];
+        }
+        // a thread takes four consecutive COLUMNS at one tile row (lanes along the rows: conflict-free LDS reads): the 8 x 5
+        // cells they share are read once, 10 LDS reads per output instead of 25; per output the taps are still added dx
+        // then dy ascending (k_ldcf_conv's order)
+        const int nQ = (nCols + 3) >> 2;
+        for (int i = threadIdx.x; i < nQ * nRows; i += 256)
+        {
+            const int cq = i / nRows, rr = i - cq * nRows, cc = cq * 4;
+            // output (x, y) = (colLo + cc + j, rowLo + rr); tap (dx, dy) reads P[cc + j + 2 - dx][rr + 2 - dy]
+            float v[8][5];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+            {
+                const float* pc0 = P + min(cc + q, nCols + 3) * pR + rr; // columns cc .. cc + 7 of the padded tile (clamped past its end: never stored)
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+                {
+                    v[q][t] = pc0[t]; // padded rows rr .. rr + 4 = y - 2 .. y + 2
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int dx = -2; dx <= 2; dx++)
+                {
+#pragma unroll
+                    for (int dy = -2; dy <= 2; dy++)
+                    {
+                        acc = acc + v[j + 2 - dx][2 - dy] * w[(dx + 2) * 5 + (dy + 2)];
+                    }
+                }
+                if (cc + j < nCols)
+                {
+                    T[(cc + j) * nRows + rr] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        float* __restrict__ B = out + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(pc) * hb * wb;
+        rt_passes(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk, recL);
+        __syncthreads(); // T and C are rewritten by the next filter
     }
 }
 

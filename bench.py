@@ -1,21 +1,20 @@
 #!/usr/bin/env python
 """bench.py — detector FPS @1080p, 8 scales/octave, FACE80 model on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--contexts C] [--config {2,4,5}] [--frames-total T]
 
-One "step" = one pass of the hot path (acf_hip_run: chnsPyramid + acfDetect,
-then the device-side export of the detection records) over a batch of B
-synthetic 1080p planar-f32 LUV frames that are already resident in HBM.  With
-N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its
-own B frames (weak scaling, no data-path collective) and the fixed-capacity
-detection records are gathered to rank 0 over RCCL inside the timed step.
+One "step" = one pass of the hot path (acf_hip_run: chnsPyramid + acfDetect, then the device-side export of the
+detection records) over batches of synthetic frames that are already resident in HBM.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank runs its own frames (weak scaling, no data-path collective) and the
+fixed-capacity detection records are gathered to rank 0 over RCCL inside the timed step.  --frames-total T is
+BASELINE.json's cfg 3 as worded: T frames per step shared by the N GPUs (T/N per GPU: strong scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with
  - value: whole-job frames/s,
- - roofline: whole-path algorithmic bytes (B = B_in + 2*B_pyr per
-   frame) over the kernels' HIP-event time, plus the dominant kernel's own share,
- - cpu_baseline: the oracle (CPU restatement, 1 thread) on a bounded sample of the
-   same workload, rank 0 at N=1 only.
+ - roofline: the dominant kernel's algorithmic bytes per launch over its average launch duration INSIDE the timed region
+   (HIP events on the launch stream), the same kernel alone on the GPU under `solo`, the whole path under `path_*`,
+ - latency_ms_batch1: one frame, one context, submit to synchronise,
+ - cpu_baseline: the oracle (CPU restatement) on a bounded sample of the same workload, rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -31,6 +30,16 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# BASELINE.json configs that are bench lines (cfg 1 is the CPU plumbing case, cfg 3 is cfg 2 batched over GPUs)
+CONFIGS = {
+    2: dict(H=1080, W=1920, kind="luv", model=dict(name="FACE80"),
+            what="1920x1080 planar f32 LUV frames, synthetic FACE80-shaped model (80x80, 10 ch, depth 2, 2048 trees), nPerOct 8, nApprox 7, shrink 4"),
+    4: dict(H=480, W=640, kind="rgb", model=dict(name="INRIA"),
+            what="640x480 planar f32 RGB frames (RGB->LUV on the device), synthetic INRIA-shaped model (128x64 padded window, pad [16 12], nOctUp 1, 2048 trees)"),
+    5: dict(H=2160, W=3840, kind="luv", model=dict(name="FACE80", nPerOct=12, nApprox=11, ldcfK=4),
+            what="3840x2160 planar f32 LUV frames, 12 scales/octave, FACE80-shaped model over LDCF channels (k = 4 5x5 filters per channel, 40 channels at shrink 8)"),
+}
+
 
 def kernel_bytes_per_frame(det, model):
     """Algorithmic (compulsory in+out) bytes per frame of each kernel, from the plan."""
@@ -42,7 +51,6 @@ def kernel_bytes_per_frame(det, model):
     np_real = [l.hC * sh * l.wC * sh for l in real]
     raw_real = 4 * nC * sum(l.hC * l.wC for l in real)
     pyr = 4 * det.pyr_floats
-    mh, mw = model["modelDsPad_h"] // sh, model["modelDsPad_w"] // sh
     b = {}
     b["k_smooth_tri1(image)"] = sum(2 * d * n * 4 for n in np_real)
     # fused smoothing: every plane read; the gradient plane written at every scale, all planes at the scale later scales are
@@ -58,18 +66,25 @@ def kernel_bytes_per_frame(det, model):
     b["k_level(smooth)"] = 2 * pyr
     b["k_resample(approx)"] = raw_real + pyr
     b["k_smooth_tri1(levels)"] = 2 * pyr
-    b["k_cascade_tile"] = pyr                     # every pyramid cell read once (halo re-reads are L2 hits)
-    b["k_cascade"] = pyr
-    b["k_cascade_tail2"] = 0                      # data dependent: (survivors of 128 trees) x 4*nC*mh*mw bytes, ~15 MB/frame here
+    casc = pyr
+    if det.ldcf_levels:
+        k = int(model.get("ldcfK", 0))
+        casc = 4 * sum(nC * k * l.hP * l.wP for l in det.ldcf_levels)
+        b["k_ldcf_conv"] = pyr + 4 * casc  # the plain pyramid in, k filtered full-resolution levels out
+        b["k_resample(ldcf)"] = 4 * casc + casc
+    b["k_cascade_tile"] = casc                    # every cell of the cascade's pyramid read once (halo re-reads are L2 hits)
+    b["k_cascade"] = casc
+    b["k_tail_scan"] = 0                          # data dependent: (windows alive after tree 128) x (tail trees) code bytes
+    b["k_cascade_tail2"] = 0
     b["k_sort_map"] = 0
     return b
 
 
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json:
     FETCH_SIZE x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             t = json.load(f)
         if t.get("frames_per_step") != batch:
             return None
@@ -86,10 +101,15 @@ def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
     import threading
     from oracle import binding as ob
     plan = ob.Plan(model, H, W, 3)
+    ldcf = int(model.get("ldcfK", 0)) > 0
 
     def one(i):
         pyr, _, _ = ob.chns_pyramid(plan, frames_np[i % len(frames_np)])
-        ob.detect(plan, pyr)
+        if ldcf:
+            lvL, pyrL, _ = ob.ldcf(plan, pyr)
+            ob.detect_ldcf(plan, lvL, pyrL, cap=1 << 17)
+        else:
+            ob.detect(plan, pyr)
 
     t0 = time.perf_counter()
     one(0)  # also initialises the oracle's lazily built tables before any thread starts
@@ -113,9 +133,18 @@ def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
         t.join()
     dt = time.perf_counter() - t0
     n = sum(done)
-    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": single,
-            "sample": "%d synthetic 1080p LUV frames, FACE80 synthetic model, oracle/acf_oracle.c (gcc -O2), %d threads (one frame each at a time), %.1f s"
-                      % (n, cores, dt)}
+    out = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": single,
+           "sample": "%d synthetic frames of the benchmarked workload, oracle/acf_oracle.c (gcc -O3, no FMA, no fast-math), %d threads "
+                     "(one frame each at a time), %.1f s" % (n, cores, dt)}
+    try:
+        # how the port compares with the reference's own SSE kernels where those compile here (profiles/oracle_vs_ref_stages.py,
+        # run in the build container): > 1 means the port is slower, i.e. this baseline understates the reference by about that
+        with open(os.path.join(ROOT, "profiles", "r02_oracle_vs_ref.json")) as f:
+            st = json.load(f)["stages"]
+        out["port_over_reference_kernels"] = {k: v["oracle_over_reference"] for k, v in st.items()}
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -123,11 +152,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=96, help="frames per detector context per launch")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2: the metric's; 4, 5: extra bench lines)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per detector context per launch (default: 96 at cfg 2, 192 at cfg 4, 16 at cfg 5)")
     ap.add_argument("--contexts", type=int, default=3, help="detector contexts per GPU, each on its own HIP stream; a step runs one batch on each "
-                    "(the cascade of one batch overlaps the pyramid of another: +16%% over one context at 256 frames)")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
+                    "(the cascade of one batch overlaps the pyramid of another)")
+    ap.add_argument("--frames-total", type=int, default=0, help="cfg 3 as worded: this many frames per step shared by all GPUs (strong scaling); "
+                    "overrides --batch (frames per GPU = total / gpus, split over the contexts)")
     ap.add_argument("--cap", type=int, default=1024, help="detections exported per frame (gather record capacity)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,12 +178,24 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    H, W, B, C = args.height, args.width, args.batch, max(1, args.contexts)
+    cfg = CONFIGS[args.config]
+    H, W, C = cfg["H"], cfg["W"], max(1, args.contexts)
+    B = args.batch or {2: 96, 4: 192, 5: 16}[args.config]
+    scaling = "weak"
+    if args.frames_total:
+        per_gpu = args.frames_total // world
+        if per_gpu * world != args.frames_total or per_gpu < 1:
+            raise SystemExit("--frames-total must be a positive multiple of the number of GPUs")
+        C = min(C, per_gpu)
+        while per_gpu % C:
+            C -= 1
+        B = per_gpu // C
+        scaling = "strong"
 
-    model = synth.make_model(seed=1, name="FACE80")
+    model = synth.make_model(seed=1, **cfg["model"])
     # distinct base frames per rank, expanded to C*B distinct frames by cyclic shifts (cheap, on device)
     nbase = 4
-    base_np = [synth.make_frame(1000 * rank + i + 1, H, W, "luv") for i in range(nbase)]
+    base_np = [synth.make_frame(1000 * rank + i + 1, H, W, cfg["kind"]) for i in range(nbase)]
     base = torch.from_numpy(np.stack(base_np)).to(dev)
     frames = torch.empty((C * B, 3, W, H), dtype=torch.float32, device=dev)
     for i in range(C * B):
@@ -163,7 +205,7 @@ def main():
 
     # C detector contexts per GPU, each with its own HIP stream, plan and buffers (the reference runs one detector per thread the
     # same way, src/app/acf/acf.cpp:255-320).  The path alternates HBM-bound kernels (smoothing, gradMag, running sums) with
-    # VALU/LDS-bound ones (level chains, cascade): with independent streams the cascade of one batch fills the machine while
+    # latency-bound ones (level chains, cascade tiles): with independent streams the cascade of one batch fills the machine while
     # another batch's pyramid waits on memory.  Every context has its own record gather (the only exchange of the path, issued
     # asynchronously on the context's stream over two record buffers); everything in flight is waited for inside the timed region.
     pool = DetectorPool(C, model, H, W, 3, max_batch=B, max_hits=8192, device=local, streams=args.streams)
@@ -171,8 +213,6 @@ def main():
     for det in dets:
         if not args.no_profile:
             det.set_option("profile", 1)
-        if os.environ.get("ACF_BENCH_LEVEL_MODE"):  # A/B knob (profiles/ab_levels.sh)
-            det.set_option("fused_levels", int(os.environ["ACF_BENCH_LEVEL_MODE"]))
     pipes = [RecordGather(B, 1 + 6 * args.cap, world, rank, dev) for _ in range(C)]
 
     def step():
@@ -211,23 +251,41 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_rank = dt
     dt = float(tmax.item())
+    rank_fps = torch.zeros(world, dtype=torch.float64, device=dev)
+    rank_fps[rank] = C * B * args.steps / dt_rank
+    if world > 1:
+        dist.all_reduce(rank_fps, op=dist.ReduceOp.SUM)
 
     det = dets[0]
     prof, solo = {}, {}
+    latency_ms = None
     if not args.no_profile:
         for d_ in dets:
             for k_, (ms_, n_) in d_.profile().items():
                 a_ = prof.get(k_, (0.0, 0))
                 prof[k_] = (a_[0] + ms_, a_[1] + n_)
-        if C > 1:
-            # outside the timed region: the same launches with one context alone on the machine, so that a kernel's own speed
-            # can be read next to its speed while sharing the chip with the other contexts' kernels
-            with torch.cuda.stream(streams[0]):
-                for _ in range(3):
-                    dets[0].run(frames[:B], B)
-            dets[0].synchronize()
-            solo = dets[0].profile()
+        # outside the timed region: the same launches with one context alone on the machine, so that a kernel's own speed
+        # can be read next to its speed while sharing the chip with the other contexts' kernels
+        with torch.cuda.stream(streams[0]):
+            for _ in range(3):
+                dets[0].run(frames[:B], B)
+        dets[0].synchronize()
+        solo = dets[0].profile()
+    if rank == 0:
+        # one frame through one context, submit -> results on the device (cfg 2 is worded "single frame")
+        lat = []
+        with torch.cuda.stream(streams[0]):
+            for _ in range(12):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dets[0].run(frames[:1], 1)
+                dets[0].synchronize()
+                lat.append(time.perf_counter() - t1)
+        latency_ms = 1e3 * float(np.median(lat[2:]))
+        if not args.no_profile:
+            dets[0].profile()
     counts = pipes[0].rec[(pipes[0].k - 1) & 1][:, 0].cpu().numpy()
     if rank == 0:
         frames_total = C * B * world * args.steps
@@ -235,16 +293,23 @@ def main():
         b_in = 3 * 4 * H * W
         b_pyr = 4 * det.pyr_floats
         b_frame = b_in + 2 * b_pyr
+        metric = "detector FPS @1080p, 8 scales/octave, FACE80 model" if args.config == 2 else \
+            "detector FPS, BASELINE.json cfg %d (%dx%d)" % (args.config, W, H)
         out = {
-            "metric": "detector FPS @1080p, 8 scales/octave, FACE80 model",
+            "metric": metric,
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d planar f32 LUV frames, synthetic FACE80-shaped model (80x80, 10 ch, depth 2, 2048 trees), "
-                                   "nPerOct 8, nApprox 7, shrink 4; %d frames resident in HBM per GPU per step (%d detector contexts x %d frames)" % (W, H, C * B, C, B),
-                       "frames_per_gpu_per_step": C * B, "contexts": C, "frames_per_launch": B, "levels": len(det.levels), "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in det.levels)),
-                       "mean_detections_per_frame": float(counts.mean()), "parallelism": "frames sharded, %d rank(s)" % world},
+            "latency_ms_batch1": latency_ms,
+            "config": {"workload": "%s; %d frames resident in HBM per GPU per step (%d detector contexts x %d frames)" % (cfg["what"], C * B, C, B),
+                       "baseline_config": args.config,
+                       "frames_per_gpu_per_step": C * B, "contexts": C, "frames_per_launch": B, "levels": len(det.levels),
+                       "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in (det.ldcf_levels or det.levels))),
+                       "mean_detections_per_frame": float(counts.mean()), "parallelism": "frames sharded, %d rank(s)" % world,
+                       "rccl_ranks": world, "per_rank_fps": [float(x) for x in rank_fps.cpu().numpy()]},
         }
+        if args.frames_total:
+            out["config"]["frames_total_per_step"] = args.frames_total
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if prof:
             tot_ms = sum(v[0] for v in prof.values())
@@ -253,8 +318,9 @@ def main():
             launches = max(prof[dom][1], 1)
             avg_ms = prof[dom][0] / launches
             frames_per_launch = C * B * args.steps / launches
-            # dominant kernel: its algorithmic bytes per launch / its average launch duration (HIP events on the launch stream;
-            # with C contexts the launch shares the machine with other contexts' kernels, which is how it runs in the product)
+            # dominant kernel of the TIMED REGION: its algorithmic bytes per launch / its average launch duration there (HIP
+            # events on the launch stream; with C contexts the launch shares the machine with other contexts' kernels, which
+            # is how it runs in the product and what produced `value`)
             ach = kb.get(dom, 0) * frames_per_launch / (avg_ms * 1e-3) / 1e9
             # whole hot path: B = B_in + 2*B_pyr per frame over the wall clock of the timed region (kernel times of
             # concurrent contexts overlap, so their sum is not elapsed time)
@@ -263,22 +329,19 @@ def main():
                 "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
                 "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_share": prof[dom][0] / tot_ms,
                 "kernel_bytes_per_launch": kb.get(dom, 0) * frames_per_launch,
+                "measured": "inside the timed region (%d contexts sharing the GPU)" % C,
                 "path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
                 # summed over the C contexts of a step (they run concurrently: the sum exceeds ms_per_step when C > 1)
                 "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             })
             if solo.get(dom):
-                # The roofline of the KERNEL is quoted from launches that have the machine to themselves (same process, same
-                # buffers, HIP events on the launch stream, 3 launches right after the timed region): among concurrent contexts
-                # a launch's duration is mostly time spent sharing the chip — it varies 2x from run to run (5-13 ms for this
-                # kernel) and says nothing about the kernel.  rocprofv3 agrees with these launches to <1 %
-                # (profiles/r01_e_solo_kernel_stats.md); the in-flight figures of the timed region stay next to them.
+                # the same kernel with the GPU to itself (same process, buffers and event mechanism; 3 launches right after the
+                # timed region): a property of the kernel, next to the figure of the configuration that produced `value`
                 s_ms = solo[dom][0] / max(solo[dom][1], 1)
                 s_ach = kb.get(dom, 0) * B / (s_ms * 1e-3) / 1e9
-                roof["in_flight"] = {"note": "same kernel inside the timed region, sharing the GPU with the other contexts' kernels",
-                                     "kernel_avg_ms": avg_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
-                roof.update({"achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "kernel_avg_ms": s_ms, "kernel_bytes_per_launch": kb.get(dom, 0) * B,
-                             "measured": "one context alone on the GPU, 3 launches after the timed region (see in_flight for the timed region)"})
+                roof["solo"] = {"note": "same kernel, one context alone on the GPU, 3 launches after the timed region",
+                                "kernel_avg_ms": s_ms, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
+                                "kernels_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])}}
         else:
             path = b_frame * fps / world / 1e9
             roof.update({"path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
