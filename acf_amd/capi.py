@@ -63,6 +63,17 @@ class Params(C.Structure):
     ]
 
 
+class NmsParams(C.Structure):
+    _fields_ = [("type", C.c_int32), ("ovrDnmUnion", C.c_int32), ("overlap", C.c_double), ("thr", C.c_double),
+                ("prune", C.c_int32), ("maxCount", C.c_int32), ("pruneRatio", C.c_double)]
+
+
+def make_nms(type="maxg", overlap=0.65, ovrDnm="min", thr=-1.7976931348623157e308, prune=False, maxCount=10, pruneRatio=0.0):
+    """acf_hip_nms_params from the reference's option names (Options::Nms, ObjectDetector setters)."""
+    return NmsParams({"none": 0, "max": 1, "maxg": 2}[type], 1 if ovrDnm == "union" else 0, float(overlap), float(thr),
+                     1 if prune else 0, int(maxCount), float(pruneRatio))
+
+
 class Detection(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
                 ("score", C.c_float), ("scale", C.c_int32)]
@@ -183,6 +194,8 @@ def load():
         "acf_hip_stream_close": ([ctx], C.c_int),
         "acf_hip_host_alloc": ([C.c_size_t, C.POINTER(C.c_void_p)], C.c_int),
         "acf_hip_host_free": ([C.c_void_p], C.c_int),
+        "acf_hip_set_nms": ([ctx, C.POINTER(NmsParams)], C.c_int),
+        "acf_hip_op_nms": ([ctx, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(NmsParams), C.POINTER(C.c_int32), C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_detections": ([ctx, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_hits": ([ctx, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_export_detections": ([ctx, C.c_void_p, C.c_int], C.c_int),
@@ -213,7 +226,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_create", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_get_lambdas", "acf_hip_pyramid",
-    "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_get_detections", "acf_hip_get_hits",
+    "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits",
     "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",

@@ -180,6 +180,11 @@ struct acf_hip_ctx
     // acf_hip_op_acf_detect1 can swap in a temporary set and restore the plan's
     CascState cs;
     BoxLevel* d_boxLevels = nullptr;
+    // device bbNms + prune (acf_hip_set_nms): survivors of every frame, what get_detections / export then return
+    bool nmsOn = false;
+    acf_hip_nms_params nms{};
+    int32_t *d_nmsKeep = nullptr, *d_nmsN = nullptr, *d_nmsCounts = nullptr;
+    acf_hip_detection* d_nmsDets = nullptr;
     std::vector<int32_t> h_counts;
     bool countsFetched = false;
 };
@@ -277,6 +282,8 @@ void freeAll(acf_hip_ctx* c)
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->d_ldcfJobs = nullptr;
     c->d_ldcfTileJobs = nullptr;
+    c->d_nmsKeep = c->d_nmsN = c->d_nmsCounts = nullptr;
+    c->d_nmsDets = nullptr;
     c->ldcfTiles = 0;
     c->lastFrames = nullptr;
     c->pyramidValid = c->detectValid = false;
@@ -2797,6 +2804,55 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     return ACF_HIP_OK;
 }
 
+static const size_t kNmsLds = size_t(NMS_CAP) * (8 + 16 + 4 + 1);
+
+static void fillNmsArgs(NmsArgs& a, const acf_hip_nms_params& q)
+{
+    a.greedy = q.type == 2;
+    a.ovrUnion = q.ovrDnmUnion != 0;
+    a.doPrune = q.prune != 0;
+    a.maxCount = q.maxCount;
+    a.overlap = q.overlap;
+    a.thr = q.thr;
+    a.pruneRatio = q.pruneRatio;
+}
+
+// bbNms + prune of every frame's detections (k_nms, one workgroup per frame)
+static int launchNms(acf_hip_ctx* c, int nF)
+{
+    int rc;
+    if (!c->d_nmsKeep)
+    {
+        if ((rc = devAlloc(c, &c->d_nmsKeep, size_t(c->maxBatch) * NMS_CAP)) || (rc = devAlloc(c, &c->d_nmsN, size_t(c->maxBatch))) ||
+            (rc = devAlloc(c, &c->d_nmsCounts, size_t(c->maxBatch))) || (rc = devAlloc(c, &c->d_nmsDets, size_t(c->maxBatch) * c->maxHits)))
+        {
+            return rc;
+        }
+    }
+    NmsArgs a{};
+    a.dets = c->cs.d_dets;
+    a.counts = c->cs.d_counts;
+    a.maxHits = c->maxHits;
+    fillNmsArgs(a, c->nms);
+    a.keep = c->d_nmsKeep;
+    a.nKeep = c->d_nmsN;
+    a.outDets = c->d_nmsDets;
+    a.outCounts = c->d_nmsCounts;
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_nms), kNmsLds)))
+    {
+        return rc;
+    }
+    prof(c, "k_nms");
+    hipLaunchKernelGGL(k_nms, dim3(nF), dim3(1024), kNmsLds, c->stream, a);
+    LAUNCHCHK(c, "k_nms");
+    return ACF_HIP_OK;
+}
+
+static inline bool nmsActive(const acf_hip_ctx* c)
+{
+    return c->nmsOn && c->nms.type != 0 && c->d_nmsDets;
+}
+
 static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const BoxLevel* d_box, int nF, int nChns)
 {
     const acf_hip_params& p = c->p;
@@ -2929,6 +2985,14 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
     hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, (const int32_t*)c->cs.d_counts, c->maxHits,
         d_box, p.stride, shift_h, shift_w, c->cs.d_sorted, c->cs.d_dets);
     LAUNCHCHK(c, "k_sort_map");
+    if (c->nmsOn && c->nms.type != 0)
+    {
+        int rc = launchNms(c, nF);
+        if (rc)
+        {
+            return rc;
+        }
+    }
     prof(c, "(end)");
     c->countsFetched = false;
     return ACF_HIP_OK;
@@ -3397,10 +3461,120 @@ static int fetchCounts(acf_hip_ctx* c)
     }
     if (!c->countsFetched)
     {
-        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->cs.d_counts, sizeof(int32_t) * c->lastBatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), nmsActive(c) ? c->d_nmsCounts : c->cs.d_counts, sizeof(int32_t) * c->lastBatch, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->countsFetched = true;
     }
+    return ACF_HIP_OK;
+}
+
+static int checkNmsParams(acf_hip_ctx* c, const acf_hip_nms_params* q)
+{
+    if (q->type < 0 || q->type > 2 || !(q->overlap == q->overlap) || (q->prune && q->maxCount < 0))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "nms: type 0..2, overlap a number, maxCount >= 0");
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_set_nms(acf_hip_ctx* c, const acf_hip_nms_params* q)
+{
+    if (!c)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (q)
+    {
+        const int rc = checkNmsParams(c, q);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    for (acf_hip_ctx* k : c->kids)
+    {
+        (void)acf_hip_set_nms(k, q);
+    }
+    c->nmsOn = q != nullptr;
+    if (q)
+    {
+        c->nms = *q;
+    }
+    c->detectValid = false; // the resident detections were produced under the previous setting
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_nms(acf_hip_ctx* c, const int32_t* boxes, const double* scores, int n, const acf_hip_nms_params* q, int32_t* keep_idx, int* count)
+{
+    if (!c || !q || !count || n < 0 || (n > 0 && (!boxes || !scores || !keep_idx)))
+    {
+        return c ? fail(c, ACF_HIP_E_INVALID, "op_nms: arguments") : ACF_HIP_E_INVALID;
+    }
+    int rc = checkNmsParams(c, q);
+    if (rc)
+    {
+        return rc;
+    }
+    if (n == 0 || q->type == 0)
+    {
+        // bbNms returns its input for an empty list and for type "none" (bbNms.cpp:262-273); prune still applies to the caller
+        for (int i = 0; i < n; i++)
+        {
+            keep_idx[i] = i;
+        }
+        *count = n;
+        return ACF_HIP_OK;
+    }
+    if (n > NMS_CAP)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "op_nms: more than ACF_HIP_NMS_CAP boxes");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t *d_box = nullptr, *d_keep = nullptr, *d_n = nullptr;
+    double* d_sc = nullptr;
+    HIPCHK(c, hipMalloc(&d_box, size_t(n) * 16));
+    HIPCHK(c, hipMalloc(&d_sc, size_t(n) * 8));
+    HIPCHK(c, hipMalloc(&d_keep, size_t(NMS_CAP) * 4));
+    HIPCHK(c, hipMalloc(&d_n, 4));
+    auto cleanup = [&]() {
+        (void)hipFree(d_box);
+        (void)hipFree(d_sc);
+        (void)hipFree(d_keep);
+        (void)hipFree(d_n);
+    };
+    NmsArgs a{};
+    a.boxes = d_box;
+    a.scores = d_sc;
+    a.nOp = n;
+    fillNmsArgs(a, *q);
+    a.keep = d_keep;
+    a.nKeep = d_n;
+    hipError_t e = hipMemcpyAsync(d_box, boxes, size_t(n) * 16, hipMemcpyHostToDevice, c->stream);
+    e = e ? e : hipMemcpyAsync(d_sc, scores, size_t(n) * 8, hipMemcpyHostToDevice, c->stream);
+    if (!e && (rc = allowLds(c, reinterpret_cast<const void*>(&k_nms), kNmsLds)))
+    {
+        cleanup();
+        return rc;
+    }
+    int32_t m = 0;
+    if (!e)
+    {
+        hipLaunchKernelGGL(k_nms, dim3(1), dim3(1024), kNmsLds, c->stream, a);
+        e = hipGetLastError();
+    }
+    e = e ? e : hipMemcpyAsync(&m, d_n, 4, hipMemcpyDeviceToHost, c->stream);
+    e = e ? e : hipStreamSynchronize(c->stream);
+    if (!e && m > 0)
+    {
+        e = hipMemcpy(keep_idx, d_keep, size_t(m) * 4, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e)
+    {
+        c->err = std::string("op_nms: ") + hipGetErrorString(e);
+        return ACF_HIP_E_HIP;
+    }
+    *count = m;
     return ACF_HIP_OK;
 }
 
@@ -3430,6 +3604,10 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
         return fail(c, ACF_HIP_E_INVALID, "get_detections: frame index");
     }
     const int n = c->h_counts[frame];
+    if (n < 0)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "more than ACF_HIP_NMS_CAP detections into the device NMS: raise cascThr or take the raw list (acf_hip_set_nms(NULL))");
+    }
     if (count)
     {
         *count = n;
@@ -3437,7 +3615,7 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
     const int m = std::min(std::min(n, c->maxHits), cap);
     if (m > 0 && out)
     {
-        HIPCHK(c, hipMemcpy(out, c->cs.d_dets + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(out, (nmsActive(c) ? c->d_nmsDets : c->cs.d_dets) + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
     }
     if (n > c->maxHits)
     {
@@ -3516,8 +3694,8 @@ int acf_hip_export_detections(acf_hip_ctx* c, int32_t* dst_dev, int cap)
         return fail(c, ACF_HIP_E_INVALID, "export_detections: nothing to export");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_export, dim3(cdiv(cap, 256), c->lastBatch), dim3(256), 0, c->stream, (const acf_hip_detection*)c->cs.d_dets,
-        (const int32_t*)c->cs.d_counts, c->maxHits, cap, dst_dev);
+    hipLaunchKernelGGL(k_export, dim3(cdiv(cap, 256), c->lastBatch), dim3(256), 0, c->stream,
+        (const acf_hip_detection*)(nmsActive(c) ? c->d_nmsDets : c->cs.d_dets), (const int32_t*)(nmsActive(c) ? c->d_nmsCounts : c->cs.d_counts), c->maxHits, cap, dst_dev);
     LAUNCHCHK(c, "k_export");
     return ACF_HIP_OK;
 }

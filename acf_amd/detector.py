@@ -188,6 +188,23 @@ class HipDetector:
         return det[:n.value].copy(), hits[:n.value].copy()
 
     # ---- parity taps
+    def set_nms(self, params):
+        """params: capi.NmsParams (capi.make_nms) or None.  From the next detect()/run() on, detections() and
+        export_detections() return the survivors of bbNms (+ prune), in score order."""
+        self._nms_keep = params
+        self._chk(self.lib.acf_hip_set_nms(self.ctx, C.byref(params) if params is not None else None))
+
+    def op_nms(self, boxes, scores, params):
+        """bbNms + prune of one host list: boxes int32 [n][4] = x, y, w, h; scores float64 [n] -> indices of the survivors in order."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        n = len(scores)
+        keep = np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int(0)
+        self._chk(self.lib.acf_hip_op_nms(self.ctx, boxes.ctypes.data_as(C.POINTER(C.c_int32)), scores.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                          C.byref(params), keep.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(cnt)))
+        return keep[:cnt.value].copy()
+
     def lambdas(self, frame=0):
         """The three lambdas frame `frame` of the last pyramid was approximated with (the model's, or estimated from the image)."""
         out = (C.c_double * 3)()

@@ -214,29 +214,59 @@ void HipDetector::ensurePlan(int imgH, int imgW, int d, int batch)
     }
 }
 
+// ---- host-side bbNms + prune.  The hot paths run both on the device (acf_hip_set_nms: k_nms, one workgroup per frame,
+// before the records leave the GPU); these host forms serve operator()(Pyramid) and callers of the public methods.
+// Semantics: bbNms.cpp:111-192,229-304 and ObjectDetector.cpp:28-44, written as predicates over the score ranking:
+//   a box is suppressed when some box RANKED ABOVE it overlaps it by more than `overlap` — any such box for "max",
+//   one that itself survived for "maxg" (greedy).
+
+namespace
+{
+struct RankedBox
+{
+    int x0, y0, x1, y1, area;
+    size_t src; // index in the caller's list
+};
+
+// area of the intersection over the union / the smaller area (ovrDnm), 0 for disjoint boxes
+inline double overlapRatio(const RankedBox& a, const RankedBox& b, bool overUnion)
+{
+    const int iw = std::min(a.x1, b.x1) - std::max(a.x0, b.x0);
+    const int ih = std::min(a.y1, b.y1) - std::max(a.y0, b.y0);
+    if (iw <= 0 || ih <= 0)
+    {
+        return 0.0;
+    }
+    const double inter = double(iw * ih);
+    return inter / (overUnion ? double(a.area + b.area) - inter : double(std::min(a.area, b.area)));
+}
+} // namespace
+
 void HipDetector::prune(RectVec& objects, RealVec& scores) const
 {
-    // ObjectDetector.cpp:28-44
-    if (objects.size() > 1)
+    // keep the leading run of scores >= scores[0] * ratio, plus the first one below it, at most m_maxDetectionCount
+    // (ObjectDetector.cpp:28-44: `cutoff = i + 1` is assigned before the ratio test)
+    const size_t n = objects.size();
+    if (n < 2)
     {
-        int cutoff = 1;
-        for (size_t i = 1; i < std::min(m_maxDetectionCount, objects.size()); i++)
-        {
-            cutoff = int(i) + 1;
-            if (scores[i] < (scores[0] * m_detectionScorePruneRatio))
-            {
-                break;
-            }
-        }
-        objects.erase(objects.begin() + cutoff, objects.end());
-        scores.erase(scores.begin() + cutoff, scores.end());
+        return;
     }
+    const size_t limit = std::min(m_maxDetectionCount, n);
+    const double floorScore = scores[0] * m_detectionScorePruneRatio;
+    size_t firstLow = 1;
+    while (firstLow < limit && !(scores[firstLow] < floorScore))
+    {
+        firstLow++;
+    }
+    const size_t keep = limit < 2 ? 1 : std::min(firstLow + 1, limit);
+    objects.resize(keep);
+    scores.resize(keep);
 }
 
 int HipDetector::bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, DetectionVec& bbs)
 {
-    // bbNms.cpp:229-304 + nmsMax :111-192.  ms / cover are stubs in the reference (:100-108): pass-through.
     bbs = bbsIn;
+    // "ms" and "cover" are pass-through stubs in the reference (bbNms.cpp:100-108)
     if (bbs.empty() || pNms.type == "none" || pNms.type == "ms" || pNms.type == "cover")
     {
         return 0;
@@ -245,72 +275,75 @@ int HipDetector::bbNms(const DetectionVec& bbsIn, const Options::Nms& pNms, Dete
     {
         throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown type " + pNms.type);
     }
-    int ovrDnm;
-    if (pNms.ovrDnm == "union") ovrDnm = 1;
-    else if (pNms.ovrDnm == "min") ovrDnm = 0;
-    else throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown ovrDnm " + pNms.ovrDnm);
-    const double thr = pNms.thr;
-    bbs.erase(std::remove_if(bbs.begin(), bbs.end(), [=](const Detection& b) { return b.score < thr; }), bbs.end());
-    if (bbs.empty())
+    if (pNms.ovrDnm != "union" && pNms.ovrDnm != "min")
     {
-        return 0;
+        throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown ovrDnm " + pNms.ovrDnm);
     }
-    const bool greedy = pNms.type == "maxg";
-    const size_t n = bbs.size();
-    std::vector<size_t> ord(n);
-    std::iota(ord.begin(), ord.end(), size_t(0));
-    // The reference uses std::sort (util/ordered.h:27), whose order among equal scores is unspecified;
-    // a stable sort is one of its valid outcomes and is deterministic.
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return bbs[a].score > bbs[b].score; });
-    struct R { int as, xs, xe, ys, ye, kp; };
-    std::vector<R> c(n);
-    DetectionVec sorted(n);
-    for (size_t i = 0; i < n; i++)
+    const bool overUnion = pNms.ovrDnm == "union", greedy = pNms.type == "maxg";
+    // ranking: scores at or above thr, best first; equal scores keep their input order (the reference's std::sort,
+    // util/ordered.h:27, leaves that order open — this is one of its outcomes, and the device kernel's)
+    std::vector<RankedBox> rank;
+    rank.reserve(bbsIn.size());
+    for (size_t i = 0; i < bbsIn.size(); i++)
     {
-        sorted[i] = bbs[ord[i]];
-        const Rect& r = sorted[i].roi;
-        c[i] = R{ r.width * r.height, r.x, r.x + r.width, r.y, r.y + r.height, 1 };
-    }
-    for (size_t i = 0; i < n; i++)
-    {
-        if (greedy && !c[i].kp)
+        if (!(bbsIn[i].score < pNms.thr))
         {
-            continue;
-        }
-        for (size_t j = i + 1; j < n; j++)
-        {
-            if (!c[j].kp)
-            {
-                continue;
-            }
-            const int iw = std::min(c[i].xe, c[j].xe) - std::max(c[i].xs, c[j].xs);
-            if (iw <= 0)
-            {
-                continue;
-            }
-            const int ih = std::min(c[i].ye, c[j].ye) - std::max(c[i].ys, c[j].ys);
-            if (ih <= 0)
-            {
-                continue;
-            }
-            double o = double(iw * ih);
-            const double u = ovrDnm ? (c[i].as + c[j].as - o) : std::min(c[i].as, c[j].as);
-            o /= u;
-            if (o > pNms.overlap)
-            {
-                c[j].kp = 0;
-            }
+            const Rect& r = bbsIn[i].roi;
+            rank.push_back(RankedBox{ r.x, r.y, r.x + r.width, r.y + r.height, r.width * r.height, i });
         }
     }
+    std::stable_sort(rank.begin(), rank.end(), [&](const RankedBox& a, const RankedBox& b) { return bbsIn[a.src].score > bbsIn[b.src].score; });
+    std::vector<char> survives(rank.size(), 1);
     bbs.clear();
-    for (size_t i = 0; i < n; i++)
+    for (size_t j = 0; j < rank.size(); j++)
     {
-        if (c[i].kp)
+        for (size_t i = 0; i < j && survives[j]; i++)
         {
-            bbs.push_back(sorted[i]);
+            if ((!greedy || survives[i]) && overlapRatio(rank[i], rank[j], overUnion) > pNms.overlap)
+            {
+                survives[j] = 0;
+            }
+        }
+        if (survives[j])
+        {
+            bbs.push_back(bbsIn[rank[j].src]);
         }
     }
     return 0;
+}
+
+// Tell the library what the reference's operator() does after the cascade (ACF.cpp:332-364): bbNms + prune on the
+// device when non-maxima suppression is on, the raw list otherwise.
+void HipDetector::syncNms()
+{
+    const bool deviceNms = m_doNms && (opts.pNms.type == "max" || opts.pNms.type == "maxg");
+    if (!deviceNms)
+    {
+        if (m_nmsOnDevice)
+        {
+            check(m_api->acf_hip_set_nms(m_ctx, nullptr), "acf_hip_set_nms");
+            m_nmsOnDevice = false;
+        }
+        return;
+    }
+    if (opts.pNms.ovrDnm != "union" && opts.pNms.ovrDnm != "min")
+    {
+        throw Exception(ACF_HIP_E_INVALID, "bbNms: unknown ovrDnm " + opts.pNms.ovrDnm);
+    }
+    acf_hip_nms_params q{};
+    q.type = opts.pNms.type == "maxg" ? 2 : 1;
+    q.ovrDnmUnion = opts.pNms.ovrDnm == "union";
+    q.overlap = opts.pNms.overlap;
+    q.thr = opts.pNms.thr;
+    q.prune = 1;
+    q.maxCount = int(std::min<size_t>(m_maxDetectionCount, size_t(1) << 30));
+    q.pruneRatio = m_detectionScorePruneRatio;
+    if (!m_nmsOnDevice || std::memcmp(&q, &m_nmsSent, sizeof(q)) != 0)
+    {
+        check(m_api->acf_hip_set_nms(m_ctx, &q), "acf_hip_set_nms");
+        m_nmsSent = q;
+        m_nmsOnDevice = true;
+    }
 }
 
 void HipDetector::fetch(int frame, RectVec& objects, RealVec* scores)
@@ -330,7 +363,7 @@ void HipDetector::fetch(int frame, RectVec& objects, RealVec* scores)
 
 void HipDetector::finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const
 {
-    if (m_doNms)
+    if (m_doNms && !m_nmsOnDevice)
     {
         // ACF.cpp:332-353
         if (!bbs.empty())
@@ -372,6 +405,7 @@ int HipDetector::operator()(const MatP& Ip, RectVec& objects, RealVec* scores)
     }
     // rows = image width, cols = image height
     ensurePlan(Ip.cols(), Ip.rows(), Ip.channels(), 1);
+    syncNms();
     check(m_api->acf_hip_run_host(m_ctx, Ip.data(), 1), "acf_hip_run_host");
     fetch(0, objects, scores);
     return 0;
@@ -451,6 +485,7 @@ void HipDetector::streamOpen(int rows, int cols, int pix, int rowStrideBytes, in
 int HipDetector::streamSubmit(const uint8_t* frames, int nFrames)
 {
     int t = -1;
+    syncNms();
     check(m_api->acf_hip_stream_submit(m_ctx, frames, nFrames, &t), "acf_hip_stream_submit");
     return t;
 }
@@ -469,7 +504,7 @@ void HipDetector::streamCollect(int ticket, std::vector<RectVec>& objects, std::
     for (int f = 0; f < n; f++)
     {
         const int32_t* r = rec + size_t(f) * per;
-        if (r[0] > m_streamCap)
+        if (r[0] > m_streamCap || r[0] < 0)
         {
             throw Exception(ACF_HIP_E_CAPACITY, "streamCollect: more detections than maxDetectionsPerFrame");
         }
@@ -517,6 +552,7 @@ int HipDetector::detectBatch(const float* frames, int nFrames, int rows, int col
     std::vector<RectVec>& objects, std::vector<RealVec>* scores)
 {
     ensurePlan(cols, rows, channels, nFrames);
+    syncNms();
     check(m_api->acf_hip_run_host(m_ctx, frames, nFrames), "acf_hip_run_host");
     objects.assign(size_t(nFrames), RectVec());
     if (scores)

@@ -294,6 +294,9 @@ private:
     acf_hip_ctx* m_ctx = nullptr;
     bool m_good = false, m_dirty = true;
     bool m_doNms = false, m_isLuv = false, m_isTranspose = false, m_isRowMajor = false;
+    void syncNms();
+    bool m_nmsOnDevice = false;
+    acf_hip_nms_params m_nmsSent{};
     size_t m_maxDetectionCount = 10;
     double m_detectionScorePruneRatio = 0.0;
     int m_planH = 0, m_planW = 0, m_planD = 0, m_planBatch = 0;

@@ -46,6 +46,8 @@ struct Api
     ACF_HIP_FN(acf_hip_stream_close)
     ACF_HIP_FN(acf_hip_host_alloc)
     ACF_HIP_FN(acf_hip_host_free)
+    ACF_HIP_FN(acf_hip_set_nms)
+    ACF_HIP_FN(acf_hip_op_nms)
     ACF_HIP_FN(acf_hip_get_detections)
     ACF_HIP_FN(acf_hip_get_hits)
     ACF_HIP_FN(acf_hip_export_detections)

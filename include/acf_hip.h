@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 4
+#define ACF_HIP_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -126,6 +126,22 @@ typedef struct acf_hip_detection
     float score;
     int32_t scale; /* pyramid level that produced it */
 } acf_hip_detection;
+
+/* bbNms (types max / maxg; ms and cover are pass-through stubs in the reference, bbNms.cpp:100-108) and
+ * ObjectDetector::prune, run on the device on every frame's detections (bbNms.cpp:111-192,229-304;
+ * ObjectDetector.cpp:28-44).  Equal scores keep their detection order (the reference's std::sort leaves it open). */
+typedef struct acf_hip_nms_params
+{
+    int32_t type;       /* 0 none, 1 max, 2 maxg (greedy) */
+    int32_t ovrDnmUnion;/* 1: overlap / union (ovrDnm "union"), 0: overlap / smaller area ("min") */
+    double overlap;     /* suppress when the ratio exceeds this */
+    double thr;         /* scores below thr are dropped first (reference default: -DBL_MAX) */
+    int32_t prune;      /* 1: apply ObjectDetector::prune to the survivors */
+    int32_t maxCount;   /* m_maxDetectionCount */
+    double pruneRatio;  /* m_detectionScorePruneRatio */
+} acf_hip_nms_params;
+
+#define ACF_HIP_NMS_CAP 4096 /* detections per frame the device NMS takes; more is ACF_HIP_E_CAPACITY */
 
 /* One cascade hit before box mapping: DetectionSink::add({c,r},h) (acfDetect1.cpp:39-47,92-95). */
 typedef struct acf_hip_hit
@@ -267,6 +283,14 @@ ACF_HIP_API int acf_hip_host_free(void* p);
 /* Wait for the stream, then return frame `frame`'s detections in the
  * reference's order (level ascending, then c, then r; ACF.cpp:326-329,
  * acfDetect1.cpp:86-96).  `*count` is the true number even if > cap. */
+/* params != NULL: from the next acf_hip_detect / acf_hip_run* on, every frame's detections go through bbNms (+ prune)
+ * on the device, and acf_hip_get_detections / acf_hip_export_detections / the stream records return the survivors, in
+ * score order (Detector::operator(), ACF.cpp:332-353).  NULL: back to the raw list (scale, column, row order). */
+ACF_HIP_API int acf_hip_set_nms(acf_hip_ctx* ctx, const acf_hip_nms_params* params);
+/* bbNms + prune of one host list: boxes [n][4] = {x, y, w, h}, f64 scores; keep_idx receives the indices of the survivors
+ * in output order (capacity n), *count their number.  n <= ACF_HIP_NMS_CAP. */
+ACF_HIP_API int acf_hip_op_nms(acf_hip_ctx* ctx, const int32_t* boxes, const double* scores, int n, const acf_hip_nms_params* params,
+    int32_t* keep_idx, int* count);
 ACF_HIP_API int acf_hip_get_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
 ACF_HIP_API int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, int cap, int* count);
 

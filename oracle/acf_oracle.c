@@ -1301,6 +1301,120 @@ static void pad_reflect(const float* src, float* dst, int h, int w, int py, int 
  * level, unsmoothed/unpadded channels, may be NULL.
  * ---------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------
+ * f1  bbNms (types max / maxg) + ObjectDetector::prune — bbNms.cpp:111-192 (nmsMax), :229-304 (threshold, dispatch),
+ * ObjectDetector.cpp:28-44 (prune).  boxes [n][4] = {x, y, w, h}; scores f64.  keep receives the indices of the
+ * survivors in output order; returns their number.  type: 1 max, 2 maxg (0: everything, in input order).
+ * The reference orders by score with std::sort (util/ordered.h:23-31): the order among equal scores is unspecified
+ * there; here (and on the device) ties keep their input order.  Checked against the reference's own numbers only
+ * through the properties its code implies (tests/test_nms.py): PARITY UNPINNED by a reference-produced vector.
+ * ---------------------------------------------------------------------- */
+ACFO_API int acfo_nms(const int32_t* boxes, const double* scores, int n, int type, int ovrDnmUnion, double overlap, double thr,
+    int doPrune, int maxCount, double pruneRatio, int32_t* keep)
+{
+    if (n <= 0)
+    {
+        return 0;
+    }
+    int* ord = (int*)xmalloc(sizeof(int) * (size_t)n);
+    int m = 0;
+    if (type == 0)
+    {
+        for (int i = 0; i < n; i++)
+        {
+            keep[i] = i;
+        }
+        free(ord);
+        m = n;
+    }
+    else
+    {
+        for (int i = 0; i < n; i++) /* :276-279 erase score < thr */
+        {
+            if (!(scores[i] < thr))
+            {
+                ord[m++] = i;
+            }
+        }
+        /* descending score, stable (insertion sort: n is small in the tests) */
+        for (int i = 1; i < m; i++)
+        {
+            const int v = ord[i];
+            int j = i - 1;
+            while (j >= 0 && scores[ord[j]] < scores[v])
+            {
+                ord[j + 1] = ord[j];
+                j--;
+            }
+            ord[j + 1] = v;
+        }
+        char* kp = (char*)xmalloc((size_t)m + 1);
+        memset(kp, 1, (size_t)m + 1);
+        const int greedy = type == 2;
+        for (int i = 0; i < m; i++) /* :145-183 */
+        {
+            if (greedy && !kp[i])
+            {
+                continue;
+            }
+            const int32_t* bi = boxes + 4 * (size_t)ord[i];
+            const int xsi = bi[0], ysi = bi[1], xei = bi[0] + bi[2], yei = bi[1] + bi[3], asi = bi[2] * bi[3];
+            for (int j = i + 1; j < m; j++)
+            {
+                if (!kp[j])
+                {
+                    continue;
+                }
+                const int32_t* bj = boxes + 4 * (size_t)ord[j];
+                const int xsj = bj[0], ysj = bj[1], xej = bj[0] + bj[2], yej = bj[1] + bj[3], asj = bj[2] * bj[3];
+                const int iw = (xei < xej ? xei : xej) - (xsi > xsj ? xsi : xsj);
+                if (iw <= 0)
+                {
+                    continue;
+                }
+                const int ih = (yei < yej ? yei : yej) - (ysi > ysj ? ysi : ysj);
+                if (ih <= 0)
+                {
+                    continue;
+                }
+                double o = (double)(iw * ih);
+                const double u = ovrDnmUnion ? ((double)(asi + asj) - o) : (double)(asi < asj ? asi : asj);
+                o /= u;
+                if (o > overlap)
+                {
+                    kp[j] = 0;
+                }
+            }
+        }
+        int k = 0;
+        for (int i = 0; i < m; i++)
+        {
+            if (kp[i])
+            {
+                keep[k++] = ord[i];
+            }
+        }
+        free(kp);
+        free(ord);
+        m = k;
+    }
+    if (doPrune && m > 1) /* ObjectDetector.cpp:30-42 */
+    {
+        int cutoff = 1;
+        const int L = maxCount < m ? maxCount : m;
+        for (int i = 1; i < L; i++)
+        {
+            cutoff = i + 1;
+            if (scores[keep[i]] < scores[keep[0]] * pruneRatio)
+            {
+                break;
+            }
+        }
+        m = cutoff;
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------
  * a12  image-specific lambdas — chnsPyramid.cpp:341-374, MatP.cpp:97-111 (sum, numel), acf_math.h:20-29 (util::log2 =
  * log(x) / log(2)).  sum(MatP) adds the per-plane cv::sum(plane)[0] in plane order; cv::sum accumulates the f32 data in
  * f64 in OpenCV's own SIMD-blocked order, which cannot be restated without OpenCV (absent from this image): PARITY

@@ -66,6 +66,9 @@ def lib():
         o.acfo_chns_compute.restype = C.c_int
         o.acfo_chns_pyramid.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, L, C.c_int, fp, C.POINTER(Taps), C.POINTER(fp)]
         o.acfo_chns_pyramid.restype = C.c_int
+        o.acfo_nms.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                               C.c_double, C.POINTER(C.c_int32)]
+        o.acfo_nms.restype = C.c_int
         o.acfo_plane_sum.argtypes = [fp, C.c_int]
         o.acfo_plane_sum.restype = C.c_double
         o.acfo_lambda.argtypes = [C.c_double] * 6
@@ -204,6 +207,17 @@ def chns_pyramid(plan, frame, want_taps=False, want_chns=False):
     if rc:
         raise RuntimeError("acfo_chns_pyramid rc=%d" % rc)
     return out, taps, chns
+
+
+def nms(boxes, scores, params):
+    """Oracle bbNms + prune: boxes int32 [n][4], scores float64 [n], params capi.NmsParams -> indices of the survivors in order."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    keep = np.zeros(max(len(scores), 1), np.int32)
+    m = lib().acfo_nms(boxes.ctypes.data_as(C.POINTER(C.c_int32)), scores.ctypes.data_as(C.POINTER(C.c_double)), len(scores), params.type,
+                       params.ovrDnmUnion, params.overlap, params.thr, params.prune, params.maxCount, params.pruneRatio,
+                       keep.ctypes.data_as(C.POINTER(C.c_int32)))
+    return keep[:m].copy()
 
 
 def last_lambdas():

@@ -1,9 +1,8 @@
 """The C++ host side (acf_amd/host: acf::HipDetector + dlopen loader + CLI).
 
-CPU tests: it builds with g++ alone, its NMS / prune host logic matches a
-line-by-line numpy restatement of the reference's nmsMax (bbNms.cpp:111-192)
-and prune (ObjectDetector.cpp:28-44), and it fails loudly when libacf_hip.so is
-missing.  GPU tests: the CLI's detections through every entry (image, batch,
+CPU tests: it builds with g++ alone, its NMS / prune host logic matches the
+oracle's restatement of the reference's nmsMax (bbNms.cpp:111-192) and prune
+(ObjectDetector.cpp:28-44), and it fails loudly when libacf_hip.so is missing.  GPU tests: the CLI's detections through every entry (image, batch,
 host-pyramid round trip, NMS) equal the oracle's.
 """
 import os
@@ -50,63 +49,21 @@ def parse(out):
     return frames
 
 
-def nms_ref(boxes, scores, overlap, greedy, ovr_union, thr=-np.inf):
-    """nmsMax restated (bbNms.cpp:111-192) with a stable descending sort."""
-    keep_thr = [i for i in range(len(boxes)) if not scores[i] < thr]
-    boxes = [boxes[i] for i in keep_thr]
-    scores = [scores[i] for i in keep_thr]
-    order = sorted(range(len(boxes)), key=lambda i: -scores[i])  # python's sort is stable
-    b = [boxes[i] for i in order]
-    s = [scores[i] for i in order]
-    n = len(b)
-    kp = [1] * n
-    for i in range(n):
-        if greedy and not kp[i]:
-            continue
-        for j in range(i + 1, n):
-            if not kp[j]:
-                continue
-            iw = min(b[i][0] + b[i][2], b[j][0] + b[j][2]) - max(b[i][0], b[j][0])
-            if iw <= 0:
-                continue
-            ih = min(b[i][1] + b[i][3], b[j][1] + b[j][3]) - max(b[i][1], b[j][1])
-            if ih <= 0:
-                continue
-            o = float(iw * ih)
-            ai, aj = b[i][2] * b[i][3], b[j][2] * b[j][3]
-            u = (ai + aj - o) if ovr_union else min(ai, aj)
-            if o / u > overlap:
-                kp[j] = 0
-    return [b[i] for i in range(n) if kp[i]], [s[i] for i in range(n) if kp[i]]
-
-
-def prune_ref(boxes, scores, max_count, ratio):
-    if len(boxes) > 1:
-        cutoff = 1
-        for i in range(1, min(max_count, len(boxes))):
-            cutoff = i + 1
-            if scores[i] < scores[0] * ratio:
-                break
-        return boxes[:cutoff], scores[:cutoff]
-    return boxes, scores
-
-
 @pytest.mark.parametrize("typ,ovr,overlap", [("maxg", "min", 0.65), ("max", "union", 0.5), ("maxg", "union", 0.3), ("none", "min", 0.5)])
-def test_nms_and_prune_match_restated_reference(cli, tmp_path, typ, ovr, overlap):
+def test_nms_and_prune_match_the_oracle(cli, oracle, tmp_path, typ, ovr, overlap):
+    """Host bbNms + prune of acf::HipDetector (own formulation over the score ranking) against oracle/acf_oracle.c:acfo_nms,
+    the restatement of bbNms.cpp:111-192,229-304 + ObjectDetector.cpp:28-44.  Scores repeat (quantised), so ties occur."""
     u = synth.uniform(5, 400 * 5, 3).reshape(400, 5)
     boxes = [(int(r[0] * 300), int(r[1] * 200), 20 + int(r[2] * 60), 20 + int(r[3] * 60)) for r in u]
-    scores = [float(np.float32(r[4] * 30)) for r in u]
+    scores = [float(np.float32(np.floor(r[4] * 60) / 2)) for r in u]
     path = tmp_path / "boxes.txt"
     path.write_text("\n".join("%d %d %d %d %.9g" % (b + (s,)) for b, s in zip(boxes, scores)))
     p = run(cli, ["--nms-only", str(path), "--type", typ, "--ovrdnm", ovr, "--overlap", str(overlap), "--prune", "--max-count", "7", "--prune-ratio", "0.5"])
     got = parse(p.stdout)[0]
-    if typ == "none":
-        wb, ws = boxes, scores
-    else:
-        wb, ws = nms_ref(boxes, scores, overlap, typ == "maxg", ovr == "union")
-    wb, ws = prune_ref(wb, ws, 7, 0.5)
-    assert [g[:4] for g in got] == [tuple(b) for b in wb]
-    assert [g[4] for g in got] == [int(np.float32(s).view(np.uint32)) for s in ws]
+    keep = oracle.nms(boxes, scores, capi.make_nms(type=typ, overlap=overlap, ovrDnm=ovr, prune=True, maxCount=7, pruneRatio=0.5))
+    assert len(set(scores)) < len(scores)
+    assert [g[:4] for g in got] == [tuple(boxes[i]) for i in keep]
+    assert [g[4] for g in got] == [int(np.float32(scores[i]).view(np.uint32)) for i in keep]
 
 
 def test_missing_library_fails_loudly(cli, tmp_path):
@@ -166,10 +123,11 @@ def test_cli_nms_and_calibration(cli, oracle, tmp_path):
     m2["hs"] = (model["hs"] + np.float32(0.01)).astype(np.float32)  # acfModify.cpp:143
     want = _oracle_dets(oracle, m2, frames, H, W, 3)[0]
     scores = [float(np.uint32(w[4]).view(np.float32)) for w in want]
-    wb, ws = nms_ref([w[:4] for w in want], scores, 0.65, True, False)
-    wb, ws = prune_ref(wb, ws, 5, 0.0)
+    # HipDetector's default pNms (maxg, overlap .65, ovrDnm min) + prune(5, 0): on the device before the records leave it
+    keep = oracle.nms([w[:4] for w in want], scores, capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=5, pruneRatio=0.0))
     assert len(got) > 0
-    assert [g[:4] for g in got] == [tuple(b) for b in wb]
+    assert [g[:4] for g in got] == [tuple(want[i][:4]) for i in keep]
+    assert [g[4] for g in got] == [want[i][4] for i in keep]
 
 
 @pytest.mark.gpu
@@ -197,9 +155,8 @@ def test_cli_packed_u8_and_stream(cli, oracle, tmp_path, mode):
         want = [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det]
         if "--nms" in mode:
             scores = [float(np.uint32(w[4]).view(np.float32)) for w in want]
-            wb, ws = nms_ref([w[:4] for w in want], scores, 0.65, True, False)
-            wb, ws = prune_ref(wb, ws, 6, 0.0)
-            assert [g[:4] for g in got[f]] == [tuple(b) for b in wb], f
+            keep = oracle.nms([w[:4] for w in want], scores, capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=6, pruneRatio=0.0))
+            assert got[f] == [want[i] for i in keep], f
         else:
             assert got[f] == want, f
         total += len(want)
