@@ -63,16 +63,15 @@ struct CascState
     int nTiles = 0;
     TreeNode* d_tileNodes = nullptr; // offsets in the tile's LDS layout, every tree
     uint32_t* d_tileNodesS = nullptr; // stage A of k_cascade_tile2: 40 dwords per batch of four trees
-    bool tile2 = false;               // k_cascade_tile2 (one window per lane in stage A, two survivor lists)
     int aTB = 4;                      // trees per stage-A batch of k_cascade_tile2
     TreeNode* d_tailNodes = nullptr; // offsets = feature ids (window-local layout), all trees
     TileGeom geom{};
     int tailWaves = 0;
     float* d_tailScratch = nullptr; // k_cascade_tail3 leaf matrices: [blocks][tailWaves][TAIL_G][tailPad]
     int tailPad = 0, tailSlab = 0, tailBlocks = 0, tailNodesLds = 0;
-    // k_tail_codes / k_tail_scan (trees stationary, windows streaming): leaf codes of the first codeCap queue entries per frame
+    // stage E of k_cascade_tile2 + k_tail_scan: leaf codes of the first codeCap queue entries per frame
     uint8_t* d_tailCodes = nullptr;
-    int codeCap = 0, codePitch = 0, codeBpw = 0, codeDpw = 0;
+    int codeCap = 0, codePitch = 0;
 };
 
 struct acf_hip_ctx
@@ -950,10 +949,12 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             }
             if (p.treeDepth == 0 && c->child[q] != 0)
             {
-                // child[k0]-k+offset must stay inside the tree
-                if (c->child[q] >= uint32_t(p.nTreeNodes) || c->child[q] < 1)
+                // next node = child[k] - (ftr < thr) in 0-based terms child[k] - 1 or child[k] (acfDetect1.cpp:146-155): both must
+                // stay inside the tree AND lie after k — trees are stored parent-first, and a backward or self reference in
+                // an untrusted model file would make the walk `while (child[k])` spin forever on the GPU
+                if (c->child[q] >= uint32_t(p.nTreeNodes) || c->child[q] - 1 <= uint32_t(k))
                 {
-                    return fail(c, ACF_HIP_E_INVALID, "model: child index out of range");
+                    return fail(c, ACF_HIP_E_INVALID, "model: child index out of range or not after its parent");
                 }
             }
         }
@@ -1059,10 +1060,6 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         // (k_cascade_tile2, measured at cfg 2: 32 dense trees then sparse pieces [32,64) and [64,128) is 10 % faster than
         // 16 / 32 / 64 / 128: the sparse stages are latency chains, the dense stage is VALU work)
         int bounds[5] = { 0, 32, 32, 64, 128 };
-        if (getenv("ACF_HIP_TILE1"))
-        {
-            bounds[1] = 16;
-        }
         if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
         {
             int v1, v2, v3, v4;
@@ -1080,18 +1077,13 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         }
         // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for two
         // workgroups per CU (160 KiB LDS), else one
-        int W = 1; // windows per lane in stage A (kernels.hip.h): node reads and address math shared by W windows
-        if (const char* e = getenv("ACF_HIP_CASC_W"))
-        {
-            W = atoi(e) == 2 ? 2 : 1; // measured: W = 2 halves the LDS node traffic but stage A is chain-latency bound, and fewer waves slow stage D
-        }
-        const bool tile2 = W == 1 && !getenv("ACF_HIP_TILE1"); // A/B: ACF_HIP_TILE1 keeps round 1's k_cascade_tile
+        const int W = 1; // windows per lane in stage A
         auto ldsBytes = [&](int nw) {
             const int tc = nw * W * 64 / g.TR;
             const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
             const int64_t rowsP = (rows + 3) / 4 * 4;
-            // k_cascade_tile2: footprint + two survivor lists; k_cascade_tile: footprint + one list + the node table of [0, b3)
-            return int64_t(nChns) * rowsP * cols * 4 + (tile2 ? int64_t(2) * nw * 64 * 8 + 64 : int64_t(nw) * W * 64 * 8 + int64_t(48) * g.b[3]);
+            // k_cascade_tile2: footprint + two survivor lists (+ its few static words)
+            return int64_t(nChns) * rowsP * cols * 4 + int64_t(2) * nw * 64 * 8 + 64;
         };
         int nw = 0;
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
@@ -1200,7 +1192,6 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     }
                 }
                 cs.aTB = aTB;
-                cs.tile2 = tile2;
                 if ((rc = devUpload(c, &cs.d_tileNodesS, nodesS)))
                 {
                     return rc;
@@ -1228,20 +1219,11 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     return rc;
                 }
                 cs.codeCap = 0;
-                if (g.b[4] < p.nTrees && (mH % 4 == 0 || tile2) && !getenv("ACF_HIP_TAIL3"))
+                if (g.b[4] < p.nTrees && !getenv("ACF_HIP_TAIL3")) // A/B: ACF_HIP_TAIL3 sends every tail window to k_cascade_tail3
                 {
-                    // k_tail_codes: 64-tree batches per wave (1, 2 or 4; more trees than 16 waves x 4 batches x 64 take extra
-                    // passes), LDS-DMA instructions per wave per footprint (1 KB each; footprints above 32 KB keep the old tail)
-                    const int nT = p.nTrees - g.b[4], nB = (nT + 63) / 64;
-                    const int bpw = nB <= TC_NW ? 1 : (nB <= 2 * TC_NW ? 2 : 4);
-                    const int chunks = g.winFloats / 4, dpw = (chunks + TC_NW * 64 - 1) / (TC_NW * 64);
-                    if (dpw <= 2 || tile2)
                     {
-                        // row pitch: k_cascade_tile2's stage E writes 64-tree batches; k_tail_codes whole passes of 16 waves x bpw batches
-                        const int per = tile2 ? 64 : TC_NW * bpw * 64;
-                        cs.codeBpw = bpw;
-                        cs.codeDpw = dpw;
-                        cs.codePitch = (nT + per - 1) / per * per;
+                        const int nT = p.nTrees - g.b[4];
+                        cs.codePitch = (nT + 63) / 64 * 64; // stage E writes whole 64-tree batches
                         int64_t nWinTotal = 0;
                         for (const auto& l : lv)
                         {
@@ -2650,43 +2632,22 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         const int64_t total = int64_t(cs.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = cs.tile2 ? size_t(g.tileFloats) * 4 + size_t(2) * g.NW * 64 * 8 : size_t(g.tileFloats) * 4 + size_t(g.NW) * g.W * 64 * 8 + size_t(48) * g.b[3];
+        const size_t lds = size_t(g.tileFloats) * 4 + size_t(2) * g.NW * 64 * 8;
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");
-        if (cs.tile2)
-        {
 #define TILE2_LAUNCH(N)                                                                           \
     if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N>), lds)))              \
         return rc;                                                                                \
     hipLaunchKernelGGL((k_cascade_tile2<N>), grid, block, lds, c->stream, a);
-            switch (g.NW)
-            {
-                case 8: TILE2_LAUNCH(8); break;
-                case 4: TILE2_LAUNCH(4); break;
-                case 2: TILE2_LAUNCH(2); break;
-                default: TILE2_LAUNCH(1); break;
-            }
+        switch (g.NW)
+        {
+            case 8: TILE2_LAUNCH(8); break;
+            case 4: TILE2_LAUNCH(4); break;
+            case 2: TILE2_LAUNCH(2); break;
+            default: TILE2_LAUNCH(1); break;
+        }
 #undef TILE2_LAUNCH
-        }
-        else
-        {
-#define TILE_LAUNCH(N, WW)                                                                           \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile<N, WW>), lds)))              \
-        return rc;                                                                                   \
-    hipLaunchKernelGGL((k_cascade_tile<N, WW>), grid, block, lds, c->stream, a);
-        switch (g.NW * 4 + g.W)
-        {
-            case 8 * 4 + 1: TILE_LAUNCH(8, 1); break;
-            case 4 * 4 + 1: TILE_LAUNCH(4, 1); break;
-            case 2 * 4 + 1: TILE_LAUNCH(2, 1); break;
-            case 1 * 4 + 1: TILE_LAUNCH(1, 1); break;
-            case 4 * 4 + 2: TILE_LAUNCH(4, 2); break;
-            case 2 * 4 + 2: TILE_LAUNCH(2, 2); break;
-            default: TILE_LAUNCH(1, 2); break;
-        }
-#undef TILE_LAUNCH
-        }
         LAUNCHCHK(c, "k_cascade_tile");
         if (a.debug & 4)
         {
@@ -2717,32 +2678,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         }
         if (g.b[4] < p.nTrees && cs.codeCap > 0)
         {
-            // first codeCap queue entries of every frame: leaf codes (trees in registers, windows streamed), then the ordered scan
-            // workgroups per frame: two per CU over the batch, and at most 1024 windows each (their descriptors live in LDS)
-            const int K = std::max(std::max(1, 512 / nF), (cs.codeCap + 1023) / 1024);
-            const size_t ldsC = size_t(TC_NBUF) * cs.codeDpw * TC_NW * 64 * 16 + size_t((cs.codeCap + K - 1) / K) * 16;
-            const void* kc = nullptr;
-            switch (cs.codeBpw * 4 + cs.codeDpw)
-            {
-                case 1 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<1, 1>); break;
-                case 2 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<2, 1>); break;
-                case 4 * 4 + 1: kc = reinterpret_cast<const void*>(&k_tail_codes<4, 1>); break;
-                case 1 * 4 + 2: kc = reinterpret_cast<const void*>(&k_tail_codes<1, 2>); break;
-                case 2 * 4 + 2: kc = reinterpret_cast<const void*>(&k_tail_codes<2, 2>); break;
-                default: kc = reinterpret_cast<const void*>(&k_tail_codes<4, 2>); break;
-            }
-            int rc = allowLds(c, kc, ldsC);
-            if (rc)
-            {
-                return rc;
-            }
-            if (!cs.tile2) // k_cascade_tile2 wrote the codes itself (stage E)
-            {
-                prof(c, "k_tail_codes");
-                void* kargs[] = { &a };
-                HIPCHK(c, hipLaunchKernel(kc, dim3(K * nF), dim3(TC_NW * 64), kargs, ldsC, c->stream));
-                LAUNCHCHK(c, "k_tail_codes");
-            }
+            // the first codeCap queue entries of every frame carry leaf codes (stage E of the tile kernel): the ordered scan
             const size_t ldsS = size_t(p.nTrees - g.b[4]) * 16;
             if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_tail_scan), ldsS)))
             {
@@ -2754,36 +2690,23 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         }
         if (g.b[4] < p.nTrees)
         {
-            static const bool oldTail = getenv("ACF_HIP_TAIL2") != nullptr; // A/B: the one-window-per-wave ordered scan
+            // queue entries without codes (beyond codeCap, or ACF_HIP_TAIL3): k_cascade_tail3; its blocks leave at once when
+            // k_tail_scan has taken the whole queue
             dim3 tgrid(std::min(cs.tailBlocks, std::max(1, 512 / nF) * nF)), tblock(cs.tailWaves * 64);
-            if (oldTail)
-            {
-                a.tailSlab = g.winFloats;
-                a.tailNodesLds = 0;
-            }
             const size_t tl = (size_t(cs.tailWaves) * a.tailSlab + size_t(a.tailNodesLds)) * 4;
-            prof(c, "k_cascade_tail2");
+            prof(c, "k_cascade_tail3");
 #define TAIL_LAUNCH(N)                                                                                              \
-    if (oldTail)                                                                                                    \
+    if (a.tailNodesLds)                                                                                             \
     {                                                                                                               \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail2<N>), tl)))                             \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, true>), tl)))                       \
             return rc;                                                                                              \
-        hipLaunchKernelGGL(k_cascade_tail2<N>, tgrid, tblock, tl, c->stream, a);                                    \
+        hipLaunchKernelGGL((k_cascade_tail3<N, true>), tgrid, tblock, tl, c->stream, a);                            \
     }                                                                                                               \
     else                                                                                                            \
     {                                                                                                               \
-        if (a.tailNodesLds)                                                                                         \
-        {                                                                                                           \
-            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, true>), tl)))                   \
-                return rc;                                                                                          \
-            hipLaunchKernelGGL((k_cascade_tail3<N, true>), tgrid, tblock, tl, c->stream, a);                        \
-        }                                                                                                           \
-        else                                                                                                        \
-        {                                                                                                           \
-            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, false>), tl)))                  \
-                return rc;                                                                                          \
-            hipLaunchKernelGGL((k_cascade_tail3<N, false>), tgrid, tblock, tl, c->stream, a);                       \
-        }                                                                                                           \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, false>), tl)))                      \
+            return rc;                                                                                              \
+        hipLaunchKernelGGL((k_cascade_tail3<N, false>), tgrid, tblock, tl, c->stream, a);                           \
     }
             switch (cs.tailWaves)
             {
@@ -2798,7 +2721,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
                     break;
             }
 #undef TAIL_LAUNCH
-            LAUNCHCHK(c, "k_cascade_tail2");
+            LAUNCHCHK(c, "k_cascade_tail3");
         }
     }
     return ACF_HIP_OK;
@@ -2982,7 +2905,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
     const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
     const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
     prof(c, "k_sort_map");
-    hipLaunchKernelGGL(k_sort_map, dim3(4, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, (const int32_t*)c->cs.d_counts, c->maxHits,
+    hipLaunchKernelGGL(k_sort_map, dim3(SM_BLOCKS, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, (const int32_t*)c->cs.d_counts, c->maxHits,
         d_box, p.stride, shift_h, shift_w, c->cs.d_sorted, c->cs.d_dets);
     LAUNCHCHK(c, "k_sort_map");
     if (c->nmsOn && c->nms.type != 0)

@@ -3278,15 +3278,11 @@ __global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
 // two workgroups per CU, and each pyramid cell is fetched ~2.8x per frame in
 // total instead of once per (window, tree node) touching it.
 //
-//   stage A  trees [b0,b1): one lane per window (lanes run along r, so a wave's
-//            LDS addresses are consecutive: conflict-free), node data by scalar
-//            loads from one level-independent table of LDS offsets.
-//   compaction in LDS (ballot prefix + one LDS atomic per wave), then
-//   stage B  [b1,b2) and stage C [b2,b3): dense lanes over the survivor list.
-//   stage D  [b3,b4): the handful of windows still alive get one WAVE each,
-//            lanes = 64 consecutive trees (wave_eval_trees below).
-//   survivors of the last tile stage go to the frame's tail queue (or are hits
-//   if the model has no more trees).
+//   stage A  trees [b0,b1): one lane per window (lanes run along r, so a wave's LDS addresses are consecutive:
+//            conflict-free), node records through the scalar unit;
+//   sparse stages [b1,b2) [b2,b3) [b3,b4): items = survivors x trees, the score accumulated in tree order by a DPP chain;
+//   stage E  the leaf codes of every remaining tree for the windows that reach the tail (k_tail_scan adds them up).
+//   (k_cascade_tile2 below; round 1's k_cascade_tile, one lane per window in every stage, is gone.)
 //
 // Scores are those of ParallelDetectionBody::evaluate (acfDetect1.cpp:123-138):
 // every window adds the same leaves in the same order and stops at the first
@@ -3347,7 +3343,7 @@ struct TileArgs
     float* tailScratch;
     int32_t tailPad, tailSlab;
     int32_t tailNodesLds; // the tail's node table fits in LDS next to the footprint slabs (floats reserved at the start of LDS, else 0)
-    // k_tail_codes / k_tail_scan: leaf codes [frame][codeCap][codePitch] bytes (4 * leaf index of every tail tree of a queued window)
+    // stage E of k_cascade_tile2 / k_tail_scan: leaf codes [frame][codeCap][codePitch] bytes (4 * leaf index of every tail tree of a queued window)
     uint8_t* tailCodes;
     int32_t codeCap, codePitch;
 };
@@ -3355,352 +3351,13 @@ struct TileArgs
 // Keep scalar / vector values materialised at this point: stops the compiler from
 // sinking the loads that produce them into the data-dependent selects below (which
 // turns straight-line select code into branches with a memory wait in every arm).
-#define ACF_PIN_S4(q) asm volatile("" ::"s"((q).x), "s"((q).y), "s"((q).z), "s"((q).w))
 #define ACF_PIN_V(x) asm volatile("" : "+v"(x))
 
-// Lanes = windows.  `win` points at the lane's window inside the LDS tile.  Trees are
-// taken TG at a time.  The node table is read through the constant address space, so
-// the (wave-uniform) loads go through the scalar unit: measured against wave-uniform
-// vector loads (12 per 4 trees, each a full 64-lane pass through the texture
-// addresser) the scalar path is 1.7x faster for the whole kernel; TG = 4 without
-// software prefetch measured faster than TG = 2 with the next batch requested early
-// (SGPR budget does not allow two batches of four).
-#define CASC_TG 4
-struct NodeBatch
-{
-    u32x4 o[CASC_TG], tq[CASC_TG], hq[CASC_TG];
-};
-
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) u32x16* cptr16_t;
-
-// CASC_TG = 4 nodes = 192 contiguous bytes = three s_load_dwordx16 (fewer, larger scalar requests)
-__device__ __forceinline__ void load_nodes(NodeBatch& b, const TreeNode* __restrict__ nodes, int t)
-{
-    cptr16_t np = (cptr16_t)(uintptr_t)(nodes + t);
-    const u32x16 q0 = np[0], q1 = np[1], q2 = np[2];
-    uint32_t w[48];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-    {
-        w[i] = q0[i];
-        w[16 + i] = q1[i];
-        w[32 + i] = q2[i];
-    }
-#pragma unroll
-    for (int g = 0; g < CASC_TG; g++)
-    {
-        b.o[g] = u32x4{ w[12 * g + 0], w[12 * g + 1], w[12 * g + 2], w[12 * g + 3] };
-        b.tq[g] = u32x4{ w[12 * g + 4], w[12 * g + 5], w[12 * g + 6], w[12 * g + 7] };
-        b.hq[g] = u32x4{ w[12 * g + 8], w[12 * g + 9], w[12 * g + 10], w[12 * g + 11] };
-    }
-}
-
-__device__ __forceinline__ void tile_eval(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h, bool& alive)
-{
-    int t = t0;
-    for (; t + CASC_TG <= t1; t += CASC_TG)
-    {
-        if (!__any(alive))
-        {
-            return;
-        }
-        NodeBatch cur;
-        load_nodes(cur, nodes, t);
-        {
-            float f0[CASC_TG], f1[CASC_TG], f2[CASC_TG];
-#pragma unroll
-            for (int g = 0; g < CASC_TG; g++)
-            {
-                f0[g] = win[cur.o[g].x];
-                f1[g] = win[cur.o[g].y];
-                f2[g] = win[cur.o[g].z];
-            }
-#pragma unroll
-            for (int g = 0; g < CASC_TG; g++)
-            {
-                ACF_PIN_V(f0[g]);
-                ACF_PIN_V(f1[g]);
-                ACF_PIN_V(f2[g]);
-            }
-#pragma unroll
-            for (int g = 0; g < CASC_TG; g++)
-            {
-                const bool lt0 = f0[g] < __uint_as_float(cur.tq[g].x);
-                const float fc = lt0 ? f1[g] : f2[g];
-                const float th1 = __uint_as_float(lt0 ? cur.tq[g].y : cur.tq[g].z);
-                const bool lt1 = fc < th1;
-                const float hv = __uint_as_float(lt0 ? (lt1 ? cur.hq[g].x : cur.hq[g].y) : (lt1 ? cur.hq[g].z : cur.hq[g].w));
-                const float hn = h + hv;
-                h = alive ? hn : h; // a rejected window keeps the score it was rejected with
-                alive = alive && (hn > thrC);
-            }
-        }
-    }
-    for (; t < t1; t++)
-    {
-        if (!__any(alive))
-        {
-            return;
-        }
-        cptr4_t np = (cptr4_t)(uintptr_t)(nodes + t);
-        const u32x4 o = np[0], tq = np[1], hq = np[2];
-        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
-        ACF_PIN_V(f0);
-        ACF_PIN_V(f1);
-        ACF_PIN_V(f2);
-        const bool lt0 = f0 < __uint_as_float(tq.x);
-        const float fc = lt0 ? f1 : f2;
-        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
-        const bool lt1 = fc < th1;
-        const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
-        const float hn = h + hv;
-        h = alive ? hn : h;
-        alive = alive && (hn > thrC);
-    }
-}
-
-// Same, with the node table staged in LDS and W windows per lane.  A node is packed as
-// {off0, off1, off2, thr0} {thr1, thr2, hs0, hs1} {hs2, hs3}: two ds_read_b128 and one
-// ds_read_b64, every lane the same address (served as a broadcast) — 10 LDS cycles per
-// tree instead of the 20 of three 12/16-byte reads of the unpacked layout.  Stage A is
-// LDS-bandwidth bound (every wave of the tile repeats the node reads), so with W > 1 a
-// lane evaluates W windows dW floats apart with ONE set of node reads and ONE set of
-// address computations per tree.
-// trees per batch in the list stages (B, C): few waves are active there and a batch is one chain of two LDS round
-// trips, so larger batches shorten the tile's critical path
-#ifndef CASC_TG_LIST
-#define CASC_TG_LIST 8
-#endif
-template <int W, int TG = 4, bool TIMED = false>
-__device__ __forceinline__ void tile_eval_lds(const float* win, int dW, const uint4* nodesL, int t0, int t1, float thrC, float (&h)[W], bool (&alive)[W],
-    long long* tacc = nullptr)
-{
-    int t = t0;
-    // (requesting the next batch's nodes one iteration early was measured: no gain — the node reads are not on the
-    // critical path of a batch)
-    for (; t + TG <= t1; t += TG)
-    {
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            any = any || alive[u];
-        }
-        if (!__any(any))
-        {
-            return;
-        }
-        long long tA = 0, tB = 0, tC = 0;
-        if (TIMED)
-        {
-            tA = __builtin_amdgcn_s_memtime();
-        }
-        uint4 q0[TG], q1[TG];
-        uint2 q2[TG];
-#pragma unroll
-        for (int g = 0; g < TG; g++)
-        {
-            q0[g] = nodesL[3 * (t + g) + 0];
-            q1[g] = nodesL[3 * (t + g) + 1];
-            q2[g] = *reinterpret_cast<const uint2*>(nodesL + 3 * (t + g) + 2);
-        }
-        if (TIMED)
-        {
-#pragma unroll
-            for (int g = 0; g < TG; g++)
-            {
-                asm volatile("" ::"v"(q0[g].x), "v"(q1[g].x), "v"(q2[g].x));
-            }
-            tB = __builtin_amdgcn_s_memtime();
-        }
-        float f0[W][TG], f1[W][TG], f2[W][TG];
-#pragma unroll
-        for (int g = 0; g < TG; g++)
-        {
-#pragma unroll
-            for (int u = 0; u < W; u++)
-            {
-                f0[u][g] = win[q0[g].x + u * dW];
-                f1[u][g] = win[q0[g].y + u * dW];
-                f2[u][g] = win[q0[g].z + u * dW];
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < TG; g++)
-        {
-#pragma unroll
-            for (int u = 0; u < W; u++)
-            {
-                ACF_PIN_V(f0[u][g]);
-                ACF_PIN_V(f1[u][g]);
-                ACF_PIN_V(f2[u][g]);
-            }
-        }
-        if (TIMED)
-        {
-            tC = __builtin_amdgcn_s_memtime();
-        }
-#pragma unroll
-        for (int g = 0; g < TG; g++)
-        {
-#pragma unroll
-            for (int u = 0; u < W; u++)
-            {
-                const bool lt0 = f0[u][g] < __uint_as_float(q0[g].w);
-                const float fc = lt0 ? f1[u][g] : f2[u][g];
-                const float th1 = __uint_as_float(lt0 ? q1[g].x : q1[g].y);
-                const bool lt1 = fc < th1;
-                const float hv = __uint_as_float(lt0 ? (lt1 ? q1[g].z : q1[g].w) : (lt1 ? q2[g].x : q2[g].y));
-                const float hn = h[u] + hv;
-                h[u] = hn; // a rejected window's score is never read again: no select to freeze it
-                alive[u] = alive[u] && (hn > thrC);
-            }
-        }
-        if (TIMED && tacc)
-        {
-            asm volatile("" ::"v"(h[0]));
-            const long long tD = __builtin_amdgcn_s_memtime();
-            tacc[0] += tB - tA; // node reads
-            tacc[1] += tC - tB; // feature reads
-            tacc[2] += tD - tC; // resolve
-        }
-    }
-    for (; t < t1; t++)
-    {
-        const uint4 q0 = nodesL[3 * t + 0], q1 = nodesL[3 * t + 1];
-        const uint2 q2 = *reinterpret_cast<const uint2*>(nodesL + 3 * t + 2);
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            float f0 = win[q0.x + u * dW], f1 = win[q0.y + u * dW], f2 = win[q0.z + u * dW];
-            ACF_PIN_V(f0);
-            ACF_PIN_V(f1);
-            ACF_PIN_V(f2);
-            const bool lt0 = f0 < __uint_as_float(q0.w);
-            const float fc = lt0 ? f1 : f2;
-            const float th1 = __uint_as_float(lt0 ? q1.x : q1.y);
-            const bool lt1 = fc < th1;
-            const float hv = __uint_as_float(lt0 ? (lt1 ? q1.z : q1.w) : (lt1 ? q2.x : q2.y));
-            const float hn = h[u] + hv;
-            h[u] = hn;
-            alive[u] = alive[u] && (hn > thrC);
-        }
-    }
-}
-
-// Lanes = trees: one wave evaluates trees [t0,t1) of ONE window, 64 at a time.
-// Each lane walks its own tree against the window's features in LDS, then the
-// 64 leaf values are added to the running score strictly in tree order (a
-// wave-uniform chain of v_readlane + add); the window is rejected if any prefix
-// falls to cascThr or below — exactly evaluate()'s early exit.  Returns whether
-// the window is still alive after t1; h is exact for windows that are.
+// a tree's node record as one lane holds it (k_cascade_tail3: lanes = trees)
 struct LaneNode
 {
     uint4 o, tq, hq;
 };
-
-// lane's tree of the 64-tree batch starting at tb (clamped to the last tree: lanes past the end are masked by the caller)
-__device__ __forceinline__ LaneNode lane_node(const TreeNode* __restrict__ nodes, int tb, int t1)
-{
-    const uint4* np = reinterpret_cast<const uint4*>(nodes + min(tb + int(threadIdx.x & 63), t1 - 1));
-    LaneNode n;
-    n.o = np[0];
-    n.tq = np[1];
-    n.hq = np[2];
-    return n;
-}
-
-// `first`: the batch at t0 already in registers (a wave that evaluates the same tree range for many windows loads
-// it once).  The next batch's nodes are requested before the current batch is scanned.
-__device__ __forceinline__ bool wave_eval_trees(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h,
-    const LaneNode& first)
-{
-    const int lane = threadIdx.x & 63;
-    LaneNode cur = first;
-    for (int tb = t0; tb < t1; tb += 64)
-    {
-        const int nt = min(64, t1 - tb);
-        LaneNode nxt = cur;
-        if (tb + 64 < t1)
-        {
-            nxt = lane_node(nodes, tb + 64, t1);
-        }
-        float hv = 0.f;
-        {
-            const float f0 = win[cur.o.x];
-            const bool lt0 = f0 < __uint_as_float(cur.tq.x);
-            const float fc = win[lt0 ? cur.o.y : cur.o.z];
-            const float th1 = __uint_as_float(lt0 ? cur.tq.y : cur.tq.z);
-            const bool lt1 = fc < th1;
-            const float leaf = __uint_as_float(lt0 ? (lt1 ? cur.hq.x : cur.hq.y) : (lt1 ? cur.hq.z : cur.hq.w));
-            hv = (lane < nt) ? leaf : 0.f;
-        }
-        float m = h; // running minimum of the prefix scores
-        if (nt == 64)
-        {
-#pragma unroll
-            for (int q = 0; q < 64; q++)
-            {
-                h = h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), q));
-                asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
-            }
-        }
-        else
-        {
-            for (int q = 0; q < nt; q++)
-            {
-                h = h + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), q));
-                asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));
-            }
-        }
-        if (!(m > thrC) || !(h > thrC))
-        {
-            return false;
-        }
-        cur = nxt;
-    }
-    return true;
-}
-
-
-// Emit one wave's surviving lanes: hits if the model has no more trees, else
-// entries of the frame's tail queue.  One global atomic per wave.
-__device__ __forceinline__ void tile_emit(const TileArgs& a, bool final_, int frame, bool alive, int lvl, int n, int nWinR, float h)
-{
-    const unsigned long long mask = __ballot(alive);
-    if (!mask)
-    {
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0)
-    {
-        base = atomicAdd((final_ ? a.counts : a.qcount) + frame, __popcll(mask));
-    }
-    base = __shfl(base, 0);
-    if (alive)
-    {
-        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (final_)
-        {
-            if (idx < a.maxHits)
-            {
-                acf_hip_hit hit;
-                hit.scale = lvl;
-                hit.c = n / nWinR;
-                hit.r = n - hit.c * nWinR;
-                hit.score = h;
-                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
-            }
-        }
-        else if (idx < a.qcap)
-        {
-            a.q[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
-        }
-    }
-}
 
 // Survivors of a tile stage -> LDS list {thread id in tile, h bits}.
 __device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2* list, int* cnt)
@@ -3729,215 +3386,11 @@ __device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2
         a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     }
 
-// NW waves per tile, W windows per lane in stage A: the tile holds TR x TC = 64 * NW * W windows
-template <int NW, int W>
-__global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
-{
-    extern __shared__ float lds[];
-    __shared__ int s_cnt[4];
-    float* tileF = lds;
-    uint2* list = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
-    uint4* nodesL = reinterpret_cast<uint4*>(list + NW * 64 * W); // trees [0, b3): 3 x uint4 each (tileFloats % 4 == 0: 16-byte aligned)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    // Block -> (frame, tile).  Hardware block b runs on XCD b % 8: give every XCD
-    // one contiguous range of (frame-major) tiles, so tiles that share halo rows
-    // and columns — neighbours in this order — hit the same XCD's L2.
-    const int64_t total = int64_t(a.nTiles) * a.nFrames;
-    const int64_t perX = (total + 7) >> 3;
-    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
-    if (id >= total || (blockIdx.x >> 3) >= perX)
-    {
-        return;
-    }
-    const int frame = int(id / a.nTiles);
-    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
-    const int lvl = T.level;
-    const CascLevel L = a.levels[lvl];
-    const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
-    const int gr0 = T.r0 * step, gc0 = T.c0 * step;
-    const int area = L.hP * L.wP;
-    const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
-    const int colsValid = min(colsT, L.wP - gc0);
-
-    if (tid < 4)
-    {
-        s_cnt[tid] = 0;
-    }
-    for (int t = tid; t < a.g.b[3]; t += NW * 64)
-    {
-        // repack {off[4]} {thr[4]} {hs[4]} -> {off0, off1, off2, thr0} {thr1, thr2, hs0, hs1} {hs2, hs3, -, -}
-        const uint4* gp = reinterpret_cast<const uint4*>(a.tileNodes + t);
-        const uint4 o = gp[0], tq = gp[1], hq = gp[2];
-        nodesL[3 * t + 0] = make_uint4(o.x, o.y, o.z, tq.x);
-        nodesL[3 * t + 1] = make_uint4(tq.y, tq.z, hq.x, hq.y);
-        nodesL[3 * t + 2] = make_uint4(hq.z, hq.w, 0u, 0u);
-    }
-    TILE_STAMP(0);
-    // ---- fill.  The tile is nChns*colsT column segments of rowsP floats = rowsP/4
-    // 16-byte chunks each; chunk q lives at LDS float 4q.  One global_load_lds_dwordx4
-    // moves 64 chunks (1 KB) from 64 per-lane global addresses straight into LDS
-    // (LDS address = M0 + 16*lane: no VGPR round trip, no ds_write) — measured 4-byte
-    // LDS-DMA kept the LDS busy ~12k cycles per tile and starved the co-resident
-    // workgroup's feature reads; 16-byte chunks cut that four-fold.  Nothing waits
-    // between instructions, so a wave's ~9 requests are all in flight.  A segment's
-    // last chunk may run up to 3 floats past the rows the tile needs (into the next
-    // column / plane; the pyramid allocation is padded): those cells, like cells of
-    // columns beyond the plane (address clamped), are only reachable from windows
-    // outside the grid, whose lanes never contribute.
-    if (!(a.debug & 1))
-    {
-        const uint32_t cps = uint32_t(rowsP) >> 2;
-        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
-        const int ccMax = colsValid - 1;
-        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
-        {
-            const uint32_t q = q0 + lane;
-            if (q < nChunks)
-            {
-                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
-                const uint32_t j = q - seg * cps;
-                const uint32_t z = __umulhi(seg, a.g.colsMagic);
-                const int cc = int(seg - z * uint32_t(colsT));
-                // level planes are < 2^31 floats (checked at plan time): 32-bit offsets
-                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(L.hP) + 4u * j;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    TILE_STAMP(1);
-    if (a.debug & 2)
-    {
-        return;
-    }
-
-    const float thrC = a.cascThr;
-    const int tEnd = a.g.b[4];
-    const bool lastAll = tEnd == a.nTrees;
-    // ---- stage A: lanes = windows, W per lane (tile columns c_l + u * TC/W)
-    const int r_l = tid % a.g.TR, c_l = tid / a.g.TR;
-    const int cStep = a.g.TC / W;
-    const int wr = T.r0 + r_l;
-    bool alive[W];
-    float h[W];
-#pragma unroll
-    for (int u = 0; u < W; u++)
-    {
-        alive[u] = wr < L.nWinR && (T.c0 + c_l + u * cStep) < L.nWinC;
-        h[u] = 0.f;
-    }
-    if (a.debug & 8)
-    {
-        long long tacc[3] = { 0, 0, 0 };
-        tile_eval_lds<W, 4, true>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive, tacc);
-        if (threadIdx.x == 0)
-        {
-            a.stamps[int64_t(blockIdx.x) * 8 + 5] = tacc[0];
-            a.stamps[int64_t(blockIdx.x) * 8 + 6] = tacc[1];
-            a.stamps[int64_t(blockIdx.x) * 8 + 7] = tacc[2];
-        }
-    }
-    else
-    {
-        tile_eval_lds<W>(tileF + (c_l * step) * rowsP + r_l * step, cStep * step * rowsP, nodesL, a.g.b[0], a.g.b[1], thrC, h, alive);
-    }
-    if (a.g.b[1] == tEnd)
-    {
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            tile_emit(a, lastAll, frame, alive[u], lvl, (T.c0 + c_l + u * cStep) * L.nWinR + wr, L.nWinR, h[u]);
-        }
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < W; u++)
-    {
-        tile_compact(alive[u], (c_l + u * cStep) * a.g.TR + r_l, h[u], list, &s_cnt[0]);
-    }
-    __syncthreads();
-    TILE_STAMP(2);
-    // ---- stages B, C: dense lanes over the survivor list (tag = c * TR + r).  The list is compacted in
-    // place: every thread reads its entries, a barrier, then the survivors are rewritten.
-    int nIn = s_cnt[0];
-    for (int stage = 1; stage <= 2; stage++)
-    {
-        const int t0 = a.g.b[stage], t1 = a.g.b[stage + 1];
-        if (t0 == t1)
-        {
-            continue;
-        }
-        bool al[W];
-        uint2 e[W];
-        float hh[W];
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            const int idx = tid + u * NW * 64;
-            al[u] = idx < nIn;
-            e[u] = al[u] ? list[idx] : make_uint2(0u, 0u);
-            hh[u] = __uint_as_float(e[u].y);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            const int rl = int(e[u].x) % a.g.TR, cl = int(e[u].x) / a.g.TR;
-            float h1[1] = { hh[u] };
-            bool a1[1] = { al[u] };
-            if (t1 <= a.g.b[3])
-            {
-                tile_eval_lds<1, CASC_TG_LIST>(tileF + (cl * step) * rowsP + rl * step, 0, nodesL, t0, t1, thrC, h1, a1);
-            }
-            else
-            {
-                tile_eval(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, h1[0], a1[0]);
-            }
-            hh[u] = h1[0];
-            al[u] = a1[0];
-        }
-        if (t1 == tEnd)
-        {
-#pragma unroll
-            for (int u = 0; u < W; u++)
-            {
-                const int rl = int(e[u].x) % a.g.TR, cl = int(e[u].x) / a.g.TR;
-                tile_emit(a, lastAll, frame, al[u], lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh[u]);
-            }
-            return;
-        }
-#pragma unroll
-        for (int u = 0; u < W; u++)
-        {
-            tile_compact(al[u], int(e[u].x), hh[u], list, &s_cnt[stage]);
-        }
-        __syncthreads();
-        nIn = s_cnt[stage];
-    }
-    TILE_STAMP(3);
-    // ---- stage D: one wave per surviving window, lanes = trees
-    {
-        const int t0 = a.g.b[3], t1 = a.g.b[4];
-        const LaneNode first = lane_node(a.tileNodes, t0, t1); // same trees for every survivor this wave takes
-        for (int i = wv; i < nIn; i += NW)
-        {
-            const uint2 e = list[i];
-            const int rl = int(e.x) % a.g.TR, cl = int(e.x) / a.g.TR;
-            float hh = __uint_as_float(e.y);
-            const bool ok = wave_eval_trees(tileF + (cl * step) * rowsP + rl * step, a.tileNodes, t0, t1, thrC, hh, first);
-            tile_emit(a, lastAll, frame, ok && lane == 0, lvl, (T.c0 + cl) * L.nWinR + (T.r0 + rl), L.nWinR, hh);
-        }
-    }
-    TILE_STAMP(4);
-}
-
 // ------------------------------------------------------------------------
 // k_cascade_tile2: the tile kernel with (i) stage A's node records on the scalar unit, (ii) item-parallel sparse
 // stages and (iii) the tail's leaf codes computed while the tile is still in LDS.
 //
-// What the round-1 kernel (k_cascade_tile above) spent per 512-window tile, from its own phase stamps: fill 4.5k
+// What the round-1 kernel (one lane per window in every stage, node table in LDS) spent per 512-window tile, from its own phase stamps: fill 4.5k
 // cycles, stage A (16 trees, every lane) 5.9k, the list stages B+C 9.0k, stage D 2.4k.
 //  * Stage A was bound by LDS bandwidth, and 10 of its 16 LDS cycles per tree and wave were the NODE reads (every
 //    wave re-reads the same 40 bytes per tree as 64-lane broadcasts).  Here a batch of four trees is 160 contiguous
@@ -3951,7 +3404,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile(TileArgs a)
 //    and their order are evaluate()'s, acfDetect1.cpp:123-138), and a window survives when every prefix stays above
 //    cascThr.
 //  * The ~930 windows per 1080p frame that outlive tree 128 used to be re-fetched from HBM as 16 KB footprints by the
-//    tail kernel (k_cascade_tail3: 11.5 us per frame; k_tail_codes: 5.5 us, bound by those 80-byte column runs).  Their
+//    tail kernel (k_cascade_tail3: 11.5 us per frame; a stand-alone code kernel: 5.5 us, bound by those 80-byte column runs).  Their
 //    features are in this tile already: stage E evaluates every remaining tree for them (lanes = trees, nodes streamed
 //    from L2 once per tile, not per window) and writes one code byte per tree; k_tail_scan finishes them.
 // ------------------------------------------------------------------------
@@ -4540,69 +3993,8 @@ __device__ __forceinline__ void tail_fill(const TileArgs& a, float* win, const f
         }
 }
 
-// Tail stage [tEnd, nTrees) of the tiled path: the few windows still alive each
-// need thousands of feature reads scattered over their own modelDsPad footprint.
-// One WAVE owns one window: the footprint (nChns*mW*mH floats — exactly the
-// cids[] index space, acfDetect1.cpp:390-406, so a feature id addresses it
-// directly) is copied to the wave's LDS slab, then wave_eval_trees runs the
-// remaining trees 64 at a time.  Waves pull windows from the frame's queue with
-// an atomic head counter, so long-lived windows do not stall a fixed partition.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64) k_cascade_tail2(TileArgs a)
-{
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* win = lds + wv * a.g.winFloats;
-    const int frame = blockIdx.x % a.nFrames;
-    const int cnt = min(a.qcount[frame], a.qcap);
-    const int mH = a.mH, mW = a.mW;
-    const int tEnd = a.g.b[4];
-    const TailFill tf = tail_fill_setup(a, lane);
-    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees); // first tail batch: same trees for every window
-    for (;;)
-    {
-        int i = 0;
-        if (lane == 0)
-        {
-            i = atomicAdd(a.qhead + frame, 1);
-        }
-        i = __shfl(i, 0);
-        if (i >= cnt)
-        {
-            break;
-        }
-        const uint2 e = a.q[int64_t(frame) * a.qcap + i];
-        const int lvl = int(e.x >> 24);
-        const int n = int(e.x & 0xffffffu);
-        const CascLevel L = a.levels[lvl];
-        const int c = n / L.nWinR;
-        const int r = n - c * L.nWinR;
-        const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
-        const int area = L.hP * L.wP;
-        tail_fill(a, win, chn, L.hP, area, lane, tf);
-        // the wave's own writes, read back by its own lanes: LDS ops of one wave complete in order
-        __builtin_amdgcn_wave_barrier();
-        float h = __uint_as_float(e.y);
-        const bool ok = wave_eval_trees(win, a.tailNodes, tEnd, a.nTrees, a.cascThr, h, firstTail);
-        if (ok && lane == 0)
-        {
-            const int idx = atomicAdd(a.counts + frame, 1);
-            if (idx < a.maxHits)
-            {
-                acf_hip_hit hit;
-                hit.scale = lvl;
-                hit.c = c;
-                hit.r = r;
-                hit.score = h;
-                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Tail stage, two phases per wave (replaces the per-window ordered scan of k_cascade_tail2, whose 64-step
-// wave-uniform add chain was ~90 % of that kernel's instructions):
+// Tail stage for queue entries WITHOUT leaf codes (beyond codeCap per frame, or tiles whose geometry keeps stage E off):
+// two phases per wave.
 //
 //   phase 1  lanes = trees.  The wave takes TAIL_G windows from the frame's queue; for each one it copies the
 //            footprint to its LDS slab and walks ALL remaining trees 64 at a time, writing the leaf values
@@ -4650,7 +4042,6 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
         }
         __syncthreads();
     }
-    const LaneNode firstTail = lane_node(a.tailNodes, tEnd, a.nTrees);
     const float thrC = a.cascThr;
     for (;;)
     {
@@ -4823,163 +4214,15 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
 }
 
 // ------------------------------------------------------------------------
-// Tail stage [tEnd, nTrees), trees stationary / windows streaming (replaces k_cascade_tail3 for the first codeCap
-// queue entries of a frame; k_cascade_tail3 takes whatever is beyond).
-//
-// The few windows that reach the tail (~930 of 662,799 per 1080p frame) each walk up to ~1900 more trees.  Which LEAF
-// a tree selects does not depend on the running score — only the early exit does (acfDetect1.cpp:123-138) — so the
-// tail is split into
-//   k_tail_codes   every tail tree of every queued window -> one byte, 4 * (leaf index - 3).  A workgroup of 16 waves
-//                  keeps 64 * BPW trees per wave in REGISTERS (feature offsets and thresholds of its trees, loaded
-//                  once) and streams the windows of one frame's queue through a ring of TC_NBUF footprint slabs in LDS
-//                  (LDS-DMA, 16-byte chunks, three fills in flight behind the window being evaluated: counted vmcnt,
-//                  raw s_barrier).  Per window a wave does BPW x {root read, child read, two compares, one byte store}:
-//                  no node traffic at all, every window costs the same, so the queue is dealt statically.
-//   k_tail_scan    lanes = windows: h = h + hs[leaf] strictly in tree order, 16 code bytes per 16-byte load, the leaf
-//                  values of tree t read from an LDS table at [t][code] (all lanes of a wave hit the same 16 bytes);
-//                  a lane dies at the first prefix <= cascThr.  Scores are bit-identical to evaluate()'s.
+// k_tail_scan: the ordered part of the tail [tEnd, nTrees).  Which LEAF a tree selects does not depend on the running
+// score — only the early exit does (acfDetect1.cpp:123-138) — so k_cascade_tile2's stage E writes one byte per tail tree
+// of every window that reaches the tail (4 * (leaf index - 3)), and this kernel does what is sequential: lanes = windows,
+// h = h + hs[leaf] strictly in tree order, 16 code bytes per 16-byte load, the leaf values of tree t read from an LDS
+// table at [t][code] (all lanes of a wave hit the same 16 bytes); a lane dies at the first prefix <= cascThr.  Scores are
+// bit-identical to evaluate()'s.  (A stand-alone code kernel that re-fetched each window's 16 KB footprint from HBM —
+// trees in registers, windows streamed through LDS — measured 5.5 us per 1080p frame, bound by the 80-byte column runs of a
+// footprint; inside the tile the features are already in LDS.)
 // ------------------------------------------------------------------------
-constexpr int TC_NW = 16;
-constexpr int TC_NBUF = 4;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int BPW, int DPW> // BPW: 64-tree batches per wave; DPW: LDS-DMA instructions per wave per footprint
-__global__ void __launch_bounds__(TC_NW * 64) k_tail_codes(TileArgs a)
-{
-    extern __shared__ float lds[]; // TC_NBUF slabs of DPW * TC_NW * 64 * 4 floats
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    const int frame = blockIdx.x % a.nFrames, j0 = blockIdx.x / a.nFrames, K = gridDim.x / a.nFrames;
-    const int cnt = min(min(a.qcount[frame], a.qcap), a.codeCap);
-    const int nMine = j0 < cnt ? (cnt - j0 + K - 1) / K : 0; // windows j0, j0 + K, ...
-    if (nMine == 0)
-    {
-        return;
-    }
-    const int tEnd = a.g.b[4], nT = a.nTrees - tEnd;
-    constexpr int slabFloats = DPW * TC_NW * 64 * 4;
-    const int mH = a.mH, mW = a.mW;
-    const uint32_t cps = uint32_t(mH) >> 2, nChunks = uint32_t(a.nChns * mW) * cps;
-    const uint32_t cpsMagic = uint32_t(((uint64_t(1) << 32) + cps - 1) / cps);
-    const uint32_t mwMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(mW) - 1) / uint32_t(mW));
-    // this lane's chunks of a footprint (the same for every window): chunk q = floats [4q, 4q+4) of the window's cids[] index
-    // space, run = q / cps = z * mW + cc.  Lanes past the last chunk re-copy the last chunk into the slab's padding.
-    uint32_t zq[DPW], ccq[DPW], jq[DPW];
-#pragma unroll
-    for (int d = 0; d < DPW; d++)
-    {
-        const uint32_t q = min(uint32_t((d * TC_NW + wv) * 64 + lane), nChunks - 1u);
-        const uint32_t run = cps == 1 ? q : __umulhi(q, cpsMagic);
-        jq[d] = q - run * cps;
-        zq[d] = mW == 1 ? run : __umulhi(run, mwMagic);
-        ccq[d] = run - zq[d] * uint32_t(mW);
-    }
-    // Per-window source descriptors {float offset of the window's first cell (64 bit), hP, area}, built once by the whole
-    // workgroup into LDS: inside the streaming loop a fill then costs one broadcast ds_read instead of a chain of two
-    // dependent memory round trips (queue entry -> level record) on every wave's critical path.
-    uint4* desc = reinterpret_cast<uint4*>(lds + TC_NBUF * slabFloats);
-    for (int m = threadIdx.x; m < nMine; m += TC_NW * 64)
-    {
-        const uint32_t ex = a.q[int64_t(frame) * a.qcap + j0 + m * K].x;
-        const CascLevel L = a.levels[ex >> 24];
-        const int n = int(ex & 0xffffffu);
-        const int c = n / L.nWinR, r = n - c * L.nWinR;
-        const int64_t off = int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
-        desc[m] = make_uint4(uint32_t(uint64_t(off)), uint32_t(uint64_t(off) >> 32), uint32_t(L.hP), uint32_t(L.hP) * uint32_t(L.wP));
-    }
-    __syncthreads();
-    auto fill = [&](int m) {
-        const uint4 d4 = desc[m];
-        const float* __restrict__ chn = a.pyr + int64_t(uint64_t(d4.x) | (uint64_t(d4.y) << 32));
-        const uint32_t hP = d4.z, area = d4.w;
-        float* slab = lds + (m % TC_NBUF) * slabFloats;
-#pragma unroll
-        for (int d = 0; d < DPW; d++)
-        {
-            __builtin_amdgcn_global_load_lds((gptr_t)(chn + (zq[d] * area + ccq[d] * hP + 4u * jq[d])),
-                (lptr_t)(slab + 4 * ((d * TC_NW + wv) * 64)), 16, 0, 0);
-        }
-    };
-    for (int tc = 0; tc < nT; tc += TC_NW * BPW * 64) // one pass unless the model has more than 1024 * BPW tail trees
-    {
-        uint32_t o0[BPW], o1[BPW], o2[BPW];
-        float t0[BPW], t1[BPW], t2[BPW];
-#pragma unroll
-        for (int b = 0; b < BPW; b++)
-        {
-            const int tb = tc + (b * TC_NW + wv) * 64;
-            const TreeNode nd = a.tailNodes[tEnd + min(tb + lane, nT - 1)];
-            o0[b] = nd.off[0];
-            o1[b] = nd.off[1];
-            o2[b] = nd.off[2];
-            t0[b] = nd.thr[0];
-            t1[b] = nd.thr[1];
-            t2[b] = nd.thr[2];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the node loads: the counted waits below see only fills and code stores
-        __builtin_amdgcn_s_barrier();                    // every wave is done with the slabs of the previous pass
-#pragma unroll
-        for (int m = 0; m < TC_NBUF - 1; m++)
-        {
-            fill(min(m, nMine - 1)); // a short queue re-copies its last window: the instruction count stays fixed
-        }
-        for (int m = 0; m < nMine; m++)
-        {
-            // fill m is done when at most the fills m+1, m+2 and the code stores of windows m-3 .. m-1 are outstanding
-            const int s = min(m, 3);
-            if (s == 0)
-            {
-                wait_vmcnt<2 * DPW>();
-            }
-            else if (s == 1)
-            {
-                wait_vmcnt<2 * DPW + BPW>();
-            }
-            else if (s == 2)
-            {
-                wait_vmcnt<2 * DPW + 2 * BPW>();
-            }
-            else
-            {
-                wait_vmcnt<2 * DPW + 3 * BPW>();
-            }
-            __builtin_amdgcn_s_barrier(); // all waves' parts of fill m have landed; everyone is done with window m-1
-            fill(min(m + TC_NBUF - 1, nMine - 1));
-            const float* win = lds + (m % TC_NBUF) * slabFloats;
-            uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + (j0 + m * K)) * a.codePitch + tc + wv * 64 + lane;
-            float f0[BPW], fc[BPW];
-            bool lt0[BPW];
-#pragma unroll
-            for (int b = 0; b < BPW; b++)
-            {
-                f0[b] = win[o0[b]];
-            }
-#pragma unroll
-            for (int b = 0; b < BPW; b++)
-            {
-                lt0[b] = f0[b] < t0[b];
-                fc[b] = win[lt0[b] ? o1[b] : o2[b]];
-            }
-#pragma unroll
-            for (int b = 0; b < BPW; b++)
-            {
-                const bool lt1 = fc[b] < (lt0[b] ? t1[b] : t2[b]);
-                // leaf k = 3 + code / 4: lt0 ? (lt1 ? 3 : 4) : (lt1 ? 5 : 6) (getChild, acfDetect1.cpp:100-107)
-                const uint8_t code = uint8_t((lt0[b] ? 0 : 8) + (lt1 ? 0 : 4));
-                // stored unconditionally (a fixed number of stores per window keeps the vmcnt arithmetic exact): batches past the
-                // last tree land in the row's padding
-                row[b * TC_NW * 64] = code;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-}
-
 __global__ void __launch_bounds__(256) k_tail_scan(TileArgs a)
 {
     extern __shared__ float lds[]; // [nT][4] leaf values of the tail trees
@@ -5181,35 +4424,80 @@ struct BoxLevel
     int32_t bw, bh; // cvRound(modelDs / scale), precomputed on the host (ACF.cpp:304)
 };
 
+constexpr int SM_BLOCKS = 32; // workgroups per frame (256 threads each); blocks without items leave at once
+constexpr int SM_ITEMS = 8;   // hits per thread and pass
+constexpr int SM_CHUNK = 2048;
+
 __global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict__ hits, const int32_t* __restrict__ counts,
     int maxHits, const BoxLevel* __restrict__ bl, int stride, int shift_h, int shift_w,
     acf_hip_hit* __restrict__ sortedHits, acf_hip_detection* __restrict__ dets)
 {
+    // Rank sort on the 64-bit key (scale, c, r) — the order acfDetect1's loops emit (ACF.cpp:283-300).  The keys are
+    // staged through LDS SM_CHUNK at a time and every thread ranks SM_ITEMS hits against a chunk per pass, so a frame
+    // near capacity (65,536 hits: a low cascThr) costs 4e9 LDS compares spread over 8192 threads instead of 4e9 global
+    // reads on 1024 (round 1).  Typical frames (a few hundred hits) use one block and one chunk.
+    __shared__ long long keys[SM_CHUNK];
     const int frame = blockIdx.y;
     const int n = min(counts[frame], maxHits);
     const acf_hip_hit* H = hits + int64_t(frame) * maxHits;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    const int nThreads = SM_BLOCKS * 256;
+    // hits per thread: one while the frame's hits fit the grid (a few hundred hits: every hit its own thread), up to SM_ITEMS
+    const int items = min(SM_ITEMS, (n + nThreads - 1) / nThreads);
+    for (int i0 = 0; i0 < n; i0 += nThreads * items)
     {
-        const acf_hip_hit me = H[i];
-        const long long key = (((long long)me.scale) << 40) | (((long long)me.c) << 20) | (long long)me.r;
-        int rank = 0;
-        for (int j = 0; j < n; j++)
+        const int first = i0 + (blockIdx.x * 256 + threadIdx.x) * items;
+        if (i0 + blockIdx.x * 256 * items >= n) // block-uniform: nothing for this block in this pass (nor in later ones)
         {
-            const acf_hip_hit o = H[j];
-            const long long ko = (((long long)o.scale) << 40) | (((long long)o.c) << 20) | (long long)o.r;
-            rank += ko < key;
+            return;
         }
-        sortedHits[int64_t(frame) * maxHits + rank] = me;
-        const BoxLevel b = bl[me.scale];
-        acf_hip_detection d;
-        // roi = ({c*stride, r*stride}); x = int(double(x + shift)/scaleshw) (truncation)
-        d.x = (int)((double)(me.c * stride + shift_w) / b.shw_w);
-        d.y = (int)((double)(me.r * stride + shift_h) / b.shw_h);
-        d.w = b.bw;
-        d.h = b.bh;
-        d.score = me.score;
-        d.scale = me.scale;
-        dets[int64_t(frame) * maxHits + rank] = d;
+        acf_hip_hit me[SM_ITEMS];
+        long long key[SM_ITEMS];
+        int rank[SM_ITEMS];
+#pragma unroll
+        for (int q = 0; q < SM_ITEMS; q++)
+        {
+            me[q] = H[min(first + q, n - 1)];
+            key[q] = (((long long)me[q].scale) << 40) | (((long long)me[q].c) << 20) | (long long)me[q].r;
+            rank[q] = 0;
+        }
+        for (int c0 = 0; c0 < n; c0 += SM_CHUNK)
+        {
+            const int m = min(SM_CHUNK, n - c0);
+            __syncthreads();
+            for (int j = threadIdx.x; j < m; j += 256)
+            {
+                const acf_hip_hit o = H[c0 + j];
+                keys[j] = (((long long)o.scale) << 40) | (((long long)o.c) << 20) | (long long)o.r;
+            }
+            __syncthreads();
+            for (int j = 0; j < m; j++)
+            {
+                const long long ko = keys[j];
+#pragma unroll
+                for (int q = 0; q < SM_ITEMS; q++)
+                {
+                    rank[q] += ko < key[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SM_ITEMS; q++)
+        {
+            if (q < items && first + q < n)
+            {
+                sortedHits[int64_t(frame) * maxHits + rank[q]] = me[q];
+                const BoxLevel b = bl[me[q].scale];
+                acf_hip_detection d;
+                // roi = ({c*stride, r*stride}); x = int(double(x + shift)/scaleshw) (truncation)
+                d.x = (int)((double)(me[q].c * stride + shift_w) / b.shw_w);
+                d.y = (int)((double)(me[q].r * stride + shift_h) / b.shw_h);
+                d.w = b.bw;
+                d.h = b.bh;
+                d.score = me[q].score;
+                d.scale = me[q].scale;
+                dets[int64_t(frame) * maxHits + rank[q]] = d;
+            }
+        }
     }
 }
 
@@ -5473,7 +4761,9 @@ __global__ void __launch_bounds__(256) k_export(const acf_hip_detection* __restr
     int maxHits, int cap, int32_t* __restrict__ dst)
 {
     const int frame = blockIdx.y;
-    const int n = min(min(counts[frame], maxHits), cap);
+    // more hits than max_hits: which ones were kept depends on the order of atomics, so no record is exported — the count
+    // (> max_hits) tells the consumer; a frame over the device NMS capacity carries count -1
+    const int n = counts[frame] > maxHits ? 0 : min(min(counts[frame], maxHits), cap);
     int32_t* D = dst + int64_t(frame) * (1 + 6 * int64_t(cap));
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {

@@ -129,9 +129,25 @@ void field(Archive& ar, const char* type, const char* name, T& value, bool isLea
     ar.str(nm);
     ar.flag(has);
     ar.flag(leaf);
+    if (ar.loading() && nm != name)
+    {
+        // the layout is restated from the reference's serialisers, not checked against a cereal-written file: a drift in
+        // field order or count must fail here, not misparse a model silently
+        Archive::bad((std::string("field name mismatch: expected '") + name + "', found '" + nm + "'").c_str());
+    }
     if (!ar.loading() || has)
     {
         value = tmp;
+    }
+}
+// name / has / isLeaf trailer of a Field<struct>; on load the stored name must be the expected one
+void checkedName(Archive& ar, std::string& nm, bool& has, bool& leaf)
+{
+    const std::string want = nm;
+    ar.str(nm), ar.flag(has), ar.flag(leaf);
+    if (ar.loading() && nm != want)
+    {
+        Archive::bad(("field name mismatch: expected '" + want + "', found '" + nm + "'").c_str());
     }
 }
 void fInt(Archive& ar, const char* name, int& v)
@@ -287,7 +303,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
             }
             std::string nm = "pColor";
             bool has = true, leaf = false;
-            ar.str(nm), ar.flag(has), ar.flag(leaf);
+            checkedName(ar, nm, has, leaf);
             ar.version("Field<GradMag>");
             {
                 ar.version("GradMag"); // :194-202
@@ -298,7 +314,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
                 fInt(ar, "full", ch.pGradMag.full);
             }
             nm = "pGradMag", has = true, leaf = false;
-            ar.str(nm), ar.flag(has), ar.flag(leaf);
+            checkedName(ar, nm, has, leaf);
             ar.version("Field<GradHist>");
             {
                 ar.version("GradHist"); // :204-214
@@ -312,11 +328,11 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
                 fDouble(ar, "clipHog", clipHog);
             }
             nm = "pGradHist", has = true, leaf = false;
-            ar.str(nm), ar.flag(has), ar.flag(leaf);
+            checkedName(ar, nm, has, leaf);
         }
         std::string nm = "pChns";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
         fInt(ar, "nPerOct", p.nPerOct);
         fInt(ar, "nOctUp", p.nOctUp);
         fInt(ar, "nApprox", p.nApprox);
@@ -331,7 +347,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
     {
         std::string nm = "pPyramid";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
     }
     fSize(ar, "modelDs", o.modelDs);
     fSize(ar, "modelDsPad", o.modelDsPad);
@@ -346,7 +362,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
     {
         std::string nm = "pNms";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
     }
     fInt(ar, "stride", o.stride);
     fDouble(ar, "cascThr", o.cascThr);
@@ -370,7 +386,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
         }
         std::string nm = "pTree";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
         int nW = 128, discrete = 1, verbose = 16;
         fInt(ar, "nWeak", nW);
         fInt(ar, "discrete", discrete);
@@ -379,7 +395,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
     {
         std::string nm = "pBoost";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
     }
     // ---- training bookkeeping (:115-128)
     for (const char* k : { "posGtDir", "posImgDir", "negImgDir", "posWinDir", "negWinDir" })
@@ -401,7 +417,7 @@ void serializeOptions(Archive& ar, HipDetector::Options& o)
     {
         std::string nm = "pJitter";
         bool has = true, leaf = false;
-        ar.str(nm), ar.flag(has), ar.flag(leaf);
+        checkedName(ar, nm, has, leaf);
     }
     int winsSave = zero;
     fInt(ar, "winsSave", winsSave);
@@ -422,6 +438,15 @@ void loadCpb(std::istream& is, HipDetector::Options& opts, HipDetector::Classifi
 {
     Archive ar(is);
     serializeDetector(ar, opts, clf);
+    // the archive holds exactly one Detector: trailing bytes mean the layout above is not the file's
+    if (is.peek() != std::istream::traits_type::eof())
+    {
+        Archive::bad("trailing bytes after the detector");
+    }
+    if (clf.nTrees < 0 || clf.nTreeNodes < 0 || clf.nTrees > (1 << 20) || clf.nTreeNodes > (1 << 12))
+    {
+        Archive::bad("implausible classifier size");
+    }
 }
 
 void saveCpb(std::ostream& os, const HipDetector::Options& opts, const HipDetector::Classifier& clf)
@@ -487,6 +512,10 @@ bool loadAcfm(std::istream& is, HipDetector::Options& o, HipDetector::Classifier
     p.pChns.pGradHist.binSize = I("binSize");
     p.pChns.pGradHist.nOrients = I("nOrients");
     p.pChns.pGradHist.softBin = I("softBin");
+    if (c.nTrees < 0 || c.nTreeNodes < 0 || c.nTrees > (1 << 20) || c.nTreeNodes > (1 << 12))
+    {
+        return false; // header values are untrusted: bound them before sizing the arrays
+    }
     const size_t n = size_t(c.nTrees) * c.nTreeNodes;
     c.fids.resize(n);
     c.thrs.resize(n);
@@ -501,7 +530,12 @@ bool loadAcfm(std::istream& is, HipDetector::Options& o, HipDetector::Classifier
     if (kv.count("ldcfK") && kv.count("ldcfCount"))
     {
         o.ldcfK = I("ldcfK");
-        o.ldcfFilters.resize(size_t(std::stoul(kv.at("ldcfCount"))));
+        const unsigned long cnt = std::stoul(kv.at("ldcfCount"));
+        if (o.ldcfK < 0 || o.ldcfK > 16 || cnt > (1ul << 24))
+        {
+            return false;
+        }
+        o.ldcfFilters.resize(size_t(cnt));
         is.read(reinterpret_cast<char*>(o.ldcfFilters.data()), std::streamsize(o.ldcfFilters.size() * 4));
     }
     return bool(is);

@@ -75,8 +75,9 @@ def kernel_bytes_per_frame(det, model):
     b["k_cascade_tile"] = casc                    # every cell of the cascade's pyramid read once (halo re-reads are L2 hits)
     b["k_cascade"] = casc
     b["k_tail_scan"] = 0                          # data dependent: (windows alive after tree 128) x (tail trees) code bytes
-    b["k_cascade_tail2"] = 0
+    b["k_cascade_tail3"] = 0
     b["k_sort_map"] = 0
+    b["k_nms"] = 0
     return b
 
 
@@ -158,7 +159,9 @@ def main():
                     "(the cascade of one batch overlaps the pyramid of another)")
     ap.add_argument("--frames-total", type=int, default=0, help="cfg 3 as worded: this many frames per step shared by all GPUs (strong scaling); "
                     "overrides --batch (frames per GPU = total / gpus, split over the contexts)")
-    ap.add_argument("--cap", type=int, default=1024, help="detections exported per frame (gather record capacity)")
+    ap.add_argument("--cap", type=int, default=0, help="detections exported per frame (gather record capacity; default 32 with the device NMS, 1024 without)")
+    ap.add_argument("--no-nms", action="store_true", help="export the raw detections (scale, column, row order) instead of the survivors of the "
+                    "device bbNms + prune (Detector::operator()'s default: maxg, overlap .65 / min, at most 10 per frame)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
@@ -210,9 +213,15 @@ def main():
     # asynchronously on the context's stream over two record buffers); everything in flight is waited for inside the timed region.
     pool = DetectorPool(C, model, H, W, 3, max_batch=B, max_hits=8192, device=local, streams=args.streams)
     streams, dets = pool.streams, pool.dets
+    from acf_amd import capi
+    args.cap = args.cap or (1024 if args.no_nms else 32)
     for det in dets:
         if not args.no_profile:
             det.set_option("profile", 1)
+        if not args.no_nms:
+            # ACF.cpp:332-353 + ObjectDetector.cpp:28-44 with acf::Detector's defaults, on the device: the gather record shrinks
+            # from 24 KB to < 1 KB per frame
+            det.set_nms(capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10, pruneRatio=0.0))
     pipes = [RecordGather(B, 1 + 6 * args.cap, world, rank, dev) for _ in range(C)]
 
     def step():
@@ -305,7 +314,8 @@ def main():
                        "baseline_config": args.config,
                        "frames_per_gpu_per_step": C * B, "contexts": C, "frames_per_launch": B, "levels": len(det.levels),
                        "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in (det.ldcf_levels or det.levels))),
-                       "mean_detections_per_frame": float(counts.mean()), "parallelism": "frames sharded, %d rank(s)" % world,
+                       "mean_detections_per_frame": float(counts.mean()), "nms": "none (raw detections)" if args.no_nms else "device bbNms maxg .65/min + prune(10)",
+                       "gather_record_bytes_per_frame": 4 * (1 + 6 * args.cap), "parallelism": "frames sharded, %d rank(s)" % world,
                        "rccl_ranks": world, "per_rank_fps": [float(x) for x in rank_fps.cpu().numpy()]},
         }
         if args.frames_total:
