@@ -437,7 +437,9 @@ int launchSmooth(acf_hip_ctx* c, const float* in, float* out, const SmoothJob* d
     return ACF_HIP_OK;
 }
 
-int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames)
+// fuse: the ChnsArgs of the level when convTriY may be followed at once by the channel cells (k_triy_chns); *fused reports it
+int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames, const ChnsArgs* fuse = nullptr,
+    bool* fused = nullptr)
 {
     if (rad > 15)
     {
@@ -453,6 +455,28 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
         hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
     }
     LAUNCHCHK(c, "k_tri_x");
+    if (fused)
+    {
+        *fused = false;
+    }
+    static const bool noFuse = getenv("ACF_HIP_TRIY_UNFUSED") != nullptr; // A/B
+    if (fuse && !noFuse && rad == 5 && h % 4 == 0 && h >= 48 && w % 4 == 0 && fs % 4 == 0 && (uintptr_t(U) & 15) == 0 && fuse->doNorm && !fuse->Mn &&
+        (fuse->colorDone || !fuse->colorEnabled) && (fuse->magEnabled || fuse->histEnabled) && fuse->nOrients <= 12 &&
+        ((uintptr_t(fuse->M) | uintptr_t(fuse->O)) & 15) == 0)
+    {
+        prof(c, "k_triy_chns");
+        if (fuse->nOrients <= 6)
+        {
+            hipLaunchKernelGGL((k_triy_chns<6>), dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, *fuse);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_triy_chns<12>), dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, *fuse);
+        }
+        LAUNCHCHK(c, "k_triy_chns");
+        *fused = true;
+        return ACF_HIP_OK;
+    }
     prof(c, "k_tri_y");
     if (rad == 5 && h % 4 == 0 && h >= 48 && fs % 4 == 0 && ((uintptr_t(U) | uintptr_t(S)) & 15) == 0)
     {
@@ -1100,7 +1124,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         const int tailSlab = (std::max(g.winFloats, TAIL_G * TAIL_PITCH) + 3) / 4 * 4; // footprint, reused as phase 2's transposition tile (16-byte rows)
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
         {
-            for (int cand : { 4, 2, 1 })
+            for (int cand : { 2, 1 })
             {
                 if (!tw && int64_t(cand) * tailSlab * 4 <= limit)
                 {
@@ -1205,7 +1229,10 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     // node table of the tail in LDS if it fits beside the footprint slabs (TreeNode = 12 dwords)
                     const int64_t nodeFloats = int64_t(std::max(p.nTrees - g.b[4], 0)) * 12;
                     cs.tailNodesLds = 0;
-                    for (int cand : { 4, 2 })
+                    // k_cascade_tail3 only takes queue overflow now: keep its LDS small (footprint slabs only, node table from
+                    // L2) so that its blocks — which leave at once in the normal case — never wait for a whole CU's LDS while
+                    // other streams' kernels are resident (measured: up to 2.7 ms of queueing per launch with 156 KB blocks)
+                    for (int cand : std::initializer_list<int>{})
                     {
                         if (!cs.tailNodesLds && cand <= tw && nodeFloats > 0 && (nodeFloats + int64_t(cand) * tailSlab) * 4 <= int64_t(159) * 1024)
                         {
@@ -2321,13 +2348,6 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb);
             }
             LAUNCHCHK(c, "k_grad_mag");
-            if (p.normRad)
-            {
-                if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF)))
-                {
-                    return rc;
-                }
-            }
         }
         ChnsArgs a{};
         a.sm = rs.sm;
@@ -2351,6 +2371,20 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         a.full = p.full;
         a.normConst = float(p.normConst);
         a.rq_y = shrinkGainY(shrink);
+        bool cellsDone = false;
+        if ((p.gradMagEnabled || p.gradHistEnabled) && p.normRad)
+        {
+            // convTri(M, normRad): x running sums, then the y pass — fused with the channel cells when the level allows it
+            // (S then never reaches HBM), else S is written for k_chns
+            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, (shrink == 4 && !c->taps) ? &a : nullptr, &cellsDone)))
+            {
+                return rc;
+            }
+        }
+        if (cellsDone)
+        {
+            continue;
+        }
         if ((rc = launchChns(c, a, shrink, nF)))
         {
             return rc;

@@ -1482,6 +1482,258 @@ __device__ __forceinline__ void chns_load_vec(const float* __restrict__ p, float
     }
 }
 
+// ------------------------------------------------------------------------
+// convTriY (r = 5) + gradMagNorm + the magnitude channel + gradHist in one kernel: k_tri_y5s's column recurrence, whose
+// 16-row x 64-column blocks of S already pass through LDS (lane = column -> coalesced rows), followed at once by k_chns's
+// cell arithmetic on that block (lane = one 4 x 4 cell: 64 cells per block) — S never reaches HBM (16.6 MB per 1080p frame
+// written and read back by the two-kernel form).  M and O of the block are requested before the recurrence and consumed
+// after it.  Values, association order and the histogram's accumulation order are k_tri_y5s's and k_chns's
+// (convConst.cpp:347-442; gradientMex.cpp:254-275, 278-372; imResampleMex.cpp:210-215, 312-317).
+// Needs shrink 4, h % 4 == 0, h >= 48, normalisation on, the colour channels already written (or disabled), no Mnorm tap.
+// ------------------------------------------------------------------------
+template <int MAXO>
+__global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca)
+{
+    __shared__ float ty_lds[4][2][64 * TY_PITCH];
+    const int h = ca.h, w = ca.w;
+    const int64_t fs = ca.m_fs;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 4 + wv) * 64;
+    if (x0 >= w)
+    {
+        return;
+    }
+    float* inb = ty_lds[wv][0];
+    float* outb = ty_lds[wv][1];
+    const int x = min(x0 + lane, w - 1); // lanes past the last column duplicate it and never store
+    const float* __restrict__ U0 = Ui + int64_t(blockIdx.z) * fs;
+    const float* __restrict__ col = U0 + int64_t(x) * h;
+    // cooperative mapping: instruction q moves columns 4q + (lane >> 4), rows base + (lane & 15)
+    const int cl = lane >> 4, rl = lane & 15;
+    constexpr int r = 6, r0 = 5, r1 = 7, h0 = 7;
+    const int r2 = 2 * h - r, h1 = h - r + 1;
+    float t, u;
+    // rows 0..15: the reference's head (reflected taps), straight from memory
+    u = t = col[0];
+#pragma unroll
+    for (int q = 1; q < r; q++)
+    {
+        t += col[q];
+        u += t;
+    }
+    u = 2 * u - t;
+    t = 0;
+    float o[16];
+    o[0] = u;
+#pragma unroll
+    for (int j = 1; j < 16; j++)
+    {
+        const float a = (j < h0) ? col[r - j] : col[j - r1];
+        const float b = col[r0 + j];
+        t += a + b - 2 * col[j - 1];
+        u += t;
+        o[j] = u;
+    }
+    // rows J0 .. J0+15 of S are in o[]: hand them to the cells through the LDS buffer (lane = column -> lane = cell) and
+    // finish the cells: gradMagNorm, the magnitude channel and the orientation histogram (k_chns's arithmetic and order).
+    const int xcL = lane >> 2, ycL = lane & 3;             // cell of this lane inside the wave's 64 x 16 block
+    const int hc = h >> 2;
+    const int64_t cellsN = int64_t(hc) * (w >> 2);
+    const float* __restrict__ Mf = ca.M + int64_t(blockIdx.z) * fs;
+    const float* __restrict__ Of = ca.O + int64_t(blockIdx.z) * fs;
+    float* __restrict__ chn = ca.chns + int64_t(blockIdx.z) * ca.chns_fs;
+    const int chMag = ca.colorEnabled ? ca.d : 0;            // the colour channels were written by k_smooth_vec
+    const float oMult = (float)ca.nOrients / (ca.full ? 2 * 3.14159265f : 3.14159265f);
+    const float sInv2 = 1 / (float)4 / (float)4;
+    const int nO = ca.nOrients;
+    float4 mq[4], oq[4];
+#define TY_MO_FETCH(J0)                                                                                     \
+    {                                                                                                       \
+        const int yq_ = min((J0) + 4 * ycL, h - 4);                                                         \
+        _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
+        {                                                                                                   \
+            const int64_t off_ = int64_t(min(x0 + 4 * xcL + xx, w - 1)) * h + yq_;                          \
+            mq[xx] = *reinterpret_cast<const float4*>(Mf + off_);                                           \
+            oq[xx] = *reinterpret_cast<const float4*>(Of + off_);                                           \
+        }                                                                                                   \
+    }
+#define TY_CELLS(J0, NROWS)                                                                                 \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            *reinterpret_cast<float4*>(outb + lane * TY_PITCH + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]); \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        float sq[4][4], mn[4][4], ov[4][4];                                                                 \
+        _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
+        {                                                                                                   \
+            const float4 sv_ = *reinterpret_cast<const float4*>(outb + (4 * xcL + xx) * TY_PITCH + 4 * ycL); \
+            sq[xx][0] = sv_.x, sq[xx][1] = sv_.y, sq[xx][2] = sv_.z, sq[xx][3] = sv_.w;                      \
+            const float mr_[4] = { mq[xx].x, mq[xx].y, mq[xx].z, mq[xx].w };                                \
+            ov[xx][0] = oq[xx].x, ov[xx][1] = oq[xx].y, ov[xx][2] = oq[xx].z, ov[xx][3] = oq[xx].w;          \
+            _Pragma("unroll") for (int yy = 0; yy < 4; yy++)                                                \
+            {                                                                                               \
+                mn[xx][yy] = mr_[yy] * (1.0f / (sq[xx][yy] + ca.normConst)); /* gradMagNorm: M * rcp(S + norm) */ \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        if (4 * ycL < (NROWS) && x0 + 4 * xcL < w)                                                          \
+        {                                                                                                   \
+            float* outc = chn + int64_t((x0 >> 2) + xcL) * hc + (((J0) >> 2) + ycL);                        \
+            if (ca.magEnabled)                                                                               \
+            {                                                                                               \
+                float C_[4];                                                                                \
+                _Pragma("unroll") for (int yy = 0; yy < 4; yy++)                                            \
+                {                                                                                           \
+                    C_[yy] = ((mn[0][yy] + mn[1][yy]) + mn[2][yy]) + mn[3][yy];                             \
+                }                                                                                           \
+                outc[int64_t(chMag) * cellsN] = (((C_[0] + C_[1]) + C_[2]) + C_[3]) * ca.rq_y;               \
+            }                                                                                               \
+            if (ca.histEnabled)                                                                              \
+            {                                                                                               \
+                float H_[MAXO];                                                                             \
+                _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                            \
+                {                                                                                           \
+                    H_[b] = 0.f;                                                                            \
+                }                                                                                           \
+                _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                            \
+                {                                                                                           \
+                    _Pragma("unroll") for (int yy = 0; yy < 4; yy++)                                        \
+                    {                                                                                       \
+                        const float ob_ = ov[xx][yy] * oMult;                                               \
+                        int o0_ = (int)ob_;                                                                 \
+                        const float od_ = ob_ - (float)o0_;                                                 \
+                        o0_ = (o0_ >= nO) ? 0 : o0_;                                                        \
+                        int o1_ = o0_ + 1;                                                                  \
+                        o1_ = (o1_ == nO) ? 0 : o1_;                                                        \
+                        const float m_ = mn[xx][yy] * sInv2;                                                \
+                        const float m1_ = od_ * m_;                                                         \
+                        const float m0_ = m_ - m1_;                                                         \
+                        _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                    \
+                        {                                                                                   \
+                            H_[b] = (b == o0_) ? H_[b] + m0_ : H_[b];                                       \
+                        }                                                                                   \
+                        _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                    \
+                        {                                                                                   \
+                            H_[b] = (b == o1_) ? H_[b] + m1_ : H_[b];                                       \
+                        }                                                                                   \
+                    }                                                                                       \
+                }                                                                                           \
+                const int chH_ = chMag + (ca.magEnabled ? 1 : 0);                                            \
+                _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                            \
+                {                                                                                           \
+                    if (b < nO)                                                                             \
+                    {                                                                                       \
+                        outc[int64_t(chH_ + b) * cellsN] = H_[b];                                           \
+                    }                                                                                       \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+    // request rows R0..R0+15 of the wave's 64 columns (16 coalesced loads) into g[]
+#define TY_FETCH(G, R0)                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 16; q++)                                                          \
+    {                                                                                                       \
+        G[q] = U0[int64_t(min(x0 + 4 * q + cl, w - 1)) * h + (R0) + rl];                                    \
+    }
+    // hand g[] to the owning lanes: N[q] = rows R0+4q .. R0+4q+3 of this lane's column
+#define TY_TAKE(G, N)                                                                                       \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 16; q++)                                                      \
+        {                                                                                                   \
+            inb[(4 * q + cl) * TY_PITCH + rl] = G[q];                                                       \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            N[q] = *reinterpret_cast<const float4*>(inb + lane * TY_PITCH + 4 * q);                         \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+    }
+    TY_MO_FETCH(0);
+    TY_CELLS(0, 16);
+    // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
+    float ring[16];
+    float g[16];
+    float4 nx[4];
+    {
+        TY_FETCH(g, 8);
+        TY_TAKE(g, nx); // rows 8..23
+        ring[8] = nx[0].x, ring[9] = nx[0].y, ring[10] = nx[0].z, ring[11] = nx[0].w;
+        ring[12] = nx[1].x, ring[13] = nx[1].y, ring[14] = nx[1].z, ring[15] = nx[1].w;
+        ring[0] = nx[2].x, ring[1] = nx[2].y, ring[2] = nx[2].z, ring[3] = nx[2].w;
+        ring[4] = nx[3].x, ring[5] = nx[3].y, ring[6] = nx[3].z, ring[7] = nx[3].w;
+    }
+    int J = 16;
+    const int lastFast = h - 24; // J + 23 <= h - 1 and every j <= J + 15 < h1
+    if (J <= lastFast)
+    {
+        TY_FETCH(g, J + 8);
+        TY_TAKE(g, nx); // rows J+8 .. J+23
+    }
+    for (; J <= lastFast; J += 16)
+    {
+        const bool more = J + 16 <= lastFast;
+        TY_MO_FETCH(J); // this group's M and O cells: in flight during the recurrence
+        if (more)
+        {
+            TY_FETCH(g, J + 24); // next iteration's rows, in flight during this iteration's recurrence
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++)
+            {
+                const int jj = 4 * q + s2; // j = J + jj, J % 16 == 0
+                if (s2 == 3)
+                {
+                    // rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago)
+                    ring[(8 + 4 * q) & 15] = nx[q].x;
+                    ring[(9 + 4 * q) & 15] = nx[q].y;
+                    ring[(10 + 4 * q) & 15] = nx[q].z;
+                    ring[(11 + 4 * q) & 15] = nx[q].w;
+                }
+                const float a = ring[(jj - 7) & 15];
+                const float b = ring[(jj + 5) & 15];
+                const float cc = ring[(jj - 1) & 15];
+                t += a + b - 2 * cc;
+                u += t;
+                o[jj] = u;
+            }
+        }
+        TY_CELLS(J, 16);
+        if (more)
+        {
+            TY_TAKE(g, nx);
+        }
+    }
+#undef TY_FETCH
+#undef TY_TAKE
+    // remaining rows (the reflected tail, 8 .. 23 of them), from memory, 16 at a time through the same cell step
+    for (; J < h; J += 16)
+    {
+        const int nr = min(16, h - J); // a multiple of 4
+        TY_MO_FETCH(J);
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++)
+        {
+            const int j = J + jj;
+            if (jj < nr) // wave-uniform
+            {
+                const float a_ = col[j - r1];
+                const float b_ = (j < h1) ? col[r0 + j] : col[r2 - j];
+                t += a_ + b_ - 2 * col[j - 1];
+                u += t;
+                o[jj] = u;
+            }
+        }
+        TY_CELLS(J, nr);
+    }
+#undef TY_MO_FETCH
+#undef TY_CELLS
+}
+
 // MAXO: compile-time bound of nOrients (6 for every shipped model): the bin update is a select chain over MAXO registers,
 // 2 * MAXO * 3 VALU per pixel — half of the kernel's instructions at MAXO = 12.
 template <int S, int MAXO>
@@ -4428,33 +4680,23 @@ constexpr int SM_BLOCKS = 32; // workgroups per frame (256 threads each); blocks
 constexpr int SM_ITEMS = 8;   // hits per thread and pass
 constexpr int SM_CHUNK = 2048;
 
-__global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict__ hits, const int32_t* __restrict__ counts,
-    int maxHits, const BoxLevel* __restrict__ bl, int stride, int shift_h, int shift_w,
-    acf_hip_hit* __restrict__ sortedHits, acf_hip_detection* __restrict__ dets)
+template <int ITEMS>
+__device__ __forceinline__ void sort_map_body(const acf_hip_hit* __restrict__ H, int n, int frame, int maxHits, const BoxLevel* __restrict__ bl, int stride,
+    int shift_h, int shift_w, acf_hip_hit* __restrict__ sortedHits, acf_hip_detection* __restrict__ dets, long long* keys)
 {
-    // Rank sort on the 64-bit key (scale, c, r) — the order acfDetect1's loops emit (ACF.cpp:283-300).  The keys are
-    // staged through LDS SM_CHUNK at a time and every thread ranks SM_ITEMS hits against a chunk per pass, so a frame
-    // near capacity (65,536 hits: a low cascThr) costs 4e9 LDS compares spread over 8192 threads instead of 4e9 global
-    // reads on 1024 (round 1).  Typical frames (a few hundred hits) use one block and one chunk.
-    __shared__ long long keys[SM_CHUNK];
-    const int frame = blockIdx.y;
-    const int n = min(counts[frame], maxHits);
-    const acf_hip_hit* H = hits + int64_t(frame) * maxHits;
     const int nThreads = SM_BLOCKS * 256;
-    // hits per thread: one while the frame's hits fit the grid (a few hundred hits: every hit its own thread), up to SM_ITEMS
-    const int items = min(SM_ITEMS, (n + nThreads - 1) / nThreads);
-    for (int i0 = 0; i0 < n; i0 += nThreads * items)
+    for (int i0 = 0; i0 < n; i0 += nThreads * ITEMS)
     {
-        const int first = i0 + (blockIdx.x * 256 + threadIdx.x) * items;
-        if (i0 + blockIdx.x * 256 * items >= n) // block-uniform: nothing for this block in this pass (nor in later ones)
+        const int first = i0 + (blockIdx.x * 256 + threadIdx.x) * ITEMS;
+        if (i0 + blockIdx.x * 256 * ITEMS >= n) // block-uniform: nothing for this block in this pass (nor in later ones)
         {
             return;
         }
-        acf_hip_hit me[SM_ITEMS];
-        long long key[SM_ITEMS];
-        int rank[SM_ITEMS];
+        acf_hip_hit me[ITEMS];
+        long long key[ITEMS];
+        int rank[ITEMS];
 #pragma unroll
-        for (int q = 0; q < SM_ITEMS; q++)
+        for (int q = 0; q < ITEMS; q++)
         {
             me[q] = H[min(first + q, n - 1)];
             key[q] = (((long long)me[q].scale) << 40) | (((long long)me[q].c) << 20) | (long long)me[q].r;
@@ -4474,16 +4716,16 @@ __global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict_
             {
                 const long long ko = keys[j];
 #pragma unroll
-                for (int q = 0; q < SM_ITEMS; q++)
+                for (int q = 0; q < ITEMS; q++)
                 {
                     rank[q] += ko < key[q];
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < SM_ITEMS; q++)
+        for (int q = 0; q < ITEMS; q++)
         {
-            if (q < items && first + q < n)
+            if (first + q < n)
             {
                 sortedHits[int64_t(frame) * maxHits + rank[q]] = me[q];
                 const BoxLevel b = bl[me[q].scale];
@@ -4501,8 +4743,28 @@ __global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict_
     }
 }
 
-// Fixed-capacity export record per frame for the multi-GPU gather:
-// [count, cap x {x,y,w,h,score bits,scale}] int32.
+__global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict__ hits, const int32_t* __restrict__ counts,
+    int maxHits, const BoxLevel* __restrict__ bl, int stride, int shift_h, int shift_w,
+    acf_hip_hit* __restrict__ sortedHits, acf_hip_detection* __restrict__ dets)
+{
+    // Rank sort on the 64-bit key (scale, c, r) — the order acfDetect1's loops emit (ACF.cpp:283-300).  The keys are
+    // staged through LDS SM_CHUNK at a time.  A frame whose hits fit the grid (the usual few hundred) gives every hit
+    // its own thread; beyond that a thread ranks SM_ITEMS hits per key read, so a frame near capacity (65,536 hits: a
+    // low cascThr) costs 4e9 LDS compares spread over 8192 threads instead of 4e9 global reads on 1024 (round 1).
+    __shared__ long long keys[SM_CHUNK];
+    const int frame = blockIdx.y;
+    const int n = min(counts[frame], maxHits);
+    const acf_hip_hit* H = hits + int64_t(frame) * maxHits;
+    if (n <= SM_BLOCKS * 256)
+    {
+        sort_map_body<1>(H, n, frame, maxHits, bl, stride, shift_h, shift_w, sortedHits, dets, keys);
+    }
+    else
+    {
+        sort_map_body<SM_ITEMS>(H, n, frame, maxHits, bl, stride, shift_h, shift_w, sortedHits, dets, keys);
+    }
+}
+
 // ------------------------------------------------------------------------
 // bbNms (max / maxg) + ObjectDetector::prune on the device: one workgroup per frame, before the records are exported
 // or gathered (bbNms.cpp:111-192, 229-304; ObjectDetector.cpp:28-44).
@@ -4517,7 +4779,7 @@ __global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict_
 //      past the first score below scores[0] * ratio).
 // Output: indices into the frame's input in output order (+ the gathered records for the pipeline form).
 // ------------------------------------------------------------------------
-constexpr int NMS_CAP = 4096;
+constexpr int NMS_CAP = 2048; // 58 KB of LDS: a block can start next to a resident cascade tile workgroup (81 KB)
 
 struct NmsArgs
 {

@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
     args = ap.parse_args()
 
     import torch
@@ -282,7 +283,7 @@ def main():
                 dets[0].run(frames[:B], B)
         dets[0].synchronize()
         solo = dets[0].profile()
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         # one frame through one context, submit -> results on the device (cfg 2 is worded "single frame")
         lat = []
         with torch.cuda.stream(streams[0]):

@@ -141,7 +141,7 @@ typedef struct acf_hip_nms_params
     double pruneRatio;  /* m_detectionScorePruneRatio */
 } acf_hip_nms_params;
 
-#define ACF_HIP_NMS_CAP 4096 /* detections per frame the device NMS takes; more is ACF_HIP_E_CAPACITY */
+#define ACF_HIP_NMS_CAP 2048 /* detections per frame the device NMS takes; more is ACF_HIP_E_CAPACITY */
 
 /* One cascade hit before box mapping: DetectionSink::add({c,r},h) (acfDetect1.cpp:39-47,92-95). */
 typedef struct acf_hip_hit

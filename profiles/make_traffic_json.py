@@ -1,15 +1,16 @@
 #!/usr/bin/env python
-"""Build profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+"""Build profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
-usage: make_traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <frames_per_step> > profiles/r01_pmc_traffic.json
+usage: make_traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <frames_per_step> > profiles/r02_pmc_traffic.json
 Bytes per launch = FETCH_SIZE*f + WRITE_SIZE (KB -> bytes); f = 2 for kernels whose reads are 16 B/lane streams (gfx950's
 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md §HBM), 1 otherwise (uncalibrated).  Launches of one bench
 "kernel" (prof name) are summed: k_level(fused) = all k_level<R,mode> launches of a step, etc.
 """
 import csv, json, sys, collections
 
-WIDE = ("k_cascade_tile", "k_cascade_tail2", "k_cascade_tail3", "k_grad_mag_vec", "k_tri_x5v", "k_tri_y5(", "k_chns", "k_resample_half", "k_smooth_vec")
-GROUP = [("k_cascade_tile", "k_cascade_tile"), ("k_cascade_tail", "k_cascade_tail2"), ("k_level", "k_level(fused)"),
+WIDE = ("k_cascade_tile", "k_cascade_tail3", "k_grad_mag_vec", "k_tri_x5v", "k_tri_y5(", "k_chns", "k_resample_half", "k_smooth_vec", "k_tail_scan")
+GROUP = [("k_cascade_tile", "k_cascade_tile"), ("k_cascade_tail", "k_cascade_tail3"), ("k_tail_scan", "k_tail_scan"), ("k_level", "k_level(fused)"),
+         ("k_triy_chns", "k_triy_chns"), ("k_sort_map", "k_sort_map"), ("k_nms", "k_nms"), ("k_export", "k_export"),
          ("k_chns", "k_chns"), ("k_smooth_vec", "k_smooth_vec"), ("k_smooth_tri1", "k_smooth_tri1(image)"), ("k_grad_mag", "k_grad_mag"), ("k_tri_x", "k_tri_x"),
          ("k_tri_y", "k_tri_y"), ("k_resample", "k_resample(image)")]
 
@@ -49,6 +50,8 @@ def main():
            "note": __doc__.split("\n\n")[1].strip().replace("\n", " "),
            "frames_per_step": frames,
            "kernels": {g: int((ft.get(g, 0) + wt.get(g, 0)) / steps) for g in sorted(set(ft) | set(wt))}}
+    out["MB_per_frame"] = {g: round(v / frames / 1e6, 2) for g, v in out["kernels"].items()}
+    out["total_MB_per_frame"] = round(sum(out["MB_per_frame"].values()), 1)
     print(json.dumps(out, indent=1))
 
 
