@@ -10,7 +10,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o trace -- python bench
 python profiles/summarize.py $OUT/kt/trace_results.db > $OUT/kernel_stats.md
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kts -o trace -- python bench.py --contexts 1 --batch 96 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/solo_bench.log 2>&1
 python profiles/summarize.py $OUT/kts/trace_results.db > $OUT/solo_kernel_stats.md
-tail -1 $OUT/solo_bench.log > $OUT/solo_bench.json
+grep '^{"metric"' $OUT/solo_bench.log | tail -1 > $OUT/solo_bench.json
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python bench.py --contexts 1 --batch 96 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-latency > $OUT/pmc_$C.log 2>&1
 done
