@@ -1110,11 +1110,17 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             return int64_t(nChns) * rowsP * cols * 4 + int64_t(2) * nw * 64 * 8 + 64;
         };
         int nw = 0;
+        if (const char* e = getenv("ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
+        {
+            const int v = atoi(e);
+            g.TR = (v == 8 || v == 16 || v == 32 || v == 64) ? v : g.TR;
+        }
+        const int nwForce = getenv("ACF_HIP_TILE_NW") ? atoi(getenv("ACF_HIP_TILE_NW")) : 0;
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
         {
             for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
             {
-                if (!nw && cand >= 1 && ldsBytes(cand) <= limit)
+                if (!nw && cand >= 1 && ldsBytes(cand) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR)
                 {
                     nw = cand;
                 }
@@ -1196,9 +1202,11 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     tailNodes[size_t(t)] = b;
                 }
                 // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
-                const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && !getenv("ACF_HIP_TILE_TB4")) ? 8 : 4;
-                std::vector<uint32_t> nodesS(size_t(std::max(g.b[1] / aTB, 1)) * 10 * aTB, 0u);
-                for (int t = 0; t + aTB - 1 < g.b[1]; t += aTB)
+                // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC: ACF_HIP_TILE_TB8 for the A/B)
+                const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
+                const int nTreesS = g.b[1] / aTB * aTB;
+                std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
+                for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
                 {
                     uint32_t* d = nodesS.data() + size_t(t / aTB) * 10 * aTB;
                     for (int q = 0; q < aTB; q++)
@@ -2706,7 +2714,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
                     nb++;
                 }
             }
-            fprintf(stderr, "[casc stamps] blocks %lld  fill %.0f  A %.0f  B %.0f  D %.0f cycles   (tile2, since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
+            fprintf(stderr, "[casc stamps] blocks %lld (those with tail windows)  fill %.0f  wave 0: A + sparse pieces %.0f  barrier %.0f  E %.0f cycles   (since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
                 acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
             (void)hipFree(a.stamps);
         }

@@ -1492,7 +1492,7 @@ __device__ __forceinline__ void chns_load_vec(const float* __restrict__ p, float
 // Needs shrink 4, h % 4 == 0, h >= 48, normalisation on, the colour channels already written (or disabled), no Mnorm tap.
 // ------------------------------------------------------------------------
 template <int MAXO>
-__global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca)
 {
     __shared__ float ty_lds[4][2][64 * TY_PITCH];
     const int h = ca.h, w = ca.w;
@@ -1546,18 +1546,27 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
     const float oMult = (float)ca.nOrients / (ca.full ? 2 * 3.14159265f : 3.14159265f);
     const float sInv2 = 1 / (float)4 / (float)4;
     const int nO = ca.nOrients;
-    float4 mq[4], oq[4];
-#define TY_MO_FETCH(J0)                                                                                     \
+    // M and O cells of block k+1 are requested while block k is worked on (requested at the top of the step that consumes
+    // them, every step paid a full memory round trip).  M: one register set, re-requested as soon as the normalised
+    // magnitudes of the current block exist; O: two sets that swap roles every step (it is live until the histogram).
+    float4 mq[4], oqA[4], oqB[4];
+#define TY_M_FETCH(J0)                                                                                      \
     {                                                                                                       \
         const int yq_ = min((J0) + 4 * ycL, h - 4);                                                         \
         _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
         {                                                                                                   \
-            const int64_t off_ = int64_t(min(x0 + 4 * xcL + xx, w - 1)) * h + yq_;                          \
-            mq[xx] = *reinterpret_cast<const float4*>(Mf + off_);                                           \
-            oq[xx] = *reinterpret_cast<const float4*>(Of + off_);                                           \
+            mq[xx] = *reinterpret_cast<const float4*>(Mf + (uint32_t(min(x0 + 4 * xcL + xx, w - 1)) * uint32_t(h) + uint32_t(yq_))); \
         }                                                                                                   \
     }
-#define TY_CELLS(J0, NROWS)                                                                                 \
+#define TY_O_FETCH(oq, J0)                                                                                  \
+    {                                                                                                       \
+        const int yq_ = min((J0) + 4 * ycL, h - 4);                                                         \
+        _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
+        {                                                                                                   \
+            oq[xx] = *reinterpret_cast<const float4*>(Of + (uint32_t(min(x0 + 4 * xcL + xx, w - 1)) * uint32_t(h) + uint32_t(yq_))); \
+        }                                                                                                   \
+    }
+#define TY_CELLS(oq, J0, NROWS, JN)                                                                                 \
     {                                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
         {                                                                                                   \
@@ -1577,9 +1586,10 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
             }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_wave_barrier();                                                                    \
+        TY_M_FETCH(JN); /* the next block's magnitudes (clamped rows: harmless past the end) */             \
         if (4 * ycL < (NROWS) && x0 + 4 * xcL < w)                                                          \
         {                                                                                                   \
-            float* outc = chn + int64_t((x0 >> 2) + xcL) * hc + (((J0) >> 2) + ycL);                        \
+            float* outc = chn + (uint32_t((x0 >> 2) + xcL) * uint32_t(hc) + uint32_t(((J0) >> 2) + ycL));                      \
             if (ca.magEnabled)                                                                               \
             {                                                                                               \
                 float C_[4];                                                                                \
@@ -1634,7 +1644,7 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
 #define TY_FETCH(G, R0)                                                                                     \
     _Pragma("unroll") for (int q = 0; q < 16; q++)                                                          \
     {                                                                                                       \
-        G[q] = U0[int64_t(min(x0 + 4 * q + cl, w - 1)) * h + (R0) + rl];                                    \
+        G[q] = U0[uint32_t(min(x0 + 4 * q + cl, w - 1)) * uint32_t(h) + uint32_t((R0) + rl)];                                  \
     }
     // hand g[] to the owning lanes: N[q] = rows R0+4q .. R0+4q+3 of this lane's column
 #define TY_TAKE(G, N)                                                                                       \
@@ -1650,8 +1660,10 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
         }                                                                                                   \
         __builtin_amdgcn_wave_barrier();                                                                    \
     }
-    TY_MO_FETCH(0);
-    TY_CELLS(0, 16);
+    TY_M_FETCH(0);
+    TY_O_FETCH(oqA, 0);
+    TY_O_FETCH(oqB, 16);
+    TY_CELLS(oqA, 0, 16, 16);
     // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
     float ring[16];
     float g[16];
@@ -1671,50 +1683,74 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
         TY_FETCH(g, J + 8);
         TY_TAKE(g, nx); // rows J+8 .. J+23
     }
-    for (; J <= lastFast; J += 16)
+#define TY_ITER(CO, NO)                                                                             \
+    {                                                                                                       \
+        const bool more = J + 16 <= lastFast;                                                               \
+        TY_O_FETCH(NO, J + 16); /* the NEXT block's orientations */                                         \
+        if (more)                                                                                           \
+        {                                                                                                   \
+            TY_FETCH(g, J + 24); /* next iteration's rows, in flight during this iteration's recurrence */  \
+        }                                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            _Pragma("unroll") for (int s2 = 0; s2 < 4; s2++)                                                \
+            {                                                                                               \
+                const int jj = 4 * q + s2; /* j = J + jj, J % 16 == 0 */                                    \
+                if (s2 == 3)                                                                                \
+                {                                                                                           \
+                    /* rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago) */ \
+                    ring[(8 + 4 * q) & 15] = nx[q].x;                                                       \
+                    ring[(9 + 4 * q) & 15] = nx[q].y;                                                       \
+                    ring[(10 + 4 * q) & 15] = nx[q].z;                                                      \
+                    ring[(11 + 4 * q) & 15] = nx[q].w;                                                      \
+                }                                                                                           \
+                const float a_ = ring[(jj - 7) & 15];                                                       \
+                const float b_ = ring[(jj + 5) & 15];                                                       \
+                const float cc_ = ring[(jj - 1) & 15];                                                      \
+                t += a_ + b_ - 2 * cc_;                                                                     \
+                u += t;                                                                                     \
+                o[jj] = u;                                                                                  \
+            }                                                                                               \
+        }                                                                                                   \
+        TY_CELLS(CO, J, 16, J + 16);                                                                         \
+        if (more)                                                                                           \
+        {                                                                                                   \
+            TY_TAKE(g, nx);                                                                                 \
+        }                                                                                                   \
+        J += 16;                                                                                            \
+    }
+    bool inA = false; // which set holds the block at J (block 16 is in B)
+    while (J <= lastFast)
     {
-        const bool more = J + 16 <= lastFast;
-        TY_MO_FETCH(J); // this group's M and O cells: in flight during the recurrence
-        if (more)
+        TY_ITER(oqB, oqA);
+        inA = true;
+        if (J > lastFast)
         {
-            TY_FETCH(g, J + 24); // next iteration's rows, in flight during this iteration's recurrence
+            break;
         }
+        TY_ITER(oqA, oqB);
+        inA = false;
+    }
+#undef TY_ITER
+    if (!inA) // wave-uniform; once
+    {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int xx = 0; xx < 4; xx++)
         {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; s2++)
-            {
-                const int jj = 4 * q + s2; // j = J + jj, J % 16 == 0
-                if (s2 == 3)
-                {
-                    // rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago)
-                    ring[(8 + 4 * q) & 15] = nx[q].x;
-                    ring[(9 + 4 * q) & 15] = nx[q].y;
-                    ring[(10 + 4 * q) & 15] = nx[q].z;
-                    ring[(11 + 4 * q) & 15] = nx[q].w;
-                }
-                const float a = ring[(jj - 7) & 15];
-                const float b = ring[(jj + 5) & 15];
-                const float cc = ring[(jj - 1) & 15];
-                t += a + b - 2 * cc;
-                u += t;
-                o[jj] = u;
-            }
-        }
-        TY_CELLS(J, 16);
-        if (more)
-        {
-            TY_TAKE(g, nx);
+            oqA[xx] = oqB[xx];
         }
     }
 #undef TY_FETCH
 #undef TY_TAKE
-    // remaining rows (the reflected tail, 8 .. 23 of them), from memory, 16 at a time through the same cell step
-    for (; J < h; J += 16)
+    // remaining rows (the reflected tail, 8 .. 23 of them), from memory, 16 at a time through the same cell step; the first
+    // group's M and O are already in set A
+    for (bool firstTail = true; J < h; J += 16, firstTail = false)
     {
         const int nr = min(16, h - J); // a multiple of 4
-        TY_MO_FETCH(J);
+        if (!firstTail)
+        {
+            TY_O_FETCH(oqA, J); // (M was requested by the previous group's cell step)
+        }
 #pragma unroll
         for (int jj = 0; jj < 16; jj++)
         {
@@ -1728,9 +1764,10 @@ __global__ void __launch_bounds__(256) k_triy_chns(const float* __restrict__ Ui,
                 o[jj] = u;
             }
         }
-        TY_CELLS(J, nr);
+        TY_CELLS(oqA, J, nr, J + 16);
     }
-#undef TY_MO_FETCH
+#undef TY_M_FETCH
+#undef TY_O_FETCH
 #undef TY_CELLS
 }
 
@@ -3611,27 +3648,6 @@ struct LaneNode
     uint4 o, tq, hq;
 };
 
-// Survivors of a tile stage -> LDS list {thread id in tile, h bits}.
-__device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2* list, int* cnt)
-{
-    const unsigned long long mask = __ballot(alive);
-    if (!mask)
-    {
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0)
-    {
-        base = atomicAdd(cnt, __popcll(mask)); // LDS atomic
-    }
-    base = __shfl(base, 0);
-    if (alive)
-    {
-        list[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(tag), __float_as_uint(h));
-    }
-}
-
 #define TILE_STAMP(k)                                                          \
     if ((a.debug & 4) && threadIdx.x == 0)                                      \
     {                                                                          \
@@ -3655,6 +3671,13 @@ __device__ __forceinline__ void tile_compact(bool alive, int tag, float h, uint2
 //    order ACROSS the TL lanes with a DPP chain (lane j takes lane j-1's prefix and adds its own leaf: the additions
 //    and their order are evaluate()'s, acfDetect1.cpp:123-138), and a window survives when every prefix stays above
 //    cascThr.
+//  * With a workgroup barrier around every sparse piece, a tile spent 5.9k cycles in them plus 2.2k waiting for the slowest
+//    wave of stage A.  Every wave now keeps ITS OWN 64 windows from stage A to stage E (private list segments, no barrier,
+//    no LDS atomics), and a wave's columns are interleaved with the other waves' (w, w + NW: survivors come in clusters;
+//    it also makes stage A's reads conflict-free: 8 * rowsP = 32 banks apart).  Measured, not kept: stage A split in two
+//    with a compaction in between (the second half on two waves is a latency chain: slower), a dense form of the pieces
+//    for long lists, two rounds per iteration side by side, an L2 warm-up of a later tile by 4-byte LDS-DMA requests
+//    (+10 %: the fill is not waiting for HBM latency), 16 x 16-window tiles with three workgroups per CU (+50 %).
 //  * The ~930 windows per 1080p frame that outlive tree 128 used to be re-fetched from HBM as 16 KB footprints by the
 //    tail kernel (k_cascade_tail3: 11.5 us per frame; a stand-alone code kernel: 5.5 us, bound by those 80-byte column runs).  Their
 //    features are in this tile already: stage E evaluates every remaining tree for them (lanes = trees, nodes streamed
@@ -3675,7 +3698,8 @@ __device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __
     {
         o[i] = p[i];
     }
-    unsigned long long aliveM = ~0ull;
+    const unsigned long long execAll = __builtin_amdgcn_read_exec(); // every lane of the wave is here (callers: wave-uniform control flow only)
+    float hMin = __builtin_inff();
     for (int b = 0; b < nBatches; b++)
     {
         float f[3 * TB];
@@ -3707,29 +3731,54 @@ __device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __
         {
             o[i] = pn[i];
         }
+        // Per tree: thresholds are compared straight from SGPRs (one scalar operand per VALU instruction on gfx9), the three
+        // compares produce wave masks, and the leaf is added UNDER EXEC: the four leaf masks (root & left child, root & ~left,
+        // ~root & right, ~(root | right)) partition the wave, so four `v_add_f32 hNew, leaf_k (SGPR), hOld` with EXEC = mask_k
+        // write every lane of hNew exactly once with hOld + its leaf — no v_mov of the leaf values into VGPRs, no v_cndmask
+        // chain, no separate add (8 VALU -> 4; the masks are 4 SALU instructions).  hOld/hNew alternate between two
+        // registers, so that one v_min3 per PAIR of trees keeps the minimum over the prefixes (evaluate()'s early exit:
+        // a window is rejected as soon as one prefix is <= cascThr, acfDetect1.cpp:123-138).  10.5 VALU per tree and window
+        // instead of 15 (three v_cndmask on four v_mov'ed leaves + add + compare): 31.4 -> 30.1 us per frame with batches of 4.
 #pragma unroll
-        for (int g = 0; g < TB; g++)
+        for (int g = 0; g < TB; g += 2)
         {
-            // Thresholds are compared straight from SGPRs (one scalar operand per VALU instruction on gfx9); all three
-            // compares produce wave masks, the child's outcome is combined on the scalar unit, and the leaf is three
-            // v_cndmask with those masks: 12 VALU instructions per tree besides the three address adds.
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * g] < __uint_as_float(th[3 * g]));
-            const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * g + 1] < __uint_as_float(th[3 * g + 1]));
-            const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * g + 2] < __uint_as_float(th[3 * g + 2]));
-            const unsigned long long m1 = (m0 & mA) | (~m0 & mB);
-            float A, B, C, D, x, y, hv;
-            asm("v_mov_b32 %0, %1" : "=v"(A) : "s"(hv4[4 * g]));
-            asm("v_mov_b32 %0, %1" : "=v"(B) : "s"(hv4[4 * g + 1]));
-            asm("v_mov_b32 %0, %1" : "=v"(C) : "s"(hv4[4 * g + 2]));
-            asm("v_mov_b32 %0, %1" : "=v"(D) : "s"(hv4[4 * g + 3]));
-            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x) : "v"(B), "v"(A), "s"(m1));
-            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(y) : "v"(D), "v"(C), "s"(m1));
-            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hv) : "v"(y), "v"(x), "s"(m0));
-            h = h + hv; // a rejected window's score is never read again
-            aliveM &= __builtin_amdgcn_ballot_w64(h > thrC);
+            float h1, h2;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                const int t = g + q;
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * t] < __uint_as_float(th[3 * t]));
+                const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * t + 1] < __uint_as_float(th[3 * t + 1]));
+                const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * t + 2] < __uint_as_float(th[3 * t + 2]));
+                float hOut;
+                const float hIn = q == 0 ? h : h1;
+                asm volatile("s_and_b64 exec, %[m0], %[mA]\n\t"
+                             "v_add_f32 %[o], %[A], %[i]\n\t"
+                             "s_andn2_b64 exec, %[m0], %[mA]\n\t"
+                             "v_add_f32 %[o], %[B], %[i]\n\t"
+                             "s_andn2_b64 exec, %[mB], %[m0]\n\t"
+                             "v_add_f32 %[o], %[C], %[i]\n\t"
+                             "s_nor_b64 exec, %[m0], %[mB]\n\t"
+                             "v_add_f32 %[o], %[D], %[i]\n\t"
+                             "s_mov_b64 exec, %[ex]"
+                             : [o] "=&v"(hOut)
+                             : [i] "v"(hIn), [m0] "s"(m0), [mA] "s"(mA), [mB] "s"(mB), [A] "s"(hv4[4 * t]), [B] "s"(hv4[4 * t + 1]),
+                             [C] "s"(hv4[4 * t + 2]), [D] "s"(hv4[4 * t + 3]), [ex] "s"(execAll)
+                             : "scc");
+                if (q == 0)
+                {
+                    h1 = hOut;
+                }
+                else
+                {
+                    h2 = hOut;
+                }
+            }
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
+            h = h2; // a rejected window's score is never read again
         }
     }
-    alive = alive && ((aliveM >> (threadIdx.x & 63)) & 1ull);
+    alive = alive && (hMin > thrC);
 }
 
 // one tree at a time through the TreeNode table (stage A trees beyond the last full batch of four)
@@ -3852,16 +3901,16 @@ __device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ n
     return n;
 }
 
-// One sparse stage over trees [t0, t0 + T), T <= 64: TL = 2^tlShift >= T lanes per listed window, every lane one tree.
+// One sparse piece over trees [t0, t0 + T), T <= 64, for ONE WAVE's own survivors (lin/lout: the wave's private list
+// segments; no barrier, no atomics): TL = 2^tlShift >= T lanes per listed window, every lane one tree.
 // The score is accumulated in tree order by lane 15 of each 16-lane row (row_chain), rows of one window in sequence
 // (row_bcast:15 hands the prefix to the next row).  Lanes past T contribute +0.0f: h is a sum that starts at +0.0f, so
 // it is never -0.0f and h + 0.0f == h bit for bit.  `last`: survivors go to the hit list / tail queue (their
-// {tag, slot} to lout for stage E), else {tag, h} to lout.  The caller separates stages with a barrier.
-template <int NW>
-__device__ __forceinline__ void tile_sparse_stage(const TileArgs& a, const TileCtx& X, const uint2* lin, int nIn, uint2* lout, int* cntOut, const SparseNode& nd,
+// {tag, slot} to lout for stage E), else {tag, h} to lout.  Returns the number of entries written to lout.
+__device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx& X, const uint2* lin, int nIn, uint2* lout, const SparseNode& nd,
     int T, int tlShift, bool last, bool lastAll)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int TL = 1 << tlShift, G = 64 >> tlShift, K = TL >> 4;
     const int pos = lane & (TL - 1), g = lane >> tlShift;
     const int rowInWin = (lane >> 4) & (K - 1);
@@ -3880,7 +3929,8 @@ __device__ __forceinline__ void tile_sparse_stage(const TileArgs& a, const TileC
     ACF_PIN_V(h1);
     ACF_PIN_V(h2);
     ACF_PIN_V(h3);
-    for (int base = wv * G; base < nIn; base += NW * G)
+    int nOut = 0;
+    for (int base = 0; base < nIn; base += G)
     {
         const int wi = base + g;
         const bool valid = wi < nIn;
@@ -3911,20 +3961,20 @@ __device__ __forceinline__ void tile_sparse_stage(const TileArgs& a, const TileC
         }
         // lane 15 of a window's last row: its final score and the minimum over all its prefixes (evaluate()'s early exit)
         const bool emitLane = valid && (lane & 15) == 15 && rowInWin == K - 1 && (mm > X.thrC) && (acc > X.thrC);
+        float val = acc;
         if (last)
         {
             const int n = (X.c0 + cl) * X.nWinR + (X.r0 + rl);
-            const int slot = tile_emit2(a, lastAll, X.frame, emitLane, X.lvl, n, X.nWinR, acc);
-            if (!lastAll)
-            {
-                tile_compact(emitLane, int(e.x), __int_as_float(slot), lout, cntOut);
-            }
+            val = __int_as_float(tile_emit2(a, lastAll, X.frame, emitLane, X.lvl, n, X.nWinR, acc));
         }
-        else
+        const unsigned long long m = __ballot(emitLane);
+        if (emitLane)
         {
-            tile_compact(emitLane, int(e.x), acc, lout, cntOut);
+            lout[nOut + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, __float_as_uint(val));
         }
+        nOut += __popcll(m);
     }
+    return nOut;
 }
 
 template <int NW>
@@ -4012,8 +4062,10 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
         pN[k] = sparse_node(a.tileNodes, min(a.g.b[k + 1], a.nTrees - 1), pT[k], pShift[k]);
     }
     TILE_STAMP_REL(5);
-    // ---- stage A: lanes = windows
-    const int r_l = tid % a.g.TR, c_l = tid / a.g.TR;
+    // ---- stage A: lanes = windows, trees [0,b1) for every window of the tile
+    // wave w takes the window columns w, w + NW, ... (64 / TR of them): survivors come in spatial clusters, and a cluster
+    // that sits in one wave's columns would serialise that wave's sparse pieces while the other waves wait at stage E
+    const int r_l = lane % a.g.TR, c_l = (lane / a.g.TR) * NW + wv;
     const int wr = T.r0 + r_l;
     bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC;
     float h = 0.f;
@@ -4035,28 +4087,30 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     }
     asm volatile("" ::"v"(h));
     TILE_STAMP_REL(6);
-    const int tagA = c_l * a.g.TR + r_l;
-    if (a.g.b[1] == tEnd)
+    // ---- from here to stage E every wave works on ITS OWN 64 windows: its survivors go to its private list segment and
+    // through the sparse pieces [b1,b2) [b2,b3) [b3,b4) (each cut into pieces of at most 64 trees) without a workgroup
+    // barrier — the pieces are latency chains (two LDS round trips + a 16..64-step add chain per round) that now overlap
+    // the other waves' stage A instead of idling the whole workgroup three times (measured with barriers: 5.9k cycles
+    // for the pieces + 2.2k waiting for the slowest wave of stage A, per tile).
+    uint2* segA = listA + wv * 64;
+    uint2* segB = listB + wv * 64;
+    int nIn;
     {
-        const int slot = tile_emit2(a, lastAll, frame, alive, lvl, (T.c0 + c_l) * L.nWinR + wr, L.nWinR, h);
-        if (lastAll)
+        float val = h;
+        if (a.g.b[1] == tEnd)
         {
-            return;
+            val = __int_as_float(tile_emit2(a, lastAll, frame, alive, lvl, (T.c0 + c_l) * L.nWinR + wr, L.nWinR, h));
         }
-        tile_compact(alive, tagA, __int_as_float(slot), listA, &s_cnt[0]);
-    }
-    else
-    {
-        tile_compact(alive, tagA, h, listA, &s_cnt[0]);
+        const unsigned long long m = __ballot(alive);
+        if (alive)
+        {
+            segA[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(c_l * a.g.TR + r_l), __float_as_uint(val));
+        }
+        nIn = __popcll(m);
     }
     TILE_STAMP_REL(7);
-    __syncthreads();
-    TILE_STAMP(2);
-    // ---- sparse stages over [b1,b2) [b2,b3) [b3,b4), each cut into pieces of at most 64 trees
-    uint2* lin = listA;
-    uint2* lout = listB;
-    int nIn = s_cnt[0];
-    int ci = 1;
+    uint2* lin = segA;
+    uint2* lout = segB;
     if (a.g.b[1] < tEnd)
     {
 #pragma unroll
@@ -4067,40 +4121,53 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 const int Tn = min(64, a.g.b[stage + 1] - t0);
                 const int tlShift = Tn <= 16 ? 4 : (Tn <= 32 ? 5 : 6);
                 const bool last = t0 + Tn == tEnd;
+                __builtin_amdgcn_wave_barrier(); // (the list written above is read across lanes below: keep the order)
                 if (nIn > 0)
                 {
                     if (t0 == a.g.b[stage])
                     {
-                        tile_sparse_stage<NW>(a, X, lin, nIn, lout, &s_cnt[ci & 7], pN[stage - 1], Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave(a, X, lin, nIn, lout, pN[stage - 1], Tn, tlShift, last, lastAll);
                     }
                     else
                     {
                         const SparseNode nd = sparse_node(a.tileNodes, t0, Tn, tlShift);
-                        tile_sparse_stage<NW>(a, X, lin, nIn, lout, &s_cnt[ci & 7], nd, Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave(a, X, lin, nIn, lout, nd, Tn, tlShift, last, lastAll);
                     }
                 }
-                __syncthreads();
-                nIn = s_cnt[ci & 7];
-                if (tid == 0)
-                {
-                    s_cnt[(ci + 6) & 7] = 0; // counter of the piece six ahead (read long ago: barriers in between)
-                }
-                ci++;
-                uint2* tmp = lin;
+                uint2* tmp = lin; // (every wave swaps at every piece, so the final segment is the same for all of them)
                 lin = lout;
                 lout = tmp;
             }
         }
     }
-    TILE_STAMP(3);
-    if (lastAll || nIn == 0 || a.codeCap <= 0)
+    if (lastAll || a.codeCap <= 0)
     {
         TILE_STAMP(4);
         return;
     }
-    // ---- stage E: leaf codes of every tail tree for the nIn windows now in the tail queue (lin: {tag, queue slot}).
-    // lanes = trees; a wave takes four 64-tree batches at a time (nodes in registers, their reads of one window's
-    // features issued together), windows in the inner loop: the node stream is read once per tile, not per window.
+    // ---- stage E: leaf codes of every tail tree for the windows now in the tail queue ({tag, queue slot} in the waves'
+    // segments).  lanes = trees; a wave takes four 64-tree batches at a time (nodes in registers, their reads of one
+    // window's features issued together), windows in the inner loop: the node stream is read once per tile, not per window.
+    if (lane == 0)
+    {
+        s_cnt[wv] = nIn;
+    }
+    TILE_STAMP(2);
+    __syncthreads();
+    TILE_STAMP(3);
+    int cntW[NW], nTail = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+    {
+        cntW[w] = s_cnt[w];
+        nTail += cntW[w];
+    }
+    if (nTail == 0)
+    {
+        TILE_STAMP(4);
+        return;
+    }
+    const uint2* listE = lin - wv * 64; // wave 0's final segment; wave w's is 64 entries further
     {
         const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
         for (int b0 = wv; b0 < nB; b0 += 4 * NW)
@@ -4120,37 +4187,41 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 t1[k] = __uint_as_float(tq.y);
                 t2[k] = __uint_as_float(tq.z);
             }
-            for (int s = 0; s < nIn; s++)
+#pragma unroll
+            for (int w = 0; w < NW; w++)
             {
-                const uint2 e = lin[s];
-                const int slot = int(e.y);
-                if (slot < 0 || slot >= a.codeCap)
+                for (int s = 0; s < cntW[w]; s++)
                 {
-                    continue; // no code row: k_cascade_tail3 takes this entry
-                }
-                const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
-                const float* win = tileF + (cl * step) * rowsP + rl * step;
-                uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + slot) * a.codePitch + lane;
-                float f0[4], fc[4];
-                bool lt0[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    f0[k] = win[o0[k]];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    lt0[k] = f0[k] < t0[k];
-                    fc[k] = win[lt0[k] ? o1[k] : o2[k]];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    const bool lt1 = fc[k] < (lt0[k] ? t1[k] : t2[k]);
-                    if (b0 + k * NW < nB) // wave-uniform
+                    const uint2 e = listE[w * 64 + s];
+                    const int slot = int(e.y);
+                    if (slot < 0 || slot >= a.codeCap)
                     {
-                        row[(b0 + k * NW) * 64] = uint8_t((lt0[k] ? 0 : 8) + (lt1 ? 0 : 4));
+                        continue; // no code row: k_cascade_tail3 takes this entry
+                    }
+                    const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
+                    const float* win = tileF + (cl * step) * rowsP + rl * step;
+                    uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + slot) * a.codePitch + lane;
+                    float f0[4], fc[4];
+                    bool lt0[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        f0[k] = win[o0[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        lt0[k] = f0[k] < t0[k];
+                        fc[k] = win[lt0[k] ? o1[k] : o2[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const bool lt1 = fc[k] < (lt0[k] ? t1[k] : t2[k]);
+                        if (b0 + k * NW < nB) // wave-uniform
+                        {
+                            row[(b0 + k * NW) * 64] = uint8_t((lt0[k] ? 0 : 8) + (lt1 ? 0 : 4));
+                        }
                     }
                 }
             }
