@@ -1106,8 +1106,8 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             const int tc = nw * W * 64 / g.TR;
             const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
             const int64_t rowsP = (rows + 3) / 4 * 4;
-            // k_cascade_tile2: footprint + two survivor lists (+ its few static words)
-            return int64_t(nChns) * rowsP * cols * 4 + int64_t(2) * nw * 64 * 8 + 64;
+            // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
+            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * 64 * 8 + 64;
         };
         int nw = 0;
         if (const char* e = getenv("ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
@@ -2436,7 +2436,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
             if (nAll > 0)
             {
-                hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, 4), nLF, nAll), dim3(256), 0, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,
+                hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, LEVEL_WAVES), nLF, nAll), dim3(64 * LEVEL_WAVES), 0, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,
                     (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
                 LAUNCHCHK(c, "k_level_all");
             }
@@ -2445,7 +2445,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             {
                 const auto& g = *git;
                 hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
-                dim3 grid(cdiv(pl.nChns, 4), g.count, nLF), block(256);
+                dim3 grid(cdiv(pl.nChns, LEVEL_WAVES), g.count, nLF), block(64 * LEVEL_WAVES);
     #define LV_LAUNCH(RR, MM)                                                                                                         \
         hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)chnsF, pyrF, rawOut, ljobs + g.first, dd, \
             (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
@@ -2674,7 +2674,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         const int64_t total = int64_t(cs.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(g.tileFloats) * 4 + size_t(2) * g.NW * 64 * 8;
+        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * 64 * 8;
         dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");

@@ -2238,15 +2238,21 @@ __device__ __forceinline__ void buf_st(srd_t r, uint32_t voff, uint32_t soff, fl
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
-// Source-column window of an approximated level.  The x pass of imResample combines JX adjacent source columns per
-// output column and successive output columns move on by s = 0, 1 or 2 source columns, so instead of fetching
-// JX*NY taps per output row every step (3 source columns through the L1 per step, every one a miss with 16 planes
-// in flight per CU: the k_level experiments of round 1 put 50 % of the kernel there) the wave keeps the JX source
-// columns in registers with lanes on SOURCE rows, fetches only the s new columns per step (requested one step
-// ahead), runs the x pass once per source row, and hands the column to the y pass through a wave-private LDS
-// buffer: row r of the x-pass column at float r, gathered by each output row's y taps.  Per element the operands
-// and their order are those of k_resample (x pass then y pass), so the result is bit-identical.
-constexpr int LEVEL_LDS_WAVE = 12 * 64; // floats: the x-pass column of one wave, RS <= 12 source-row registers (R <= 8)
+// Source columns of an approximated level.  The x pass of imResample combines JX adjacent source columns per output
+// column and successive output columns move on by s = 0, 1 or 2 source columns.  Every source column is fetched ONCE,
+// by LDS-DMA (`buffer_load_dword ... lds`, lanes on SOURCE rows), into a wave-private ring of NB column slots, LA = NB - JX
+// columns ahead of the window; the x pass reads its JX columns from the ring, runs once per source row, and hands the
+// column to the y pass through the wave's column buffer (row r at float r, gathered by each output row's y taps).
+// Round 2 measured what the register window of round 1 cost: its new columns were requested ONE step ahead, inside
+// wave-uniform branches on the shift, so every step of every approximated plane (27 of 31 levels) waited a full memory
+// round trip (4.7k cycles per column step with 14 waves per CU: 2.4 TB/s); deeper register prefetch would need copies
+// of registers that loads are still writing.  A ring has no copies, and its wait is a constant: when the window needs
+// columns <= c, columns <= c + LA have been requested, so at least LA * RS younger requests exist and
+// `s_waitcnt vmcnt(LA * RS)` (completion is in order; stores only add younger entries) covers c.
+// Per element the operands and their order are those of k_resample (x pass then y pass): bit-identical.
+// waves (= channel planes) per workgroup of the level kernels: 2, so that ten channels are 5 full workgroups
+constexpr int LEVEL_WAVES = 2;
+constexpr int LEVEL_RING_FLOATS = 2304; // 9 KB per wave: 6 slots of 6 x 64 rows ... 12 slots of <= 3 x 64 rows
 
 template <int R, int MODE>
 struct LevelWindow
@@ -2256,94 +2262,67 @@ struct LevelWindow
     static constexpr int NY = YDOWN ? 3 : 2;
     static constexpr int JX = XDOWN ? 3 : 2;
     static constexpr int RS = YDOWN ? (3 * R + 1) / 2 : R; // source rows per lane: ha <= 64 * RS (host-checked)
+    static constexpr int NBRAW = LEVEL_RING_FLOATS / (RS * 64);
+    static constexpr int NB = NBRAW > 12 ? 12 : (NBRAW < JX + 2 ? JX + 2 : NBRAW); // ring slots
+    static constexpr int LA = NB - JX;                                             // columns requested ahead of the window
+    static constexpr int LDS_FLOATS = RS * 64 * (NB + 1);                          // x-pass column + ring, per wave
+    static_assert(LA * RS <= 63, "vmcnt immediate");
 
-    float win[JX][RS]; // source columns xaCur .. xaCur + JX - 1
-    float nw[2][RS];   // source columns xaCur + JX, xaCur + JX + 1 (requested during the previous step)
     uint32_t srow[RS]; // byte offset of the lane's (clamped) source rows in a column
-    int xaCur;
+    int issued;        // last source column requested (wave-uniform)
+    float* ring;       // NB slots of RS * 64 floats: column c in slot c % NB, source row q at float q
 
-    __device__ __forceinline__ void load_col(float (&d)[RS], srd_t A, int col, int ha, int wa) const
+    __device__ __forceinline__ void request(srd_t A, int col, int ha, int wa) const
     {
         const uint32_t cb = uint32_t(min(col, wa - 1)) * uint32_t(ha) * 4u;
+        float* slot = ring + (uint32_t(col) % uint32_t(NB)) * (RS * 64);
 #pragma unroll
         for (int r = 0; r < RS; r++)
         {
-            d[r] = buf_ld(A, srow[r], cb);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(A, (lptr_t)(slot + 64 * r), 4, srow[r], cb, 0, 0);
         }
     }
 
-    __device__ __forceinline__ void init(srd_t A, int lane, int ha, int wa, int xa0)
+    __device__ __forceinline__ void init(srd_t A, float* ring_, int lane, int ha, int wa, int xa0)
     {
 #pragma unroll
         for (int r = 0; r < RS; r++)
         {
             srow[r] = 4u * uint32_t(min(lane + 64 * r, ha - 1));
         }
-        xaCur = xa0;
+        ring = ring_;
+        for (int k = 0; k < JX + LA; k++)
+        {
+            request(A, xa0 + k, ha, wa);
+        }
+        issued = xa0 + JX + LA - 1;
+    }
+
+    // the window moves to source column xa (wave-uniform): request the columns that enter the look-ahead
+    __device__ __forceinline__ void advance(srd_t A, int xa, int ha, int wa)
+    {
+        const int target = xa + JX - 1 + LA;
+        while (issued < target) // 0, 1 or 2 rounds for ratios within 2^(+-1/2)
+        {
+            issued++;
+            request(A, issued, ha, wa);
+        }
+    }
+
+    // columns xa .. xa + JX - 1 of the lane's source rows
+    __device__ __forceinline__ void read(float (&d)[JX][RS], int xa, int lane) const
+    {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA * RS) : "memory");
 #pragma unroll
         for (int j = 0; j < JX; j++)
         {
-            load_col(win[j], A, xa0 + j, ha, wa);
-        }
-        load_col(nw[0], A, xa0 + JX, ha, wa);
-        load_col(nw[1], A, xa0 + JX + 1, ha, wa);
-    }
-
-    // move the window to source column xa (wave-uniform), fetching exactly the columns that enter it
-    __device__ __forceinline__ void advance(srd_t A, int xa, int ha, int wa)
-    {
-        const int sft = xa - xaCur;
-        if (sft == 0)
-        {
-            return;
-        }
-        if (sft == 1)
-        {
+            const float* slot = ring + (uint32_t(xa + j) % uint32_t(NB)) * (RS * 64) + lane;
 #pragma unroll
             for (int r = 0; r < RS; r++)
             {
-#pragma unroll
-                for (int j = 0; j + 1 < JX; j++)
-                {
-                    win[j][r] = win[j + 1][r];
-                }
-                win[JX - 1][r] = nw[0][r];
-                nw[0][r] = nw[1][r];
+                d[j][r] = slot[64 * r];
             }
-            load_col(nw[1], A, xa + JX + 1, ha, wa);
         }
-        else if (sft == 2)
-        {
-#pragma unroll
-            for (int r = 0; r < RS; r++)
-            {
-                if (JX == 3)
-                {
-                    win[0][r] = win[2][r];
-                    win[1][r] = nw[0][r];
-                    win[2][r] = nw[1][r];
-                }
-                else
-                {
-                    win[0][r] = nw[0][r];
-                    win[1][r] = nw[1][r];
-                }
-            }
-            load_col(nw[0], A, xa + JX, ha, wa);
-            load_col(nw[1], A, xa + JX + 1, ha, wa);
-        }
-        else
-        {
-            // not reached for ratios within 2^(+-1/2); kept for safety (any jump, either direction)
-#pragma unroll
-            for (int j = 0; j < JX; j++)
-            {
-                load_col(win[j], A, xa + j, ha, wa);
-            }
-            load_col(nw[0], A, xa + JX, ha, wa);
-            load_col(nw[1], A, xa + JX + 1, ha, wa);
-        }
-        xaCur = xa;
     }
 };
 
@@ -2362,7 +2341,7 @@ struct LaneTaps
 template <int R, int MODE>
 __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int h, const uint32_t (&yoff)[R],
     int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, srd_t raw, bool haveRaw, bool lastOk,
-    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>& win, float* __restrict__ ldsCol, int lane)
+    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>& win, float* ldsCol, int lane)
 {
     if (MODE == LM_REAL)
     {
@@ -2379,13 +2358,16 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     // An approximated level is within a factor 2^(+-1/2) of its real level, so an output has at most three
     // taps per axis when down-sampling and two when up-sampling (the plan falls back to separate launches
     // otherwise).  All JX*NY source values of every register are requested before any is used.
-    constexpr int NY = YDOWN ? 3 : 2;
-    constexpr int JX = XDOWN ? 3 : 2;
+    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> Win;
+    constexpr int NY = Win::NY;
+    constexpr int JX = Win::JX;
     const int xa = int(xr[0]), m = int(xr[1]);
     const bool border = xr[3] != 0;
     const float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
     constexpr int RS = LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::RS;
     win.advance(A, xa, ha, wa);
+    float sc[JX][RS];
+    win.read(sc, xa, lane);
     // x pass on the lane's source rows: taps accumulate left to right (imResampleMex.cpp:198-280).  The tap count m and
     // the border flag are wave-uniform per column: branch on them once, around arithmetic only.
     float Cr[RS];
@@ -2396,7 +2378,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 #pragma unroll
             for (int r = 0; r < RS; r++)
             {
-                Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1];
+                Cr[r] = sc[0][r] * w[0] + sc[1][r] * w[1];
             }
         }
         else if (m >= 3)
@@ -2404,7 +2386,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 #pragma unroll
             for (int r = 0; r < RS; r++)
             {
-                Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1] + win.win[JX - 1][r] * w[2];
+                Cr[r] = sc[0][r] * w[0] + sc[1][r] * w[1] + sc[JX - 1][r] * w[2];
             }
         }
         else
@@ -2412,7 +2394,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 #pragma unroll
             for (int r = 0; r < RS; r++)
             {
-                Cr[r] = win.win[0][r] * w[0];
+                Cr[r] = sc[0][r] * w[0];
             }
         }
     }
@@ -2422,7 +2404,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 #pragma unroll
         for (int r = 0; r < RS; r++)
         {
-            Cr[r] = win.win[0][r];
+            Cr[r] = sc[0][r];
         }
     }
     else
@@ -2430,7 +2412,7 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 #pragma unroll
         for (int r = 0; r < RS; r++)
         {
-            Cr[r] = win.win[0][r] * w[0] + win.win[1][r] * w[1]; // A0*wt + A1*(1-wt)
+            Cr[r] = sc[0][r] * w[0] + sc[1][r] * w[1]; // A0*wt + A1*(1-wt)
         }
     }
     // hand the column to the y pass: source row q at ldsCol[q]; an output row gathers its NY taps (byte offsets
@@ -2513,11 +2495,11 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
 template <int R, int MODE>
 __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* __restrict__ ldsBlock)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* ldsBlock, int ldsWaveFloats)
 {
     // the plane index is the same for the 64 lanes of a wave; say so (readfirstlane), or every plane pointer is
     // treated as per-lane and all address arithmetic lands on the VALU in 64 bits
-    const int z = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int z = __builtin_amdgcn_readfirstlane(blockIdx.x * LEVEL_WAVES + (threadIdx.x >> 6));
     if (z >= nChns)
     {
         return;
@@ -2623,11 +2605,12 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
     u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
     // approximated levels: the source-column window (registers) and the wave's x-pass column buffer (LDS)
-    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> lw;
-    float* __restrict__ ldsCol = ldsBlock + (threadIdx.x >> 6) * LEVEL_LDS_WAVE;
+    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> Win;
+    Win lw;
+    float* ldsCol = ldsBlock + (threadIdx.x >> 6) * ldsWaveFloats; // the wave's x-pass column, then its ring
     if (MODE != LM_REAL)
     {
-        lw.init(A, lane, ha, wa, int(xr[0]));
+        lw.init(A, ldsCol + Win::RS * 64, lane, ha, wa, int(xr[0]));
     }
     const int lastLane = (h - 1) & 63; // lane holding row h-1 in the last register
 #define LV_LOAD(FAR, COL)                                                                                           \
@@ -2701,13 +2684,14 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
 
 // One launch per run of levels with equal (R, mode): blockIdx.y = level of the run, blockIdx.z = frame.
 template <int R, int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+__global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
     const LevelJob J = jobs[blockIdx.y];
-    __shared__ float ldsBlock[4 * LEVEL_LDS_WAVE];
-    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock);
+    constexpr int WF = MODE == LM_REAL ? 1 : LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::LDS_FLOATS;
+    __shared__ float ldsBlock[LEVEL_WAVES * WF];
+    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF);
 }
 
 // All levels whose specialisation fits 128 VGPRs (R <= 4 in any mode, real levels up to R = 8) in ONE launch:
@@ -2717,16 +2701,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 4
 // kernel trace).  In one grid the dispatcher starts the long chains first and back-fills slots with short ones as
 // they free up.  The specialisation is picked by a workgroup-uniform switch.
 #define ACF_LEVEL_KIND(R, M) ((R) * 8 + (M))
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
+__global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
     int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
 {
     const LevelJob J = jobs[blockIdx.z];
     const int64_t f = blockIdx.y;
-    __shared__ float ldsBlock[4 * LEVEL_LDS_WAVE];
-#define LV_CASE(RR, MM)                                                                                          \
-    case ACF_LEVEL_KIND(RR, MM):                                                                                  \
-        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock);   \
+    constexpr int WF = LevelWindow<4, LM_DD>::LDS_FLOATS; // the largest of the specialisations below (R <= 4)
+    static_assert(LevelWindow<3, LM_DD>::LDS_FLOATS <= WF && LevelWindow<4, LM_UU>::LDS_FLOATS <= WF && LevelWindow<2, LM_DD>::LDS_FLOATS <= WF &&
+                      LevelWindow<3, LM_UU>::LDS_FLOATS <= WF && LevelWindow<1, LM_DD>::LDS_FLOATS <= WF,
+        "ring size");
+    __shared__ float ldsBlock[LEVEL_WAVES * WF];
+#define LV_CASE(RR, MM)                                                                                              \
+    case ACF_LEVEL_KIND(RR, MM):                                                                                      \
+        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF);   \
         break;
 #define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_UU)
     switch (J.kind)
@@ -3901,13 +3889,14 @@ __device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ n
     return n;
 }
 
-// One sparse piece over trees [t0, t0 + T), T <= 64, for ONE WAVE's own survivors (lin/lout: the wave's private list
-// segments; no barrier, no atomics): TL = 2^tlShift >= T lanes per listed window, every lane one tree.
+// One sparse piece over trees [t0, t0 + T), T <= 64, for ONE WAVE's own survivors (list: the wave's private segment,
+// compacted in place — a round has read its 64 / TL entries before it writes at most as many at or below them; no
+// barrier, no atomics): TL = 2^tlShift >= T lanes per listed window, every lane one tree.
 // The score is accumulated in tree order by lane 15 of each 16-lane row (row_chain), rows of one window in sequence
 // (row_bcast:15 hands the prefix to the next row).  Lanes past T contribute +0.0f: h is a sum that starts at +0.0f, so
 // it is never -0.0f and h + 0.0f == h bit for bit.  `last`: survivors go to the hit list / tail queue (their
-// {tag, slot} to lout for stage E), else {tag, h} to lout.  Returns the number of entries written to lout.
-__device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx& X, const uint2* lin, int nIn, uint2* lout, const SparseNode& nd,
+// {tag, slot} to the list for stage E), else {tag, h}.  Returns the number of entries now in the list.
+__device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx& X, uint2* list, int nIn, const SparseNode& nd,
     int T, int tlShift, bool last, bool lastAll)
 {
     const int lane = threadIdx.x & 63;
@@ -3934,7 +3923,7 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
     {
         const int wi = base + g;
         const bool valid = wi < nIn;
-        const uint2 e = lin[valid ? wi : base];
+        const uint2 e = list[valid ? wi : base];
         const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
         const float* win = X.tileF + (cl * X.step) * X.rowsP + rl * X.step;
         const float f0 = win[o0];
@@ -3970,7 +3959,7 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
         const unsigned long long m = __ballot(emitLane);
         if (emitLane)
         {
-            lout[nOut + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, __float_as_uint(val));
+            list[nOut + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, __float_as_uint(val));
         }
         nOut += __popcll(m);
     }
@@ -3983,8 +3972,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     extern __shared__ float lds[];
     __shared__ int s_cnt[8];
     float* tileF = lds;
-    uint2* listA = reinterpret_cast<uint2*>(lds + a.g.tileFloats);
-    uint2* listB = listA + NW * 64;
+    uint2* listA = reinterpret_cast<uint2*>(lds + a.g.tileFloats); // NW segments of 64 entries, one per wave
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
@@ -4092,8 +4080,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     // barrier — the pieces are latency chains (two LDS round trips + a 16..64-step add chain per round) that now overlap
     // the other waves' stage A instead of idling the whole workgroup three times (measured with barriers: 5.9k cycles
     // for the pieces + 2.2k waiting for the slowest wave of stage A, per tile).
-    uint2* segA = listA + wv * 64;
-    uint2* segB = listB + wv * 64;
+    uint2* seg = listA + wv * 64;
     int nIn;
     {
         float val = h;
@@ -4104,13 +4091,11 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
         const unsigned long long m = __ballot(alive);
         if (alive)
         {
-            segA[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(c_l * a.g.TR + r_l), __float_as_uint(val));
+            seg[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(c_l * a.g.TR + r_l), __float_as_uint(val));
         }
         nIn = __popcll(m);
     }
     TILE_STAMP_REL(7);
-    uint2* lin = segA;
-    uint2* lout = segB;
     if (a.g.b[1] < tEnd)
     {
 #pragma unroll
@@ -4126,17 +4111,14 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 {
                     if (t0 == a.g.b[stage])
                     {
-                        nIn = tile_sparse_wave(a, X, lin, nIn, lout, pN[stage - 1], Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave(a, X, seg, nIn, pN[stage - 1], Tn, tlShift, last, lastAll);
                     }
                     else
                     {
                         const SparseNode nd = sparse_node(a.tileNodes, t0, Tn, tlShift);
-                        nIn = tile_sparse_wave(a, X, lin, nIn, lout, nd, Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave(a, X, seg, nIn, nd, Tn, tlShift, last, lastAll);
                     }
                 }
-                uint2* tmp = lin; // (every wave swaps at every piece, so the final segment is the same for all of them)
-                lin = lout;
-                lout = tmp;
             }
         }
     }
@@ -4167,7 +4149,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
         TILE_STAMP(4);
         return;
     }
-    const uint2* listE = lin - wv * 64; // wave 0's final segment; wave w's is 64 entries further
+    const uint2* listE = listA; // wave w's entries: 64 * w ...
     {
         const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
         for (int b0 = wv; b0 < nB; b0 += 4 * NW)
