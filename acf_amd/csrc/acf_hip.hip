@@ -2248,7 +2248,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
         bool colorDone = false;
         const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 8 == 0 &&
-            rs.h / 4 <= 512 && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
+            rs.h / 4 <= 8 * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
         if (fuseSm)
         {
             // k_smooth_vec: smoothing + the level's colour channels (+ the next real scale's image when it is an exact half
@@ -2290,8 +2290,8 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 halfDone[k + 1] = true;
             }
             prof(c, "k_smooth_vec");
-            const int nq = rs.h / 4, nt = ((nq + 63) / 64) * 64;
-            const size_t ldsB = size_t(4) * nq * sizeof(float);
+            const int nq = rs.h / 4, nt = cdiv(nq, SV_OWN) * 64; // a wave owns SV_OWN row quads and shadows SV_K of each neighbour
+            const size_t ldsB = size_t(2) * 8 * 2 * SV_K * 4 * sizeof(float);
             {
                 uint32_t fullMask = 0;
                 for (int z = 0; z < d; z++)

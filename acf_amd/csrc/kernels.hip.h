@@ -449,8 +449,15 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
 // Image smoothing with 16 bytes per lane and fused consumers (h % 4 == 0, w % 8 == 0).
 // A thread owns 4 consecutive image rows of one plane; the recursion along image-x
 // is k_smooth_tri1's.  Of the two y neighbours a row needs, three of four are the
-// thread's own registers; the first / last row's come from the adjacent threads
-// through two LDS floats per thread and one barrier per column.
+// thread's own registers; the first / last row's are the adjacent LANES' (two wave rotates).
+// Across waves the recursion would need one value per column and side — a workgroup barrier
+// per column, which is what bounded this kernel (1.45k cycles per column step, 3 TB/s).
+// out[x][y] depends on out[x-1][y-1 .. y+1] only, so a wave that also carries SV_K = 2 row
+// quads (8 rows) of each neighbouring wave computes its own 60 quads correctly for 8 columns
+// without hearing from anybody: the error of a stale halo moves inwards one ROW per column.
+// The halo lanes' state (the previous column's four outputs) is refreshed from the owning
+// waves once per 8-column chunk: one barrier per chunk instead of eight, 6 % redundant lanes.
+// Every value an owner lane stores is computed from the same operands in the same order.
 //
 // Because a thread's four rows are exactly one shrink-4 cell row and two
 // half-resolution row pairs, the consumers of the smoothed image are produced here,
@@ -477,14 +484,26 @@ struct SmoothVecArgs
     float* dump;      // >= 256 floats nobody reads
 };
 
+__device__ __forceinline__ float wave_rol1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false)); // lane l <- lane l+1 (63 <- 0)
+}
+__device__ __forceinline__ float wave_ror1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // lane l <- lane l-1 (0 <- 63)
+}
+
 #define SV_CH 8
+constexpr int SV_K = 2;              // halo quads per side: 4 * SV_K rows = SV_CH columns of independence
+constexpr int SV_OWN = 64 - 2 * SV_K; // quads a wave owns
 template <bool FULL, bool HALF, bool SHRINK>
 __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
-    const int q = threadIdx.x;
-    const bool valid = q < nq;
-    const int qc = valid ? q : nq - 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nWv = blockDim.x >> 6;
+    const int qraw = wv * SV_OWN + lane - SV_K;
+    const bool valid = lane >= SV_K && lane < 64 - SV_K && qraw < nq; // this lane owns quad qraw; the others are halo / idle
+    const int qc = min(max(qraw, 0), nq - 1);
     const int64_t f = blockIdx.z;
     const float* __restrict__ I = a.in + f * a.in_fs + int64_t(z) * a.in_ps + 4 * qc;
     float* __restrict__ Of = FULL ? a.sm + f * a.sm_fs + int64_t(z) * a.sm_ps + 4 * qc : nullptr;
@@ -492,8 +511,13 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     float* __restrict__ Oc = SHRINK ? a.chns + f * a.chns_fs + int64_t(z) * a.cells + qc : nullptr;
     const int hb = h >> 1, hc = h >> 2;
     const float p = a.p, nrm = 1.0f / ((p + 2) * (p + 2)), p1 = 1 + p;
-    const bool first = qc == 0, last = qc == nq - 1;
-    const int qm = max(qc - 1, 0), qp = min(qc + 1, nq - 1);
+    const bool first = qraw == 0, last = qraw == nq - 1;
+    // exchange slots: lds[parity][wave][side][SV_K quads][4]; side 0 = the wave's first owned quads, 1 = its last
+    const int ownSide = lane < 32 ? 0 : 1;
+    const int ownIdx = lane < 32 ? lane - SV_K : lane - (64 - 2 * SV_K);      // 0 .. SV_K-1 on the edge lanes
+    const bool ownEdge = (lane >= SV_K && lane < 2 * SV_K) || (lane >= 64 - 2 * SV_K && lane < 64 - SV_K);
+    const bool haloLo = lane < SV_K && wv > 0, haloHi = lane >= 64 - SV_K && wv + 1 < nWv;
+    const int srcWave = haloLo ? wv - 1 : wv + 1, srcSide = haloLo ? 1 : 0, srcIdx = haloLo ? lane : lane - (64 - SV_K);
     float prev[4] = { 0.f, 0.f, 0.f, 0.f }, acc[4] = { 0.f, 0.f, 0.f, 0.f };
     float4 c0[SV_CH], c1[SV_CH];
 #define SV_LOAD(BUF, I0)                                                                          \
@@ -505,7 +529,6 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
 #define SV_COL(I0, JJ, CUR, NXT)                                                                  \
     {                                                                                             \
         const int i_ = (I0) + (JJ);                                                               \
-        float* tl = lds + (i_ & 1) * 2 * nq;                                                      \
         const float im[4] = { CUR.x, CUR.y, CUR.z, CUR.w };                                       \
         const float ir[4] = { NXT.x, NXT.y, NXT.z, NXT.w };                                       \
         float T[4];                                                                               \
@@ -514,10 +537,8 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             const float il = (i_ == 0) ? im[k] : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507) */ \
             T[k] = nrm * (il + p * im[k] + ir[k]);                                                \
         }                                                                                         \
-        tl[qc] = T[0];                                                                            \
-        tl[nq + qc] = T[3];                                                                       \
-        __syncthreads();                                                                          \
-        const float up = tl[nq + qm], dn = tl[qp];                                                \
+        const float up = wave_ror1(T[3]); /* row 4q-1: the previous lane's last row */            \
+        const float dn = wave_rol1(T[0]); /* row 4q+4: the next lane's first row */               \
         float o[4];                                                                               \
         {                                                                                         \
             const float mid0 = up + p * T[0] + T[1], top0 = p1 * T[0] + T[1];                     \
@@ -529,7 +550,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         }                                                                                         \
         if (FULL)                                                                                 \
         {                                                                                         \
-            float* dst = valid ? Of + int64_t(i_) * h : a.dump + 4 * (q & 63);                    \
+            float* dst = valid ? Of + int64_t(i_) * h : a.dump + 4 * lane;                        \
             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);                \
         }                                                                                         \
         if (HALF && ((JJ) & 1))                                                                   \
@@ -537,7 +558,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             float2 hv;                                                                            \
             hv.x = ((prev[0] + o[0]) + (prev[1] + o[1])) * a.rkHalf;                              \
             hv.y = ((prev[2] + o[2]) + (prev[3] + o[3])) * a.rkHalf;                              \
-            float* dst = valid ? Oh + int64_t(i_ >> 1) * hb : a.dump + 2 * (q & 63);              \
+            float* dst = valid ? Oh + int64_t(i_ >> 1) * hb : a.dump + 2 * lane;                  \
             *reinterpret_cast<float2*>(dst) = hv;                                                 \
         }                                                                                         \
         if (SHRINK)                                                                               \
@@ -548,7 +569,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             }                                                                                     \
             if (((JJ) & 3) == 3)                                                                  \
             {                                                                                     \
-                float* dst = valid ? Oc + int64_t(i_ >> 2) * hc : a.dump + (q & 63);              \
+                float* dst = valid ? Oc + int64_t(i_ >> 2) * hc : a.dump + lane;                  \
                 *dst = (((acc[0] + acc[1]) + acc[2]) + acc[3]) * a.rq_y;                          \
             }                                                                                     \
         }                                                                                         \
@@ -557,9 +578,27 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             prev[k] = o[k];                                                                       \
         }                                                                                         \
     }
+    // after a chunk: the halo lanes take the state of the quads they shadow from the waves that own them.  Two slot sets
+    // alternate: a wave can only overwrite a set two chunks later, i.e. after the barrier that follows every wave's reads.
+#define SV_REFRESH(I0)                                                                            \
+    if (nWv > 1)                                                                                  \
+    {                                                                                             \
+        float* xs = lds + (((I0) >> 3) & 1) * (8 * 2 * SV_K * 4);                                 \
+        if (ownEdge)                                                                              \
+        {                                                                                         \
+            *reinterpret_cast<float4*>(xs + ((wv * 2 + ownSide) * SV_K + ownIdx) * 4) = make_float4(prev[0], prev[1], prev[2], prev[3]); \
+        }                                                                                         \
+        __syncthreads();                                                                          \
+        if (haloLo || haloHi)                                                                     \
+        {                                                                                         \
+            const float4 v_ = *reinterpret_cast<const float4*>(xs + ((srcWave * 2 + srcSide) * SV_K + srcIdx) * 4); \
+            prev[0] = v_.x, prev[1] = v_.y, prev[2] = v_.z, prev[3] = v_.w;                       \
+        }                                                                                         \
+    }
 #define SV_CHUNK(I0, A_, B_)                                                                      \
     SV_COL(I0, 0, A_[0], A_[1]) SV_COL(I0, 1, A_[1], A_[2]) SV_COL(I0, 2, A_[2], A_[3]) SV_COL(I0, 3, A_[3], A_[4]) \
-    SV_COL(I0, 4, A_[4], A_[5]) SV_COL(I0, 5, A_[5], A_[6]) SV_COL(I0, 6, A_[6], A_[7]) SV_COL(I0, 7, A_[7], B_[0])
+    SV_COL(I0, 4, A_[4], A_[5]) SV_COL(I0, 5, A_[5], A_[6]) SV_COL(I0, 6, A_[6], A_[7]) SV_COL(I0, 7, A_[7], B_[0]) \
+    SV_REFRESH(I0)
     SV_LOAD(c0, 0);
     int i = 0;
     for (; i + 2 * SV_CH <= w; i += 2 * SV_CH)
@@ -576,6 +615,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     }
 #undef SV_LOAD
 #undef SV_COL
+#undef SV_REFRESH
 #undef SV_CHUNK
 }
 
@@ -587,7 +627,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
 template <bool HALF>
 __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fullMask)
 {
-    extern __shared__ float lds[]; // [2 parities][lo, hi][nq]
+    extern __shared__ float lds[]; // [2 chunk parities][8 waves][2 sides][SV_K quads][4]: the waves' edge state
     const int z = a.plane0 + blockIdx.x;
     if ((fullMask >> z) & 1u)
     {
@@ -2188,14 +2228,6 @@ struct LevelJob
     int64_t in_ps, out_ps;        // plane strides
 };
 
-__device__ __forceinline__ float wave_rol1(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false)); // lane l <- lane l+1 (63 <- 0)
-}
-__device__ __forceinline__ float wave_ror1(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // lane l <- lane l-1 (0 <- 63)
-}
 
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x8* cptr8_t;
