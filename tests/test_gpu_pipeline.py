@@ -191,6 +191,14 @@ def test_sub_batch_streams(oracle, streams):
     (200, 264, dict(name="TINY", nTrees=96)),                       # sz != sz1 at scale 1 (image resampled first), generic next-scale resample
     (96, 132, dict(name="TINY", nTrees=96)),                        # w % 8 != 0 at some scale: falls back per scale
     (240, 320, dict(name="TINY", nTrees=96, nApprox=0, minDs_h=32, minDs_w=32)),  # every scale real
+    # k_smooth_vec's waves own 60 row quads each and shadow two of each neighbour: 60 quads = one wave exactly, 61 = a second
+    # wave with a single owned quad, 122 = three waves, 480 = eight (the most), 482 = the separate-kernel path for that scale;
+    # the tall planes also take k_level's R = 5..8 specialisations (their own launches, ring of 5 slots)
+    (240, 128, dict(name="TINY", nTrees=96)),
+    (244, 128, dict(name="TINY", nTrees=96)),
+    (488, 136, dict(name="TINY", nTrees=96)),
+    (1920, 128, dict(name="TINY", nTrees=96)),
+    (1928, 136, dict(name="TINY", nTrees=96)),
 ])
 def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
     """k_smooth_vec (smoothing + colour channels + exact-half next image, taps off) against the oracle, and the
