@@ -36,6 +36,7 @@ struct RealScale
     int descIndex = -1;
     ResampleTiling tiling;          // k_resample_tile plan of the image resample (rows == 0: not eligible)
     float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
+    int64_t uFloats = 0, moFloats = 0; // floats per frame of U and of M, O (room for the blocked layouts' padding)
 };
 
 } // namespace
@@ -438,17 +439,68 @@ int launchSmooth(acf_hip_ctx* c, const float* in, float* out, const SmoothJob* d
 }
 
 // fuse: the ChnsArgs of the level when convTriY may be followed at once by the channel cells (k_triy_chns); *fused reports it
-int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames, const ChnsArgs* fuse = nullptr,
-    bool* fused = nullptr)
+// floats per frame of U in the blocked layout: [ceil(w / 64)][ceil((h + 8) / 16)] blocks of 64 columns x 16 rows
+static int64_t uBlockedFloats(int h, int w)
+{
+    return int64_t(cdiv(w, 64)) * ((h + 8 + 15) / 16) * 1024;
+}
+
+// ... and of M / O: [ceil(w / 64)][ceil(h / 16)] blocks
+static int64_t moBlockedFloats(int h, int w)
+{
+    return int64_t(cdiv(w, 64)) * ((h + 15) / 16) * 1024;
+}
+
+struct TriPlan
+{
+    bool vecX, doFuse, blocked;
+};
+
+// Which forms convTri(M) + the channel cells of a level take: the vector x pass, the fused y pass + cells, and the blocked
+// layout of M, O and U (kernels.hip.h, k_tri_x5v) — possible when gradMag, the x pass and the fused y pass are all the vector
+// forms and the buffers have room for the blocks' padding (A/B: ACF_HIP_MOU_PLAIN).  gradVec: k_grad_mag_vec writes M and O.
+static TriPlan triPlan(const float* in, const float* U, int h, int w, int rad, int64_t fs, const ChnsArgs* fuse, int64_t uCapacity, int64_t moCapacity,
+    bool gradVec)
+{
+    static const bool noFuse = getenv("ACF_HIP_TRIY_UNFUSED") != nullptr; // A/B
+    static const bool plain = getenv("ACF_HIP_MOU_PLAIN") != nullptr;
+    TriPlan t;
+    t.vecX = rad == 5 && h % 4 == 0 && w >= 48 && fs % 4 == 0 && ((uintptr_t(in) | uintptr_t(U)) & 15) == 0;
+    t.doFuse = fuse && !noFuse && rad == 5 && h % 4 == 0 && h >= 48 && w % 4 == 0 && fs % 4 == 0 && (uintptr_t(U) & 15) == 0 && fuse->doNorm &&
+        !fuse->Mn && (fuse->colorDone || !fuse->colorEnabled) && (fuse->magEnabled || fuse->histEnabled) && fuse->nOrients <= 12 &&
+        ((uintptr_t(fuse->M) | uintptr_t(fuse->O)) & 15) == 0;
+    t.blocked = t.vecX && t.doFuse && gradVec && !plain && uCapacity >= uBlockedFloats(h, w) && moCapacity >= moBlockedFloats(h, w);
+    return t;
+}
+
+// uCapacity / moCapacity: floats per frame the U and the M, O buffers hold (>= fs); blocked: M and O ARE in the blocked layout
+// (the caller ran k_grad_mag_vec<true> after asking triPlan)
+int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames, ChnsArgs* fuse = nullptr,
+    bool* fused = nullptr, int64_t uCapacity = 0, int64_t moCapacity = 0, bool blocked = false)
 {
     if (rad > 15)
     {
         return fail(c, ACF_HIP_E_UNSUPPORTED, "convTri: radius > 15");
     }
-    prof(c, "k_tri_x");
-    if (rad == 5 && h % 4 == 0 && w >= 48 && fs % 4 == 0 && ((uintptr_t(in) | uintptr_t(U)) & 15) == 0)
+    const TriPlan tp = triPlan(in, U, h, w, rad, fs, fuse, uCapacity, moCapacity, blocked);
+    if (blocked && !tp.blocked)
     {
-        hipLaunchKernelGGL(k_tri_x5v, dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, fs);
+        return fail(c, ACF_HIP_E_INVALID, "convTri: blocked M/O without the kernels that read them");
+    }
+    const bool vecX = tp.vecX, doFuse = tp.doFuse, ut = blocked;
+    const int nyb = (h + 8 + 15) / 16, nybM = (h + 15) / 16;
+    const int64_t ufs = uBlockedFloats(h, w), mfs = moBlockedFloats(h, w);
+    prof(c, "k_tri_x");
+    if (vecX)
+    {
+        if (ut)
+        {
+            hipLaunchKernelGGL((k_tri_x5v<true>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, mfs, ufs, nyb, nybM);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_tri_x5v<false>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, fs, fs, 0, 0);
+        }
     }
     else
     {
@@ -459,19 +511,33 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     {
         *fused = false;
     }
-    static const bool noFuse = getenv("ACF_HIP_TRIY_UNFUSED") != nullptr; // A/B
-    if (fuse && !noFuse && rad == 5 && h % 4 == 0 && h >= 48 && w % 4 == 0 && fs % 4 == 0 && (uintptr_t(U) & 15) == 0 && fuse->doNorm && !fuse->Mn &&
-        (fuse->colorDone || !fuse->colorEnabled) && (fuse->magEnabled || fuse->histEnabled) && fuse->nOrients <= 12 &&
-        ((uintptr_t(fuse->M) | uintptr_t(fuse->O)) & 15) == 0)
+    if (doFuse)
     {
         prof(c, "k_triy_chns");
+        if (ut)
+        {
+            fuse->m_fs = mfs;
+            fuse->nybM = nybM;
+        }
+        const dim3 grid(cdiv(w, 256), 1, nFrames), block(256);
         if (fuse->nOrients <= 6)
         {
-            hipLaunchKernelGGL((k_triy_chns<6>), dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, *fuse);
+            if (ut)
+            {
+                hipLaunchKernelGGL((k_triy_chns<6, true>), grid, block, 0, c->stream, (const float*)U, *fuse, ufs, nyb);
+            }
+            else
+            {
+                hipLaunchKernelGGL((k_triy_chns<6, false>), grid, block, 0, c->stream, (const float*)U, *fuse, fs, 0);
+            }
+        }
+        else if (ut)
+        {
+            hipLaunchKernelGGL((k_triy_chns<12, true>), grid, block, 0, c->stream, (const float*)U, *fuse, ufs, nyb);
         }
         else
         {
-            hipLaunchKernelGGL((k_triy_chns<12>), dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, *fuse);
+            hipLaunchKernelGGL((k_triy_chns<12, false>), grid, block, 0, c->stream, (const float*)U, *fuse, fs, 0);
         }
         LAUNCHCHK(c, "k_triy_chns");
         *fused = true;
@@ -1503,13 +1569,15 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         }
         if (p.gradMagEnabled || p.gradHistEnabled)
         {
-            if ((rc = devAlloc(c, &rs.M, size_t(B) * np)) || (rc = devAlloc(c, &rs.O, size_t(B) * np)))
+            rs.moFloats = std::max<int64_t>(np, moBlockedFloats(rs.h, rs.w));
+            if ((rc = devAlloc(c, &rs.M, size_t(B) * size_t(rs.moFloats))) || (rc = devAlloc(c, &rs.O, size_t(B) * size_t(rs.moFloats))))
             {
                 return rc;
             }
             if (p.normRad)
             {
-                if ((rc = devAlloc(c, &rs.U, size_t(B) * np)) || (rc = devAlloc(c, &rs.S, size_t(B) * np)))
+                rs.uFloats = std::max<int64_t>(np, uBlockedFloats(rs.h, rs.w));
+                if ((rc = devAlloc(c, &rs.U, size_t(B) * size_t(rs.uFloats))) || (rc = devAlloc(c, &rs.S, size_t(B) * np)))
                 {
                     return rc;
                 }
@@ -2335,28 +2403,6 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             curH = rs.h;
             curW = rs.w;
         }
-        if (p.gradMagEnabled || p.gradHistEnabled)
-        {
-            prof(c, "k_grad_mag");
-            if (rs.h % 4 == 0 && np % 4 == 0)
-            {
-                // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
-                const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
-                const int blocks = int(std::min<int64_t>(256, (items + GMV_BLOCK - 1) / GMV_BLOCK));
-                hipLaunchKernelGGL(k_grad_mag_vec, dim3(blocks), dim3(GMV_BLOCK), 0, c->stream,
-                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF);
-            }
-            else
-            {
-                // enough workgroups to fill the chip twice over, each long enough to amortise its 80 KB table copy
-                const int rowBlocks = cdiv(rs.h, GM_ROWS), nStrips = cdiv(rs.w, GM_XT);
-                const int want = std::max(1, cdiv(1024, rowBlocks * nF));
-                const int spb = std::max(8, cdiv(nStrips, want));
-                hipLaunchKernelGGL(k_grad_mag_strip, dim3(rowBlocks, cdiv(nStrips, spb), nF), dim3(GM_ROWS), 0, c->stream,
-                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb);
-            }
-            LAUNCHCHK(c, "k_grad_mag");
-        }
         ChnsArgs a{};
         a.sm = rs.sm;
         a.M = rs.M;
@@ -2379,12 +2425,48 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         a.full = p.full;
         a.normConst = float(p.normConst);
         a.rq_y = shrinkGainY(shrink);
+        // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
+        const bool gradVec = rs.h % 4 == 0 && np % 4 == 0;
+        const bool wantTri = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
+        const bool blockedMO = wantTri &&
+            triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, (shrink == 4 && !c->taps) ? &a : nullptr, rs.uFloats, rs.moFloats, gradVec).blocked;
+        if (p.gradMagEnabled || p.gradHistEnabled)
+        {
+            prof(c, "k_grad_mag");
+            if (rs.h % 4 == 0 && np % 4 == 0)
+            {
+                // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
+                const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
+                const int blocks = int(std::min<int64_t>(256, (items + GMV_BLOCK - 1) / GMV_BLOCK));
+                if (blockedMO)
+                {
+                    hipLaunchKernelGGL((k_grad_mag_vec<true>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
+                        rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, moBlockedFloats(rs.h, rs.w), nF, (rs.h + 15) / 16);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((k_grad_mag_vec<false>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
+                        rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF, 0);
+                }
+            }
+            else
+            {
+                // enough workgroups to fill the chip twice over, each long enough to amortise its 80 KB table copy
+                const int rowBlocks = cdiv(rs.h, GM_ROWS), nStrips = cdiv(rs.w, GM_XT);
+                const int want = std::max(1, cdiv(1024, rowBlocks * nF));
+                const int spb = std::max(8, cdiv(nStrips, want));
+                hipLaunchKernelGGL(k_grad_mag_strip, dim3(rowBlocks, cdiv(nStrips, spb), nF), dim3(GM_ROWS), 0, c->stream,
+                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb);
+            }
+            LAUNCHCHK(c, "k_grad_mag");
+        }
         bool cellsDone = false;
         if ((p.gradMagEnabled || p.gradHistEnabled) && p.normRad)
         {
             // convTri(M, normRad): x running sums, then the y pass — fused with the channel cells when the level allows it
             // (S then never reaches HBM), else S is written for k_chns
-            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, (shrink == 4 && !c->taps) ? &a : nullptr, &cellsDone)))
+            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, (shrink == 4 && !c->taps) ? &a : nullptr, &cellsDone, rs.uFloats, rs.moFloats,
+                     blockedMO)))
             {
                 return rc;
             }

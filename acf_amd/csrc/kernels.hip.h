@@ -814,8 +814,11 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
 // GMV_BLOCK threads share one copy of the 80 KB table: one workgroup per CU, 16 waves (256 threads = 2 workgroups of 4
 // waves per CU left the loads of a wave exposed).
 #define GMV_BLOCK 1024
+// BL: M and O leave in 64-column x 16-row blocks ([x >> 6][y >> 4][x & 63][y & 15], 4 KB each; nyb = ceil(h / 16), out_fs the
+// blocked frame stride): the layout k_tri_x5v<true> and k_triy_chns<.., true> read, see k_tri_x5v.
+template <bool BL>
 __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
-    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames)
+    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames, int nyb)
 {
     __shared__ float acosL[GM_ACOS_N];
     for (int i = threadIdx.x; i < GM_ACOS_N; i += GMV_BLOCK)
@@ -889,7 +892,9 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
             }
             if (x < w)
             {
-                const int64_t o = int64_t(f) * out_fs + int64_t(x) * h + y0;
+                const int64_t o = int64_t(f) * out_fs +
+                    (BL ? int64_t((((uint32_t(x) >> 6) * uint32_t(nyb) + (uint32_t(y0) >> 4)) << 10) + ((uint32_t(x) & 63u) << 4) + (uint32_t(y0) & 15u))
+                        : int64_t(x) * h + y0);
                 *reinterpret_cast<float4*>(M + o) = make_float4(mo[0], mo[1], mo[2], mo[3]);
                 *reinterpret_cast<float4*>(O + o) = make_float4(oo[0], oo[1], oo[2], oo[3]);
             }
@@ -988,7 +993,17 @@ __global__ void __launch_bounds__(256) k_tri_x(const float* __restrict__ in, flo
 // float4 exactly once (step i needs columns i-7, i-1, i+5: with the loop unrolled 16x every ring index is
 // static), and the 16 columns of the next iteration are requested one iteration ahead into a second register
 // set that swaps roles with the first.  Per chain the arithmetic is k_tri_x's: T += Il + Ir - 2*Im; U += nrm*T.
-__global__ void __launch_bounds__(64) k_tri_x5v(const float* __restrict__ in, float* __restrict__ Uo, int h, int w, int64_t fs)
+//
+// UT: U leaves in the BLOCKED layout k_triy_chns<.., true> reads: per frame [x >> 6][(y + 8) >> 4][x & 63][(y + 8) & 15] — a
+// 64-column x 16-row block is 4 KB contiguous, and the blocks are shifted by 8 rows because the y pass takes rows J+8 .. J+23
+// per step.  There a wave's step is then ONE contiguous 4 KB read (lane = column: 64 bytes each) instead of 64-byte halves of
+// 128-byte lines taken in two consecutive steps through an L1 that holds a sixth of the CU's working set, and the rows arrive
+// in the lanes that own the columns: no transposition through LDS.  Here a column step stores 64-byte pieces 4 KB apart; the
+// next column's pieces complete the lines in L2.  ufs: frame stride of U in floats, nyb = (h + 8 + 15) / 16.
+// With UT the INPUT is blocked too (unshifted: [x >> 6][y >> 4][x & 63][y & 15], frame stride fs, nybM = ceil(h / 16)), as
+// k_grad_mag_vec<true> writes it: k_triy_chns's cells then take a block's M and O in one step as well.
+template <bool UT>
+__global__ void __launch_bounds__(64) k_tri_x5v(const float* __restrict__ in, float* __restrict__ Uo, int h, int w, int64_t fs, int64_t ufs, int nyb, int nybM)
 {
     const int h4 = h >> 2;
     const int q = blockIdx.x * 64 + threadIdx.x;
@@ -996,12 +1011,16 @@ __global__ void __launch_bounds__(64) k_tri_x5v(const float* __restrict__ in, fl
     {
         return;
     }
-    const float* __restrict__ I = in + int64_t(blockIdx.z) * fs + 4 * q;
-    float* __restrict__ Uc = Uo + int64_t(blockIdx.z) * fs + 4 * q;
+    const float* __restrict__ I = UT ? in + int64_t(blockIdx.z) * fs + ((uint32_t(4 * q) >> 4) << 10) + (uint32_t(4 * q) & 15u)
+                                     : in + int64_t(blockIdx.z) * fs + 4 * q;
+    float* __restrict__ Uc = UT ? Uo + int64_t(blockIdx.z) * ufs + ((uint32_t(4 * q + 8) >> 4) << 10) + (uint32_t(4 * q + 8) & 15u)
+                                : Uo + int64_t(blockIdx.z) * fs + 4 * q;
     constexpr int r = 6;
     const float nrm = 1.0f / (r * r * r * r);
-#define TXV_LD(col) (*reinterpret_cast<const float4*>(I + int64_t(col) * h))
-#define TXV_ST(col, v) (*reinterpret_cast<float4*>(Uc + int64_t(col) * h) = (v))
+#define TXV_LD(col)                                                                                                                 \
+    (*reinterpret_cast<const float4*>(UT ? I + (((uint32_t(col) >> 6) * uint32_t(nybM)) << 10) + ((uint32_t(col) & 63u) << 4) : I + int64_t(col) * h))
+#define TXV_ST(col, v)                                                                                                              \
+    (*reinterpret_cast<float4*>(UT ? Uc + (((uint32_t(col) >> 6) * uint32_t(nyb)) << 10) + ((uint32_t(col) & 63u) << 4) : Uc + int64_t(col) * h) = (v))
     float T[4], U[4];
     {
         const float4 v0 = TXV_LD(0);
@@ -1497,6 +1516,7 @@ struct ChnsArgs
     int32_t colorDone; // the colour channels were already written by k_smooth_vec: skip them, keep their slots
     float normConst, rq; // rq = (1/S)/(1+1e-6) then /S in the y pass (imResampleMex.cpp:145-157,316)
     float rq_y;
+    int32_t nybM;      // blocked M / O (k_triy_chns<.., true>): 16-row blocks per column block, ceil(h / 16); m_fs is then the blocked frame stride
 };
 
 template <int S>
@@ -1531,10 +1551,12 @@ __device__ __forceinline__ void chns_load_vec(const float* __restrict__ p, float
 // (convConst.cpp:347-442; gradientMex.cpp:254-275, 278-372; imResampleMex.cpp:210-215, 312-317).
 // Needs shrink 4, h % 4 == 0, h >= 48, normalisation on, the colour channels already written (or disabled), no Mnorm tap.
 // ------------------------------------------------------------------------
-template <int MAXO>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca)
+// UT: U comes in k_tri_x5v<true>'s blocked layout (ufs, nyb as there): a step's rows are four 16-byte loads per lane from one
+// contiguous 4 KB block, already in the lane that owns the column.
+template <int MAXO, bool UT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca, int64_t ufs, int nyb)
 {
-    __shared__ float ty_lds[4][2][64 * TY_PITCH];
+    __shared__ float ty_lds[4][UT ? 1 : 2][64 * TY_PITCH];
     const int h = ca.h, w = ca.w;
     const int64_t fs = ca.m_fs;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1544,21 +1566,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         return;
     }
     float* inb = ty_lds[wv][0];
-    float* outb = ty_lds[wv][1];
+    float* outb = ty_lds[wv][UT ? 0 : 1];
     const int x = min(x0 + lane, w - 1); // lanes past the last column duplicate it and never store
-    const float* __restrict__ U0 = Ui + int64_t(blockIdx.z) * fs;
-    const float* __restrict__ col = U0 + int64_t(x) * h;
+    const float* __restrict__ U0 = Ui + int64_t(blockIdx.z) * (UT ? ufs : fs);
+    // row j of this lane's column
+    const float* __restrict__ colP = U0 + int64_t(x) * h;                                                                    // plain
+    const float* __restrict__ colT = U0 + (((uint32_t(x) >> 6) * uint32_t(nyb)) << 10) + ((uint32_t(x) & 63u) << 4);         // blocked
+#define TY_U(j) (UT ? colT[((uint32_t((j) + 8) >> 4) << 10) + (uint32_t((j) + 8) & 15u)] : colP[(j)])
     // cooperative mapping: instruction q moves columns 4q + (lane >> 4), rows base + (lane & 15)
     const int cl = lane >> 4, rl = lane & 15;
     constexpr int r = 6, r0 = 5, r1 = 7, h0 = 7;
     const int r2 = 2 * h - r, h1 = h - r + 1;
     float t, u;
     // rows 0..15: the reference's head (reflected taps), straight from memory
-    u = t = col[0];
+    u = t = TY_U(0);
 #pragma unroll
     for (int q = 1; q < r; q++)
     {
-        t += col[q];
+        t += TY_U(q);
         u += t;
     }
     u = 2 * u - t;
@@ -1568,9 +1593,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int j = 1; j < 16; j++)
     {
-        const float a = (j < h0) ? col[r - j] : col[j - r1];
-        const float b = col[r0 + j];
-        t += a + b - 2 * col[j - 1];
+        const float a = (j < h0) ? TY_U(r - j) : TY_U(j - r1);
+        const float b = TY_U(r0 + j);
+        t += a + b - 2 * TY_U(j - 1);
         u += t;
         o[j] = u;
     }
@@ -1590,12 +1615,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // them, every step paid a full memory round trip).  M: one register set, re-requested as soon as the normalised
     // magnitudes of the current block exist; O: two sets that swap roles every step (it is live until the histogram).
     float4 mq[4], oqA[4], oqB[4];
+    // float offset of (column X, row Y) in a frame of M / O: plain [w][h], or 64 x 16 blocks (UT)
+#define TY_MO_OFF(X, Y)                                                                                                       \
+    (UT ? (((uint32_t(X) >> 6) * uint32_t(ca.nybM) + (uint32_t(Y) >> 4)) << 10) + ((uint32_t(X) & 63u) << 4) + (uint32_t(Y) & 15u) \
+        : uint32_t(X) * uint32_t(h) + uint32_t(Y))
 #define TY_M_FETCH(J0)                                                                                      \
     {                                                                                                       \
         const int yq_ = min((J0) + 4 * ycL, h - 4);                                                         \
         _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
         {                                                                                                   \
-            mq[xx] = *reinterpret_cast<const float4*>(Mf + (uint32_t(min(x0 + 4 * xcL + xx, w - 1)) * uint32_t(h) + uint32_t(yq_))); \
+            mq[xx] = *reinterpret_cast<const float4*>(Mf + TY_MO_OFF(min(x0 + 4 * xcL + xx, w - 1), yq_));  \
         }                                                                                                   \
     }
 #define TY_O_FETCH(oq, J0)                                                                                  \
@@ -1603,7 +1632,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int yq_ = min((J0) + 4 * ycL, h - 4);                                                         \
         _Pragma("unroll") for (int xx = 0; xx < 4; xx++)                                                    \
         {                                                                                                   \
-            oq[xx] = *reinterpret_cast<const float4*>(Of + (uint32_t(min(x0 + 4 * xcL + xx, w - 1)) * uint32_t(h) + uint32_t(yq_))); \
+            oq[xx] = *reinterpret_cast<const float4*>(Of + TY_MO_OFF(min(x0 + 4 * xcL + xx, w - 1), yq_));  \
         }                                                                                                   \
     }
 #define TY_CELLS(oq, J0, NROWS, JN)                                                                                 \
@@ -1680,14 +1709,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }                                                                                               \
         }                                                                                                   \
     }
-    // request rows R0..R0+15 of the wave's 64 columns (16 coalesced loads) into g[]
-#define TY_FETCH(G, R0)                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 16; q++)                                                          \
+    // request rows R0..R0+15 of the wave's 64 columns: plain layout — 16 coalesced loads into G[], handed to the owning lanes
+    // through LDS by TY_TAKE; blocked layout (R0 = J + 8: exactly one block row) — four 16-byte loads per lane, already home
+#define TY_FETCH(G, G4, R0)                                                                                 \
+    if (UT)                                                                                                 \
     {                                                                                                       \
-        G[q] = U0[uint32_t(min(x0 + 4 * q + cl, w - 1)) * uint32_t(h) + uint32_t((R0) + rl)];                                  \
+        const float* p_ = colT + ((uint32_t((R0) + 8) >> 4) << 10);                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            G4[q] = *reinterpret_cast<const float4*>(p_ + 4 * q);                                           \
+        }                                                                                                   \
+    }                                                                                                       \
+    else                                                                                                    \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 16; q++)                                                      \
+        {                                                                                                   \
+            G[q] = U0[uint32_t(min(x0 + 4 * q + cl, w - 1)) * uint32_t(h) + uint32_t((R0) + rl)];           \
+        }                                                                                                   \
     }
-    // hand g[] to the owning lanes: N[q] = rows R0+4q .. R0+4q+3 of this lane's column
-#define TY_TAKE(G, N)                                                                                       \
+    // N[q] = rows R0+4q .. R0+4q+3 of this lane's column
+#define TY_TAKE(G, G4, N)                                                                                   \
+    if (UT)                                                                                                 \
+    {                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
+        {                                                                                                   \
+            N[q] = G4[q];                                                                                   \
+        }                                                                                                   \
+    }                                                                                                       \
+    else                                                                                                    \
     {                                                                                                       \
         _Pragma("unroll") for (int q = 0; q < 16; q++)                                                      \
         {                                                                                                   \
@@ -1707,10 +1756,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
     float ring[16];
     float g[16];
+    float4 g4[4];
     float4 nx[4];
     {
-        TY_FETCH(g, 8);
-        TY_TAKE(g, nx); // rows 8..23
+        TY_FETCH(g, g4, 8);
+        TY_TAKE(g, g4, nx); // rows 8..23
         ring[8] = nx[0].x, ring[9] = nx[0].y, ring[10] = nx[0].z, ring[11] = nx[0].w;
         ring[12] = nx[1].x, ring[13] = nx[1].y, ring[14] = nx[1].z, ring[15] = nx[1].w;
         ring[0] = nx[2].x, ring[1] = nx[2].y, ring[2] = nx[2].z, ring[3] = nx[2].w;
@@ -1720,8 +1770,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int lastFast = h - 24; // J + 23 <= h - 1 and every j <= J + 15 < h1
     if (J <= lastFast)
     {
-        TY_FETCH(g, J + 8);
-        TY_TAKE(g, nx); // rows J+8 .. J+23
+        TY_FETCH(g, g4, J + 8);
+        TY_TAKE(g, g4, nx); // rows J+8 .. J+23
     }
 #define TY_ITER(CO, NO)                                                                             \
     {                                                                                                       \
@@ -1729,7 +1779,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         TY_O_FETCH(NO, J + 16); /* the NEXT block's orientations */                                         \
         if (more)                                                                                           \
         {                                                                                                   \
-            TY_FETCH(g, J + 24); /* next iteration's rows, in flight during this iteration's recurrence */  \
+            TY_FETCH(g, g4, J + 24); /* next iteration's rows, in flight during this iteration's recurrence */  \
         }                                                                                                   \
         _Pragma("unroll") for (int q = 0; q < 4; q++)                                                       \
         {                                                                                                   \
@@ -1755,7 +1805,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         TY_CELLS(CO, J, 16, J + 16);                                                                         \
         if (more)                                                                                           \
         {                                                                                                   \
-            TY_TAKE(g, nx);                                                                                 \
+            TY_TAKE(g, g4, nx);                                                                                 \
         }                                                                                                   \
         J += 16;                                                                                            \
     }
@@ -1797,15 +1847,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int j = J + jj;
             if (jj < nr) // wave-uniform
             {
-                const float a_ = col[j - r1];
-                const float b_ = (j < h1) ? col[r0 + j] : col[r2 - j];
-                t += a_ + b_ - 2 * col[j - 1];
+                const float a_ = TY_U(j - r1);
+                const float b_ = (j < h1) ? TY_U(r0 + j) : TY_U(r2 - j);
+                t += a_ + b_ - 2 * TY_U(j - 1);
                 u += t;
                 o[jj] = u;
             }
         }
         TY_CELLS(oqA, J, nr, J + 16);
     }
+#undef TY_U
+#undef TY_MO_OFF
 #undef TY_M_FETCH
 #undef TY_O_FETCH
 #undef TY_CELLS
