@@ -353,6 +353,16 @@ def main():
                 roof["solo"] = {"note": "same kernel, one context alone on the GPU, 3 launches after the timed region",
                                 "kernel_avg_ms": s_ms, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
                                 "kernels_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])}}
+                # every kernel's HBM rate alone: committed PMC traffic of all its launches in a step (profiles/r02_pmc_traffic.json,
+                # measured with this batch size) over the time of those launches here; GB/s (fraction of the 8 TB/s peak)
+                rates = {}
+                for k, v in solo.items():
+                    tb = pmc_traffic(k, B)
+                    if tb and v[0] > 0:
+                        r = tb * 3 / (v[0] * 1e-3) / 1e9  # 3 solo steps
+                        rates[k] = [round(r, 1), round(r / HBM_PEAK_GBS, 3)]
+                if rates:
+                    roof["solo"]["kernels_hbm_GBps_frac"] = dict(sorted(rates.items(), key=lambda kv: -solo[kv[0]][0]))
         else:
             path = b_frame * fps / world / 1e9
             roof.update({"path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
