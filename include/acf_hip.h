@@ -182,7 +182,10 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * acf_hip_read_tap, the role of setLogger's MatLoggerType tap,
  * chnsCompute.cpp:241-250,285-300; costs one extra full-resolution write; set
  * before acf_hip_plan), "profile" (0/1: record HIP events around every kernel,
- * read with acf_hip_profile_get). */
+ * read with acf_hip_profile_get), "scale_streams" (1, default: the real scales of a
+ * batch run concurrently on streams of the context — lowest latency and best
+ * throughput for ONE context; 0: everything on the context's stream in order, for
+ * applications that run several contexts side by side on one GPU). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.

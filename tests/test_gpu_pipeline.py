@@ -209,6 +209,7 @@ def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
     frame = synth.make_frame(23, H, W, "luv")
     det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
     det.set_option("fused_smooth", fused_smooth)
+    det.set_option("scale_streams", fused_smooth)  # real scales on their own streams / all on the context's stream
     det.run(torch.from_numpy(np.stack([frame, frame])).cuda())
     plan = oracle.Plan(model, H, W, 3)
     pyr, _, _ = oracle.chns_pyramid(plan, frame)
