@@ -77,6 +77,14 @@ HipDetector::~HipDetector()
     }
 }
 
+void HipDetector::setDoParallel(bool flag)
+{
+    if (m_ctx && m_api)
+    {
+        check(m_api->acf_hip_set_option(m_ctx, "scale_streams", flag ? 1 : 0), "acf_hip_set_option");
+    }
+}
+
 void HipDetector::check(int rc, const char* what) const
 {
     if (rc != ACF_HIP_OK)

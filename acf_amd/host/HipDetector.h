@@ -219,7 +219,9 @@ public:
     bool getIsLuv() const { return m_isLuv; }
     void setIsTranspose(bool flag) { m_isTranspose = flag; }
     bool getIsTranspose() const { return m_isTranspose; }
-    void setDoParallel(bool) {} // scales/frames always run concurrently on the device
+    // Detector::setDoParallel (ACF.h:410: cv::parallel_for_ over scales): the real scales of a batch on streams of the context
+    // beside each other (default, lowest latency) or all on one stream (several detectors side by side on one GPU)
+    void setDoParallel(bool flag);
     void setIsRowMajor(bool flag) { m_isRowMajor = flag; } // ACF.h:588-595: stored for callers that orient the window size by it
     bool getIsRowMajor() const { return m_isRowMajor; }
     Size getWindowSize() const { return opts.modelDs; }
