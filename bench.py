@@ -148,6 +148,52 @@ def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under torch.distributed.run
+    (one process per GPU, LOCAL_RANK -> device, rendezvous on 127.0.0.1 at a free port).  Rank 0's JSON line is this
+    process's output; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, world):
+    """The N-rank protocol of the bench with the detector work left out: rendezvous, barrier-bracketed clock, MAX over
+    ranks, per-rank figures summed into one vector, one JSON line from rank 0.  gloo when no GPU is visible."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = torch.zeros(world, dtype=torch.float64)
+    per_rank[rank] = float(rank + 1)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "launch plumbing only (no detector work)", "value": None, "dry_launch": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "seconds_max_over_ranks": float(dt.item()),
+                          "config": {"rccl_ranks": world, "per_rank": [float(x) for x in per_rank]}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +212,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
+    ap.add_argument("--dry-launch", action="store_true", help="launch plumbing only (spawn, rendezvous, max-over-ranks clock, per-rank gather) "
+                    "with no detector work: runs without a GPU over gloo (tests/test_bench_launch.py); never a measurement")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world == 0 and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run, rendezvous on 127.0.0.1
+        sys.exit(spawn_ranks(args.gpus))
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if args.dry_launch:
+        return dry_launch(args, world)
 
     import torch
     import torch.distributed as dist
@@ -174,9 +235,11 @@ def main():
     from acf_amd.detector import DetectorPool
     from acf_amd.dist import RecordGather
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d needs GPU %d but %d device(s) are visible (the hot path has no CPU form)"
+                         % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
