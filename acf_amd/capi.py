@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libacf_hip.so")
 
 OK = 0
+E_INVALID, E_UNSUPPORTED, E_NOMODEL, E_NOPLAN, E_HIP, E_NODEVICE, E_CAPACITY = 1, 2, 3, 4, 5, 6, 7  # include/acf_hip.h:44-51
+NMS_CAP = 2048  # ACF_HIP_NMS_CAP
 CS_GRAY, CS_RGB, CS_LUV, CS_HSV, CS_ORIG = 0, 1, 2, 3, 4
 TAP_IMAGE, TAP_SMOOTHED, TAP_M, TAP_O, TAP_S, TAP_MNORM, TAP_CHNS, TAP_LDCF = range(8)
 
@@ -198,6 +200,7 @@ def load():
         "acf_hip_op_nms": ([ctx, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(NmsParams), C.POINTER(C.c_int32), C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_detections": ([ctx, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_get_hits": ([ctx, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
+        "acf_hip_get_raw_detections": ([ctx, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_export_detections": ([ctx, C.c_void_p, C.c_int], C.c_int),
         "acf_hip_synchronize": ([ctx], C.c_int),
         "acf_hip_profile_get": ([ctx, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int], C.c_int),
@@ -226,7 +229,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_create", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_get_lambdas", "acf_hip_pyramid",
-    "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits",
+    "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits", "acf_hip_get_raw_detections",
     "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_tap",

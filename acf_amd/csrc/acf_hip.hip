@@ -1324,14 +1324,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     // k_cascade_tail3 only takes queue overflow now: keep its LDS small (footprint slabs only, node table from
                     // L2) so that its blocks — which leave at once in the normal case — never wait for a whole CU's LDS while
                     // other streams' kernels are resident (measured: up to 2.7 ms of queueing per launch with 156 KB blocks)
-                    for (int cand : std::initializer_list<int>{})
-                    {
-                        if (!cs.tailNodesLds && cand <= tw && nodeFloats > 0 && (nodeFloats + int64_t(cand) * tailSlab) * 4 <= int64_t(159) * 1024)
-                        {
-                            cs.tailNodesLds = int(nodeFloats);
-                            cs.tailWaves = cand;
-                        }
-                    }
+                    (void)nodeFloats;
                 }
                 if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
                 {
@@ -1349,14 +1342,22 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                             nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
                         }
                         // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
-                        // images), at most 1 GB for the batch; whatever is beyond goes to k_cascade_tail3
+                        // images), at most 256 MB for the batch (the rows are touched per survivor: ~1k of them per 1080p
+                        // frame); whatever is beyond goes to k_cascade_tail3, and so does everything if the buffer cannot be had
                         int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
-                        cap = std::min(cap, std::max<int64_t>((int64_t(1) << 30) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
+                        cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
                         cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
                         cs.codeCap = int(cap);
-                        if ((rc = devAlloc(c, &cs.d_tailCodes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch))))
+                        void* codes = nullptr;
+                        if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch)) == hipSuccess)
                         {
-                            return rc;
+                            c->allocs.push_back(codes);
+                            cs.d_tailCodes = static_cast<uint8_t*>(codes);
+                        }
+                        else
+                        {
+                            (void)hipGetLastError();
+                            cs.codeCap = 0;
                         }
                     }
                 }
@@ -1484,6 +1485,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
+            k->scaleStreams = c->scaleStreams;
+            k->nmsOn = c->nmsOn; // (acf_hip_set_nms before the plan, or a re-plan: the new children run what the parent reports)
+            k->nms = c->nms;
             if ((rc = acf_hip_set_model(k, &c->p)) || (rc = acf_hip_plan(k, H, W, d_in, c->kidChunk, max_hits)))
             {
                 return kidFail(c, k, rc);
@@ -3648,18 +3652,13 @@ int acf_hip_op_nms(acf_hip_ctx* c, const int32_t* boxes, const double* scores, i
         return fail(c, ACF_HIP_E_CAPACITY, "op_nms: more than ACF_HIP_NMS_CAP boxes");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    int32_t *d_box = nullptr, *d_keep = nullptr, *d_n = nullptr;
-    double* d_sc = nullptr;
-    HIPCHK(c, hipMalloc(&d_box, size_t(n) * 16));
-    HIPCHK(c, hipMalloc(&d_sc, size_t(n) * 8));
-    HIPCHK(c, hipMalloc(&d_keep, size_t(NMS_CAP) * 4));
-    HIPCHK(c, hipMalloc(&d_n, 4));
-    auto cleanup = [&]() {
-        (void)hipFree(d_box);
-        (void)hipFree(d_sc);
-        (void)hipFree(d_keep);
-        (void)hipFree(d_n);
-    };
+    // one allocation, freed on every exit: boxes [n][4] int32 | scores [n] f64 | keep [NMS_CAP] int32 | count
+    const size_t offSc = (size_t(n) * 16 + 7) / 8 * 8, offKeep = offSc + size_t(n) * 8, offN = offKeep + size_t(NMS_CAP) * 4;
+    char* d_all = nullptr;
+    HIPCHK(c, hipMalloc(&d_all, offN + 4));
+    int32_t *d_box = reinterpret_cast<int32_t*>(d_all), *d_keep = reinterpret_cast<int32_t*>(d_all + offKeep), *d_n = reinterpret_cast<int32_t*>(d_all + offN);
+    double* d_sc = reinterpret_cast<double*>(d_all + offSc);
+    auto cleanup = [&]() { (void)hipFree(d_all); };
     NmsArgs a{};
     a.boxes = d_box;
     a.scores = d_sc;
@@ -3724,7 +3723,7 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
     const int n = c->h_counts[frame];
     if (n < 0)
     {
-        return fail(c, ACF_HIP_E_CAPACITY, "more than ACF_HIP_NMS_CAP detections into the device NMS: raise cascThr or take the raw list (acf_hip_set_nms(NULL))");
+        return fail(c, ACF_HIP_E_CAPACITY, "more than ACF_HIP_NMS_CAP detections into the device NMS: take the raw list (acf_hip_get_raw_detections) and suppress it on the host");
     }
     if (count)
     {
@@ -3734,6 +3733,67 @@ int acf_hip_get_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, in
     if (m > 0 && out)
     {
         HIPCHK(c, hipMemcpy(out, (nmsActive(c) ? c->d_nmsDets : c->cs.d_dets) + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
+    }
+    if (n > c->maxHits)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "more hits than max_hits; re-plan with a larger capacity");
+    }
+    return ACF_HIP_OK;
+}
+
+// raw (pre-NMS) count of one frame of the last batch
+static int rawCount(acf_hip_ctx* c, int frame, int* n)
+{
+    if (!nmsActive(c))
+    {
+        *n = c->h_counts[frame];
+        return ACF_HIP_OK;
+    }
+    int32_t v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->cs.d_counts + frame, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n = v;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_raw_detections(acf_hip_ctx* c, int frame, acf_hip_detection* out, int cap, int* count)
+{
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_get_raw_detections(k, frame % c->kidChunk, out, cap, count);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    int rc = fetchCounts(c);
+    if (rc)
+    {
+        return rc;
+    }
+    if (frame < 0 || frame >= c->lastBatch)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "get_raw_detections: frame index");
+    }
+    int n = 0;
+    if ((rc = rawCount(c, frame, &n)))
+    {
+        return rc;
+    }
+    if (count)
+    {
+        *count = n;
+    }
+    const int m = std::min(std::min(n, c->maxHits), cap);
+    if (m > 0 && out)
+    {
+        HIPCHK(c, hipMemcpy(out, c->cs.d_dets + size_t(frame) * c->maxHits, sizeof(acf_hip_detection) * m, hipMemcpyDeviceToHost));
     }
     if (n > c->maxHits)
     {
@@ -3768,6 +3828,45 @@ int acf_hip_get_hits(acf_hip_ctx* c, int frame, acf_hip_hit* out, int cap, int* 
         return fail(c, ACF_HIP_E_INVALID, "get_hits: frame index");
     }
     const int n = c->h_counts[frame];
+    if (nmsActive(c))
+    {
+        // hit i belongs to detection i of acf_hip_get_detections: the survivors' entries of the raw list, through k_nms's keep indices
+        if (n < 0)
+        {
+            return fail(c, ACF_HIP_E_CAPACITY, "more than ACF_HIP_NMS_CAP detections into the device NMS: take the raw list (acf_hip_get_raw_detections)");
+        }
+        if (n > c->maxHits)
+        {
+            return fail(c, ACF_HIP_E_CAPACITY, "more hits than max_hits; re-plan with a larger capacity");
+        }
+        if (count)
+        {
+            *count = n;
+        }
+        const int m = std::min(n, cap);
+        if (m > 0 && out)
+        {
+            int nRaw = 0;
+            if ((rc = rawCount(c, frame, &nRaw)))
+            {
+                return rc;
+            }
+            nRaw = std::min(nRaw, c->maxHits);
+            std::vector<int32_t> keep(static_cast<size_t>(m));
+            std::vector<acf_hip_hit> raw(static_cast<size_t>(std::max(nRaw, 1)));
+            HIPCHK(c, hipMemcpy(keep.data(), c->d_nmsKeep + size_t(frame) * NMS_CAP, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(raw.data(), c->cs.d_sorted + size_t(frame) * c->maxHits, sizeof(acf_hip_hit) * nRaw, hipMemcpyDeviceToHost));
+            for (int i = 0; i < m; i++)
+            {
+                if (keep[size_t(i)] < 0 || keep[size_t(i)] >= nRaw)
+                {
+                    return fail(c, ACF_HIP_E_INVALID, "get_hits: survivor index outside the raw list");
+                }
+                out[i] = raw[size_t(keep[size_t(i)])];
+            }
+        }
+        return ACF_HIP_OK;
+    }
     if (count)
     {
         *count = n;

@@ -187,6 +187,13 @@ class HipDetector:
         self._chk(self.lib.acf_hip_get_hits(self.ctx, frame, hits.ctypes.data_as(C.POINTER(capi.Hit)), self.max_hits, C.byref(n)))
         return det[:n.value].copy(), hits[:n.value].copy()
 
+    def raw_detections(self, frame):
+        """acfDetect1's list (scale, column, row order) whether or not the device NMS is on."""
+        det = np.zeros(self.max_hits, dtype=capi.DET_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.acf_hip_get_raw_detections(self.ctx, frame, det.ctypes.data_as(C.POINTER(capi.Detection)), self.max_hits, C.byref(n)))
+        return det[:n.value].copy()
+
     # ---- parity taps
     def set_nms(self, params):
         """params: capi.NmsParams (capi.make_nms) or None.  From the next detect()/run() on, detections() and

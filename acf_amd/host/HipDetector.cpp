@@ -357,21 +357,30 @@ void HipDetector::syncNms()
 void HipDetector::fetch(int frame, RectVec& objects, RealVec* scores)
 {
     int n = 0;
-    check(m_api->acf_hip_get_detections(m_ctx, frame, nullptr, 0, &n), "acf_hip_get_detections");
+    int rc = m_api->acf_hip_get_detections(m_ctx, frame, nullptr, 0, &n);
+    // The device NMS takes ACF_HIP_NMS_CAP detections per frame; bbNms.cpp has no limit.  A frame beyond it (crowded scene,
+    // low cascThr) is suppressed here from the raw list instead of failing.
+    const bool hostNms = m_nmsOnDevice && rc == ACF_HIP_E_CAPACITY;
+    auto get = hostNms ? m_api->acf_hip_get_raw_detections : m_api->acf_hip_get_detections;
+    if (hostNms)
+    {
+        rc = get(m_ctx, frame, nullptr, 0, &n);
+    }
+    check(rc, "acf_hip_get_detections");
     std::vector<acf_hip_detection> d(size_t(std::max(n, 1)));
-    check(m_api->acf_hip_get_detections(m_ctx, frame, d.data(), n, &n), "acf_hip_get_detections");
+    check(get(m_ctx, frame, d.data(), n, &n), "acf_hip_get_detections");
     DetectionVec bbs(static_cast<size_t>(n));
     for (int i = 0; i < n; i++)
     {
         bbs[size_t(i)].roi = Rect(d[size_t(i)].x, d[size_t(i)].y, d[size_t(i)].w, d[size_t(i)].h);
         bbs[size_t(i)].score = double(d[size_t(i)].score);
     }
-    finish(bbs, objects, scores);
+    finish(bbs, objects, scores, hostNms);
 }
 
-void HipDetector::finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const
+void HipDetector::finish(DetectionVec& bbs, RectVec& objects, RealVec* scores, bool forceHostNms) const
 {
-    if (m_doNms && !m_nmsOnDevice)
+    if (m_doNms && (!m_nmsOnDevice || forceHostNms))
     {
         // ACF.cpp:332-353
         if (!bbs.empty())
@@ -512,9 +521,16 @@ void HipDetector::streamCollect(int ticket, std::vector<RectVec>& objects, std::
     for (int f = 0; f < n; f++)
     {
         const int32_t* r = rec + size_t(f) * per;
-        if (r[0] > m_streamCap || r[0] < 0)
+        if (r[0] < 0)
         {
-            throw Exception(ACF_HIP_E_CAPACITY, "streamCollect: more detections than maxDetectionsPerFrame");
+            // (the raw list of a streamed batch is gone once the slot is reused: no host fallback here)
+            throw Exception(ACF_HIP_E_CAPACITY, "streamCollect: frame " + std::to_string(f) + " produced more than ACF_HIP_NMS_CAP raw detections, "
+                "the capacity of the device NMS; detectBatch / operator() suppress such frames on the host, or raise cascThr");
+        }
+        if (r[0] > m_streamCap)
+        {
+            throw Exception(ACF_HIP_E_CAPACITY, "streamCollect: frame " + std::to_string(f) + " has " + std::to_string(r[0]) +
+                " detections, more than maxDetectionsPerFrame = " + std::to_string(m_streamCap));
         }
         DetectionVec bbs(static_cast<size_t>(r[0]));
         for (int i = 0; i < r[0]; i++)

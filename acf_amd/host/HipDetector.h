@@ -290,7 +290,7 @@ private:
     void ensurePlan(int imgH, int imgW, int d, int batch);
     void fetch(int frame, RectVec& objects, RealVec* scores);
     void detect1(const float* f32, const uint8_t* u8, int rows, int cols, DetectionVec& objects);
-    void finish(DetectionVec& bbs, RectVec& objects, RealVec* scores) const; // ACF.cpp:332-364
+    void finish(DetectionVec& bbs, RectVec& objects, RealVec* scores, bool forceHostNms = false) const; // ACF.cpp:332-364
 
     const hip::Api* m_api = nullptr;
     acf_hip_ctx* m_ctx = nullptr;

@@ -66,6 +66,7 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_op_nms)
     ACF_HIP_FN(acf_hip_get_detections)
     ACF_HIP_FN(acf_hip_get_hits)
+    ACF_HIP_FN(acf_hip_get_raw_detections)
     ACF_HIP_FN(acf_hip_export_detections)
     ACF_HIP_FN(acf_hip_synchronize)
     ACF_HIP_FN(acf_hip_profile_get)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 5
+#define ACF_HIP_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -295,7 +295,13 @@ ACF_HIP_API int acf_hip_set_nms(acf_hip_ctx* ctx, const acf_hip_nms_params* para
 ACF_HIP_API int acf_hip_op_nms(acf_hip_ctx* ctx, const int32_t* boxes, const double* scores, int n, const acf_hip_nms_params* params,
     int32_t* keep_idx, int* count);
 ACF_HIP_API int acf_hip_get_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
+/* The cascade's hits behind the detections: hit i is the window that produced detection i of acf_hip_get_detections (with
+ * the device NMS on: the survivors' windows, in the survivors' order; *count = their number). */
 ACF_HIP_API int acf_hip_get_hits(acf_hip_ctx* ctx, int frame, acf_hip_hit* out, int cap, int* count);
+/* The list acfDetect1 produced (ACF.cpp:302-329: scale, column, row order) whether or not the device NMS is on.  The device
+ * NMS takes at most ACF_HIP_NMS_CAP detections per frame; beyond that acf_hip_get_detections returns ACF_HIP_E_CAPACITY for the
+ * frame (record count -1) and the caller suppresses this list on the host (acf::HipDetector does; bbNms.cpp has no limit). */
+ACF_HIP_API int acf_hip_get_raw_detections(acf_hip_ctx* ctx, int frame, acf_hip_detection* out, int cap, int* count);
 
 /* Device-side export for the multi-GPU gather: writes, for every frame of the
  * last batch, a fixed-capacity record [count, then cap x {x,y,w,h,score bits,scale}]

@@ -241,3 +241,25 @@ def test_cli_ldcf_model(cli, oracle, tmp_path):
         assert got[f] == want
         total += len(want)
     assert total > 0
+
+
+@pytest.mark.gpu
+def test_cli_nms_beyond_device_capacity_is_suppressed_on_the_host(cli, oracle, tmp_path):
+    """A frame with more raw detections than ACF_HIP_NMS_CAP (bbNms.cpp has no limit): acf::HipDetector takes the raw list
+    and runs its host bbNms + prune instead of failing; the result equals the checker's NMS of the raw list."""
+    H, W = 240, 320
+    model = synth.make_model(seed=3, name="TINY", nTrees=8, cascThr=-1e6)  # every window is a detection
+    frames = [synth.make_frame(70, H, W, "luv")]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    common = ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+              "--channels", "3", "--count", "1", "--luv"]
+    want = _oracle_dets(oracle, model, frames, H, W, 3)[0]
+    assert len(want) > capi.NMS_CAP
+    for mode in ([], ["--batch"]):
+        got = parse(run(cli, common + ["--nms", "--max-count", "12"] + mode).stdout)[0]
+        scores = [float(np.uint32(w[4]).view(np.float32)) for w in want]
+        keep = oracle.nms([w[:4] for w in want], scores, capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=12, pruneRatio=0.0))
+        assert 0 < len(keep) <= 12
+        assert [g[:4] for g in got] == [tuple(want[i][:4]) for i in keep]
+        assert [g[4] for g in got] == [want[i][4] for i in keep]

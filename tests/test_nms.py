@@ -140,3 +140,81 @@ def test_gpu_pipeline_nms_before_export(oracle):
     det.set_nms(None)
     det.run(fr)
     assert det.detections(1)[0].tobytes() == raw[1].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_nms_with_sub_batch_streams_and_replan(oracle):
+    """Device NMS state reaches the sub-batch child contexts (option streams > 1) whether acf_hip_set_nms comes before the
+    plan, after it, or the context is re-planned (children are destroyed and recreated)."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 120, 160
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-2.0)
+    frames = np.stack([synth.make_frame(90 + i, H, W, "luv") for i in range(4)])
+    fr = torch.from_numpy(frames).cuda()
+    q = capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=15, pruneRatio=0.1)
+    ref = HipDetector(model, H, W, 3, max_batch=4, max_hits=1 << 14)
+    ref.run(fr)
+    raw = [ref.detections(f)[0] for f in range(4)]
+    want = []
+    for r in raw:
+        keep = oracle.nms(np.stack([r["x"], r["y"], r["w"], r["h"]], axis=1), r["score"].astype(np.float64), q)
+        assert 1 <= len(keep) < len(r)
+        want.append(r[keep].tobytes())
+    det = HipDetector(streams=2)
+    det.set_model(model)
+    det.set_nms(q)                      # before any plan: no children exist yet
+    det.plan(H, W, 3, max_batch=4, max_hits=1 << 14)
+    det.run(fr)
+    assert [det.detections(f)[0].tobytes() for f in range(4)] == want
+    assert [det.raw_detections(f).tobytes() for f in range(4)] == [r.tobytes() for r in raw]
+    det.plan(H, W, 3, max_batch=4, max_hits=1 << 13)   # re-plan: new children
+    det.run(fr)
+    assert [det.detections(f)[0].tobytes() for f in range(4)] == want
+    det.set_nms(None)
+    det.run(fr)
+    assert [det.detections(f)[0].tobytes() for f in range(4)] == [r.tobytes() for r in raw]
+
+
+@pytest.mark.gpu
+def test_gpu_hits_follow_the_survivors(oracle):
+    """With the device NMS on, hit i of acf_hip_get_hits is the window behind detection i (the survivors' order)."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 240, 320
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-2.0)
+    fr = torch.from_numpy(np.stack([synth.make_frame(70 + i, H, W, "luv") for i in range(2)])).cuda()
+    det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 14)
+    det.run(fr)
+    raw = [det.detections(f) for f in range(2)]
+    q = capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=40, pruneRatio=0.1)
+    det.set_nms(q)
+    det.run(fr)
+    for f in range(2):
+        d, h = det.detections(f)
+        rd, rh = raw[f]
+        keep = oracle.nms(np.stack([rd["x"], rd["y"], rd["w"], rd["h"]], axis=1), rd["score"].astype(np.float64), q)
+        assert len(d) == len(h) == len(keep)
+        assert d.tobytes() == rd[keep].tobytes() and h.tobytes() == rh[keep].tobytes()
+        assert np.array_equal(h["score"].view(np.uint32), d["score"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_nms_capacity_falls_back_to_the_raw_list():
+    """More than ACF_HIP_NMS_CAP raw detections in a frame: get_detections reports E_CAPACITY for it, the raw list stays
+    available (acf::HipDetector suppresses it on the host: tests/test_host_cpp.py)."""
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    H, W = 240, 320
+    model = synth.make_model(seed=3, name="TINY", nTrees=8, cascThr=-1e6)  # every window is a detection
+    fr = torch.from_numpy(synth.make_frame(70, H, W, "luv")[None]).cuda()
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 16)
+    det.run(fr)
+    raw = det.detections(0)[0]
+    assert len(raw) > 2048
+    det.set_nms(capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10))
+    det.run(fr)
+    with pytest.raises(HipError) as e:
+        det.detections(0)
+    assert e.value.code == capi.E_CAPACITY
+    assert det.raw_detections(0).tobytes() == raw.tobytes()
