@@ -113,6 +113,13 @@ def ref():
         r.ref_gradHist.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         for f in (r.ref_convTri, r.ref_convTri1, r.ref_grad2, r.ref_gradMag, r.ref_gradMagNorm, r.ref_gradHist):
             f.restype = None
+        if hasattr(r, "ref_resample"):  # (a prebuilt _ref from before round 3 has only the six kernels above)
+            r.ref_resample.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+            r.ref_resample.restype = None
+            r.ref_rgbConvert.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float]
+            r.ref_rgbConvert.restype = C.c_int
+            r.ref_rgb2luv_scalar.argtypes = [fp, fp, C.c_int, C.c_float]
+            r.ref_rgb2luv_scalar.restype = None
         _r = r
     return _r
 

@@ -19,6 +19,11 @@ Two kinds of fixture, both plain data (inputs + expected outputs):
                      -> bit-exact targets;
                      gradMag M/O and gradMagNorm -> targets within the
                      _mm_rsqrt_ps/_mm_rcp_ps bound.
+ ref_resample_luv.npz  the same for `resample` (imResampleMex.cpp) and rgbConvert's
+                   rgb2luv / rgb2luv_sse / rgb2gray (rgbConvertMex.cpp), whose
+                   OpenCV-free bodies the Makefile takes from the reference
+                   files by line range (oracle/ref_api_resample.cpp,
+                   oracle/ref_api_rgbconvert.cpp state the ranges).
  pipeline_*.npz    end-to-end vectors of the restated orchestration (oracle/
                    acf_oracle.c): frame, model arrays, scales, every level of
                    the fused pyramid, cascade hits and mapped boxes.  The
@@ -104,6 +109,46 @@ def ref_ops():
     return out
 
 
+# geometries (ha, wa, hb, wb, d, gain): exact /2 /3 /4, generic down (2..4 taps and the >4-tap scatter form), up-sampling, mixed
+# axes, odd sizes, and the shapes the pyramid uses (an approximated channel level with its power-law gain)
+RESAMPLE_CASES = [(64, 48, 32, 24, 3, 1.0), (66, 48, 22, 16, 1, 1.0), (64, 48, 16, 12, 1, 1.0), (64, 48, 57, 43, 3, 1.0), (63, 50, 31, 27, 3, 1.0),
+                  (120, 160, 13, 17, 1, 1.0), (32, 24, 64, 48, 3, 1.0), (31, 27, 63, 50, 1, 1.0), (64, 48, 32, 60, 1, 1.0), (37, 41, 37, 41, 1, 1.0),
+                  (68, 120, 62, 110, 4, 0.8705506), (68, 120, 74, 132, 4, 1.3195079), (136, 240, 68, 121, 3, 1.0)]
+
+
+def ref_resample_luv():
+    """ref_resample_luv.npz: outputs of the reference's own `resample` (imResampleMex.cpp:122-383) and rgbConvert /
+    rgb2luv / rgb2luv_sse / rgb2gray bodies (rgbConvertMex.cpp:17-380), spliced by line range into oracle/_ref/libacfref.so
+    (oracle/Makefile), on seeded inputs.  resample, rgb2gray and the scalar rgb2luv are bit-exact targets; the vector
+    rgb2luv (n % 4 == 0, one _mm_rcp_ps) is a target within the rcp bound with L exact."""
+    assert ob.have_ref(), "oracle/_ref/libacfref.so missing: run `make -C oracle` with /root/reference present"
+    r = ob.ref()
+    o = ob.lib()
+    out = {"resample_cases": np.asarray(RESAMPLE_CASES, dtype=np.float64)}
+    for k, (ha, wa, hb, wb, d, g) in enumerate(RESAMPLE_CASES):
+        a = ob.aligned_copy(rnd(500 + k, (d, wa, ha)))
+        b, t = ob.aligned((d, wb, hb)), ob.aligned((d, wb, hb))
+        r.ref_resample(F(a), F(b), ha, hb, wa, wb, d, np.float32(g))
+        assert o.acfo_resample(F(a), F(t), ha, hb, wa, wb, d, np.float32(g)) == 0
+        assert np.array_equal(b.view(np.uint32), t.view(np.uint32))  # the oracle agrees before anything is frozen
+        out["rs_out%d" % k] = np.array(b)  # input: rnd(500 + k, (d, wa, ha)) (seeded: not stored)
+    luv = [(48, 36), (37, 29), (64, 51)]  # (h, w): n % 4 == 0 -> vector body; the other two -> scalar body
+    out["luv_sizes"] = np.asarray(luv, dtype=np.int32)
+    for k, (h, w) in enumerate(luv):
+        a = ob.aligned_copy(synth.make_frame(600 + k, h, w, "rgb"))
+        b, t, gr, tg = ob.aligned((3, w, h)), ob.aligned((3, w, h)), ob.aligned((w, h)), ob.aligned((w, h))
+        assert r.ref_rgbConvert(F(a), F(b), h * w, 3, 2, np.float32(1.0)) == 0
+        assert r.ref_rgbConvert(F(a), F(gr), h * w, 3, 0, np.float32(1.0)) == 0
+        o.acfo_rgb2luv(F(a), F(t), h * w)
+        o.acfo_rgb2gray(F(a), F(tg), h * w)
+        assert np.array_equal(gr.view(np.uint32), tg.view(np.uint32)) and np.array_equal(b[0].view(np.uint32), t[0].view(np.uint32))
+        if (h * w) % 4:
+            assert np.array_equal(b.view(np.uint32), t.view(np.uint32))
+        out["luv_out%d" % k], out["gray_out%d" % k] = np.array(b), np.array(gr)  # input: synth.make_frame(600 + k, h, w, "rgb")
+    np.savez_compressed(os.path.join(HERE, "ref_resample_luv.npz"), **out)
+    return out
+
+
 PIPELINES = {
     # name: (H, W, kind, d_in, frame seed, model kwargs)
     "tiny_luv": (64, 80, "luv", 3, 17, dict(name="TINY", nTrees=96, seed=3)),
@@ -167,7 +212,11 @@ def scales():
 
 if __name__ == "__main__":
     ob.build()
-    ref_ops()
+    if "--only-new" not in sys.argv:  # (the older fixtures are deterministic; this only saves time)
+        ref_ops()
+    ref_resample_luv()
+    if "--only-new" in sys.argv:
+        sys.exit(0)
     pipelines()
     scales()
     for f in sorted(os.listdir(HERE)):

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from acf_amd import capi
+from acf_amd import capi, synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 F = capi.fptr
@@ -215,3 +215,71 @@ def test_ldcf_oracle_properties(oracle):
         assert lvL[i].offset == acc
         acc += plan.nChns * 2 * lvL[i].hP * lvL[i].wP
     assert tot == acc
+
+
+# ------------------------------------------------------------------ reference bytes of resample / rgbConvert (round 3)
+
+def _rnd77(seed, shape):
+    n = int(np.prod(shape))
+    return synth.uniform(seed, n, 77).astype(np.float32).reshape(shape)  # tests/golden/make_golden.py: rnd
+
+
+@pytest.fixture(scope="module")
+def rsl():
+    return np.load(os.path.join(GOLD, "ref_resample_luv.npz"))
+
+
+def test_oracle_matches_reference_resample_and_luv_bytes(oracle, rsl):
+    """CPU leg: the restatement against the frozen outputs of the reference's own resample / rgbConvert bodies (the GPU box
+    has no /root/reference; where oracle/_ref is present tests/test_oracle_vs_ref.py repeats this on many more cases)."""
+    for k, (ha, wa, hb, wb, d, g) in enumerate(rsl["resample_cases"]):
+        ha, wa, hb, wb, d = int(ha), int(wa), int(hb), int(wb), int(d)
+        a = np.ascontiguousarray(_rnd77(500 + k, (d, wa, ha)))
+        out = np.zeros((d, wb, hb), np.float32)
+        assert oracle.lib().acfo_resample(oracle.F(a), oracle.F(out), ha, hb, wa, wb, d, np.float32(g)) == 0
+        assert np.array_equal(bits(out), bits(rsl["rs_out%d" % k])), k
+    for k, (h, w) in enumerate(rsl["luv_sizes"]):
+        h, w = int(h), int(w)
+        a = np.ascontiguousarray(synth.make_frame(600 + k, h, w, "rgb"))
+        luv, gray = np.zeros((3, w, h), np.float32), np.zeros((w, h), np.float32)
+        oracle.lib().acfo_rgb2luv(oracle.F(a), oracle.F(luv), h * w)
+        oracle.lib().acfo_rgb2gray(oracle.F(a), oracle.F(gray), h * w)
+        ref = rsl["luv_out%d" % k]
+        assert np.array_equal(bits(gray), bits(rsl["gray_out%d" % k]))
+        assert np.array_equal(bits(luv[0]), bits(ref[0]))
+        if (h * w) % 4:
+            assert np.array_equal(bits(luv), bits(ref))
+        else:
+            assert np.abs(luv - ref).max() <= 2 * RCP
+
+
+@pytest.mark.gpu
+def test_hip_resample_matches_reference_bytes(dev, rsl):
+    """k_resample / k_resample_tile (acf_hip_op_im_resample) against the reference's own `resample` output, bit for bit."""
+    for k, (ha, wa, hb, wb, d, g) in enumerate(rsl["resample_cases"]):
+        ha, wa, hb, wb, d = int(ha), int(wa), int(hb), int(wb), int(d)
+        a = np.ascontiguousarray(_rnd77(500 + k, (d, wa, ha)))
+        got = dev.op_im_resample(a, hb, wb, float(np.float32(g)))
+        assert np.array_equal(bits(got), bits(rsl["rs_out%d" % k])), (k, ha, wa, hb, wb)
+
+
+@pytest.mark.gpu
+def test_hip_rgb_convert_matches_reference_bytes(dev, rsl):
+    """k_rgb2luv / k_rgb2gray against the reference's rgbConvert: gray and L bit-exact; U, V bit-exact where the reference
+    takes its scalar body (n % 4 != 0) and within its one _mm_rcp_ps where it takes rgb2luv_sse."""
+    from acf_amd import capi
+    for k, (h, w) in enumerate(rsl["luv_sizes"]):
+        h, w = int(h), int(w)
+        a = np.ascontiguousarray(synth.make_frame(600 + k, h, w, "rgb"))
+        ref = rsl["luv_out%d" % k]
+        luv = dev.op_rgb_convert(a, capi.CS_LUV)
+        gray = dev.op_rgb_convert(a, capi.CS_GRAY)
+        assert np.array_equal(bits(gray.reshape(w, h)), bits(rsl["gray_out%d" % k]))
+        assert np.array_equal(bits(luv[0]), bits(ref[0]))
+        if (h * w) % 4:
+            assert np.array_equal(bits(luv), bits(ref)), k
+        else:
+            l = ref[0].astype(np.float64)
+            for ch, c, mn in ((1, 13 * 0.197833, -88.0 / 270), (2, 13 * 0.468331, -134.0 / 270)):
+                mag = np.abs(ref[ch].astype(np.float64) + mn + c * l)
+                assert (np.abs(luv[ch].astype(np.float64) - ref[ch]) <= 1.1 * RCP * mag + 4e-7).all(), (k, ch)

@@ -170,3 +170,110 @@ def test_chain_with_reference_kernels(oracle, refk):
     refk.ref_gradHist(oracle.F(Mn_r), oracle.F(O_r), oracle.F(H_r), h, w, 4, 6, 0, 0)
     oracle.lib().acfo_grad_hist(oracle.F(Mn_r), oracle.F(O_r), oracle.F(H_o), h, w, 4, 6, 0, 0)
     assert np.array_equal(H_r.view(np.uint32), H_o.view(np.uint32))
+
+
+# ---- imResample and rgbConvert: the reference's own bodies, spliced by line range (oracle/Makefile, oracle/ref_api_*.cpp)
+
+@pytest.fixture(scope="module")
+def refk2(refk):
+    if not hasattr(refk, "ref_resample"):
+        pytest.skip("oracle/_ref/libacfref.so predates the resample / rgbConvert pins")
+    return refk
+
+
+# (ha, wa) -> (hb, wb): the geometry classes of resample (imResampleMex.cpp:145-157,198-373) — exact /2 /3 /4 per axis, generic
+# down-sampling with 2..4 taps and with more than 4 taps per output (scatter form), up-sampling, identity, mixed axes, and
+# the pyramid's own sizes (1080p real scales, approximated channel levels).
+RESAMPLE_GEOMS = [
+    ((64, 48), (32, 24)), ((66, 48), (22, 16)), ((64, 48), (16, 12)), ((64, 48), (32, 16)),
+    ((64, 48), (57, 43)), ((64, 48), (40, 30)), ((63, 50), (31, 27)), ((120, 160), (13, 17)), ((97, 131), (9, 23)),
+    ((32, 24), (64, 48)), ((31, 27), (63, 50)), ((30, 40), (37, 41)), ((37, 41), (37, 41)), ((64, 48), (32, 60)), ((48, 64), (60, 32)),
+    ((1080, 1920), (540, 960)), ((540, 960), (272, 484)), ((270, 480), (248, 440)), ((270, 480), (136, 240)), ((68, 121), (62, 111)),
+    ((135, 240), (150, 264)), ((8, 8), (4, 4)), ((5, 7), (4, 4)), ((4, 4), (9, 11)),
+]
+
+
+@pytest.mark.parametrize("a,b", RESAMPLE_GEOMS)
+@pytest.mark.parametrize("r", [1.0, 0.8705506, 1.3195079])
+def test_resample_bit_exact(oracle, refk2, a, b, r):
+    (ha, wa), (hb, wb) = a, b
+    d = 3 if ha * wa < 300000 else 1
+    src = oracle.aligned_copy(rnd(ha * 13 + wa * 7 + hb, (d, wa, ha)))
+    out_r, out_o = oracle.aligned((d, wb, hb)), oracle.aligned((d, wb, hb))
+    out_r[:] = -7.0  # resample writes every output (its scatter form zeroes first): poison must disappear
+    out_o[:] = -7.0
+    refk2.ref_resample(oracle.F(src), oracle.F(out_r), ha, hb, wa, wb, d, r)
+    assert oracle.lib().acfo_resample(oracle.F(src), oracle.F(out_o), ha, hb, wa, wb, d, r) == 0
+    assert np.array_equal(out_r.view(np.uint32), out_o.view(np.uint32)), np.abs(out_r - out_o).max()
+    assert out_r.min() >= 0.0
+
+
+def test_resample_chain_of_the_pyramid_bit_exact(oracle, refk2):
+    """The image chain of cfg 2 at quarter size: 270x480 -> 136x240 (exact half) -> 68x121-ish generic, each fed from the
+    REFERENCE's previous output."""
+    src = oracle.aligned_copy(synth.make_frame(3, 272, 480, "luv"))
+    cur_r, cur_o, (h, w) = src, src, (272, 480)
+    for hb, wb in ((136, 240), (68, 124), (36, 60)):
+        nr, no = oracle.aligned((3, wb, hb)), oracle.aligned((3, wb, hb))
+        refk2.ref_resample(oracle.F(cur_r), oracle.F(nr), h, hb, w, wb, 3, 1.0)
+        oracle.lib().acfo_resample(oracle.F(cur_o), oracle.F(no), h, hb, w, wb, 3, 1.0)
+        assert np.array_equal(nr.view(np.uint32), no.view(np.uint32))
+        cur_r, cur_o, (h, w) = nr, no, (hb, wb)
+
+
+@pytest.mark.parametrize("h,w", SIZES + [(1080, 1920)])
+def test_rgb2luv_vector_body_within_rcp_bound(oracle, refk2, h, w):
+    """n % 4 == 0 and aligned planes: the reference takes rgb2luv_sse (rgbConvertMex.cpp:88-190), whose only approximate
+    operation is one _mm_rcp_ps (:161).  L involves no rcp: bit-exact.  U, V: l * (c * x * zz - 13 * un) - minu with
+    zz = rcp(..) -> the difference is bounded by RCP_EPS * l * |c * x * zz| <= RCP_EPS * |U + minu + 13 * un * l| (+ rounding)."""
+    n = h * w
+    if n % 4:
+        pytest.skip("vector body needs n % 4 == 0")
+    src = oracle.aligned_copy(synth.make_frame(h + w, h, w, "rgb"))
+    out_r, out_o = oracle.aligned((3, w, h)), oracle.aligned((3, w, h))
+    assert refk2.ref_rgbConvert(oracle.F(src), oracle.F(out_r), n, 3, 2, 1.0) == 0
+    oracle.lib().acfo_rgb2luv(oracle.F(src), oracle.F(out_o), n)
+    assert np.array_equal(out_r[0].view(np.uint32), out_o[0].view(np.uint32))
+    l = out_o[0].astype(np.float64)
+    for k, c in ((1, 13 * 0.197833), (2, 13 * 0.468331)):
+        minc = (-88.0 if k == 1 else -134.0) / 270.0
+        mag = np.abs(out_o[k].astype(np.float64) + minc + c * l)   # = l * (52 x zz) resp. l * (117 y zz)
+        err = np.abs(out_r[k].astype(np.float64) - out_o[k].astype(np.float64))
+        assert (err <= 1.05 * RCP_EPS * mag + 4e-7).all(), (k, err.max())
+        assert err.max() > 0  # and it IS the approximate path (the bound is not vacuous)
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 250, 257, 4093])
+def test_rgb2luv_scalar_body_bit_exact(oracle, refk2, n):
+    """n % 4 != 0: the reference's scalar rgb2luv (rgbConvertMex.cpp:62-84, true division) — the restatement's second
+    branch must agree bit for bit, through rgbConvert's own dispatch and called directly."""
+    assert n % 4
+    src = oracle.aligned_copy(rnd(900 + n, (3, n)))
+    out_r, out_d, out_o = oracle.aligned((3, n)), oracle.aligned((3, n)), oracle.aligned((3, n))
+    assert refk2.ref_rgbConvert(oracle.F(src), oracle.F(out_r), n, 3, 2, 1.0) == 0
+    refk2.ref_rgb2luv_scalar(oracle.F(src), oracle.F(out_d), n, 1.0)
+    oracle.lib().acfo_rgb2luv(oracle.F(src), oracle.F(out_o), n)
+    assert np.array_equal(out_r.view(np.uint32), out_d.view(np.uint32))
+    assert np.array_equal(out_r.view(np.uint32), out_o.view(np.uint32))
+
+
+def test_luv_table_bit_exact_through_the_reference(oracle, refk2):
+    """rgb2luv_setup's lTable (:39-58) read back through the scalar body: grey pixels r = g = b = v give y = v * (mr1 + mg1 + mb1),
+    L = lTable[(int)(y * 1024)]; sweeping v hits every table entry the conversion can reach."""
+    n = 4099
+    v = (np.arange(n, dtype=np.float64) / (n - 1)).astype(np.float32)
+    src = oracle.aligned_copy(np.stack([v, v, v]))
+    out_r, out_o = oracle.aligned((3, n)), oracle.aligned((3, n))
+    refk2.ref_rgb2luv_scalar(oracle.F(src), oracle.F(out_r), n, 1.0)
+    oracle.lib().acfo_rgb2luv(oracle.F(src), oracle.F(out_o), n)
+    assert np.array_equal(out_r[0].view(np.uint32), out_o[0].view(np.uint32))
+    assert len(np.unique(out_r[0])) > 1000
+
+
+@pytest.mark.parametrize("n", [16, 250, 4096])
+def test_rgb2gray_bit_exact(oracle, refk2, n):
+    src = oracle.aligned_copy(rnd(77 + n, (3, n)))
+    out_r, out_o = oracle.aligned((n,)), oracle.aligned((n,))
+    assert refk2.ref_rgbConvert(oracle.F(src), oracle.F(out_r), n, 3, 0, 1.0) == 0
+    oracle.lib().acfo_rgb2gray(oracle.F(src), oracle.F(out_o), n)
+    assert np.array_equal(out_r.view(np.uint32), out_o.view(np.uint32))
