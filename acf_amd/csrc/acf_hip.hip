@@ -73,6 +73,21 @@ struct CascState
     // stage E of k_cascade_tile2 + k_tail_scan: leaf codes of the first codeCap queue entries per frame
     uint8_t* d_tailCodes = nullptr;
     int codeCap = 0, codePitch = 0;
+    // threshold-rank cells (host_plan.h): the tile kernel's second form, reading a 16-bit pyramid
+    bool useRank = false;
+    TileGeom geomR{};
+    CascTile* d_tilesR = nullptr;
+    int nTilesR = 0;
+    TreeNode* d_tileNodesR = nullptr;  // rank-tile offsets, thresholds as rank indices
+    uint32_t* d_tileNodesSR = nullptr;
+    RankChan* d_rankChan = nullptr;
+    uint16_t* d_rankLut = nullptr;
+    float* d_rankThr = nullptr;
+    int rankMaxLut = 0, rankMaxThr = 0;
+    RankJob* d_rankJobs = nullptr;
+    uint16_t* d_pyrR = nullptr;
+    int64_t pyrRCells = 0; // cells per frame
+    int rankMaxWP = 0;
 };
 
 struct acf_hip_ctx
@@ -97,6 +112,8 @@ struct acf_hip_ctx
     int profile = 0;
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
+    int noRank = 0;  // option "rank_cells" = 0: the tile kernel reads the float pyramid (A/B and parity of both forms)
+    bool ranksValid = false; // the rank pyramid of the last batch has been written (by the level kernels or by k_rank)
     std::vector<hipEvent_t> evPool;
     std::vector<const char*> evName;
     size_t evUsed = 0;
@@ -873,6 +890,19 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
         c->noTiles = value == 0;
         return ACF_HIP_OK;
     }
+    if (!strcmp(key, "rank_cells"))
+    {
+        // 1 (default): the tile kernel of depth-2 models reads 16-bit threshold-rank cells (host_plan.h) — identical decisions,
+        // half the tile; 0: it reads the float pyramid
+        c->noRank = value == 0;
+        c->detectValid = false;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            k->noRank = c->noRank;
+            k->detectValid = false;
+        }
+        return ACF_HIP_OK;
+    }
     if (!strcmp(key, "scale_streams"))
     {
         // 1 (default): the real scales of a batch run on their own streams (best for ONE context: +8 % frames/s, batch-1 latency
@@ -1027,7 +1057,181 @@ struct ShrinkScope
 
 // Build the cascade tables for a list of level geometries (hP, wP) into the
 // context.  Shared by acf_hip_plan and acf_hip_op_acf_detect1.
-static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, CascState& cs)
+// One set of tile tables of the LDS-tiled cascade: geometry, tile list, node records with tile-layout offsets.  `rank` ==
+// nullptr: float cells, thresholds as float bits; else 16-bit threshold-rank cells, thresholds as rank indices.
+struct TileSet
+{
+    bool ok = false;
+    TileGeom g{};
+    int nTiles = 0, aTB = 4;
+    CascTile* d_tiles = nullptr;
+    TreeNode* d_tileNodes = nullptr;
+    uint32_t* d_tileNodesS = nullptr;
+};
+
+static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out)
+{
+    const acf_hip_params& p = c->p;
+    const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
+    const int cellBytes = rank ? 2 : 4, CPB = 16 / cellBytes; // cells per 16-byte fill chunk
+    int rc;
+    TileGeom g{};
+    g.step = p.stride / p.shrink;
+    g.TR = 32;
+    g.winFloats = nChns * mW * mH;
+    // stage boundaries (kernels.hip.h, k_cascade_tile2), measured at cfg 2: 32 dense trees then sparse pieces [32,64) and
+    // [64,128) is 10 % faster than 16 / 32 / 64 / 128: the sparse stages are latency chains, the dense stage is VALU work
+    int bounds[5] = { 0, 32, 32, 64, 128 };
+    if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
+    {
+        int v1, v2, v3, v4;
+        if (sscanf(e, "%d,%d,%d,%d", &v1, &v2, &v3, &v4) == 4 && 0 < v1 && v1 <= v2 && v2 <= v3 && v3 <= v4)
+        {
+            bounds[1] = v1;
+            bounds[2] = v2;
+            bounds[3] = v3;
+            bounds[4] = v4;
+        }
+    }
+    for (int i = 0; i < 5; i++)
+    {
+        g.b[i] = std::min(bounds[i], p.nTrees);
+    }
+    // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for several workgroups per CU
+    // (160 KiB LDS: three with rank cells, two with floats), else one
+    const int W = 1; // windows per lane in stage A
+    auto ldsBytes = [&](int nw) {
+        const int tc = nw * W * 64 / g.TR;
+        const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
+        const int64_t rowsP = (rows + CPB - 1) / CPB * CPB;
+        // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
+        return int64_t(nChns) * rowsP * cols * cellBytes + int64_t(nw) * 64 * 8 + 64;
+    };
+    int nw = 0;
+    if (const char* e = getenv(rank ? "ACF_HIP_RTILE_TR" : "ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
+    {
+        const int v = atoi(e);
+        g.TR = (v == 8 || v == 16 || v == 32 || v == 64) ? v : g.TR;
+    }
+    const char* nwEnv = getenv(rank ? "ACF_HIP_RTILE_NW" : "ACF_HIP_TILE_NW");
+    const int nwForce = nwEnv ? atoi(nwEnv) : 0;
+    for (int64_t limit : { int64_t(rank ? 53 : 80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
+    {
+        for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
+        {
+            if (!nw && cand >= 1 && ldsBytes(cand) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR)
+            {
+                nw = cand;
+            }
+        }
+    }
+    if (!nw)
+    {
+        return ACF_HIP_OK;
+    }
+    g.NW = nw;
+    g.W = W;
+    g.TC = nw * W * 64 / g.TR;
+    g.rowsT = (g.TR - 1) * g.step + mH;
+    g.colsT = (g.TC - 1) * g.step + mW;
+    g.rowsP = (g.rowsT + CPB - 1) / CPB * CPB;
+    g.tileFloats = nChns * g.rowsP * g.colsT; // cells
+    g.cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.rowsP / CPB) - 1) / uint32_t(g.rowsP / CPB));
+    g.colsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.colsT) - 1) / uint32_t(g.colsT));
+    std::vector<CascTile> tiles;
+    bool ok = true;
+    {
+        // the fill kernel divides chunk indices by mulhi with these magics: check every index it will see
+        const uint32_t cps = uint32_t(g.rowsP / CPB), nSeg = uint32_t(nChns * g.colsT);
+        for (uint32_t q = 0; q < nSeg * cps && ok; q++)
+        {
+            const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32); // a divisor of 1 has magic 2^32 = 0 in 32 bits: caught here
+            ok = seg == q / cps && uint32_t((uint64_t(seg) * g.colsMagic) >> 32) == seg / uint32_t(g.colsT);
+        }
+    }
+    for (size_t i = 0; i < lv.size() && ok; i++)
+    {
+        for (int c0 = 0; c0 < lv[i].nWinC; c0 += g.TC)
+        {
+            for (int r0 = 0; r0 < lv[i].nWinR; r0 += g.TR)
+            {
+                if (r0 > 32767 || c0 > 32767)
+                {
+                    ok = false;
+                    break;
+                }
+                CascTile t{};
+                t.level = int16_t(i);
+                t.r0 = int16_t(r0);
+                t.c0 = int16_t(c0);
+                tiles.push_back(t);
+            }
+        }
+    }
+    if (!ok)
+    {
+        return ACF_HIP_OK;
+    }
+    std::vector<TreeNode> tileNodes(size_t(std::max(p.nTrees, 1)));
+    for (int t = 0; t < p.nTrees; t++)
+    {
+        const size_t q = size_t(t) * p.nTreeNodes;
+        TreeNode a{};
+        for (int k = 0; k < 3; k++)
+        {
+            const uint32_t f = c->fids[q + k];
+            const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
+            a.off[k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
+            if (rank)
+            {
+                const uint32_t rk = rank->rankOfThreshold(int(z), c->thrs[q + k]);
+                memcpy(&a.thr[k], &rk, 4);
+            }
+            else
+            {
+                a.thr[k] = c->thrs[q + k];
+            }
+        }
+        for (int k = 0; k < 4; k++)
+        {
+            a.hs[k] = c->hs[q + 3 + k];
+        }
+        tileNodes[size_t(t)] = a;
+    }
+    // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
+    // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC: ACF_HIP_TILE_TB8 for the A/B)
+    const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
+    const int nTreesS = g.b[1] / aTB * aTB;
+    std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
+    for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
+    {
+        uint32_t* d = nodesS.data() + size_t(t / aTB) * 10 * aTB;
+        for (int q = 0; q < aTB; q++)
+        {
+            const TreeNode& nd = tileNodes[size_t(t + q)];
+            for (int k = 0; k < 3; k++)
+            {
+                d[3 * q + k] = nd.off[k];
+                memcpy(&d[3 * aTB + 3 * q + k], &nd.thr[k], 4);
+            }
+            for (int k = 0; k < 4; k++)
+            {
+                memcpy(&d[6 * aTB + 4 * q + k], &nd.hs[k], 4);
+            }
+        }
+    }
+    out.aTB = aTB;
+    out.g = g;
+    out.nTiles = int(tiles.size());
+    if ((rc = devUpload(c, &out.d_tileNodesS, nodesS)) || (rc = devUpload(c, &out.d_tiles, tiles)) || (rc = devUpload(c, &out.d_tileNodes, tileNodes)))
+    {
+        return rc;
+    }
+    out.ok = true;
+    return ACF_HIP_OK;
+}
+
+static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, CascState& cs, bool wantRank = false)
 {
     CascLevel** d_levels = &cs.d_cascLevels;
     int32_t** d_blockLevel = &cs.d_blockLevel;
@@ -1154,64 +1358,20 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     {
         return rc;
     }
-    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile / k_cascade_tail2)
+    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile2 + stage E + k_tail_scan, k_cascade_tail3 for queue overflow)
     cs.useTiles = false;
+    cs.useRank = false;
     if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
     {
-        TileGeom g{};
-        g.step = p.stride / p.shrink;
-        g.TR = 32;
-        g.winFloats = nChns * mW * mH;
-        // stage boundaries (kernels.hip.h): A [0,16), B [16,32), C [32,64) one lane per window (node table in LDS);
-        // D [64,128) one wave per window.  PMC (SQ_INSTS_VALU) showed stage D's ordered 64-step scans were 2/3 of the
-        // kernel's VALU work when ~40 windows per tile reached it at tree 32; at tree 64 only ~2.5 do.
-        // (k_cascade_tile2, measured at cfg 2: 32 dense trees then sparse pieces [32,64) and [64,128) is 10 % faster than
-        // 16 / 32 / 64 / 128: the sparse stages are latency chains, the dense stage is VALU work)
-        int bounds[5] = { 0, 32, 32, 64, 128 };
-        if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
+        TileSet tsF;
+        if ((rc = buildTileSet(c, lv, nChns, nullptr, tsF)))
         {
-            int v1, v2, v3, v4;
-            if (sscanf(e, "%d,%d,%d,%d", &v1, &v2, &v3, &v4) == 4 && 0 < v1 && v1 <= v2 && v2 <= v3 && v3 <= v4)
-            {
-                bounds[1] = v1;
-                bounds[2] = v2;
-                bounds[3] = v3;
-                bounds[4] = v4;
-            }
+            return rc;
         }
-        for (int i = 0; i < 5; i++)
-        {
-            g.b[i] = std::min(bounds[i], p.nTrees);
-        }
-        // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for two
-        // workgroups per CU (160 KiB LDS), else one
-        const int W = 1; // windows per lane in stage A
-        auto ldsBytes = [&](int nw) {
-            const int tc = nw * W * 64 / g.TR;
-            const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
-            const int64_t rowsP = (rows + 3) / 4 * 4;
-            // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
-            return int64_t(nChns) * rowsP * cols * 4 + int64_t(nw) * 64 * 8 + 64;
-        };
-        int nw = 0;
-        if (const char* e = getenv("ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
-        {
-            const int v = atoi(e);
-            g.TR = (v == 8 || v == 16 || v == 32 || v == 64) ? v : g.TR;
-        }
-        const int nwForce = getenv("ACF_HIP_TILE_NW") ? atoi(getenv("ACF_HIP_TILE_NW")) : 0;
-        for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
-        {
-            for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
-            {
-                if (!nw && cand >= 1 && ldsBytes(cand) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR)
-                {
-                    nw = cand;
-                }
-            }
-        }
+        const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
         int tw = 0;
-        const int tailSlab = (std::max(g.winFloats, TAIL_G * TAIL_PITCH) + 3) / 4 * 4; // footprint, reused as phase 2's transposition tile (16-byte rows)
+        const int winFloats = nChns * mWc * mHc;
+        const int tailSlab = (std::max(winFloats, TAIL_G * TAIL_PITCH) + 3) / 4 * 4; // footprint, reused as phase 2's transposition tile (16-byte rows)
         for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
         {
             for (int cand : { 2, 1 })
@@ -1222,151 +1382,133 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 }
             }
         }
-        if (nw && tw)
+        if (tsF.ok && tw)
         {
-            g.NW = nw;
-            g.W = W;
-            g.TC = nw * W * 64 / g.TR;
-            g.rowsT = (g.TR - 1) * g.step + mH;
-            g.colsT = (g.TC - 1) * g.step + mW;
-            g.rowsP = (g.rowsT + 3) / 4 * 4;
-            g.tileFloats = nChns * g.rowsP * g.colsT;
-            g.cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.rowsP / 4) - 1) / uint32_t(g.rowsP / 4));
-            g.colsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.colsT) - 1) / uint32_t(g.colsT));
-            std::vector<CascTile> tiles;
-            bool ok = true;
+            const TileGeom& g = tsF.g;
+            std::vector<TreeNode> tailNodes(static_cast<size_t>(p.nTrees));
+            for (int t = 0; t < p.nTrees; t++)
             {
-                // the fill kernel divides chunk indices by mulhi with these magics: check every index it will see
-                const uint32_t cps = uint32_t(g.rowsP / 4), nSeg = uint32_t(nChns * g.colsT);
-                for (uint32_t q = 0; q < nSeg * cps && ok; q++)
+                const size_t q = size_t(t) * p.nTreeNodes;
+                TreeNode b{};
+                for (int k = 0; k < 3; k++)
                 {
-                    const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32); // a divisor of 1 has magic 2^32 = 0 in 32 bits: caught here
-                    ok = seg == q / cps && uint32_t((uint64_t(seg) * g.colsMagic) >> 32) == seg / uint32_t(g.colsT);
+                    b.off[k] = c->fids[q + k];
+                    b.thr[k] = c->thrs[q + k];
+                }
+                for (int k = 0; k < 4; k++)
+                {
+                    b.hs[k] = c->hs[q + 3 + k];
+                }
+                tailNodes[size_t(t)] = b;
+            }
+            cs.aTB = tsF.aTB;
+            cs.d_tileNodesS = tsF.d_tileNodesS;
+            cs.d_tileNodes = tsF.d_tileNodes;
+            cs.d_tiles = tsF.d_tiles;
+            cs.nTiles = tsF.nTiles;
+            cs.geom = g;
+            cs.tailWaves = tw;
+            cs.tailSlab = tailSlab;
+            cs.tailPad = (std::max(p.nTrees - g.b[4], 1) + 63) / 64 * 64;
+            cs.tailBlocks = std::max(512, c->maxBatch);
+            // k_cascade_tail3 only takes queue overflow now: its LDS stays small (footprint slabs only, node table from
+            // L2) so that its blocks — which leave at once in the normal case — never wait for a whole CU's LDS while
+            // other streams' kernels are resident (measured: up to 2.7 ms of queueing per launch with 156 KB blocks)
+            cs.tailNodesLds = 0;
+            if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
+            {
+                return rc;
+            }
+            cs.codeCap = 0;
+            if (g.b[4] < p.nTrees && !getenv("ACF_HIP_TAIL3")) // A/B: ACF_HIP_TAIL3 sends every tail window to k_cascade_tail3
+            {
+                const int nT = p.nTrees - g.b[4];
+                cs.codePitch = (nT + 63) / 64 * 64; // stage E writes whole 64-tree batches
+                int64_t nWinTotal = 0;
+                for (const auto& l : lv)
+                {
+                    nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
+                }
+                // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
+                // images), at most 256 MB for the batch (the rows are touched per survivor: ~1k of them per 1080p
+                // frame); whatever is beyond goes to k_cascade_tail3, and so does everything if the buffer cannot be had
+                int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
+                cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
+                cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
+                cs.codeCap = int(cap);
+                void* codes = nullptr;
+                if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch)) == hipSuccess)
+                {
+                    c->allocs.push_back(codes);
+                    cs.d_tailCodes = static_cast<uint8_t*>(codes);
+                }
+                else
+                {
+                    (void)hipGetLastError();
+                    cs.codeCap = 0;
                 }
             }
-            for (size_t i = 0; i < lv.size() && ok; i++)
+            if ((rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
             {
-                for (int c0 = 0; c0 < lv[i].nWinC; c0 += g.TC)
-                {
-                    for (int r0 = 0; r0 < lv[i].nWinR; r0 += g.TR)
-                    {
-                        if (r0 > 32767 || c0 > 32767)
-                        {
-                            ok = false;
-                            break;
-                        }
-                        CascTile t{};
-                        t.level = int16_t(i);
-                        t.r0 = int16_t(r0);
-                        t.c0 = int16_t(c0);
-                        tiles.push_back(t);
-                    }
-                }
+                return rc;
             }
-            if (ok)
+            cs.useTiles = true;
+            // ---- the same tiles over threshold-rank cells (16 bits per cell): half the fill, half the LDS
+            if (wantRank && !getenv("ACF_HIP_NO_RANK"))
             {
-                std::vector<TreeNode> tileNodes(size_t(std::max(p.nTrees, 1))), tailNodes(size_t(p.nTrees));
-                for (int t = 0; t < p.nTrees; t++)
+                std::vector<int32_t> chnOfNode(nNodes, -1);
+                for (size_t q = 0; q < nNodes; q++)
                 {
-                    const size_t q = size_t(t) * p.nTreeNodes;
-                    TreeNode a{}, b{};
-                    for (int k = 0; k < 3; k++)
+                    if (internal[q])
                     {
-                        const uint32_t f = c->fids[q + k];
-                        const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
-                        a.off[k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
-                        b.off[k] = f;
-                        a.thr[k] = b.thr[k] = c->thrs[q + k];
-                    }
-                    for (int k = 0; k < 4; k++)
-                    {
-                        a.hs[k] = b.hs[k] = c->hs[q + 3 + k];
-                    }
-                    tileNodes[size_t(t)] = a;
-                    tailNodes[size_t(t)] = b;
-                }
-                // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
-                // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC: ACF_HIP_TILE_TB8 for the A/B)
-                const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
-                const int nTreesS = g.b[1] / aTB * aTB;
-                std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
-                for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
-                {
-                    uint32_t* d = nodesS.data() + size_t(t / aTB) * 10 * aTB;
-                    for (int q = 0; q < aTB; q++)
-                    {
-                        const TreeNode& nd = tileNodes[size_t(t + q)];
-                        for (int k = 0; k < 3; k++)
-                        {
-                            d[3 * q + k] = nd.off[k];
-                            memcpy(&d[3 * aTB + 3 * q + k], &nd.thr[k], 4);
-                        }
-                        for (int k = 0; k < 4; k++)
-                        {
-                            memcpy(&d[6 * aTB + 4 * q + k], &nd.hs[k], 4);
-                        }
+                        chnOfNode[q] = int32_t(c->fids[q] / uint32_t(mWc * mHc));
                     }
                 }
-                cs.aTB = aTB;
-                if ((rc = devUpload(c, &cs.d_tileNodesS, nodesS)))
+                RankTables rt;
+                buildRankTables(c->thrs.data(), chnOfNode.data(), nNodes, nChns, rt);
+                TileSet tsR;
+                if (rt.ok && (rc = buildTileSet(c, lv, nChns, &rt, tsR)))
                 {
                     return rc;
                 }
-                cs.geom = g;
-                cs.tailWaves = tw;
-                cs.tailSlab = tailSlab;
-                cs.tailPad = (std::max(p.nTrees - g.b[4], 1) + 63) / 64 * 64;
-                cs.tailBlocks = std::max(512, c->maxBatch);
+                if (rt.ok && tsR.ok)
                 {
-                    // node table of the tail in LDS if it fits beside the footprint slabs (TreeNode = 12 dwords)
-                    const int64_t nodeFloats = int64_t(std::max(p.nTrees - g.b[4], 0)) * 12;
-                    cs.tailNodesLds = 0;
-                    // k_cascade_tail3 only takes queue overflow now: keep its LDS small (footprint slabs only, node table from
-                    // L2) so that its blocks — which leave at once in the normal case — never wait for a whole CU's LDS while
-                    // other streams' kernels are resident (measured: up to 2.7 ms of queueing per launch with 156 KB blocks)
-                    (void)nodeFloats;
-                }
-                if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
-                {
-                    return rc;
-                }
-                cs.codeCap = 0;
-                if (g.b[4] < p.nTrees && !getenv("ACF_HIP_TAIL3")) // A/B: ACF_HIP_TAIL3 sends every tail window to k_cascade_tail3
-                {
+                    // rank pyramid layout: per level nChns planes [wP][pitchR], pitchR = hP rounded up to 8 cells (16 bytes)
+                    std::vector<RankJob> jobs(lv.size());
+                    int64_t off = 0;
+                    cs.rankMaxWP = 0;
+                    for (size_t i = 0; i < lv.size(); i++)
                     {
-                        const int nT = p.nTrees - g.b[4];
-                        cs.codePitch = (nT + 63) / 64 * 64; // stage E writes whole 64-tree batches
-                        int64_t nWinTotal = 0;
-                        for (const auto& l : lv)
-                        {
-                            nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
-                        }
-                        // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
-                        // images), at most 256 MB for the batch (the rows are touched per survivor: ~1k of them per 1080p
-                        // frame); whatever is beyond goes to k_cascade_tail3, and so does everything if the buffer cannot be had
-                        int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
-                        cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
-                        cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
-                        cs.codeCap = int(cap);
-                        void* codes = nullptr;
-                        if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch)) == hipSuccess)
-                        {
-                            c->allocs.push_back(codes);
-                            cs.d_tailCodes = static_cast<uint8_t*>(codes);
-                        }
-                        else
-                        {
-                            (void)hipGetLastError();
-                            cs.codeCap = 0;
-                        }
+                        const int pitch = (lv[i].hP + 7) / 8 * 8;
+                        cl[i].offR = off;
+                        cl[i].pitchR = pitch;
+                        jobs[i].src_off = lv[i].offset;
+                        jobs[i].dst_off = off;
+                        jobs[i].hP = lv[i].hP;
+                        jobs[i].wP = lv[i].wP;
+                        jobs[i].pitchR = pitch;
+                        off += int64_t(nChns) * pitch * lv[i].wP;
+                        cs.rankMaxWP = std::max(cs.rankMaxWP, lv[i].wP);
                     }
+                    cs.pyrRCells = off;
+                    cs.geomR = tsR.g;
+                    cs.d_tilesR = tsR.d_tiles;
+                    cs.nTilesR = tsR.nTiles;
+                    cs.d_tileNodesR = tsR.d_tileNodes;
+                    cs.d_tileNodesSR = tsR.d_tileNodesS;
+                    cs.rankMaxLut = rt.maxLut;
+                    cs.rankMaxThr = rt.maxThr;
+                    // + slack: a tile's 16-byte fill chunks run up to rowsP cells past the last column of the last plane
+                    if ((rc = devUpload(c, &cs.d_rankChan, rt.chan)) || (rc = devUpload(c, &cs.d_rankLut, rt.lut)) || (rc = devUpload(c, &cs.d_rankThr, rt.thr)) ||
+                        (rc = devUpload(c, &cs.d_rankJobs, jobs)) || (rc = devAlloc(c, &cs.d_pyrR, size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096)))
+                    {
+                        return rc;
+                    }
+                    HIPCHK(c, hipMemset(cs.d_pyrR, 0, (size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096) * sizeof(uint16_t))); // pitch padding cells: defined
+                    // the level table again, now with the rank layout
+                    HIPCHK(c, hipMemcpy(*d_levels, cl.data(), cl.size() * sizeof(CascLevel), hipMemcpyHostToDevice));
+                    cs.useRank = true;
                 }
-                cs.nTiles = int(tiles.size());
-                if ((rc = devUpload(c, &cs.d_tiles, tiles)) || (rc = devUpload(c, &cs.d_tileNodes, tileNodes)) || (rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
-                {
-                    return rc;
-                }
-                cs.useTiles = true;
             }
         }
     }
@@ -1482,6 +1624,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->taps = c->taps;
             k->profile = c->profile;
             k->noTiles = c->noTiles;
+            k->noRank = c->noRank;
             k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
@@ -1911,7 +2054,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     const std::vector<acf_hip_level>& cascLevels = p.ldcfK > 0 ? c->ldcfLevels : pl.levels;
     {
         ShrinkScope ss(c, p.ldcfK > 0 ? 2 : 1);
-        if ((rc = buildCascadeTables(c, cascLevels, pl.nChns * std::max(p.ldcfK, 1), c->cs)))
+        if ((rc = buildCascadeTables(c, cascLevels, pl.nChns * std::max(p.ldcfK, 1), c->cs, p.ldcfK <= 0)))
         {
             return rc;
         }
@@ -2752,6 +2895,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     prof(c, "(end)");
     c->lastBatch = nF;
     c->pyramidValid = true;
+    c->ranksValid = false; // (no level kernel has written rank cells: the cascade converts the float pyramid first)
     return ACF_HIP_OK;
 }
 } // namespace
@@ -2817,29 +2961,68 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     if (a.debug & 12)
     {
         a.debug |= 4;
-        const int64_t total = int64_t(cs.nTiles) * nF;
+        const int64_t total = int64_t(std::max(cs.nTiles, cs.nTilesR)) * nF;
         HIPCHK(c, hipMalloc(&a.stamps, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long)));
         HIPCHK(c, hipMemsetAsync(a.stamps, 0, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long), c->stream));
     }
+    const bool rank = cs.useRank && !c->noRank && pyr == c->d_pyr;
+    if (rank && !c->ranksValid)
+    {
+        // the float pyramid -> threshold-rank cells (levels whose kernels did not emit them)
+        int rc = 0;
+        const size_t ldsR = size_t(cs.rankMaxLut) * 2 + size_t(cs.rankMaxThr) * 4;
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_rank), ldsR)))
+        {
+            return rc;
+        }
+        prof(c, "k_rank");
+        hipLaunchKernelGGL(k_rank, dim3(cdiv(cs.rankMaxWP, RANK_CHUNK_COLS), int(c->plan.levels.size()) * nChns, nF), dim3(256), ldsR, c->stream, pyr, pyr_fs,
+            cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const uint16_t*)cs.d_rankLut, (const float*)cs.d_rankThr,
+            cs.rankMaxLut);
+        LAUNCHCHK(c, "k_rank");
+        c->ranksValid = true;
+    }
     if (cs.nTiles > 0)
     {
-        const int64_t total = int64_t(cs.nTiles) * nF;
+        TileArgs at = a; // the tile kernel's view: the rank form has its own tile geometry, tile list and node records
+        if (rank)
+        {
+            at.pyrR = cs.d_pyrR;
+            at.pyrR_fs = cs.pyrRCells;
+            at.g = cs.geomR;
+            at.tiles = cs.d_tilesR;
+            at.nTiles = cs.nTilesR;
+            at.tileNodes = cs.d_tileNodesR;
+            at.tileNodesS = cs.d_tileNodesSR;
+        }
+        const TileGeom& gt = at.g;
+        const int64_t total = int64_t(at.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(g.tileFloats) * 4 + size_t(g.NW) * 64 * 8;
-        dim3 grid((unsigned int)(perX * 8)), block(g.NW * 64);
+        const size_t lds = size_t(gt.tileFloats) * (rank ? 2 : 4) + size_t(gt.NW) * 64 * 8;
+        dim3 grid((unsigned int)(perX * 8)), block(gt.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");
-#define TILE2_LAUNCH(N)                                                                           \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N>), lds)))              \
-        return rc;                                                                                \
-    hipLaunchKernelGGL((k_cascade_tile2<N>), grid, block, lds, c->stream, a);
-        switch (g.NW)
+#define TILE2_LAUNCH(N, CT)                                                                           \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N, CT>), lds)))              \
+        return rc;                                                                                    \
+    hipLaunchKernelGGL((k_cascade_tile2<N, CT>), grid, block, lds, c->stream, at);
+#define TILE2_NW(CT)                              \
+    switch (gt.NW)                                \
+    {                                             \
+        case 8: TILE2_LAUNCH(8, CT); break;       \
+        case 4: TILE2_LAUNCH(4, CT); break;       \
+        case 2: TILE2_LAUNCH(2, CT); break;       \
+        default: TILE2_LAUNCH(1, CT); break;      \
+    }
+        if (rank)
         {
-            case 8: TILE2_LAUNCH(8); break;
-            case 4: TILE2_LAUNCH(4); break;
-            case 2: TILE2_LAUNCH(2); break;
-            default: TILE2_LAUNCH(1); break;
+            TILE2_NW(CellRank);
         }
+        else
+        {
+            TILE2_NW(CellF32);
+        }
+#undef TILE2_NW
 #undef TILE2_LAUNCH
         LAUNCHCHK(c, "k_cascade_tile");
         if (a.debug & 4)
@@ -3940,6 +4123,88 @@ int acf_hip_read_level(acf_hip_ctx* c, int frame, int level, float* host_out)
     const acf_hip_level& l = c->plan.levels[level];
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(host_out, c->d_pyr + size_t(frame) * c->plan.pyr_floats + l.offset, sizeof(float) * c->plan.nChns * l.hP * l.wP, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_read_rank_level(acf_hip_ctx* c, int frame, int level, uint16_t* host_out)
+{
+    if (c && !c->kids.empty())
+    {
+        if (frame < 0 || frame >= c->lastBatch)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "frame index");
+        }
+        acf_hip_ctx* k = c->kids[size_t(frame / c->kidChunk)];
+        const int rc = acf_hip_read_rank_level(k, frame % c->kidChunk, level, host_out);
+        return rc ? kidFail(c, k, rc) : rc;
+    }
+    if (!c || !c->hasPlan)
+    {
+        return ACF_HIP_E_NOPLAN;
+    }
+    if (!c->cs.useRank || c->noRank)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "read_rank_level: the plan has no rank cells (model not depth 2 / thresholds too dense / option rank_cells off / LDCF)");
+    }
+    if (!c->pyramidValid || !c->ranksValid || frame < 0 || frame >= c->lastBatch || level < 0 || level >= int(c->plan.levels.size()) || !host_out)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "read_rank_level: arguments, or no detect since the last pyramid");
+    }
+    const acf_hip_level& l = c->plan.levels[level];
+    const int pitch = (l.hP + 7) / 8 * 8;
+    int64_t off = 0;
+    for (int i = 0; i < level; i++)
+    {
+        off += int64_t(c->plan.nChns) * ((c->plan.levels[i].hP + 7) / 8 * 8) * c->plan.levels[i].wP;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(host_out, size_t(l.hP) * 2, c->cs.d_pyrR + size_t(frame) * c->cs.pyrRCells + off, size_t(pitch) * 2, size_t(l.hP) * 2,
+        size_t(c->plan.nChns) * l.wP, hipMemcpyDeviceToHost));
+    return ACF_HIP_OK;
+}
+
+int acf_hip_rank_cells_host(const acf_hip_params* p, int nChns, int chn, const float* v, int n, uint16_t* cells_out, uint32_t* thr_index_out, int32_t* info)
+{
+    if (!p || !p->fids || !p->thrs || nChns <= 0 || chn < 0 || chn >= nChns || n < 0 || (n > 0 && !v) || p->treeDepth <= 0 || p->shrink <= 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    const int mH = p->modelDsPad_h / p->shrink, mW = p->modelDsPad_w / p->shrink;
+    if (mH <= 0 || mW <= 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    const size_t nNodes = size_t(p->nTrees) * p->nTreeNodes;
+    std::vector<int32_t> chnOfNode(nNodes, -1);
+    for (int t = 0; t < p->nTrees; t++)
+    {
+        for (int k = 0; k < (1 << p->treeDepth) - 1 && k < p->nTreeNodes; k++)
+        {
+            const size_t q = size_t(t) * p->nTreeNodes + k;
+            chnOfNode[q] = int32_t(p->fids[q] / uint32_t(mW * mH));
+        }
+    }
+    RankTables rt;
+    buildRankTables(p->thrs, chnOfNode.data(), nNodes, nChns, rt);
+    if (info)
+    {
+        info[0] = rt.ok ? 1 : 0;
+        info[1] = rt.ok ? rt.chan[size_t(chn)].shift : 0;
+        info[2] = rt.ok ? rt.chan[size_t(chn)].nb : 0;
+        info[3] = rt.ok ? rt.chan[size_t(chn)].nThr : 0;
+    }
+    if (!rt.ok)
+    {
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < n && cells_out; i++)
+    {
+        cells_out[i] = uint16_t(rt.rankOfCell(chn, v[i]));
+    }
+    for (size_t q = 0; q < nNodes && thr_index_out; q++)
+    {
+        thr_index_out[q] = chnOfNode[q] >= 0 ? rt.rankOfThreshold(chnOfNode[q], p->thrs[q]) : 0u;
+    }
     return ACF_HIP_OK;
 }
 

@@ -473,4 +473,155 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
     return ACF_HIP_OK;
 }
 
+
+// ---- threshold-rank cells (host_plan.h) ------------------------------------------------------------------------------
+namespace
+{
+inline int32_t rankKey(float v)
+{
+    int32_t b;
+    std::memcpy(&b, &v, 4);
+    return b > 0 ? b : 0;
+}
+inline int rankBucket(const RankChan& c, float v)
+{
+    const int b = (rankKey(v) >> c.shift) - c.base;
+    return b < 0 ? 0 : (b > c.nb - 1 ? c.nb - 1 : b);
+}
+} // namespace
+
+uint32_t RankTables::rankOfCell(int chn, float v) const
+{
+    const RankChan& c = chan[size_t(chn)];
+    const uint32_t lo = lut[size_t(c.lutOff) + size_t(rankBucket(c, v))];
+    const float* t = thr.data() + c.thrOff;
+    uint32_t pos = lo;
+    pos += (t[pos + 3] <= v) ? 4u : 0u;
+    pos += (t[pos + 1] <= v) ? 2u : 0u;
+    pos += (t[pos] <= v) ? 1u : 0u;
+    return pos;
+}
+
+uint32_t RankTables::rankOfThreshold(int chn, float t) const
+{
+    const RankChan& c = chan[size_t(chn)];
+    if (!(t == t))
+    {
+        return 0; // `ftr < NaN` is never true
+    }
+    const float* b = thr.data() + c.thrOff;
+    return uint32_t(std::lower_bound(b, b + c.nThr, t) - b) + 1u; // t is one of the channel's thresholds: index + 1
+}
+
+void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes, int nChns, RankTables& out)
+{
+    out = RankTables();
+    out.chan.assign(size_t(nChns), RankChan{});
+    std::vector<std::vector<float>> per(static_cast<size_t>(nChns));
+    for (size_t q = 0; q < nNodes; q++)
+    {
+        const int z = chnOfNode[q];
+        if (z < 0)
+        {
+            continue;
+        }
+        if (z >= nChns)
+        {
+            out.why = "feature channel out of range";
+            return;
+        }
+        const float t = thrs[q];
+        if (t == t) // NaN thresholds have no rank (never true)
+        {
+            per[size_t(z)].push_back(t == 0.f ? 0.f : t); // -0.0 and +0.0 are one threshold
+        }
+    }
+    for (int z = 0; z < nChns; z++)
+    {
+        std::vector<float>& t = per[size_t(z)];
+        std::sort(t.begin(), t.end());
+        t.erase(std::unique(t.begin(), t.end()), t.end());
+        out.chan[size_t(z)].nThr = int32_t(t.size());
+        if (t.size() > 65534)
+        {
+            out.why = "more than 65534 distinct thresholds in one channel";
+            return;
+        }
+    }
+    // per channel: the largest shift (smallest table) whose buckets hold at most `scan` thresholds each
+    auto shiftFor = [&](const std::vector<float>& t, int scan) -> int {
+        for (int shift = 30; shift >= 0; shift--)
+        {
+            if (t.empty())
+            {
+                return shift;
+            }
+            const int64_t kLo = rankKey(t.front()) >> shift, kHi = rankKey(t.back()) >> shift;
+            if (kHi - kLo + 3 > RANK_MAX_BUCKETS)
+            {
+                return -1; // finer buckets only get more numerous
+            }
+            int run = 0, worst = 0;
+            int64_t prev = -1;
+            for (float v : t)
+            {
+                const int64_t k = rankKey(v) >> shift;
+                run = (k == prev) ? run + 1 : 1;
+                prev = k;
+                worst = std::max(worst, run);
+            }
+            if (worst <= scan)
+            {
+                return shift;
+            }
+        }
+        return -1;
+    };
+    std::vector<int> shifts(static_cast<size_t>(nChns), -1);
+    for (int z = 0; z < nChns; z++)
+    {
+        shifts[size_t(z)] = shiftFor(per[size_t(z)], RANK_WINDOW);
+        if (shifts[size_t(z)] < 0)
+        {
+            out.why = "thresholds of a channel too dense for the bucket table (more than RANK_WINDOW per bucket at RANK_MAX_BUCKETS buckets)";
+            return;
+        }
+    }
+    for (int z = 0; z < nChns; z++)
+    {
+        const std::vector<float>& t = per[size_t(z)];
+        RankChan& c = out.chan[size_t(z)];
+        const int best = shifts[size_t(z)];
+        c.shift = best;
+        // bucket 0 lies below every threshold's bucket, bucket nb - 1 above: values outside the thresholds' range clamp into them
+        c.base = t.empty() ? 0 : int32_t((rankKey(t.front()) >> best) - 1);
+        c.nb = t.empty() ? 1 : int32_t((rankKey(t.back()) >> best) - c.base + 2);
+        c.lutOff = int32_t(out.lut.size());
+        c.thrOff = int32_t(out.thr.size());
+        out.lut.resize(out.lut.size() + size_t(c.nb) + (size_t(c.nb) & 1u), 0); // channels start on 4-byte boundaries
+        uint16_t* lut = out.lut.data() + c.lutOff;
+        size_t j = 0;
+        for (int b = 0; b < c.nb; b++)
+        {
+            while (j < t.size() && rankBucket(c, t[j]) < b)
+            {
+                j++;
+            }
+            lut[b] = uint16_t(j); // thresholds in lower buckets
+        }
+        if ((size_t(c.nb) & 1u) != 0)
+        {
+            lut[c.nb] = uint16_t(t.size());
+        }
+        out.thr.insert(out.thr.end(), t.begin(), t.end());
+        for (int k = 0; k < RANK_PAD; k++)
+        {
+            out.thr.push_back(std::numeric_limits<float>::infinity());
+        }
+        out.maxLut = std::max(out.maxLut, c.nb + (c.nb & 1));
+        out.maxThr = std::max(out.maxThr, c.nThr + RANK_PAD);
+    }
+    out.ok = true;
+}
+
 } // namespace acfhip

@@ -93,6 +93,51 @@ struct Plan
 
 int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err);
 
+// ---- threshold-rank cells (the cascade's 16-bit pyramid) --------------------------------------------------------------
+// The cascade only ever evaluates `chns[cid] < thrs[node]` (acfDetect1.cpp:102-104,157-166).  Per channel, let
+// t_0 < t_1 < ... < t_{m-1} be the distinct thresholds of the model's nodes whose feature lies in that channel, and
+//     rank(v) = #{ j : t_j <= v }            (0 .. m, a 16-bit value for m <= 65534).
+// Then for every cell value v and every node threshold t_k:   v < t_k  <=>  rank(v) <= k  <=>  rank(v) < k + 1,
+// so a pyramid of rank cells compared against `k + 1` gives the cascade exactly the decisions of the float pyramid: same
+// leaves, same sums, same hits, in half the bytes.  rank(v) needs no search over the whole list: a table indexed by the
+// top bits of v's (order-preserving) bit pattern gives the number of thresholds in lower buckets, and the value's own
+// bucket — at most RANK_WINDOW = 7 thresholds — is resolved by three branch-free bisection steps,
+//     key = max(int(bits(v)), 0);  b = clamp((key >> shift) - base, 0, nb - 1);  pos = lut[b];
+//     pos += 4 * (thr[pos + 3] <= v);  pos += 2 * (thr[pos + 1] <= v);  pos += (thr[pos] <= v);  rank = pos
+// (thr is padded with +inf; thresholds of later buckets are > v, so the seven-entry window may run past the bucket's own).
+// Exact for every finite v provided no bucket holds more than RANK_WINDOW thresholds, which buildRankTables guarantees by
+// its choice of each channel's `shift` (the largest, i.e. the smallest table, that does), or reports as not possible within
+// RANK_MAX_BUCKETS entries (ok = false: the float pyramid stays the cascade's input).  Negative values and -0.0 share
+// bucket 0 with +0.0 (the direct compares keep them apart).
+constexpr int RANK_WINDOW = 7;
+constexpr int RANK_PAD = 8; // +inf entries after a channel's thresholds
+constexpr int RANK_MAX_BUCKETS = 4096;
+
+struct RankChan
+{
+    int32_t shift, base, nb; // bucket function
+    int32_t lutOff;          // first entry of this channel in RankTables::lut
+    int32_t thrOff;          // first entry of this channel in RankTables::thr (nThr values + RANK_PAD x +inf)
+    int32_t nThr;
+    int32_t pad_[2];
+};
+
+struct RankTables
+{
+    bool ok = false;
+    std::string why; // ok == false: what ruled the rank cells out
+    std::vector<RankChan> chan;
+    std::vector<uint16_t> lut;
+    std::vector<float> thr;
+    int maxLut = 0, maxThr = 0; // largest per-channel table sizes (entries incl. padding): the kernels' LDS budget
+
+    uint32_t rankOfCell(int chn, float v) const;      // host mirror of the device function (tests, op entry)
+    uint32_t rankOfThreshold(int chn, float t) const; // k + 1 of the text above (0: never true, nThr + 1: true for every finite cell)
+};
+
+// chnOfNode[q] >= 0: node q tests a feature of that channel (fids[q] / (mW * mH)); < 0: not a feature test (leaf)
+void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes, int nChns, RankTables& out);
+
 int colorPlanes(const acf_hip_params& p);
 int numChannels(const acf_hip_params& p);
 

@@ -2253,6 +2253,85 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------
+// Threshold-rank cells (host_plan.h): rank(v) = number of the channel's distinct node thresholds <= v, the 16-bit cell
+// the cascade tile kernel reads.  `lut`/`thr` are the CHANNEL's tables (in LDS): lut[b] = thresholds in buckets below b,
+// thr = the sorted thresholds + RANK_PAD x +inf.
+// ------------------------------------------------------------------------
+struct RankFn
+{
+    int32_t shift, base, nbm1;
+};
+__device__ __forceinline__ uint32_t rank_cell(float v, const RankFn& f, const uint16_t* lut, const float* thr)
+{
+    const int key = max(__float_as_int(v), 0);
+    const int b = min(max((key >> f.shift) - f.base, 0), f.nbm1);
+    uint32_t pos = lut[b];
+    static_assert(RANK_WINDOW == 7, "three bisection steps");
+    pos += thr[pos + 3] <= v ? 4u : 0u;
+    pos += thr[pos + 1] <= v ? 2u : 0u;
+    pos += thr[pos] <= v ? 1u : 0u;
+    return pos;
+}
+
+// copy a channel's tables into LDS: [lut: maxLut u16][thr: maxThr f32]; returns the bucket function
+__device__ __forceinline__ RankFn rank_tables_to_lds(const RankChan& rc, const uint16_t* __restrict__ lutG, const float* __restrict__ thrG,
+    uint16_t* lutL, float* thrL, int tid, int nThreads)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lutG + rc.lutOff); // channels start on 4-byte boundaries, padded to even
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lutL);
+    for (int i = tid; i < (rc.nb + 1) / 2; i += nThreads)
+    {
+        dst[i] = src[i];
+    }
+    for (int i = tid; i < rc.nThr + RANK_PAD; i += nThreads)
+    {
+        thrL[i] = thrG[rc.thrOff + i];
+    }
+    RankFn f;
+    f.shift = rc.shift;
+    f.base = rc.base;
+    f.nbm1 = rc.nb - 1;
+    return f;
+}
+
+// Stand-alone form: the fused float pyramid -> rank cells, one workgroup per (64-column chunk, level x channel, frame).
+// Used when the level kernels that emit rank cells themselves do not cover the plan (and by the parity tests of both).
+struct RankJob
+{
+    int64_t src_off; // float offset of the level in one frame's fused pyramid
+    int64_t dst_off; // cell offset of the level in one frame's rank pyramid
+    int32_t hP, wP, pitchR, pad_;
+};
+constexpr int RANK_CHUNK_COLS = 64;
+__global__ void __launch_bounds__(256) k_rank(const float* __restrict__ pyr, int64_t pyr_fs, uint16_t* __restrict__ out, int64_t out_fs,
+    const RankJob* __restrict__ jobs, int nChns, const RankChan* __restrict__ chan, const uint16_t* __restrict__ lutG, const float* __restrict__ thrG, int maxLut)
+{
+    extern __shared__ float lds[];
+    const int lvl = blockIdx.y / nChns, z = blockIdx.y - lvl * nChns;
+    const RankJob J = jobs[lvl];
+    const int c0 = blockIdx.x * RANK_CHUNK_COLS;
+    if (c0 >= J.wP)
+    {
+        return;
+    }
+    uint16_t* lutL = reinterpret_cast<uint16_t*>(lds);
+    float* thrL = lds + maxLut / 2;
+    const RankFn fn = rank_tables_to_lds(chan[z], lutG, thrG, lutL, thrL, threadIdx.x, 256);
+    __syncthreads();
+    const float* __restrict__ src = pyr + int64_t(blockIdx.z) * pyr_fs + J.src_off + int64_t(z) * J.hP * J.wP;
+    uint16_t* __restrict__ dst = out + int64_t(blockIdx.z) * out_fs + J.dst_off + int64_t(z) * J.pitchR * J.wP;
+    const int c1 = min(c0 + RANK_CHUNK_COLS, J.wP);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = c0 + wv; c < c1; c += 4)
+    {
+        for (int r = lane; r < J.hP; r += 64)
+        {
+            dst[int64_t(c) * J.pitchR + r] = uint16_t(rank_cell(src[int64_t(c) * J.hP + r], fn, lutL, thrL));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // Fused level kernel: approximated-scale resample (chnsPyramid.cpp:385-397) +
 // final convTri1 smoothing with the in-place aliasing (:399-407) + placement in
 // the padded, fused pyramid (:410-435), one pass, no intermediate plane.
@@ -3259,6 +3338,9 @@ struct CascLevel
     int32_t nWin;
     int64_t off;        // level offset in the fused pyramid
     int64_t nodeOff;    // generic path: offset of this level's cid table
+    int64_t offR;       // rank pyramid (16-bit cells): cell offset of the level inside one frame (a multiple of 8)
+    int32_t pitchR;     // rank pyramid: cells between columns (hP rounded up to 8: every column starts on 16 bytes)
+    int32_t padR_;
 };
 
 struct __attribute__((aligned(16))) CascNode2
@@ -3681,6 +3763,8 @@ struct TileArgs
 {
     const float* pyr;
     int64_t pyr_fs;
+    const uint16_t* pyrR; // threshold-rank cells (host_plan.h): what k_cascade_tile2<NW, CellRank> reads instead of `pyr`
+    int64_t pyrR_fs;
     const CascLevel* levels;
     const CascTile* tiles;
     int32_t nTiles, nFrames, nChns, mH, mW, nTrees;
@@ -3757,12 +3841,34 @@ struct LaneNode
 // ------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) uint32_t* cu32p_t;
 
+// What a cell of the tile is.  CellF32: the fused pyramid's floats, node thresholds as float bits.  CellRank: 16-bit
+// threshold ranks (host_plan.h, "threshold-rank cells"), node thresholds as rank indices: `rank(v) < k + 1` is `v < t_k`
+// for every cell and every node of the model, so both forms take the same branch at every node, add the same leaves in
+// the same order and stop at the same tree — in half the LDS and half the fill bytes.
+struct CellF32
+{
+    typedef float cell_t;
+    typedef float val_t;
+    static constexpr int CPB = 4; // cells per 16-byte fill chunk
+    static constexpr bool RANK = false;
+    static __device__ __forceinline__ val_t thr(uint32_t bits) { return __uint_as_float(bits); }
+};
+struct CellRank
+{
+    typedef uint16_t cell_t;
+    typedef uint32_t val_t;
+    static constexpr int CPB = 8;
+    static constexpr bool RANK = true;
+    static __device__ __forceinline__ val_t thr(uint32_t bits) { return bits; }
+};
+
 // Stage A.  tab: per batch of TB trees 10 * TB dwords {off[TB][3], thr[TB][3], hs[TB][4]} (host: buildCascadeTables).
 // All 3 * TB feature reads of a batch are issued before anything is resolved; the thresholds and leaf values arrive
 // (s_load) while those reads are in flight, and the next batch's offsets while this batch is resolved.
-template <int TB>
-__device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
+template <int TB, class CT>
+__device__ __forceinline__ void tile_eval_s(const typename CT::cell_t* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
 {
+    typedef typename CT::val_t val_t;
     cu32p_t p = (cu32p_t)(uintptr_t)tab;
     uint32_t o[3 * TB];
 #pragma unroll
@@ -3774,11 +3880,11 @@ __device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __
     float hMin = __builtin_inff();
     for (int b = 0; b < nBatches; b++)
     {
-        float f[3 * TB];
+        val_t f[3 * TB];
 #pragma unroll
         for (int i = 0; i < 3 * TB; i++)
         {
-            f[i] = win[o[i]];
+            f[i] = val_t(win[o[i]]);
         }
         cu32p_t pb = p + 10 * TB * b;
         uint32_t th[3 * TB], hv4[4 * TB];
@@ -3819,9 +3925,9 @@ __device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __
             for (int q = 0; q < 2; q++)
             {
                 const int t = g + q;
-                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * t] < __uint_as_float(th[3 * t]));
-                const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * t + 1] < __uint_as_float(th[3 * t + 1]));
-                const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * t + 2] < __uint_as_float(th[3 * t + 2]));
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * t] < CT::thr(th[3 * t]));
+                const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * t + 1] < CT::thr(th[3 * t + 1]));
+                const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * t + 2] < CT::thr(th[3 * t + 2]));
                 float hOut;
                 const float hIn = q == 0 ? h : h1;
                 asm volatile("s_and_b64 exec, %[m0], %[mA]\n\t"
@@ -3854,19 +3960,21 @@ __device__ __forceinline__ void tile_eval_s(const float* win, const uint32_t* __
 }
 
 // one tree at a time through the TreeNode table (stage A trees beyond the last full batch of four)
-__device__ __forceinline__ void tile_eval_s1(const float* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h, bool& alive)
+template <class CT>
+__device__ __forceinline__ void tile_eval_s1(const typename CT::cell_t* win, const TreeNode* __restrict__ nodes, int t0, int t1, float thrC, float& h, bool& alive)
 {
+    typedef typename CT::val_t val_t;
     for (int t = t0; t < t1; t++)
     {
         cptr4_t np = (cptr4_t)(uintptr_t)(nodes + t);
         const u32x4 o = np[0], tq = np[1], hq = np[2];
-        float f0 = win[o.x], f1 = win[o.y], f2 = win[o.z];
+        val_t f0 = val_t(win[o.x]), f1 = val_t(win[o.y]), f2 = val_t(win[o.z]);
         ACF_PIN_V(f0);
         ACF_PIN_V(f1);
         ACF_PIN_V(f2);
-        const bool lt0 = f0 < __uint_as_float(tq.x);
-        const float fc = lt0 ? f1 : f2;
-        const float th1 = __uint_as_float(lt0 ? tq.y : tq.z);
+        const bool lt0 = f0 < CT::thr(tq.x);
+        const val_t fc = lt0 ? f1 : f2;
+        const val_t th1 = CT::thr(lt0 ? tq.y : tq.z);
         const bool lt1 = fc < th1;
         const float hv = __uint_as_float(lt0 ? (lt1 ? hq.x : hq.y) : (lt1 ? hq.z : hq.w));
         const float hn = h + hv;
@@ -3917,7 +4025,7 @@ __device__ __forceinline__ int tile_emit2(const TileArgs& a, bool final_, int fr
 
 struct TileCtx
 {
-    const float* tileF;
+    const void* tileF; // the tile's cells (CT::cell_t)
     int step, rowsP, TR;
     float thrC;
     int frame, lvl, r0, c0, nWinR;
@@ -3950,7 +4058,8 @@ __device__ __forceinline__ void row_chain(float leaf, float& a, float& m)
 struct SparseNode
 {
     uint32_t o0, o1, o2;
-    float t0, t1, t2, h0, h1, h2, h3;
+    uint32_t t0, t1, t2; // threshold bits (CT::thr)
+    float h0, h1, h2, h3;
 };
 
 // this lane's tree of a sparse stage over [t0, t0 + T) with 2^tlShift lanes per window (clamped: lanes past T are masked)
@@ -3963,9 +4072,9 @@ __device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ n
     n.o0 = o.x;
     n.o1 = o.y;
     n.o2 = o.z;
-    n.t0 = __uint_as_float(tq.x);
-    n.t1 = __uint_as_float(tq.y);
-    n.t2 = __uint_as_float(tq.z);
+    n.t0 = tq.x;
+    n.t1 = tq.y;
+    n.t2 = tq.z;
     n.h0 = __uint_as_float(hq.x);
     n.h1 = __uint_as_float(hq.y);
     n.h2 = __uint_as_float(hq.z);
@@ -3980,9 +4089,12 @@ __device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ n
 // (row_bcast:15 hands the prefix to the next row).  Lanes past T contribute +0.0f: h is a sum that starts at +0.0f, so
 // it is never -0.0f and h + 0.0f == h bit for bit.  `last`: survivors go to the hit list / tail queue (their
 // {tag, slot} to the list for stage E), else {tag, h}.  Returns the number of entries now in the list.
+template <class CT>
 __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx& X, uint2* list, int nIn, const SparseNode& nd,
     int T, int tlShift, bool last, bool lastAll)
 {
+    typedef typename CT::val_t val_t;
+    typedef typename CT::cell_t cell_t;
     const int lane = threadIdx.x & 63;
     const int TL = 1 << tlShift, G = 64 >> tlShift, K = TL >> 4;
     const int pos = lane & (TL - 1), g = lane >> tlShift;
@@ -3991,7 +4103,8 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
     // the node in registers, opaquely: otherwise `c ? nd.x : nd.y` becomes a load from a selected address of the struct,
     // which keeps the struct in scratch memory
     uint32_t o0 = nd.o0, o1 = nd.o1, o2 = nd.o2;
-    float t0 = nd.t0, t1 = nd.t1, t2 = nd.t2, h0 = nd.h0, h1 = nd.h1, h2 = nd.h2, h3 = nd.h3;
+    uint32_t t0 = nd.t0, t1 = nd.t1, t2 = nd.t2;
+    float h0 = nd.h0, h1 = nd.h1, h2 = nd.h2, h3 = nd.h3;
     ACF_PIN_V(o0);
     ACF_PIN_V(o1);
     ACF_PIN_V(o2);
@@ -4009,11 +4122,11 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
         const bool valid = wi < nIn;
         const uint2 e = list[valid ? wi : base];
         const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
-        const float* win = X.tileF + (cl * X.step) * X.rowsP + rl * X.step;
-        const float f0 = win[o0];
-        const bool lt0 = f0 < t0;
-        const float fc = win[lt0 ? o1 : o2];
-        const float th1 = lt0 ? t1 : t2;
+        const cell_t* win = static_cast<const cell_t*>(X.tileF) + (cl * X.step) * X.rowsP + rl * X.step;
+        const val_t f0 = val_t(win[o0]);
+        const bool lt0 = f0 < CT::thr(t0);
+        const val_t fc = val_t(win[lt0 ? o1 : o2]);
+        const val_t th1 = CT::thr(lt0 ? t1 : t2);
         const bool lt1 = fc < th1;
         float leaf = lt0 ? (lt1 ? h0 : h1) : (lt1 ? h2 : h3);
         leaf = act ? leaf : 0.f;
@@ -4050,13 +4163,17 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
     return nOut;
 }
 
-template <int NW>
+template <int NW, class CT>
 __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
 {
+    typedef typename CT::cell_t cell_t;
+    typedef typename CT::val_t val_t;
+    constexpr int CPB = CT::CPB;
     extern __shared__ float lds[];
     __shared__ int s_cnt[8];
-    float* tileF = lds;
-    uint2* listA = reinterpret_cast<uint2*>(lds + a.g.tileFloats); // NW segments of 64 entries, one per wave
+    cell_t* tileF = reinterpret_cast<cell_t*>(lds);
+    // (tileFloats counts CELLS; cells * sizeof(cell_t) is a multiple of 16 bytes: rowsP is a multiple of CPB)
+    uint2* listA = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + size_t(a.g.tileFloats) * sizeof(cell_t)); // NW segments of 64 entries, one per wave
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
@@ -4073,8 +4190,10 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     const CascLevel L = a.levels[lvl];
     const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
     const int gr0 = T.r0 * step, gc0 = T.c0 * step;
-    const int area = L.hP * L.wP;
-    const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+    const int colPitch = CT::RANK ? L.pitchR : L.hP;
+    const int area = colPitch * L.wP;
+    const cell_t* __restrict__ src0 = (CT::RANK ? reinterpret_cast<const cell_t*>(a.pyrR) + int64_t(frame) * a.pyrR_fs + L.offR
+                                                : reinterpret_cast<const cell_t*>(a.pyr) + int64_t(frame) * a.pyr_fs + L.off) + gr0;
     const int colsValid = min(colsT, L.wP - gc0);
     if (tid < 8)
     {
@@ -4083,7 +4202,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     TILE_STAMP(0);
     // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
     {
-        const uint32_t cps = uint32_t(rowsP) >> 2;
+        const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
         const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
         const int ccMax = colsValid - 1;
         for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
@@ -4095,8 +4214,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 const uint32_t j = q - seg * cps;
                 const uint32_t z = __umulhi(seg, a.g.colsMagic);
                 const int cc = int(seg - z * uint32_t(colsT));
-                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(L.hP) + 4u * j;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + uint32_t(CPB) * q0), 16, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -4142,20 +4261,20 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC;
     float h = 0.f;
     {
-        const float* win = tileF + (c_l * step) * rowsP + r_l * step;
+        const cell_t* win = tileF + (c_l * step) * rowsP + r_l * step;
         const int nb = a.g.b[1] / a.aTB;
         if (nb > 0)
         {
             if (a.aTB == 8)
             {
-                tile_eval_s<8>(win, a.tileNodesS, nb, X.thrC, h, alive);
+                tile_eval_s<8, CT>(win, a.tileNodesS, nb, X.thrC, h, alive);
             }
             else
             {
-                tile_eval_s<4>(win, a.tileNodesS, nb, X.thrC, h, alive);
+                tile_eval_s<4, CT>(win, a.tileNodesS, nb, X.thrC, h, alive);
             }
         }
-        tile_eval_s1(win, a.tileNodes, nb * a.aTB, a.g.b[1], X.thrC, h, alive);
+        tile_eval_s1<CT>(win, a.tileNodes, nb * a.aTB, a.g.b[1], X.thrC, h, alive);
     }
     asm volatile("" ::"v"(h));
     TILE_STAMP_REL(6);
@@ -4195,12 +4314,12 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 {
                     if (t0 == a.g.b[stage])
                     {
-                        nIn = tile_sparse_wave(a, X, seg, nIn, pN[stage - 1], Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave<CT>(a, X, seg, nIn, pN[stage - 1], Tn, tlShift, last, lastAll);
                     }
                     else
                     {
                         const SparseNode nd = sparse_node(a.tileNodes, t0, Tn, tlShift);
-                        nIn = tile_sparse_wave(a, X, seg, nIn, nd, Tn, tlShift, last, lastAll);
+                        nIn = tile_sparse_wave<CT>(a, X, seg, nIn, nd, Tn, tlShift, last, lastAll);
                     }
                 }
             }
@@ -4239,7 +4358,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
         for (int b0 = wv; b0 < nB; b0 += 4 * NW)
         {
             uint32_t o0[4], o1[4], o2[4];
-            float t0[4], t1[4], t2[4];
+            val_t t0[4], t1[4], t2[4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
@@ -4249,9 +4368,9 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                 o0[k] = o.x;
                 o1[k] = o.y;
                 o2[k] = o.z;
-                t0[k] = __uint_as_float(tq.x);
-                t1[k] = __uint_as_float(tq.y);
-                t2[k] = __uint_as_float(tq.z);
+                t0[k] = CT::thr(tq.x);
+                t1[k] = CT::thr(tq.y);
+                t2[k] = CT::thr(tq.z);
             }
 #pragma unroll
             for (int w = 0; w < NW; w++)
@@ -4265,20 +4384,20 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
                         continue; // no code row: k_cascade_tail3 takes this entry
                     }
                     const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
-                    const float* win = tileF + (cl * step) * rowsP + rl * step;
+                    const cell_t* win = tileF + (cl * step) * rowsP + rl * step;
                     uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + slot) * a.codePitch + lane;
-                    float f0[4], fc[4];
+                    val_t f0[4], fc[4];
                     bool lt0[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        f0[k] = win[o0[k]];
+                        f0[k] = val_t(win[o0[k]]);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
                         lt0[k] = f0[k] < t0[k];
-                        fc[k] = win[lt0[k] ? o1[k] : o2[k]];
+                        fc[k] = val_t(win[lt0[k] ? o1[k] : o2[k]]);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++)

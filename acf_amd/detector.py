@@ -224,6 +224,13 @@ class HipDetector:
         self._chk(self.lib.acf_hip_read_level(self.ctx, frame, level, capi.fptr(out)))
         return out
 
+    def read_rank_level(self, frame, level):
+        """The 16-bit threshold-rank cells of one level, as the cascade read them (after detect()/run())."""
+        l = self.levels[level]
+        out = np.zeros((self.nChns, l.wP, l.hP), dtype=np.uint16)
+        self._chk(self.lib.acf_hip_read_rank_level(self.ctx, frame, level, out.ctypes.data_as(C.POINTER(C.c_uint16))))
+        return out
+
     def read_pyramid(self, frame):
         return np.concatenate([self.read_level(frame, i).ravel() for i in range(len(self.levels))])
 

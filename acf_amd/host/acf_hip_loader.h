@@ -55,6 +55,8 @@ struct Api
     ACF_HIP_FN(acf_hip_synchronize)
     ACF_HIP_FN(acf_hip_profile_get)
     ACF_HIP_FN(acf_hip_read_level)
+    ACF_HIP_FN(acf_hip_read_rank_level)
+    ACF_HIP_FN(acf_hip_rank_cells_host)
     ACF_HIP_FN(acf_hip_read_tap)
     ACF_HIP_FN(acf_hip_op_rgb_convert)
     ACF_HIP_FN(acf_hip_op_conv_tri)

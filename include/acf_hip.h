@@ -185,7 +185,13 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * read with acf_hip_profile_get), "scale_streams" (1, default: the real scales of a
  * batch run concurrently on streams of the context — lowest latency and best
  * throughput for ONE context; 0: everything on the context's stream in order, for
- * applications that run several contexts side by side on one GPU). */
+ * applications that run several contexts side by side on one GPU), "rank_cells" (1,
+ * default: the cascade of a depth-2 model reads 16-bit threshold-rank cells — the
+ * comparison `chns[cid] < thrs[node]` of acfDetect1.cpp:102-104 decided on
+ * rank(cell) < rank index of the threshold, the same decision for every cell and
+ * node, hence identical hits and scores — instead of the float pyramid; 0: floats),
+ * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
+ * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.
@@ -321,6 +327,16 @@ ACF_HIP_API int acf_hip_profile_get(acf_hip_ctx* ctx, int* n, const char** names
 
 /* Copy level `level` of frame `frame`'s fused pyramid ([nChns][wP][hP]) to host. */
 ACF_HIP_API int acf_hip_read_level(acf_hip_ctx* ctx, int frame, int level, float* host_out);
+/* The same level as the 16-bit threshold-rank cells the cascade read ([nChns][wP][hP], after acf_hip_detect / acf_hip_run
+ * with "rank_cells" on and a model that admits them; ACF_HIP_E_UNSUPPORTED otherwise). */
+ACF_HIP_API int acf_hip_read_rank_level(acf_hip_ctx* ctx, int frame, int level, uint16_t* host_out);
+/* Host only, no context: the rank cells of `n` values of channel `chn` and the rank indices of every node threshold, as
+ * acf_hip_plan builds them for this model (`nChns` channels).  rank(v) = number of distinct node thresholds t of the
+ * channel with t <= v; node q's index is k + 1 where t_k is its threshold, so that v < thrs[q]  <=>  rank(v) < index[q].
+ * cells_out[n]; thr_index_out[nTrees * nTreeNodes] (0 for leaves); either may be NULL.  info[4] = {usable, shift, buckets,
+ * distinct thresholds} of the channel.  ACF_HIP_E_UNSUPPORTED when the model's thresholds do not admit the table. */
+ACF_HIP_API int acf_hip_rank_cells_host(const acf_hip_params* params, int nChns, int chn, const float* v, int n, uint16_t* cells_out,
+    uint32_t* thr_index_out, int32_t* info);
 
 enum {
     ACF_HIP_TAP_IMAGE = 0,    /* resampled image at a real scale, before smoothing: d planes */
