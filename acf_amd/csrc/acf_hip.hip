@@ -79,11 +79,11 @@ struct CascState
     CascTile* d_tilesR = nullptr;
     int nTilesR = 0;
     TreeNode* d_tileNodesR = nullptr;  // rank-tile offsets, thresholds as rank indices
+    TreeNode* d_tailNodesR = nullptr;  // k_cascade_tail_rank: packed (z, c, r) feature positions, thresholds as rank indices
     uint32_t* d_tileNodesSR = nullptr;
     RankChan* d_rankChan = nullptr;
-    uint16_t* d_rankLut = nullptr;
-    float* d_rankThr = nullptr;
-    int rankMaxLut = 0, rankMaxThr = 0;
+    RankRec* d_rankRec = nullptr;
+    int rankMaxRec = 0;
     RankJob* d_rankJobs = nullptr;
     uint16_t* d_pyrR = nullptr;
     int64_t pyrRCells = 0; // cells per frame
@@ -114,6 +114,7 @@ struct acf_hip_ctx
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     int noRank = 0;  // option "rank_cells" = 0: the tile kernel reads the float pyramid (A/B and parity of both forms)
     bool ranksValid = false; // the rank pyramid of the last batch has been written (by the level kernels or by k_rank)
+    bool floatPyramid = true; // the float pyramid of the last batch exists (option keep_pyramid = 0: it may not)
     std::vector<hipEvent_t> evPool;
     std::vector<const char*> evName;
     size_t evUsed = 0;
@@ -175,6 +176,9 @@ struct acf_hip_ctx
     bool fusedOk = false;      // the fused resample+smooth level kernel covers this plan
     int noFused = 0;           // option "fused_levels" = 0: separate resample and smoothing launches
     PadJob* d_padJobs = nullptr;
+    PadJob* d_padJobsR = nullptr; // the same borders in the rank pyramid's layout
+    bool levelsEmitRank = false;  // every level goes through k_level_all: the level kernels can write the rank cells themselves
+    int keepPyramid = 1;          // option "keep_pyramid": 0 = a run()/detect-only caller does not need the float pyramid (levels leave as rank cells only)
     int finalMaxH = 0;
     int approxMaxBlocks = 0;
     int64_t padMaxElems = 0;
@@ -399,6 +403,12 @@ int ensureConstTables(acf_hip_ctx* c)
         return rc;
     }
     return devAlloc(c, &c->d_dump, 1024);
+}
+
+// rank pyramid: cells between the columns of a level (every column starts on 16 bytes)
+inline int rankPitch(int hP)
+{
+    return (hP + 7) / 8 * 8;
 }
 
 inline int cdiv(int64_t a, int64_t b)
@@ -888,6 +898,18 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "cascade_tiles"))
     {
         c->noTiles = value == 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "keep_pyramid"))
+    {
+        // 0: the caller only wants detections (acf_hip_run / acf_hip_detect): when the levels leave as rank cells the float
+        // pyramid is not written at all (acf_hip_read_level and the Pyramid-returning entries then fail with
+        // ACF_HIP_E_INVALID); 1 (default): both
+        c->keepPyramid = value != 0;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            k->keepPyramid = c->keepPyramid;
+        }
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "rank_cells"))
@@ -1479,7 +1501,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     cs.rankMaxWP = 0;
                     for (size_t i = 0; i < lv.size(); i++)
                     {
-                        const int pitch = (lv[i].hP + 7) / 8 * 8;
+                        const int pitch = rankPitch(lv[i].hP);
                         cl[i].offR = off;
                         cl[i].pitchR = pitch;
                         jobs[i].src_off = lv[i].offset;
@@ -1491,15 +1513,37 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                         cs.rankMaxWP = std::max(cs.rankMaxWP, lv[i].wP);
                     }
                     cs.pyrRCells = off;
+                    std::vector<TreeNode> tailR(static_cast<size_t>(p.nTrees));
+                    for (int t = 0; t < p.nTrees; t++)
+                    {
+                        const size_t q = size_t(t) * p.nTreeNodes;
+                        TreeNode b{};
+                        for (int k = 0; k < 3; k++)
+                        {
+                            const uint32_t f = c->fids[q + k];
+                            const uint32_t z = f / uint32_t(mWc * mHc), cc = (f / uint32_t(mHc)) % uint32_t(mWc), rr = f % uint32_t(mHc);
+                            b.off[k] = (z << 24) | (cc << 12) | rr; // (mW, mH <= 4095 and nChns <= 255: checked for the packed node table above)
+                            const uint32_t rk = rt.rankOfThreshold(int(z), c->thrs[q + k]);
+                            memcpy(&b.thr[k], &rk, 4);
+                        }
+                        for (int k = 0; k < 4; k++)
+                        {
+                            b.hs[k] = c->hs[q + 3 + k];
+                        }
+                        tailR[size_t(t)] = b;
+                    }
+                    if ((rc = devUpload(c, &cs.d_tailNodesR, tailR)))
+                    {
+                        return rc;
+                    }
                     cs.geomR = tsR.g;
                     cs.d_tilesR = tsR.d_tiles;
                     cs.nTilesR = tsR.nTiles;
                     cs.d_tileNodesR = tsR.d_tileNodes;
                     cs.d_tileNodesSR = tsR.d_tileNodesS;
-                    cs.rankMaxLut = rt.maxLut;
-                    cs.rankMaxThr = rt.maxThr;
+                    cs.rankMaxRec = rt.maxRec;
                     // + slack: a tile's 16-byte fill chunks run up to rowsP cells past the last column of the last plane
-                    if ((rc = devUpload(c, &cs.d_rankChan, rt.chan)) || (rc = devUpload(c, &cs.d_rankLut, rt.lut)) || (rc = devUpload(c, &cs.d_rankThr, rt.thr)) ||
+                    if ((rc = devUpload(c, &cs.d_rankChan, rt.chan)) || (rc = devUpload(c, &cs.d_rankRec, rt.rec)) ||
                         (rc = devUpload(c, &cs.d_rankJobs, jobs)) || (rc = devAlloc(c, &cs.d_pyrR, size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096)))
                     {
                         return rc;
@@ -1625,6 +1669,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->profile = c->profile;
             k->noTiles = c->noTiles;
             k->noRank = c->noRank;
+            k->keepPyramid = c->keepPyramid;
             k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
@@ -1810,7 +1855,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
 
     // final smoothing + padding jobs (chnsPyramid.cpp:399-435)
     std::vector<SmoothJob> finalJobs;
-    std::vector<PadJob> padJobs;
+    std::vector<int64_t> rankOffs;
+    std::vector<PadJob> padJobs, padJobsR;
+    int64_t rankOff = 0; // the rank pyramid's layout (rankPitch): levels in order, nChns planes [wP][pitch] each
     c->finalMaxH = 0;
     c->padMaxElems = 0;
     const int py = p.pad_h / shrink, px = p.pad_w / shrink;
@@ -1836,9 +1883,15 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         q.py = py;
         q.px = px;
         q.nplanes = pl.nChns;
+        q.pitch = l.hP;
         q.off = l.offset;
         padJobs.push_back(q);
+        q.pitch = rankPitch(l.hP);
+        q.off = rankOff;
+        padJobsR.push_back(q);
         c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * l.hP * l.wP);
+        rankOffs.push_back(rankOff);
+        rankOff += int64_t(pl.nChns) * rankPitch(l.hP) * l.wP;
     }
     // level jobs (k_level): every level, real ones read their raw channels, approximated ones resample on the
     // fly; sorted into runs of equal (rows-per-lane R, mode) because both are template parameters of the kernel
@@ -1863,6 +1916,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             j.out_off = l.offset + int64_t(px) * l.hP + py;
             j.in_ps = int64_t(l.hC) * l.wC;
             j.out_ps = int64_t(l.hP) * l.wP;
+            j.rank_cs = rankPitch(l.hP);
+            j.rank_ps = int64_t(j.rank_cs) * l.wP;
+            j.rank_off = rankOffs[i] + int64_t(px) * j.rank_cs + py;
             j.desc = -1;
             const int R = (l.hC + 63) / 64;
             int mode = LM_REAL;
@@ -1932,6 +1988,14 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs, &c->nAllJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw, &c->nAllJobsRaw)))
         {
             return rc;
+        }
+        c->levelsEmitRank = c->fusedOk && c->levelGroups.empty() && c->nAllJobs == int(pl.levels.size());
+        for (const auto& l : pl.levels)
+        {
+            if ((py & 1) && l.hC % 64 == 0)
+            {
+                c->levelsEmitRank = false; // (level_body's paired rank stores: no lane holds row hC)
+            }
         }
     }
     // ---- LDCF post-stage (acf_hip_params::ldcfK): level table of the filtered, halved pyramid + one resample per level
@@ -2041,7 +2105,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         }
     }
     if ((rc = devUpload(c, &c->d_descs, c->h_descs)) || (rc = devUpload(c, &c->d_it, arena.ints)) || (rc = devUpload(c, &c->d_ft, arena.floats)) ||
-        (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)))
+        (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)) || (rc = devUpload(c, &c->d_padJobsR, padJobsR)))
     {
         return rc;
     }
@@ -2694,6 +2758,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     }
 
     // ---- approximated levels, smoothing and padding of frames [f0, f0 + nLF) of the batch
+    bool wroteRank = false, wroteF32 = true;
     auto launchLevels = [&](int f0, int nLF) -> int {
         float* const chnsF = c->d_chns + int64_t(f0) * pl.raw_floats;
         float* const pyrF = c->d_pyr + int64_t(f0) * pl.pyr_floats;
@@ -2728,10 +2793,43 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 }
             }
             const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
+            // what the levels leave as: floats (always, unless the caller has declared the float pyramid unneeded), and the
+            // cascade's 16-bit rank cells when every level goes through this one launch
+            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps;
+            const bool emitF32 = !(emitRank && !c->keepPyramid && !c->autoLambdas);
+            wroteRank = emitRank;
+            wroteF32 = emitF32;
             if (nAll > 0)
             {
-                hipLaunchKernelGGL(k_level_all, dim3(cdiv(pl.nChns, LEVEL_WAVES), nLF, nAll), dim3(64 * LEVEL_WAVES), 0, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,
-                    (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+                LevelRankArgs ra{};
+                size_t ldsL = size_t(LEVEL_WAVES) * (emitRank ? LEVEL_ALL_WF_RANK : LEVEL_ALL_WF) * sizeof(float);
+                if (emitRank)
+                {
+                    ra.out = c->cs.d_pyrR + int64_t(f0) * c->cs.pyrRCells;
+                    ra.fs = c->cs.pyrRCells;
+                    ra.chan = c->cs.d_rankChan;
+                    ra.rec = c->cs.d_rankRec;
+                    ldsL += size_t(c->cs.rankMaxRec) * sizeof(RankRec);
+                }
+                dim3 lgrid(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll), lblock(64 * LEVEL_WAVES);
+#define LVALL_LAUNCH(OUT)                                                                                                   \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT>), ldsL)))                                         \
+        return rc;                                                                                                          \
+    hipLaunchKernelGGL((k_level_all<OUT>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,    \
+        (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra);
+                if (emitRank && emitF32)
+                {
+                    LVALL_LAUNCH(LO_F32 | LO_RANK);
+                }
+                else if (emitRank)
+                {
+                    LVALL_LAUNCH(LO_RANK);
+                }
+                else
+                {
+                    LVALL_LAUNCH(LO_F32);
+                }
+#undef LVALL_LAUNCH
                 LAUNCHCHK(c, "k_level_all");
             }
             size_t gi = 0;
@@ -2739,10 +2837,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             {
                 const auto& g = *git;
                 hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
-                dim3 grid(cdiv(pl.nChns, LEVEL_WAVES), g.count, nLF), block(64 * LEVEL_WAVES);
+                dim3 grid(pl.nChns, g.count, cdiv(nLF, LEVEL_WAVES)), block(64 * LEVEL_WAVES);
     #define LV_LAUNCH(RR, MM)                                                                                                         \
         hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)chnsF, pyrF, rawOut, ljobs + g.first, dd, \
-            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump);
+            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF);
     #define LV_MODES(RR)                                  \
         switch (g.mode)                                   \
         {                                                 \
@@ -2800,7 +2898,15 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
         {
             prof(c, "k_pad_reflect");
-            hipLaunchKernelGGL(k_pad_reflect, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream, pyrF, (const PadJob*)c->d_padJobs, pl.pyr_floats);
+            if (wroteF32)
+            {
+                hipLaunchKernelGGL(k_pad_reflect<float>, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream, pyrF, (const PadJob*)c->d_padJobs, pl.pyr_floats);
+            }
+            if (wroteRank)
+            {
+                hipLaunchKernelGGL(k_pad_reflect<uint16_t>, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream,
+                    c->cs.d_pyrR + int64_t(f0) * c->cs.pyrRCells, (const PadJob*)c->d_padJobsR, c->cs.pyrRCells);
+            }
             LAUNCHCHK(c, "k_pad_reflect");
         }
         return ACF_HIP_OK;
@@ -2895,7 +3001,8 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     prof(c, "(end)");
     c->lastBatch = nF;
     c->pyramidValid = true;
-    c->ranksValid = false; // (no level kernel has written rank cells: the cascade converts the float pyramid first)
+    c->ranksValid = wroteRank;   // else the cascade converts the float pyramid first (k_rank)
+    c->floatPyramid = wroteF32;
     return ACF_HIP_OK;
 }
 } // namespace
@@ -2970,15 +3077,14 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     {
         // the float pyramid -> threshold-rank cells (levels whose kernels did not emit them)
         int rc = 0;
-        const size_t ldsR = size_t(cs.rankMaxLut) * 2 + size_t(cs.rankMaxThr) * 4;
+        const size_t ldsR = size_t(cs.rankMaxRec) * sizeof(RankRec);
         if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_rank), ldsR)))
         {
             return rc;
         }
         prof(c, "k_rank");
         hipLaunchKernelGGL(k_rank, dim3(cdiv(cs.rankMaxWP, RANK_CHUNK_COLS), int(c->plan.levels.size()) * nChns, nF), dim3(256), ldsR, c->stream, pyr, pyr_fs,
-            cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const uint16_t*)cs.d_rankLut, (const float*)cs.d_rankThr,
-            cs.rankMaxLut);
+            cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const RankRec*)cs.d_rankRec);
         LAUNCHCHK(c, "k_rank");
         c->ranksValid = true;
     }
@@ -3064,7 +3170,15 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             hipLaunchKernelGGL(k_tail_scan, dim3(nF * ((cs.codeCap + 255) / 256)), dim3(256), ldsS, c->stream, a);
             LAUNCHCHK(c, "k_tail_scan");
         }
-        if (g.b[4] < p.nTrees)
+        if (g.b[4] < p.nTrees && rank)
+        {
+            // queue entries without codes (beyond codeCap) from the rank cells: a wave per entry; its blocks leave at once
+            // when k_tail_scan has taken the whole queue
+            prof(c, "k_cascade_tail3");
+            hipLaunchKernelGGL(k_cascade_tail_rank, dim3(std::max(1, 1024 / nF) * nF), dim3(64), 0, c->stream, at, (const TreeNode*)cs.d_tailNodesR);
+            LAUNCHCHK(c, "k_cascade_tail_rank");
+        }
+        else if (g.b[4] < p.nTrees)
         {
             // queue entries without codes (beyond codeCap, or ACF_HIP_TAIL3): k_cascade_tail3; its blocks leave at once when
             // k_tail_scan has taken the whole queue
@@ -4120,6 +4234,10 @@ int acf_hip_read_level(acf_hip_ctx* c, int frame, int level, float* host_out)
     {
         return fail(c, ACF_HIP_E_INVALID, "read_level: arguments");
     }
+    if (!c->floatPyramid)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "read_level: the float pyramid was not kept (option keep_pyramid = 0: the levels left as rank cells only)");
+    }
     const acf_hip_level& l = c->plan.levels[level];
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(host_out, c->d_pyr + size_t(frame) * c->plan.pyr_floats + l.offset, sizeof(float) * c->plan.nChns * l.hP * l.wP, hipMemcpyDeviceToHost));
@@ -4151,11 +4269,11 @@ int acf_hip_read_rank_level(acf_hip_ctx* c, int frame, int level, uint16_t* host
         return fail(c, ACF_HIP_E_INVALID, "read_rank_level: arguments, or no detect since the last pyramid");
     }
     const acf_hip_level& l = c->plan.levels[level];
-    const int pitch = (l.hP + 7) / 8 * 8;
+    const int pitch = rankPitch(l.hP);
     int64_t off = 0;
     for (int i = 0; i < level; i++)
     {
-        off += int64_t(c->plan.nChns) * ((c->plan.levels[i].hP + 7) / 8 * 8) * c->plan.levels[i].wP;
+        off += int64_t(c->plan.nChns) * rankPitch(c->plan.levels[i].hP) * c->plan.levels[i].wP;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(host_out, size_t(l.hP) * 2, c->cs.d_pyrR + size_t(frame) * c->cs.pyrRCells + off, size_t(pitch) * 2, size_t(l.hP) * 2,

@@ -483,9 +483,9 @@ inline int32_t rankKey(float v)
     std::memcpy(&b, &v, 4);
     return b > 0 ? b : 0;
 }
-inline int rankBucket(const RankChan& c, float v)
+inline int rankBucket(const RankChan& c, int32_t key)
 {
-    const int b = (rankKey(v) >> c.shift) - c.base;
+    const int b = (key >> c.shift) - c.base;
     return b < 0 ? 0 : (b > c.nb - 1 ? c.nb - 1 : b);
 }
 } // namespace
@@ -493,13 +493,19 @@ inline int rankBucket(const RankChan& c, float v)
 uint32_t RankTables::rankOfCell(int chn, float v) const
 {
     const RankChan& c = chan[size_t(chn)];
-    const uint32_t lo = lut[size_t(c.lutOff) + size_t(rankBucket(c, v))];
-    const float* t = thr.data() + c.thrOff;
-    uint32_t pos = lo;
-    pos += (t[pos + 3] <= v) ? 4u : 0u;
-    pos += (t[pos + 1] <= v) ? 2u : 0u;
-    pos += (t[pos] <= v) ? 1u : 0u;
-    return pos;
+    if (v < 0.f)
+    {
+        return 0;
+    }
+    const int32_t key = rankKey(v);
+    const RankRec& r = rec[size_t(c.recOff) + size_t(rankBucket(c, key))];
+    const uint32_t low = uint32_t(key) & ((1u << c.shift) - 1u);
+    uint32_t n = r.lo;
+    for (int j = 0; j < RANK_WINDOW; j++)
+    {
+        n += (uint32_t(r.t[j]) <= low) ? 1u : 0u;
+    }
+    return n;
 }
 
 uint32_t RankTables::rankOfThreshold(int chn, float t) const
@@ -531,6 +537,11 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
             return;
         }
         const float t = thrs[q];
+        if (t < 0.f)
+        {
+            out.why = "negative threshold (rank cells place every negative cell below all thresholds)";
+            return;
+        }
         if (t == t) // NaN thresholds have no rank (never true)
         {
             per[size_t(z)].push_back(t == 0.f ? 0.f : t); // -0.0 and +0.0 are one threshold
@@ -541,25 +552,34 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
         std::vector<float>& t = per[size_t(z)];
         std::sort(t.begin(), t.end());
         t.erase(std::unique(t.begin(), t.end()), t.end());
-        out.chan[size_t(z)].nThr = int32_t(t.size());
+        RankChan& c = out.chan[size_t(z)];
+        c.nThr = int32_t(t.size());
         if (t.size() > 65534)
         {
             out.why = "more than 65534 distinct thresholds in one channel";
             return;
         }
-    }
-    // per channel: the largest shift (smallest table) whose buckets hold at most `scan` thresholds each
-    auto shiftFor = [&](const std::vector<float>& t, int scan) -> int {
-        for (int shift = 30; shift >= 0; shift--)
+        // a threshold of exactly 0 is <= every v >= -0 (and a negative v ranks 0 anyway): it only shifts every record's
+        // `lo` by one, and stays out of the bucket geometry (its key, 0, is far below every positive float's)
+        std::vector<float> tAll = t;
+        const uint32_t hasZero = (!t.empty() && t.front() == 0.f) ? 1u : 0u;
+        if (hasZero)
+        {
+            t.erase(t.begin());
+        }
+        // the largest shift (smallest table) whose buckets hold at most RANK_WINDOW thresholds each
+        int best = -1;
+        for (int shift = 15; shift >= 0 && best < 0; shift--)
         {
             if (t.empty())
             {
-                return shift;
+                best = shift;
+                break;
             }
             const int64_t kLo = rankKey(t.front()) >> shift, kHi = rankKey(t.back()) >> shift;
             if (kHi - kLo + 3 > RANK_MAX_BUCKETS)
             {
-                return -1; // finer buckets only get more numerous
+                break; // finer buckets only get more numerous
             }
             int run = 0, worst = 0;
             int64_t prev = -1;
@@ -570,56 +590,44 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
                 prev = k;
                 worst = std::max(worst, run);
             }
-            if (worst <= scan)
+            if (worst <= RANK_WINDOW)
             {
-                return shift;
+                best = shift;
             }
         }
-        return -1;
-    };
-    std::vector<int> shifts(static_cast<size_t>(nChns), -1);
-    for (int z = 0; z < nChns; z++)
-    {
-        shifts[size_t(z)] = shiftFor(per[size_t(z)], RANK_WINDOW);
-        if (shifts[size_t(z)] < 0)
+        if (best < 0)
         {
-            out.why = "thresholds of a channel too dense for the bucket table (more than RANK_WINDOW per bucket at RANK_MAX_BUCKETS buckets)";
+            out.why = "thresholds of a channel spread too wide or packed too densely for a bucket table of RANK_MAX_BUCKETS records";
             return;
         }
-    }
-    for (int z = 0; z < nChns; z++)
-    {
-        const std::vector<float>& t = per[size_t(z)];
-        RankChan& c = out.chan[size_t(z)];
-        const int best = shifts[size_t(z)];
         c.shift = best;
-        // bucket 0 lies below every threshold's bucket, bucket nb - 1 above: values outside the thresholds' range clamp into them
         c.base = t.empty() ? 0 : int32_t((rankKey(t.front()) >> best) - 1);
         c.nb = t.empty() ? 1 : int32_t((rankKey(t.back()) >> best) - c.base + 2);
-        c.lutOff = int32_t(out.lut.size());
+        c.recOff = int32_t(out.rec.size());
         c.thrOff = int32_t(out.thr.size());
-        out.lut.resize(out.lut.size() + size_t(c.nb) + (size_t(c.nb) & 1u), 0); // channels start on 4-byte boundaries
-        uint16_t* lut = out.lut.data() + c.lutOff;
-        size_t j = 0;
+        RankRec empty;
+        empty.lo = 0;
+        for (int j = 0; j < RANK_WINDOW; j++)
+        {
+            empty.t[j] = 0xffff;
+        }
+        out.rec.resize(out.rec.size() + size_t(c.nb), empty);
+        RankRec* rec = out.rec.data() + c.recOff;
+        std::vector<int> fill(static_cast<size_t>(c.nb), 0);
+        for (size_t j = 0; j < t.size(); j++)
+        {
+            const int32_t key = rankKey(t[j]);
+            const int b = rankBucket(c, key);
+            rec[b].t[fill[size_t(b)]++] = uint16_t(uint32_t(key) & ((1u << best) - 1u));
+        }
+        uint32_t acc = hasZero;
         for (int b = 0; b < c.nb; b++)
         {
-            while (j < t.size() && rankBucket(c, t[j]) < b)
-            {
-                j++;
-            }
-            lut[b] = uint16_t(j); // thresholds in lower buckets
+            rec[b].lo = uint16_t(acc); // thresholds in lower buckets
+            acc += uint32_t(fill[size_t(b)]);
         }
-        if ((size_t(c.nb) & 1u) != 0)
-        {
-            lut[c.nb] = uint16_t(t.size());
-        }
-        out.thr.insert(out.thr.end(), t.begin(), t.end());
-        for (int k = 0; k < RANK_PAD; k++)
-        {
-            out.thr.push_back(std::numeric_limits<float>::infinity());
-        }
-        out.maxLut = std::max(out.maxLut, c.nb + (c.nb & 1));
-        out.maxThr = std::max(out.maxThr, c.nThr + RANK_PAD);
+        out.thr.insert(out.thr.end(), tAll.begin(), tAll.end());
+        out.maxRec = std::max(out.maxRec, c.nb);
     }
     out.ok = true;
 }

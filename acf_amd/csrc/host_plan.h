@@ -99,27 +99,37 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
 //     rank(v) = #{ j : t_j <= v }            (0 .. m, a 16-bit value for m <= 65534).
 // Then for every cell value v and every node threshold t_k:   v < t_k  <=>  rank(v) <= k  <=>  rank(v) < k + 1,
 // so a pyramid of rank cells compared against `k + 1` gives the cascade exactly the decisions of the float pyramid: same
-// leaves, same sums, same hits, in half the bytes.  rank(v) needs no search over the whole list: a table indexed by the
-// top bits of v's (order-preserving) bit pattern gives the number of thresholds in lower buckets, and the value's own
-// bucket — at most RANK_WINDOW = 7 thresholds — is resolved by three branch-free bisection steps,
-//     key = max(int(bits(v)), 0);  b = clamp((key >> shift) - base, 0, nb - 1);  pos = lut[b];
-//     pos += 4 * (thr[pos + 3] <= v);  pos += 2 * (thr[pos + 1] <= v);  pos += (thr[pos] <= v);  rank = pos
-// (thr is padded with +inf; thresholds of later buckets are > v, so the seven-entry window may run past the bucket's own).
-// Exact for every finite v provided no bucket holds more than RANK_WINDOW thresholds, which buildRankTables guarantees by
-// its choice of each channel's `shift` (the largest, i.e. the smallest table, that does), or reports as not possible within
-// RANK_MAX_BUCKETS entries (ok = false: the float pyramid stays the cascade's input).  Negative values and -0.0 share
-// bucket 0 with +0.0 (the direct compares keep them apart).
+// leaves, same sums, same hits, in half the bytes.
+//
+// rank(v) without a search.  For v >= 0 the bit pattern of v is an order-preserving integer key.  Its top bits select a
+// bucket; a bucket's 16-byte record holds `lo` = the number of thresholds in lower buckets and the LOW `shift` bits of the
+// keys of its own thresholds (at most RANK_WINDOW = 7 of them; 0xffff in unused slots).  Inside a bucket all keys share
+// their top bits, so comparing low bits compares the floats:
+//     key = max(int(bits(v)), 0);  b = clamp((key >> shift) - base, 0, nb - 1);  low = key & ((1 << shift) - 1);
+//     rec = table[b] (one 16-byte read);  rank = rec.lo + #{ j : rec.t[j] <= low };   v < 0: rank = 0.
+// buildRankTables picks each channel's `shift` (<= 15, so that 0xffff is above every low key) as the largest — i.e. the
+// smallest table — whose buckets hold at most RANK_WINDOW thresholds, or reports that none exists within
+// RANK_MAX_BUCKETS buckets (ok = false: the float pyramid stays the cascade's input).  Bucket 0 lies below and bucket
+// nb - 1 above every threshold's bucket: values outside the thresholds' range clamp into records without thresholds.
+// (A threshold of exactly 0 is <= every v >= -0: it is counted in every record's `lo` and has no slot.)
+// Exact for EVERY finite v (and -0.0 == +0.0) provided no threshold is negative — then a negative v is below all of
+// them, rank 0 — which buildRankTables also requires (a model with a negative threshold keeps the float cascade).
 constexpr int RANK_WINDOW = 7;
-constexpr int RANK_PAD = 8; // +inf entries after a channel's thresholds
 constexpr int RANK_MAX_BUCKETS = 4096;
 
 struct RankChan
 {
     int32_t shift, base, nb; // bucket function
-    int32_t lutOff;          // first entry of this channel in RankTables::lut
-    int32_t thrOff;          // first entry of this channel in RankTables::thr (nThr values + RANK_PAD x +inf)
-    int32_t nThr;
+    int32_t recOff;          // first record of this channel in RankTables::rec
+    int32_t nThr;            // distinct thresholds
+    int32_t thrOff;          // first of them in RankTables::thr (host side only: rankOfThreshold)
     int32_t pad_[2];
+};
+
+struct RankRec // 16 bytes
+{
+    uint16_t lo;
+    uint16_t t[RANK_WINDOW];
 };
 
 struct RankTables
@@ -127,12 +137,12 @@ struct RankTables
     bool ok = false;
     std::string why; // ok == false: what ruled the rank cells out
     std::vector<RankChan> chan;
-    std::vector<uint16_t> lut;
-    std::vector<float> thr;
-    int maxLut = 0, maxThr = 0; // largest per-channel table sizes (entries incl. padding): the kernels' LDS budget
+    std::vector<RankRec> rec;
+    std::vector<float> thr; // sorted distinct thresholds, channel after channel
+    int maxRec = 0;         // largest per-channel record count: the kernels' LDS budget
 
     uint32_t rankOfCell(int chn, float v) const;      // host mirror of the device function (tests, op entry)
-    uint32_t rankOfThreshold(int chn, float t) const; // k + 1 of the text above (0: never true, nThr + 1: true for every finite cell)
+    uint32_t rankOfThreshold(int chn, float t) const; // k + 1 of the text above (0: never true)
 };
 
 // chnOfNode[q] >= 0: node q tests a feature of that channel (fids[q] / (mW * mH)); < 0: not a feature test (leaf)

@@ -688,8 +688,9 @@ __global__ void __launch_bounds__(256) k_plane_sums(const float* __restrict__ ch
 // smoothing kernel (chnsPyramid.cpp:410-424): fills only the border cells.
 struct PadJob
 {
-    int32_t hC, wC, hP, wP, py, px, nplanes, pad_;
-    int64_t off; // level offset in the fused pyramid
+    int32_t hC, wC, hP, wP, py, px, nplanes;
+    int32_t pitch; // cells between columns (hP in the float pyramid, hP rounded up to 8 in the rank pyramid)
+    int64_t off;   // level offset in the fused pyramid
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n)
@@ -701,7 +702,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
     return i;
 }
 
-__global__ void __launch_bounds__(256) k_pad_reflect(float* __restrict__ pyr, const PadJob* __restrict__ jobs, int64_t fs)
+template <class T> // float: the fused pyramid; uint16_t: its threshold-rank cells (a copied cell keeps its rank)
+__global__ void __launch_bounds__(256) k_pad_reflect(T* __restrict__ pyr, const PadJob* __restrict__ jobs, int64_t fs)
 {
     const PadJob j = jobs[blockIdx.y];
     const int64_t cells = int64_t(j.hP) * j.wP;
@@ -718,9 +720,9 @@ __global__ void __launch_bounds__(256) k_pad_reflect(float* __restrict__ pyr, co
     {
         return; // interior
     }
-    float* P = pyr + int64_t(blockIdx.z) * fs + j.off + int64_t(c) * cells;
+    T* P = pyr + int64_t(blockIdx.z) * fs + j.off + int64_t(c) * j.pitch * j.wP;
     const int rx = reflect_idx(sx, j.wC) + j.px, ry = reflect_idx(sy, j.hC) + j.py;
-    P[int64_t(x) * j.hP + y] = P[int64_t(rx) * j.hP + ry];
+    P[int64_t(x) * j.pitch + y] = P[int64_t(rx) * j.pitch + ry];
 }
 
 // ------------------------------------------------------------------------
@@ -2254,43 +2256,54 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
 
 // ------------------------------------------------------------------------
 // Threshold-rank cells (host_plan.h): rank(v) = number of the channel's distinct node thresholds <= v, the 16-bit cell
-// the cascade tile kernel reads.  `lut`/`thr` are the CHANNEL's tables (in LDS): lut[b] = thresholds in buckets below b,
-// thr = the sorted thresholds + RANK_PAD x +inf.
+// the cascade tile kernel reads.  `rec` = the CHANNEL's bucket records in LDS: one 16-byte read per cell.
 // ------------------------------------------------------------------------
 struct RankFn
 {
     int32_t shift, base, nbm1;
+    uint32_t mask;
 };
-__device__ __forceinline__ uint32_t rank_cell(float v, const RankFn& f, const uint16_t* lut, const float* thr)
+// the read: issue it early, count late (rank_count) — the level kernels put a column's other LDS traffic in between
+__device__ __forceinline__ uint4 rank_fetch(float v, const RankFn& f, const uint4* rec, uint32_t& low)
 {
     const int key = max(__float_as_int(v), 0);
     const int b = min(max((key >> f.shift) - f.base, 0), f.nbm1);
-    uint32_t pos = lut[b];
-    static_assert(RANK_WINDOW == 7, "three bisection steps");
-    pos += thr[pos + 3] <= v ? 4u : 0u;
-    pos += thr[pos + 1] <= v ? 2u : 0u;
-    pos += thr[pos] <= v ? 1u : 0u;
-    return pos;
+    low = uint32_t(key) & f.mask;
+    return rec[b];
+}
+__device__ __forceinline__ uint32_t rank_count(float v, const uint4& r, uint32_t low)
+{
+    static_assert(RANK_WINDOW == 7 && sizeof(RankRec) == 16, "record layout");
+    uint32_t n = r.x & 0xffffu; // lo
+    n += (r.x >> 16) <= low ? 1u : 0u;
+    n += (r.y & 0xffffu) <= low ? 1u : 0u;
+    n += (r.y >> 16) <= low ? 1u : 0u;
+    n += (r.z & 0xffffu) <= low ? 1u : 0u;
+    n += (r.z >> 16) <= low ? 1u : 0u;
+    n += (r.w & 0xffffu) <= low ? 1u : 0u;
+    n += (r.w >> 16) <= low ? 1u : 0u;
+    return v < 0.f ? 0u : n; // every threshold is >= 0 (buildRankTables): a negative cell is below all of them
+}
+__device__ __forceinline__ uint32_t rank_cell(float v, const RankFn& f, const uint4* rec)
+{
+    uint32_t low;
+    const uint4 r = rank_fetch(v, f, rec, low);
+    return rank_count(v, r, low);
 }
 
-// copy a channel's tables into LDS: [lut: maxLut u16][thr: maxThr f32]; returns the bucket function
-__device__ __forceinline__ RankFn rank_tables_to_lds(const RankChan& rc, const uint16_t* __restrict__ lutG, const float* __restrict__ thrG,
-    uint16_t* lutL, float* thrL, int tid, int nThreads)
+// copy a channel's records into LDS; returns the bucket function
+__device__ __forceinline__ RankFn rank_tables_to_lds(const RankChan& rc, const RankRec* __restrict__ recG, uint4* recL, int tid, int nThreads)
 {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(lutG + rc.lutOff); // channels start on 4-byte boundaries, padded to even
-    uint32_t* dst = reinterpret_cast<uint32_t*>(lutL);
-    for (int i = tid; i < (rc.nb + 1) / 2; i += nThreads)
+    const uint4* src = reinterpret_cast<const uint4*>(recG + rc.recOff);
+    for (int i = tid; i < rc.nb; i += nThreads)
     {
-        dst[i] = src[i];
-    }
-    for (int i = tid; i < rc.nThr + RANK_PAD; i += nThreads)
-    {
-        thrL[i] = thrG[rc.thrOff + i];
+        recL[i] = src[i];
     }
     RankFn f;
     f.shift = rc.shift;
     f.base = rc.base;
     f.nbm1 = rc.nb - 1;
+    f.mask = (1u << rc.shift) - 1u;
     return f;
 }
 
@@ -2304,9 +2317,9 @@ struct RankJob
 };
 constexpr int RANK_CHUNK_COLS = 64;
 __global__ void __launch_bounds__(256) k_rank(const float* __restrict__ pyr, int64_t pyr_fs, uint16_t* __restrict__ out, int64_t out_fs,
-    const RankJob* __restrict__ jobs, int nChns, const RankChan* __restrict__ chan, const uint16_t* __restrict__ lutG, const float* __restrict__ thrG, int maxLut)
+    const RankJob* __restrict__ jobs, int nChns, const RankChan* __restrict__ chan, const RankRec* __restrict__ recG)
 {
-    extern __shared__ float lds[];
+    extern __shared__ uint4 ldsRec[];
     const int lvl = blockIdx.y / nChns, z = blockIdx.y - lvl * nChns;
     const RankJob J = jobs[lvl];
     const int c0 = blockIdx.x * RANK_CHUNK_COLS;
@@ -2314,9 +2327,7 @@ __global__ void __launch_bounds__(256) k_rank(const float* __restrict__ pyr, int
     {
         return;
     }
-    uint16_t* lutL = reinterpret_cast<uint16_t*>(lds);
-    float* thrL = lds + maxLut / 2;
-    const RankFn fn = rank_tables_to_lds(chan[z], lutG, thrG, lutL, thrL, threadIdx.x, 256);
+    const RankFn fn = rank_tables_to_lds(chan[z], recG, ldsRec, threadIdx.x, 256);
     __syncthreads();
     const float* __restrict__ src = pyr + int64_t(blockIdx.z) * pyr_fs + J.src_off + int64_t(z) * J.hP * J.wP;
     uint16_t* __restrict__ dst = out + int64_t(blockIdx.z) * out_fs + J.dst_off + int64_t(z) * J.pitchR * J.wP;
@@ -2326,7 +2337,7 @@ __global__ void __launch_bounds__(256) k_rank(const float* __restrict__ pyr, int
     {
         for (int r = lane; r < J.hP; r += 64)
         {
-            dst[int64_t(c) * J.pitchR + r] = uint16_t(rank_cell(src[int64_t(c) * J.hP + r], fn, lutL, thrL));
+            dst[int64_t(c) * J.pitchR + r] = uint16_t(rank_cell(src[int64_t(c) * J.hP + r], fn, ldsRec));
         }
     }
 }
@@ -2357,6 +2368,8 @@ struct LevelJob
     int64_t raw_off;              // where the level's raw (unsmoothed) channels go when taps are kept
     int64_t out_off;              // float offset of the level's interior in the per-frame pyramid
     int64_t in_ps, out_ps;        // plane strides
+    int64_t rank_off, rank_ps;    // rank pyramid (16-bit cells): cell offset of the level's interior in one frame, plane stride
+    int32_t rank_cs, pad2_;       // rank pyramid: cells between columns
 };
 
 
@@ -2414,10 +2427,17 @@ __device__ __forceinline__ void buf_st(srd_t r, uint32_t voff, uint32_t soff, fl
 // `s_waitcnt vmcnt(LA * RS)` (completion is in order; stores only add younger entries) covers c.
 // Per element the operands and their order are those of k_resample (x pass then y pass): bit-identical.
 // waves (= channel planes) per workgroup of the level kernels: 2, so that ten channels are 5 full workgroups
-constexpr int LEVEL_WAVES = 2;
+// (4 since round 3 — a multiple of the CU's four SIMDs: six measured 12 % slower, two SIMDs carry twice the waves —: the
+// waves of a workgroup take the SAME channel of four frames, so that one copy of the channel's
+// threshold-rank tables in LDS serves the workgroup)
+constexpr int LEVEL_WAVES = 4;
 constexpr int LEVEL_RING_FLOATS = 2304; // 9 KB per wave: 6 slots of 6 x 64 rows ... 12 slots of <= 3 x 64 rows
+// ... and 7.5 KB (5 slots of 6 x 64 rows) in the forms that also hold a channel's rank records in LDS: a workgroup's LDS is
+// allocated in 1280-byte granules and three workgroups per CU must fit (4 x 10.75 KB + 10.6 KB of records was 43 granules:
+// two workgroups per CU, k_level 1.25 -> 2.0 ms); one column of look-ahead less costs the seven largest levels ~6 %
+constexpr int LEVEL_RING_FLOATS_RANK = 1920;
 
-template <int R, int MODE>
+template <int R, int MODE, int RING = LEVEL_RING_FLOATS>
 struct LevelWindow
 {
     static constexpr bool XDOWN = MODE == LM_DD || MODE == LM_DU;
@@ -2425,7 +2445,7 @@ struct LevelWindow
     static constexpr int NY = YDOWN ? 3 : 2;
     static constexpr int JX = XDOWN ? 3 : 2;
     static constexpr int RS = YDOWN ? (3 * R + 1) / 2 : R; // source rows per lane: ha <= 64 * RS (host-checked)
-    static constexpr int NBRAW = LEVEL_RING_FLOATS / (RS * 64);
+    static constexpr int NBRAW = RING / (RS * 64);
     static constexpr int NB = NBRAW > 12 ? 12 : (NBRAW < JX + 2 ? JX + 2 : NBRAW); // ring slots
     static constexpr int LA = NB - JX;                                             // columns requested ahead of the window
     static constexpr int LDS_FLOATS = RS * 64 * (NB + 1);                          // x-pass column + ring, per wave
@@ -2501,10 +2521,10 @@ struct LaneTaps
 
 // One column of an approximated level: x pass then y pass, reference association order
 // (imResampleMex.cpp:198-280, 319-373).
-template <int R, int MODE>
+template <int R, int MODE, int RING>
 __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int h, const uint32_t (&yoff)[R],
     int ha, int wa, int ny, const u32x8& xr, const LaneTaps<R>& tp, srd_t raw, bool haveRaw, bool lastOk,
-    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>& win, float* ldsCol, int lane)
+    LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE, RING>& win, float* ldsCol, int lane)
 {
     if (MODE == LM_REAL)
     {
@@ -2521,13 +2541,13 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     // An approximated level is within a factor 2^(+-1/2) of its real level, so an output has at most three
     // taps per axis when down-sampling and two when up-sampling (the plan falls back to separate launches
     // otherwise).  All JX*NY source values of every register are requested before any is used.
-    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> Win;
+    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE, RING> Win;
     constexpr int NY = Win::NY;
     constexpr int JX = Win::JX;
     const int xa = int(xr[0]), m = int(xr[1]);
     const bool border = xr[3] != 0;
     const float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
-    constexpr int RS = LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::RS;
+    constexpr int RS = Win::RS;
     win.advance(A, xa, ha, wa);
     float sc[JX][RS];
     win.read(sc, xa, lane);
@@ -2655,21 +2675,38 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     }
 }
 
-template <int R, int MODE>
+// What a level kernel writes: the float level (the Pyramid the API returns), its threshold-rank cells (what the cascade's
+// tile kernel reads), or both.
+enum
+{
+    LO_F32 = 1,
+    LO_RANK = 2
+};
+struct LevelRank
+{
+    uint16_t* out;        // rank pyramid
+    int64_t fs;           // cells per frame
+    RankFn fn;            // the channel's bucket function
+    const uint4* rec;     // the channel's bucket records, in LDS
+};
+
+template <int R, int MODE, int OUT>
 __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* ldsBlock, int ldsWaveFloats)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* ldsBlock, int ldsWaveFloats, const LevelRank& rk)
 {
-    // the plane index is the same for the 64 lanes of a wave; say so (readfirstlane), or every plane pointer is
-    // treated as per-lane and all address arithmetic lands on the VALU in 64 bits
-    const int z = __builtin_amdgcn_readfirstlane(blockIdx.x * LEVEL_WAVES + (threadIdx.x >> 6));
-    if (z >= nChns)
-    {
-        return;
-    }
+    // the plane index is the same for the 64 lanes of a wave (and of the workgroup: its waves are the same plane of
+    // LEVEL_WAVES frames); say so (readfirstlane), or every plane pointer is treated as per-lane and all address
+    // arithmetic lands on the VALU in 64 bits
+    const int z = __builtin_amdgcn_readfirstlane(blockIdx.x);
     const int lane = threadIdx.x & 63;
     const int h = J.hC, w = J.wC;
     const srd_t Osrd = make_srd(pyr + f * pyr_fs + J.out_off + int64_t(z) * J.out_ps, (int64_t(w - 1) * J.out_cs + h) * 4);
+    // rank cells leave two rows per lane (below): the descriptor starts `par` cells before the level's interior so that
+    // it starts on a 4-byte boundary (pitches and plane sizes are multiples of 8 cells), and reaches one cell past the
+    // interior's last row
+    const int par = int(J.rank_off & 1);
+    const srd_t Rsrd = (OUT & LO_RANK) ? make_srd(rk.out + f * rk.fs + (J.rank_off - par) + int64_t(z) * J.rank_ps, (int64_t(w - 1) * J.rank_cs + h + 1 + par) * 2) : Osrd;
     srd_t A, raw = Osrd;
     bool haveRaw = false;
     int ha = 0, wa = 0, ny = 0;
@@ -2768,7 +2805,8 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
     u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
     // approximated levels: the source-column window (registers) and the wave's x-pass column buffer (LDS)
-    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> Win;
+    constexpr int RING = (OUT & LO_RANK) ? LEVEL_RING_FLOATS_RANK : LEVEL_RING_FLOATS;
+    typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE, RING> Win;
     Win lw;
     float* ldsCol = ldsBlock + (threadIdx.x >> 6) * ldsWaveFloats; // the wave's x-pass column, then its ring
     if (MODE != LM_REAL)
@@ -2778,7 +2816,7 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     const int lastLane = (h - 1) & 63; // lane holding row h-1 in the last register
 #define LV_LOAD(FAR, COL)                                                                                           \
     {                                                                                                               \
-        level_column<R, MODE>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, haveRaw, lastOk, lw, ldsCol, lane); \
+        level_column<R, MODE, RING>(FAR, min((COL), w - 1), A, h, yoff, ha, wa, ny, xr, tp, raw, haveRaw, lastOk, lw, ldsCol, lane); \
         xr = xrn;                                                                                                   \
         xrn = (MODE == LM_REAL) ? zrec : xrec[min((COL) + 2, w - 1)];                                               \
     }
@@ -2808,10 +2846,63 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             /* lanes past the end of the plane (last register only) are clamped to row h-1: they store row h-1's */ \
             /* value to row h-1's address, so every store is unconditional and base + 32-bit offset             */ \
             const float ov = (k < R - 1 || lastOk) ? o : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o), lastLane)); \
-            buf_st(Osrd, yoff[k], uint32_t(i_) * uint32_t(J.out_cs) * 4u, ov);                                      \
+            if (OUT & LO_F32)                                                                                       \
+            {                                                                                                       \
+                buf_st(Osrd, yoff[k], uint32_t(i_) * uint32_t(J.out_cs) * 4u, ov);                                  \
+            }                                                                                                       \
         }                                                                                                           \
     }
     // (storing four columns at a time instead of one was measured: no gain, 16 more VGPRs)
+    // Rank cells one column behind: `prev` holds column i - 1's output during step i.  Its bucket records are requested
+    // BEFORE the next column's LDS traffic (ring reads, y-tap gathers) and counted after it, so the one LDS round trip of
+    // a rank hides behind waits the step has anyway (LDS operations of a wave complete in order); emitting the rank
+    // inline, right after the float store, cost a dependent round trip per column step: 1.27 -> 1.9 ms per 96 frames.
+    uint4 rrec[R];
+    uint32_t rlow[R];
+    // 2-byte stores are slow (one 128-byte buffer_store_short per register measured as much as 1.5 float stores: the rank
+    // cells alone made the kernel 28 % slower than the floats alone).  Rows y - 1 and y leave as ONE dword from the lane of
+    // row y, for the rows with (y + par) odd — i.e. cell pairs that start on 4 bytes —, row y - 1's rank coming from the
+    // neighbouring lane; the other lanes' stores go out of the descriptor's range and are dropped.  Pairs may cover one
+    // cell above the interior (y = 0, par = 1) or below it (y = h): a border cell k_pad_reflect rewrites afterwards, or
+    // the unused tail of the column's pitch.  (hC a multiple of 64 with par = 1 has no lane for y = h: the host keeps such
+    // plans on k_rank.)
+    uint32_t rvoff[R];
+    if (OUT & LO_RANK)
+    {
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            const int y = lane + 64 * k;
+            rvoff[k] = (((y + par) & 1) && y <= h) ? uint32_t(2 * (y - 1 + par)) : 0x40000000u;
+        }
+    }
+#define LV_RANK_FETCH()                                                                                             \
+    if (OUT & LO_RANK)                                                                                              \
+    {                                                                                                               \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            rrec[k] = rank_fetch(prev[k], rk.fn, rk.rec, rlow[k]);                                                  \
+        }                                                                                                           \
+    }
+    // column COL of the rank level <- ranks of `prev` (COL < 0: nothing yet; the stores go out of the descriptor's range
+    // and are dropped by the buffer bounds check: no branch)
+#define LV_RANK_STORE(COL)                                                                                          \
+    if (OUT & LO_RANK)                                                                                              \
+    {                                                                                                               \
+        const int c_ = (COL);                                                                                       \
+        const uint32_t so_ = c_ >= 0 ? uint32_t(c_) * uint32_t(J.rank_cs) * 2u : 0x40000000u;                       \
+        uint32_t n_[R], up_[R];                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            n_[k] = rank_count(prev[k], rrec[k], rlow[k]);                                                          \
+            up_[k] = __float_as_uint(wave_ror1(__uint_as_float(n_[k]))); /* row y-1's rank for lanes 1..63 */       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
+        {                                                                                                           \
+            const uint32_t lo_ = (lane == 0) ? up_[k > 0 ? k - 1 : 0] : up_[k];                                     \
+            __builtin_amdgcn_raw_buffer_store_b32((n_[k] << 16) | (lo_ & 0xffffu), Rsrd, rvoff[k], so_, 0);         \
+        }                                                                                                           \
+    }
     // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
     LV_LOAD(b0, 0);
     LV_LOAD(b1, 1);
@@ -2819,65 +2910,123 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     int i = 0;
     for (; i + 3 < w; i += 4)
     {
+        LV_RANK_FETCH();
         LV_LOAD(b3, i + 3);
+        LV_RANK_STORE(i - 1);
         LV_FILTER(i, b0, b1);
+        LV_RANK_FETCH();
         LV_LOAD(b0, i + 4);
+        LV_RANK_STORE(i);
         LV_FILTER(i + 1, b1, b2);
+        LV_RANK_FETCH();
         LV_LOAD(b1, i + 5);
+        LV_RANK_STORE(i + 1);
         LV_FILTER(i + 2, b2, b3);
+        LV_RANK_FETCH();
         LV_LOAD(b2, i + 6);
+        LV_RANK_STORE(i + 2);
         LV_FILTER(i + 3, b3, b0);
     }
     // tail: up to three columns; their inputs are already in b0, b1, b2
     if (i < w)
     {
+        LV_RANK_FETCH();
+        LV_RANK_STORE(i - 1);
         LV_FILTER(i, b0, b1);
     }
     if (i + 1 < w)
     {
+        LV_RANK_FETCH();
+        LV_RANK_STORE(i);
         LV_FILTER(i + 1, b1, b2);
     }
     if (i + 2 < w)
     {
+        LV_RANK_FETCH();
+        LV_RANK_STORE(i + 1);
         LV_FILTER(i + 2, b2, b2);
     }
+    LV_RANK_FETCH();
+    LV_RANK_STORE(w - 1);
+#undef LV_RANK_FETCH
+#undef LV_RANK_STORE
 #undef LV_LOAD
 #undef LV_FILTER
 }
 
-// One launch per run of levels with equal (R, mode): blockIdx.y = level of the run, blockIdx.z = frame.
+// One launch per run of levels with equal (R, mode): blockIdx.x = channel, blockIdx.y = level of the run, blockIdx.z =
+// group of LEVEL_WAVES frames (wave w of the workgroup takes frame blockIdx.z * LEVEL_WAVES + w).  Float output only: the
+// runs that do not fit k_level_all are the large planes of large frames; their rank cells come from k_rank.
+template <int R, int MODE>
+constexpr int levelWaveFloats()
+{
+    return MODE == LM_REAL ? 1 : LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::LDS_FLOATS;
+}
 template <int R, int MODE>
 __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(R <= 4 ? 4 : 1))) k_level(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, int nFrames)
 {
     const LevelJob J = jobs[blockIdx.y];
-    constexpr int WF = MODE == LM_REAL ? 1 : LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE>::LDS_FLOATS;
+    constexpr int WF = levelWaveFloats<R, MODE>();
     __shared__ float ldsBlock[LEVEL_WAVES * WF];
-    level_body<R, MODE>(J, blockIdx.z, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF);
+    const int f = __builtin_amdgcn_readfirstlane(int(blockIdx.z) * LEVEL_WAVES + int(threadIdx.x >> 6));
+    if (f >= nFrames)
+    {
+        return;
+    }
+    const LevelRank rk{};
+    level_body<R, MODE, LO_F32>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk);
 }
 
 // All levels whose specialisation fits 128 VGPRs (R <= 4 in any mode, real levels up to R = 8) in ONE launch:
-// blockIdx.z = level, longest plane chain first, blockIdx.y = frame.  A plane is a sequential chain of wC column
-// steps, so a launch lasts as long as its longest wave; as separate launches per (R, mode) on the 4 hardware queues
-// the stage cost max-over-queues of a sum of such tails and kept 38 % of the wave slots busy (PMC SQ_WAVE_CYCLES,
-// kernel trace).  In one grid the dispatcher starts the long chains first and back-fills slots with short ones as
-// they free up.  The specialisation is picked by a workgroup-uniform switch.
+// blockIdx.z = level, longest plane chain first, blockIdx.y = group of LEVEL_WAVES frames, blockIdx.x = channel.  A plane
+// is a sequential chain of wC column steps, so a launch lasts as long as its longest wave; as separate launches per
+// (R, mode) on the 4 hardware queues the stage cost max-over-queues of a sum of such tails and kept 38 % of the wave slots
+// busy (PMC SQ_WAVE_CYCLES, kernel trace).  In one grid the dispatcher starts the long chains first and back-fills slots
+// with short ones as they free up.  The specialisation is picked by a workgroup-uniform switch.
+// OUT & LO_RANK: every cell also (or only) leaves as its 16-bit threshold rank (host_plan.h) — the channel's tables sit in
+// LDS behind the waves' rings (dynamic shared memory: LEVEL_WAVES * LEVEL_ALL_WF floats + maxRec records of 16 bytes).
 #define ACF_LEVEL_KIND(R, M) ((R) * 8 + (M))
+constexpr int LEVEL_ALL_WF = LevelWindow<4, LM_DD>::LDS_FLOATS; // the largest of the specialisations of k_level_all (R <= 4)
+constexpr int LEVEL_ALL_WF_RANK = LevelWindow<4, LM_DD, LEVEL_RING_FLOATS_RANK>::LDS_FLOATS;
+struct LevelRankArgs
+{
+    uint16_t* out;
+    int64_t fs;
+    const RankChan* chan;
+    const RankRec* rec;
+};
+template <int OUT>
 __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, int nFrames, LevelRankArgs ra)
 {
     const LevelJob J = jobs[blockIdx.z];
-    const int64_t f = blockIdx.y;
-    constexpr int WF = LevelWindow<4, LM_DD>::LDS_FLOATS; // the largest of the specialisations below (R <= 4)
-    static_assert(LevelWindow<3, LM_DD>::LDS_FLOATS <= WF && LevelWindow<4, LM_UU>::LDS_FLOATS <= WF && LevelWindow<2, LM_DD>::LDS_FLOATS <= WF &&
-                      LevelWindow<3, LM_UU>::LDS_FLOATS <= WF && LevelWindow<1, LM_DD>::LDS_FLOATS <= WF,
+    constexpr int RING = (OUT & LO_RANK) ? LEVEL_RING_FLOATS_RANK : LEVEL_RING_FLOATS;
+    constexpr int WF = (OUT & LO_RANK) ? LEVEL_ALL_WF_RANK : LEVEL_ALL_WF;
+    static_assert(LevelWindow<3, LM_DD, RING>::LDS_FLOATS <= WF && LevelWindow<4, LM_UU, RING>::LDS_FLOATS <= WF && LevelWindow<2, LM_DD, RING>::LDS_FLOATS <= WF &&
+                      LevelWindow<3, LM_UU, RING>::LDS_FLOATS <= WF && LevelWindow<1, LM_DD, RING>::LDS_FLOATS <= WF,
         "ring size");
-    __shared__ float ldsBlock[LEVEL_WAVES * WF];
-#define LV_CASE(RR, MM)                                                                                              \
-    case ACF_LEVEL_KIND(RR, MM):                                                                                      \
-        level_body<RR, MM>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF);   \
+    extern __shared__ float ldsBlock[];
+    LevelRank rk{};
+    if ((OUT & LO_RANK) != 0)
+    {
+        uint4* recL = reinterpret_cast<uint4*>(ldsBlock + LEVEL_WAVES * WF);
+        rk.fn = rank_tables_to_lds(ra.chan[blockIdx.x], ra.rec, recL, threadIdx.x, 64 * LEVEL_WAVES);
+        rk.out = ra.out;
+        rk.fs = ra.fs;
+        rk.rec = recL;
+        __syncthreads();
+    }
+    const int f = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * LEVEL_WAVES + int(threadIdx.x >> 6));
+    if (f >= nFrames)
+    {
+        return;
+    }
+#define LV_CASE(RR, MM)                                                                                                  \
+    case ACF_LEVEL_KIND(RR, MM):                                                                                          \
+        level_body<RR, MM, OUT>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk); \
         break;
 #define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_UU)
     switch (J.kind)
@@ -4714,6 +4863,88 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
                 hit.scale = lvl;
                 hit.c = n / nWinR;
                 hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// k_cascade_tail_rank: queue entries without leaf codes (beyond codeCap per frame) when the cascade runs on rank cells —
+// k_cascade_tail3's job without the float pyramid.  A correctness path for frames with thousands of tail windows (a very
+// low cascThr), not a fast one: one wave per entry, lanes = 64 consecutive trees, every lane gathers its tree's cells
+// straight from the rank pyramid in global memory; the leaves are added in tree order by the 16-lane row chains of the
+// sparse tile stages (row_chain, rows in sequence), the window dies at the first prefix <= cascThr (evaluate(),
+// acfDetect1.cpp:123-138: same additions, same order).
+// rankNodes: per tree {off[k] = (z << 24) | (c << 12) | r of node k, thr[k] = rank index bits, hs[4]}.
+// ------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_cascade_tail_rank(TileArgs a, const TreeNode* __restrict__ rankNodes)
+{
+    const int lane = threadIdx.x;
+    const int frame = blockIdx.x % a.nFrames;
+    const int cnt = min(a.qcount[frame], a.qcap);
+    const int tEnd = a.g.b[4], nT = a.nTrees - tEnd;
+    const float thrC = a.cascThr;
+    for (;;)
+    {
+        int i0 = 0;
+        if (lane == 0)
+        {
+            i0 = atomicAdd(a.qhead + frame, 1);
+        }
+        i0 = __builtin_amdgcn_readfirstlane(__shfl(i0, 0));
+        if (i0 >= cnt)
+        {
+            return;
+        }
+        const uint2 e = a.q[int64_t(frame) * a.qcap + i0];
+        const int lvl = int(e.x >> 24), n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR, r = n - c * L.nWinR;
+        const uint16_t* __restrict__ chn = a.pyrR + int64_t(frame) * a.pyrR_fs + L.offR + int64_t(c * a.g.step) * L.pitchR + r * a.g.step;
+        const uint32_t area = uint32_t(L.pitchR) * uint32_t(L.wP);
+        float h = __uint_as_float(e.y);
+        bool alive = true;
+        for (int tb = 0; tb < nT && alive; tb += 64) // wave-uniform
+        {
+            const bool act = tb + lane < nT;
+            const TreeNode nd = rankNodes[tEnd + min(tb + lane, nT - 1)];
+            uint32_t f[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const uint32_t zcr = nd.off[k];
+                f[k] = chn[(zcr >> 24) * area + ((zcr >> 12) & 0xfffu) * uint32_t(L.pitchR) + (zcr & 0xfffu)];
+            }
+            const bool lt0 = f[0] < __float_as_uint(nd.thr[0]);
+            const bool lt1 = (lt0 ? f[1] : f[2]) < __float_as_uint(lt0 ? nd.thr[1] : nd.thr[2]);
+            float leaf = lt0 ? (lt1 ? nd.hs[0] : nd.hs[1]) : (lt1 ? nd.hs[2] : nd.hs[3]);
+            leaf = act ? leaf : 0.f; // h never is -0.0f: h + 0.0f == h bit for bit
+            float acc = h, mm = h;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                float sa = k == 0 ? h : dpp_row_bcast15(acc);
+                float sm = k == 0 ? h : dpp_row_bcast15(mm);
+                row_chain(leaf, sa, sm);
+                const bool mine = (lane >> 4) == k;
+                acc = mine ? sa : acc;
+                mm = mine ? sm : mm;
+            }
+            h = __shfl(acc, 63);
+            const float mAll = __shfl(mm, 63);
+            alive = (mAll > thrC) && (h > thrC);
+        }
+        if (alive && lane == 0)
+        {
+            const int idx = atomicAdd(a.counts + frame, 1);
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = c;
+                hit.r = r;
                 hit.score = h;
                 a.hits[int64_t(frame) * a.maxHits + idx] = hit;
             }

@@ -284,6 +284,8 @@ def main():
             # several contexts side by side already fill each other's gaps: a context's real scales stay on its one stream
             # (acf_hip.h, scale_streams; measured: 3 contexts 12.1k frames/s with 0, 11.6k with 1; one context 9.8k / 10.5k)
             det.set_option("scale_streams", 0)
+        if os.environ.get("BENCH_KEEP_PYRAMID") == "0":
+            det.set_option("keep_pyramid", 0)
         if not args.no_profile:
             det.set_option("profile", 1)
         if not args.no_nms:

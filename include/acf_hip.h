@@ -190,6 +190,9 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * comparison `chns[cid] < thrs[node]` of acfDetect1.cpp:102-104 decided on
  * rank(cell) < rank index of the threshold, the same decision for every cell and
  * node, hence identical hits and scores — instead of the float pyramid; 0: floats),
+ * "keep_pyramid" (1, default; 0: the caller wants detections only — acf_hip_run /
+ * acf_hip_pyramid + acf_hip_detect — and when the levels leave as rank cells the float
+ * pyramid is not written at all: acf_hip_read_level then fails with ACF_HIP_E_INVALID),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);

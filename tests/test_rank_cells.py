@@ -97,17 +97,21 @@ def test_host_rank_tables_dense_and_degenerate_models():
     m3 = dict(m2, thrs=thrs.reshape(model["thrs"].shape))
     rc, _, _, info = host_ranks(m3, nChns, 0, v)
     assert rc == capi.E_UNSUPPORTED and info[0] == 0
-    # duplicates, zeros of both signs and a negative threshold
+    # duplicates and zeros of both signs
     thrs[:, :3] = 0.5
-    thrs[0, 0], thrs[0, 1], thrs[0, 2], thrs[1, 0] = 0.0, -0.0, -0.25, 0.75
+    thrs[0, 0], thrs[0, 1], thrs[1, 0] = 0.0, -0.0, 0.75
     m4 = dict(m2, thrs=thrs.reshape(model["thrs"].shape))
-    t = np.asarray([-0.25, 0.0, 0.5, 0.75], np.float32)
+    t = np.asarray([0.0, 0.5, 0.75], np.float32)
     v = probes(t)
     rc, cells, idx, info = host_ranks(m4, nChns, 0, v)
-    assert rc == 0 and info[3] == 4
+    assert rc == 0 and info[3] == 3
     assert np.array_equal(cells, np.searchsorted(t, v, side="right").astype(np.uint16))
     idx = idx.reshape(model["thrs"].shape)
     assert np.array_equal(v[:, None] < thrs[:2, :3].ravel()[None, :], cells[:, None].astype(np.uint32) < idx[:2, :3].ravel()[None, :])
+    # a negative threshold: negative cells could no longer rank 0 -> the model keeps the float cascade
+    thrs[0, 2] = -0.25
+    rc, _, _, info = host_ranks(dict(m2, thrs=thrs.reshape(model["thrs"].shape)), nChns, 0, v)
+    assert rc == capi.E_UNSUPPORTED and info[0] == 0
 
 
 # ------------------------------------------------------------------ GPU
@@ -178,3 +182,60 @@ def test_gpu_rank_cells_with_sub_batch_streams_and_nms(oracle):
     for f in range(4):
         assert a.detections(f)[0].tobytes() == b.detections(f)[0].tobytes()
         assert np.array_equal(b.read_rank_level(f, 0).shape, (b.nChns, b.levels[0].wP, b.levels[0].hP))
+
+
+@pytest.mark.gpu
+def test_gpu_detections_without_the_float_pyramid(oracle):
+    """Option keep_pyramid = 0: the level kernels write rank cells only; detections stay the oracle's, the float level is
+    reported as absent (not silently stale)."""
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    H, W = 200, 264
+    model = synth.make_model(seed=3, name="TINY", nTrees=256, cascThr=-1.0)
+    frames = np.stack([synth.make_frame(11 + i, H, W, "luv") for i in range(5)])   # 5: one full group of 4 frames + 1
+    fr = torch.from_numpy(frames).cuda()
+    det = HipDetector(model, H, W, 3, max_batch=5, max_hits=1 << 15)
+    det.set_option("keep_pyramid", 0)
+    det.run(fr)
+    plan = oracle.Plan(model, H, W, 3)
+    for f in range(5):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want, whits = oracle.detect(plan, pyr)
+        d, h = det.detections(f)
+        assert len(want) > 0 and d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes(), f
+        l = det.levels[3]
+        lvl = pyr[l.offset:l.offset + det.nChns * l.hP * l.wP].reshape(det.nChns, l.wP, l.hP)
+        assert np.array_equal(det.read_rank_level(f, 3), _ranks_of(model, det.nChns, lvl))
+    with pytest.raises(HipError):
+        det.read_level(0, 0)
+    det.set_option("keep_pyramid", 1)
+    det.run(fr)
+    pyr, _, _ = oracle.chns_pyramid(plan, frames[4])
+    assert np.array_equal(det.read_pyramid(4).view(np.uint32), pyr.view(np.uint32))
+    det.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tail_queue_overflow_on_rank_cells(oracle):
+    """More windows reach the tail than stage E has code rows for (cascThr far below every score): the overflow handler of
+    the rank form (k_cascade_tail_rank) finishes them from the rank pyramid; with and without the float pyramid, == oracle."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 160, 200
+    model = synth.make_model(seed=5, name="TINY", nTrees=200, cascThr=-1e6)
+    frames = np.stack([synth.make_frame(31 + i, H, W, "luv") for i in range(2)])
+    fr = torch.from_numpy(frames).cuda()
+    plan = oracle.Plan(model, H, W, 3)
+    want = []
+    for f in range(2):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want.append(oracle.detect(plan, pyr, cap=1 << 16) if False else oracle.detect(plan, pyr))
+    assert all(len(w[0]) > 1500 for w in want)
+    for keep in (1, 0):
+        det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 16)
+        det.set_option("keep_pyramid", keep)
+        det.run(fr)
+        for f in range(2):
+            d, h = det.detections(f)
+            assert d.tobytes() == want[f][0].tobytes() and h.tobytes() == want[f][1].tobytes(), (keep, f)
+        det.close()
