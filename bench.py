@@ -72,7 +72,7 @@ def kernel_bytes_per_frame(det, model):
         casc = 4 * sum(nC * k * l.hP * l.wP for l in det.ldcf_levels)
         b["k_ldcf_conv"] = pyr + 4 * casc  # the plain pyramid in, k filtered full-resolution levels out
         b["k_resample(ldcf)"] = 4 * casc + casc
-    b["k_cascade_tile"] = casc                    # every cell of the cascade's pyramid read once (halo re-reads are L2 hits)
+    b["k_cascade_tile"] = casc                    # every cell of the cascade's pyramid read once at SURVEY §8d's 4 bytes per cell (halo re-reads are L2 hits); the rank-cell form moves half of it
     b["k_cascade"] = casc
     b["k_tail_scan"] = 0                          # data dependent: (windows alive after tree 128) x (tail trees) code bytes
     b["k_cascade_tail3"] = 0
@@ -81,17 +81,50 @@ def kernel_bytes_per_frame(det, model):
     return b
 
 
+PMC_FILE = "profiles/r03_pmc_traffic.json"
+
+
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json:
-    FETCH_SIZE x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes), or None."""
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary (PMC_FILE, produced by profiles/r03_profile.sh:
+    FETCH_SIZE x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes), or None.  Not measured
+    in this run: the line says so (roofline.traffic_source)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             t = json.load(f)
         if t.get("frames_per_step") != batch:
             return None
         return t["kernels"].get(kernel)
     except Exception:
         return None
+
+
+def verify_frames(model, H, W, frames, recs, cap, nms, picks):
+    """Outside the clock: the records the TIMED contexts exported for `picks` = [(context, frame in batch), ...] against the
+    oracle on the very same frames (pulled back from HBM): chnsPyramid + acfDetect (+ bbNms + prune) on the CPU, boxes and
+    levels exact, score bits exact.  Returns the number of frames checked; raises on the first difference."""
+    from acf_amd import capi
+    from acf_amd.dist import records_to_detections
+    from oracle import binding as ob
+    plan = ob.Plan(model, H, W, 3)
+    n = 0
+    for (ci, fi) in picks:
+        frame = frames[ci][fi].cpu().numpy()
+        pyr, _, _ = ob.chns_pyramid(plan, frame)
+        want, _ = ob.detect(plan, pyr)
+        if nms is not None:
+            keep = ob.nms(np.stack([want["x"], want["y"], want["w"], want["h"]], axis=1), want["score"].astype(np.float64), nms)
+            want = want[keep]
+        rec = recs[ci][fi]
+        if int(rec[0]) != len(want) or len(want) > cap:
+            raise SystemExit("bench self-check: context %d frame %d: %d detections exported, oracle has %d (cap %d)" % (ci, fi, int(rec[0]), len(want), cap))
+        got = records_to_detections(rec, cap)
+        for g, w_ in zip(got, want):
+            same = (g[0], g[1], g[2], g[3], g[5]) == (int(w_["x"]), int(w_["y"]), int(w_["w"]), int(w_["h"]), int(w_["scale"])) and \
+                np.float32(g[4]).view(np.uint32) == np.float32(w_["score"]).view(np.uint32)
+            if not same:
+                raise SystemExit("bench self-check: context %d frame %d differs from the oracle: %r vs %r" % (ci, fi, g, w_))
+        n += 1
+    return n
 
 
 def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
@@ -212,6 +245,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
+    ap.add_argument("--keep-pyramid", action="store_true", help="also materialise the float pyramid (acf_hip option keep_pyramid = 1); by default the timed "
+                    "call is detection only — Detector::operator()(image) — and the levels leave the level kernel as 16-bit threshold-rank cells")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of three timed frames against the oracle")
     ap.add_argument("--dry-launch", action="store_true", help="launch plumbing only (spawn, rendezvous, max-over-ranks clock, per-rank gather) "
                     "with no detector work: runs without a GPU over gloo (tests/test_bench_launch.py); never a measurement")
     args = ap.parse_args()
@@ -278,21 +314,25 @@ def main():
     pool = DetectorPool(C, model, H, W, 3, max_batch=B, max_hits=8192, device=local, streams=args.streams)
     streams, dets = pool.streams, pool.dets
     from acf_amd import capi
+    nms_params = None
     args.cap = args.cap or (1024 if args.no_nms else 32)
     for det in dets:
         if C > 1:
             # several contexts side by side already fill each other's gaps: a context's real scales stay on its one stream
             # (acf_hip.h, scale_streams; measured: 3 contexts 12.1k frames/s with 0, 11.6k with 1; one context 9.8k / 10.5k)
             det.set_option("scale_streams", 0)
-        if os.environ.get("BENCH_KEEP_PYRAMID") == "0":
+        if not args.keep_pyramid and args.config != 5:
             det.set_option("keep_pyramid", 0)
         if not args.no_profile:
             det.set_option("profile", 1)
         if not args.no_nms:
             # ACF.cpp:332-353 + ObjectDetector.cpp:28-44 with acf::Detector's defaults, on the device: the gather record shrinks
             # from 24 KB to < 1 KB per frame
-            det.set_nms(capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10, pruneRatio=0.0))
+            nms_params = capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10, pruneRatio=0.0)
+            det.set_nms(nms_params)
     pipes = [RecordGather(B, 1 + 6 * args.cap, world, rank, dev) for _ in range(C)]
+    if args.no_nms:
+        nms_params = None
 
     def step():
         for i in range(C):
@@ -367,6 +407,36 @@ def main():
         if not args.no_profile:
             dets[0].profile()
     counts = pipes[0].rec[(pipes[0].k - 1) & 1][:, 0].cpu().numpy()
+    verified = None
+    if rank == 0 and not args.no_verify and args.config != 5:
+        # the timed contexts' own last records (still in their record buffers), three frames of three different contexts
+        recs = [pipes[i].rec[(pipes[i].k - 1) & 1].cpu().numpy() for i in range(C)]
+        picks = [(i % C, (7 + 31 * i) % B) for i in range(3)]
+        verified = verify_frames(model, H, W, [frames[i * B:(i + 1) * B] for i in range(C)], recs, args.cap, nms_params, picks)
+    strong64 = None
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_latency and not args.frames_total and C * B >= 64:
+        # BASELINE cfg 3 as worded (64 frames per step) on this one GPU: 2 contexts x 32 frames, same contexts and buffers
+        c2 = min(C, 2)
+        per = 64 // c2
+        if per <= B:
+            for d_ in dets:
+                d_.set_option("scale_streams", 0 if c2 > 1 else 1)
+            def step64():
+                for i in range(c2):
+                    with torch.cuda.stream(streams[i]):
+                        dets[i].run(frames[i * B:i * B + per], per)
+                        dets[i].export_detections(pipes[i].rec[0], args.cap)
+            for _ in range(2):
+                step64()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step64()
+            torch.cuda.synchronize()
+            strong64 = 64 * 10 / (time.perf_counter() - t1)
+            if not args.no_profile:
+                for d_ in dets:
+                    d_.profile()
     if rank == 0:
         frames_total = C * B * world * args.steps
         fps = frames_total / dt
@@ -381,17 +451,24 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "latency_ms_batch1": latency_ms,
+            "verified_frames": verified,
             "config": {"workload": "%s; %d frames resident in HBM per GPU per step (%d detector contexts x %d frames)" % (cfg["what"], C * B, C, B),
                        "baseline_config": args.config,
                        "frames_per_gpu_per_step": C * B, "contexts": C, "frames_per_launch": B, "levels": len(det.levels),
                        "windows_per_frame": int(sum(l.nWinR * l.nWinC for l in (det.ldcf_levels or det.levels))),
                        "mean_detections_per_frame": float(counts.mean()), "nms": "none (raw detections)" if args.no_nms else "device bbNms maxg .65/min + prune(10)",
                        "gather_record_bytes_per_frame": 4 * (1 + 6 * args.cap), "parallelism": "frames sharded, %d rank(s)" % world,
-                       "rccl_ranks": world, "per_rank_fps": [float(x) for x in rank_fps.cpu().numpy()]},
+                       "rccl_ranks": world, "per_rank_fps": [float(x) for x in rank_fps.cpu().numpy()],
+                       "pyramid_output": ("float pyramid + 16-bit threshold-rank cells" if args.keep_pyramid else
+                                          "16-bit threshold-rank cells only (detection-only call; --keep-pyramid also writes the float levels)") if args.config != 5 else "float (LDCF)",
+                       # BASELINE cfg 2 as worded ("single frame") and cfg 3 as worded (64 frames per step, here on ONE GPU)
+                       "cfg2_single_frame_latency_ms": latency_ms, "cfg2_single_frame_fps": (1e3 / latency_ms) if latency_ms else None,
+                       "cfg3_64_frames_per_step_fps_1gpu": strong64},
         }
         if args.frames_total:
             out["config"]["frames_total_per_step"] = args.frames_total
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "traffic_source": "%s (committed rocprofv3 PMC passes of this workload; not measured in this run)" % PMC_FILE}
         if prof:
             tot_ms = sum(v[0] for v in prof.values())
             kb = kernel_bytes_per_frame(det, model)
