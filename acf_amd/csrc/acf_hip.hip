@@ -178,6 +178,12 @@ struct acf_hip_ctx
     PadJob* d_padJobs = nullptr;
     PadJob* d_padJobsR = nullptr; // the same borders in the rank pyramid's layout
     bool levelsEmitRank = false;  // every level goes through k_level_all: the level kernels can write the rank cells themselves
+    // k_smooth_vec's speculative column segments (kernels.hip.h): options smooth_segments (0 auto, 1 off, n), smooth_warm, smooth_force_redo
+    int smoothSegments = getenv("ACF_HIP_SMOOTH_SEGMENTS") ? atoi(getenv("ACF_HIP_SMOOTH_SEGMENTS")) : 0; // (env: A/B default)
+    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 48, smoothForceRedo = 0;
+    float *d_specState = nullptr, *d_trueState = nullptr;
+    int32_t* d_redo = nullptr;
+    int segCap = 0;               // segments the state buffers hold per plane
     int keepPyramid = 1;          // option "keep_pyramid": 0 = a run()/detect-only caller does not need the float pyramid (levels leave as rank cells only)
     int finalMaxH = 0;
     int approxMaxBlocks = 0;
@@ -304,6 +310,9 @@ void freeAll(acf_hip_ctx* c)
     c->hasPlan = false;
     c->d_lTable = c->d_acos = nullptr;
     c->d_dump = nullptr;
+    c->d_specState = c->d_trueState = nullptr;
+    c->d_redo = nullptr;
+    c->segCap = 0;
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->d_ldcfJobs = nullptr;
@@ -898,6 +907,23 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "cascade_tiles"))
     {
         c->noTiles = value == 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "smooth_segments") || !strcmp(key, "smooth_warm") || !strcmp(key, "smooth_force_redo"))
+    {
+        // the image smoothing's recursion along image-x cut into column segments that start `smooth_warm` columns early and are
+        // checked against each other (kernels.hip.h, "speculative segments"): 0 = as many as fill the GPU for the batch, 1 = one
+        // chain per plane, n = n segments; smooth_force_redo = 1 marks every plane for the repair launch (tests)
+        int& dst = !strcmp(key, "smooth_segments") ? c->smoothSegments : (!strcmp(key, "smooth_warm") ? c->smoothWarm : c->smoothForceRedo);
+        if (value < 0 || (!strcmp(key, "smooth_warm") && value % 16 != 0))
+        {
+            return fail(c, ACF_HIP_E_INVALID, "option: smooth_segments >= 0, smooth_warm a multiple of 16");
+        }
+        dst = value;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            (void)acf_hip_set_option(k, key, value);
+        }
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "keep_pyramid"))
@@ -1670,6 +1696,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->noTiles = c->noTiles;
             k->noRank = c->noRank;
             k->keepPyramid = c->keepPyramid;
+            k->smoothSegments = c->smoothSegments;
+            k->smoothWarm = c->smoothWarm;
+            k->smoothForceRedo = c->smoothForceRedo;
             k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
@@ -2112,6 +2141,15 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     if ((rc = devAlloc(c, &c->d_chns, size_t(B) * pl.raw_floats)) || (rc = devAlloc(c, &c->d_pyr, size_t(B) * pl.pyr_floats + 64)) /* + slack: the cascade's 16-byte tile fill may read a few floats past the last plane */)
     {
         return rc;
+    }
+    {
+        // k_smooth_vec's column segments: hand-over states of up to 32 segments per plane, one repair flag per plane
+        c->segCap = 32;
+        const size_t nState = size_t(B) * d * c->segCap * size_t(std::max(H, 4));
+        if ((rc = devAlloc(c, &c->d_specState, nState)) || (rc = devAlloc(c, &c->d_trueState, nState)) || (rc = devAlloc(c, &c->d_redo, size_t(B) * d)))
+        {
+            return rc;
+        }
     }
     // cascade
     // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
@@ -2631,16 +2669,54 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     }
                 }
                 sa.plane0 = 0;
-                dim3 grid(d, 1, nF), block(nt);
-                if (halfNext)
+                sa.nPlanes = d;
+                // column segments: as many as give the launch ~6 waves per SIMD (a plane is a chain of column steps with
+                // nt / 64 waves), each at least 4 warm-ups long; one segment = the plain recursion
+                const int warm = std::max(16, c->smoothWarm);
+                int nSeg = c->smoothSegments;
+                if (nSeg == 0)
                 {
-                    hipLaunchKernelGGL((k_smooth_vec<true>), grid, block, ldsB, c->stream, sa, fullMask);
+                    const int64_t waves = int64_t(d) * nF * (nt / 64);
+                    nSeg = int(std::min<int64_t>((6 * 1024 + waves - 1) / waves, rs.w / (4 * warm)));
                 }
-                else
+                nSeg = std::max(1, std::min(nSeg, std::min(c->segCap, rs.w / 16)));
+                int segW = cdiv(cdiv(rs.w, nSeg), 16) * 16;
+                nSeg = cdiv(rs.w, segW);
+                sa.segW = segW;
+                sa.warm = warm;
+                sa.nSeg = nSeg;
+                sa.specState = c->d_specState;
+                sa.trueState = c->d_trueState;
+                sa.redo = nullptr;
+                auto launchSv = [&](dim3 grid) {
+                    if (halfNext)
+                    {
+                        hipLaunchKernelGGL((k_smooth_vec<true>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
+                    }
+                    else
+                    {
+                        hipLaunchKernelGGL((k_smooth_vec<false>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
+                    }
+                };
+                if (nSeg > 1)
                 {
-                    hipLaunchKernelGGL((k_smooth_vec<false>), grid, block, ldsB, c->stream, sa, fullMask);
+                    HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * size_t(nF) * d, c->stream));
                 }
+                launchSv(dim3(d, nSeg, nF));
                 LAUNCHCHK(c, "k_smooth_vec");
+                if (nSeg > 1)
+                {
+                    // the segments' hand-overs, bit for bit; planes with a difference are recomputed as one chain
+                    hipLaunchKernelGGL(k_smooth_verify, dim3(nSeg - 1, d, nF), dim3(256), 0, c->stream, (const float*)c->d_specState, (const float*)c->d_trueState,
+                        rs.h, nSeg, d, c->d_redo, c->smoothForceRedo);
+                    LAUNCHCHK(c, "k_smooth_verify");
+                    sa.segW = rs.w;
+                    sa.warm = 0;
+                    sa.nSeg = 1;
+                    sa.redo = c->d_redo;
+                    launchSv(dim3(d, 1, nF));
+                    LAUNCHCHK(c, "k_smooth_vec(repair)");
+                }
             }
             colorDone = true;
         }

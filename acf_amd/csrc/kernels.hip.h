@@ -482,6 +482,12 @@ struct SmoothVecArgs
     int32_t h, w, plane0; // plane0: first plane of this launch (blockIdx.x is relative to it)
     float p, rkHalf, rq_y;
     float* dump;      // >= 256 floats nobody reads
+    // Column segments (blockIdx.y = segment): see "speculative segments" below.  segW = columns per segment (a multiple of
+    // 16; >= w: one segment, the plain recursion), warm = warm-up columns before a segment's first (a multiple of 16).
+    int32_t segW, warm, nSeg, nPlanes;
+    float* specState; // [frame][plane][segment][h]: a segment's state after its warm-up = its guess of column x0 - 1
+    float* trueState; // [frame][plane][segment][h]: the previous segment's output column x0 - 1
+    const int32_t* redo; // repair launch (nSeg == 1): [frame][plane] != 0 -> this plane is recomputed as one segment; NULL: every plane
 };
 
 __device__ __forceinline__ float wave_rol1(float v)
@@ -496,10 +502,23 @@ __device__ __forceinline__ float wave_ror1(float v)
 #define SV_CH 8
 constexpr int SV_K = 2;              // halo quads per side: 4 * SV_K rows = SV_CH columns of independence
 constexpr int SV_OWN = 64 - 2 * SV_K; // quads a wave owns
+// Speculative segments.  The recursion along image-x is a contraction: column i depends on column i - 1 through
+// nrm * (1, 2, 1) = a factor 1/4 (convConst.cpp:445-525 with p = 2), so the influence of whatever a chain STARTED from
+// shrinks fourfold per column and is below the last bit of every float after ~15-25 columns; once two chains agree in
+// every bit they agree for ever (same inputs, same state, same instructions).  One plane is a chain of w steps with ~5
+// waves: at 1080p a launch of 96 frames keeps 1.4 waves per SIMD busy, bound by the latency of a column step.  So the
+// plane is cut into segments; segment s starts `warm` columns early from the border formula (Il = Im, what column 0 does),
+// discards what it computes there, and from its first own column on emits the same bits as the single chain — PROVIDED
+// its state at the end of the warm-up equals the previous segment's last output, which is not assumed but checked:
+// both are written to side buffers, k_smooth_verify compares them bit for bit, and a plane with any difference is
+// recomputed as one chain by a second launch of this kernel (`redo`) before anything reads it.  Exactness therefore does
+// not rest on the contraction argument; only speed does (no repair has been observed with warm >= 32).
 template <bool FULL, bool HALF, bool SHRINK>
 __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
+    const int seg = blockIdx.y;
+    const int x0 = seg * a.segW, x1 = min(x0 + a.segW, w), xs = max(x0 - a.warm, 0);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nWv = blockDim.x >> 6;
     const int qraw = wv * SV_OWN + lane - SV_K;
     const bool valid = lane >= SV_K && lane < 64 - SV_K && qraw < nq; // this lane owns quad qraw; the others are halo / idle
@@ -526,7 +545,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         BUF[j] = *reinterpret_cast<const float4*>(I + int64_t(min((I0) + j, w - 1)) * h);         \
     }
     // column i = I0 + JJ (JJ compile-time, I0 % 8 == 0): CUR = column i, NXT = column min(i+1, w-1)
-#define SV_COL(I0, JJ, CUR, NXT)                                                                  \
+#define SV_COL(EMIT, I0, JJ, CUR, NXT)                                                            \
     {                                                                                             \
         const int i_ = (I0) + (JJ);                                                               \
         const float im[4] = { CUR.x, CUR.y, CUR.z, CUR.w };                                       \
@@ -534,7 +553,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         float T[4];                                                                               \
         _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
         {                                                                                         \
-            const float il = (i_ == 0) ? im[k] : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507) */ \
+            const float il = (i_ == xs) ? im[k] : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507); a later segment's warm-up starts the same way */ \
             T[k] = nrm * (il + p * im[k] + ir[k]);                                                \
         }                                                                                         \
         const float up = wave_ror1(T[3]); /* row 4q-1: the previous lane's last row */            \
@@ -548,12 +567,12 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             const float mid3 = T[2] + p * T[3] + dn, bot3 = T[2] + p1 * T[3];                     \
             o[3] = last ? bot3 : mid3;                                                            \
         }                                                                                         \
-        if (FULL)                                                                                 \
+        if (FULL && (EMIT))                                                                       \
         {                                                                                         \
             float* dst = valid ? Of + int64_t(i_) * h : a.dump + 4 * lane;                        \
             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);                \
         }                                                                                         \
-        if (HALF && ((JJ) & 1))                                                                   \
+        if (HALF && (EMIT) && ((JJ) & 1))                                                         \
         {                                                                                         \
             float2 hv;                                                                            \
             hv.x = ((prev[0] + o[0]) + (prev[1] + o[1])) * a.rkHalf;                              \
@@ -561,7 +580,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             float* dst = valid ? Oh + int64_t(i_ >> 1) * hb : a.dump + 2 * lane;                  \
             *reinterpret_cast<float2*>(dst) = hv;                                                 \
         }                                                                                         \
-        if (SHRINK)                                                                               \
+        if (SHRINK && (EMIT))                                                                     \
         {                                                                                         \
             _Pragma("unroll") for (int k = 0; k < 4; k++)                                         \
             {                                                                                     \
@@ -595,23 +614,40 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             prev[0] = v_.x, prev[1] = v_.y, prev[2] = v_.z, prev[3] = v_.w;                       \
         }                                                                                         \
     }
-#define SV_CHUNK(I0, A_, B_)                                                                      \
-    SV_COL(I0, 0, A_[0], A_[1]) SV_COL(I0, 1, A_[1], A_[2]) SV_COL(I0, 2, A_[2], A_[3]) SV_COL(I0, 3, A_[3], A_[4]) \
-    SV_COL(I0, 4, A_[4], A_[5]) SV_COL(I0, 5, A_[5], A_[6]) SV_COL(I0, 6, A_[6], A_[7]) SV_COL(I0, 7, A_[7], B_[0]) \
+#define SV_CHUNK(EMIT, I0, A_, B_)                                                                \
+    SV_COL(EMIT, I0, 0, A_[0], A_[1]) SV_COL(EMIT, I0, 1, A_[1], A_[2]) SV_COL(EMIT, I0, 2, A_[2], A_[3]) SV_COL(EMIT, I0, 3, A_[3], A_[4]) \
+    SV_COL(EMIT, I0, 4, A_[4], A_[5]) SV_COL(EMIT, I0, 5, A_[5], A_[6]) SV_COL(EMIT, I0, 6, A_[6], A_[7]) SV_COL(EMIT, I0, 7, A_[7], B_[0]) \
     SV_REFRESH(I0)
-    SV_LOAD(c0, 0);
-    int i = 0;
-    for (; i + 2 * SV_CH <= w; i += 2 * SV_CH)
+    const int64_t stateOff = ((f * a.nPlanes + z) * a.nSeg) * int64_t(h) + 4 * qc;
+    SV_LOAD(c0, xs);
+    int i = xs;
+    // warm-up of a later segment (x0 - xs is a multiple of 16): same arithmetic, nothing leaves
+    for (; i < x0; i += 2 * SV_CH)
     {
         SV_LOAD(c1, i + SV_CH);
-        SV_CHUNK(i, c0, c1);
-        SV_LOAD(c0, i + 2 * SV_CH); // clamped to the last column past the end
-        SV_CHUNK(i + SV_CH, c1, c0);
+        SV_CHUNK(false, i, c0, c1);
+        SV_LOAD(c0, i + 2 * SV_CH);
+        SV_CHUNK(false, i + SV_CH, c1, c0);
     }
-    if (i < w) // one chunk left (w % 16 == 8)
+    if (seg > 0 && valid)
+    {
+        *reinterpret_cast<float4*>(a.specState + stateOff + int64_t(seg) * h) = make_float4(prev[0], prev[1], prev[2], prev[3]);
+    }
+    for (; i + 2 * SV_CH <= x1; i += 2 * SV_CH)
     {
         SV_LOAD(c1, i + SV_CH);
-        SV_CHUNK(i, c0, c1);
+        SV_CHUNK(true, i, c0, c1);
+        SV_LOAD(c0, i + 2 * SV_CH); // clamped to the last column past the end
+        SV_CHUNK(true, i + SV_CH, c1, c0);
+    }
+    if (i < x1) // one chunk left (w % 16 == 8)
+    {
+        SV_LOAD(c1, i + SV_CH);
+        SV_CHUNK(true, i, c0, c1);
+    }
+    if (seg + 1 < a.nSeg && valid)
+    {
+        *reinterpret_cast<float4*>(a.trueState + stateOff + int64_t(seg + 1) * h) = make_float4(prev[0], prev[1], prev[2], prev[3]);
     }
 #undef SV_LOAD
 #undef SV_COL
@@ -629,6 +665,10 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fu
 {
     extern __shared__ float lds[]; // [2 chunk parities][8 waves][2 sides][SV_K quads][4]: the waves' edge state
     const int z = a.plane0 + blockIdx.x;
+    if (a.redo && a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+    {
+        return; // repair launch: this plane's segments agreed
+    }
     if ((fullMask >> z) & 1u)
     {
         smooth_vec_body<true, HALF, true>(a, lds, z);
@@ -636,6 +676,26 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fu
     else
     {
         smooth_vec_body<false, HALF, true>(a, lds, z);
+    }
+}
+
+// k_smooth_vec's segments: spec[f][z][s] (segment s's state after its warm-up) against tru[f][z][s] (segment s - 1's last
+// output column), s = 1 .. nSeg - 1, bit for bit; any difference marks the plane for the repair launch.
+__global__ void __launch_bounds__(256) k_smooth_verify(const float* __restrict__ spec, const float* __restrict__ tru, int h, int nSeg, int nPlanes,
+    int32_t* __restrict__ redo, int force)
+{
+    const int64_t plane = int64_t(blockIdx.z) * nPlanes + blockIdx.y;
+    const int s = 1 + blockIdx.x;
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(spec) + (plane * nSeg + s) * int64_t(h);
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(tru) + (plane * nSeg + s) * int64_t(h);
+    bool bad = force != 0;
+    for (int y = threadIdx.x; y < h; y += 256)
+    {
+        bad = bad || (a[y] != b[y]);
+    }
+    if (bad)
+    {
+        redo[plane] = 1;
     }
 }
 

@@ -1,0 +1,56 @@
+"""k_smooth_vec's speculative column segments (acf_amd/csrc/kernels.hip.h): the image smoothing's recursion along image-x
+(convTri1 called in place, chnsCompute.cpp:239: SURVEY.md H2) is cut into segments that start `smooth_warm` columns early,
+and every hand-over is checked bit for bit on the device; a plane with a difference is recomputed as one chain.  Whatever
+the segmentation, the pyramid must be the oracle's, bit for bit — including when the warm-up is too short to converge
+(the repair launch does the work), when every plane is forced through the repair, and on frames with exactly-zero regions."""
+import numpy as np
+import pytest
+
+from acf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, det, frames, model, H, W):
+    import torch
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    for f in range(len(frames)):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want, whits = oracle.detect(plan, pyr)
+        assert np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)), f
+        d, h = det.detections(f)
+        assert d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes()
+
+
+@pytest.mark.parametrize("segments,warm,force", [(0, 48, 0), (1, 48, 0), (4, 48, 0), (7, 32, 0), (16, 16, 0), (5, 48, 1)])
+def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force):
+    from acf_amd.detector import HipDetector
+    H, W = 272, 640   # w % 8 == 0, h % 4 == 0: the vector smoothing kernel; two real scales use it
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
+    frames = np.stack([synth.make_frame(51 + i, H, W, "luv") for i in range(3)])
+    # a black band and a black box: regions where the recursion's state is exactly zero
+    frames[1, :, 200:330, :] = 0.0
+    frames[2, :, 400:, 100:180] = 0.0
+    det = HipDetector(model, H, W, 3, max_batch=3, max_hits=1 << 15)
+    det.set_option("smooth_segments", segments)
+    det.set_option("smooth_warm", warm)
+    det.set_option("smooth_force_redo", force)
+    _check(oracle, det, frames, model, H, W)
+    det.close()
+
+
+def test_segmented_smoothing_rgb_and_sub_batches(oracle):
+    """RGB input (the smoothing follows rgb2luv), sub-batch contexts (option streams) and the rank-cell cascade together."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 200, 512
+    model = synth.make_model(seed=5, name="TINY", nTrees=96, cascThr=-1.0)
+    frames = np.stack([synth.make_frame(71 + i, H, W, "rgb") for i in range(4)])
+    det = HipDetector(streams=2)
+    det.set_model(model)
+    det.set_option("smooth_segments", 6)
+    det.set_option("smooth_warm", 32)
+    det.plan(H, W, 3, max_batch=4, max_hits=1 << 15)
+    _check(oracle, det, frames, model, H, W)
+    det.close()
