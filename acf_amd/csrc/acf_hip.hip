@@ -1789,7 +1789,13 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             dd.dst_frame_stride = int64_t(d) * np;
             rs.descIndex = int(c->h_descs.size());
             c->h_descs.push_back(dd);
-            rs.tiling = resampleTilePlan(dd, arena);
+            // 8 output columns per tile: the image resamples are bound by the latency of a tile's fill, and small tiles put more
+            // of them on a CU (13 KB of LDS instead of 40: 0.65 -> 0.57 ms per 96 frames for the two small real scales); env: A/B
+            rs.tiling = resampleTilePlan(dd, arena, getenv("ACF_HIP_RT_XO") ? atoi(getenv("ACF_HIP_RT_XO")) : 8);
+            if (rs.tiling.rows == 0)
+            {
+                rs.tiling = resampleTilePlan(dd, arena);
+            }
             if ((rc = devAlloc(c, &rs.img, size_t(B) * d * np)))
             {
                 return rc;
@@ -2614,7 +2620,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         }
         // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
         bool colorDone = false;
-        const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 8 == 0 &&
+        const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 4 == 0 && rs.w >= 16 &&
             rs.h / 4 <= 8 * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
         if (fuseSm)
         {

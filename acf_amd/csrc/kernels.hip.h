@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(1024) k_smooth_tri1(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------
-// Image smoothing with 16 bytes per lane and fused consumers (h % 4 == 0, w % 8 == 0).
+// Image smoothing with 16 bytes per lane and fused consumers (h % 4 == 0, w % 4 == 0).
 // A thread owns 4 consecutive image rows of one plane; the recursion along image-x
 // is k_smooth_tri1's.  Of the two y neighbours a row needs, three of four are the
 // thread's own registers; the first / last row's are the adjacent LANES' (two wave rotates).
@@ -640,11 +640,24 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         SV_LOAD(c0, i + 2 * SV_CH); // clamped to the last column past the end
         SV_CHUNK(true, i + SV_CH, c1, c0);
     }
-    if (i < x1) // one chunk left (w % 16 == 8)
+    // what is left of the last segment: a chunk (w % 16 >= 8) and / or four columns (w % 8 == 4; column w - 1's right
+    // neighbour is itself: the loads are clamped to w - 1)
+#define SV_TAIL4(I0, A_) SV_COL(true, I0, 0, A_[0], A_[1]) SV_COL(true, I0, 1, A_[1], A_[2]) SV_COL(true, I0, 2, A_[2], A_[3]) SV_COL(true, I0, 3, A_[3], A_[4])
+    if (i + SV_CH <= x1)
     {
         SV_LOAD(c1, i + SV_CH);
         SV_CHUNK(true, i, c0, c1);
+        i += SV_CH;
+        if (i < x1)
+        {
+            SV_TAIL4(i, c1);
+        }
     }
+    else if (i < x1)
+    {
+        SV_TAIL4(i, c0);
+    }
+#undef SV_TAIL4
     if (seg + 1 < a.nSeg && valid)
     {
         *reinterpret_cast<float4*>(a.trueState + stateOff + int64_t(seg + 1) * h) = make_float4(prev[0], prev[1], prev[2], prev[3]);

@@ -54,3 +54,22 @@ def test_segmented_smoothing_rgb_and_sub_batches(oracle):
     det.plan(H, W, 3, max_batch=4, max_hits=1 << 15)
     _check(oracle, det, frames, model, H, W)
     det.close()
+
+
+@pytest.mark.parametrize("W,segments", [(484, 0), (484, 3), (492, 1), (20, 0), (36, 2)])
+def test_widths_that_are_not_multiples_of_eight(oracle, W, segments):
+    """w % 8 == 4: the vector smoothing kernel's four-column tail (the third real scale of a 1080p frame is 484 columns wide)."""
+    from acf_amd.detector import HipDetector
+    H = 136 if W > 100 else 64
+    model = synth.make_model(seed=3, name="TINY", nTrees=64, cascThr=-1.0)
+    frames = np.stack([synth.make_frame(81 + i, H, W, "luv") for i in range(2)])
+    det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
+    det.set_option("smooth_segments", segments)
+    det.set_option("smooth_warm", 16)
+    import torch
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    for f in range(2):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        assert np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)), (W, f)
+    det.close()
