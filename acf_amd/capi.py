@@ -173,6 +173,7 @@ def load():
         "acf_hip_create": ([C.c_int, C.c_void_p, C.POINTER(ctx)], C.c_int),
         "acf_hip_destroy": ([ctx], C.c_int),
         "acf_hip_abi_version": ([], C.c_int),
+        "acf_hip_device_count": ([C.POINTER(C.c_int)], C.c_int),
         "acf_hip_last_error": ([ctx], C.c_char_p),
         "acf_hip_set_option": ([ctx, C.c_char_p, C.c_int], C.c_int),
         "acf_hip_set_model": ([ctx, C.POINTER(Params)], C.c_int),
@@ -228,7 +229,7 @@ def load():
 
 
 DECLARED_SYMBOLS = [
-    "acf_hip_create", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
+    "acf_hip_create", "acf_hip_device_count", "acf_hip_destroy", "acf_hip_abi_version", "acf_hip_last_error", "acf_hip_set_option",
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_get_lambdas", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits", "acf_hip_get_raw_detections",

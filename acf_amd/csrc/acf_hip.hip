@@ -812,6 +812,30 @@ int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
     return ACF_HIP_OK;
 }
 
+int acf_hip_device_count(int* count)
+{
+    if (!count)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    {
+        (void)hipGetLastError();
+        return ACF_HIP_E_NODEVICE;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, i) == hipSuccess && std::string(pr.gcnArchName).rfind("gfx950", 0) == 0)
+        {
+            (*count)++;
+        }
+    }
+    return *count > 0 ? ACF_HIP_OK : ACF_HIP_E_NODEVICE;
+}
+
 int acf_hip_destroy(acf_hip_ctx* c)
 {
     if (c)

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace acf
 {
@@ -713,7 +714,14 @@ int HipDetector::operator()(const Pyramid& P, RectVec& objects, RealVec* scores)
     for (int i = 0; i < P.nScales; i++)
     {
         DetectionVec ds;
-        acfDetect1(P.data[size_t(i)][0], opts.pPyramid.pChns.shrink, opts.modelDsPad, opts.stride, opts.cascThr, ds);
+        if (P.rois.size() > size_t(i) && !P.rois[size_t(i)].empty()) // ACF.cpp:292-299
+        {
+            acfDetect1(P.data[size_t(i)][0], P.rois[size_t(i)], opts.pPyramid.pChns.shrink, opts.modelDsPad, opts.stride, opts.cascThr, ds);
+        }
+        else
+        {
+            acfDetect1(P.data[size_t(i)][0], opts.pPyramid.pChns.shrink, opts.modelDsPad, opts.stride, opts.cascThr, ds);
+        }
         // ACF.cpp:302-312 — ds rois are in the transposed convention (x along image-y)
         const double sw = P.scaleshw[size_t(i)].width, sh = P.scaleshw[size_t(i)].height;
         const int bw = int(std::nearbyint(double(opts.modelDs.width) / P.scales[size_t(i)]));
@@ -765,6 +773,33 @@ void HipDetector::acfDetect1(const MatP& chns, int, const Size&, int, double, De
 {
     // chns: fused level buffer, rows = nChns * wP, cols = hP
     detect1(chns.data(), nullptr, chns.rows(), chns.cols(), objects);
+}
+
+void HipDetector::acfDetect1(const MatP& atlas, const RectVec& rois, int, const Size&, int, double, DetectionVec& objects)
+{
+    // computeChannelIndex (acfDetect1.cpp:346-366): cids[z][c][r] = z * chnStride + c * rowStride + r with
+    // chnStride = rois[1].x - rois[0].x and rowStride = the atlas plane's step; window grid from the channel size
+    if (rois.size() < 2)
+    {
+        throw Exception(ACF_HIP_E_INVALID, "acfDetect1(rois): at least two channel rois (the reference asserts rois.size() > 1)");
+    }
+    const int nChns = int(rois.size()), rowStride = atlas.cols();
+    const int chnStride = rois[1].x - rois[0].x;
+    const int wP = rois[0].height, hP = rois[0].width; // a channel: wP columns c (stride rowStride) of hP rows r
+    if (chnStride <= 0 || wP <= 0 || hP <= 0 || hP > rowStride ||
+        size_t(nChns - 1) * chnStride + size_t(wP - 1) * rowStride + hP > atlas.numel())
+    {
+        throw Exception(ACF_HIP_E_INVALID, "acfDetect1(rois): channel rois outside the atlas plane");
+    }
+    MatP fused(nChns * wP, hP, 1);
+    for (int z = 0; z < nChns; z++)
+    {
+        for (int c = 0; c < wP; c++)
+        {
+            std::memcpy(fused.data() + (size_t(z) * wP + c) * hP, atlas.data() + size_t(z) * chnStride + size_t(c) * rowStride, sizeof(float) * hP);
+        }
+    }
+    detect1(fused.data(), nullptr, fused.rows(), fused.cols(), objects);
 }
 
 void HipDetector::acfDetect1(const uint8_t* chnsU8, int rows, int cols, DetectionVec& objects)
@@ -907,6 +942,104 @@ int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize
     }
     H.create(M.rows() / binSize, M.cols() / binSize, nOrients);
     check(m_api->acf_hip_op_gradient_hist(m_ctx, M.data(), O.data(), H.data(), M.cols(), M.rows(), binSize, nOrients, full), "acf_hip_op_gradient_hist");
+    return 0;
+}
+
+// ---- HipDetectorPool: one detector per device, frames in contiguous blocks
+static std::vector<int> poolDevices(std::vector<int> devices)
+{
+    if (devices.empty())
+    {
+        int n = 0;
+        if (hip::load().acf_hip_device_count(&n) || n <= 0)
+        {
+            throw Exception(ACF_HIP_E_NODEVICE, "HipDetectorPool: no gfx950 device");
+        }
+        for (int i = 0; i < n; i++)
+        {
+            devices.push_back(i);
+        }
+    }
+    return devices;
+}
+
+HipDetectorPool::HipDetectorPool(const HipDetector::Options& o, const HipDetector::Classifier& c, std::vector<int> devices)
+{
+    for (int dev : poolDevices(std::move(devices)))
+    {
+        m_dets.emplace_back(new HipDetector(o, c, dev));
+    }
+}
+
+HipDetectorPool::HipDetectorPool(const std::string& filename, std::vector<int> devices)
+{
+    for (int dev : poolDevices(std::move(devices)))
+    {
+        m_dets.emplace_back(new HipDetector(filename, dev));
+    }
+}
+
+void HipDetectorPool::shardRange(int nFrames, int world, int rank, int& begin, int& end)
+{
+    const int base = nFrames / world, extra = nFrames % world;
+    begin = rank * base + std::min(rank, extra);
+    end = begin + base + (rank < extra ? 1 : 0);
+}
+
+int HipDetectorPool::detectBatch(const float* frames, int nFrames, int rows, int cols, int channels,
+    std::vector<RectVec>& objects, std::vector<RealVec>* scores)
+{
+    const int world = int(m_dets.size());
+    objects.assign(size_t(std::max(nFrames, 0)), RectVec());
+    if (scores)
+    {
+        scores->assign(size_t(std::max(nFrames, 0)), RealVec());
+    }
+    const size_t per = size_t(rows) * cols * channels;
+    std::vector<std::vector<RectVec>> obj(static_cast<size_t>(world));
+    std::vector<std::vector<RealVec>> sc(static_cast<size_t>(world));
+    std::vector<std::string> errs(static_cast<size_t>(world));
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++)
+    {
+        int b, e;
+        shardRange(nFrames, world, r, b, e);
+        if (e <= b)
+        {
+            continue;
+        }
+        th.emplace_back([&, r, b, e] {
+            try
+            {
+                m_dets[size_t(r)]->detectBatch(frames + size_t(b) * per, e - b, rows, cols, channels, obj[size_t(r)], scores ? &sc[size_t(r)] : nullptr);
+            }
+            catch (const std::exception& ex)
+            {
+                errs[size_t(r)] = ex.what();
+            }
+        });
+    }
+    for (auto& t : th)
+    {
+        t.join();
+    }
+    for (int r = 0; r < world; r++)
+    {
+        if (!errs[size_t(r)].empty())
+        {
+            throw Exception(ACF_HIP_E_HIP, "HipDetectorPool: device " + std::to_string(r) + ": " + errs[size_t(r)]);
+        }
+        int b, e;
+        shardRange(nFrames, world, r, b, e);
+        for (int f = b; f < e; f++)
+        {
+            objects[size_t(f)] = std::move(obj[size_t(r)][size_t(f - b)]);
+            if (scores)
+            {
+                (*scores)[size_t(f)] = std::move(sc[size_t(r)][size_t(f - b)]);
+            }
+        }
+    }
     return 0;
 }
 

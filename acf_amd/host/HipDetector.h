@@ -25,6 +25,7 @@
 #include <stdexcept>
 #include <iosfwd>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace acf
@@ -176,8 +177,15 @@ public:
         std::vector<std::vector<MatP>> data;
         std::vector<double> lambdas, scales;
         std::vector<Size2d> scaleshw;
+        // ACF.h:377-378 ".rois - [LEVELS x CHANNELS] array for channel access": when rois[i] is not empty, data[i][0] is an
+        // ATLAS plane (the GL backend's texture read-back, GPUACF.cpp) whose channels sit side by side: channel z starts
+        // (rois[i][1].x - rois[i][0].x) * z elements after the plane's origin, element (c, r) of a channel c * rowStride + r
+        // further (computeChannelIndex, acfDetect1.cpp:346-366, GPU_ACF_TRANSPOSE form); rois[i][z].{height, width} = the
+        // channel's {columns c, rows r}.  The plane's cols() is its row stride.
+        std::vector<std::vector<Rect>> rois;
         void clear()
         {
+            rois.clear();
             data.clear();
             lambdas.clear();
             scales.clear();
@@ -265,8 +273,11 @@ public:
     static void getScales(int nPerOct, int nOctUp, const Size& minDs, int shrink, const Size& sz,
         std::vector<double>& scales, std::vector<Size2d>& scaleshw);
 
-    // acfDetect1.cpp:309-335: one level; rois unused on this path (fused buffers only)
+    // acfDetect1.cpp:309-335: one level of fused channels ([nChns * wP rows][hP cols]) ...
     void acfDetect1(const MatP& chns, int shrink, const Size& modelDsPad, int stride, double cascThr, DetectionVec& objects);
+    // ... or of an atlas plane with one roi per channel (createDetector's computeChannelIndex branch, acfDetect1.cpp:262-265,
+    // 346-366): the channels are gathered into a fused buffer on the host and take the same device path
+    void acfDetect1(const MatP& atlas, const RectVec& rois, int shrink, const Size& modelDsPad, int stride, double cascThr, DetectionVec& objects);
     // the same on uint8_t channels ([nChns * wP rows][hP cols] bytes), the CV_8UC1 branch of allocDetector (acfDetect1.cpp:187-192)
     void acfDetect1(const uint8_t* chnsU8, int rows, int cols, DetectionVec& objects);
     // Detector::evaluate (ACF.h:543-544, acfDetect1.cpp:337-342): score of the window at (0,0) of a fused channel buffer, trees added
@@ -309,6 +320,33 @@ private:
     bool m_taps = false; // "taps" option on: per-stage planes stay readable (needed by the logger)
     void* m_pin = nullptr; // pinned scratch of operator()(packed 8-bit)
     size_t m_pinBytes = 0;
+};
+
+// One acf::HipDetector per visible MI355X (the north star's "batched frames shard across the GPUs of one node", host side in
+// C++): detectBatch cuts the batch into contiguous blocks — the rule of acf_amd/dist.py:shard_range, blocks differ by at most
+// one frame —, runs every block on its device from its own thread (frames are independent: no exchange between devices) and
+// returns the per-frame results in frame order.  Setters are forwarded to every detector.
+class HipDetectorPool
+{
+public:
+    using RectVec = HipDetector::RectVec;
+    using RealVec = HipDetector::RealVec;
+    // devices: the device ordinals to use; empty = every visible gfx950 device (acf_hip_device_count)
+    HipDetectorPool(const HipDetector::Options& o, const HipDetector::Classifier& c, std::vector<int> devices = {});
+    explicit HipDetectorPool(const std::string& filename, std::vector<int> devices = {});
+    size_t size() const { return m_dets.size(); }
+    HipDetector& operator[](size_t i) { return *m_dets[i]; }
+    static void shardRange(int nFrames, int world, int rank, int& begin, int& end);
+    void setDoNonMaximaSuppression(bool f) { for (auto& d : m_dets) d->setDoNonMaximaSuppression(f); }
+    void setMaxDetectionCount(size_t n) { for (auto& d : m_dets) d->setMaxDetectionCount(n); }
+    void setDetectionScorePruneRatio(double r) { for (auto& d : m_dets) d->setDetectionScorePruneRatio(r); }
+    void setIsLuv(bool f) { for (auto& d : m_dets) d->setIsLuv(f); }
+    int acfModify(const HipDetector::Modify& m) { int rc = 0; for (auto& d : m_dets) rc |= d->acfModify(m); return rc; }
+    int detectBatch(const float* framesTransposedPlanar, int nFrames, int rows, int cols, int channels,
+        std::vector<RectVec>& objects, std::vector<RealVec>* scores = nullptr);
+
+private:
+    std::vector<std::unique_ptr<HipDetector>> m_dets;
 };
 
 } // namespace acf

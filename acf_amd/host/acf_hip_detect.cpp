@@ -17,6 +17,7 @@
 #include "HipDetector.h"
 #include "ModelIO.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -219,7 +220,34 @@ int main(int argc, char** argv)
             }
         }
         const size_t per = size_t(rows) * cols * ch;
-        if (a.count("batch"))
+        if (a.count("pool"))
+        {
+            // acf::HipDetectorPool: one detector per visible device ("--pool N": the first N devices, several times the same
+            // device allowed through --pool-devices 0,0: contexts are independent), frames in contiguous blocks
+            std::vector<int> devs;
+            if (a.count("pool-devices"))
+            {
+                std::stringstream ss(a["pool-devices"]);
+                std::string tok;
+                while (std::getline(ss, tok, ','))
+                {
+                    devs.push_back(std::stoi(tok));
+                }
+            }
+            acf::HipDetectorPool pool(a["model"], devs);
+            pool.setIsLuv(a.count("luv") != 0);
+            pool.setDoNonMaximaSuppression(a.count("nms") != 0);
+            if (a.count("max-count")) pool.setMaxDetectionCount(size_t(std::stoul(a["max-count"])));
+            std::vector<HipDetector::RectVec> objs;
+            std::vector<HipDetector::RealVec> scores;
+            pool.detectBatch(frames.data(), cnt, rows, cols, ch, objs, &scores);
+            std::fprintf(stderr, "pool: %zu detector(s)\n", pool.size());
+            for (int f = 0; f < cnt; f++)
+            {
+                printFrame(f, objs[size_t(f)], scores[size_t(f)]);
+            }
+        }
+        else if (a.count("batch"))
         {
             std::vector<HipDetector::RectVec> objs;
             std::vector<HipDetector::RealVec> scores;
@@ -252,7 +280,36 @@ int main(int argc, char** argv)
                     });
                     continue;
                 }
-                if (a.count("via-pyramid"))
+                if (a.count("via-atlas"))
+                {
+                    // the Pyramid a GL-style backend hands over: every level as ONE atlas plane with a roi per channel
+                    // (ACF.h:377-378, acfDetect1.cpp:346-366): channels side by side with a gap, row stride > channel rows
+                    HipDetector::Pyramid P, A;
+                    det.computePyramid(Ip, P);
+                    A = P;
+                    A.rois.assign(size_t(P.nScales), {});
+                    for (int i = 0; i < P.nScales; i++)
+                    {
+                        const acf::MatP& L = P.data[size_t(i)][0];
+                        const int hP = L.cols(), wP = L.rows() / P.nChns;
+                        // channels side by side along the atlas rows (GPUACF's texture layout): element (c, r) of channel z at
+                        // c * rowStride + z * chnStride + r
+                        const int chnStride = hP + 3, rowStride = P.nChns * chnStride;
+                        acf::MatP view(wP, rowStride, 1);
+                        std::fill(view.data(), view.data() + view.numel(), -1.f);
+                        for (int z = 0; z < P.nChns; z++)
+                        {
+                            for (int c = 0; c < wP; c++)
+                            {
+                                std::memcpy(view.data() + size_t(c) * rowStride + size_t(z) * chnStride, L.data() + (size_t(z) * wP + c) * hP, sizeof(float) * hP);
+                            }
+                            A.rois[size_t(i)].push_back(acf::Rect(z * chnStride, 0, hP, wP));
+                        }
+                        A.data[size_t(i)][0] = view;
+                    }
+                    det(A, objs, &scores);
+                }
+                else if (a.count("via-pyramid"))
                 {
                     // computePyramid -> host Pyramid -> another image through the detector -> operator()(Pyramid): the
                     // detections must be P's (the reference re-runs acfDetect1 on the pyramid it is handed, ACF.cpp:268-367)

@@ -37,6 +37,7 @@ static void doLoad(const std::string& path)
         return;                                                                           \
     }
     ACF_HIP_FN(acf_hip_create)
+    ACF_HIP_FN(acf_hip_device_count)
     ACF_HIP_FN(acf_hip_destroy)
     ACF_HIP_FN(acf_hip_abi_version)
     ACF_HIP_FN(acf_hip_last_error)

@@ -21,6 +21,7 @@ struct Api
     void* handle = nullptr;
 #define ACF_HIP_FN(name) decltype(&::name) name = nullptr;
     ACF_HIP_FN(acf_hip_create)
+    ACF_HIP_FN(acf_hip_device_count)
     ACF_HIP_FN(acf_hip_destroy)
     ACF_HIP_FN(acf_hip_abi_version)
     ACF_HIP_FN(acf_hip_last_error)

@@ -172,6 +172,9 @@ typedef struct acf_hip_ctx acf_hip_ctx;
  * stream owned by the context).  Replaces constructing an acf::Detector
  * (ACF.h:59-66); good() == (return value == ACF_HIP_OK). */
 ACF_HIP_API int acf_hip_create(int device, void* stream, acf_hip_ctx** out);
+/* Number of gfx950 devices visible to the process (0 and ACF_HIP_E_NODEVICE when there is none): what a multi-device host
+ * (acf::HipDetectorPool, one context per device) iterates over. */
+ACF_HIP_API int acf_hip_device_count(int* count);
 ACF_HIP_API int acf_hip_destroy(acf_hip_ctx* ctx);
 ACF_HIP_API int acf_hip_abi_version(void);
 /* Last error text for this context (thread-compatible, like one Detector per thread). */

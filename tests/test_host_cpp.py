@@ -263,3 +263,35 @@ def test_cli_nms_beyond_device_capacity_is_suppressed_on_the_host(cli, oracle, t
         assert 0 < len(keep) <= 12
         assert [g[:4] for g in got] == [tuple(want[i][:4]) for i in keep]
         assert [g[4] for g in got] == [want[i][4] for i in keep]
+
+
+@pytest.mark.gpu
+def test_cli_pyramid_as_roi_atlas(cli, oracle, tmp_path):
+    """Pyramid::rois (ACF.h:377-378): every level handed over as one atlas plane with a roi per channel — the form the GL
+    backend's read-back has — goes through computeChannelIndex's addressing (acfDetect1.cpp:346-366) to the same detections."""
+    H, W = 96, 128
+    model = synth.make_model(seed=3, name="TINY", nTrees=96)
+    frames = [synth.make_frame(40 + i, H, W, "luv") for i in range(2)]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", "2", "--luv", "--via-atlas"])
+    got = parse(p.stdout)
+    want = _oracle_dets(oracle, model, frames, H, W, 3)
+    assert sum(len(w) for w in want) > 0 and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,count", [("0", 5), ("0,0", 5), ("0,0,0", 2)])
+def test_cli_detector_pool_shards_frames(cli, oracle, tmp_path, devices, count):
+    """acf::HipDetectorPool: one detector per listed device (the same device several times = independent contexts: what a
+    one-GPU box can exercise), frames in contiguous blocks that differ by at most one, results in frame order."""
+    H, W = 96, 128
+    model = synth.make_model(seed=3, name="TINY", nTrees=96)
+    frames = [synth.make_frame(60 + i, H, W, "luv") for i in range(count)]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H),
+                  "--channels", "3", "--count", str(count), "--luv", "--pool", "--pool-devices", devices])
+    assert "pool: %d detector(s)" % len(devices.split(",")) in p.stderr
+    assert parse(p.stdout) == _oracle_dets(oracle, model, frames, H, W, 3)
