@@ -204,6 +204,7 @@ def load():
         "acf_hip_get_raw_detections": ([ctx, C.c_int, C.POINTER(Detection), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_export_detections": ([ctx, C.c_void_p, C.c_int], C.c_int),
         "acf_hip_synchronize": ([ctx], C.c_int),
+        "acf_hip_get_repairs": ([ctx, C.POINTER(C.c_int64)], C.c_int),
         "acf_hip_profile_get": ([ctx, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int], C.c_int),
         "acf_hip_read_level": ([ctx, C.c_int, C.c_int, fp], C.c_int),
         "acf_hip_read_rank_level": ([ctx, C.c_int, C.c_int, C.POINTER(C.c_uint16)], C.c_int),
@@ -235,7 +236,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits", "acf_hip_get_raw_detections",
     "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
-    "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_rank_level", "acf_hip_rank_cells_host", "acf_hip_read_tap",
+    "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_get_repairs", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_rank_level", "acf_hip_rank_cells_host", "acf_hip_read_tap",
     "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_op_gradient_hist",
     "acf_hip_op_im_resample", "acf_hip_op_acf_detect1", "acf_hip_op_acf_detect1_u8", "acf_hip_thrs_u8", "acf_hip_op_evaluate",
 ]

@@ -180,9 +180,25 @@ struct acf_hip_ctx
     bool levelsEmitRank = false;  // every level goes through k_level_all: the level kernels can write the rank cells themselves
     // k_smooth_vec's speculative column segments (kernels.hip.h): options smooth_segments (0 auto, 1 off, n), smooth_warm, smooth_force_redo
     int smoothSegments = getenv("ACF_HIP_SMOOTH_SEGMENTS") ? atoi(getenv("ACF_HIP_SMOOTH_SEGMENTS")) : 0; // (env: A/B default)
-    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 48, smoothForceRedo = 0;
+    // 96 warm-up columns: a value decays fourfold per column, so 12-25 columns settle the last bit of ordinary values — but where
+    // the image turns exactly 0 (a black bar) the true chain carries a tail that only reaches 0 by underflow, after ~75 columns,
+    // while a warm-up started inside the bar is 0 at once (profiles/r03_repair_rates.json: 3 % of planes repaired at 48, none
+    // at 64+ on frames with black and flat bands); at 96 frames per launch 48 / 64 / 96 columns cost the same (0.36-0.38 ms)
+    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 96, smoothForceRedo = 0;
     float *d_specState = nullptr, *d_trueState = nullptr;
     int32_t* d_redo = nullptr;
+    // the same for the level chains (k_level_all<OUT, 1>), for batches of at most levelSegFrames frames
+    float *d_lvSpec = nullptr, *d_lvTrue = nullptr;
+    int32_t* d_lvRedo = nullptr;
+    int levelSegFrames = 0, levelSegCap = 0, levelHMax = 0;
+    // The level chains' segments are OFF by default (option level_segments = n > 1 turns them on): a level is at most 480 columns,
+    // so they only pay with warm-ups of ~32 columns (one frame: 412 -> 205 us), and channel planes have exactly-zero regions
+    // wherever the image is flat (no gradient) — with the plane-level repair one such plane costs the whole chain again.
+    int levelSegments = getenv("ACF_HIP_LEVEL_SEGMENTS") ? atoi(getenv("ACF_HIP_LEVEL_SEGMENTS")) : 1;
+    int levelWarm = getenv("ACF_HIP_LEVEL_WARM") ? atoi(getenv("ACF_HIP_LEVEL_WARM")) : 32; // option level_warm
+    // option count_repairs: planes the repair launches had to recompute (synchronises after every verify: measurements only)
+    int countRepairs = 0;
+    int64_t repairs[4] = { 0, 0, 0, 0 }; // {smoothing planes checked, redone, level planes checked, redone}
     int segCap = 0;               // segments the state buffers hold per plane
     int keepPyramid = 1;          // option "keep_pyramid": 0 = a run()/detect-only caller does not need the float pyramid (levels leave as rank cells only)
     int finalMaxH = 0;
@@ -313,6 +329,9 @@ void freeAll(acf_hip_ctx* c)
     c->d_specState = c->d_trueState = nullptr;
     c->d_redo = nullptr;
     c->segCap = 0;
+    c->d_lvSpec = c->d_lvTrue = nullptr;
+    c->d_lvRedo = nullptr;
+    c->levelSegFrames = 0;
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->d_ldcfJobs = nullptr;
@@ -931,6 +950,19 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "cascade_tiles"))
     {
         c->noTiles = value == 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "count_repairs") || !strcmp(key, "level_warm") || !strcmp(key, "level_segments"))
+    {
+        if ((!strcmp(key, "level_warm") && (value < 4 || value % 4 != 0)) || value < 0)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "option: level_warm a positive multiple of 4, level_segments >= 0");
+        }
+        (!strcmp(key, "count_repairs") ? c->countRepairs : (!strcmp(key, "level_warm") ? c->levelWarm : c->levelSegments)) = value;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            (void)acf_hip_set_option(k, key, value);
+        }
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "smooth_segments") || !strcmp(key, "smooth_warm") || !strcmp(key, "smooth_force_redo"))
@@ -1723,6 +1755,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->smoothSegments = c->smoothSegments;
             k->smoothWarm = c->smoothWarm;
             k->smoothForceRedo = c->smoothForceRedo;
+            k->levelWarm = c->levelWarm;
+            k->levelSegments = c->levelSegments;
+            k->countRepairs = c->countRepairs;
             k->noFusedSmooth = c->noFusedSmooth;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
@@ -2181,6 +2216,18 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             return rc;
         }
     }
+    {
+        // k_level_all's column segments: only small batches are bound by a level's chain length
+        c->levelSegFrames = std::min(B, 8);
+        c->levelSegCap = 8;
+        c->levelHMax = std::max(c->finalMaxH, 4);
+        const size_t nState = size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns * c->levelSegCap * size_t(c->levelHMax);
+        if ((rc = devAlloc(c, &c->d_lvSpec, nState)) || (rc = devAlloc(c, &c->d_lvTrue, nState)) ||
+            (rc = devAlloc(c, &c->d_lvRedo, size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns)))
+        {
+            return rc;
+        }
+    }
     // cascade
     // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
     const std::vector<acf_hip_level>& cascLevels = p.ldcfK > 0 ? c->ldcfLevels : pl.levels;
@@ -2288,6 +2335,23 @@ int acf_hip_pyramid_floats(const acf_hip_ctx* c, int64_t* n)
         return ACF_HIP_E_NOPLAN;
     }
     *n = c->plan.pyr_floats;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_get_repairs(acf_hip_ctx* c, int64_t out[4])
+{
+    if (!c || !out)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    for (int i = 0; i < 4; i++)
+    {
+        out[i] = c->repairs[i];
+        for (const acf_hip_ctx* k : c->kids)
+        {
+            out[i] += k->repairs[i];
+        }
+    }
     return ACF_HIP_OK;
 }
 
@@ -2740,6 +2804,17 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     hipLaunchKernelGGL(k_smooth_verify, dim3(nSeg - 1, d, nF), dim3(256), 0, c->stream, (const float*)c->d_specState, (const float*)c->d_trueState,
                         rs.h, nSeg, d, c->d_redo, c->smoothForceRedo);
                     LAUNCHCHK(c, "k_smooth_verify");
+                    if (c->countRepairs)
+                    {
+                        std::vector<int32_t> fl(size_t(nF) * d);
+                        HIPCHK(c, hipMemcpyAsync(fl.data(), c->d_redo, fl.size() * 4, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        c->repairs[0] += int64_t(fl.size());
+                        for (int32_t v : fl)
+                        {
+                            c->repairs[1] += v != 0;
+                        }
+                    }
                     sa.segW = rs.w;
                     sa.warm = 0;
                     sa.nSeg = 1;
@@ -2917,12 +2992,59 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     ra.rec = c->cs.d_rankRec;
                     ldsL += size_t(c->cs.rankMaxRec) * sizeof(RankRec);
                 }
-                dim3 lgrid(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll), lblock(64 * LEVEL_WAVES);
+                // column segments for small batches (a level's chain of up to wC column steps is then the launch's duration):
+                // as many as give the launch ~4 waves per SIMD, at most levelSegCap; every hand-over verified on the device
+                int nSegL = 1;
+                const int warmL = std::max(4, c->levelWarm / 4 * 4);
+                if (fused && !c->taps && nLF <= c->levelSegFrames && c->levelSegments != 1 && !c->autoLambdas)
+                {
+                    const int64_t wavesL = int64_t(nAll) * pl.nChns * nLF;
+                    nSegL = c->levelSegments > 1 ? c->levelSegments : int((4 * 1024 + wavesL - 1) / wavesL); // 0: ~4 waves per SIMD
+                    nSegL = std::max(1, std::min(nSegL, c->levelSegCap));
+                }
+                LevelSegArgs lsa{};
+                lsa.nSeg = nSegL;
+                lsa.warm = warmL;
+                lsa.hMax = c->levelHMax;
+                lsa.nJobs = nAll;
+                lsa.spec = c->d_lvSpec;
+                lsa.tru = c->d_lvTrue;
+                lsa.redo = nullptr;
+                dim3 lgrid(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll * nSegL), lblock(64 * LEVEL_WAVES);
 #define LVALL_LAUNCH(OUT)                                                                                                   \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT>), ldsL)))                                         \
-        return rc;                                                                                                          \
-    hipLaunchKernelGGL((k_level_all<OUT>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd,    \
-        (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra);
+    if (nSegL > 1)                                                                                                          \
+    {                                                                                                                       \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT, 1>), ldsL)))                                  \
+            return rc;                                                                                                      \
+        HIPCHK(c, hipMemsetAsync(c->d_lvRedo, 0, sizeof(int32_t) * size_t(nLF) * nAll * pl.nChns, c->stream));              \
+        hipLaunchKernelGGL((k_level_all<OUT, 1>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd, \
+            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa); \
+        hipLaunchKernelGGL(k_level_verify, dim3(nAll * nSegL, pl.nChns, nLF), dim3(64), 0, c->stream, (const float*)c->d_lvSpec,  \
+            (const float*)c->d_lvTrue, ljobs, lsa, pl.nChns, c->d_lvRedo, c->smoothForceRedo);                               \
+        if (c->countRepairs)                                                                                                \
+        {                                                                                                                   \
+            std::vector<int32_t> fl(size_t(nLF) * nAll * pl.nChns);                                                         \
+            HIPCHK(c, hipMemcpyAsync(fl.data(), c->d_lvRedo, fl.size() * 4, hipMemcpyDeviceToHost, c->stream));             \
+            HIPCHK(c, hipStreamSynchronize(c->stream));                                                                     \
+            c->repairs[2] += int64_t(fl.size());                                                                            \
+            for (int32_t v : fl)                                                                                            \
+            {                                                                                                               \
+                c->repairs[3] += v != 0;                                                                                    \
+            }                                                                                                               \
+        }                                                                                                                   \
+        lsa.nSeg = 1;                                                                                                       \
+        lsa.redo = c->d_lvRedo;                                                                                             \
+        hipLaunchKernelGGL((k_level_all<OUT, 1>), dim3(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll), lblock, ldsL, c->stream,    \
+            (const float*)chnsF, pyrF, rawOut, ljobs, dd, (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns,         \
+            pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa);                                                     \
+    }                                                                                                                       \
+    else                                                                                                                    \
+    {                                                                                                                       \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT, 0>), ldsL)))                                  \
+            return rc;                                                                                                      \
+        hipLaunchKernelGGL((k_level_all<OUT, 0>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd, \
+            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa); \
+    }
                 if (emitRank && emitF32)
                 {
                     LVALL_LAUNCH(LO_F32 | LO_RANK);

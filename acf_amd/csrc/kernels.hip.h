@@ -2763,10 +2763,23 @@ struct LevelRank
     const uint4* rec;     // the channel's bucket records, in LDS
 };
 
-template <int R, int MODE, int OUT>
+// A plane's column chain cut into speculative segments (SEG = 1; the smoothing's recursion is k_smooth_vec's: see
+// "speculative segments" there): columns [x0, x1), started `x0 - xs` columns early from the border formula; the state
+// after the warm-up goes to `spec`, the state after the last column to `tru` (the next segment's slot), both [hC] floats;
+// k_level_verify compares them and a repair launch recomputes the planes that differ as one chain.  For the small batches
+// where a level's 480-step chain is the launch's duration (one frame: 368 -> ~100 us).
+struct LevelSeg
+{
+    int x0, x1, xs;
+    float* spec; // nullptr: first segment
+    float* tru;  // nullptr: last segment
+};
+
+template <int R, int MODE, int OUT, int SEG>
 __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* ldsBlock, int ldsWaveFloats, const LevelRank& rk)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, float* ldsBlock, int ldsWaveFloats, const LevelRank& rk,
+    const LevelSeg& sg)
 {
     // the plane index is the same for the 64 lanes of a wave (and of the workgroup: its waves are the same plane of
     // LEVEL_WAVES frames); say so (readfirstlane), or every plane pointer is treated as per-lane and all address
@@ -2875,8 +2888,9 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     // slot instead of being masked.  vmcnt completes in order, and the compiler can only leave older
     // loads in flight across a step if it sees the whole step as one basic block — with a branch per
     // store it waited for the loads it had just issued, every step.
-    u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[0];
-    u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(1, w - 1)];
+    const int xs = SEG ? sg.xs : 0, x0 = SEG ? sg.x0 : 0, x1 = SEG ? sg.x1 : w; // this wave's columns (SEG = 0: the whole plane)
+    u32x8 xr = (MODE == LM_REAL) ? zrec : xrec[xs];
+    u32x8 xrn = (MODE == LM_REAL) ? zrec : xrec[min(xs + 1, w - 1)];
     // approximated levels: the source-column window (registers) and the wave's x-pass column buffer (LDS)
     constexpr int RING = (OUT & LO_RANK) ? LEVEL_RING_FLOATS_RANK : LEVEL_RING_FLOATS;
     typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE, RING> Win;
@@ -2901,7 +2915,7 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
         {                                                                                                           \
             const float Im = CUR[k];                                                                                \
             const float Ir = (i_ < w - 1) ? NXT[k] : Im;                                                            \
-            const float Il = (i_ == 0) ? Im : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507) */              \
+            const float Il = (i_ == xs) ? Im : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507); a segment's warm-up starts the same way */ \
             T[k] = nrm * (Il + p * Im + Ir);                                                                        \
             up[k] = wave_ror1(T[k]); /* T[y-1] for lanes 1..63 */                                                   \
             dn[k] = wave_rol1(T[k]); /* T[y+1] for lanes 0..62 */                                                   \
@@ -2921,7 +2935,8 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             const float ov = (k < R - 1 || lastOk) ? o : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o), lastLane)); \
             if (OUT & LO_F32)                                                                                       \
             {                                                                                                       \
-                buf_st(Osrd, yoff[k], uint32_t(i_) * uint32_t(J.out_cs) * 4u, ov);                                  \
+                /* (warm-up columns of a segment: the store goes out of the descriptor's range and is dropped) */   \
+                buf_st(Osrd, yoff[k], (!SEG || i_ >= x0) ? uint32_t(i_) * uint32_t(J.out_cs) * 4u : 0x40000000u, ov); \
             }                                                                                                       \
         }                                                                                                           \
     }
@@ -2963,7 +2978,7 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
     if (OUT & LO_RANK)                                                                                              \
     {                                                                                                               \
         const int c_ = (COL);                                                                                       \
-        const uint32_t so_ = c_ >= 0 ? uint32_t(c_) * uint32_t(J.rank_cs) * 2u : 0x40000000u;                       \
+        const uint32_t so_ = c_ >= x0 ? uint32_t(c_) * uint32_t(J.rank_cs) * 2u : 0x40000000u;                      \
         uint32_t n_[R], up_[R];                                                                                     \
         _Pragma("unroll") for (int k = 0; k < R; k++)                                                               \
         {                                                                                                           \
@@ -2976,13 +2991,24 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             __builtin_amdgcn_raw_buffer_store_b32((n_[k] << 16) | (lo_ & 0xffffu), Rsrd, rvoff[k], so_, 0);         \
         }                                                                                                           \
     }
-    // prologue: columns 0, 1, 2 -> b0, b1, b2 (buffer of column c is b[c & 3])
-    LV_LOAD(b0, 0);
-    LV_LOAD(b1, 1);
-    LV_LOAD(b2, 2);
-    int i = 0;
-    for (; i + 3 < w; i += 4)
+    // prologue: columns xs, xs + 1, xs + 2 -> b0, b1, b2
+    LV_LOAD(b0, xs);
+    LV_LOAD(b1, xs + 1);
+    LV_LOAD(b2, xs + 2);
+    // a segment's state after its warm-up (x0 - xs is a multiple of 4: the loop below passes i == x0)
+    const srd_t Ssrd = (SEG && sg.spec) ? make_srd(sg.spec, int64_t(h) * 4) : Osrd;
+    int i = xs;
+    for (; i + 3 < x1; i += 4)
     {
+        if (SEG)
+        {
+            const uint32_t ss_ = (sg.spec && i == x0) ? 0u : 0x40000000u;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+            {
+                buf_st(Ssrd, yoff[k], ss_, prev[k]);
+            }
+        }
         LV_RANK_FETCH();
         LV_LOAD(b3, i + 3);
         LV_RANK_STORE(i - 1);
@@ -3000,27 +3026,46 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
         LV_RANK_STORE(i + 2);
         LV_FILTER(i + 3, b3, b0);
     }
+    if (SEG && sg.spec && i == x0)
+    {
+        // (a last segment shorter than four columns: the loop above never reached x0)
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            buf_st(Ssrd, yoff[k], 0u, prev[k]);
+        }
+    }
     // tail: up to three columns; their inputs are already in b0, b1, b2
-    if (i < w)
+    if (i < x1)
     {
         LV_RANK_FETCH();
         LV_RANK_STORE(i - 1);
         LV_FILTER(i, b0, b1);
     }
-    if (i + 1 < w)
+    if (i + 1 < x1)
     {
         LV_RANK_FETCH();
         LV_RANK_STORE(i);
         LV_FILTER(i + 1, b1, b2);
     }
-    if (i + 2 < w)
+    if (i + 2 < x1)
     {
         LV_RANK_FETCH();
         LV_RANK_STORE(i + 1);
         LV_FILTER(i + 2, b2, b2);
     }
     LV_RANK_FETCH();
-    LV_RANK_STORE(w - 1);
+    LV_RANK_STORE(x1 - 1);
+    if (SEG && sg.tru)
+    {
+        // the state the next segment's warm-up must have reached (clamped duplicate lanes write their own row again)
+        const srd_t Tsrd = make_srd(sg.tru, int64_t(h) * 4);
+#pragma unroll
+        for (int k = 0; k < R; k++)
+        {
+            buf_st(Tsrd, yoff[k], 0u, prev[k]);
+        }
+    }
 #undef LV_RANK_FETCH
 #undef LV_RANK_STORE
 #undef LV_LOAD
@@ -3049,7 +3094,8 @@ __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_
         return;
     }
     const LevelRank rk{};
-    level_body<R, MODE, LO_F32>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk);
+    const LevelSeg sg{};
+    level_body<R, MODE, LO_F32, 0>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk, sg);
 }
 
 // All levels whose specialisation fits 128 VGPRs (R <= 4 in any mode, real levels up to R = 8) in ONE launch:
@@ -3070,12 +3116,21 @@ struct LevelRankArgs
     const RankChan* chan;
     const RankRec* rec;
 };
-template <int OUT>
+// SEG = 1: blockIdx.z = job * nSeg + segment; a job has min(nSeg, wC / (2 * warm)) segments (short levels stay one chain)
+struct LevelSegArgs
+{
+    int32_t nSeg, warm, hMax, nJobs;
+    float* spec;          // [frame][job][channel][segment][hMax]
+    float* tru;
+    const int32_t* redo;  // repair launch (nSeg == 1): [frame][job][channel] != 0 -> recompute this plane; NULL: every plane
+};
+template <int OUT, int SEG>
 __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
     const LevelJob* __restrict__ jobs, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft,
-    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, int nFrames, LevelRankArgs ra)
+    int nChns, int64_t chns_fs, int64_t pyr_fs, float p, float* __restrict__ dump, int nFrames, LevelRankArgs ra, LevelSegArgs sa)
 {
-    const LevelJob J = jobs[blockIdx.z];
+    const int job = SEG ? int(blockIdx.z) / sa.nSeg : int(blockIdx.z);
+    const LevelJob J = jobs[job];
     constexpr int RING = (OUT & LO_RANK) ? LEVEL_RING_FLOATS_RANK : LEVEL_RING_FLOATS;
     constexpr int WF = (OUT & LO_RANK) ? LEVEL_ALL_WF_RANK : LEVEL_ALL_WF;
     static_assert(LevelWindow<3, LM_DD, RING>::LDS_FLOATS <= WF && LevelWindow<4, LM_UU, RING>::LDS_FLOATS <= WF && LevelWindow<2, LM_DD, RING>::LDS_FLOATS <= WF &&
@@ -3097,9 +3152,35 @@ __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_
     {
         return;
     }
-#define LV_CASE(RR, MM)                                                                                                  \
-    case ACF_LEVEL_KIND(RR, MM):                                                                                          \
-        level_body<RR, MM, OUT>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk); \
+    LevelSeg sg{};
+    if (SEG)
+    {
+        const int64_t plane = (int64_t(f) * sa.nJobs + job) * nChns + blockIdx.x;
+        if (sa.redo && sa.redo[plane] == 0)
+        {
+            return; // repair launch: this plane's segments agreed
+        }
+        const int seg = int(blockIdx.z) - job * sa.nSeg;
+        const int nSegJ = max(1, min(sa.nSeg, J.wC / (2 * sa.warm)));
+        if (seg >= nSegJ)
+        {
+            return;
+        }
+        const int segW = ((J.wC + nSegJ - 1) / nSegJ + 3) & ~3;
+        sg.x0 = seg * segW;
+        sg.x1 = min(sg.x0 + segW, J.wC);
+        sg.xs = max(sg.x0 - sa.warm, 0);
+        if (sg.x0 >= sg.x1)
+        {
+            return;
+        }
+        const bool lastSeg = sg.x1 >= J.wC;
+        sg.spec = seg > 0 ? sa.spec + (plane * sa.nSeg + seg) * int64_t(sa.hMax) : nullptr;
+        sg.tru = !lastSeg ? sa.tru + (plane * sa.nSeg + seg + 1) * int64_t(sa.hMax) : nullptr;
+    }
+#define LV_CASE(RR, MM)                                                                                                       \
+    case ACF_LEVEL_KIND(RR, MM):                                                                                               \
+        level_body<RR, MM, OUT, SEG>(J, f, chns, pyr, rawOut, descs, it, ft, nChns, chns_fs, pyr_fs, p, dump, ldsBlock, WF, rk, sg); \
         break;
 #define LV_CASES(RR) LV_CASE(RR, LM_REAL) LV_CASE(RR, LM_DD) LV_CASE(RR, LM_UU)
     switch (J.kind)
@@ -3117,6 +3198,34 @@ __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_
     }
 #undef LV_CASES
 #undef LV_CASE
+}
+
+// k_level_all's segments: spec (a segment's state after its warm-up) against tru (the previous segment's last column),
+// bit for bit; the segment slots that were never written (a job with fewer segments) are skipped by the same rule the
+// kernel used.  One workgroup per (job x segment, channel, frame).
+__global__ void __launch_bounds__(64) k_level_verify(const float* __restrict__ spec, const float* __restrict__ tru, const LevelJob* __restrict__ jobs,
+    LevelSegArgs sa, int nChns, int32_t* __restrict__ redo, int force)
+{
+    const int job = int(blockIdx.x) / sa.nSeg, seg = int(blockIdx.x) - job * sa.nSeg;
+    const LevelJob J = jobs[job];
+    const int nSegJ = max(1, min(sa.nSeg, J.wC / (2 * sa.warm)));
+    const int segW = ((J.wC + nSegJ - 1) / nSegJ + 3) & ~3;
+    if (seg == 0 || seg >= nSegJ || seg * segW >= J.wC)
+    {
+        return;
+    }
+    const int64_t plane = (int64_t(blockIdx.z) * sa.nJobs + job) * nChns + blockIdx.y;
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(spec) + (plane * sa.nSeg + seg) * int64_t(sa.hMax);
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(tru) + (plane * sa.nSeg + seg) * int64_t(sa.hMax);
+    bool bad = force != 0;
+    for (int y = threadIdx.x; y < J.hC; y += 64)
+    {
+        bad = bad || (a[y] != b[y]);
+    }
+    if (bad)
+    {
+        redo[plane] = 1;
+    }
 }
 
 // imResample, exact 1/2 in both axes (imResampleMex.cpp:198-215, 284-288), ha % 4 == 0: 16 bytes per lane.
@@ -5395,14 +5504,26 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
     {
         P <<= 1;
     }
+    // As many threads as the sort has compare-exchange pairs (at least a wave): the waves beyond them leave before the first
+    // barrier — a barrier among 4 waves costs a quarter of one among 16, and the kernel is a sequence of ~100 barriers
+    // (one frame of 360 raw detections: 86 -> 35 us)
+    const int T = min(1024, max(64, P >> 1));
+    if (tid >= T)
+    {
+        return;
+    }
     if (tid == 0)
     {
         s_drop = 0;
         s_cut = 0x7fffffff;
     }
+    if (tid < 16)
+    {
+        s_wave[tid] = 0;
+    }
     __syncthreads();
     // ---- 1. keys (dropped and padding entries sort last)
-    for (int i = tid; i < P; i += 1024)
+    for (int i = tid; i < P; i += T)
     {
         unsigned long long k = 0ull;
         uint32_t ix = 0xffffffffu;
@@ -5431,7 +5552,7 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
     {
         for (int j = k2 >> 1; j > 0; j >>= 1)
         {
-            for (int t = tid; t < (P >> 1); t += 1024)
+            for (int t = tid; t < (P >> 1); t += T)
             {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int hi = lo | j;
@@ -5451,7 +5572,7 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
         }
     }
     // ---- boxes in sorted order
-    for (int i = tid; i < m; i += 1024)
+    for (int i = tid; i < m; i += T)
     {
         const uint32_t q = idx[i];
         int x, y, w, h;
@@ -5476,7 +5597,7 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
         }
         const int4 bi = box[i];
         const int asI = (bi.z - bi.x) * (bi.w - bi.y);
-        for (int j = i + 1 + tid; j < m; j += 1024)
+        for (int j = i + 1 + tid; j < m; j += T)
         {
             if (!kp[j])
             {
@@ -5547,7 +5668,7 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
         const int L = min(a.maxCount, total);
         const uint32_t q0 = outIdx[0];
         const double s0 = pipe ? double(D[q0].score) : a.scores[q0];
-        for (int i = 1 + tid; i < L; i += 1024)
+        for (int i = 1 + tid; i < L; i += T)
         {
             const uint32_t qi = outIdx[i];
             const double si = pipe ? double(D[qi].score) : a.scores[qi];
@@ -5559,7 +5680,7 @@ __global__ void __launch_bounds__(1024) k_nms(NmsArgs a)
         __syncthreads();
         finalCount = L < 2 ? 1 : (s_cut < L ? s_cut + 1 : L);
     }
-    for (int i = tid; i < finalCount; i += 1024)
+    for (int i = tid; i < finalCount; i += T)
     {
         const uint32_t q = outIdx[i];
         keep[i] = int32_t(q);

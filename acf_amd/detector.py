@@ -163,6 +163,12 @@ class HipDetector:
     def synchronize(self):
         self._chk(self.lib.acf_hip_synchronize(self.ctx))
 
+    def repairs(self):
+        """(smoothing planes checked, recomputed, level planes checked, recomputed) with option count_repairs on."""
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.acf_hip_get_repairs(self.ctx, out))
+        return tuple(int(x) for x in out)
+
     def set_option(self, key, value):
         self._chk(self.lib.acf_hip_set_option(self.ctx, key.encode(), int(value)))
 

@@ -54,6 +54,7 @@ struct Api
     ACF_HIP_FN(acf_hip_get_raw_detections)
     ACF_HIP_FN(acf_hip_export_detections)
     ACF_HIP_FN(acf_hip_synchronize)
+    ACF_HIP_FN(acf_hip_get_repairs)
     ACF_HIP_FN(acf_hip_profile_get)
     ACF_HIP_FN(acf_hip_read_level)
     ACF_HIP_FN(acf_hip_read_rank_level)

@@ -321,6 +321,10 @@ ACF_HIP_API int acf_hip_get_raw_detections(acf_hip_ctx* ctx, int frame, acf_hip_
 ACF_HIP_API int acf_hip_export_detections(acf_hip_ctx* ctx, int32_t* dst_dev, int cap);
 
 ACF_HIP_API int acf_hip_synchronize(acf_hip_ctx* ctx);
+/* With option "count_repairs" = 1 (measurements: it synchronises after every verification): out = {image planes whose
+ * smoothing segments were checked, of those recomputed as one chain, level planes checked, recomputed} since the context
+ * was created — how often the speculative column segments (options smooth_segments / smooth_warm / level_warm) miss. */
+ACF_HIP_API int acf_hip_get_repairs(acf_hip_ctx* ctx, int64_t out[4]);
 
 /* Per-kernel timing with HIP events recorded on the context's stream (option
  * "profile" = 1): the counterpart of the reference's ScopeTimeLogger stage

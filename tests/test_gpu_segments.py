@@ -26,17 +26,29 @@ def _check(oracle, det, frames, model, H, W):
 @pytest.mark.parametrize("segments,warm,force", [(0, 48, 0), (1, 48, 0), (4, 48, 0), (7, 32, 0), (16, 16, 0), (5, 48, 1)])
 def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force):
     from acf_amd.detector import HipDetector
-    H, W = 272, 640   # w % 8 == 0, h % 4 == 0: the vector smoothing kernel; two real scales use it
+    H, W = 256, 512   # w % 8 == 0, h % 4 == 0: the vector smoothing kernel; every level goes through the fused level kernel
     model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
     frames = np.stack([synth.make_frame(51 + i, H, W, "luv") for i in range(3)])
     # a black band and a black box: regions where the recursion's state is exactly zero
-    frames[1, :, 200:330, :] = 0.0
-    frames[2, :, 400:, 100:180] = 0.0
+    frames[1, :, 160:290, :] = 0.0
+    frames[2, :, 330:, 100:180] = 0.0
     det = HipDetector(model, H, W, 3, max_batch=3, max_hits=1 << 15)
     det.set_option("smooth_segments", segments)
     det.set_option("smooth_warm", warm)
     det.set_option("smooth_force_redo", force)
+    # the level chains' segments too (off by default): as many as the smoothing's, with a warm-up short enough to miss sometimes
+    det.set_option("level_segments", 0 if segments == 0 else min(segments, 8))
+    det.set_option("level_warm", min(warm, 32))
+    det.set_option("count_repairs", 1)
     _check(oracle, det, frames, model, H, W)
+    r = det.repairs()
+    assert r[0] > 0 or segments == 1
+    if force:
+        assert r[1] == r[0] and r[3] > 0           # every smoothing plane and every level plane with more than one segment was repaired
+    if segments > 1:
+        assert r[2] > 0                            # the level chains were cut too
+    if segments == 16:
+        assert r[1] > 0                            # 16-column warm-ups DO miss: the repair is what makes the result right
     det.close()
 
 
