@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacf_hip.so")
+# ACF_HIP_LIB: another build of the same library (profiles/build_variant.sh: A/B of compile-time constants on one box)
+LIB_PATH = os.environ.get("ACF_HIP_LIB") or os.path.join(_HERE, "libacf_hip.so")
 
 OK = 0
 E_INVALID, E_UNSUPPORTED, E_NOMODEL, E_NOPLAN, E_HIP, E_NODEVICE, E_CAPACITY = 1, 2, 3, 4, 5, 6, 7  # include/acf_hip.h:44-51

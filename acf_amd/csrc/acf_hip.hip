@@ -781,6 +781,25 @@ int acf_hip_abi_version(void)
     return ACF_HIP_ABI_VERSION;
 }
 
+// The side streams of a context (real scales beside each other, level groups): created when something first forks.
+// The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and kernels of
+// two streams that share a queue never overlap: with seven streams per context the main streams of three contexts
+// shared queues (rocprofv3 timeline: never more than two kernels at once; profiles/timeline.py).
+constexpr int ACF_SIDE_STREAMS = 6;
+static void ensureSide(acf_hip_ctx* c)
+{
+    while (int(c->side.size()) < std::min<int>(ACF_SIDE_STREAMS, int(c->evJoin.size())))
+    {
+        hipStream_t st;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            break;
+        }
+        c->side.push_back(st);
+    }
+}
+
 int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
 {
     if (!out)
@@ -816,13 +835,13 @@ int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
         }
         c->ownStream = true;
     }
-    for (int i = 0; i < 6; i++)
+    // (the side streams themselves are created at their first use, ensureSide: every HIP stream takes a share of the
+    // runtime's few hardware queues, and contexts that never fork must not push each other's main streams onto one queue)
+    for (int i = 0; i < ACF_SIDE_STREAMS; i++)
     {
-        hipStream_t st;
         hipEvent_t ev;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess)
         {
-            c->side.push_back(st);
             c->evJoin.push_back(ev);
         }
     }
@@ -1205,7 +1224,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     // (160 KiB LDS: three with rank cells, two with floats), else one
     const int W = 1; // windows per lane in stage A
     auto ldsBytes = [&](int nw) {
-        const int tc = nw * W * 64 / g.TR;
+        const int tc = nw * W * (64 / g.TR);
         const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
         const int64_t rowsP = (rows + CPB - 1) / CPB * CPB;
         // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
@@ -1215,11 +1234,13 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     if (const char* e = getenv(rank ? "ACF_HIP_RTILE_TR" : "ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
     {
         const int v = atoi(e);
-        g.TR = (v == 8 || v == 16 || v == 32 || v == 64) ? v : g.TR;
+        g.TR = (v >= 8 && v <= 64) ? v : g.TR; // (a value that does not divide 64 leaves 64 % TR lanes of a wave idle in stage A)
     }
+    // ACF_HIP_RTILE_WG = n: the footprint + lists must fit n times into a CU's LDS (default: three with rank cells)
+    const int wgPerCu = (rank && getenv("ACF_HIP_RTILE_WG")) ? std::max(1, atoi(getenv("ACF_HIP_RTILE_WG"))) : 3;
     const char* nwEnv = getenv(rank ? "ACF_HIP_RTILE_NW" : "ACF_HIP_TILE_NW");
     const int nwForce = nwEnv ? atoi(nwEnv) : 0;
-    for (int64_t limit : { int64_t(rank ? 53 : 80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
+    for (int64_t limit : { rank ? int64_t(160 * 1024 / wgPerCu / 1280 * 1280) : int64_t(80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
     {
         for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
         {
@@ -1235,7 +1256,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     }
     g.NW = nw;
     g.W = W;
-    g.TC = nw * W * 64 / g.TR;
+    g.TC = nw * W * (64 / g.TR);
     g.rowsT = (g.TR - 1) * g.step + mH;
     g.colsT = (g.TC - 1) * g.step + mW;
     g.rowsP = (g.rowsT + CPB - 1) / CPB * CPB;
@@ -2626,6 +2647,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     // idle — runs beside the smaller scales' own chains: every scale gets a stream, ordered by "scale k has been smoothed"
     // events (option scale_streams; A/B: ACF_HIP_SCALES_SERIAL).
     static const bool scalesSerial = getenv("ACF_HIP_SCALES_SERIAL") != nullptr;
+    if (!scalesSerial && c->scaleStreams && c->real.size() > 1 && !c->taps)
+    {
+        ensureSide(c);
+    }
     const size_t nSideS = c->side.size();
     const bool scalePar = !scalesSerial && c->scaleStreams && c->real.size() > 1 && nSideS >= c->real.size() - 1 && c->evJoin.size() >= nSideS && !c->taps;
     while (scalePar && c->evScale.size() < c->real.size())
@@ -2687,13 +2712,32 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             {
                 const ResampleTiling& tl = rs.tiling;
                 const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
-                if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes)))
+                const size_t ldsMarch = (2 * size_t(tl.cols) + tl.xo) * tl.rows * 4;
+                static const bool noMarch = getenv("ACF_HIP_RESAMPLE_NO_MARCH") != nullptr; // A/B: one workgroup per tile
+                const int ntX = cdiv(hd.wb, tl.xo), rowJobs = cdiv(hd.hb, RT_YO) * hd.nplanes;
+                if (!noMarch && ldsMarch <= size_t(80) * 1024 && ntX >= 4)
                 {
-                    return rc;
+                    // a workgroup marches over the column tiles of its (plane, row tile): the next tile's fill in flight during
+                    // the current tile's passes; column segments so that a small batch still spreads over the machine
+                    const int nSplit = std::max(1, std::min(ntX / 4, cdiv(2048, rowJobs * nF)));
+                    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_march), ldsMarch)))
+                    {
+                        return rc;
+                    }
+                    hipLaunchKernelGGL(k_resample_march, dim3(rowJobs * nSplit, 1, nF), dim3(256), ldsMarch, c->stream, cur, rs.img,
+                        (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y,
+                        tl.tile_x, nSplit);
                 }
-                const int nb = cdiv(hd.hb, RT_YO) * cdiv(hd.wb, tl.xo) * hd.nplanes;
-                hipLaunchKernelGGL(k_resample_tile, dim3(nb, 1, nF), dim3(256), ldsBytes, c->stream, cur, rs.img,
-                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
+                else
+                {
+                    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes)))
+                    {
+                        return rc;
+                    }
+                    const int nb = cdiv(hd.hb, RT_YO) * cdiv(hd.wb, tl.xo) * hd.nplanes;
+                    hipLaunchKernelGGL(k_resample_tile, dim3(nb, 1, nF), dim3(256), ldsBytes, c->stream, cur, rs.img,
+                        (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
+                }
             }
             else
             {
@@ -2964,7 +3008,11 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             const ResampleDesc* dd = c->d_descs + c->nImgDescs;
             prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
             // fork: every group is an independent launch (disjoint outputs); biggest planes first
-            const size_t nSide = c->side.size();
+            if (!groups.empty())
+            {
+                ensureSide(c);
+            }
+            const size_t nSide = groups.empty() ? 0 : c->side.size();
             if (nSide && c->evFork)
             {
                 HIPCHK(c, hipEventRecord(c->evFork, c->stream));
@@ -3336,10 +3384,20 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         dim3 grid((unsigned int)(perX * 8)), block(gt.NW * 64);
         int rc = 0;
         prof(c, "k_cascade_tile");
+        static const bool occ8 = getenv("ACF_HIP_TILE_OCC8") != nullptr;
 #define TILE2_LAUNCH(N, CT)                                                                           \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N, CT>), lds)))              \
-        return rc;                                                                                    \
-    hipLaunchKernelGGL((k_cascade_tile2<N, CT>), grid, block, lds, c->stream, at);
+    if (occ8 && N == 8)                                                                               \
+    {                                                                                                 \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<8, CT, 8>), lds)))       \
+            return rc;                                                                                \
+        hipLaunchKernelGGL((k_cascade_tile2<8, CT, 8>), grid, block, lds, c->stream, at);             \
+    }                                                                                                 \
+    else                                                                                              \
+    {                                                                                                 \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N, CT>), lds)))          \
+            return rc;                                                                                \
+        hipLaunchKernelGGL((k_cascade_tile2<N, CT>), grid, block, lds, c->stream, at);                \
+    }
 #define TILE2_NW(CT)                              \
     switch (gt.NW)                                \
     {                                             \

@@ -2503,7 +2503,10 @@ __device__ __forceinline__ void buf_st(srd_t r, uint32_t voff, uint32_t soff, fl
 // (4 since round 3 — a multiple of the CU's four SIMDs: six measured 12 % slower, two SIMDs carry twice the waves —: the
 // waves of a workgroup take the SAME channel of four frames, so that one copy of the channel's
 // threshold-rank tables in LDS serves the workgroup)
-constexpr int LEVEL_WAVES = 4;
+#ifndef ACF_LEVEL_WAVES
+#define ACF_LEVEL_WAVES 4
+#endif
+constexpr int LEVEL_WAVES = ACF_LEVEL_WAVES;
 constexpr int LEVEL_RING_FLOATS = 2304; // 9 KB per wave: 6 slots of 6 x 64 rows ... 12 slots of <= 3 x 64 rows
 // ... and 7.5 KB (5 slots of 6 x 64 rows) in the forms that also hold a channel's rank records in LDS: a workgroup's LDS is
 // allocated in 1280-byte granules and three workgroups per CU must fit (4 x 10.75 KB + 10.6 KB of records was 43 granules:
@@ -3518,6 +3521,85 @@ __global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__
     rt_passes(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk);
 }
 
+// k_resample_tile with the column tiles of one (plane, row tile, frame) taken IN SEQUENCE by one workgroup, the next
+// tile's source columns requested (LDS-DMA into the other of two tile buffers) before the current tile's two passes run.
+// A tile of k_resample_tile is ~500 outputs for 256 threads: the 960 x 540 -> 484 x 272 / 240 x 136 resamples of a 1080p
+// batch were 88 k / 26 k workgroups per launch, each one fill latency + two barriers long, at 1.4 TB/s (round 3:
+// 310 + 247 us per 96 frames, and nothing else runs beside them: every wave slot of the machine holds one of their
+// short-lived waves).  blockIdx.x = (plane, row tile) x column segment (nSplit segments of the column tiles, so that small
+// batches still fill the machine).  Same passes (rt_passes), same tables: bit-identical.
+__global__ void __launch_bounds__(256) k_resample_march(const float* __restrict__ src, float* __restrict__ dst,
+    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
+    int tile_y, int tile_x, int nSplit)
+{
+    extern __shared__ float rt_lds[];
+    const ResampleDesc& d = descs[blockIdx.y];
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int ntY = (hb + RT_YO - 1) / RT_YO;
+    const int ntX = (wb + xo - 1) / xo;
+    int t = blockIdx.x;
+    const int part = t % nSplit;
+    t /= nSplit;
+    const int ytile = t % ntY;
+    const int z = t / ntY;
+    if (z >= d.nplanes)
+    {
+        return;
+    }
+    const int perPart = (ntX + nSplit - 1) / nSplit;
+    const int xt0 = part * perPart, xt1 = min(xt0 + perPart, ntX);
+    if (xt0 >= xt1)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty], rk = d.rk[ty];
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
+    const int nRows = min(rowHi - rowLo + 1, maxRows);
+    float* const Tb[2] = { rt_lds, rt_lds + size_t(maxCols) * maxRows }; // two source tiles [nCols][nRows]
+    float* C = rt_lds + 2 * size_t(maxCols) * maxRows;                    // [xo][nRows] x-pass columns
+    const int yb = yb0 + lane;
+    const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
+    // this lane's source rows of a column (clamped: rows >= ha are zeroed by the x pass)
+    const int nR64 = (nRows + 63) >> 6;
+    auto fill = [&](int xtile, float* T) {
+        const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
+        const int nCols = min(colHi - colLo + 1, maxCols);
+        for (int cc = wv; cc < nCols; cc += 4)
+        {
+            const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
+            for (int k = 0; k < nR64; k++)
+            {
+                const int r0 = 64 * k;
+                if (r0 + lane < nRows)
+                {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
+                }
+            }
+        }
+    };
+    fill(xt0, Tb[0]);
+    for (int xtile = xt0; xtile < xt1; xtile++)
+    {
+        // tile `xtile` has arrived (and the stores of the previous tile have left); every wave is past the previous tile's
+        // y pass: the other tile buffer (read by the previous x pass) and C may be written again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = (xtile - xt0) & 1;
+        if (xtile + 1 < xt1)
+        {
+            fill(xtile + 1, Tb[cur ^ 1]);
+        }
+        const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
+        const int colLo = it[tile_x + 2 * xtile];
+        rt_passes(d, it, ft, Tb[cur], C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk);
+    }
+}
+
 // ------------------------------------------------------------------------
 // LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
 // tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
@@ -4494,8 +4576,10 @@ __device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx
     return nOut;
 }
 
-template <int NW, class CT>
-__global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
+// OCC: waves per SIMD the register allocation must allow (1: whatever the code needs, currently 7; 8: at most 64 VGPRs —
+// four 8-wave workgroups per CU when their LDS fits four times)
+template <int NW, class CT, int OCC = 1>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC))) k_cascade_tile2(TileArgs a)
 {
     typedef typename CT::cell_t cell_t;
     typedef typename CT::val_t val_t;
@@ -4530,6 +4614,20 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     {
         s_cnt[tid] = 0;
     }
+    if (a.debug >> 8)
+    {
+        // experiment (ACF_HIP_CASC_DEBUG = 256 * D): the workgroups of the first wave of dispatches start D * 64 cycles
+        // apart per CU slot, so that the three workgroups of a CU are in different phases
+        const int slot = int(blockIdx.x >> 3) / 32;
+        if (slot < 3)
+        {
+            const long long t0_ = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0_ < (long long)(slot) * (a.debug >> 8) * 64)
+            {
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     TILE_STAMP(0);
     // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
     {
@@ -4553,6 +4651,10 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     }
     __syncthreads();
     TILE_STAMP(1);
+    if (a.debug & 2)
+    {
+        return; // timing experiment: the fill alone
+    }
     const long long tS1 = (a.debug & 4) ? __builtin_amdgcn_s_memtime() : 0;
 #define TILE_STAMP_REL(k)                                                                  \
     if ((a.debug & 4) && threadIdx.x == 0)                                                  \
@@ -4589,10 +4691,11 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     // that sits in one wave's columns would serialise that wave's sparse pieces while the other waves wait at stage E
     const int r_l = lane % a.g.TR, c_l = (lane / a.g.TR) * NW + wv;
     const int wr = T.r0 + r_l;
-    bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC;
+    // (TR need not divide 64: the lanes past the wave's last whole column of windows idle)
+    bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / a.g.TR) * a.g.TR;
     float h = 0.f;
     {
-        const cell_t* win = tileF + (c_l * step) * rowsP + r_l * step;
+        const cell_t* win = tileF + (min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step;
         const int nb = a.g.b[1] / a.aTB;
         if (nb > 0)
         {
@@ -4609,6 +4712,14 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile2(TileArgs a)
     }
     asm volatile("" ::"v"(h));
     TILE_STAMP_REL(6);
+    if (a.debug & 1)
+    {
+        if (h == 12345.678f)
+        {
+            a.stamps[0] = 1; // (keeps stage A alive)
+        }
+        return; // timing experiment: fill + stage A
+    }
     // ---- from here to stage E every wave works on ITS OWN 64 windows: its survivors go to its private list segment and
     // through the sparse pieces [b1,b2) [b2,b3) [b3,b4) (each cut into pieces of at most 64 trees) without a workgroup
     // barrier — the pieces are latency chains (two LDS round trips + a 16..64-step add chain per round) that now overlap
