@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,11 @@ struct acf_hip_ctx
     std::vector<hipStream_t> evStream; // the stream each profile event was recorded on (a kernel ends at the next event of ITS stream)
     std::vector<hipEvent_t> evScale;   // pyramid: "real scale k has been smoothed" (the next real scale starts from it on its own stream)
     bool scaleStreams = true;          // option scale_streams
+    // option cascade_turns: the tile kernels of the contexts of one device take turns (each waits for the tile kernel submitted
+    // before it on that device, whichever context's): contexts that run in phase otherwise run their cascades — bound by
+    // LDS and VALU, not by memory — beside each other instead of beside the other contexts' memory-bound pyramid kernels
+    int cascTurns = getenv("ACF_HIP_CASCADE_TURNS") ? atoi(getenv("ACF_HIP_CASCADE_TURNS")) : 0;
+    hipEvent_t evTurn[2] = { nullptr, nullptr }; // [0] tile kernel, [1] level kernel (bit 1 of the option: own turns; bit 2: the tile kernels' turns)
 
     acf_hip_params p{};
     std::vector<uint32_t> fids, child;
@@ -773,6 +779,62 @@ int kidCount(const acf_hip_ctx* c, size_t i, int n)
 }
 } // namespace
 
+// option cascade_turns: the last submission of every device per kernel class (an event owned by the submitting context)
+namespace
+{
+std::mutex g_turnMu;
+hipEvent_t g_turnLast[2][64] = {};
+// which: 0 = the tile kernel, 1 = the level kernel; chain: whose turns it takes (0 / 1)
+int turnBegin(acf_hip_ctx* c, int which, int chain)
+{
+    if (c->device < 0 || c->device >= 64)
+    {
+        return ACF_HIP_OK;
+    }
+    if (!c->evTurn[which])
+    {
+        HIPCHK(c, hipEventCreateWithFlags(&c->evTurn[which], hipEventDisableTiming));
+    }
+    std::lock_guard<std::mutex> lk(g_turnMu);
+    hipEvent_t last = g_turnLast[chain][c->device];
+    if (last && last != c->evTurn[0] && last != c->evTurn[1])
+    {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, last, 0));
+    }
+    return ACF_HIP_OK;
+}
+int turnEnd(acf_hip_ctx* c, int which, int chain)
+{
+    if (!c->evTurn[which] || c->device < 0 || c->device >= 64)
+    {
+        return ACF_HIP_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_turnMu);
+    HIPCHK(c, hipEventRecord(c->evTurn[which], c->stream));
+    g_turnLast[chain][c->device] = c->evTurn[which];
+    return ACF_HIP_OK;
+}
+void cascTurnForget(acf_hip_ctx* c)
+{
+    std::lock_guard<std::mutex> lk(g_turnMu);
+    for (int w = 0; w < 2; w++)
+    {
+        if (c->evTurn[w])
+        {
+            for (int ch = 0; ch < 2; ch++)
+            {
+                if (c->device >= 0 && c->device < 64 && g_turnLast[ch][c->device] == c->evTurn[w])
+                {
+                    g_turnLast[ch][c->device] = nullptr;
+                }
+            }
+            (void)hipEventDestroy(c->evTurn[w]);
+            c->evTurn[w] = nullptr;
+        }
+    }
+}
+} // namespace
+
 extern "C" {
 
 
@@ -891,6 +953,7 @@ int acf_hip_destroy(acf_hip_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)acf_hip_stream_close(c);
+    cascTurnForget(c);
     freeAll(c);
     for (hipEvent_t e : c->evPool)
     {
@@ -1023,6 +1086,15 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
         {
             k->noRank = c->noRank;
             k->detectValid = false;
+        }
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "cascade_turns"))
+    {
+        c->cascTurns = value;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            k->cascTurns = value;
         }
         return ACF_HIP_OK;
     }
@@ -1783,6 +1855,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
             k->scaleStreams = c->scaleStreams;
+            k->cascTurns = c->cascTurns;
             k->nmsOn = c->nmsOn; // (acf_hip_set_nms before the plan, or a re-plan: the new children run what the parent reports)
             k->nms = c->nms;
             if ((rc = acf_hip_set_model(k, &c->p)) || (rc = acf_hip_plan(k, H, W, d_in, c->kidChunk, max_hits)))
@@ -3006,6 +3079,12 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             const LevelJob* ljobs = fused ? c->d_levelJobs : c->d_levelJobsRaw;
             const auto& groups = fused ? c->levelGroups : c->levelGroupsRaw;
             const ResampleDesc* dd = c->d_descs + c->nImgDescs;
+            const int lvChain = (c->cascTurns & 4) ? 0 : 1;
+            const bool lvTurns = (c->cascTurns & 6) && fused && c->nAllJobs > 0;
+            if (lvTurns && (rc = turnBegin(c, 1, lvChain)))
+            {
+                return rc;
+            }
             prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
             // fork: every group is an independent launch (disjoint outputs); biggest planes first
             if (!groups.empty())
@@ -3107,6 +3186,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 }
 #undef LVALL_LAUNCH
                 LAUNCHCHK(c, "k_level_all");
+                if (lvTurns && (rc = turnEnd(c, 1, lvChain)))
+                {
+                    return rc;
+                }
             }
             size_t gi = 0;
             for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
@@ -3380,9 +3463,14 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const TileGeom& gt = at.g;
         const int64_t total = int64_t(at.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        const size_t lds = size_t(gt.tileFloats) * (rank ? 2 : 4) + size_t(gt.NW) * 64 * 8;
+        static const size_t padKb = getenv("ACF_HIP_TILE_PAD_KB") ? size_t(atoi(getenv("ACF_HIP_TILE_PAD_KB"))) : 0; // A/B: fewer workgroups per CU
+        const size_t lds = size_t(gt.tileFloats) * (rank ? 2 : 4) + size_t(gt.NW) * 64 * 8 + padKb * 1024;
         dim3 grid((unsigned int)(perX * 8)), block(gt.NW * 64);
         int rc = 0;
+        if ((c->cascTurns & 1) && (rc = turnBegin(c, 0, 0))) // (before the profile event: the wait for the turn is not the kernel's time)
+        {
+            return rc;
+        }
         prof(c, "k_cascade_tile");
         static const bool occ8 = getenv("ACF_HIP_TILE_OCC8") != nullptr;
 #define TILE2_LAUNCH(N, CT)                                                                           \
@@ -3417,6 +3505,10 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
 #undef TILE2_NW
 #undef TILE2_LAUNCH
         LAUNCHCHK(c, "k_cascade_tile");
+        if ((c->cascTurns & 1) && (rc = turnEnd(c, 0, 0)))
+        {
+            return rc;
+        }
         if (a.debug & 4)
         {
             // debug only: mean cycles per phase of thread 0 of every block

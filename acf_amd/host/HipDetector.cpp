@@ -86,6 +86,14 @@ void HipDetector::setDoParallel(bool flag)
     }
 }
 
+void HipDetector::setOption(const std::string& key, int value)
+{
+    if (m_ctx && m_api)
+    {
+        check(m_api->acf_hip_set_option(m_ctx, key.c_str(), value), "acf_hip_set_option");
+    }
+}
+
 void HipDetector::check(int rc, const char* what) const
 {
     if (rc != ACF_HIP_OK)
@@ -963,20 +971,36 @@ static std::vector<int> poolDevices(std::vector<int> devices)
     return devices;
 }
 
+// contexts that share a device take turns with their VALU / LDS-bound kernels (acf_hip.h, option cascade_turns)
+static void poolTurns(const std::vector<int>& devices, std::vector<std::unique_ptr<HipDetector>>& dets)
+{
+    for (size_t i = 0; i < dets.size(); i++)
+    {
+        if (std::count(devices.begin(), devices.end(), devices[i]) > 1)
+        {
+            dets[i]->setOption("cascade_turns", 5);
+        }
+    }
+}
+
 HipDetectorPool::HipDetectorPool(const HipDetector::Options& o, const HipDetector::Classifier& c, std::vector<int> devices)
 {
-    for (int dev : poolDevices(std::move(devices)))
+    const std::vector<int> devs = poolDevices(std::move(devices));
+    for (int dev : devs)
     {
         m_dets.emplace_back(new HipDetector(o, c, dev));
     }
+    poolTurns(devs, m_dets);
 }
 
 HipDetectorPool::HipDetectorPool(const std::string& filename, std::vector<int> devices)
 {
-    for (int dev : poolDevices(std::move(devices)))
+    const std::vector<int> devs = poolDevices(std::move(devices));
+    for (int dev : devs)
     {
         m_dets.emplace_back(new HipDetector(filename, dev));
     }
+    poolTurns(devs, m_dets);
 }
 
 void HipDetectorPool::shardRange(int nFrames, int world, int rank, int& begin, int& end)

@@ -230,6 +230,8 @@ public:
     // Detector::setDoParallel (ACF.h:410: cv::parallel_for_ over scales): the real scales of a batch on streams of the context
     // beside each other (default, lowest latency) or all on one stream (several detectors side by side on one GPU)
     void setDoParallel(bool flag);
+    // acf_hip_set_option (include/acf_hip.h): backend knobs without a counterpart among the reference's setters
+    void setOption(const std::string& key, int value);
     void setIsRowMajor(bool flag) { m_isRowMajor = flag; } // ACF.h:588-595: stored for callers that orient the window size by it
     bool getIsRowMajor() const { return m_isRowMajor; }
     Size getWindowSize() const { return opts.modelDs; }

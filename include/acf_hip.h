@@ -196,6 +196,13 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * "keep_pyramid" (1, default; 0: the caller wants detections only — acf_hip_run /
  * acf_hip_pyramid + acf_hip_detect — and when the levels leave as rank cells the float
  * pyramid is not written at all: acf_hip_read_level then fails with ACF_HIP_E_INVALID),
+ * "cascade_turns" (0, default; for applications that run several contexts on one device,
+ * the way the reference runs one Detector per thread: bit 0 = a context's cascade tile
+ * kernel waits for the tile kernel submitted before it on that device, whichever
+ * context's, bit 2 = the level kernel takes its turns in the same chain (bit 1: in a
+ * chain of its own) — these kernels are bound by VALU and LDS, and two of them side by
+ * side displace each other where each could run beside another context's memory-bound
+ * pyramid kernels; three contexts, cfg 2: +4 % frames/s with 5),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);

@@ -260,6 +260,18 @@ def test_detector_pool_concurrent_contexts_match_single(oracle):
     odet, _ = oracle.detect(plan, pyr)
     assert np.array_equal(bits(odet["score"]), bits(want[1][2]["score"]))
     pool.close()
+    # the pool's contexts take turns with their level and tile kernels (option cascade_turns: events shared through the library);
+    # a second pool after the first one is gone must not wait on a destroyed context's event
+    pool = DetectorPool(2, model, H, W, d_in, max_batch=nF, max_hits=1 << 14)
+    for rep in range(2):
+        for (det, stream), x in zip(pool, dev_batches):
+            with torch.cuda.stream(stream):
+                det.run(x)
+    pool.synchronize()
+    for c, (det, _) in enumerate(pool):
+        for f in range(nF):
+            assert det.detections(f)[0].tobytes() == want[c][f].tobytes()
+    pool.close()
 
 
 LDCF_CASES = {
