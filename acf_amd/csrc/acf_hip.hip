@@ -2120,9 +2120,11 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                     c->fusedOk = false; // more than three taps on an axis or an exact 1/k ratio: separate launches
                 }
                 mode = dd.xmode == RS_DOWN ? (dd.ymode == RS_DOWN ? LM_DD : LM_DU) : (dd.ymode == RS_DOWN ? LM_UD : LM_UU);
-                if (dd.ha > 64 * (dd.ymode == RS_DOWN ? (3 * R + 1) / 2 : R))
+                if (dd.ha >= 64 * (dd.ymode == RS_DOWN ? (3 * R + 1) / 2 : R))
                 {
-                    c->fusedOk = false; // more source rows than LevelWindow's registers hold (ratio beyond 2^(1/2))
+                    // more source rows than LevelWindow's registers hold (ratio beyond 2^(1/2)), or no row left in the
+                    // column buffer for the zeros that taps beyond the source's last row read (level_column)
+                    c->fusedOk = false;
                 }
                 if (mode == LM_DU || mode == LM_UD)
                 {

@@ -503,7 +503,7 @@ uint32_t RankTables::rankOfCell(int chn, float v) const
     uint32_t n = r.lo;
     for (int j = 0; j < RANK_WINDOW; j++)
     {
-        n += (uint32_t(r.t[j]) <= low) ? 1u : 0u;
+        n += (uint32_t(r.t(j)) <= low) ? 1u : 0u;
     }
     return n;
 }
@@ -609,7 +609,7 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
         empty.lo = 0;
         for (int j = 0; j < RANK_WINDOW; j++)
         {
-            empty.t[j] = 0xffff;
+            empty.t(j) = RANK_UNUSED;
         }
         out.rec.resize(out.rec.size() + size_t(c.nb), empty);
         RankRec* rec = out.rec.data() + c.recOff;
@@ -618,7 +618,7 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
         {
             const int32_t key = rankKey(t[j]);
             const int b = rankBucket(c, key);
-            rec[b].t[fill[size_t(b)]++] = uint16_t(uint32_t(key) & ((1u << best) - 1u));
+            rec[b].t(fill[size_t(b)]++) = uint16_t(uint32_t(key) & ((1u << best) - 1u));
         }
         uint32_t acc = hasZero;
         for (int b = 0; b < c.nb; b++)

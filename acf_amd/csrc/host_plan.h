@@ -103,11 +103,11 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
 //
 // rank(v) without a search.  For v >= 0 the bit pattern of v is an order-preserving integer key.  Its top bits select a
 // bucket; a bucket's 16-byte record holds `lo` = the number of thresholds in lower buckets and the LOW `shift` bits of the
-// keys of its own thresholds (at most RANK_WINDOW = 7 of them; 0xffff in unused slots).  Inside a bucket all keys share
+// keys of its own thresholds (at most RANK_WINDOW = 7 of them; 0x8000 in unused slots).  Inside a bucket all keys share
 // their top bits, so comparing low bits compares the floats:
 //     key = max(int(bits(v)), 0);  b = clamp((key >> shift) - base, 0, nb - 1);  low = key & ((1 << shift) - 1);
 //     rec = table[b] (one 16-byte read);  rank = rec.lo + #{ j : rec.t[j] <= low };   v < 0: rank = 0.
-// buildRankTables picks each channel's `shift` (<= 15, so that 0xffff is above every low key) as the largest — i.e. the
+// buildRankTables picks each channel's `shift` (<= 15, so that 0x8000 is above every low key) as the largest — i.e. the
 // smallest table — whose buckets hold at most RANK_WINDOW thresholds, or reports that none exists within
 // RANK_MAX_BUCKETS buckets (ok = false: the float pyramid stays the cascade's input).  Bucket 0 lies below and bucket
 // nb - 1 above every threshold's bucket: values outside the thresholds' range clamp into records without thresholds.
@@ -126,10 +126,18 @@ struct RankChan
     int32_t pad_[2];
 };
 
+// Record layout (round 3): dword 0 = t[0] | lo << 16, dwords 1..3 = t[1] | t[2] << 16, ...  Low keys are < 0x8000 and an
+// unused slot holds RANK_UNUSED = 0x8000, so with X = (low | 0x8000) in both halves of a dword, `X - dword` leaves
+// "t <= low" in bits 15 and 31 without a borrow between the halves: seven compares are four subtractions (the device's
+// rank_count; full-rate VALU instead of seven v_cmp + v_addc, which issue at half rate on gfx950).
+constexpr uint16_t RANK_UNUSED = 0x8000;
 struct RankRec // 16 bytes
 {
+    uint16_t t0;
     uint16_t lo;
-    uint16_t t[RANK_WINDOW];
+    uint16_t tr[RANK_WINDOW - 1];
+    uint16_t& t(int j) { return j == 0 ? t0 : tr[j - 1]; }
+    uint16_t t(int j) const { return j == 0 ? t0 : tr[j - 1]; }
 };
 
 struct RankTables

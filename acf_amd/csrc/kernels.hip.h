@@ -2339,22 +2339,26 @@ struct RankFn
 // the read: issue it early, count late (rank_count) — the level kernels put a column's other LDS traffic in between
 __device__ __forceinline__ uint4 rank_fetch(float v, const RankFn& f, const uint4* rec, uint32_t& low)
 {
-    const int key = max(__float_as_int(v), 0);
+    // (a negative v lands in bucket 0 through the arithmetic shift; its rank is forced to 0 in rank_count)
+    const int key = __float_as_int(v);
     const int b = min(max((key >> f.shift) - f.base, 0), f.nbm1);
-    low = uint32_t(key) & f.mask;
+    low = (uint32_t(key) & f.mask) | 0x8000u; // the guard bit of rank_count's packed compares
     return rec[b];
 }
 __device__ __forceinline__ uint32_t rank_count(float v, const uint4& r, uint32_t low)
 {
-    static_assert(RANK_WINDOW == 7 && sizeof(RankRec) == 16, "record layout");
-    uint32_t n = r.x & 0xffffu; // lo
-    n += (r.x >> 16) <= low ? 1u : 0u;
-    n += (r.y & 0xffffu) <= low ? 1u : 0u;
-    n += (r.y >> 16) <= low ? 1u : 0u;
-    n += (r.z & 0xffffu) <= low ? 1u : 0u;
-    n += (r.z >> 16) <= low ? 1u : 0u;
-    n += (r.w & 0xffffu) <= low ? 1u : 0u;
-    n += (r.w >> 16) <= low ? 1u : 0u;
+    static_assert(RANK_WINDOW == 7 && sizeof(RankRec) == 16 && RANK_UNUSED == 0x8000, "record layout");
+    // Seven `t <= low` as four subtractions: low keys are < 0x8000 and carry the guard bit 0x8000 here, slots hold
+    // <= 0x8000, so (low | 0x8000) - t has bit 15 set exactly when t <= low and never borrows from the upper half.  The
+    // indicator bits (15 and 31 of every difference; dword 0's upper half is `lo`, not a slot) are moved to distinct
+    // positions and counted with one v_bcnt that also adds `lo`.  18 VALU at full rate; the seven v_cmp_le_u32_sdwa +
+    // v_addc/v_cndmask of the scalar form issue at half rate on gfx950 (profiles/ubench/valu_rate.hip).
+    const uint32_t X = low | (low << 16);
+    const uint32_t m0 = (X - r.x) & 0x00008000u;
+    const uint32_t m1 = (X - r.y) & 0x80008000u;
+    const uint32_t m2 = (X - r.z) & 0x80008000u;
+    const uint32_t m3 = (X - r.w) & 0x80008000u;
+    const uint32_t n = uint32_t(__builtin_popcount(m0 | (m1 >> 1) | (m2 >> 2) | (m3 >> 3))) + (r.x >> 16);
     return v < 0.f ? 0u : n; // every threshold is >= 0 (buildRankTables): a negative cell is below all of them
 }
 __device__ __forceinline__ uint32_t rank_cell(float v, const RankFn& f, const uint4* rec)
@@ -2547,7 +2551,10 @@ struct LevelWindow
 #pragma unroll
         for (int r = 0; r < RS; r++)
         {
-            srow[r] = 4u * uint32_t(min(lane + 64 * r, ha - 1));
+            // rows >= ha: an offset beyond the descriptor's range — the load returns 0, so the ring, the x pass's column
+            // (0 * w) and with it the column buffer hold +0 there: the zeroed tail of the reference's column buffer
+            // (imResampleMex.cpp:133-137), which the y taps of the plane's last rows read (level_column)
+            srow[r] = lane + 64 * r < ha ? 4u * uint32_t(lane + 64 * r) : 0x40000000u;
         }
         ring = ring_;
         for (int k = 0; k < JX + LA; k++)
@@ -2590,9 +2597,7 @@ struct LaneTaps
 {
     uint32_t roff[R][3]; // clamped source row of y tap o, as a BYTE offset in a source column
     float wy[R][3];      // y weights, gain folded in (imResampleMex.cpp:158-161)
-    uint32_t bad[R];     // bit o: tap row >= ha (reads the zeroed tail of the column buffer, :133-137)
     uint32_t one[R];     // y up: a clamped border row uses one tap only
-    bool anyBad;         // wave-uniform: some lane has a tap row >= ha
 };
 
 // One column of an approximated level: x pass then y pass, reference association order
@@ -2692,20 +2697,9 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
             C[k][o] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ldsCol) + tp.roff[k][o]);
         }
     }
-    // rows >= ha read the zeroed tail of the reference's column buffer (:133-137): only the lanes of the plane's last
-    // rows can have such taps, so the select is skipped when no lane of the wave has one (tp.anyBad, wave-uniform)
-    if (tp.anyBad)
-    {
-#pragma unroll
-        for (int k = 0; k < R; k++)
-        {
-#pragma unroll
-            for (int o = 0; o < NY; o++)
-            {
-                C[k][o] = ((tp.bad[k] >> o) & 1u) ? 0.f : C[k][o];
-            }
-        }
-    }
+    // (a tap row >= ha reads the zeroed tail of the reference's column buffer, :133-137: rows ha .. 64 * RS - 1 of ldsCol
+    // are +0 — LevelWindow::init — and tp.roff points there: no select.  Round 2 applied `bad` masks here: 12 v_cndmask
+    // per column step on SGPR masks that no longer fitted the SGPR file, i.e. 24 v_readlane of spilled masks as well.)
     // y pass (:319-373)
     if (YDOWN)
     {
@@ -2828,6 +2822,7 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
         wa = d.wa;
         xcol = it + d.x_col;
         constexpr bool YDOWN = MODE == LM_DD || MODE == LM_UD;
+        typedef LevelWindow<R, MODE == LM_REAL ? LM_DD : MODE> Win0; // (RS does not depend on the ring size)
         ny = YDOWN ? d.ybd0 : 2;
 #pragma unroll
         for (int k = 0; k < R; k++)
@@ -2856,21 +2851,13 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
                 tp.wy[k][1] = r - tp.wy[k][0];
                 tp.one[k] = (ybc < d.ybd0 || ybc >= hb - d.ybd1) ? 1u : 0u;
             }
-            tp.bad[k] = 0;
 #pragma unroll
             for (int o = 0; o < 3; o++)
             {
-                tp.roff[k][o] = 4u * uint32_t(min(ya + o, ha - 1));
-                tp.bad[k] |= (ya + o >= ha) ? (1u << o) : 0u;
+                // rows ha .. 64 * RS - 1 of the column buffer hold +0 (the host keeps ha < 64 * RS for this kernel)
+                tp.roff[k][o] = 4u * uint32_t(min(ya + o, 64 * Win0::RS - 1));
             }
         }
-        uint32_t anyb = 0;
-#pragma unroll
-        for (int k = 0; k < R; k++)
-        {
-            anyb |= tp.bad[k];
-        }
-        tp.anyBad = __any(anyb != 0);
     }
     const float nrm = 1.0f / ((p + 2) * (p + 2));
     const float p1 = 1 + p;
@@ -4614,26 +4601,42 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
     {
         s_cnt[tid] = 0;
     }
-    if (a.debug >> 8)
-    {
-        // experiment (ACF_HIP_CASC_DEBUG = 256 * D): the workgroups of the first wave of dispatches start D * 64 cycles
-        // apart per CU slot, so that the three workgroups of a CU are in different phases
-        const int slot = int(blockIdx.x >> 3) / 32;
-        if (slot < 3)
-        {
-            const long long t0_ = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0_ < (long long)(slot) * (a.debug >> 8) * 64)
-            {
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-    }
     TILE_STAMP(0);
     // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
     {
         const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
         const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
         const int ccMax = colsValid - 1;
+        if (a.debug & 512)
+        {
+            // experiment: no fill at all (stage A's time on whatever the LDS holds)
+        }
+        else if (a.debug & 256)
+        {
+            // experiment: the chunks through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
+            uint4 v[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const uint32_t q = min(uint32_t(wv) * 64u + uint32_t(k) * (NW * 64u) + lane, nChunks - 1);
+                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                const uint32_t j = q - seg * cps;
+                const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                const int cc = int(seg - z * uint32_t(colsT));
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
+                v[k] = *reinterpret_cast<const uint4*>(src0 + soff);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const uint32_t q = uint32_t(wv) * 64u + uint32_t(k) * (NW * 64u) + lane;
+                if (q < nChunks)
+                {
+                    *reinterpret_cast<uint4*>(tileF + uint32_t(CPB) * q) = v[k];
+                }
+            }
+        }
+        else
         for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
         {
             const uint32_t q = q0 + lane;
@@ -4741,6 +4744,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
         nIn = __popcll(m);
     }
     TILE_STAMP_REL(7);
+    if (a.debug & 128)
+    {
+        __builtin_amdgcn_s_setprio(3); // experiment: the sparse pieces are the tile's critical path
+    }
     if (a.g.b[1] < tEnd)
     {
 #pragma unroll

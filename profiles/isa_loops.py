@@ -4,7 +4,7 @@
 shows large N (the wave waits until at most N younger memory operations are outstanding); N near 0 in a loop with many
 branches means every step waits for a full memory round trip (MI355X: completion is in order).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math --offload-device-only -S \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize --offload-device-only -S \
           -x hip acf_amd/csrc/acf_hip.hip -o /tmp/k.s
     python profiles/isa_loops.py /tmp/k.s k_level_all [min_instructions]
 """
