@@ -492,12 +492,20 @@ struct SmoothVecArgs
 
 __device__ __forceinline__ float wave_rol1(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, false)); // lane l <- lane l+1 (63 <- 0)
+    // (bound_ctrl: every lane of a rotate has a source, so `old` is never used — without it the compiler writes a
+    // v_mov_b32 vD, 0 before every rotate and cannot fold the DPP operand into the instruction that consumes it)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, true)); // lane l <- lane l+1 (63 <- 0)
 }
 __device__ __forceinline__ float wave_ror1(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, false)); // lane l <- lane l-1 (0 <- 63)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C, 0xf, 0xf, true)); // lane l <- lane l-1 (0 <- 63)
 }
+
+// Keep scalar / vector values materialised at this point: stops the compiler from sinking the loads that produce them
+// into data-dependent selects (which turns straight-line select code into branches with a memory wait in every arm).
+// Also used to force a wave-uniform value into a VGPR: a VALU instruction with an SGPR operand issues at 1.7x the cost
+// of one without on gfx950 (profiles/ubench/valu_rate.hip).
+#define ACF_PIN_V(x) asm volatile("" : "+v"(x))
 
 #define SV_CH 8
 constexpr int SV_K = 2;              // halo quads per side: 4 * SV_K rows = SV_CH columns of independence
@@ -2341,7 +2349,8 @@ __device__ __forceinline__ uint4 rank_fetch(float v, const RankFn& f, const uint
 {
     // (a negative v lands in bucket 0 through the arithmetic shift; its rank is forced to 0 in rank_count)
     const int key = __float_as_int(v);
-    const int b = min(max((key >> f.shift) - f.base, 0), f.nbm1);
+    int b; // clamp to [0, nbm1] in one instruction (the compiler cannot prove nbm1 >= 0 and keeps v_max + v_min)
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(b) : "v"((key >> f.shift) - f.base), "v"(f.nbm1));
     low = (uint32_t(key) & f.mask) | 0x8000u; // the guard bit of rank_count's packed compares
     return rec[b];
 }
@@ -2627,8 +2636,15 @@ __device__ __forceinline__ void level_column(float (&v)[R], int xb, srd_t A, int
     constexpr int JX = Win::JX;
     const int xa = int(xr[0]), m = int(xr[1]);
     const bool border = xr[3] != 0;
-    const float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
+    float w[4] = { __uint_as_float(xr[4]), __uint_as_float(xr[5]), __uint_as_float(xr[6]), __uint_as_float(xr[7]) };
     constexpr int RS = Win::RS;
+    if (RS >= 3 && RS < 6)
+    {
+        // the column's x weights multiply RS rows each: three v_mov from SGPRs are cheaper than RS * JX SGPR operands
+        ACF_PIN_V(w[0]);
+        ACF_PIN_V(w[1]);
+        ACF_PIN_V(w[2]);
+    }
     win.advance(A, xa, ha, wa);
     float sc[JX][RS];
     win.read(sc, xa, lane);
@@ -2859,8 +2875,17 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             }
         }
     }
-    const float nrm = 1.0f / ((p + 2) * (p + 2));
+    // (nrm, p, p1 in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without on gfx950,
+    // profiles/ubench/valu_rate.hip, and these are operands of ~5 multiplies per cell)
+    float nrm = 1.0f / ((p + 2) * (p + 2));
     const float p1 = 1 + p;
+    float pv = p;
+    if (R <= 5)
+    {
+        // (p1 only multiplies in the two border rows' registers: it stays scalar; R >= 6 has no VGPR to spare)
+        ACF_PIN_V(nrm);
+        ACF_PIN_V(pv);
+    }
     // Column records come through the scalar unit (constant address space) ahead of the column loads
     // they drive; column loads are issued three steps before the recursion consumes them.  Four column
     // buffers rotate through the roles (loop unrolled 4x) so no register is copied — a copy would force
@@ -2906,7 +2931,7 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             const float Im = CUR[k];                                                                                \
             const float Ir = (i_ < w - 1) ? NXT[k] : Im;                                                            \
             const float Il = (i_ == xs) ? Im : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507); a segment's warm-up starts the same way */ \
-            T[k] = nrm * (Il + p * Im + Ir);                                                                        \
+            T[k] = nrm * (Il + pv * Im + Ir);                                                                       \
             up[k] = wave_ror1(T[k]); /* T[y-1] for lanes 1..63 */                                                   \
             dn[k] = wave_rol1(T[k]); /* T[y+1] for lanes 0..62 */                                                   \
         }                                                                                                           \
@@ -2915,10 +2940,18 @@ __device__ __forceinline__ void level_body(const LevelJob& J, const int64_t f, c
             const int y = lane + 64 * k;                                                                            \
             const float tm = (lane == 0) ? up[k > 0 ? k - 1 : 0] : up[k];       /* row y-1 */                       \
             const float tpv = (lane == 63) ? dn[k + 1 < R ? k + 1 : k] : dn[k]; /* row y+1 */                       \
-            const float mid = tm + p * T[k] + tpv;                                                                  \
-            const float top = p1 * T[k] + tpv;                                                                      \
-            const float bot = tm + p1 * T[k];                                                                       \
-            const float o = (y == 0) ? top : ((y == h - 1) ? bot : mid);                                            \
+            const float mid = tm + pv * T[k] + tpv;                                                                 \
+            /* row 0 is lane 0 of register 0 and row h - 1 lives in the last register (R == ceil(h / 64)): the other */ \
+            /* registers have neither border form nor select                                                      */ \
+            float o = mid;                                                                                          \
+            if (k == R - 1)                                                                                         \
+            {                                                                                                       \
+                o = (y == h - 1) ? tm + p1 * T[k] : o;                                                              \
+            }                                                                                                       \
+            if (k == 0)                                                                                             \
+            {                                                                                                       \
+                o = (y == 0) ? p1 * T[k] + tpv : o;                                                                 \
+            }                                                                                                       \
             prev[k] = o;                                                                                            \
             /* lanes past the end of the plane (last register only) are clamped to row h-1: they store row h-1's */ \
             /* value to row h-1's address, so every store is unconditional and base + 32-bit offset             */ \
@@ -4192,11 +4225,6 @@ struct TileArgs
     uint8_t* tailCodes;
     int32_t codeCap, codePitch;
 };
-
-// Keep scalar / vector values materialised at this point: stops the compiler from
-// sinking the loads that produce them into the data-dependent selects below (which
-// turns straight-line select code into branches with a memory wait in every arm).
-#define ACF_PIN_V(x) asm volatile("" : "+v"(x))
 
 // a tree's node record as one lane holds it (k_cascade_tail3: lanes = trees)
 struct LaneNode

@@ -15,6 +15,10 @@ ops = {
  "cmpu_s": "v_cmp_lt_u32 s[22:23], {d}, {a}", "cmpu_vcc": "v_cmp_lt_u32 vcc, {d}, {a}", "cmpf_vcc": "v_cmp_lt_f32 vcc, {d}, {a}", "cmpx": "v_cmpx_lt_u32 exec, {d}, {a}",
  "cnd_vcc": "v_cndmask_b32 {d}, {d}, {a}, vcc", "cnd_s": "v_cndmask_b32 {d}, {d}, {a}, s[22:23]",
  "cmp_cnd": "v_cmp_lt_u32 vcc, {d}, {a}\\nv_cndmask_b32 {d}, {d}, {a}, vcc", "cmp_cnd_s": "v_cmp_lt_u32 s[22:23], {d}, {a}\\nv_cndmask_b32 {d}, {d}, {a}, s[22:23]",
+ "cnd_vcc_e64": "v_cndmask_b32_e64 {d}, {d}, {a}, vcc", "cnd_vcc_salu": "s_mov_b64 vcc, s[24:25]\\nv_cndmask_b32 {d}, {d}, {a}, vcc",
+ "cnd_vcc_salu4": "s_mov_b64 vcc, s[24:25]\\nv_cndmask_b32 {d}, {d}, {a}, vcc\\nv_cndmask_b32 {a}, {a}, {b}, vcc\\nv_cndmask_b32 {b}, {b}, {d}, vcc\\nv_cndmask_b32 {d}, {d}, {b}, vcc",
+ "cnd_s_salu": "s_mov_b64 s[22:23], s[24:25]\\nv_cndmask_b32 {d}, {d}, {a}, s[22:23]", "cnd_zero": "v_cndmask_b32 {d}, 0, {a}, s[22:23]",
+ "cnd_vcc_cmp4": "v_cmp_lt_u32 vcc, {d}, {a}\\nv_cndmask_b32 {d}, {d}, {a}, vcc\\nv_cndmask_b32 {a}, {a}, {b}, vcc\\nv_cndmask_b32 {b}, {b}, {d}, vcc\\nv_cndmask_b32 {d}, {d}, {b}, vcc",
  "mov": "v_mov_b32 {d}, {a}", "movdpp": "v_mov_b32_dpp {d}, {a} row_shr:1 row_mask:0xf bank_mask:0xf", "adddpp": "v_add_f32_dpp {d}, {a}, {d} row_shr:1 row_mask:0xf bank_mask:0xf",
  "sdwa_cmp": "v_cmp_le_u32_sdwa vcc, {d}, {a} src0_sel:WORD_0 src1_sel:WORD_1", "sdwa_add": "v_add_u32_sdwa {d}, {d}, {a} dst_sel:DWORD src0_sel:WORD_0 src1_sel:WORD_1",
  "pkaddu16": "v_pk_add_u16 {d}, {d}, {a}", "pksubu16c": "v_pk_sub_u16 {d}, {d}, {a} clamp", "pkminu16": "v_pk_min_u16 {d}, {d}, {a}",
