@@ -112,6 +112,9 @@ struct acf_hip_ctx
     int taps = 0;
     int profile = 0;
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
+    // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
+    // (k_smooth_grad) where that pays (big planes, many frames), 2 = wherever k_smooth_grad applies
+    int fusedGrad = getenv("ACF_HIP_NO_FUSED_GRAD") ? 0 : (getenv("ACF_HIP_FUSED_GRAD") ? atoi(getenv("ACF_HIP_FUSED_GRAD")) : 1);
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     int noRank = 0;  // option "rank_cells" = 0: the tile kernel reads the float pyramid (A/B and parity of both forms)
     bool ranksValid = false; // the rank pyramid of the last batch has been written (by the level kernels or by k_rank)
@@ -1029,6 +1032,11 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
         c->noFusedSmooth = value == 0;
         return ACF_HIP_OK;
     }
+    if (!strcmp(key, "fused_grad"))
+    {
+        c->fusedGrad = value;
+        return ACF_HIP_OK;
+    }
     if (!strcmp(key, "cascade_tiles"))
     {
         c->noTiles = value == 0;
@@ -1852,6 +1860,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->levelSegments = c->levelSegments;
             k->countRepairs = c->countRepairs;
             k->noFusedSmooth = c->noFusedSmooth;
+            k->fusedGrad = c->fusedGrad;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
             k->scaleStreams = c->scaleStreams;
@@ -2827,6 +2836,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         }
         // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
         bool colorDone = false;
+        bool gradFused = false, gradBlocked = false; // M and O written by k_smooth_grad, in blocks
         const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 4 == 0 && rs.w >= 16 &&
             rs.h / 4 <= 8 * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
         if (fuseSm)
@@ -2901,7 +2911,77 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 sa.specState = c->d_specState;
                 sa.trueState = c->d_trueState;
                 sa.redo = nullptr;
+                sa.skipZ = -1;
+                // the gradient plane's chain also emits gradMag (k_smooth_grad): its smoothed plane is then written only
+                // where a later scale is resampled from it, and k_grad_mag_vec does not run for this scale
+                const bool gradVecOk = rs.h % 4 == 0 && np % 4 == 0;
+                // Where it pays (measured at 1080p, 3 x 96 frames: +4 % frames/s with scale 0 fused, +2 % with every scale; one
+                // frame alone 1.21 -> 1.61 / 2.40 ms): the gradient work rides on a chain of column steps, so it needs many
+                // chains (frames x segments) and a plane big enough for the saved round trip to matter.  A/B: the variables.
+                static const int64_t gradMinPx = getenv("ACF_HIP_FUSED_GRAD_MINPX") ? atoll(getenv("ACF_HIP_FUSED_GRAD_MINPX")) : (int64_t(1) << 20);
+                static const int gradMinF = getenv("ACF_HIP_FUSED_GRAD_MINF") ? atoi(getenv("ACF_HIP_FUSED_GRAD_MINF")) : 16;
+                const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk &&
+                    (c->fusedGrad >= 2 || (c->fusedGrad == 1 && np >= gradMinPx && nF >= gradMinF));
+                if (wantGrad)
+                {
+                    const bool wantTri0 = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
+                    // (the layout of M and O: the decision the y pass takes below, from the same inputs)
+                    ChnsArgs a0{};
+                    a0.M = rs.M;
+                    a0.O = rs.O;
+                    a0.Mn = nullptr; // (no taps on this path)
+                    a0.doNorm = p.normRad != 0;
+                    a0.colorDone = 1;
+                    a0.colorEnabled = p.colorEnabled;
+                    a0.magEnabled = p.gradMagEnabled;
+                    a0.histEnabled = p.gradHistEnabled;
+                    a0.nOrients = p.nOrients;
+                    const bool blocked0 = wantTri0 && triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, &a0, rs.uFloats, rs.moFloats, true).blocked;
+                    gradBlocked = blocked0;
+                    sa.skipZ = p.colorChn;
+                    sa.gM = rs.M;
+                    sa.gO = rs.O;
+                    sa.acos = c->d_acos;
+                    sa.mo_fs = blocked0 ? moBlockedFloats(rs.h, rs.w) : np;
+                    sa.nybM = blocked0 ? (rs.h + 15) / 16 : 0;
+                    sa.full = p.full;
+                    gradFused = true;
+                    if (!needFullAll)
+                    {
+                        fullMask &= ~(1u << p.colorChn);
+                    }
+                }
+                const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float);
+                if (wantGrad)
+                {
+                    int rcl = 0;
+                    if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true>), ldsG)) ||
+                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false>), ldsG)))
+                    {
+                        return rcl;
+                    }
+                }
                 auto launchSv = [&](dim3 grid) {
+                    if (wantGrad)
+                    {
+                        // (first: its chains are the long ones)
+                        SmoothVecArgs sg = sa;
+                        sg.plane0 = p.colorChn;
+                        sg.skipZ = -1;
+                        if (halfNext)
+                        {
+                            hipLaunchKernelGGL((k_smooth_grad<true>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                        }
+                        else
+                        {
+                            hipLaunchKernelGGL((k_smooth_grad<false>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                        }
+                        grid.x -= 1;
+                        if (grid.x == 0)
+                        {
+                            return;
+                        }
+                    }
                     if (halfNext)
                     {
                         hipLaunchKernelGGL((k_smooth_vec<true>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
@@ -2995,14 +3075,23 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         const bool wantTri = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
         const bool blockedMO = wantTri &&
             triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, (shrink == 4 && !c->taps) ? &a : nullptr, rs.uFloats, rs.moFloats, gradVec).blocked;
-        if (p.gradMagEnabled || p.gradHistEnabled)
+        if (gradFused)
+        {
+            // (M and O are there already)
+            if (gradBlocked != blockedMO)
+            {
+                return fail(c, ACF_HIP_E_INVALID, "k_smooth_grad: M / O layout differs from the y pass's");
+            }
+        }
+        else if (p.gradMagEnabled || p.gradHistEnabled)
         {
             prof(c, "k_grad_mag");
             if (rs.h % 4 == 0 && np % 4 == 0)
             {
                 // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
                 const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
-                const int blocks = int(std::min<int64_t>(256, (items + GMV_BLOCK - 1) / GMV_BLOCK));
+                static const int gmvMax = getenv("ACF_HIP_GMV_BLOCKS") ? atoi(getenv("ACF_HIP_GMV_BLOCKS")) : 256;
+                const int blocks = int(std::min<int64_t>(gmvMax, (items + GMV_BLOCK - 1) / GMV_BLOCK));
                 if (blockedMO)
                 {
                     hipLaunchKernelGGL((k_grad_mag_vec<true>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),

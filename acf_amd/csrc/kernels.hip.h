@@ -488,6 +488,14 @@ struct SmoothVecArgs
     float* specState; // [frame][plane][segment][h]: a segment's state after its warm-up = its guess of column x0 - 1
     float* trueState; // [frame][plane][segment][h]: the previous segment's output column x0 - 1
     const int32_t* redo; // repair launch (nSeg == 1): [frame][plane] != 0 -> this plane is recomputed as one segment; NULL: every plane
+    int32_t skipZ;       // >= 0: this launch leaves plane skipZ out (k_smooth_grad runs it); blockIdx.x counts the others
+    // GRAD (k_smooth_grad): gradMag of the smoothed plane from the chain's registers — M and O of column i - 1 leave when
+    // column i has been smoothed; the smoothed plane itself is then only written where a later scale is resampled from it
+    float* gM;           // [frame] M, plain [w][h] (nybM == 0) or in 64-column x 16-row blocks (k_grad_mag_vec<true>'s layout)
+    float* gO;
+    const float* acos;   // GM_ACOS_N floats (index 0 of the table = entry 10010)
+    int64_t mo_fs;       // frame stride of M / O in floats
+    int32_t nybM, full;
 };
 
 __device__ __forceinline__ float wave_rol1(float v)
@@ -521,8 +529,9 @@ constexpr int SV_OWN = 64 - 2 * SV_K; // quads a wave owns
 // both are written to side buffers, k_smooth_verify compares them bit for bit, and a plane with any difference is
 // recomputed as one chain by a second launch of this kernel (`redo`) before anything reads it.  Exactness therefore does
 // not rest on the contraction argument; only speed does (no repair has been observed with warm >= 32).
-template <bool FULL, bool HALF, bool SHRINK>
-__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z)
+#define GM_ACOS_N 20020
+template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false>
+__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
     const int seg = blockIdx.y;
@@ -546,7 +555,55 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     const bool haloLo = lane < SV_K && wv > 0, haloHi = lane >= 64 - SV_K && wv + 1 < nWv;
     const int srcWave = haloLo ? wv - 1 : wv + 1, srcSide = haloLo ? 1 : 0, srcIdx = haloLo ? lane : lane - (64 - SV_K);
     float prev[4] = { 0.f, 0.f, 0.f, 0.f }, acc[4] = { 0.f, 0.f, 0.f, 0.f };
+    float pp[4] = { 0.f, 0.f, 0.f, 0.f }; // GRAD: the smoothed column before `prev`
+    float* __restrict__ gMq = nullptr;
+    float* __restrict__ gOq = nullptr;
+    if (GRAD)
+    {
+        // the lane's quad in the M / O planes: blocked [x >> 6][y >> 4][x & 63][y & 15] (nybM > 0) or plain [x][y]
+        const int64_t qo = a.nybM > 0 ? int64_t(((uint32_t(4 * qc) >> 4) << 10) + (uint32_t(4 * qc) & 15u)) : int64_t(4 * qc);
+        gMq = a.gM + f * a.mo_fs + qo;
+        gOq = a.gO + f * a.mo_fs + qo;
+    }
     float4 c0[SV_CH], c1[SV_CH];
+    // gradMag of smoothed column X (gradientMex.cpp:17-87,168-251; k_grad_mag_vec's arithmetic per pixel): LFT / CUR / RGT =
+    // the lane's quad in columns max(X - 1, 0), X, min(X + 1, w - 1).  The rows above and below the quad are the
+    // neighbouring lanes' (halo lanes hold the neighbouring waves' quads: exact for the nearest row at every step, see
+    // SV_REFRESH).  OK_: wave-uniform, false = compute but store to the dump slot (no branch in the column loop).
+#define SV_GRAD(X, LFT, CUR, RGT, OK_)                                                            \
+    {                                                                                             \
+        const int x_ = (X);                                                                       \
+        const float rx = (x_ == 0 || x_ == w - 1) ? 1.f : .5f;                                    \
+        const float gup = wave_ror1(CUR[3]), gdn = wave_rol1(CUR[0]);                             \
+        float mo[4], oo[4];                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
+        {                                                                                         \
+            const bool top_ = first && k == 0, bot_ = last && k == 3;                             \
+            const float ry = (top_ || bot_) ? 1.f : .5f;                                          \
+            const float ga = (k == 0) ? (first ? CUR[0] : gup) : CUR[k > 0 ? k - 1 : 0];          \
+            const float gb = (k == 3) ? (last ? CUR[3] : gdn) : CUR[k < 3 ? k + 1 : 3];           \
+            const float gx = (RGT[k] - LFT[k]) * rx;                                              \
+            const float gy = (gb - ga) * ry;                                                      \
+            const float m2 = gx * gx + gy * gy;                                                   \
+            float m = 1.0f / sqrtf(m2);                                                           \
+            m = m < 1e10f ? m : 1e10f;                                                            \
+            float g = (gx * m) * 10000.0f;                                                        \
+            g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));            \
+            g = g < 10009.0f ? g : 10009.0f;                                                      \
+            g = g > -10009.0f ? g : -10009.0f;                                                    \
+            float ov = acosT[(int)g];                                                             \
+            if (a.full)                                                                           \
+            {                                                                                     \
+                ov += (gy < 0) * 3.14159265f;                                                     \
+            }                                                                                     \
+            mo[k] = 1.0f / m;                                                                     \
+            oo[k] = ov;                                                                           \
+        }                                                                                         \
+        const int64_t co = a.nybM > 0 ? int64_t((((uint32_t(x_) >> 6) * uint32_t(a.nybM)) << 10) + ((uint32_t(x_) & 63u) << 4)) : int64_t(x_) * h; \
+        const bool st_ = valid && (OK_);                                                          \
+        *reinterpret_cast<float4*>(st_ ? gMq + co : a.dump + 4 * lane) = make_float4(mo[0], mo[1], mo[2], mo[3]); \
+        *reinterpret_cast<float4*>(st_ ? gOq + co : a.dump + 4 * lane) = make_float4(oo[0], oo[1], oo[2], oo[3]); \
+    }
 #define SV_LOAD(BUF, I0)                                                                          \
     _Pragma("unroll") for (int j = 0; j < SV_CH; j++)                                             \
     {                                                                                             \
@@ -600,8 +657,19 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
                 *dst = (((acc[0] + acc[1]) + acc[2]) + acc[3]) * a.rq_y;                          \
             }                                                                                     \
         }                                                                                         \
+        if (GRAD && (EMIT))                                                                       \
+        {                                                                                         \
+            /* column i - 1: left neighbour pp (for column 0: itself, see below), right neighbour o = column i; the    */ \
+            /* segment's first step has no column i - 1 of its own (the previous segment's extra step emits it):      */ \
+            /* computed, not stored                                                                                   */ \
+            SV_GRAD(i_ - 1, pp, prev, o, i_ > x0)                                                 \
+        }                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
         {                                                                                         \
+            if (GRAD)                                                                             \
+            {                                                                                     \
+                pp[k] = (i_ == xs) ? o[k] : prev[k]; /* after the chain's first step pp = prev: column 0's left neighbour is itself */ \
+            }                                                                                     \
             prev[k] = o[k];                                                                       \
         }                                                                                         \
     }
@@ -670,6 +738,36 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     {
         *reinterpret_cast<float4*>(a.trueState + stateOff + int64_t(seg + 1) * h) = make_float4(prev[0], prev[1], prev[2], prev[3]);
     }
+    if (GRAD)
+    {
+        // gradMag of the segment's last column x1 - 1.  The plane's last column has no right neighbour but itself
+        // (gradientMex.cpp:31-33); an inner segment smooths one more column, x1 — the exact continuation of its chain: c0
+        // holds the input columns x1, x1 + 1 (segW is a multiple of 16: the loop's last prefetch) — for nothing else.
+        if (x1 == w)
+        {
+            SV_GRAD(w - 1, pp, prev, prev, true)
+        }
+        else
+        {
+            const float4 cur = c0[0], nxt = c0[1];
+            const float im[4] = { cur.x, cur.y, cur.z, cur.w };
+            const float ir[4] = { nxt.x, nxt.y, nxt.z, nxt.w };
+            float T[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                T[k] = nrm * (prev[k] + p * im[k] + ir[k]);
+            }
+            const float up = wave_ror1(T[3]), dn = wave_rol1(T[0]);
+            float o[4];
+            o[0] = first ? p1 * T[0] + T[1] : up + p * T[0] + T[1];
+            o[1] = T[0] + p * T[1] + T[2];
+            o[2] = T[1] + p * T[2] + T[3];
+            o[3] = last ? T[2] + p1 * T[3] : T[2] + p * T[3] + dn;
+            SV_GRAD(x1 - 1, pp, prev, o, true)
+        }
+    }
+#undef SV_GRAD
 #undef SV_LOAD
 #undef SV_COL
 #undef SV_REFRESH
@@ -685,7 +783,11 @@ template <bool HALF>
 __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fullMask)
 {
     extern __shared__ float lds[]; // [2 chunk parities][8 waves][2 sides][SV_K quads][4]: the waves' edge state
-    const int z = a.plane0 + blockIdx.x;
+    int z = a.plane0 + blockIdx.x;
+    if (a.skipZ >= 0 && z >= a.skipZ)
+    {
+        z++; // (that plane is k_smooth_grad's)
+    }
     if (a.redo && a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
     {
         return; // repair launch: this plane's segments agreed
@@ -697,6 +799,35 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fu
     else
     {
         smooth_vec_body<false, HALF, true>(a, lds, z);
+    }
+}
+
+// The gradient plane's launch: smoothing (+ colour channel, + half-size image) AND gradMag of the smoothed plane from the
+// chain's registers.  The smoothed plane then makes no HBM round trip between the two (8.3 MB written and read per 1080p
+// frame and scale 0; it is still written at a scale later scales are resampled from).  Its workgroups carry the acos table
+// (80 KB of LDS), which is why the other planes stay in k_smooth_vec's launch (a launch has ONE LDS size).
+template <bool HALF>
+__global__ void __launch_bounds__(512) k_smooth_grad(SmoothVecArgs a, uint32_t fullMask)
+{
+    extern __shared__ float lds[]; // the waves' edge state (k_smooth_vec), then the acos table
+    const int z = a.plane0;
+    if (a.redo && a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+    {
+        return;
+    }
+    float* acosL = lds + 2 * 8 * 2 * SV_K * 4;
+    for (int i = threadIdx.x; i < GM_ACOS_N; i += blockDim.x)
+    {
+        acosL[i] = a.acos[i];
+    }
+    __syncthreads();
+    if ((fullMask >> z) & 1u)
+    {
+        smooth_vec_body<true, HALF, true, true>(a, lds, z, acosL + 10010);
+    }
+    else
+    {
+        smooth_vec_body<false, HALF, true, true>(a, lds, z, acosL + 10010);
     }
 }
 
@@ -821,7 +952,6 @@ __global__ void __launch_bounds__(256) k_pad_reflect(T* __restrict__ pyr, const 
 //    are clamped indices + selects (no branch around a load).
 #define GM_XT 8
 #define GM_ROWS 384
-#define GM_ACOS_N 20020
 __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
     const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int stripsPerBlock)
 {

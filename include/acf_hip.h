@@ -203,6 +203,10 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * chain of its own) — these kernels are bound by VALU and LDS, and two of them side by
  * side displace each other where each could run beside another context's memory-bound
  * pyramid kernels; three contexts, cfg 2: +4 % frames/s with 5),
+ * "fused_grad" (1, default: gradMag is computed inside the gradient plane's smoothing
+ * chain — the smoothed plane then makes no round trip through memory — for planes of
+ * >= 2^20 pixels in batches of >= 16 frames, where that pays; 2: wherever that kernel
+ * applies; 0: always as its own kernel),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);

@@ -187,6 +187,7 @@ def test_sub_batch_streams(oracle, streams):
 @pytest.mark.parametrize("fused_smooth", [1, 0])
 @pytest.mark.parametrize("H,W,kw", [
     (256, 384, dict(name="TINY", nTrees=96)),                       # fused: exact-half next scale, colour channels from registers
+    (256, 384, dict(name="TINY", nTrees=96, full=1, colorChn=1)),   # orientation over 2 pi, gradient plane 1 (k_smooth_grad takes that plane)
     (480, 640, dict(name="FACE80", nTrees=256)),
     (200, 264, dict(name="TINY", nTrees=96)),                       # sz != sz1 at scale 1 (image resampled first), generic next-scale resample
     (96, 132, dict(name="TINY", nTrees=96)),                        # w % 8 != 0 at some scale: falls back per scale
@@ -209,6 +210,7 @@ def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
     frame = synth.make_frame(23, H, W, "luv")
     det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
     det.set_option("fused_smooth", fused_smooth)
+    det.set_option("fused_grad", 2 if fused_smooth else 0)  # gradMag inside the gradient plane's smoothing chain at every scale it applies to / its own kernel
     det.set_option("scale_streams", fused_smooth)  # real scales on their own streams / all on the context's stream
     det.run(torch.from_numpy(np.stack([frame, frame])).cuda())
     plan = oracle.Plan(model, H, W, 3)

@@ -23,8 +23,9 @@ def _check(oracle, det, frames, model, H, W):
         assert d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes()
 
 
+@pytest.mark.parametrize("fused_grad", [0, 2])   # gradMag as its own kernel / inside the gradient plane's chain (k_smooth_grad)
 @pytest.mark.parametrize("segments,warm,force", [(0, 48, 0), (1, 48, 0), (4, 48, 0), (7, 32, 0), (16, 16, 0), (5, 48, 1)])
-def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force):
+def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force, fused_grad):
     from acf_amd.detector import HipDetector
     H, W = 256, 512   # w % 8 == 0, h % 4 == 0: the vector smoothing kernel; every level goes through the fused level kernel
     model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
@@ -36,6 +37,7 @@ def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force):
     det.set_option("smooth_segments", segments)
     det.set_option("smooth_warm", warm)
     det.set_option("smooth_force_redo", force)
+    det.set_option("fused_grad", fused_grad)
     # the level chains' segments too (off by default): as many as the smoothing's, with a warm-up short enough to miss sometimes
     det.set_option("level_segments", 0 if segments == 0 else min(segments, 8))
     det.set_option("level_warm", min(warm, 32))
@@ -63,13 +65,15 @@ def test_segmented_smoothing_rgb_and_sub_batches(oracle):
     det.set_model(model)
     det.set_option("smooth_segments", 6)
     det.set_option("smooth_warm", 32)
+    det.set_option("fused_grad", 2)
     det.plan(H, W, 3, max_batch=4, max_hits=1 << 15)
     _check(oracle, det, frames, model, H, W)
     det.close()
 
 
+@pytest.mark.parametrize("fused_grad", [0, 2])
 @pytest.mark.parametrize("W,segments", [(484, 0), (484, 3), (492, 1), (20, 0), (36, 2)])
-def test_widths_that_are_not_multiples_of_eight(oracle, W, segments):
+def test_widths_that_are_not_multiples_of_eight(oracle, W, segments, fused_grad):
     """w % 8 == 4: the vector smoothing kernel's four-column tail (the third real scale of a 1080p frame is 484 columns wide)."""
     from acf_amd.detector import HipDetector
     H = 136 if W > 100 else 64
@@ -78,6 +82,7 @@ def test_widths_that_are_not_multiples_of_eight(oracle, W, segments):
     det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
     det.set_option("smooth_segments", segments)
     det.set_option("smooth_warm", 16)
+    det.set_option("fused_grad", fused_grad)
     import torch
     det.run(torch.from_numpy(frames).cuda())
     plan = oracle.Plan(model, H, W, 3)
