@@ -5027,6 +5027,35 @@ int acf_hip_op_conv_tri(acf_hip_ctx* c, const float* in, float* out, int h, int 
     return ACF_HIP_OK;
 }
 
+int acf_hip_selftest_gradmag(acf_hip_ctx* c, uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, uint32_t* first_bad_bits)
+{
+    OP_PROLOGUE(c);
+    if (!mismatches || last_bits < first_bits)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "selftest_gradmag: arguments");
+    }
+    Scratch s;
+    unsigned long long* d = s.alloc<unsigned long long>(2);
+    if (!d)
+    {
+        return fail(c, ACF_HIP_E_HIP, "selftest_gradmag: allocation");
+    }
+    const unsigned long long init[2] = { 0ull, ~0ull };
+    HIPCHK(c, hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+    const unsigned long long count = (unsigned long long)(last_bits - first_bits) + 1ull;
+    hipLaunchKernelGGL(k_gm_inv_selftest, dim3(4096), dim3(256), 0, c->stream, first_bits, count, d);
+    LAUNCHCHK(c, "k_gm_inv_selftest");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long out[2];
+    HIPCHK(c, hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
+    *mismatches = out[0];
+    if (first_bad_bits)
+    {
+        *first_bad_bits = uint32_t(out[1]);
+    }
+    return ACF_HIP_OK;
+}
+
 int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O, float* S_out, int h, int w, int normRad, double normConst, int full)
 {
     OP_PROLOGUE(c);

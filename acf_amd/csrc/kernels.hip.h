@@ -530,6 +530,65 @@ constexpr int SV_OWN = 64 - 2 * SV_K; // quads a wave owns
 // recomputed as one chain by a second launch of this kernel (`redo`) before anything reads it.  Exactness therefore does
 // not rest on the contraction argument; only speed does (no repair has been observed with warm >= 32).
 #define GM_ACOS_N 20020
+// gradMag's two reciprocals (gradientMex.cpp:209-219 with exact arithmetic): m = min(1 / sqrt(m2), 1e10),
+// M = 1 / m, every operation rounded as IEEE.  gm_inv_ieee is that text; the compiler's expansion of it is ~36 VALU
+// instructions per pixel (a correctly rounded sqrt with range scaling, two divisions with v_div_scale / v_div_fmas /
+// v_div_fixup).  gm_inv_fast returns the same two floats for EVERY finite m2 >= 0 — acf_hip_selftest_gradmag compares the
+// two over all 2^31 bit patterns on the device (tests/test_gpu_ops.py) — with one v_rsq_f32 and FMA refinements whose
+// residuals are exact: sqrt from the rsq estimate y (m2 * y corrected by its residual), 1 / s refined from the same
+// estimate, and 1 / m refined from s (m ~ 1 / s, so s is already within 1 ulp of 1 / m): 17 instructions.  Longer forms
+// (a Goldschmidt step before the sqrt residual, second Newton steps) were checked the same way and are not needed.  Inputs
+// whose m reaches the clamp (s < 1e-10, incl. m2 = 0 where the estimate is inf and the refinement NaN: `t < 1e10f` is
+// false) take the constants.
+__device__ __forceinline__ void gm_inv_ieee(float m2, float& m, float& M)
+{
+    float t = 1.0f / sqrtf(m2);
+    m = t < 1e10f ? t : 1e10f;
+    M = 1.0f / m;
+}
+__device__ __forceinline__ void gm_inv_fast(float m2, float& m, float& M)
+{
+    const float y = __builtin_amdgcn_rsqf(m2);
+    const float g = m2 * y, hh = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, m2);
+    const float s = __builtin_fmaf(d, hh, g); // RN(sqrt(m2))
+    const float e = __builtin_fmaf(-s, y, 1.0f);
+    float t = __builtin_fmaf(e, y, y);        // RN(1 / s) ...
+    // ... but for s = 2^k (1 - 2^-24) (mantissa all ones: m2 just below a power of 4), where 1 / s = 2^-k (1 + 2^-24 + 2^-48 ..)
+    // lies a hair above a tie that y (1 + e) can hit exactly and round to even: the answer there is nextup(2^-k), whose bit
+    // pattern is 0x7f000000 - bits(s).  (The only inputs the exhaustive comparison found before this line: 196 of 2^31.)
+    const uint32_t sb = __float_as_uint(s);
+    t = (sb & 0x7fffffu) == 0x7fffffu ? __uint_as_float(0x7f000000u - sb) : t;
+    const bool in = t < 1e10f;
+    const float e2 = __builtin_fmaf(-t, s, 1.0f);
+    const float q = __builtin_fmaf(e2, s, s); // RN(1 / t)
+    m = in ? t : 1e10f;
+    M = in ? q : 1.0f / 1e10f;
+}
+// bit patterns first .. first + count - 1 (as m2): mismatches of gm_inv_fast against gm_inv_ieee; bad[0] = their number,
+// bad[1] = the smallest mismatching pattern
+__global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigned long long count, unsigned long long* __restrict__ bad)
+{
+    unsigned long long nb = 0, lo = ~0ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256)
+    {
+        const uint32_t bits = first + uint32_t(i);
+        const float x = __uint_as_float(bits);
+        float m0, M0, m1, M1;
+        gm_inv_ieee(x, m0, M0);
+        gm_inv_fast(x, m1, M1);
+        if (__float_as_uint(m0) != __float_as_uint(m1) || __float_as_uint(M0) != __float_as_uint(M1))
+        {
+            nb++;
+            lo = lo < bits ? lo : bits;
+        }
+    }
+    if (nb)
+    {
+        atomicAdd(&bad[0], nb);
+        atomicMin(&bad[1], lo);
+    }
+}
 template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false>
 __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr)
 {
@@ -585,8 +644,8 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             const float gx = (RGT[k] - LFT[k]) * rx;                                              \
             const float gy = (gb - ga) * ry;                                                      \
             const float m2 = gx * gx + gy * gy;                                                   \
-            float m = 1.0f / sqrtf(m2);                                                           \
-            m = m < 1e10f ? m : 1e10f;                                                            \
+            float m;                                                                              \
+            gm_inv_fast(m2, m, mo[k]);                                                            \
             float g = (gx * m) * 10000.0f;                                                        \
             g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));            \
             g = g < 10009.0f ? g : 10009.0f;                                                      \
@@ -596,7 +655,6 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             {                                                                                     \
                 ov += (gy < 0) * 3.14159265f;                                                     \
             }                                                                                     \
-            mo[k] = 1.0f / m;                                                                     \
             oo[k] = ov;                                                                           \
         }                                                                                         \
         const int64_t co = a.nybM > 0 ? int64_t((((uint32_t(x_) >> 6) * uint32_t(a.nybM)) << 10) + ((uint32_t(x_) & 63u) << 4)) : int64_t(x_) * h; \
@@ -1089,8 +1147,8 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
                 const float gx = (rgt[k] - lft[k]) * rx;
                 const float gy = (b - a) * ry;
                 const float m2 = gx * gx + gy * gy;
-                float m = 1.0f / sqrtf(m2);
-                m = m < 1e10f ? m : 1e10f;
+                float m;
+                gm_inv_fast(m2, m, mo[k]); // m = min(1 / sqrt(m2), 1e10), M = 1 / m: the IEEE results, see gm_inv_fast
                 float g = (gx * m) * 10000.0f;
                 g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
                 g = g < 10009.0f ? g : 10009.0f;
@@ -1100,7 +1158,6 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
                 {
                     ov += (gy < 0) * 3.14159265f;
                 }
-                mo[k] = 1.0f / m;
                 oo[k] = ov;
             }
             if (x < w)

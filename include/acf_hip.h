@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 6
+#define ACF_HIP_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -385,6 +385,11 @@ ACF_HIP_API int acf_hip_op_conv_tri(acf_hip_ctx* ctx, const float* in, float* ou
 /* Detector::gradientMag (gradientMag.cpp:102-135). S_out may be NULL. */
 ACF_HIP_API int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float* M, float* O, float* S_out,
     int h, int w, int normRad, double normConst, int full);
+/* Self-check of the gradMag kernels' fast form of m = min(1/sqrt(m2), 1e10), M = 1/m (one v_rsq_f32 + FMA refinements)
+ * against the IEEE sqrt and divisions it stands for (gradientMex.cpp:209-219 with exact arithmetic), on the device, for
+ * every float bit pattern first_bits .. last_bits taken as m2: *mismatches = how many differ in either result,
+ * *first_bad_bits = the smallest such pattern.  0 .. 0x7f7fffff (every finite m2 >= 0) must give 0. */
+ACF_HIP_API int acf_hip_selftest_gradmag(acf_hip_ctx* ctx, uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, uint32_t* first_bad_bits);
 /* Detector::gradientHist (gradientHist.cpp:92-115), softBin 0. */
 ACF_HIP_API int acf_hip_op_gradient_hist(acf_hip_ctx* ctx, const float* M, const float* O, float* H,
     int h, int w, int bin, int nOrients, int full);

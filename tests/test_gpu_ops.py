@@ -345,3 +345,18 @@ def test_acf_detect1_tiled_geometries(dev, oracle, case):
     for k in ("scale", "c", "r"):
         assert np.array_equal(got[k], want[k]), k
     assert np.array_equal(bits(got["score"]), bits(want["score"]))
+
+
+def test_gradmag_fast_reciprocals_equal_ieee_for_every_input():
+    """k_grad_mag_vec / k_smooth_grad compute m = min(1/sqrt(m2), 1e10), M = 1/m with one v_rsq_f32 and FMA refinements
+    (gm_inv_fast, kernels.hip.h) instead of the compiler's IEEE sqrt + two divisions.  The two forms are functions of ONE
+    float, so the claim "same bits" is checked exhaustively on the device: every finite m2 >= 0 (2^31 - 2^23 patterns)."""
+    import ctypes as C
+    from acf_amd import capi
+    lib = capi.load()
+    ctx = C.c_void_p()
+    assert lib.acf_hip_create(0, None, C.byref(ctx)) == 0
+    bad, first = C.c_uint64(0), C.c_uint32(0)
+    assert lib.acf_hip_selftest_gradmag(ctx, 0, 0x7f7fffff, C.byref(bad), C.byref(first)) == 0
+    assert bad.value == 0, "%d mismatches, first at bits 0x%08x" % (bad.value, first.value)
+    lib.acf_hip_destroy(ctx)
