@@ -4822,36 +4822,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
         const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
         const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
         const int ccMax = colsValid - 1;
-        if (a.debug & 512)
-        {
-            // experiment: no fill at all (stage A's time on whatever the LDS holds)
-        }
-        else if (a.debug & 256)
-        {
-            // experiment: the chunks through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA
-            uint4 v[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-            {
-                const uint32_t q = min(uint32_t(wv) * 64u + uint32_t(k) * (NW * 64u) + lane, nChunks - 1);
-                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
-                const uint32_t j = q - seg * cps;
-                const uint32_t z = __umulhi(seg, a.g.colsMagic);
-                const int cc = int(seg - z * uint32_t(colsT));
-                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
-                v[k] = *reinterpret_cast<const uint4*>(src0 + soff);
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-            {
-                const uint32_t q = uint32_t(wv) * 64u + uint32_t(k) * (NW * 64u) + lane;
-                if (q < nChunks)
-                {
-                    *reinterpret_cast<uint4*>(tileF + uint32_t(CPB) * q) = v[k];
-                }
-            }
-        }
-        else
         for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
         {
             const uint32_t q = q0 + lane;
@@ -4959,10 +4929,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
         nIn = __popcll(m);
     }
     TILE_STAMP_REL(7);
-    if (a.debug & 128)
-    {
-        __builtin_amdgcn_s_setprio(3); // experiment: the sparse pieces are the tile's critical path
-    }
     if (a.g.b[1] < tEnd)
     {
 #pragma unroll
