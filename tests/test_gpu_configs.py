@@ -52,7 +52,8 @@ def test_full_size_config_bit_exact(oracle, cfg):
     det.close()
 
 
-def test_cfg3_batch_of_1080p_frames(oracle):
+@pytest.mark.parametrize("fused_grad", [1, 2])   # 2: gradMag inside the smoothing chain at every scale (what batches >= 16 frames get at scale 0)
+def test_cfg3_batch_of_1080p_frames(oracle, fused_grad):
     import torch
     from acf_amd.detector import HipDetector
     H, W = 1080, 1920
@@ -60,6 +61,7 @@ def test_cfg3_batch_of_1080p_frames(oracle):
     n = 8
     frames = np.stack([synth.make_frame(100 + i, H, W, "luv") for i in range(n)])
     det = HipDetector(model, H, W, 3, max_batch=n, max_hits=1 << 15)
+    det.set_option("fused_grad", fused_grad)
     det.run(torch.from_numpy(frames).cuda())
     plan = oracle.Plan(model, H, W, 3)
     for f in (0, 3, 7):
