@@ -74,6 +74,12 @@ struct CascState
     // stage E of k_cascade_tile2 + k_tail_scan: leaf codes of the first codeCap queue entries per frame
     uint8_t* d_tailCodes = nullptr;
     int codeCap = 0, codePitch = 0;
+    // fixed depths other than 2 (k_cascade_tileD): stage 0 of the staged path on float tiles
+    bool useTileD = false;
+    CascTile* d_tilesD = nullptr;
+    int nTilesD = 0, tbD = 0, t1D = 0;
+    TileGeom geomD{};
+    uint32_t* d_nodesD = nullptr;
     // threshold-rank cells (host_plan.h): the tile kernel's second form, reading a 16-bit pyramid
     bool useRank = false;
     TileGeom geomR{};
@@ -1270,6 +1276,9 @@ struct TileSet
     CascTile* d_tiles = nullptr;
     TreeNode* d_tileNodes = nullptr;
     uint32_t* d_tileNodesS = nullptr;
+    // depths other than 2 (k_cascade_tileD): records of trees [0, t1D) in batches of tbD
+    uint32_t* d_nodesD = nullptr;
+    int tbD = 0, t1D = 0;
 };
 
 static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out)
@@ -1375,6 +1384,50 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     }
     if (!ok)
     {
+        return ACF_HIP_OK;
+    }
+    if (p.treeDepth != 2)
+    {
+        // k_cascade_tileD: stage 0 of the staged path, trees [0, 32) (the staged path's second boundary), on float tiles.
+        // Records per batch of TB trees: {off[TB][NN], thr[TB][NN], hs[TB][NL]}, nodes in heap order, leaves left to right.
+        const int D = p.treeDepth;
+        if (rank || D < 1 || D > 4 || D == 2)
+        {
+            return ACF_HIP_OK;
+        }
+        const int NN = (1 << D) - 1, NL = 1 << D, TB = D == 1 ? 4 : (D == 3 ? 2 : 1);
+        const int t1 = std::min(32, p.nTrees) / TB * TB;
+        if (t1 <= 0 || (t1 != p.nTrees && t1 != 32) || p.nTreeNodes < NN + NL)
+        {
+            return ACF_HIP_OK; // (a model shorter than 32 trees whose length is not a multiple of the batch: staged path)
+        }
+        std::vector<uint32_t> nd(size_t(t1 / TB) * TB * (2 * NN + NL), 0u);
+        for (int t = 0; t < t1; t++)
+        {
+            const size_t q = size_t(t) * p.nTreeNodes;
+            uint32_t* d = nd.data() + size_t(t / TB) * TB * (2 * NN + NL);
+            const int tq = t % TB;
+            for (int k = 0; k < NN; k++)
+            {
+                const uint32_t f = c->fids[q + k];
+                const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
+                d[tq * NN + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
+                memcpy(&d[TB * NN + tq * NN + k], &c->thrs[q + k], 4);
+            }
+            for (int j = 0; j < NL; j++)
+            {
+                memcpy(&d[2 * TB * NN + tq * NL + j], &c->hs[q + NN + j], 4);
+            }
+        }
+        out.g = g;
+        out.nTiles = int(tiles.size());
+        out.tbD = TB;
+        out.t1D = t1;
+        if ((rc = devUpload(c, &out.d_nodesD, nd)) || (rc = devUpload(c, &out.d_tiles, tiles)))
+        {
+            return rc;
+        }
+        out.ok = true;
         return ACF_HIP_OK;
     }
     std::vector<TreeNode> tileNodes(size_t(std::max(p.nTrees, 1)));
@@ -1566,6 +1619,25 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile2 + stage E + k_tail_scan, k_cascade_tail3 for queue overflow)
     cs.useTiles = false;
     cs.useRank = false;
+    cs.useTileD = false;
+    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.stride % p.shrink == 0 && p.stride >= p.shrink)
+    {
+        TileSet tsD;
+        if ((rc = buildTileSet(c, lv, nChns, nullptr, tsD)))
+        {
+            return rc;
+        }
+        if (tsD.ok && (tsD.g.NW == 8 || tsD.g.NW == 4))
+        {
+            cs.useTileD = true;
+            cs.d_tilesD = tsD.d_tiles;
+            cs.nTilesD = tsD.nTiles;
+            cs.tbD = tsD.tbD;
+            cs.t1D = tsD.t1D;
+            cs.geomD = tsD.g;
+            cs.d_nodesD = tsD.d_nodesD;
+        }
+    }
     if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
     {
         TileSet tsF;
@@ -3796,7 +3868,74 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
         const int mode = p.treeDepth == 2 ? 2 : (p.treeDepth > 0 ? 1 : 0);
         // later stages see a shrinking survivor set; grid-stride loops cover any count
         const int qGrid[3] = { std::max(1, blocksPerFrame / 2), std::max(1, blocksPerFrame / 8), std::max(1, std::min(blocksPerFrame, 64)) };
-        for (int sidx = 0; sidx < nStages; sidx++)
+        int firstStage = 0;
+        if (c->cs.useTileD && !c->noTiles)
+        {
+            // depths 1, 3, 4: trees [0, t1D) of every window from LDS tiles (k_cascade_tileD) instead of the first stages'
+            // per-lane gathers from the pyramid; its survivors enter the queue of the stage that ends at t1D
+            const auto& cs = c->cs;
+            int sD = -1;
+            for (int i = 0; i < nStages; i++)
+            {
+                if (bounds[size_t(i)] == cs.t1D)
+                {
+                    sD = i;
+                }
+            }
+            if (sD >= 0)
+            {
+                TileDArgs at{};
+                at.pyr = pyr;
+                at.pyr_fs = pyr_fs;
+                at.levels = d_levels;
+                at.tiles = cs.d_tilesD;
+                at.nTiles = cs.nTilesD;
+                at.nFrames = nF;
+                at.nChns = nChns;
+                at.nBatches = cs.t1D / cs.tbD;
+                at.g = cs.geomD;
+                at.nodesD = cs.d_nodesD;
+                at.cascThr = float(p.cascThr);
+                at.last = sD == nStages - 1;
+                at.qout = cs.d_queue[sD & 1];
+                at.qoutCount = cs.d_qcounts + size_t(sD) * c->maxBatch;
+                at.qcap = cs.qcap;
+                at.hits = cs.d_hits;
+                at.counts = cs.d_counts;
+                at.maxHits = c->maxHits;
+                const int64_t total = int64_t(at.nTiles) * nF;
+                const int64_t perX = (total + 7) / 8;
+                const size_t lds = size_t(at.g.tileFloats) * 4;
+                dim3 grid((unsigned int)(perX * 8)), block(at.g.NW * 64);
+                int rcl = 0;
+#define TILED_LAUNCH(N, DD, TT)                                                                          \
+    {                                                                                                    \
+        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tileD<N, DD, TT>), lds)))        \
+            return rcl;                                                                                  \
+        hipLaunchKernelGGL((k_cascade_tileD<N, DD, TT>), grid, block, lds, c->stream, at);               \
+    }
+#define TILED_DEPTH(N)                                    \
+    switch (p.treeDepth)                                  \
+    {                                                     \
+        case 1: TILED_LAUNCH(N, 1, 4); break;             \
+        case 3: TILED_LAUNCH(N, 3, 2); break;             \
+        default: TILED_LAUNCH(N, 4, 1); break;            \
+    }
+                if (at.g.NW == 8)
+                {
+                    TILED_DEPTH(8)
+                }
+                else
+                {
+                    TILED_DEPTH(4)
+                }
+#undef TILED_DEPTH
+#undef TILED_LAUNCH
+                LAUNCHCHK(c, "k_cascade_tileD");
+                firstStage = sD + 1;
+            }
+        }
+        for (int sidx = firstStage; sidx < nStages; sidx++)
         {
             a.t0 = sidx == 0 ? 0 : bounds[sidx - 1];
             a.t1 = bounds[sidx];

@@ -5047,6 +5047,201 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
 
 // Copy one window's footprint (nChns*mW*mH floats, the cids[] index space) from the pyramid level into a wave's LDS
 // slab.  run = z * mW + cc  ->  win[run * mH + rr].
+// ------------------------------------------------------------------------
+// k_cascade_tileD: the first trees of a fixed-depth model OTHER than depth 2 (acfDetect1.cpp:201-228 dispatches depth
+// 1..8 through one body) on LDS tiles.  Same tiles, fill and window mapping as k_cascade_tile2 (float cells); stage A is
+// generalised to depth D: a tree's 2^D - 1 node features are all read (the walk would be D dependent LDS round trips), the
+// compares give wave masks, the 2^D leaf masks are ANDs along the paths (scalar unit), and every leaf is added under EXEC
+// to the lanes of its mask — the additions and their order are evaluate()'s (:123-138).  Nodes are in heap order (node k's
+// children 2k + 1 for `ftr < thr`, 2k + 2 otherwise, getChild :100-107); leaf j counts the paths left to right.
+// Survivors of trees [0, t1) go to the staged path's queue ({(level << 24) | window, h}: k_cascade_queue / k_cascade_tail
+// finish them from the float pyramid) or, when t1 is the model's last tree, to the hits.
+// Records: per batch of TB trees {off[TB][NN], thr[TB][NN], hs[TB][NL]} dwords, NN = 2^D - 1, NL = 2^D (host: buildTileSet).
+// ------------------------------------------------------------------------
+struct TileDArgs
+{
+    const float* pyr;
+    int64_t pyr_fs;
+    const CascLevel* levels;
+    const CascTile* tiles;
+    int32_t nTiles, nFrames, nChns, nBatches;
+    TileGeom g;
+    const uint32_t* nodesD;
+    float cascThr;
+    int32_t last;      // the stage ends the model: survivors are hits
+    uint2* qout;       // [frame][qcap]
+    int32_t* qoutCount;
+    int32_t qcap;
+    acf_hip_hit* hits;
+    int32_t* counts;
+    int32_t maxHits;
+};
+
+template <int D, int TB>
+__device__ __forceinline__ void tile_eval_d(const float* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
+{
+    constexpr int NN = (1 << D) - 1, NL = 1 << D, REC = TB * (2 * NN + NL);
+    cu32p_t p = (cu32p_t)(uintptr_t)tab;
+    uint32_t o[TB * NN];
+#pragma unroll
+    for (int i = 0; i < TB * NN; i++)
+    {
+        o[i] = p[i];
+    }
+    const unsigned long long execAll = __builtin_amdgcn_read_exec(); // (callers: wave-uniform control flow only)
+    float hMin = __builtin_inff();
+    for (int b = 0; b < nBatches; b++)
+    {
+        float f[TB * NN];
+#pragma unroll
+        for (int i = 0; i < TB * NN; i++)
+        {
+            f[i] = win[o[i]];
+        }
+        cu32p_t pb = p + REC * b;
+        uint32_t th[TB * NN], hv[TB * NL];
+#pragma unroll
+        for (int i = 0; i < TB * NN; i++)
+        {
+            th[i] = pb[TB * NN + i];
+        }
+#pragma unroll
+        for (int i = 0; i < TB * NL; i++)
+        {
+            hv[i] = pb[2 * TB * NN + i];
+        }
+#pragma unroll
+        for (int i = 0; i < TB * NN; i++)
+        {
+            ACF_PIN_V(f[i]);
+        }
+        cu32p_t pn = p + REC * min(b + 1, nBatches - 1);
+#pragma unroll
+        for (int i = 0; i < TB * NN; i++)
+        {
+            o[i] = pn[i];
+        }
+#pragma unroll
+        for (int t = 0; t < TB; t++)
+        {
+            unsigned long long m[NN];
+#pragma unroll
+            for (int k = 0; k < NN; k++)
+            {
+                m[k] = __builtin_amdgcn_ballot_w64(f[t * NN + k] < __uint_as_float(th[t * NN + k]));
+            }
+            float hOut = h;
+#pragma unroll
+            for (int j = 0; j < NL; j++)
+            {
+                // the path of leaf j: bit (D - 1 - l) of j is the branch taken at level l (0: ftr < thr)
+                unsigned long long mj = execAll;
+                int k = 0;
+#pragma unroll
+                for (int l = 0; l < D; l++)
+                {
+                    const int bit = (j >> (D - 1 - l)) & 1;
+                    mj &= bit ? ~m[k] : m[k];
+                    k = 2 * k + 1 + bit;
+                }
+                asm volatile("s_mov_b64 exec, %[m]\n\t"
+                             "v_add_f32 %[o], %[L], %[i]\n\t"
+                             "s_mov_b64 exec, %[ex]"
+                             : [o] "+v"(hOut)
+                             : [i] "v"(h), [m] "s"(mj), [L] "s"(hv[t * NL + j]), [ex] "s"(execAll));
+            }
+            h = hOut;
+            hMin = fminf(hMin, h); // (a window is rejected as soon as one prefix is <= cascThr)
+        }
+    }
+    alive = alive && (hMin > thrC);
+}
+
+template <int NW, int D, int TB>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tileD(TileDArgs a)
+{
+    extern __shared__ float lds[];
+    float* tileF = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t total = int64_t(a.nTiles) * a.nFrames;
+    const int64_t perX = (total + 7) >> 3;
+    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3); // one contiguous range of frame-major tiles per XCD
+    if (id >= total || (blockIdx.x >> 3) >= perX)
+    {
+        return;
+    }
+    const int frame = int(id / a.nTiles);
+    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+    const int lvl = T.level;
+    const CascLevel L = a.levels[lvl];
+    const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
+    const int gr0 = T.r0 * step, gc0 = T.c0 * step;
+    const int colPitch = L.hP;
+    const int area = colPitch * L.wP;
+    const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+    const int colsValid = min(colsT, L.wP - gc0);
+    // ---- fill (k_cascade_tile2's: 16-byte LDS-DMA chunks, everything in flight at once)
+    {
+        const uint32_t cps = uint32_t(rowsP) / 4u;
+        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
+        const int ccMax = colsValid - 1;
+        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
+        {
+            const uint32_t q = q0 + lane;
+            if (q < nChunks)
+            {
+                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                const uint32_t j = q - seg * cps;
+                const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                const int cc = int(seg - z * uint32_t(colsT));
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + 4u * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int r_l = lane % a.g.TR, c_l = (lane / a.g.TR) * NW + wv;
+    const int wr = T.r0 + r_l;
+    bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / a.g.TR) * a.g.TR;
+    float h = 0.f;
+    const float* win = tileF + (min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step;
+    tile_eval_d<D, TB>(win, a.nodesD, a.nBatches, a.cascThr, h, alive);
+    // survivors: one global atomic per wave
+    const unsigned long long mask = __ballot(alive);
+    if (!mask)
+    {
+        return;
+    }
+    int base = 0;
+    if (lane == 0)
+    {
+        base = atomicAdd((a.last ? a.counts : a.qoutCount) + frame, __popcll(mask));
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (alive)
+    {
+        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        const int n = (T.c0 + c_l) * L.nWinR + wr;
+        if (a.last)
+        {
+            if (idx < a.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = T.c0 + c_l;
+                hit.r = wr;
+                hit.score = h;
+                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
+            }
+        }
+        else if (idx < a.qcap)
+        {
+            a.qout[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
+        }
+    }
+}
+
 struct TailFill
 {
     int SUB, sub, rr, rrc, nRuns;

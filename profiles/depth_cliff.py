@@ -18,7 +18,8 @@ H, W, B = 1080, 1920, 48
 base = torch.from_numpy(np.stack([synth.make_frame(i + 1, H, W, "luv") for i in range(4)])).cuda()
 frames = torch.stack([torch.roll(base[i % 4], shifts=(37 * (i // 4), 53 * (i // 4)), dims=(1, 2)) for i in range(B)])
 out = {}
-for name, depth, tiles in (("depth1", 1, 1), ("depth2", 2, 1), ("depth2_staged", 2, 0), ("depth3", 3, 1)):
+for name, depth, tiles in (("depth1", 1, 1), ("depth1_staged", 1, 0), ("depth2", 2, 1), ("depth2_staged", 2, 0), ("depth3", 3, 1), ("depth3_staged", 3, 0),
+                          ("depth4", 4, 1), ("depth4_staged", 4, 0)):
     model = synth.make_model(seed=1, name="FACE80", treeDepth=depth)
     det = HipDetector(model, H, W, 3, max_batch=B, max_hits=8192)
     det.set_option("cascade_tiles", tiles)

@@ -186,10 +186,12 @@ def test_rgb2luv(dev, oracle, h, w):
 @pytest.mark.parametrize("nTrees", [128, 300, 20, 40, 70])
 def test_acf_detect1(dev, oracle, depth, nTrees, tiles):
     """The cascade on a random channel buffer: hits identical in number, order, position and score bits.
-    tiles=1: the LDS-tiled path (depth 2; its stages end at 16/32/64/128 trees, then the wave-per-window tail);
-    tiles=0 and the other depths: the global-memory staged path (first / queue / LDS tail kernels)."""
-    if tiles and depth != 2:
-        pytest.skip("tiled path is depth-2 only")
+    tiles=1: the LDS-tiled paths — depth 2: k_cascade_tile2 (its stages end at 16/32/64/128 trees, then the wave-per-window
+    tail); depths 1 and 3: k_cascade_tileD for trees [0, 32) (or the whole model when it has <= 32 trees: 20 trees at depth 3 /
+    20 at depth 1 are a multiple of its batch, so the survivors are hits), the staged queue / tail kernels behind it;
+    tiles=0 and depth 0: the global-memory staged path (first / queue / LDS tail kernels)."""
+    if tiles and depth == 0:
+        pytest.skip("variable-depth trees (child walk): staged path only")
     nC, wP, hP = 10, 60, 44
     chns = rnd(99 + depth, (nC, wP, hP), 0.0, 0.6)
     kw = dict(treeDepth=depth)
@@ -250,7 +252,7 @@ def test_acf_detect1_deep_trees(dev, oracle, depth, nTrees):
     _detect1_case(dev, oracle, depth, nTrees, 1, -1.0 if nTrees < 300 else -4.0, (-0.25, 0.2))
 
 
-@pytest.mark.parametrize("depth,tiles", [(2, 1), (2, 0), (5, 1), (0, 1)])
+@pytest.mark.parametrize("depth,tiles", [(2, 1), (2, 0), (5, 1), (0, 1), (3, 1), (1, 1), (4, 1)])
 def test_acf_detect1_4096_trees(dev, oracle, depth, tiles):
     """4096 trees (the largest detectors of the toolbox): the tile kernel's stage E and k_tail_scan then walk 3968 tail trees
     (62 batches of 64: more than four per wave), the staged path its long last stage.  Zero-mean leaves: the score is a
