@@ -80,6 +80,9 @@ struct CascState
     int nTilesD = 0, tbD = 0, t1D = 0;
     TileGeom geomD{};
     uint32_t* d_nodesD = nullptr;
+    // fixed depths 1..4, last stage [128, nTrees) of the staged path as leaf codes + ordered scan (k_tail_codesD / k_tail_scanD)
+    uint8_t* d_codesD = nullptr;
+    int codeCapD = 0, codePitchD = 0;
     // threshold-rank cells (host_plan.h): the tile kernel's second form, reading a 16-bit pyramid
     bool useRank = false;
     TileGeom geomR{};
@@ -1620,6 +1623,36 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     cs.useTiles = false;
     cs.useRank = false;
     cs.useTileD = false;
+    cs.codeCapD = 0;
+    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.nTrees > 128 && !getenv("ACF_HIP_NO_TAIL_CODES"))
+    {
+        // the staged path's last stage [128, nTrees) as leaf codes + ordered scan: the first codeCapD queue entries of a frame
+        // (sized like the depth-2 path's), when the scan's leaf table fits a workgroup's LDS
+        const int nT = p.nTrees - 128, NL = 1 << p.treeDepth;
+        if (int64_t((nT + 15) / 16 * 16) * NL * 4 <= 150 * 1024)
+        {
+            cs.codePitchD = (nT + 63) / 64 * 64;
+            int64_t nWinTotal = 0;
+            for (const auto& l : lv)
+            {
+                nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
+            }
+            int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
+            cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitchD), 256));
+            cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
+            void* codes = nullptr;
+            if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cap) * size_t(cs.codePitchD)) == hipSuccess)
+            {
+                c->allocs.push_back(codes);
+                cs.d_codesD = static_cast<uint8_t*>(codes);
+                cs.codeCapD = int(cap);
+            }
+            else
+            {
+                (void)hipGetLastError();
+            }
+        }
+    }
     if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.stride % p.shrink == 0 && p.stride >= p.shrink)
     {
         TileSet tsD;
@@ -3967,6 +4000,36 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
             {
                 // one wave per surviving window; enough waves per frame to fill the chip
                 dim3 grid(std::max(1, 8192 / nF) * nF);
+                if (mode == 1 && c->cs.codeCapD > 0 && a.t0 == 128)
+                {
+                    // leaf codes of the first codeCapD entries, then their ordered sums with lanes = windows; k_cascade_tail
+                    // (below) takes the entries beyond and leaves at once when there are none
+                    a.codes = c->cs.d_codesD;
+                    a.codeCap = c->cs.codeCapD;
+                    a.codePitch = c->cs.codePitchD;
+                    hipLaunchKernelGGL(k_tail_codesD, grid, dim3(64), winBytes, c->stream, a);
+                    LAUNCHCHK(c, "k_tail_codesD");
+                    const int nT = a.t1 - a.t0, NL = 1 << p.treeDepth;
+                    const size_t ldsS = size_t((nT + 15) / 16 * 16) * NL * sizeof(float);
+                    dim3 gridS(nF * ((a.codeCap + 255) / 256));
+                    int rcl = 0;
+#define TSD_LAUNCH(DD)                                                                              \
+    {                                                                                               \
+        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_tail_scanD<DD>), ldsS)))            \
+            return rcl;                                                                             \
+        hipLaunchKernelGGL(k_tail_scanD<DD>, gridS, dim3(256), ldsS, c->stream, a);                 \
+    }
+                    switch (p.treeDepth)
+                    {
+                        case 1: TSD_LAUNCH(1); break;
+                        case 3: TSD_LAUNCH(3); break;
+                        case 4: TSD_LAUNCH(4); break;
+                        default: TSD_LAUNCH(2); break;
+                    }
+#undef TSD_LAUNCH
+                    LAUNCHCHK(c, "k_tail_scanD");
+                    a.qskip = a.codeCap;
+                }
                 if (mode == 2)
                 {
                     hipLaunchKernelGGL(k_cascade_tail<2>, grid, dim3(64), winBytes, c->stream, a);

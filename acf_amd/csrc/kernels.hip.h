@@ -4000,6 +4000,10 @@ struct CascArgs
     acf_hip_hit* hits; // [frame][maxHits]
     int32_t* counts;   // [frame]
     int32_t maxHits;
+    // last stage of a fixed-depth model as leaf codes + ordered scan (k_tail_codesD / k_tail_scanD): the first codeCap
+    // queue entries of a frame; k_cascade_tail then starts at entry qskip
+    uint8_t* codes;    // [frame][codeCap][codePitch]: 4 * (leaf index) of tree t0 + j of entry i
+    int32_t codeCap, codePitch, qskip;
 };
 
 #define CASC_CG 4
@@ -4251,7 +4255,7 @@ __global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
     const int lane = threadIdx.x;
     const int cellsW = a.mW * a.mH, nFeat = a.nChns * cellsW;
     const float thrC = a.cascThr;
-    for (int i = bq; i < cnt; i += nbq)
+    for (int i = bq + a.qskip; i < cnt; i += nbq)
     {
         const uint2 e = a.qin[int64_t(frame) * a.qcap + i];
         const int lvl = int(e.x >> 24);
@@ -4326,6 +4330,173 @@ __global__ void __launch_bounds__(64) k_cascade_tail(CascArgs a)
                 hit.score = h;
                 a.hits[int64_t(frame) * a.maxHits + idx] = hit;
             }
+        }
+    }
+}
+
+// The last stage of a fixed-depth model without the serial part of k_cascade_tail.  Which leaf a tree selects does not
+// depend on the running score — only the early exit does (acfDetect1.cpp:123-138) — so the stage is (i) one byte per
+// (window, tree), 4 * (leaf index), and (ii) an ordered scan with lanes = windows (k_tail_scan's, for 2^D leaves per tree).
+// (i): a wave per queue entry, its footprint in LDS (feature ids address it directly), lanes = trees walking their D levels
+// (getChild, :100-107).  k_cascade_tail adds the 64 leaves of a batch one lane at a time (1920 dependent steps per window
+// and wave); here the additions of 64 WINDOWS run side by side in one wave of (ii).
+__global__ void __launch_bounds__(64) k_tail_codesD(CascArgs a)
+{
+    extern __shared__ float win[]; // nChns * mW * mH
+    const int frame = blockIdx.x % a.nFrames;
+    const int bq = blockIdx.x / a.nFrames, nbq = gridDim.x / a.nFrames;
+    const int cnt = min(min(a.qinCount[frame], a.qcap), a.codeCap);
+    const int lane = threadIdx.x;
+    const int cellsW = a.mW * a.mH, nFeat = a.nChns * cellsW;
+    const int D = a.treeDepth, NN = (1 << D) - 1;
+    for (int i = bq; i < cnt; i += nbq)
+    {
+        const uint2 e = a.qin[int64_t(frame) * a.qcap + i];
+        const int lvl = int(e.x >> 24);
+        const int n = int(e.x & 0xffffffu);
+        const CascLevel L = a.levels[lvl];
+        const int c = n / L.nWinR;
+        const int r = n - c * L.nWinR;
+        const float* chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + (r * a.stride / a.shrink) + int64_t(c * a.stride / a.shrink) * L.hP;
+        const int area = L.hP * L.wP;
+        __syncthreads();
+        for (int f = lane; f < nFeat; f += 64)
+        {
+            const int z = f / cellsW, rem = f - z * cellsW;
+            const int cc = rem / a.mH, rr = rem - cc * a.mH;
+            win[f] = chn[z * area + cc * L.hP + rr];
+        }
+        __syncthreads();
+        uint8_t* cp = a.codes + (int64_t(frame) * a.codeCap + i) * a.codePitch;
+        // four batches of 64 trees side by side: a walk is D dependent steps of (node record from L2, feature from LDS), and
+        // only independent walks hide each other's latency
+        for (int tb = a.t0; tb < a.t1; tb += 256)
+        {
+            uint32_t off4[4], k4[4], k04[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                off4[u] = uint32_t(min(tb + 64 * u + lane, a.t1 - 1)) * uint32_t(a.nTreeNodes);
+                k4[u] = off4[u];
+                k04[u] = 0;
+            }
+            for (int q = 0; q < D; q++)
+            {
+                uint32_t fid[4];
+                float thr[4], ftr[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    fid[u] = a.fids[k4[u]];
+                    thr[u] = a.thrs[k4[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    ftr[u] = win[fid[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const uint32_t k = ((ftr[u] < thr[u]) ? 1u : 2u) + k04[u] * 2u;
+                    k04[u] = k;
+                    k4[u] = k + off4[u];
+                }
+            }
+            // (lanes past the last tree write code 0: k_tail_scanD adds whole groups of 16 trees, and the rows of the trees
+            // that do not exist hold -0.0f — `x + -0.0f` is x for every x)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int j = tb - a.t0 + 64 * u + lane;
+                if (j < a.codePitch)
+                {
+                    cp[j] = tb + 64 * u + lane < a.t1 ? uint8_t(4u * (k04[u] - uint32_t(NN))) : uint8_t(0);
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_tail_scanD(CascArgs a)
+{
+    extern __shared__ float lds[]; // [nT][2^D] leaf values of trees [t0, t1)
+    constexpr int NL = 1 << D, NN = NL - 1, LB = 4 * NL;
+    const int frame = blockIdx.x % a.nFrames, chunk = blockIdx.x / a.nFrames;
+    const int cntC = min(min(a.qinCount[frame], a.qcap), a.codeCap);
+    if (chunk * 256 >= cntC)
+    {
+        return;
+    }
+    const int nT = a.t1 - a.t0, nT16 = (nT + 15) & ~15;
+    for (int x = threadIdx.x; x < nT16 * NL; x += 256)
+    {
+        const int t = x / NL, j = x - t * NL;
+        lds[x] = t < nT ? a.hs[int64_t(a.t0 + t) * a.nTreeNodes + NN + j] : -0.0f; // (padding: the identity of float addition)
+    }
+    __syncthreads();
+    const int i = chunk * 256 + int(threadIdx.x);
+    bool alive = i < cntC;
+    const int ic = min(i, cntC - 1);
+    const uint2 e = a.qin[int64_t(frame) * a.qcap + ic];
+    const uint8_t* __restrict__ cp = a.codes + (int64_t(frame) * a.codeCap + ic) * a.codePitch;
+    const float thrC = a.cascThr;
+    float h = __uint_as_float(e.y);
+    float m = h; // running minimum of the prefix scores
+    const char* leafB = reinterpret_cast<const char*>(lds);
+    // 16 trees (one 16-byte code load) per step, requested two steps ahead (a lane's codes are its own cache lines)
+    uint4 w0 = *reinterpret_cast<const uint4*>(cp), w1 = *reinterpret_cast<const uint4*>(cp + min(16, a.codePitch - 16)), w2;
+    bool done = false;
+    int tb = 0;
+#define TSD_STEP(W, T0)                                                                       \
+    {                                                                                         \
+        const char* lb = leafB + (T0) * LB;                                                   \
+        _Pragma("unroll") for (int q = 0; q < 16; q++)                                        \
+        {                                                                                     \
+            const uint32_t cw = (q >> 2) == 0 ? W.x : ((q >> 2) == 1 ? W.y : ((q >> 2) == 2 ? W.z : W.w)); \
+            const uint32_t off = (cw >> (8 * (q & 3))) & 0xffu;                               \
+            h = h + *reinterpret_cast<const float*>(lb + q * LB + off);                       \
+            asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(h));                                   \
+        }                                                                                     \
+    }
+    while (tb < nT && !done)
+    {
+        w2 = *reinterpret_cast<const uint4*>(cp + min(tb + 32, a.codePitch - 16));
+        TSD_STEP(w0, tb);
+        tb += 16;
+        w0 = w1;
+        w1 = w2;
+        if ((tb & 63) == 0)
+        {
+            alive = alive && (m > thrC) && (h > thrC);
+            done = __ballot(alive) == 0ull; // every lane of the wave is rejected: nothing left to add
+        }
+    }
+#undef TSD_STEP
+    alive = alive && (m > thrC) && (h > thrC);
+    const unsigned long long mask = __ballot(alive);
+    if (mask)
+    {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0)
+        {
+            base = atomicAdd(a.counts + frame, __popcll(mask));
+        }
+        base = __shfl(base, 0);
+        const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (alive && idx < a.maxHits)
+        {
+            const int lvl = int(e.x >> 24);
+            const int n = int(e.x & 0xffffffu);
+            const int nWinR = a.levels[lvl].nWinR;
+            acf_hip_hit hit;
+            hit.scale = lvl;
+            hit.c = n / nWinR;
+            hit.r = n - hit.c * nWinR;
+            hit.score = h;
+            a.hits[int64_t(frame) * a.maxHits + idx] = hit;
         }
     }
 }
