@@ -216,6 +216,12 @@ struct acf_hip_ctx
     int levelWarm = getenv("ACF_HIP_LEVEL_WARM") ? atoi(getenv("ACF_HIP_LEVEL_WARM")) : 32; // option level_warm
     // option count_repairs: planes the repair launches had to recompute (synchronises after every verify: measurements only)
     int countRepairs = 0;
+    // option "graph": acf_hip_run replays a HIP graph captured from its own launches (same frames pointer, same batch size):
+    // one host call instead of ~45 launches per frame — what a single frame's latency is made of when the kernels take 20 us
+    int useGraph = getenv("ACF_HIP_GRAPH") ? atoi(getenv("ACF_HIP_GRAPH")) : 0;
+    hipGraphExec_t graphExec = nullptr;
+    const float* graphFrames = nullptr;
+    int graphN = 0, plainRuns = 0, graphBroken = 0;
     int64_t repairs[4] = { 0, 0, 0, 0 }; // {smoothing planes checked, redone, level planes checked, redone}
     int segCap = 0;               // segments the state buffers hold per plane
     int keepPyramid = 1;          // option "keep_pyramid": 0 = a run()/detect-only caller does not need the float pyramid (levels leave as rank cells only)
@@ -948,8 +954,24 @@ int acf_hip_device_count(int* count)
     return *count > 0 ? ACF_HIP_OK : ACF_HIP_E_NODEVICE;
 }
 
+static void dropGraph(acf_hip_ctx* c)
+{
+    if (c && c->graphExec)
+    {
+        (void)hipGraphExecDestroy(c->graphExec);
+        c->graphExec = nullptr;
+    }
+    if (c)
+    {
+        c->graphFrames = nullptr;
+        c->graphN = 0;
+        c->plainRuns = 0; // the next run is a plain one again (it may allocate: NMS buffers, side streams)
+    }
+}
+
 int acf_hip_destroy(acf_hip_ctx* c)
 {
+    dropGraph(c);
     if (c)
     {
         for (acf_hip_ctx* k : c->kids)
@@ -1005,6 +1027,13 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!c || !key)
     {
         return ACF_HIP_E_INVALID;
+    }
+    dropGraph(c); // (whatever changes, a captured graph no longer describes the next run)
+    if (!strcmp(key, "graph"))
+    {
+        c->useGraph = value;
+        c->graphBroken = 0;
+        return ACF_HIP_OK;
     }
     if (!strcmp(key, "streams"))
     {
@@ -1181,6 +1210,7 @@ int acf_hip_plan_levels(const acf_hip_params* p, int h, int w, int d, acf_hip_le
 
 int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
 {
+    dropGraph(c);
     if (c)
     {
         for (acf_hip_ctx* k : c->kids)
@@ -1918,6 +1948,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     {
         return ACF_HIP_E_INVALID;
     }
+    dropGraph(c);
     if (!c->hasModel)
     {
         return fail(c, ACF_HIP_E_NOMODEL, "plan: set_model first");
@@ -4182,12 +4213,68 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
         c->pyramidValid = c->detectValid = true;
         return rc ? rc : kidsJoin(c);
     }
+    // option "graph": the launches of this call — same frames pointer, same batch size, nothing in the path that reads back or
+    // records events of its own — as one captured graph.  The first calls run plainly (they may allocate); a capture that the
+    // runtime refuses switches the option off for this context and the call runs plainly.
+    const bool graphable = c && c->useGraph && !c->graphBroken && c->hasPlan && !c->profile && !c->taps && !c->countRepairs && !c->autoLambdas &&
+        c->cascTurns == 0 && frames && nF > 0 && nF <= c->maxBatch;
+    if (graphable && c->graphExec && c->graphFrames == frames && c->graphN == nF)
+    {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipGraphLaunch(c->graphExec, c->stream));
+        c->lastBatch = nF;
+        c->pyramidValid = c->detectValid = true;
+        return ACF_HIP_OK;
+    }
+    if (graphable && c->plainRuns >= 1)
+    {
+        HIPCHK(c, hipSetDevice(c->device));
+        dropGraph(c);
+        c->plainRuns = 1;
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        int rcc = ACF_HIP_OK;
+        if (ok)
+        {
+            rcc = acf_hip_pyramid(c, frames, nF);
+            if (!rcc)
+            {
+                rcc = acf_hip_detect(c);
+            }
+            ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && g != nullptr && !rcc;
+        }
+        if (ok)
+        {
+            ok = hipGraphInstantiate(&c->graphExec, g, nullptr, nullptr, 0) == hipSuccess && c->graphExec != nullptr;
+        }
+        if (g)
+        {
+            (void)hipGraphDestroy(g);
+        }
+        if (ok)
+        {
+            c->graphFrames = frames;
+            c->graphN = nF;
+            HIPCHK(c, hipGraphLaunch(c->graphExec, c->stream));
+            c->lastBatch = nF;
+            c->pyramidValid = c->detectValid = true;
+            return ACF_HIP_OK;
+        }
+        (void)hipGetLastError();
+        c->graphExec = nullptr;
+        c->graphBroken = 1; // (fall through: the plain path below does the work)
+    }
     int rc = acf_hip_pyramid(c, frames, nF);
     if (rc)
     {
         return rc;
     }
-    return acf_hip_detect(c);
+    rc = acf_hip_detect(c);
+    if (!rc && c)
+    {
+        c->plainRuns++;
+    }
+    return rc;
 }
 
 int acf_hip_run_host(acf_hip_ctx* c, const float* frames_host, int nF)
@@ -4573,6 +4660,7 @@ int acf_hip_set_nms(acf_hip_ctx* c, const acf_hip_nms_params* q)
     {
         return ACF_HIP_E_INVALID;
     }
+    dropGraph(c);
     if (q)
     {
         const int rc = checkNmsParams(c, q);

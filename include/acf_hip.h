@@ -207,6 +207,11 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * chain — the smoothed plane then makes no round trip through memory — for planes of
  * >= 2^20 pixels in batches of >= 16 frames, where that pays; 2: wherever that kernel
  * applies; 0: always as its own kernel),
+ * "graph" (0, default; 1: acf_hip_run captures its own launches into a HIP graph the
+ * second time it is called with the same frames pointer and batch size, and replays it
+ * from then on — one host call instead of ~45 launches, for callers that feed one
+ * frame at a time from a fixed buffer; not with "profile", taps, image-specific
+ * lambdas or "cascade_turns"; any set_* / plan call drops the graph),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);

@@ -323,3 +323,30 @@ def test_ldcf_post_stage_bit_exact(oracle, case):
         total += len(want)
     assert total > 0
     det.close()
+
+
+@pytest.mark.parametrize("scale_streams", [1, 0])
+def test_graph_replay_matches_plain_launches(oracle, scale_streams):
+    """Option graph: acf_hip_run captures its own launches (second call with the same input pointer and batch size) and replays the
+    HIP graph afterwards.  Every call — plain, capturing, replaying, re-capturing for another input — returns the oracle's result."""
+    import torch
+    from acf_amd import capi
+    from acf_amd.detector import HipDetector
+    H, W = 480, 640
+    model = synth.make_model(seed=3, name="FACE80", nTrees=256)
+    frames = np.stack([synth.make_frame(301 + i, H, W, "luv") for i in range(2)])
+    dev = torch.from_numpy(frames).cuda()
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 14)
+    det.set_option("scale_streams", scale_streams)
+    det.set_option("graph", 1)
+    plan = oracle.Plan(model, H, W, 3)
+    want = []
+    for f in range(2):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want.append(oracle.detect(plan, pyr))
+    for k, f in enumerate([0, 0, 0, 0, 1, 1, 0, 1]):
+        det.run(dev[f:f + 1], 1)
+        got, gh = det.detections(0)
+        assert got.tobytes() == want[f][0].tobytes() and gh.tobytes() == want[f][1].tobytes(), (k, f)
+        assert np.array_equal(bits(det.read_pyramid(0)), bits(oracle.chns_pyramid(plan, frames[f])[0])), (k, f)
+    det.close()
