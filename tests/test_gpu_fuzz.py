@@ -1,4 +1,4 @@
-"""A fixed-seed slice of profiles/ubench/fuzz_parity.py: random frame sizes, model shapes (depth 1-4, trees, scales per octave,
+"""A fixed-seed slice of tests/fuzz_parity.py: random frame sizes, model shapes (depth 1-4, trees, scales per octave,
 pads, gradient plane, full orientation) and option sets (fused_grad, segments, streams, rank cells, graph, tiles) against the
 oracle — pyramid bits, hits and boxes.  (Five seeds x 60 cases ran clean when this was added; the slice keeps that alive.)"""
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [7, 23])
 def test_random_cases_match_the_oracle(seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "ubench", "fuzz_parity.py"), str(seed), "20"], cwd=ROOT,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), str(seed), "20"], cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1]
