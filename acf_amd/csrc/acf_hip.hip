@@ -3029,21 +3029,26 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 }
                 sa.plane0 = 0;
                 sa.nPlanes = d;
-                // column segments: as many as give the launch ~6 waves per SIMD (a plane is a chain of column steps with
-                // nt / 64 waves), each at least 4 warm-ups long; one segment = the plain recursion
+                // column segments: as many as give a launch ~6 waves per SIMD (a plane is a chain of column steps with
+                // nt / 64 waves), each at least 4 warm-ups long; one segment = the plain recursion.  `planesOf`: planes in the launch
                 const int warm = std::max(16, c->smoothWarm);
-                int nSeg = c->smoothSegments;
-                if (nSeg == 0)
-                {
-                    const int64_t waves = int64_t(d) * nF * (nt / 64);
-                    nSeg = int(std::min<int64_t>((6 * 1024 + waves - 1) / waves, rs.w / (4 * warm)));
-                }
-                nSeg = std::max(1, std::min(nSeg, std::min(c->segCap, rs.w / 16)));
-                int segW = cdiv(cdiv(rs.w, nSeg), 16) * 16;
-                nSeg = cdiv(rs.w, segW);
+                auto segmentsFor = [&](int planesOf, int& segW_) {
+                    int n = c->smoothSegments;
+                    if (n == 0)
+                    {
+                        const int64_t waves = int64_t(std::max(planesOf, 1)) * nF * (nt / 64);
+                        n = int(std::min<int64_t>((6 * 1024 + waves - 1) / waves, rs.w / (4 * warm)));
+                    }
+                    n = std::max(1, std::min(n, std::min(c->segCap, rs.w / 16)));
+                    segW_ = cdiv(cdiv(rs.w, n), 16) * 16;
+                    return cdiv(rs.w, segW_);
+                };
+                int segW = 0;
+                int nSeg = segmentsFor(d, segW);
                 sa.segW = segW;
                 sa.warm = warm;
                 sa.nSeg = nSeg;
+                sa.segStride = nSeg;
                 sa.specState = c->d_specState;
                 sa.trueState = c->d_trueState;
                 sa.redo = nullptr;
@@ -3087,6 +3092,24 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                         fullMask &= ~(1u << p.colorChn);
                     }
                 }
+                // the two launches cut their planes on their own: the gradient plane's launch has a third of the chains (more
+                // segments), the other planes' launch two thirds; ACF_HIP_GRAD_SEGMENTS = n fixes the former's (A/B)
+                int nSegG = nSeg, segWG = segW;
+                if (wantGrad && d > 1)
+                {
+                    static const int gradSegEnv = getenv("ACF_HIP_GRAD_SEGMENTS") ? atoi(getenv("ACF_HIP_GRAD_SEGMENTS")) : 0;
+                    nSeg = segmentsFor(d - 1, segW);
+                    nSegG = segmentsFor(1, segWG);
+                    if (gradSegEnv > 0)
+                    {
+                        nSegG = std::max(1, std::min(gradSegEnv, std::min(c->segCap, rs.w / 16)));
+                        segWG = cdiv(cdiv(rs.w, nSegG), 16) * 16;
+                        nSegG = cdiv(rs.w, segWG);
+                    }
+                    sa.segW = segW;
+                    sa.nSeg = nSeg;
+                    sa.segStride = std::max(nSeg, nSegG);
+                }
                 const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float);
                 if (wantGrad)
                 {
@@ -3104,6 +3127,15 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                         SmoothVecArgs sg = sa;
                         sg.plane0 = p.colorChn;
                         sg.skipZ = -1;
+                        if (sa.nSeg > 1 || nSegG > 1) // (not the repair launch: that one is one chain per plane)
+                        {
+                            if (!sa.redo)
+                            {
+                                sg.segW = segWG;
+                                sg.nSeg = nSegG;
+                                grid.y = unsigned(nSegG);
+                            }
+                        }
                         if (halfNext)
                         {
                             hipLaunchKernelGGL((k_smooth_grad<true>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
@@ -3113,6 +3145,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                             hipLaunchKernelGGL((k_smooth_grad<false>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
                         }
                         grid.x -= 1;
+                        grid.y = unsigned(sa.nSeg);
                         if (grid.x == 0)
                         {
                             return;
@@ -3127,17 +3160,18 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                         hipLaunchKernelGGL((k_smooth_vec<false>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
                     }
                 };
-                if (nSeg > 1)
+                const int nSegMax = std::max(nSeg, wantGrad ? nSegG : nSeg);
+                if (nSegMax > 1)
                 {
                     HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * size_t(nF) * d, c->stream));
                 }
                 launchSv(dim3(d, nSeg, nF));
                 LAUNCHCHK(c, "k_smooth_vec");
-                if (nSeg > 1)
+                if (nSegMax > 1)
                 {
                     // the segments' hand-overs, bit for bit; planes with a difference are recomputed as one chain
-                    hipLaunchKernelGGL(k_smooth_verify, dim3(nSeg - 1, d, nF), dim3(256), 0, c->stream, (const float*)c->d_specState, (const float*)c->d_trueState,
-                        rs.h, nSeg, d, c->d_redo, c->smoothForceRedo);
+                    hipLaunchKernelGGL(k_smooth_verify, dim3(nSegMax - 1, d, nF), dim3(256), 0, c->stream, (const float*)c->d_specState, (const float*)c->d_trueState,
+                        rs.h, sa.segStride, d, c->d_redo, c->smoothForceRedo, nSeg, wantGrad ? p.colorChn : -1, nSegG);
                     LAUNCHCHK(c, "k_smooth_verify");
                     if (c->countRepairs)
                     {

@@ -485,6 +485,7 @@ struct SmoothVecArgs
     // Column segments (blockIdx.y = segment): see "speculative segments" below.  segW = columns per segment (a multiple of
     // 16; >= w: one segment, the plain recursion), warm = warm-up columns before a segment's first (a multiple of 16).
     int32_t segW, warm, nSeg, nPlanes;
+    int32_t segStride;   // segments per plane in the state buffers (>= nSeg: the two launches of a scale may cut their planes differently)
     float* specState; // [frame][plane][segment][h]: a segment's state after its warm-up = its guess of column x0 - 1
     float* trueState; // [frame][plane][segment][h]: the previous segment's output column x0 - 1
     const int32_t* redo; // repair launch (nSeg == 1): [frame][plane] != 0 -> this plane is recomputed as one segment; NULL: every plane
@@ -752,7 +753,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     SV_COL(EMIT, I0, 0, A_[0], A_[1]) SV_COL(EMIT, I0, 1, A_[1], A_[2]) SV_COL(EMIT, I0, 2, A_[2], A_[3]) SV_COL(EMIT, I0, 3, A_[3], A_[4]) \
     SV_COL(EMIT, I0, 4, A_[4], A_[5]) SV_COL(EMIT, I0, 5, A_[5], A_[6]) SV_COL(EMIT, I0, 6, A_[6], A_[7]) SV_COL(EMIT, I0, 7, A_[7], B_[0]) \
     SV_REFRESH(I0)
-    const int64_t stateOff = ((f * a.nPlanes + z) * a.nSeg) * int64_t(h) + 4 * qc;
+    const int64_t stateOff = ((f * a.nPlanes + z) * a.segStride) * int64_t(h) + 4 * qc;
     SV_LOAD(c0, xs);
     int i = xs;
     // warm-up of a later segment (x0 - xs is a multiple of 16): same arithmetic, nothing leaves
@@ -891,13 +892,18 @@ __global__ void __launch_bounds__(512) k_smooth_grad(SmoothVecArgs a, uint32_t f
 
 // k_smooth_vec's segments: spec[f][z][s] (segment s's state after its warm-up) against tru[f][z][s] (segment s - 1's last
 // output column), s = 1 .. nSeg - 1, bit for bit; any difference marks the plane for the repair launch.
-__global__ void __launch_bounds__(256) k_smooth_verify(const float* __restrict__ spec, const float* __restrict__ tru, int h, int nSeg, int nPlanes,
-    int32_t* __restrict__ redo, int force)
+// (segStride: segments per plane in the buffers; plane zG — the gradient plane, k_smooth_grad's — has nSegG segments, the others nSeg)
+__global__ void __launch_bounds__(256) k_smooth_verify(const float* __restrict__ spec, const float* __restrict__ tru, int h, int segStride, int nPlanes,
+    int32_t* __restrict__ redo, int force, int nSeg, int zG, int nSegG)
 {
     const int64_t plane = int64_t(blockIdx.z) * nPlanes + blockIdx.y;
     const int s = 1 + blockIdx.x;
-    const uint32_t* a = reinterpret_cast<const uint32_t*>(spec) + (plane * nSeg + s) * int64_t(h);
-    const uint32_t* b = reinterpret_cast<const uint32_t*>(tru) + (plane * nSeg + s) * int64_t(h);
+    if (s >= (int(blockIdx.y) == zG ? nSegG : nSeg))
+    {
+        return;
+    }
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(spec) + (plane * segStride + s) * int64_t(h);
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(tru) + (plane * segStride + s) * int64_t(h);
     bool bad = force != 0;
     for (int y = threadIdx.x; y < h; y += 256)
     {
