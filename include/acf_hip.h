@@ -211,7 +211,8 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * second time it is called with the same frames pointer and batch size, and replays it
  * from then on — one host call instead of ~45 launches, for callers that feed one
  * frame at a time from a fixed buffer; not with "profile", taps, image-specific
- * lambdas or "cascade_turns"; any set_* / plan call drops the graph),
+ * lambdas, "cascade_turns" or sub-batch contexts ("streams" > 1), where the call runs
+ * plainly; any set_* / plan call drops the graph),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results). */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
