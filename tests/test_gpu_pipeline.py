@@ -350,3 +350,25 @@ def test_graph_replay_matches_plain_launches(oracle, scale_streams):
         assert got.tobytes() == want[f][0].tobytes() and gh.tobytes() == want[f][1].tobytes(), (k, f)
         assert np.array_equal(bits(det.read_pyramid(0)), bits(oracle.chns_pyramid(plan, frames[f])[0])), (k, f)
     det.close()
+
+
+@pytest.mark.parametrize("nTrees", [129, 144, 145, 193])
+@pytest.mark.parametrize("depth", [1, 3, 4])
+def test_fixed_depth_tail_codes_tree_counts(oracle, depth, nTrees):
+    """Depths 1, 3, 4: trees [0, 32) on LDS tiles (k_cascade_tileD), [32, 128) on the staged queue, the rest as leaf codes + ordered
+    scan (k_tail_codesD / k_tail_scanD).  Tree counts just past 128: one tail tree, exactly one / one more than one group of 16
+    (the scan adds whole groups, padded with rows of -0.0f), one more than a 64-tree code batch."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 200, 264
+    model = synth.make_model(seed=5 + depth, name="TINY", nTrees=nTrees, treeDepth=depth, cascThr=-2.0)
+    frame = synth.make_frame(77, H, W, "luv")
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 15)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    want, wh = oracle.detect(plan, pyr)
+    got, gh = det.detections(0)
+    assert len(want) > 0
+    assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes()
+    det.close()
