@@ -219,9 +219,19 @@ struct acf_hip_ctx
     // option "graph": acf_hip_run replays a HIP graph captured from its own launches (same frames pointer, same batch size):
     // one host call instead of ~45 launches per frame — what a single frame's latency is made of when the kernels take 20 us
     int useGraph = getenv("ACF_HIP_GRAPH") ? atoi(getenv("ACF_HIP_GRAPH")) : 0;
-    hipGraphExec_t graphExec = nullptr;
-    const float* graphFrames = nullptr;
-    int graphN = 0, plainRuns = 0, graphBroken = 0;
+    // option "graph": captured runs keyed by (input pointer, batch size); a caller that alternates between a few input buffers
+    // (double / triple buffering) replays one graph per buffer instead of re-capturing on every call
+    struct GraphSlot
+    {
+        hipGraphExec_t exec = nullptr;
+        const float* frames = nullptr;
+        int n = 0;
+        bool ranksValid = false, floatPyramid = true; // what the captured host code left behind
+    };
+    static constexpr int GRAPH_SLOTS = 4;
+    GraphSlot graphs[GRAPH_SLOTS];
+    int graphNext = 0; // slot the next capture replaces (round robin)
+    int plainRuns = 0, graphBroken = 0;
     int64_t repairs[4] = { 0, 0, 0, 0 }; // {smoothing planes checked, redone, level planes checked, redone}
     int segCap = 0;               // segments the state buffers hold per plane
     int keepPyramid = 1;          // option "keep_pyramid": 0 = a run()/detect-only caller does not need the float pyramid (levels leave as rank cells only)
@@ -956,17 +966,28 @@ int acf_hip_device_count(int* count)
 
 static void dropGraph(acf_hip_ctx* c)
 {
-    if (c && c->graphExec)
+    if (!c)
     {
-        (void)hipGraphExecDestroy(c->graphExec);
-        c->graphExec = nullptr;
+        return;
     }
-    if (c)
+    bool synced = false;
+    for (auto& g : c->graphs)
     {
-        c->graphFrames = nullptr;
-        c->graphN = 0;
-        c->plainRuns = 0; // the next run is a plain one again (it may allocate: NMS buffers, side streams)
+        if (g.exec)
+        {
+            if (!synced)
+            {
+                // (the last replay may still be running: an executable graph is not released under it)
+                (void)hipSetDevice(c->device);
+                (void)hipStreamSynchronize(c->stream);
+                synced = true;
+            }
+            (void)hipGraphExecDestroy(g.exec);
+        }
+        g = acf_hip_ctx::GraphSlot();
     }
+    c->graphNext = 0;
+    c->plainRuns = 0; // the next run is a plain one again (it may allocate: NMS buffers, side streams)
 }
 
 int acf_hip_destroy(acf_hip_ctx* c)
@@ -3364,7 +3385,8 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
             // what the levels leave as: floats (always, unless the caller has declared the float pyramid unneeded), and the
             // cascade's 16-bit rank cells when every level goes through this one launch
-            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps;
+            // (the rank cells have one reader, the tile kernel: a plan or option that routes the cascade elsewhere keeps floats)
+            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps && c->cs.useTiles && !c->noTiles;
             const bool emitF32 = !(emitRank && !c->keepPyramid && !c->autoLambdas);
             wroteRank = emitRank;
             wroteF32 = emitF32;
@@ -3914,6 +3936,12 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
     const uint32_t* d_cidAll = c->cs.d_cidAll;
     const CascNode2* d_nodes2 = c->cs.d_nodes2;
     prof(c, "k_cascade");
+    const bool rankPath = c->cs.useTiles && !c->noTiles && c->cs.useRank && !c->noRank;
+    if (pyr == c->d_pyr && !c->floatPyramid && !(rankPath && c->ranksValid))
+    {
+        // (options changed between acf_hip_pyramid and acf_hip_detect: the float cells this path reads were never written)
+        return fail(c, ACF_HIP_E_INVALID, "detect: the float pyramid of this batch was not written (keep_pyramid = 0) and the selected cascade reads floats");
+    }
     HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
     if (c->cs.useTiles && !c->noTiles)
     {
@@ -4225,6 +4253,16 @@ int acf_hip_detect(acf_hip_ctx* c)
     return ACF_HIP_OK;
 }
 
+// Host-side state after a replayed (or just captured) run: what runPyramid / runCascade's host code would have left.
+static void graphRunState(acf_hip_ctx* c, const acf_hip_ctx::GraphSlot& gs)
+{
+    c->lastBatch = gs.n;
+    c->pyramidValid = c->detectValid = true;
+    c->ranksValid = gs.ranksValid;
+    c->floatPyramid = gs.floatPyramid;
+    c->countsFetched = false; // the counts on the host are the previous run's
+}
+
 int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
 {
     if (c && !c->kids.empty())
@@ -4252,19 +4290,29 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
     // runtime refuses switches the option off for this context and the call runs plainly.
     const bool graphable = c && c->useGraph && !c->graphBroken && c->hasPlan && !c->profile && !c->taps && !c->countRepairs && !c->autoLambdas &&
         c->cascTurns == 0 && frames && nF > 0 && nF <= c->maxBatch;
-    if (graphable && c->graphExec && c->graphFrames == frames && c->graphN == nF)
+    if (graphable)
     {
-        HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipGraphLaunch(c->graphExec, c->stream));
-        c->lastBatch = nF;
-        c->pyramidValid = c->detectValid = true;
-        return ACF_HIP_OK;
+        for (auto& gs : c->graphs)
+        {
+            if (gs.exec && gs.frames == frames && gs.n == nF)
+            {
+                HIPCHK(c, hipSetDevice(c->device));
+                HIPCHK(c, hipGraphLaunch(gs.exec, c->stream));
+                graphRunState(c, gs);
+                return ACF_HIP_OK;
+            }
+        }
     }
     if (graphable && c->plainRuns >= 1)
     {
         HIPCHK(c, hipSetDevice(c->device));
-        dropGraph(c);
-        c->plainRuns = 1;
+        acf_hip_ctx::GraphSlot& gs = c->graphs[c->graphNext];
+        if (gs.exec)
+        {
+            (void)hipStreamSynchronize(c->stream); // (a replay of the slot being replaced may still be running)
+            (void)hipGraphExecDestroy(gs.exec);
+            gs = acf_hip_ctx::GraphSlot();
+        }
         hipGraph_t g = nullptr;
         bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
         int rcc = ACF_HIP_OK;
@@ -4279,7 +4327,7 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
         }
         if (ok)
         {
-            ok = hipGraphInstantiate(&c->graphExec, g, nullptr, nullptr, 0) == hipSuccess && c->graphExec != nullptr;
+            ok = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0) == hipSuccess && gs.exec != nullptr;
         }
         if (g)
         {
@@ -4287,15 +4335,17 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
         }
         if (ok)
         {
-            c->graphFrames = frames;
-            c->graphN = nF;
-            HIPCHK(c, hipGraphLaunch(c->graphExec, c->stream));
-            c->lastBatch = nF;
-            c->pyramidValid = c->detectValid = true;
+            gs.frames = frames;
+            gs.n = nF;
+            gs.ranksValid = c->ranksValid;
+            gs.floatPyramid = c->floatPyramid;
+            c->graphNext = (c->graphNext + 1) % acf_hip_ctx::GRAPH_SLOTS;
+            HIPCHK(c, hipGraphLaunch(gs.exec, c->stream));
+            graphRunState(c, gs);
             return ACF_HIP_OK;
         }
         (void)hipGetLastError();
-        c->graphExec = nullptr;
+        gs = acf_hip_ctx::GraphSlot();
         c->graphBroken = 1; // (fall through: the plain path below does the work)
     }
     int rc = acf_hip_pyramid(c, frames, nF);

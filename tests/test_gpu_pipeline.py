@@ -352,6 +352,67 @@ def test_graph_replay_matches_plain_launches(oracle, scale_streams):
     det.close()
 
 
+def test_graph_replay_sees_new_content_in_the_same_buffer(oracle):
+    """The documented use of option graph: new frame content copied into the SAME device buffer between replays.  Frames with
+    different detection counts, detections() after every run (which caches the counts on the host): a replay must not hand out
+    the previous run's counts.  Then two buffers alternating (double buffering): one cached graph per buffer, no re-capture."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 480, 640
+    model = synth.make_model(seed=3, name="FACE80", nTrees=256)
+    frames = np.stack([synth.make_frame(311 + i, H, W, "luv") for i in range(3)])
+    src = torch.from_numpy(frames).cuda()
+    plan = oracle.Plan(model, H, W, 3)
+    want = []
+    for f in range(3):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want.append(oracle.detect(plan, pyr))
+    assert len({len(w[0]) for w in want}) > 1, "the frames must differ in their detection counts"
+    for keep in (1, 0):
+        det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 14)
+        det.set_option("graph", 1)
+        det.set_option("keep_pyramid", keep)
+        buf = [torch.empty_like(src[0:1]), torch.empty_like(src[0:1])]
+        for k, (b, f) in enumerate([(0, 0), (0, 0), (0, 1), (0, 2), (0, 0), (1, 1), (0, 2), (1, 0), (0, 1), (1, 2)]):
+            buf[b].copy_(src[f:f + 1])
+            det.run(buf[b], 1)
+            got, gh = det.detections(0)
+            assert got.tobytes() == want[f][0].tobytes() and gh.tobytes() == want[f][1].tobytes(), (keep, k, b, f)
+        det.close()
+
+
+def test_detection_only_call_with_the_staged_cascade(oracle):
+    """keep_pyramid = 0 (the level kernel may leave rank cells only) together with cascade_tiles = 0 (the staged cascade reads
+    floats): the levels must still leave as floats; switching the cascade between acf_hip_pyramid and acf_hip_detect to one
+    whose cells were not written is an error, not garbage."""
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    H, W = 480, 640
+    model = synth.make_model(seed=3, name="FACE80", nTrees=256)
+    frame = synth.make_frame(321, H, W, "luv")
+    dev = torch.from_numpy(frame[None]).cuda()
+    plan = oracle.Plan(model, H, W, 3)
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    want, wh = oracle.detect(plan, pyr)
+    assert len(want) > 0
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 14)
+    det.set_option("keep_pyramid", 0)
+    det.set_option("cascade_tiles", 0)
+    det.run(dev, 1)
+    got, gh = det.detections(0)
+    assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes()
+    det.set_option("cascade_tiles", 1)
+    det.run(dev, 1)
+    got, gh = det.detections(0)
+    assert got.tobytes() == want.tobytes() and gh.tobytes() == wh.tobytes()
+    # pyramid with rank cells only, then the float-reading cascade selected: refused
+    det.pyramid(dev, 1)
+    det.set_option("cascade_tiles", 0)
+    with pytest.raises(HipError):
+        det.detect()
+    det.close()
+
+
 @pytest.mark.parametrize("nTrees", [129, 144, 145, 193])
 @pytest.mark.parametrize("depth", [1, 3, 4])
 def test_fixed_depth_tail_codes_tree_counts(oracle, depth, nTrees):
