@@ -1345,9 +1345,16 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     g.step = p.stride / p.shrink;
     g.TR = 32;
     g.winFloats = nChns * mW * mH;
-    // stage boundaries (kernels.hip.h, k_cascade_tile2), measured at cfg 2: 32 dense trees then sparse pieces [32,64) and
-    // [64,128) is 10 % faster than 16 / 32 / 64 / 128: the sparse stages are latency chains, the dense stage is VALU work
+    // Stage boundaries.  k_cascade_tile3 (pooled survivors, the default for depth 2): dense [0,16) on every window, dense
+    // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.  k_cascade_tile2
+    // (ACF_HIP_TILE2: every wave keeps its own windows): 32 dense trees then sparse pieces [32,64) and [64,128).
+    const bool pooled = p.treeDepth == 2 && !getenv("ACF_HIP_TILE2");
     int bounds[5] = { 0, 32, 32, 64, 128 };
+    if (pooled)
+    {
+        bounds[1] = 16;
+        bounds[3] = 32;
+    }
     if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
     {
         int v1, v2, v3, v4;
@@ -1359,19 +1366,44 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
             bounds[4] = v4;
         }
     }
+    if (pooled)
+    {
+        // the dense stages run whole batches of four trees (unless the model ends inside one); at most 128 sparse trees
+        bounds[1] = std::max(4, bounds[1] / 4 * 4);
+        bounds[2] = std::max(bounds[1], bounds[2] / 4 * 4);
+        bounds[3] = bounds[2];
+        bounds[4] = std::min(std::max(bounds[4], bounds[2]), bounds[2] + 128);
+    }
     for (int i = 0; i < 5; i++)
     {
         g.b[i] = std::min(bounds[i], p.nTrees);
     }
+    g.pooled = pooled ? 1 : 0;
+    if (pooled)
+    {
+        const int tsPad = (g.b[4] - g.b[2] + 15) / 16 * 16;
+        g.pitchC = (tsPad / 4) | 1; // dwords per window, odd: the chain's lanes (windows) read conflict-free
+        g.pitchC *= 4;
+    }
     // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for several workgroups per CU
     // (160 KiB LDS: three with rank cells, two with floats), else one
     const int W = 1; // windows per lane in stage A
-    auto ldsBytes = [&](int nw) {
+    auto ldsBytes = [&](int nw, int passW) {
         const int tc = nw * W * (64 / g.TR);
         const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
         const int64_t rowsP = (rows + CPB - 1) / CPB * CPB;
         // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
-        return int64_t(nChns) * rowsP * cols * cellBytes + int64_t(nw) * 64 * 8 + 64;
+        if (!g.pooled)
+        {
+            return int64_t(nChns) * rowsP * cols * cellBytes + int64_t(nw) * 64 * 8 + 64;
+        }
+        // k_cascade_tile3: leaf table + footprint + list 1 (later the codes of 64 windows) + list 2
+        const int64_t nwin = int64_t(nw) * 64;
+        if (int64_t(nChns) * rowsP * cols > 65535)
+        {
+            return int64_t(1) << 40; // (its list entries hold a window's first cell in 16 bits)
+        }
+        return int64_t(TILE3_LEAF_BYTES) + int64_t(nChns) * rowsP * cols * cellBytes + ((std::max<int64_t>(nwin * 8, passW * int64_t(g.pitchC)) + 15) / 16 * 16) + nwin * 8 + 64;
     };
     int nw = 0;
     if (const char* e = getenv(rank ? "ACF_HIP_RTILE_TR" : "ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
@@ -1385,11 +1417,17 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     const int nwForce = nwEnv ? atoi(nwEnv) : 0;
     for (int64_t limit : { rank ? int64_t(160 * 1024 / wgPerCu / 1280 * 1280) : int64_t(80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
     {
-        for (int cand : { 8 / W, 4 / W, 2 / W, 1 })
+        for (int cand : { nwForce == 16 && pooled ? 16 : 8, 8 / W, 4 / W, 2 / W, 1 })
         {
-            if (!nw && cand >= 1 && ldsBytes(cand) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR)
+            // (k_cascade_tile3's sparse stage: one thread per tree of a window)
+            const int tlp = g.b[4] - g.b[2] <= 32 ? 32 : (g.b[4] - g.b[2] <= 64 ? 64 : 128);
+            for (int passW : { 64, 32 }) // (k_cascade_tile3: windows per pass of the sparse stage)
             {
-                nw = cand;
+                if (!nw && cand >= 1 && ldsBytes(cand, passW) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR && (!g.pooled || cand * 64 >= tlp))
+                {
+                    nw = cand;
+                    g.passW = passW;
+                }
             }
         }
     }
@@ -1512,8 +1550,8 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     }
     // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
     // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC: ACF_HIP_TILE_TB8 for the A/B)
-    const int aTB = (g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
-    const int nTreesS = g.b[1] / aTB * aTB;
+    const int aTB = (!g.pooled && g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
+    const int nTreesS = (g.pooled ? g.b[2] : g.b[1]) / aTB * aTB; // (k_cascade_tile3: both dense stages read batches)
     std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
     for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
     {
@@ -3705,8 +3743,11 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.tailCodes = cs.d_tailCodes;
     a.codeCap = cs.codeCap;
     a.codePitch = cs.codePitch;
+    a.debug = 0;
+#ifdef ACF_HIP_STAMPS
     static const int cascDebug = getenv("ACF_HIP_CASC_DEBUG") ? atoi(getenv("ACF_HIP_CASC_DEBUG")) : 0; // timing experiments (profiles/ab_*.sh)
     a.debug = cascDebug;
+#endif
     if (a.debug & 12)
     {
         a.debug |= 4;
@@ -3747,7 +3788,9 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const int64_t total = int64_t(at.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
         static const size_t padKb = getenv("ACF_HIP_TILE_PAD_KB") ? size_t(atoi(getenv("ACF_HIP_TILE_PAD_KB"))) : 0; // A/B: fewer workgroups per CU
-        const size_t lds = size_t(gt.tileFloats) * (rank ? 2 : 4) + size_t(gt.NW) * 64 * 8 + padKb * 1024;
+        const size_t nwin = size_t(gt.NW) * 64;
+        const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8 + padKb * 1024
+                                     : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8 + padKb * 1024;
         dim3 grid((unsigned int)(perX * 8)), block(gt.NW * 64);
         int rc = 0;
         if ((c->cascTurns & 1) && (rc = turnBegin(c, 0, 0))) // (before the profile event: the wait for the turn is not the kernel's time)
@@ -3757,7 +3800,13 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         prof(c, "k_cascade_tile");
         static const bool occ8 = getenv("ACF_HIP_TILE_OCC8") != nullptr;
 #define TILE2_LAUNCH(N, CT)                                                                           \
-    if (occ8 && N == 8)                                                                               \
+    if (gt.pooled)                                                                                    \
+    {                                                                                                 \
+        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<N, CT>), lds)))          \
+            return rc;                                                                                \
+        hipLaunchKernelGGL((k_cascade_tile3<N, CT>), grid, block, lds, c->stream, at);                \
+    }                                                                                                 \
+    else if (occ8 && N == 8)                                                                          \
     {                                                                                                 \
         if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<8, CT, 8>), lds)))       \
             return rc;                                                                                \
@@ -3769,9 +3818,14 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             return rc;                                                                                \
         hipLaunchKernelGGL((k_cascade_tile2<N, CT>), grid, block, lds, c->stream, at);                \
     }
+#define TILE3_LAUNCH16(CT)                                                                        \
+    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<16, CT>), lds)))             \
+        return rc;                                                                                    \
+    hipLaunchKernelGGL((k_cascade_tile3<16, CT>), grid, block, lds, c->stream, at);
 #define TILE2_NW(CT)                              \
     switch (gt.NW)                                \
     {                                             \
+        case 16: TILE3_LAUNCH16(CT); break;       \
         case 8: TILE2_LAUNCH(8, CT); break;       \
         case 4: TILE2_LAUNCH(4, CT); break;       \
         case 2: TILE2_LAUNCH(2, CT); break;       \
@@ -3792,33 +3846,59 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         {
             return rc;
         }
+#ifdef ACF_HIP_STAMPS
         if (a.debug & 4)
         {
             // debug only: mean cycles per phase of thread 0 of every block
             HIPCHK(c, hipStreamSynchronize(c->stream));
             std::vector<long long> st(size_t(grid.x) * 8);
             HIPCHK(c, hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
-            double acc[4] = { 0, 0, 0, 0 }, sub[3] = { 0, 0, 0 };
-            long long nb = 0;
-            for (size_t b = 0; b < size_t(grid.x); b++)
+            if (gt.pooled)
             {
-                if (st[b * 8 + 4] > st[b * 8])
+                double acc[6] = { 0, 0, 0, 0, 0, 0 }, n1 = 0, n2 = 0, nE = 0;
+                long long nb = 0;
+                for (size_t b = 0; b < size_t(grid.x); b++)
                 {
-                    for (int k = 0; k < 4; k++)
+                    if (st[b * 8 + 5] > st[b * 8])
                     {
-                        acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
+                        for (int k = 0; k < 5; k++)
+                        {
+                            acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
+                        }
+                        n1 += double(st[b * 8 + 7] & 0xffff);
+                        n2 += double((st[b * 8 + 7] >> 16) & 0xffff);
+                        nE += double(st[b * 8 + 7] >> 32);
+                        nb++;
                     }
-                    for (int k = 0; k < 3; k++)
-                    {
-                        sub[k] += double(st[b * 8 + 5 + k]);
-                    }
-                    nb++;
                 }
+                fprintf(stderr, "[casc stamps, pooled] blocks %lld  fill %.0f  A1 (thread 0) %.0f  barrier %.0f  A2 + barrier %.0f  S %.0f cycles;  survivors per tile: A1 %.1f  A2 %.1f  S %.2f\n",
+                    nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, n1 / nb, n2 / nb, nE / nb);
             }
-            fprintf(stderr, "[casc stamps] blocks %lld (those with tail windows)  fill %.0f  wave 0: A + sparse pieces %.0f  barrier %.0f  E %.0f cycles   (since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
-                acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
+            else
+            {
+                double acc[4] = { 0, 0, 0, 0 }, sub[3] = { 0, 0, 0 };
+                long long nb = 0;
+                for (size_t b = 0; b < size_t(grid.x); b++)
+                {
+                    if (st[b * 8 + 4] > st[b * 8])
+                    {
+                        for (int k = 0; k < 4; k++)
+                        {
+                            acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
+                        }
+                        for (int k = 0; k < 3; k++)
+                        {
+                            sub[k] += double(st[b * 8 + 5 + k]);
+                        }
+                        nb++;
+                    }
+                }
+                fprintf(stderr, "[casc stamps] blocks %lld (those with tail windows)  fill %.0f  wave 0: A + sparse pieces %.0f  barrier %.0f  E %.0f cycles   (since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
+                    acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
+            }
             (void)hipFree(a.stamps);
         }
+#endif
         if (g.b[4] < p.nTrees && cs.codeCap > 0)
         {
             // the first codeCap queue entries of every frame carry leaf codes (stage E of the tile kernel): the ordered scan

@@ -4554,6 +4554,9 @@ struct TileGeom
     uint32_t cpsMagic, colsMagic; // ceil(2^32 / (rowsP/4)), ceil(2^32 / colsT): exact q/d by mulhi for every chunk index (checked at plan time)
     int32_t b[5];              // stage boundaries b0=0 <= b1 <= b2 <= b3 <= b4 = tEnd
     int32_t winFloats;         // nChns * mW * mH (tail kernel's per-wave window)
+    int32_t pooled;            // k_cascade_tile3: dense [0,b1) on every window, dense [b1,b2) on the workgroup's pooled survivors, b3 == b2, sparse [b2,b4)
+    int32_t passW;             // k_cascade_tile3: windows per pass of the sparse stage (64 or 32: what the LDS budget allows)
+    int32_t pitchC;            // k_cascade_tile3: bytes per window of the sparse stage's leaf codes (a multiple of 4 with pitchC / 4 odd, >= the trees padded to 16)
 };
 
 struct TileArgs
@@ -4596,11 +4599,17 @@ struct LaneNode
     uint4 o, tq, hq;
 };
 
+// Phase stamps and the timing exits of the tile kernels exist only in a build with -DACF_HIP_STAMPS (profiles/build_variant.sh):
+// the shipped kernels carry no debug branches.
+#ifdef ACF_HIP_STAMPS
 #define TILE_STAMP(k)                                                          \
     if ((a.debug & 4) && threadIdx.x == 0)                                      \
     {                                                                          \
         a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     }
+#else
+#define TILE_STAMP(k)
+#endif
 
 // ------------------------------------------------------------------------
 // k_cascade_tile2: the tile kernel with (i) stage A's node records on the scalar unit, (ii) item-parallel sparse
@@ -4815,6 +4824,53 @@ __device__ __forceinline__ int tile_emit2(const TileArgs& a, bool final_, int fr
     return idx;
 }
 
+// tile_emit2 with the destination fields passed one by one (k_cascade_tile3 reads them from the kernarg segment at the call)
+struct EmitDst
+{
+    acf_hip_hit* hits;
+    int32_t* counts;
+    uint2* q;
+    int32_t* qcount;
+    int32_t maxHits, qcap;
+};
+__device__ __forceinline__ int tile_emit3(const EmitDst& d, bool final_, int frame, bool alive, int lvl, int n, int nWinR, float h)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (!mask)
+    {
+        return -1;
+    }
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0)
+    {
+        base = atomicAdd((final_ ? d.counts : d.qcount) + frame, __popcll(mask));
+    }
+    base = __shfl(base, 0);
+    int idx = -1;
+    if (alive)
+    {
+        idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (final_)
+        {
+            if (idx < d.maxHits)
+            {
+                acf_hip_hit hit;
+                hit.scale = lvl;
+                hit.c = n / nWinR;
+                hit.r = n - hit.c * nWinR;
+                hit.score = h;
+                d.hits[int64_t(frame) * d.maxHits + idx] = hit;
+            }
+        }
+        else if (idx < d.qcap)
+        {
+            d.q[int64_t(frame) * d.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
+        }
+    }
+    return idx;
+}
+
 struct TileCtx
 {
     const void* tileF; // the tile's cells (CT::cell_t)
@@ -5016,6 +5072,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
     }
     __syncthreads();
     TILE_STAMP(1);
+#ifdef ACF_HIP_STAMPS
     if (a.debug & 2)
     {
         return; // timing experiment: the fill alone
@@ -5026,6 +5083,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
     {                                                                                      \
         a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime() - tS1;       \
     }
+#else
+#define TILE_STAMP_REL(k)
+#endif
 
     TileCtx X;
     X.tileF = tileF;
@@ -5077,6 +5137,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
     }
     asm volatile("" ::"v"(h));
     TILE_STAMP_REL(6);
+#ifdef ACF_HIP_STAMPS
     if (a.debug & 1)
     {
         if (h == 12345.678f)
@@ -5085,6 +5146,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
         }
         return; // timing experiment: fill + stage A
     }
+#endif
     // ---- from here to stage E every wave works on ITS OWN 64 windows: its survivors go to its private list segment and
     // through the sparse pieces [b1,b2) [b2,b3) [b3,b4) (each cut into pieces of at most 64 trees) without a workgroup
     // barrier — the pieces are latency chains (two LDS round trips + a 16..64-step add chain per round) that now overlap
@@ -5220,6 +5282,506 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
         }
     }
     TILE_STAMP(4);
+}
+
+// ------------------------------------------------------------------------
+// k_cascade_tile3: the tile kernel with the survivors POOLED over the workgroup.
+//
+// k_cascade_tile2 keeps every wave on its own 64 windows: 32 dense trees for each of them (the mean window needs 14), then
+// sparse pieces on the wave's ~2 survivors whose rounds cost a wave ~300 instructions however few of its lanes hold an item —
+// together 849 VALU instructions per wave, of which the kernel's time is the issue time (profiles/r03_pmc_sq_*).  Here:
+//  A1  trees [0, b1) (16): lanes = the wave's own windows, as before (tile_eval_s: records through the scalar unit, leaves
+//      added under EXEC).  Survivors {window, score} go to ONE list of the workgroup (a ballot and one LDS atomic per wave).
+//  A2  trees [b1, b2) (16..32): the same dense evaluation with lanes = list entries: ceil(n1 / 64) waves run it, the others
+//      go to the barrier and leave the SIMD's issue slots to the CU's other workgroups.
+//  S   trees [b2, b4) (32..128), items = survivors x trees, every thread one tree (node in registers), 8 / 4 windows per
+//      round: two dependent LDS reads give the leaf's code byte (4 * leaf index, as stage E's), written to codes[window][tree];
+//      then ONE wave, lanes = windows, adds the leaves in tree order — code byte -> leaf table in LDS -> h += leaf, min over the
+//      prefixes — which is evaluate()'s chain (acfDetect1.cpp:123-138) for up to 64 windows at once.
+//  E   as in k_cascade_tile2 (leaf codes of the tail trees for the windows that enter the tail queue).
+// A window's score is the same chain of f32 additions in the same order in every stage (A: v_add under EXEC per tree; S: the
+// one-wave chain; rows of -0.0f pad the leaf table to 16 trees, the identity of float addition).
+// LDS: [leaf table 2 KB][tile cells][R1: list 1 = h[NWIN] f32 + tag[NWIN] u16, later the codes 64 x pitchC][R2: list 2, same
+// form; its head becomes stage E's {tag, slot} list in place].
+// ------------------------------------------------------------------------
+#define TILE3_LEAF_BYTES 2048 // 128 trees x 4 leaves x 4 bytes
+typedef const __attribute__((address_space(4))) TileArgs* tile_args_k; // the kernel's argument block in the kernarg segment
+
+// Stage A of k_cascade_tile3: tile_eval_s<4> with a tree's three compares inside the asm block of its four leaf adds, so that
+// a tree's wave masks live for seven instructions instead of a batch (24 SGPRs fewer across the loop: the kernel's later
+// phases keep their scalars in registers instead of v_writelane / v_readlane round trips, which are VALU instructions).
+template <class CT>
+__device__ __forceinline__ void tile_eval_p(const typename CT::cell_t* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
+{
+    typedef typename CT::val_t val_t;
+    constexpr int TB = 4;
+    cu32p_t p = (cu32p_t)(uintptr_t)tab;
+    uint32_t o[3 * TB];
+#pragma unroll
+    for (int i = 0; i < 3 * TB; i++)
+    {
+        o[i] = p[i];
+    }
+    const unsigned long long execAll = __builtin_amdgcn_read_exec(); // every lane of the wave is here (callers: wave-uniform control flow only)
+    float hMin = __builtin_inff();
+    for (int b = 0; b < nBatches; b++)
+    {
+        val_t f[3 * TB];
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            f[i] = val_t(win[o[i]]);
+        }
+        cu32p_t pb = p + 10 * TB * b;
+        uint32_t th[3 * TB], hv4[4 * TB];
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            th[i] = pb[3 * TB + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * TB; i++)
+        {
+            hv4[i] = pb[6 * TB + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            ACF_PIN_V(f[i]);
+        }
+        cu32p_t pn = p + 10 * TB * min(b + 1, nBatches - 1);
+#pragma unroll
+        for (int i = 0; i < 3 * TB; i++)
+        {
+            o[i] = pn[i];
+        }
+#pragma unroll
+        for (int g = 0; g < TB; g += 2)
+        {
+            float h1, h2;
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                const int t = g + q;
+                float hOut;
+                const float hIn = q == 0 ? h : h1;
+                unsigned long long m0, mA, mB;
+                if (CT::RANK)
+                {
+                    asm volatile("v_cmp_gt_u32 %[m0], %[t0], %[f0]\n\t"
+                                 "v_cmp_gt_u32 %[mA], %[t1], %[f1]\n\t"
+                                 "v_cmp_gt_u32 %[mB], %[t2], %[f2]\n\t"
+                                 "s_and_b64 exec, %[m0], %[mA]\n\t"
+                                 "v_add_f32 %[o], %[A], %[i]\n\t"
+                                 "s_andn2_b64 exec, %[m0], %[mA]\n\t"
+                                 "v_add_f32 %[o], %[B], %[i]\n\t"
+                                 "s_andn2_b64 exec, %[mB], %[m0]\n\t"
+                                 "v_add_f32 %[o], %[C], %[i]\n\t"
+                                 "s_nor_b64 exec, %[m0], %[mB]\n\t"
+                                 "v_add_f32 %[o], %[D], %[i]\n\t"
+                                 "s_mov_b64 exec, %[ex]"
+                                 : [o] "=&v"(hOut), [m0] "=&s"(m0), [mA] "=&s"(mA), [mB] "=&s"(mB)
+                                 : [i] "v"(hIn), [f0] "v"(f[3 * t]), [f1] "v"(f[3 * t + 1]), [f2] "v"(f[3 * t + 2]), [t0] "s"(th[3 * t]), [t1] "s"(th[3 * t + 1]),
+                                 [t2] "s"(th[3 * t + 2]), [A] "s"(hv4[4 * t]), [B] "s"(hv4[4 * t + 1]), [C] "s"(hv4[4 * t + 2]), [D] "s"(hv4[4 * t + 3]), [ex] "s"(execAll)
+                                 : "scc");
+                }
+                else
+                {
+                    asm volatile("v_cmp_gt_f32 %[m0], %[t0], %[f0]\n\t"
+                                 "v_cmp_gt_f32 %[mA], %[t1], %[f1]\n\t"
+                                 "v_cmp_gt_f32 %[mB], %[t2], %[f2]\n\t"
+                                 "s_and_b64 exec, %[m0], %[mA]\n\t"
+                                 "v_add_f32 %[o], %[A], %[i]\n\t"
+                                 "s_andn2_b64 exec, %[m0], %[mA]\n\t"
+                                 "v_add_f32 %[o], %[B], %[i]\n\t"
+                                 "s_andn2_b64 exec, %[mB], %[m0]\n\t"
+                                 "v_add_f32 %[o], %[C], %[i]\n\t"
+                                 "s_nor_b64 exec, %[m0], %[mB]\n\t"
+                                 "v_add_f32 %[o], %[D], %[i]\n\t"
+                                 "s_mov_b64 exec, %[ex]"
+                                 : [o] "=&v"(hOut), [m0] "=&s"(m0), [mA] "=&s"(mA), [mB] "=&s"(mB)
+                                 : [i] "v"(hIn), [f0] "v"(f[3 * t]), [f1] "v"(f[3 * t + 1]), [f2] "v"(f[3 * t + 2]), [t0] "s"(th[3 * t]), [t1] "s"(th[3 * t + 1]),
+                                 [t2] "s"(th[3 * t + 2]), [A] "s"(hv4[4 * t]), [B] "s"(hv4[4 * t + 1]), [C] "s"(hv4[4 * t + 2]), [D] "s"(hv4[4 * t + 3]), [ex] "s"(execAll)
+                                 : "scc");
+                }
+                if (q == 0)
+                {
+                    h1 = hOut;
+                }
+                else
+                {
+                    h2 = hOut;
+                }
+            }
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
+            h = h2; // a rejected window's score is never read again
+        }
+    }
+    alive = alive && (hMin > thrC);
+}
+
+template <int NW, class CT>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
+{
+    typedef typename CT::cell_t cell_t;
+    typedef typename CT::val_t val_t;
+    constexpr int CPB = CT::CPB;
+    constexpr int NT = NW * 64;
+    extern __shared__ float lds[];
+    __shared__ int s_n[4]; // entries in list 1, list 2, (unused), stage E's list
+    float* leafT = lds;
+    cell_t* tileF = reinterpret_cast<cell_t*>(reinterpret_cast<char*>(lds) + TILE3_LEAF_BYTES);
+    const int NWIN = a.g.TR * a.g.TC;
+    // list entries: {score bits, tag | window offset << 16}: tag = column * TR + row of the window in the tile, offset = its first cell in the tile
+    char* r1 = reinterpret_cast<char*>(tileF) + size_t(a.g.tileFloats) * sizeof(cell_t);
+    const int passW = a.g.passW;
+    const int r1Bytes = (max(NWIN * 8, passW * a.g.pitchC) + 15) & ~15;
+    uint2* l1 = reinterpret_cast<uint2*>(r1);
+    uint8_t* codes = reinterpret_cast<uint8_t*>(r1);
+    uint2* l2 = reinterpret_cast<uint2*>(r1 + r1Bytes);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
+    const int64_t total = int64_t(a.nTiles) * a.nFrames;
+    const int64_t perX = (total + 7) >> 3;
+    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
+    if (id >= total || (blockIdx.x >> 3) >= perX)
+    {
+        return;
+    }
+    const int frame = int(id / a.nTiles);
+    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+    const int lvl = T.level;
+    const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
+    if (tid < 4)
+    {
+        s_n[tid] = 0;
+    }
+    TILE_STAMP(0);
+    // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
+    {
+        const CascLevel L = a.levels[lvl];
+        const int colsT = a.g.colsT;
+        const int gr0 = T.r0 * step, gc0 = T.c0 * step;
+        const int colPitch = CT::RANK ? L.pitchR : L.hP;
+        const int area = colPitch * L.wP;
+        const cell_t* __restrict__ src0 = (CT::RANK ? reinterpret_cast<const cell_t*>(a.pyrR) + int64_t(frame) * a.pyrR_fs + L.offR
+                                                    : reinterpret_cast<const cell_t*>(a.pyr) + int64_t(frame) * a.pyr_fs + L.off) + gr0;
+        const int colsValid = min(colsT, L.wP - gc0);
+        const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
+        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
+        const int ccMax = colsValid - 1;
+        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
+        {
+            const uint32_t q = q0 + lane;
+            if (q < nChunks)
+            {
+                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                const uint32_t j = q - seg * cps;
+                const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                const int cc = int(seg - z * uint32_t(colsT));
+                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + uint32_t(CPB) * q0), 16, 0, 0);
+            }
+        }
+    }
+    const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
+    // the sparse stage: this thread's tree (TLp = 32 / 64 / 128 threads per window), its node in registers; the stage's leaf table
+    const int Ts = tEnd - b2, TsPad = (Ts + 15) & ~15;
+    const int tlShift = TsPad <= 32 ? 5 : (TsPad <= 64 ? 6 : 7);
+    const int pos = tid & ((1 << tlShift) - 1);
+    uint32_t so0 = 0, so1 = 0, so2 = 0, st0 = 0, st1 = 0, st2 = 0;
+    if (Ts > 0)
+    {
+        const uint4* np = reinterpret_cast<const uint4*>(a.tileNodes + b2 + min(pos, Ts - 1));
+        const uint4 o = np[0], tq = np[1];
+        so0 = o.x, so1 = o.y, so2 = o.z;
+        st0 = tq.x, st1 = tq.y, st2 = tq.z;
+        for (int t = tid; t < TsPad; t += NT)
+        {
+            float4 hv = make_float4(-0.f, -0.f, -0.f, -0.f); // rows past the last tree: h + -0.0f == h for every h
+            if (t < Ts)
+            {
+                hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
+            }
+            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TILE_STAMP(1);
+
+    const float thrC = a.cascThr;
+    const int nWinR = a.levels[lvl].nWinR;
+    // survivors of the model's last tile tree: hits (model exhausted) or the frame's tail queue + stage E's list {slot, tag | offset}
+    auto finish = [&](tile_args_k A, bool alive, uint32_t tw, float h) {
+        const int tag = int(tw & 0xffffu);
+        const int rl = tag % TR, cl = tag / TR;
+        const bool lastAll = tEnd == A->nTrees;
+        const EmitDst dst{ A->hits, A->counts, A->q, A->qcount, A->maxHits, A->qcap };
+        const int slot = tile_emit3(dst, lastAll, frame, alive, lvl, (T.c0 + cl) * nWinR + (T.r0 + rl), nWinR, h);
+        if (!lastAll && A->codeCap > 0)
+        {
+            const unsigned long long m = __ballot(alive);
+            if (m)
+            {
+                int base = 0;
+                if (lane == 0)
+                {
+                    base = atomicAdd(&s_n[3], __popcll(m));
+                }
+                base = __shfl(base, 0);
+                if (alive)
+                {
+                    l2[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slot), tw);
+                }
+            }
+        }
+    };
+    auto append = [&](bool alive, uint32_t tw, float h, uint2* list, int* cnt) {
+        const unsigned long long m = __ballot(alive);
+        if (m)
+        {
+            int base = 0;
+            if (lane == 0)
+            {
+                base = atomicAdd(cnt, __popcll(m));
+            }
+            base = __shfl(base, 0);
+            if (alive)
+            {
+                list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(__float_as_uint(h), tw);
+            }
+        }
+    };
+    // dense trees [t0, t1) of one window per lane (t0 a multiple of four: the plan gives this kernel batches of four trees)
+    auto dense = [&](const cell_t* win, int t0, int t1, float& h, bool& alive) {
+        const int nb = (t1 - t0) / 4;
+        if (nb > 0)
+        {
+            tile_eval_p<CT>(win, a.tileNodesS + size_t(t0 / 4) * 40, nb, thrC, h, alive);
+        }
+        tile_eval_s1<CT>(win, a.tileNodes, t0 + nb * 4, t1, thrC, h, alive);
+    };
+
+    // ---- A1: lanes = windows, trees [0, b1).  Wave w takes the window columns w, w + NW, ... (conflict-free feature reads)
+    {
+        const int r_l = lane % TR, c_l = (lane / TR) * NW + wv;
+        bool alive = (T.r0 + r_l) < nWinR && (T.c0 + c_l) < a.levels[lvl].nWinC && lane < (64 / TR) * TR;
+        float h = 0.f;
+        const uint32_t woff = uint32_t((min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step);
+        dense(tileF + woff, 0, b1, h, alive);
+        const uint32_t tw = uint32_t(c_l * TR + r_l) | (woff << 16);
+        if (b1 == tEnd)
+        {
+            finish((tile_args_k)__builtin_amdgcn_kernarg_segment_ptr(), alive, tw, h);
+        }
+        else
+        {
+            append(alive, tw, h, b1 == b2 ? l2 : l1, b1 == b2 ? &s_n[1] : &s_n[0]);
+        }
+    }
+    TILE_STAMP(2);
+    __syncthreads();
+    TILE_STAMP(3);
+    // From here on the arguments are re-read from the kernarg segment where they are used (scalar loads): values kept alive across
+    // stage A1's loop would be spilled to VGPR lanes and fetched back with one VALU instruction each.
+    tile_args_k ak = (tile_args_k)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ak));
+    // ---- A2: lanes = entries of list 1, trees [b1, b2)
+    if (b1 < b2)
+    {
+        const int n1 = s_n[0];
+        for (int e0 = wv * 64; e0 < n1; e0 += NT) // (n1 <= NT: one chunk per wave at most)
+        {
+            const int e = e0 + lane;
+            bool alive = e < n1;
+            const uint2 en = l1[alive ? e : e0];
+            float h = __uint_as_float(en.x);
+            dense(tileF + (en.y >> 16), b1, b2, h, alive);
+            if (b2 == tEnd)
+            {
+                finish(ak, alive, en.y, h);
+            }
+            else
+            {
+                append(alive, en.y, h, l2, &s_n[1]);
+            }
+        }
+        __syncthreads();
+    }
+    TILE_STAMP(4);
+    const bool lastAll = tEnd == ak->nTrees;
+    const bool wantE = !lastAll && ak->codeCap > 0;
+    // ---- S: trees [b2, tEnd) for list 2, passW windows per pass
+    if (b2 < tEnd)
+    {
+        const int n2 = s_n[1];
+        const int wpr = NT >> tlShift; // windows per round
+        const int pitchC = ak->g.pitchC;
+        int nE = 0; // (wave 0) entries of stage E's list so far
+        for (int p0 = 0; p0 < n2; p0 += passW)
+        {
+            const int nP = min(passW, n2 - p0);
+            // items: two rounds side by side (their LDS round trips overlap)
+            for (int wi = tid >> tlShift; wi < nP; wi += 2 * wpr)
+            {
+                const int wj = wi + wpr;
+                const bool two = wj < nP;
+                const cell_t* winA = tileF + (l2[p0 + wi].y >> 16);
+                const cell_t* winB = tileF + (l2[p0 + (two ? wj : wi)].y >> 16);
+                const val_t fA = val_t(winA[so0]), fB = val_t(winB[so0]);
+                const bool ltA = fA < CT::thr(st0), ltB = fB < CT::thr(st0);
+                const val_t cA = val_t(winA[ltA ? so1 : so2]), cB = val_t(winB[ltB ? so1 : so2]);
+                const bool l1A = cA < CT::thr(ltA ? st1 : st2), l1B = cB < CT::thr(ltB ? st1 : st2);
+                if (pos < TsPad)
+                {
+                    codes[wi * pitchC + pos] = pos < Ts ? uint8_t((ltA ? 0 : 8) + (l1A ? 0 : 4)) : uint8_t(0);
+                    if (two)
+                    {
+                        codes[wj * pitchC + pos] = pos < Ts ? uint8_t((ltB ? 0 : 8) + (l1B ? 0 : 4)) : uint8_t(0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (wv == 0)
+            {
+                const bool valid = lane < nP;
+                const uint2 en = l2[p0 + (valid ? lane : 0)];
+                float h = __uint_as_float(en.x);
+                float hMin = __builtin_inff();
+                const uint8_t* crow = codes + (valid ? lane : 0) * pitchC;
+                const char* lt = reinterpret_cast<const char*>(leafT);
+                // the code bytes of group g + 1 are requested before group g's leaves are added
+                uint32_t cb[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                {
+                    cb[k] = crow[k];
+                }
+                for (int t = 0; t < TsPad; t += 16)
+                {
+                    float lf[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                    {
+                        lf[k] = *reinterpret_cast<const float*>(lt + 16 * (t + k) + cb[k]);
+                    }
+                    const int tn = min(t + 16, TsPad - 16);
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                    {
+                        cb[k] = crow[tn + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2)
+                    {
+                        const float h1 = h + lf[k];
+                        const float h2 = h1 + lf[k + 1];
+                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
+                        h = h2;
+                    }
+                }
+                const bool alive = valid && hMin > thrC;
+                const int tag = int(en.y & 0xffffu);
+                const int rl = tag % TR, cl = tag / TR;
+                const EmitDst dst{ ak->hits, ak->counts, ak->q, ak->qcount, ak->maxHits, ak->qcap };
+                const int slot = tile_emit3(dst, lastAll, frame, alive, lvl, (T.c0 + cl) * nWinR + (T.r0 + rl), nWinR, h);
+                if (wantE)
+                {
+                    // in place: nE + (survivors of this pass) <= p0 + nP, and this pass's entries are in registers
+                    const unsigned long long m = __ballot(alive);
+                    __builtin_amdgcn_wave_barrier();
+                    if (alive)
+                    {
+                        l2[nE + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slot), en.y);
+                    }
+                    nE += __popcll(m);
+                }
+            }
+            __syncthreads(); // (the next pass rewrites the codes)
+        }
+        if (wantE && tid == 0)
+        {
+            s_n[3] = nE;
+        }
+    }
+    TILE_STAMP(5);
+    if (!wantE)
+    {
+        return;
+    }
+    __syncthreads();
+    TILE_STAMP(6);
+    // ---- E: leaf codes of every tail tree for the windows now in the tail queue (k_cascade_tile2's stage E over one list)
+    const int nTail = s_n[3];
+#ifdef ACF_HIP_STAMPS
+    if ((a.debug & 4) && threadIdx.x == 0)
+    {
+        a.stamps[int64_t(blockIdx.x) * 8 + 7] = (long long)s_n[0] | ((long long)s_n[1] << 16) | ((long long)nTail << 32);
+    }
+#endif
+    if (nTail == 0)
+    {
+        return;
+    }
+    {
+        const int nTrees = ak->nTrees, codeCap = ak->codeCap, codePitch = ak->codePitch;
+        const TreeNode* __restrict__ nodes = ak->tileNodes + tEnd;
+        uint8_t* __restrict__ codesG = ak->tailCodes + int64_t(frame) * codeCap * codePitch + lane;
+        const int nT = nTrees - tEnd, nB = (nT + 63) >> 6;
+        for (int b0 = wv; b0 < nB; b0 += 4 * NW)
+        {
+            uint32_t o0[4], o1[4], o2[4];
+            val_t t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int b = min(b0 + k * NW, nB - 1);
+                const uint4* np = reinterpret_cast<const uint4*>(nodes + min(b * 64 + lane, nT - 1));
+                const uint4 o = np[0], tq = np[1];
+                o0[k] = o.x;
+                o1[k] = o.y;
+                o2[k] = o.z;
+                t0[k] = CT::thr(tq.x);
+                t1[k] = CT::thr(tq.y);
+                t2[k] = CT::thr(tq.z);
+            }
+            for (int s = 0; s < nTail; s++)
+            {
+                const uint2 en = l2[s];
+                const int slot = int(en.x);
+                if (slot < 0 || slot >= codeCap)
+                {
+                    continue; // no code row: k_cascade_tail3 / k_cascade_tail_rank takes this entry
+                }
+                const cell_t* win = tileF + (en.y >> 16);
+                uint8_t* __restrict__ row = codesG + int64_t(slot) * codePitch;
+                val_t f0[4], fc[4];
+                bool lt0[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    f0[k] = val_t(win[o0[k]]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    lt0[k] = f0[k] < t0[k];
+                    fc[k] = val_t(win[lt0[k] ? o1[k] : o2[k]]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const bool lt1 = fc[k] < (lt0[k] ? t1[k] : t2[k]);
+                    if (b0 + k * NW < nB) // wave-uniform
+                    {
+                        row[(b0 + k * NW) * 64] = uint8_t((lt0[k] ? 0 : 8) + (lt1 ? 0 : 4));
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Copy one window's footprint (nChns*mW*mH floats, the cids[] index space) from the pyramid level into a wave's LDS
@@ -5579,15 +6141,12 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
             const int r = n - c * L.nWinR;
             const float* __restrict__ chn = a.pyr + int64_t(frame) * a.pyr_fs + L.off + r * a.g.step + int64_t(c * a.g.step) * L.hP;
             __builtin_amdgcn_wave_barrier(); // the previous window's feature reads are done (LDS ops of a wave are in order)
-            if (!(a.debug & 32))
-            {
-                tail_fill(a, win, chn, L.hP, L.hP * L.wP, lane, tf);
-            }
+            tail_fill(a, win, chn, L.hP, L.hP * L.wP, lane, tf);
             __builtin_amdgcn_wave_barrier();
             float* __restrict__ row = S + k * pad;
             // four 64-tree batches per step: their node reads, root reads, child reads and stores are independent, so
             // the four LDS latency chains overlap (one batch per step was 760 cycles of exposed latency per batch)
-            for (int tb = 0; tb < ((a.debug & 64) ? 0 : nT); tb += 256)
+            for (int tb = 0; tb < nT; tb += 256)
             {
                 LaneNode nd[4];
 #pragma unroll
@@ -5640,10 +6199,6 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tail3(TileArgs a)
         // invalidate the XCD's whole L2 on gfx942/950 — measured 0.3 ms per 64 frames)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (a.debug & 16)
-        {
-            continue;
-        }
         __builtin_amdgcn_wave_barrier();
         float* tile = win;
         float h = __uint_as_float(mine.y);

@@ -93,8 +93,9 @@ def make_frame(seed, h, w, kind="luv"):
 
 
 # Typical value ranges (q25, q75) of the ten ACF channels on make_frame('luv')
-# data after the pyramid: L,U,V,M,H0..H5.  Frozen from a calibration run of
-# the oracle (tools/calibrate_synth.py) so that thresholds split the windows.
+# data after the pyramid: L,U,V,M,H0..H5.  Frozen from a one-off calibration run of
+# the oracle (quartiles of each channel over a few frames; the script was not kept) so that
+# thresholds split the windows.
 _CHN_Q = {
     "luv": [(0.13, 0.20), (0.38, 0.50), (0.35, 0.46)],
     "gray": [(0.3, 0.6)],

@@ -9,6 +9,7 @@ rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 ran = 0
+checked = 0  # frames whose pyramid, hits and boxes were actually compared
 for it in range(N):
     H = int(rng.randint(20, 180)) * 4 if rng.rand() < 0.8 else int(rng.randint(80, 600))
     W = int(rng.randint(20, 200)) * 4 if rng.rand() < 0.8 else int(rng.randint(80, 700))
@@ -51,6 +52,7 @@ for it in range(N):
             if len(want) >= (1 << 15):
                 continue  # (more hits than the plan's capacity: the library reports that as an error)
             got, gh = det.detections(f)
+            checked += 1
             if not np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)) or got.tobytes() != want.tobytes() or gh.tobytes() != wh.tobytes():
                 ok = False
     det.close()
@@ -58,4 +60,4 @@ for it in range(N):
     if not ok:
         bad += 1
         print("MISMATCH", H, W, nF, kw, opts)
-print("cases", N, "ran", ran, "mismatches", bad)
+print("cases", N, "ran", ran, "frames_checked", checked, "mismatches", bad)
