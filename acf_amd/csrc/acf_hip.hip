@@ -124,6 +124,9 @@ struct acf_hip_ctx
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
     // (k_smooth_grad) where that pays (big planes, many frames), 2 = wherever k_smooth_grad applies
     int fusedGrad = getenv("ACF_HIP_NO_FUSED_GRAD") ? 0 : (getenv("ACF_HIP_FUSED_GRAD") ? atoi(getenv("ACF_HIP_FUSED_GRAD")) : 1);
+    // option "tile_persist": the pooled tile kernel runs as persistent workgroups that draw tiles from a counter (best alone on the
+    // device: -8 % on that kernel) or one short-lived workgroup per tile (best beside other contexts' kernels, which then find free LDS)
+    int tilePersist = getenv("ACF_HIP_TILE_PERSIST") ? atoi(getenv("ACF_HIP_TILE_PERSIST")) : 1;
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     int noRank = 0;  // option "rank_cells" = 0: the tile kernel reads the float pyramid (A/B and parity of both forms)
     bool ranksValid = false; // the rank pyramid of the last batch has been written (by the level kernels or by k_rank)
@@ -202,7 +205,7 @@ struct acf_hip_ctx
     // the image turns exactly 0 (a black bar) the true chain carries a tail that only reaches 0 by underflow, after ~75 columns,
     // while a warm-up started inside the bar is 0 at once (profiles/r03_repair_rates.json: 3 % of planes repaired at 48, none
     // at 64+ on frames with black and flat bands); at 96 frames per launch 48 / 64 / 96 columns cost the same (0.36-0.38 ms)
-    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 96, smoothForceRedo = 0;
+    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 64, smoothForceRedo = 0; // (profiles/r03_repair_rates.json: no repair from 64 columns on)
     float *d_specState = nullptr, *d_trueState = nullptr;
     int32_t* d_redo = nullptr;
     // the same for the level chains (k_level_all<OUT, 1>), for batches of at most levelSegFrames frames
@@ -1156,6 +1159,15 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
         }
         return ACF_HIP_OK;
     }
+    if (!strcmp(key, "tile_persist"))
+    {
+        c->tilePersist = value;
+        for (acf_hip_ctx* k : c->kids)
+        {
+            k->tilePersist = value;
+        }
+        return ACF_HIP_OK;
+    }
     if (!strcmp(key, "cascade_turns"))
     {
         c->cascTurns = value;
@@ -2060,6 +2072,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->levelMode = c->levelMode;
             k->scaleStreams = c->scaleStreams;
             k->cascTurns = c->cascTurns;
+            k->tilePersist = c->tilePersist;
             k->nmsOn = c->nmsOn; // (acf_hip_set_nms before the plan, or a re-plan: the new children run what the parent reports)
             k->nms = c->nms;
             if ((rc = acf_hip_set_model(k, &c->p)) || (rc = acf_hip_plan(k, H, W, d_in, c->kidChunk, max_hits)))
@@ -2569,7 +2582,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         }
         c->cs.qcap = int(std::max<int64_t>(nWinTotal, 1));
         if ((rc = devAlloc(c, &c->cs.d_queue[0], size_t(B) * c->cs.qcap)) || (rc = devAlloc(c, &c->cs.d_queue[1], size_t(B) * c->cs.qcap)) ||
-            (rc = devAlloc(c, &c->cs.d_qcounts, size_t(8) * B)))
+            (rc = devAlloc(c, &c->cs.d_qcounts, size_t(8) * B + 8))) // (+ 8: k_cascade_tile3's tile counters, one per XCD)
         {
             return rc;
         }
@@ -3711,7 +3724,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     const acf_hip_params& p = c->p;
     const CascState& cs = c->cs;
     const TileGeom& g = cs.geom;
-    HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * 2 * size_t(c->maxBatch), c->stream));
+    HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * (2 * size_t(c->maxBatch) + 8), c->stream));
     TileArgs a{};
     a.pyr = pyr;
     a.pyr_fs = pyr_fs;
@@ -3732,6 +3745,7 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     a.q = cs.d_queue[0];
     a.qcount = cs.d_qcounts;
     a.qhead = cs.d_qcounts + c->maxBatch;
+    a.tileNext = cs.d_qcounts + 2 * size_t(c->maxBatch);
     a.qcap = cs.qcap;
     a.hits = cs.d_hits;
     a.counts = cs.d_counts;
@@ -3791,7 +3805,16 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const size_t nwin = size_t(gt.NW) * 64;
         const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8 + padKb * 1024
                                      : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8 + padKb * 1024;
-        dim3 grid((unsigned int)(perX * 8)), block(gt.NW * 64);
+        // k_cascade_tile3: persistent workgroups (as many as the CUs hold at once) that draw their tiles from one counter per XCD
+        // (tilePersist: 0 one workgroup per tile, 1 as many workgroups as the 256 CUs hold at once, n > 1 that many)
+        const int64_t resident = int64_t(256) * std::max<int64_t>(1, int64_t(160 * 1024) / int64_t((lds + 1279) / 1280 * 1280));
+        const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
+        const bool persist = gt.pooled && c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
+        if (!persist)
+        {
+            at.tileNext = nullptr;
+        }
+        dim3 grid((unsigned int)(persist ? (gridP + 7) / 8 * 8 : perX * 8)), block(gt.NW * 64);
         int rc = 0;
         if ((c->cascTurns & 1) && (rc = turnBegin(c, 0, 0))) // (before the profile event: the wait for the turn is not the kernel's time)
         {
@@ -5788,7 +5811,7 @@ static int opAcfDetect1(acf_hip_ctx* c, const void* chns, bool u8, int hP, int w
     }
     if (!rc)
     {
-        rc = devAlloc(c, &c->cs.d_qcounts, 8);
+        rc = devAlloc(c, &c->cs.d_qcounts, 16);
     }
     if (!rc)
     {

@@ -4578,6 +4578,7 @@ struct TileArgs
     uint2* q;
     int32_t* qcount;
     int32_t* qhead;
+    int32_t* tileNext; // k_cascade_tile3: [8] next tile of each XCD's range (zeroed before the launch)
     int32_t qcap;
     acf_hip_hit* hits;
     int32_t* counts;
@@ -5441,18 +5442,58 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     uint2* l2 = reinterpret_cast<uint2*>(r1 + r1Bytes);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
+    // Persistent workgroups: the grid is what the CUs hold at once; a workgroup draws tiles from the counter of its XCD (one
+    // contiguous range of frame-major tiles per XCD, as k_cascade_tile), the next one while the current tile is being filled.
     const int64_t total = int64_t(a.nTiles) * a.nFrames;
-    const int64_t perX = (total + 7) >> 3;
-    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
-    if (id >= total || (blockIdx.x >> 3) >= perX)
+    const int perX = int((total + 7) >> 3);
+    const int xcd = blockIdx.x & 7;
+    __shared__ int s_next[2]; // (two slots: a wave that is late reading tile n's successor never meets tile n + 1's write)
+    const bool persist = a.tileNext != nullptr; // else: one tile per workgroup, blockIdx.x -> tile as k_cascade_tile2
+    if (tid == 0)
     {
-        return;
+        s_next[0] = persist ? atomicAdd(a.tileNext + xcd, 1) : int(blockIdx.x >> 3);
+    }
+    __syncthreads();
+    int li = s_next[0];
+    int par = 1;
+    const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
+    const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
+    // the sparse stage: this thread's tree (TLp = 32 / 64 / 128 threads per window), its node in registers; the stage's leaf table
+    const int Ts = tEnd - b2, TsPad = (Ts + 15) & ~15;
+    const int tlShift = TsPad <= 32 ? 5 : (TsPad <= 64 ? 6 : 7);
+    const int pos = tid & ((1 << tlShift) - 1);
+    uint32_t so0 = 0, so1 = 0, so2 = 0, st0 = 0, st1 = 0, st2 = 0;
+    if (Ts > 0)
+    {
+        const uint4* np = reinterpret_cast<const uint4*>(a.tileNodes + b2 + min(pos, Ts - 1));
+        const uint4 o = np[0], tq = np[1];
+        so0 = o.x, so1 = o.y, so2 = o.z;
+        st0 = tq.x, st1 = tq.y, st2 = tq.z;
+        for (int t = tid; t < TsPad; t += NT)
+        {
+            float4 hv = make_float4(-0.f, -0.f, -0.f, -0.f); // rows past the last tree: h + -0.0f == h for every h
+            if (t < Ts)
+            {
+                hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
+            }
+            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
+        }
+    }
+    for (;;)
+    {
+    const int64_t id = int64_t(xcd) * perX + li;
+    if (li >= perX || id >= total) // (workgroup-uniform)
+    {
+        break;
+    }
+    int liNext = perX;
+    if (tid == 0 && persist)
+    {
+        liNext = atomicAdd(a.tileNext + xcd, 1); // (returns during the fill)
     }
     const int frame = int(id / a.nTiles);
     const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
     const int lvl = T.level;
-    const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
     if (tid < 4)
     {
         s_n[tid] = 0;
@@ -5485,27 +5526,9 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
             }
         }
     }
-    const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
-    // the sparse stage: this thread's tree (TLp = 32 / 64 / 128 threads per window), its node in registers; the stage's leaf table
-    const int Ts = tEnd - b2, TsPad = (Ts + 15) & ~15;
-    const int tlShift = TsPad <= 32 ? 5 : (TsPad <= 64 ? 6 : 7);
-    const int pos = tid & ((1 << tlShift) - 1);
-    uint32_t so0 = 0, so1 = 0, so2 = 0, st0 = 0, st1 = 0, st2 = 0;
-    if (Ts > 0)
+    if (tid == 0)
     {
-        const uint4* np = reinterpret_cast<const uint4*>(a.tileNodes + b2 + min(pos, Ts - 1));
-        const uint4 o = np[0], tq = np[1];
-        so0 = o.x, so1 = o.y, so2 = o.z;
-        st0 = tq.x, st1 = tq.y, st2 = tq.z;
-        for (int t = tid; t < TsPad; t += NT)
-        {
-            float4 hv = make_float4(-0.f, -0.f, -0.f, -0.f); // rows past the last tree: h + -0.0f == h for every h
-            if (t < Ts)
-            {
-                hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
-            }
-            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
-        }
+        s_next[par] = liNext; // (read after this tile's last barrier)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -5707,11 +5730,13 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
         }
     }
     TILE_STAMP(5);
+    __syncthreads(); // (stage E's list is complete; every wave is done with the codes and the lists' other uses)
+    li = s_next[par];
+    par ^= 1;
     if (!wantE)
     {
-        return;
+        continue;
     }
-    __syncthreads();
     TILE_STAMP(6);
     // ---- E: leaf codes of every tail tree for the windows now in the tail queue (k_cascade_tile2's stage E over one list)
     const int nTail = s_n[3];
@@ -5721,10 +5746,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
         a.stamps[int64_t(blockIdx.x) * 8 + 7] = (long long)s_n[0] | ((long long)s_n[1] << 16) | ((long long)nTail << 32);
     }
 #endif
-    if (nTail == 0)
-    {
-        return;
-    }
+    if (nTail != 0)
     {
         const int nTrees = ak->nTrees, codeCap = ak->codeCap, codePitch = ak->codePitch;
         const TreeNode* __restrict__ nodes = ak->tileNodes + tEnd;
@@ -5781,6 +5803,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
                 }
             }
         }
+    }
+    __syncthreads(); // (the next tile's fill rewrites the cells stage E reads)
     }
 }
 

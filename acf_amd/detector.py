@@ -327,8 +327,11 @@ class DetectorPool:
         if n > 1:
             # the contexts' level and tile kernels (VALU / LDS-bound) take turns, so that each runs beside the other contexts'
             # memory-bound pyramid kernels and not beside another of its kind (acf_hip.h, option cascade_turns): +4 % frames/s
+            # and the tile kernel runs one workgroup per tile: persistent workgroups hold every CU's LDS for the whole kernel and
+            # keep the other contexts' kernels out (3 contexts: 14.0k against 13.4k frames/s; alone it is the other way round)
             for d in self.dets:
                 d.set_option("cascade_turns", 5)
+                d.set_option("tile_persist", 0)
 
     def __len__(self):
         return len(self.dets)

@@ -979,6 +979,7 @@ static void poolTurns(const std::vector<int>& devices, std::vector<std::unique_p
         if (std::count(devices.begin(), devices.end(), devices[i]) > 1)
         {
             dets[i]->setOption("cascade_turns", 5);
+            dets[i]->setOption("tile_persist", 0); // (short-lived tile workgroups leave LDS for the other contexts' kernels)
         }
     }
 }

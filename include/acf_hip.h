@@ -203,6 +203,10 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * chain of its own) — these kernels are bound by VALU and LDS, and two of them side by
  * side displace each other where each could run beside another context's memory-bound
  * pyramid kernels; three contexts, cfg 2: +4 % frames/s with 5),
+ * "tile_persist" (1, default: the cascade's tile kernel runs as persistent workgroups that
+ * draw their tiles from a counter — best for a context that has the device to itself;
+ * 0: one workgroup per tile, which lets other contexts' kernels find free LDS between
+ * tiles — what an application with several contexts per device wants; n > 1: n workgroups),
  * "fused_grad" (1, default: gradMag is computed inside the gradient plane's smoothing
  * chain — the smoothed plane then makes no round trip through memory — for planes of
  * >= 2^20 pixels in batches of >= 16 frames, where that pays; 2: wherever that kernel
