@@ -173,7 +173,7 @@ def cpu_baseline(model, frames_np, H, W, budget_s=12.0):
     try:
         # how the port compares with the reference's own SSE kernels where those compile here (profiles/oracle_vs_ref_stages.py,
         # run in the build container): > 1 means the port is slower, i.e. this baseline understates the reference by about that
-        with open(os.path.join(ROOT, "profiles", "r02_oracle_vs_ref.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_oracle_vs_ref.json")) as f:
             st = json.load(f)["stages"]
         out["port_over_reference_kernels"] = {k: v["oracle_over_reference"] for k, v in st.items()}
     except Exception:
@@ -296,8 +296,8 @@ def main():
         scaling = "strong"
 
     model = synth.make_model(seed=1, **cfg["model"])
-    # distinct base frames per rank, expanded to C*B distinct frames by cyclic shifts (cheap, on device)
-    nbase = 4
+    # distinct base frames per rank (8 seeds), expanded to C*B distinct frames by cyclic shifts (cheap, on device)
+    nbase = 8
     base_np = [synth.make_frame(1000 * rank + i + 1, H, W, cfg["kind"]) for i in range(nbase)]
     base = torch.from_numpy(np.stack(base_np)).to(dev)
     frames = torch.empty((C * B, 3, W, H), dtype=torch.float32, device=dev)
@@ -392,6 +392,28 @@ def main():
                 dets[0].run(frames[:B], B)
         dets[0].synchronize()
         solo = dets[0].profile()
+    keep_fps = None
+    if world == 1 and not args.keep_pyramid and args.config != 5 and not args.no_latency:
+        # the chnsPyramid-returning call beside the headline's detection-only call: the same steps with the float pyramid
+        # materialised as well (option keep_pyramid = 1), timed the same way; reported in config, never `value`
+        for d_ in dets:
+            d_.set_option("keep_pyramid", 1)
+        step()
+        finish()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        keep_fps = C * B * args.steps / (time.perf_counter() - t1)
+        for d_ in dets:
+            d_.set_option("keep_pyramid", 0)
+        step()  # (the records of the detection-only call are what the self-check below reads)
+        finish()
+        if not args.no_profile:
+            for d_ in dets:
+                d_.profile()  # these launches are not the timed region's
     if rank == 0 and not args.no_latency:
         # one frame through one context, submit -> results on the device (cfg 2 is worded "single frame")
         lat = []
@@ -468,7 +490,12 @@ def main():
                                           "16-bit threshold-rank cells only (detection-only call; --keep-pyramid also writes the float levels)") if args.config != 5 else "float (LDCF)",
                        # BASELINE cfg 2 as worded ("single frame") and cfg 3 as worded (64 frames per step, here on ONE GPU)
                        "cfg2_single_frame_latency_ms": latency_ms, "cfg2_single_frame_fps": (1e3 / latency_ms) if latency_ms else None,
-                       "cfg3_64_frames_per_step_fps_1gpu": strong64},
+                       "cfg3_64_frames_per_step_fps_1gpu": strong64,
+                       # the Pyramid-returning call (float levels written as well as the rank cells), same steps, timed the same way
+                       "keep_pyramid_fps": keep_fps,
+                       "cfg3_scaling_expectation": "weak scaling (--gpus N: every GPU its own 3 x 96 frames, one 772-byte record gather per frame) is "
+                                                   "expected near-linear; strong scaling of cfg 3 as worded (64 frames per step over 8 GPUs = 8 per GPU) is bound by "
+                                                   "per-launch floors: estimate 1.4x of one GPU, not 8x.  No multi-GPU node was available: neither is measured."},
         }
         if args.frames_total:
             out["config"]["frames_total_per_step"] = args.frames_total
@@ -490,6 +517,9 @@ def main():
             path = b_frame * C * B * args.steps / dt / 1e9
             roof.update({
                 "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
+                # what the kernel really moves (PMC bytes of the committed pass) over its launch time here, as a fraction of peak:
+                # the rank-cell tile kernel reads half of the 4 bytes per cell that `achieved` charges (SURVEY.md 8d's figure)
+                "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (pmc_traffic(dom, B) and frames_per_launch == B) else None,
                 "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_share": prof[dom][0] / tot_ms,
                 "kernel_bytes_per_launch": kb.get(dom, 0) * frames_per_launch,
                 "measured": "inside the timed region (%d contexts sharing the GPU)" % C,
@@ -504,6 +534,7 @@ def main():
                 s_ach = kb.get(dom, 0) * B / (s_ms * 1e-3) / 1e9
                 roof["solo"] = {"note": "same kernel, one context alone on the GPU, 3 launches after the timed region",
                                 "kernel_avg_ms": s_ms, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
+                                "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_traffic(dom, B) else None,
                                 "kernels_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])}}
                 # every kernel's HBM rate alone: committed PMC traffic of all its launches in a step (profiles/r02_pmc_traffic.json,
                 # measured with this batch size) over the time of those launches here; GB/s (fraction of the 8 TB/s peak)

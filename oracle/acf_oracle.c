@@ -892,21 +892,33 @@ ACFO_API int acfo_grad_mag(const float* I, float* M, float* O, int h, int w, int
                 }
             }
         }
-        for (int y = 0; y < h; y++) /* :209-219; RCPSQRT/RCP -> exact */
+        /* :209-219; RCPSQRT/RCP -> exact.  Written so that gcc vectorises it (IEEE sqrtps / divps, -fno-math-errno): the
+         * reference's loop is SSE too, and bench.py's cpu_baseline times this function. */
+        if (O)
         {
-            float m = 1.0f / sqrtf(M2[y]);
-            m = m < 1e10f ? m : 1e10f; /* _mm_min_ps(a,b): a<b ? a : b */
-            M2[y] = 1.0f / m;
-            if (O)
+            for (int y = 0; y < h; y++)
             {
+                float m = 1.0f / sqrtf(M2[y]);
+                m = m < 1e10f ? m : 1e10f; /* _mm_min_ps(a,b): a<b ? a : b */
+                M2[y] = 1.0f / m;
                 float g = (Gx[y] * m) * acMult;
-                if (signbit(Gy[y]))
-                {
-                    g = -g; /* XOR with the sign bit of Gy */
-                }
+                uint32_t gb, yb;
+                memcpy(&gb, &g, 4);
+                memcpy(&yb, &Gy[y], 4);
+                gb ^= yb & 0x80000000u; /* XOR with the sign bit of Gy */
+                memcpy(&g, &gb, 4);
                 g = g < upper ? g : upper; /* MIN_sse */
                 g = g > lower ? g : lower; /* MAX_sse */
                 Gx[y] = g;
+            }
+        }
+        else
+        {
+            for (int y = 0; y < h; y++)
+            {
+                float m = 1.0f / sqrtf(M2[y]);
+                m = m < 1e10f ? m : 1e10f;
+                M2[y] = 1.0f / m;
             }
         }
         memcpy(M + (size_t)x * h, M2, sizeof(float) * (size_t)h);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """How much slower the oracle (plain C restatement, gcc -O2, scalar) is than the reference's own SSE kernels, stage by stage,
 on one 1080p plane — so that bench.py's cpu_baseline (kind "port") can say by how much it understates the reference.
-Runs in the build container (needs /root/reference through oracle/_ref/libacfref.so); writes profiles/r02_oracle_vs_ref.json.
+Runs in the build container (needs /root/reference through oracle/_ref/libacfref.so); writes profiles/r04_oracle_vs_ref.json.
 
     python profiles/oracle_vs_ref_stages.py
 """
@@ -49,7 +49,7 @@ def main():
         tr, to = best(fr), best(fo)
         out[k] = {"reference_ms": round(tr * 1e3, 2), "oracle_ms": round(to * 1e3, 2), "oracle_over_reference": round(to / tr, 2)}
         print(k, out[k])
-    json.dump({"plane": "1080x1920 f32", "host": "build container, 1 thread, best of 7", "stages": out}, open(os.path.join(ROOT, "profiles", "r02_oracle_vs_ref.json"), "w"), indent=1)
+    json.dump({"plane": "1080x1920 f32", "host": "build container, 1 thread, best of 7", "stages": out}, open(os.path.join(ROOT, "profiles", "r04_oracle_vs_ref.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

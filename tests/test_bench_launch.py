@@ -50,3 +50,21 @@ def test_real_run_without_gpu_fails_loudly():
         pytest.skip("a GPU is visible")
     r = _run(["--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert r.returncode != 0 and "no CPU form" in (r.stderr + r.stdout)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_a_one_gpu_box_fail_with_the_missing_device():
+    """Multi-GPU readiness without a node: `bench.py --gpus 2 --frames-total 64` on a box with ONE device spawns both ranks;
+    rank 0 gets as far as the RCCL rendezvous, rank 1 stops with the explicit message and the launcher reports the failure —
+    nothing hangs, nothing falls back to one GPU."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    r = _run(["--gpus", "2", "--frames-total", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-latency"])
+    out = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert "rank 1 needs GPU 1 but 1 device(s) are visible" in out, out[-3000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]  # no bench line from a broken launch

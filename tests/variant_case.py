@@ -1,0 +1,53 @@
+"""One process per environment setting (the A/B knobs of DESIGN.md 6c are read once per process): a VGA frame pair through
+the library against the oracle — every pyramid level's bits, hits, boxes and scores — for a depth-2 model with a tail
+(300 trees, low cascThr: windows reach the leaf-code stages), and an LDCF model when `ldcf` is given.  tests/test_gpu_variants.py
+runs this file under each setting; exit status 0 = identical."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from acf_amd import synth  # noqa: E402
+from acf_amd.detector import HipDetector  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+
+def main():
+    ldcf = len(sys.argv) > 1 and sys.argv[1] == "ldcf"
+    H, W, nF = 480, 640, 2
+    kw = dict(name="FACE80", nTrees=300, cascThr=-3.0)
+    if ldcf:
+        kw = dict(name="FACE80", nTrees=256, ldcfK=4, cascThr=-2.0)  # (tests/test_gpu_pipeline.py, face80_k4_vga)
+    model = synth.make_model(seed=11, **kw)
+    frames = np.stack([synth.make_frame(900 + i, H, W, "luv") for i in range(nF)])
+    plan = ob.Plan(model, H, W, 3)
+    det = HipDetector(model, H, W, 3, max_batch=nF, max_hits=1 << 15)
+    det.run(torch.from_numpy(frames).cuda(), nF)
+    total = 0
+    for f in range(nF):
+        pyr, _, _ = ob.chns_pyramid(plan, frames[f])
+        if ldcf:
+            lvL, pyrL, _ = ob.ldcf(plan, pyr)
+            want, wh = ob.detect_ldcf(plan, lvL, pyrL)
+        else:
+            want, wh = ob.detect(plan, pyr)
+        got, gh = det.detections(f)
+        if not np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)):
+            print("pyramid differs, frame", f)
+            return 1
+        if got.tobytes() != want.tobytes() or gh.tobytes() != wh.tobytes():
+            print("detections differ, frame", f, len(got), len(want))
+            return 1
+        total += len(want)
+    det.close()
+    if total == 0:
+        print("no detections: the case checks nothing")
+        return 1
+    print("ok", total)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
