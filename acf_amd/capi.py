@@ -192,6 +192,9 @@ def load():
         "acf_hip_run_host": ([ctx, fp, C.c_int], C.c_int),
         "acf_hip_pyramid_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
         "acf_hip_run_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int], C.c_int),
+        "acf_hip_resize_dims": ([C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "acf_hip_set_input_resize": ([ctx, C.c_int, C.c_int, C.c_double], C.c_int),
+        "acf_hip_op_resize_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int], C.c_int),
         "acf_hip_stream_open": ([ctx, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "acf_hip_stream_submit": ([ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_stream_collect": ([ctx, C.c_int, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int)], C.c_int),
@@ -236,7 +239,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_set_model", "acf_hip_get_scales", "acf_hip_plan_levels",
     "acf_hip_plan", "acf_hip_num_levels", "acf_hip_get_levels", "acf_hip_get_ldcf_levels", "acf_hip_pyramid_floats", "acf_hip_get_lambdas", "acf_hip_pyramid",
     "acf_hip_detect", "acf_hip_run", "acf_hip_run_host", "acf_hip_set_nms", "acf_hip_op_nms", "acf_hip_get_detections", "acf_hip_get_hits", "acf_hip_get_raw_detections",
-    "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
+    "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_resize_dims", "acf_hip_set_input_resize", "acf_hip_op_resize_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_get_repairs", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_rank_level", "acf_hip_rank_cells_host", "acf_hip_read_tap",
     "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_selftest_gradmag", "acf_hip_op_gradient_hist",

@@ -270,6 +270,16 @@ struct acf_hip_ctx
     acf_hip_detection* d_nmsDets = nullptr;
     std::vector<int32_t> h_counts;
     bool countsFetched = false;
+    // acf_hip_set_input_resize: the apps' resize to a minimum object width in front of the 8-bit entries (k_resize_u8)
+    struct InputResize
+    {
+        bool on = false;
+        int rows = 0, cols = 0;
+        double scale = 1;
+        ResizeTables t;
+        int32_t *d_xlin = nullptr, *d_ylin = nullptr, *d_xrun = nullptr, *d_yrun = nullptr, *d_xtap = nullptr, *d_ytap = nullptr;
+        uint8_t* d_out = nullptr; // [maxBatch][plan.H][plan.W][4]
+    } rz;
 };
 
 #define HIPCHK(ctx, call)                                                                                  \
@@ -370,6 +380,7 @@ void freeAll(acf_hip_ctx* c)
     c->d_lvRedo = nullptr;
     c->levelSegFrames = 0;
     c->d_color = c->d_stage = c->d_chns = c->d_pyr = nullptr; // a re-plan must not see the previous plan's buffers
+    c->rz = acf_hip_ctx::InputResize();
     c->d_ldcfFilt = c->d_ldcfTmp = c->d_ldcfPyr = nullptr;
     c->d_ldcfJobs = nullptr;
     c->d_ldcfTileJobs = nullptr;
@@ -2801,6 +2812,52 @@ int launchIngest(acf_hip_ctx* c, const PackedSrc& u, int nF, float* dst, int64_t
     return ACF_HIP_OK;
 }
 
+static int pixCpp(int pix)
+{
+    return pix == ACF_HIP_PIX_GRAY ? 1 : ((pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3);
+}
+
+// k_resize_u8 over a batch: `src` frames of t.rows x t.cols (row stride `stride` bytes) -> tight t.drows x t.dcols frames at dst
+static int launchResizeU8(acf_hip_ctx* c, const acf_hip_ctx::InputResize& rz, const uint8_t* src, int cpp, int stride, int nF, uint8_t* dst)
+{
+    const ResizeTables& t = rz.t;
+    ResizeArgs a{};
+    a.src = src;
+    a.dst = dst;
+    a.rows = t.rows;
+    a.cols = t.cols;
+    a.cn = cpp;
+    a.stride = stride;
+    a.drows = t.drows;
+    a.dcols = t.dcols;
+    a.src_fs = int64_t(stride) * t.rows;
+    a.dst_fs = int64_t(t.drows) * t.dcols * cpp;
+    a.mode = t.mode;
+    a.isx = t.isx;
+    a.isy = t.isy;
+    a.xlin = reinterpret_cast<const int4*>(rz.d_xlin);
+    a.ylin = reinterpret_cast<const int4*>(rz.d_ylin);
+    a.xrun = reinterpret_cast<const int2*>(rz.d_xrun);
+    a.yrun = reinterpret_cast<const int2*>(rz.d_yrun);
+    a.xtap = reinterpret_cast<const int2*>(rz.d_xtap);
+    a.ytap = reinterpret_cast<const int2*>(rz.d_ytap);
+    prof(c, "k_resize_u8");
+    hipLaunchKernelGGL(k_resize_u8, dim3(cdiv(t.dcols, 64), cdiv(t.drows, 4), nF), dim3(256), 0, c->stream, a);
+    LAUNCHCHK(c, "k_resize_u8");
+    return ACF_HIP_OK;
+}
+
+static int uploadResizeTables(acf_hip_ctx* c, acf_hip_ctx::InputResize& rz)
+{
+    int rc;
+    if ((rc = devUpload(c, &rz.d_xlin, rz.t.xlin)) || (rc = devUpload(c, &rz.d_ylin, rz.t.ylin)) || (rc = devUpload(c, &rz.d_xrun, rz.t.xrun)) ||
+        (rc = devUpload(c, &rz.d_yrun, rz.t.yrun)) || (rc = devUpload(c, &rz.d_xtap, rz.t.xtap)) || (rc = devUpload(c, &rz.d_ytap, rz.t.ytap)))
+    {
+        return rc;
+    }
+    return ACF_HIP_OK;
+}
+
 int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF)
 {
     if (c && !c->kids.empty())
@@ -2843,6 +2900,23 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     const int64_t np0 = int64_t(H) * W;
     c->pyramidValid = c->detectValid = false;
     int rc;
+    PackedSrc reduced{};
+    if (u8 && c->rz.on)
+    {
+        // the apps' Resizer (acf.cpp:117-148) in front of the ingest: the caller's frames are rz.rows x rz.cols
+        const int cpp = pixCpp(u8->pix);
+        const int stride = u8->rowStride > 0 ? u8->rowStride : c->rz.cols * cpp;
+        if (stride < c->rz.cols * cpp)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: row stride smaller than a row of the unreduced frame");
+        }
+        if ((rc = launchResizeU8(c, c->rz, u8->frames, cpp, stride, nF, c->rz.d_out)))
+        {
+            return rc;
+        }
+        reduced = PackedSrc{ c->rz.d_out, u8->pix, 0 };
+        u8 = &reduced;
+    }
     if (u8)
     {
         // 8-bit ingest (ACF.cpp:114-119,137; MatP.cpp:51-73), fused with the colour conversion below when there is one
@@ -3708,6 +3782,109 @@ int acf_hip_pyramid_u8(acf_hip_ctx* c, const uint8_t* frames, int nF, int pix, i
     }
     PackedSrc u{ frames, pix, rowStride };
     return pyramidImpl(c, nullptr, &u, nF);
+}
+
+int acf_hip_resize_dims(int rows, int cols, double scale, int* out_rows, int* out_cols)
+{
+    if (!out_rows || !out_cols || rows < 1 || cols < 1 || !(scale > 0))
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    resizeDims(rows, cols, scale, *out_rows, *out_cols);
+    return (*out_rows >= 1 && *out_cols >= 1) ? ACF_HIP_OK : ACF_HIP_E_INVALID;
+}
+
+int acf_hip_set_input_resize(acf_hip_ctx* c, int srcRows, int srcCols, double scale)
+{
+    if (!c || !c->hasPlan)
+    {
+        return c ? fail(c, ACF_HIP_E_NOPLAN, "set_input_resize: plan first (for the reduced size, acf_hip_resize_dims)") : ACF_HIP_E_INVALID;
+    }
+    if (!c->kids.empty() || !c->slots.empty())
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "set_input_resize: not with option \"streams\" > 1; before acf_hip_stream_open");
+    }
+    dropGraph(c);
+    if (srcRows <= 0 || srcCols <= 0)
+    {
+        c->rz.on = false;
+        return ACF_HIP_OK;
+    }
+    acf_hip_ctx::InputResize rz;
+    if (buildResizeTables(srcRows, srcCols, scale, rz.t) || rz.t.drows != c->plan.H || rz.t.dcols != c->plan.W)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_input_resize: the plan must be for the reduced size (acf_hip_resize_dims of the frame size and scale)");
+    }
+    rz.rows = srcRows;
+    rz.cols = srcCols;
+    rz.scale = scale;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = uploadResizeTables(c, rz)) || (rc = devAlloc(c, &rz.d_out, size_t(c->maxBatch) * c->plan.H * c->plan.W * 4)))
+    {
+        return rc;
+    }
+    rz.on = true;
+    c->rz = rz;
+    return ACF_HIP_OK;
+}
+
+int acf_hip_op_resize_u8(acf_hip_ctx* c, const uint8_t* src, int rows, int cols, int cpp, int rowStride, double scale, uint8_t* dst, int dstRows, int dstCols)
+{
+    if (!c || !src || !dst || cpp < 1 || cpp > 4)
+    {
+        return c ? fail(c, ACF_HIP_E_INVALID, "op_resize_u8: arguments") : ACF_HIP_E_INVALID;
+    }
+    acf_hip_ctx::InputResize rz;
+    if (buildResizeTables(rows, cols, scale, rz.t) || rz.t.drows != dstRows || rz.t.dcols != dstCols)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_resize_u8: dst size must be acf_hip_resize_dims(rows, cols, scale)");
+    }
+    const int stride = rowStride > 0 ? rowStride : cols * cpp;
+    if (stride < cols * cpp)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "op_resize_u8: row stride smaller than a row");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // one-off buffers (an operator entry, not the hot path)
+    uint8_t *dS = nullptr, *dD = nullptr;
+    const size_t nS = size_t(stride) * rows, nD = size_t(dstRows) * dstCols * cpp;
+    std::vector<void*> tmp;
+    auto up = [&](int32_t** d, const std::vector<int32_t>& v) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(v.size(), 1) * 4) != hipSuccess)
+        {
+            return false;
+        }
+        tmp.push_back(p);
+        *d = static_cast<int32_t*>(p);
+        return v.empty() || hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = hipMalloc(reinterpret_cast<void**>(&dS), nS) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&dD), nD) == hipSuccess;
+    ok = ok && up(&rz.d_xlin, rz.t.xlin) && up(&rz.d_ylin, rz.t.ylin) && up(&rz.d_xrun, rz.t.xrun) && up(&rz.d_yrun, rz.t.yrun) && up(&rz.d_xtap, rz.t.xtap) &&
+        up(&rz.d_ytap, rz.t.ytap);
+    int rc = ACF_HIP_OK;
+    if (ok)
+    {
+        ok = hipMemcpy(dS, src, nS, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok)
+        {
+            rc = launchResizeU8(c, rz, dS, cpp, stride, 1, dD);
+        }
+        ok = ok && !rc && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(dst, dD, nD, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    for (void* p : tmp)
+    {
+        (void)hipFree(p);
+    }
+    (void)hipFree(dS);
+    (void)hipFree(dD);
+    if (!ok && !rc)
+    {
+        (void)hipGetLastError();
+        return fail(c, ACF_HIP_E_HIP, "op_resize_u8: device allocation or copy failed");
+    }
+    return rc;
 }
 
 static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes)
@@ -4587,8 +4764,10 @@ int acf_hip_stream_open(acf_hip_ctx* c, int pix, int rowStride, int cap, int dep
     {
         return fail(c, ACF_HIP_E_INVALID, "stream_open: the plan's input planes (d) must be 3 for colour layouts and 1 for GRAY");
     }
-    const int stride = rowStride > 0 ? rowStride : c->plan.W * cpp;
-    if (stride < c->plan.W * cpp)
+    // (with acf_hip_set_input_resize the submitted frames are the unreduced ones)
+    const int inRows = c->rz.on ? c->rz.rows : c->plan.H, inCols = c->rz.on ? c->rz.cols : c->plan.W;
+    const int stride = rowStride > 0 ? rowStride : inCols * cpp;
+    if (stride < inCols * cpp)
     {
         return fail(c, ACF_HIP_E_INVALID, "stream_open: row stride smaller than a row");
     }
@@ -4600,7 +4779,7 @@ int acf_hip_stream_open(acf_hip_ctx* c, int pix, int rowStride, int cap, int dep
     c->stCap = cap;
     c->nextTicket = c->nextCollect = 0;
     c->slots.resize(size_t(depth));
-    const size_t inBytes = size_t(c->maxBatch) * stride * c->plan.H;
+    const size_t inBytes = size_t(c->maxBatch) * stride * inRows;
     const size_t recBytes = size_t(c->maxBatch) * (1 + 6 * size_t(cap)) * sizeof(int32_t);
     for (auto& s : c->slots)
     {
@@ -4632,7 +4811,7 @@ int acf_hip_stream_submit(acf_hip_ctx* c, const uint8_t* frames_host, int nF, in
     HIPCHK(c, hipSetDevice(c->device));
     acf_hip_ctx::StreamSlot& s = c->slots[size_t(c->nextTicket % depth)];
     // The slot's previous batch was collected (checked above), so its device input and host records are free.
-    const size_t bytes = size_t(nF) * c->stStride * c->plan.H;
+    const size_t bytes = size_t(nF) * c->stStride * (c->rz.on ? c->rz.rows : c->plan.H);
     HIPCHK(c, hipMemcpyAsync(s.d_in, frames_host, bytes, hipMemcpyHostToDevice, c->copyStream));
     HIPCHK(c, hipEventRecord(s.evH2D, c->copyStream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, s.evH2D, 0));

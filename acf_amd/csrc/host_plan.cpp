@@ -633,3 +633,144 @@ void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes,
 }
 
 } // namespace acfhip
+
+
+// ---- resize to a minimum object width (apps' Resizer; OpenCV's CV_8U resize restated)
+namespace acfhip
+{
+namespace
+{
+int cvRoundD(double v) { return int(std::lrint(v)); }
+int cvFloorD(double v)
+{
+    const int i = int(v);
+    return i - (i > v);
+}
+int cvCeilD(double v)
+{
+    const int i = int(v);
+    return i + (i < v);
+}
+int satS16(float v)
+{
+    const long i = std::lrintf(v);
+    return int(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
+}
+void areaTab(int ssize, int dsize, double scale, std::vector<int32_t>& run, std::vector<int32_t>& tap)
+{
+    run.assign(size_t(dsize) * 2, 0);
+    tap.clear();
+    auto push = [&](int dx, int si, float alpha) {
+        int32_t bits;
+        std::memcpy(&bits, &alpha, 4);
+        if (run[size_t(dx) * 2 + 1] == 0)
+        {
+            run[size_t(dx) * 2] = int32_t(tap.size() / 2);
+        }
+        run[size_t(dx) * 2 + 1]++;
+        tap.push_back(si);
+        tap.push_back(bits);
+    };
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cellWidth = std::min(scale, ssize - fsx1);
+        int sx1 = cvCeilD(fsx1), sx2 = cvFloorD(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3)
+        {
+            push(dx, sx1 - 1, float((sx1 - fsx1) / cellWidth));
+        }
+        for (int sx = sx1; sx < sx2; sx++)
+        {
+            push(dx, sx, float(1.0 / cellWidth));
+        }
+        if (fsx2 - sx2 > 1e-3)
+        {
+            push(dx, sx2, float(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth));
+        }
+    }
+}
+} // namespace
+
+void resizeDims(int rows, int cols, double scale, int& drows, int& dcols)
+{
+    dcols = cvRoundD(cols * scale);
+    drows = cvRoundD(rows * scale);
+}
+
+int buildResizeTables(int rows, int cols, double scale, ResizeTables& t)
+{
+    t = ResizeTables();
+    if (rows < 1 || cols < 1 || !(scale > 0))
+    {
+        return 1;
+    }
+    t.rows = rows;
+    t.cols = cols;
+    resizeDims(rows, cols, scale, t.drows, t.dcols);
+    if (t.drows < 1 || t.dcols < 1)
+    {
+        return 1;
+    }
+    const double sc = 1. / scale; // scale_x == scale_y: the caller's factor, not recomputed from the sizes
+    const int isc = cvRoundD(sc);
+    const bool areaFast = std::fabs(sc - isc) < 2.220446049250313e-16;
+    // Resizer: INTER_AREA when scale < 1, INTER_LINEAR otherwise; cv::resize takes the area form only when reducing (and takes it
+    // for INTER_LINEAR at exactly 1/2)
+    if (scale < 1.f && sc >= 1)
+    {
+        if (areaFast)
+        {
+            t.mode = 2;
+            t.isx = t.isy = isc;
+            return 0;
+        }
+        t.mode = 1;
+        areaTab(cols, t.dcols, sc, t.xrun, t.xtap);
+        areaTab(rows, t.drows, sc, t.yrun, t.ytap);
+        return 0;
+    }
+    t.mode = 0;
+    t.xlin.resize(size_t(t.dcols) * 4);
+    t.ylin.resize(size_t(t.drows) * 4);
+    int xmax = t.dcols;
+    for (int dx = 0; dx < t.dcols; dx++)
+    {
+        float f = float((dx + 0.5) * sc - 0.5);
+        int sx = cvFloorD(f);
+        f -= sx;
+        if (sx < 0)
+        {
+            f = 0, sx = 0;
+        }
+        if (sx + 1 >= cols)
+        {
+            xmax = std::min(xmax, dx);
+            if (sx >= cols - 1)
+            {
+                f = 0, sx = cols - 1;
+            }
+        }
+        t.xlin[size_t(dx) * 4] = sx;
+        t.xlin[size_t(dx) * 4 + 1] = satS16((1.f - f) * 2048.f);
+        t.xlin[size_t(dx) * 4 + 2] = satS16(f * 2048.f);
+    }
+    for (int dx = 0; dx < t.dcols; dx++)
+    {
+        t.xlin[size_t(dx) * 4 + 3] = dx < xmax ? 1 : 0;
+    }
+    for (int dy = 0; dy < t.drows; dy++)
+    {
+        float f = float((dy + 0.5) * sc - 0.5);
+        const int sy = cvFloorD(f);
+        f -= sy;
+        t.ylin[size_t(dy) * 4] = std::min(std::max(sy, 0), rows - 1);
+        t.ylin[size_t(dy) * 4 + 1] = std::min(std::max(sy + 1, 0), rows - 1);
+        t.ylin[size_t(dy) * 4 + 2] = satS16((1.f - f) * 2048.f);
+        t.ylin[size_t(dy) * 4 + 3] = satS16(f * 2048.f);
+    }
+    return 0;
+}
+} // namespace acfhip

@@ -156,6 +156,19 @@ struct RankTables
 // chnOfNode[q] >= 0: node q tests a feature of that channel (fids[q] / (mW * mH)); < 0: not a feature test (leaf)
 void buildRankTables(const float* thrs, const int32_t* chnOfNode, size_t nNodes, int nChns, RankTables& out);
 
+// cv::resize of a packed 8-bit image by (scale, scale) as the apps' Resizer calls it (src/app/acf/acf.cpp:117-148): output size and
+// the tap tables of k_resize_u8 (OpenCV's published CV_8U algorithm; parity unpinned).
+struct ResizeTables
+{
+    int rows = 0, cols = 0, drows = 0, dcols = 0;
+    int mode = 0, isx = 1, isy = 1; // RZ_LINEAR / RZ_AREA / RZ_AREA_INT (kernels.hip.h)
+    std::vector<int32_t> xlin, ylin; // 4 ints per output column {sx, a0, a1, two} / row {r0, r1, b0, b1}
+    std::vector<int32_t> xrun, yrun; // 2 ints per output column / row {first tap, count}
+    std::vector<int32_t> xtap, ytap; // 2 ints per tap {source index, float bits}
+};
+void resizeDims(int rows, int cols, double scale, int& drows, int& dcols);
+int buildResizeTables(int rows, int cols, double scale, ResizeTables& t);
+
 int colorPlanes(const acf_hip_params& p);
 int numChannels(const acf_hip_params& p);
 

@@ -288,6 +288,117 @@ __global__ void __launch_bounds__(256) k_ingest_u8(IngestArgs a)
 // re-reads what it wrote), and the y exchange goes through a double-buffered
 // LDS column with one barrier per image column.
 // ------------------------------------------------------------------------
+// ------------------------------------------------------------------------
+// The apps' resize to a minimum object width (src/app/acf/acf.cpp:117-148 `Resizer`, GPUDetectionPipeline.cpp:250-266):
+// cv::resize of the packed 8-bit image by scale = winSize.width / minWidth, INTER_AREA when reducing, INTER_LINEAR else.
+// OpenCV is not part of the reference tree: the arithmetic is the published algorithm of imgproc/resize.cpp for CV_8U,
+// written down in DESIGN.md 6b (and restated on the CPU by the test checker) — PARITY UNPINNED.  One thread per
+// output pixel (all channels); the tap tables are built on the host in double precision (host_plan.cpp).
+//   RZ_LINEAR    x: {sx, a0, a1, two} per column, y: {r0, r1, b0, b1} per row; 11-bit fixed point:
+//                (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2 with h = S[sx] * a0 + S[sx + 1] * a1
+//   RZ_AREA      fractional scales: per output column / row a run of {source index, float weight}; per source row
+//                buf = sum S * alpha (taps ascending, from 0), then sum = beta * buf (first row), sum += beta * buf; cvRound
+//   RZ_AREA_INT  integral scales: (a + b + c + d + 2) >> 2 for 2 x 2, else cvRound(int sum * float(1 / area)); cells that
+//                reach past the source: cvRound(float(sum) / count) over the pixels inside
+// ------------------------------------------------------------------------
+enum
+{
+    RZ_LINEAR = 0,
+    RZ_AREA = 1,
+    RZ_AREA_INT = 2
+};
+struct ResizeArgs
+{
+    const uint8_t* src;
+    uint8_t* dst;
+    int32_t rows, cols, cn, stride, drows, dcols;
+    int64_t src_fs, dst_fs; // bytes per frame
+    int32_t mode, isx, isy;
+    const int4* xlin;   // RZ_LINEAR [dcols]
+    const int4* ylin;   // RZ_LINEAR [drows]
+    const int2* xrun;   // RZ_AREA [dcols] {first tap, count}
+    const int2* yrun;   // RZ_AREA [drows]
+    const int2* xtap;   // RZ_AREA {source column, float bits}
+    const int2* ytap;
+};
+__device__ __forceinline__ uint8_t rz_sat_u8(float v)
+{
+    const int i = __float2int_rn(v); // cvRound: round half to even
+    return uint8_t(min(max(i, 0), 255));
+}
+__global__ void __launch_bounds__(256) k_resize_u8(ResizeArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.dcols || dy >= a.drows)
+    {
+        return;
+    }
+    const uint8_t* __restrict__ S = a.src + int64_t(blockIdx.z) * a.src_fs;
+    uint8_t* __restrict__ D = a.dst + int64_t(blockIdx.z) * a.dst_fs + (int64_t(dy) * a.dcols + dx) * a.cn;
+    const int cn = a.cn;
+    if (a.mode == RZ_LINEAR)
+    {
+        const int4 X = a.xlin[dx], Y = a.ylin[dy];
+        const uint8_t* S0 = S + int64_t(Y.x) * a.stride + X.x * cn;
+        const uint8_t* S1 = S + int64_t(Y.y) * a.stride + X.x * cn;
+        const int nx = X.w ? cn : 0; // (beyond xmax the second tap is not read: S[sx] * 2048)
+        for (int c = 0; c < cn; c++)
+        {
+            const int h0 = X.w ? S0[c] * X.y + S0[nx + c] * X.z : S0[c] * 2048;
+            const int h1 = X.w ? S1[c] * X.y + S1[nx + c] * X.z : S1[c] * 2048;
+            D[c] = uint8_t((((Y.z * (h0 >> 4)) >> 16) + ((Y.w * (h1 >> 4)) >> 16) + 2) >> 2);
+        }
+        return;
+    }
+    if (a.mode == RZ_AREA_INT)
+    {
+        const int sy0 = dy * a.isy, sx0 = dx * a.isx;
+        const bool partial = sy0 + a.isy > a.rows || sx0 + a.isx > a.cols;
+        const int ny = min(a.isy, a.rows - sy0), nx = min(a.isx, a.cols - sx0);
+        const float sc = 1.f / float(a.isx * a.isy);
+        for (int c = 0; c < cn; c++)
+        {
+            int sum = 0;
+            for (int y = 0; y < ny; y++)
+            {
+                for (int x = 0; x < nx; x++)
+                {
+                    sum += S[int64_t(sy0 + y) * a.stride + (sx0 + x) * cn + c];
+                }
+            }
+            const int count = max(ny, 0) * max(nx, 0);
+            if (partial)
+            {
+                D[c] = count > 0 ? rz_sat_u8(float(sum) / float(count)) : uint8_t(0);
+            }
+            else
+            {
+                D[c] = (a.isx == 2 && a.isy == 2) ? uint8_t((sum + 2) >> 2) : rz_sat_u8(float(sum) * sc);
+            }
+        }
+        return;
+    }
+    const int2 xr = a.xrun[dx], yr = a.yrun[dy];
+    for (int c = 0; c < cn; c++)
+    {
+        float sum = 0.f;
+        for (int j = 0; j < yr.y; j++)
+        {
+            const int2 ty = a.ytap[yr.x + j];
+            const uint8_t* Sr = S + int64_t(ty.x) * a.stride + c;
+            float buf = 0.f;
+            for (int k = 0; k < xr.y; k++)
+            {
+                const int2 tx = a.xtap[xr.x + k];
+                buf = buf + float(Sr[tx.x * cn]) * __int_as_float(tx.y);
+            }
+            const float t = __int_as_float(ty.y) * buf;
+            sum = j == 0 ? t : sum + t;
+        }
+        D[c] = rz_sat_u8(sum);
+    }
+}
+
 struct SmoothJob
 {
     int32_t h, w, nplanes, out_cs; // out_cs: destination column stride (hP)

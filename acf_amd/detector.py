@@ -139,6 +139,42 @@ class HipDetector:
         n = n if n is not None else frames.shape[0]
         self._chk(self.lib.acf_hip_run_u8(self.ctx, C.c_void_p(_dev_ptr_u8(frames)), n, pix, row_stride))
 
+    # ---- the apps' resize to a minimum object width (acf.cpp:117-148 Resizer) in front of the 8-bit entries
+    @staticmethod
+    def resize_scale(win_width, min_width):
+        """scale = float(winSize.width) / float(minWidth), a float (acf.cpp:124)."""
+        return float(np.float32(win_width) / np.float32(min_width))
+
+    @staticmethod
+    def resize_dims(rows, cols, scale):
+        r, c_ = C.c_int(), C.c_int()
+        rc = capi.load().acf_hip_resize_dims(rows, cols, float(scale), C.byref(r), C.byref(c_))
+        if rc:
+            raise HipError(rc, "acf_hip_resize_dims")
+        return r.value, c_.value
+
+    def set_input_resize(self, src_rows, src_cols, scale):
+        """The plan must be for resize_dims(src_rows, src_cols, scale); the 8-bit entries then take src_rows x src_cols frames."""
+        self._chk(self.lib.acf_hip_set_input_resize(self.ctx, src_rows, src_cols, float(scale)))
+
+    def op_resize_u8(self, img, scale):
+        """img: uint8 [rows][cols][cpp] (host) -> the reduced image (cv::resize as the apps' Resizer calls it)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols, cpp = img.shape
+        dr, dc = self.resize_dims(rows, cols, scale)
+        out = np.zeros((dr, dc, cpp), dtype=np.uint8)
+        self._chk(self.lib.acf_hip_op_resize_u8(self.ctx, img.ctypes.data, rows, cols, cpp, 0, float(scale), out.ctypes.data, dr, dc))
+        return out
+
+    @staticmethod
+    def unscale_boxes(dets, scale):
+        """Resizer::operator()(objects): cv::Rect2f(o) * (1.f / scale) -> cv::Rect (float products, cvRound); dets: DET_DTYPE array."""
+        out = dets.copy()
+        inv = np.float32(1.0) / np.float32(scale)
+        for k in ("x", "y", "w", "h"):
+            out[k] = np.rint((dets[k].astype(np.float32) * inv).astype(np.float64)).astype(out[k].dtype)
+        return out
+
     # ---- streaming front end (pinned host frames in, pinned host records out)
     def stream_open(self, pix=capi.PIX_RGB, row_stride=0, cap=1024, depth=2):
         self._chk(self.lib.acf_hip_stream_open(self.ctx, pix, row_stride, cap, depth))

@@ -477,7 +477,7 @@ int HipDetector::operator()(const uint8_t* packed, int rows, int cols, int pix, 
     const int cpp = pix == ACF_HIP_PIX_GRAY ? 1 : (pix == ACF_HIP_PIX_RGBA || pix == ACF_HIP_PIX_BGRA) ? 4 : 3;
     const int stride = rowStrideBytes > 0 ? rowStrideBytes : cols * cpp;
     // one-frame stream: H2D on the copy stream, ingest + pyramid + cascade on the context's stream
-    if (m_streamCap == 0 || m_planH != rows || m_planW != cols || m_planD != (cpp == 1 ? 1 : 3) || m_dirty || pix != m_streamPix ||
+    if (m_streamCap == 0 || m_srcRows != rows || m_srcCols != cols || m_planD != (cpp == 1 ? 1 : 3) || m_dirty || pix != m_streamPix ||
         stride != m_streamStride)
     {
         streamOpen(rows, cols, pix, stride, std::max(1, m_planBatch), 2);
@@ -494,14 +494,48 @@ int HipDetector::operator()(const uint8_t* packed, int rows, int cols, int pix, 
     const int32_t* rec = nullptr;
     int n = 0;
     check(m_api->acf_hip_stream_collect(m_ctx, t, &rec, &n), "acf_hip_stream_collect");
+    const size_t first = objects.size();
     fetch(0, objects, scores); // every detection, not only the first `cap` of the record
+    if (m_minObjectWidth >= 0)
+    {
+        const float scale = inputScale();
+        if (scale != 1.f) // Resizer::operator()(objects), acf.cpp:134-143
+        {
+            for (size_t i = first; i < objects.size(); i++)
+            {
+                objects[i] = unscale(objects[i], scale);
+            }
+        }
+    }
     return 0;
+}
+
+Rect HipDetector::unscale(const Rect& o, float scale)
+{
+    // cv::Rect2f(o) * (1.f / scale) (acf.cpp:548-551: four float products) -> cv::Rect: saturate_cast<int> = cvRound of each field
+    const float inv = 1.f / scale;
+    Rect r;
+    r.x = int(std::lrint(double(float(o.x) * inv)));
+    r.y = int(std::lrint(double(float(o.y) * inv)));
+    r.width = int(std::lrint(double(float(o.width) * inv)));
+    r.height = int(std::lrint(double(float(o.height) * inv)));
+    return r;
 }
 
 void HipDetector::streamOpen(int rows, int cols, int pix, int rowStrideBytes, int maxBatch, int depth, int maxDetectionsPerFrame)
 {
     const int d = pix == ACF_HIP_PIX_GRAY ? 1 : 3;
-    ensurePlan(rows, cols, d, maxBatch);
+    int planRows = rows, planCols = cols;
+    const bool resize = m_minObjectWidth >= 0 && inputScale() != 1.f;
+    if (resize)
+    {
+        check(m_api->acf_hip_resize_dims(rows, cols, double(inputScale()), &planRows, &planCols), "acf_hip_resize_dims");
+    }
+    ensurePlan(planRows, planCols, d, maxBatch);
+    (void)m_api->acf_hip_stream_close(m_ctx); // (the input resize is set between the plan and the stream's buffers)
+    check(m_api->acf_hip_set_input_resize(m_ctx, resize ? rows : 0, resize ? cols : 0, double(inputScale())), "acf_hip_set_input_resize");
+    m_srcRows = rows;
+    m_srcCols = cols;
     check(m_api->acf_hip_stream_open(m_ctx, pix, rowStrideBytes, maxDetectionsPerFrame, depth), "acf_hip_stream_open");
     m_streamCap = maxDetectionsPerFrame;
     m_streamPix = pix;
@@ -551,6 +585,13 @@ void HipDetector::streamCollect(int ticket, std::vector<RectVec>& objects, std::
             bbs[size_t(i)].score = double(sc);
         }
         finish(bbs, objects[size_t(f)], scores ? &(*scores)[size_t(f)] : nullptr);
+        if (m_minObjectWidth >= 0 && inputScale() != 1.f)
+        {
+            for (Rect& o : objects[size_t(f)])
+            {
+                o = unscale(o, inputScale());
+            }
+        }
     }
 }
 

@@ -235,6 +235,15 @@ public:
     void setIsRowMajor(bool flag) { m_isRowMajor = flag; } // ACF.h:588-595: stored for callers that orient the window size by it
     bool getIsRowMajor() const { return m_isRowMajor; }
     Size getWindowSize() const { return opts.modelDs; }
+    // The apps' Resizer (src/app/acf/acf.cpp:117-148; GPUDetectionPipeline.cpp:250-266 computeDetectionWidth): search for objects of
+    // at least `width` pixels — the packed 8-bit entries (operator()(packed ...), streamOpen / streamSubmit) reduce every frame by
+    // scale = float(getWindowSize().width) / float(width) on the device (cv::resize: INTER_AREA when reducing, INTER_LINEAR else;
+    // OpenCV's CV_8U arithmetic restated, parity unpinned: include/acf_hip.h) and map the boxes back with cv::Rect2f(o) * (1.f / scale).
+    // width < 0 (default): off.
+    void setMinObjectWidth(int width) { m_minObjectWidth = width; m_dirty = true; }
+    int getMinObjectWidth() const { return m_minObjectWidth; }
+    float inputScale() const { return m_minObjectWidth >= 0 ? float(getWindowSize().width) / float(m_minObjectWidth) : 1.f; }
+    static Rect unscale(const Rect& o, float scale); // Resizer::operator()(objects) for one box
     int acfModify(const Modify& params); // acfModify.cpp:83-152
 
     // Detection: planar f32 transposed image (RGB in [0,1], or LUV after setIsLuv(true)); ACF.cpp:246-265.
@@ -319,6 +328,7 @@ private:
     int m_nChns = 0;
     std::vector<float> m_upright; // scratch for operator()(interleaved)
     int m_streamCap = 0, m_streamPix = -1, m_streamStride = 0;
+    int m_minObjectWidth = -1, m_srcRows = 0, m_srcCols = 0; // frame size handed to the 8-bit entries (== the plan's without a resize)
     bool m_taps = false; // "taps" option on: per-stage planes stay readable (needed by the logger)
     void* m_pin = nullptr; // pinned scratch of operator()(packed 8-bit)
     size_t m_pinBytes = 0;

@@ -3,7 +3,7 @@
 //
 //   acf_hip_detect --model m.acfm --frames f.raw --rows W --cols H --channels d --count N
 //                  [--luv] [--nms] [--batch] [--via-pyramid] [--max-count K] [--prune-ratio R]
-//   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] ...
+//   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] [--min-width M] ...
 //                  packed 8-bit upright frames; --stream B: batches of B frames through streamSubmit/streamCollect
 //   acf_hip_detect --convert in.acfm|in.cpb --out out.cpb                                  (model file conversion, no GPU)
 //   acf_hip_detect --dump-defaults                                                         (default Options tree, no GPU)
@@ -138,6 +138,7 @@ int main(int argc, char** argv)
         det.setDoNonMaximaSuppression(a.count("nms") != 0);
         if (a.count("max-count")) det.setMaxDetectionCount(size_t(std::stoul(a["max-count"])));
         if (a.count("prune-ratio")) det.setDetectionScorePruneRatio(std::stod(a["prune-ratio"]));
+        if (a.count("min-width")) det.setMinObjectWidth(std::stoi(a["min-width"])); // the apps' Resizer (acf.cpp:117-148), 8-bit entries
         if (a.count("casc-cal"))
         {
             HipDetector::Modify m;

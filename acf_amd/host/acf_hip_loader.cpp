@@ -57,6 +57,9 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_run_host)
     ACF_HIP_FN(acf_hip_pyramid_u8)
     ACF_HIP_FN(acf_hip_run_u8)
+    ACF_HIP_FN(acf_hip_resize_dims)
+    ACF_HIP_FN(acf_hip_set_input_resize)
+    ACF_HIP_FN(acf_hip_op_resize_u8)
     ACF_HIP_FN(acf_hip_stream_open)
     ACF_HIP_FN(acf_hip_stream_submit)
     ACF_HIP_FN(acf_hip_stream_collect)

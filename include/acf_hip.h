@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 7
+#define ACF_HIP_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -293,6 +293,24 @@ enum {
  * apart).  The plan's `d` must be 3 for the colour layouts and 1 for GRAY. */
 ACF_HIP_API int acf_hip_pyramid_u8(acf_hip_ctx* ctx, const uint8_t* frames_dev, int n_frames, int pix, int row_stride_bytes);
 ACF_HIP_API int acf_hip_run_u8(acf_hip_ctx* ctx, const uint8_t* frames_dev, int n_frames, int pix, int row_stride_bytes);
+
+/* The apps' resize to a minimum object width (src/app/acf/acf.cpp:117-148 `Resizer`,
+ * GPUDetectionPipeline.cpp:250-266 computeDetectionWidth): scale = float(winSize.width) /
+ * float(minWidth); cv::resize(image, reduced, {}, scale, scale, scale < 1 ? INTER_AREA :
+ * INTER_LINEAR) on the packed 8-bit frame, the detector on `reduced`, the boxes back by
+ * cv::Rect2f(o) * (1.f / scale).  cv::resize is OpenCV's (not part of the reference tree):
+ * the CV_8U arithmetic of its imgproc/resize.cpp is restated (DESIGN.md 6b says what
+ * exactly); PARITY UNPINNED.
+ *  acf_hip_resize_dims       the reduced size cv::resize produces: cvRound(rows * scale) x cvRound(cols * scale)
+ *  acf_hip_set_input_resize  after acf_hip_plan FOR THE REDUCED SIZE: from now on the 8-bit entries
+ *                            (acf_hip_pyramid_u8 / run_u8 / stream_*) take frames of src_rows x src_cols and
+ *                            reduce them on the device first (k_resize_u8); src_rows = 0 switches it off; a new
+ *                            plan switches it off
+ *  acf_hip_op_resize_u8      the resize alone, host buffers (dst: dst_rows x dst_cols x cpp, tight) */
+ACF_HIP_API int acf_hip_resize_dims(int rows, int cols, double scale, int* out_rows, int* out_cols);
+ACF_HIP_API int acf_hip_set_input_resize(acf_hip_ctx* ctx, int src_rows, int src_cols, double scale);
+ACF_HIP_API int acf_hip_op_resize_u8(acf_hip_ctx* ctx, const uint8_t* src_host, int rows, int cols, int cpp, int row_stride_bytes, double scale,
+    uint8_t* dst_host, int dst_rows, int dst_cols);
 
 /* ---- streaming front end ---------------------------------------------
  * The overlap of transfer and compute that GPUDetectionPipeline::runFast gets

@@ -2013,3 +2013,290 @@ ACFO_API int acfo_detect(const float* pyr, const acf_hip_params* p, const acf_hi
     free(hits);
     return n;
 }
+
+/* ------------------------------------------------------------------------
+ * f4: the apps' resize-to-minimum-object-width (src/app/acf/acf.cpp:117-148 `Resizer`, GPUDetectionPipeline.cpp:250-266):
+ *   scale = float(winSize.width) / float(minWidth);  cv::resize(image, reduced, {}, scale, scale, scale < 1 ? INTER_AREA : INTER_LINEAR)
+ * on the packed 8-bit RGB image, the detector on `reduced`, boxes back with cv::Rect2f(o) * (1.f / scale) -> cv::Rect.
+ * cv::resize is OpenCV (a hunter dependency, absent from /root/reference and from this image): PARITY UNPINNED.  What is
+ * restated here is the published algorithm of OpenCV's imgproc/resize.cpp for CV_8U (3.4 / 4.x, the generic C++ paths, whose SIMD
+ * forms are written to give the same bytes):
+ *  - dsize = (cvRound(cols * fx), cvRound(rows * fy)); scale_x = 1 / fx (the caller's fx, not recomputed from the sizes)
+ *  - INTER_AREA, both scales integral: exactly 2 x 2 -> (a + b + c + d + 2) >> 2; otherwise cvRound(int_sum * float(1 / area))
+ *  - INTER_AREA, fractional: float tables of overlap fractions (computeResizeAreaTab), per source row a horizontal
+ *    accumulation buf += S * alpha (k ascending), vertically sum = beta * buf for the first row, sum += beta * buf after, cvRound
+ *  - INTER_LINEAR (and INTER_AREA when a scale < 1 would enlarge): 11-bit fixed-point weights saturate_cast<short>(w * 2048),
+ *    horizontal S0 * a0 + S1 * a1 (int), vertical (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+ * cvRound = round half to even (lrint in the default rounding mode).
+ * ------------------------------------------------------------------------ */
+static int cv_round(double v)
+{
+    return (int)lrint(v);
+}
+static int cv_floor(double v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+static int cv_ceil(double v)
+{
+    int i = (int)v;
+    return i + (i < v);
+}
+static uint8_t sat_u8_f(float v)
+{
+    int i = (int)lrintf(v);
+    return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+static short sat_s16_f(float v)
+{
+    int i = (int)lrintf(v);
+    return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i));
+}
+
+ACFO_API void acfo_resize_dims(int rows, int cols, double fx, double fy, int* drows, int* dcols)
+{
+    *dcols = cv_round(cols * fx);
+    *drows = cv_round(rows * fy);
+}
+
+typedef struct
+{
+    int si, di;
+    float alpha;
+} AreaTap;
+
+/* computeResizeAreaTab (cn = 1: indices in pixels) */
+static int area_tab(int ssize, int dsize, double scale, AreaTap* tab)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        double fsx1 = dx * scale;
+        double fsx2 = fsx1 + scale;
+        double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = cv_ceil(fsx1), sx2 = cv_floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3)
+        {
+            tab[k].di = dx;
+            tab[k].si = sx1 - 1;
+            tab[k++].alpha = (float)((sx1 - fsx1) / cellWidth);
+        }
+        for (int sx = sx1; sx < sx2; sx++)
+        {
+            tab[k].di = dx;
+            tab[k].si = sx;
+            tab[k++].alpha = (float)(1.0 / cellWidth);
+        }
+        if (fsx2 - sx2 > 1e-3)
+        {
+            double a = fsx2 - sx2;
+            a = a < 1. ? a : 1.;
+            a = a < cellWidth ? a : cellWidth;
+            tab[k].di = dx;
+            tab[k].si = sx2;
+            tab[k++].alpha = (float)(a / cellWidth);
+        }
+    }
+    return k;
+}
+
+/* interp: 1 = INTER_LINEAR, 3 = INTER_AREA (OpenCV's enum values).  src [rows][stride bytes] with cn interleaved channels,
+ * dst tight [drows][dcols][cn]; drows / dcols from acfo_resize_dims. */
+ACFO_API int acfo_resize_u8(const uint8_t* src, int rows, int cols, int cn, int stride, double fx, double fy, int interp, uint8_t* dst, int drows, int dcols)
+{
+    if (!src || !dst || rows < 1 || cols < 1 || cn < 1 || cn > 4 || drows < 1 || dcols < 1 || fx <= 0 || fy <= 0)
+    {
+        return ACF_HIP_E_INVALID;
+    }
+    if (stride <= 0)
+    {
+        stride = cols * cn;
+    }
+    const double scale_x = 1. / fx, scale_y = 1. / fy;
+    const int iscale_x = cv_round(scale_x), iscale_y = cv_round(scale_y);
+    const int area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (interp == 1 && area_fast && iscale_x == 2 && iscale_y == 2)
+    {
+        interp = 3; /* "in case of scale_x && scale_y is equal to 2 INTER_AREA (fast) also is equal to INTER_LINEAR" */
+    }
+    if (interp == 3 && scale_x >= 1 && scale_y >= 1)
+    {
+        if (area_fast)
+        {
+            const int area = iscale_x * iscale_y;
+            const float sc = 1.f / (float)area;
+            for (int dy = 0; dy < drows; dy++)
+            {
+                for (int dx = 0; dx < dcols; dx++)
+                {
+                    for (int c = 0; c < cn; c++)
+                    {
+                        uint8_t* D = dst + ((size_t)dy * dcols + dx) * cn + c;
+                        const int sy0 = dy * iscale_y, sx0 = dx * iscale_x;
+                        if (sy0 + iscale_y > rows || sx0 + iscale_x > cols)
+                        {
+                            /* ResizeAreaFast_Invoker: columns >= w = ssize.width / scale_x and rows past the source take the partial-cell form */
+                            int sum = 0, count = 0;
+                            for (int sy = 0; sy < iscale_y; sy++)
+                            {
+                                if (sy0 + sy >= rows)
+                                {
+                                    break;
+                                }
+                                for (int sx = 0; sx < iscale_x; sx++)
+                                {
+                                    if (sx0 + sx >= cols)
+                                    {
+                                        break;
+                                    }
+                                    sum += src[(size_t)(sy0 + sy) * stride + (size_t)(sx0 + sx) * cn + c];
+                                    count++;
+                                }
+                            }
+                            *D = count ? sat_u8_f((float)sum / count) : 0;
+                            continue;
+                        }
+                        int sum = 0;
+                        for (int sy = 0; sy < iscale_y; sy++)
+                        {
+                            for (int sx = 0; sx < iscale_x; sx++)
+                            {
+                                sum += src[(size_t)(sy0 + sy) * stride + (size_t)(sx0 + sx) * cn + c];
+                            }
+                        }
+                        *D = (iscale_x == 2 && iscale_y == 2) ? (uint8_t)((sum + 2) >> 2) : sat_u8_f((float)sum * sc);
+                    }
+                }
+            }
+            return ACF_HIP_OK;
+        }
+        AreaTap* xtab = (AreaTap*)xmalloc(sizeof(AreaTap) * ((size_t)cols * 2 + 2));
+        AreaTap* ytab = (AreaTap*)xmalloc(sizeof(AreaTap) * ((size_t)rows * 2 + 2));
+        const int nx = area_tab(cols, dcols, scale_x, xtab), nyt = area_tab(rows, drows, scale_y, ytab);
+        float* buf = (float*)xmalloc(sizeof(float) * (size_t)dcols * cn);
+        float* sum = (float*)xmalloc(sizeof(float) * (size_t)dcols * cn);
+        int prev_dy = ytab[0].di;
+        for (int i = 0; i < dcols * cn; i++)
+        {
+            sum[i] = 0.f;
+        }
+        for (int j = 0; j < nyt; j++)
+        {
+            const float beta = ytab[j].alpha;
+            const int dy = ytab[j].di;
+            const uint8_t* S = src + (size_t)ytab[j].si * stride;
+            for (int i = 0; i < dcols * cn; i++)
+            {
+                buf[i] = 0.f;
+            }
+            for (int k = 0; k < nx; k++)
+            {
+                const float alpha = xtab[k].alpha;
+                for (int c = 0; c < cn; c++)
+                {
+                    buf[xtab[k].di * cn + c] += S[xtab[k].si * cn + c] * alpha;
+                }
+            }
+            if (dy != prev_dy)
+            {
+                uint8_t* D = dst + (size_t)prev_dy * dcols * cn;
+                for (int i = 0; i < dcols * cn; i++)
+                {
+                    D[i] = sat_u8_f(sum[i]);
+                    sum[i] = beta * buf[i];
+                }
+                prev_dy = dy;
+            }
+            else
+            {
+                for (int i = 0; i < dcols * cn; i++)
+                {
+                    sum[i] += beta * buf[i];
+                }
+            }
+        }
+        {
+            uint8_t* D = dst + (size_t)prev_dy * dcols * cn;
+            for (int i = 0; i < dcols * cn; i++)
+            {
+                D[i] = sat_u8_f(sum[i]);
+            }
+        }
+        free(xtab);
+        free(ytab);
+        free(buf);
+        free(sum);
+        return ACF_HIP_OK;
+    }
+    /* INTER_LINEAR (also INTER_AREA that would enlarge) */
+    int* xofs = (int*)xmalloc(sizeof(int) * (size_t)dcols);
+    short* ialpha = (short*)xmalloc(sizeof(short) * 2 * (size_t)dcols);
+    int xmax = dcols;
+    for (int dx = 0; dx < dcols; dx++)
+    {
+        float f = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(f);
+        f -= sx;
+        if (sx < 0)
+        {
+            f = 0, sx = 0;
+        }
+        if (sx + 1 >= cols)
+        {
+            xmax = xmax < dx ? xmax : dx;
+            if (sx >= cols - 1)
+            {
+                f = 0, sx = cols - 1;
+            }
+        }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_s16_f((1.f - f) * 2048.f);
+        ialpha[2 * dx + 1] = sat_s16_f(f * 2048.f);
+    }
+    for (int dy = 0; dy < drows; dy++)
+    {
+        float f = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(f);
+        f -= sy;
+        const short b0 = sat_s16_f((1.f - f) * 2048.f), b1 = sat_s16_f(f * 2048.f);
+        int r0 = sy < 0 ? 0 : (sy > rows - 1 ? rows - 1 : sy);
+        int r1 = sy + 1 < 0 ? 0 : (sy + 1 > rows - 1 ? rows - 1 : sy + 1);
+        const uint8_t *S0 = src + (size_t)r0 * stride, *S1 = src + (size_t)r1 * stride;
+        for (int dx = 0; dx < dcols; dx++)
+        {
+            const int sx = xofs[dx];
+            for (int c = 0; c < cn; c++)
+            {
+                int h0, h1;
+                if (dx < xmax)
+                {
+                    h0 = S0[sx * cn + c] * ialpha[2 * dx] + S0[(sx + 1) * cn + c] * ialpha[2 * dx + 1];
+                    h1 = S1[sx * cn + c] * ialpha[2 * dx] + S1[(sx + 1) * cn + c] * ialpha[2 * dx + 1];
+                }
+                else
+                {
+                    h0 = S0[sx * cn + c] * 2048;
+                    h1 = S1[sx * cn + c] * 2048;
+                }
+                dst[((size_t)dy * dcols + dx) * cn + c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xofs);
+    free(ialpha);
+    return ACF_HIP_OK;
+}
+
+/* Resizer::operator()(objects): o = cv::Rect2f(o) * (1.f / scale) -> cv::Rect (acf.cpp:134-143, 548-551): float products,
+ * Rect_<int>(Rect_<float>) = saturate_cast<int> of each field = cvRound. */
+ACFO_API void acfo_unscale_rect(float scale, const int* in, int* out)
+{
+    const float inv = 1.f / scale;
+    for (int k = 0; k < 4; k++)
+    {
+        out[k] = cv_round((double)((float)in[k] * inv));
+    }
+}

@@ -86,6 +86,12 @@ def lib():
         o.acfo_ldcf_plan.restype = C.c_int64
         o.acfo_ldcf_pyramid.argtypes = [fp, P, L, L, C.c_int, C.c_int, fp]
         o.acfo_ldcf_pyramid.restype = C.c_int
+        o.acfo_resize_dims.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        o.acfo_resize_dims.restype = None
+        o.acfo_resize_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        o.acfo_resize_u8.restype = C.c_int
+        o.acfo_unscale_rect.argtypes = [C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        o.acfo_unscale_rect.restype = None
         o.acfo_thrs_u8.argtypes = [fp, C.c_int, C.c_void_p]
         o.acfo_thrs_u8.restype = None
         o.acfo_mean_trees.argtypes = [fp, C.c_int, C.c_int, C.c_int, P]
@@ -269,6 +275,33 @@ def detect_ldcf(plan, lvL, pyrL, cap=1 << 16):
                           det.ctypes.data_as(C.POINTER(capi.Detection)), hits.ctypes.data_as(C.POINTER(capi.Hit)), cap)
     n = min(n, cap)
     return det[:n].copy(), hits[:n].copy()
+
+
+def resize_dims(rows, cols, scale):
+    r, c_ = C.c_int(), C.c_int()
+    lib().acfo_resize_dims(rows, cols, C.c_double(scale), C.c_double(scale), C.byref(r), C.byref(c_))
+    return r.value, c_.value
+
+
+def resize_u8(img, scale, interp=None):
+    """cv::resize(img, {}, scale, scale, INTER_AREA if scale < 1 else INTER_LINEAR) as restated by acfo_resize_u8 (the apps' Resizer)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols, cn = img.shape
+    dr, dc = resize_dims(rows, cols, scale)
+    out = np.zeros((dr, dc, cn), dtype=np.uint8)
+    if interp is None:
+        interp = 3 if np.float32(scale) < np.float32(1.0) else 1
+    rc = lib().acfo_resize_u8(img.ctypes.data, rows, cols, cn, 0, C.c_double(scale), C.c_double(scale), interp, out.ctypes.data, dr, dc)
+    if rc:
+        raise RuntimeError("acfo_resize_u8 rc=%d" % rc)
+    return out
+
+
+def unscale_rect(scale, box):
+    a = (C.c_int * 4)(*[int(v) for v in box])
+    o = (C.c_int * 4)()
+    lib().acfo_unscale_rect(C.c_float(scale), a, o)
+    return list(o)
 
 
 def thrs_u8(thrs):

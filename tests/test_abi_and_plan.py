@@ -23,7 +23,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), name
     # the ctypes binding covers the whole header
     assert sorted(capi.DECLARED_SYMBOLS) == declared
-    assert lib.acf_hip_abi_version() == 7
+    assert lib.acf_hip_abi_version() == 8
 
 
 def test_no_silent_cpu_fallback():
