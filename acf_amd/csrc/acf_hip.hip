@@ -215,7 +215,7 @@ struct acf_hip_ctx
     // The level chains' segments are OFF by default (option level_segments = n > 1 turns them on): a level is at most 480 columns,
     // so they only pay with warm-ups of ~32 columns (one frame: 412 -> 205 us), and channel planes have exactly-zero regions
     // wherever the image is flat (no gradient) — with the plane-level repair one such plane costs the whole chain again.
-    int levelSegments = getenv("ACF_HIP_LEVEL_SEGMENTS") ? atoi(getenv("ACF_HIP_LEVEL_SEGMENTS")) : 1;
+    int levelSegments = getenv("ACF_HIP_LEVEL_SEGMENTS") ? atoi(getenv("ACF_HIP_LEVEL_SEGMENTS")) : 0; // option level_segments: 0 = auto (small batches only), 1 = off
     int levelWarm = getenv("ACF_HIP_LEVEL_WARM") ? atoi(getenv("ACF_HIP_LEVEL_WARM")) : 32; // option level_warm
     // option count_repairs: planes the repair launches had to recompute (synchronises after every verify: measurements only)
     int countRepairs = 0;
