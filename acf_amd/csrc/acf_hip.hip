@@ -77,6 +77,7 @@ struct CascState
     // fixed depths other than 2 (k_cascade_tileD): stage 0 of the staged path on float tiles
     bool useTileD = false;
     CascTile* d_tilesD = nullptr;
+    uint32_t* d_tileOffD = nullptr;
     int nTilesD = 0, tbD = 0, t1D = 0;
     TileGeom geomD{};
     uint32_t* d_nodesD = nullptr;
@@ -1356,9 +1357,10 @@ struct TileSet
     // depths other than 2 (k_cascade_tileD): records of trees [0, t1D) in batches of tbD
     uint32_t* d_nodesD = nullptr;
     int tbD = 0, t1D = 0;
+    uint32_t* d_tileOffD = nullptr; // k_cascade_tile3D: tile offsets of every node, [tree][nTreeNodes]
 };
 
-static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out)
+static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out, bool allowPooledD = true)
 {
     const acf_hip_params& p = c->p;
     const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
@@ -1371,7 +1373,13 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     // Stage boundaries.  k_cascade_tile3 (pooled survivors, the default for depth 2): dense [0,16) on every window, dense
     // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.  k_cascade_tile2
     // (ACF_HIP_TILE2: every wave keeps its own windows): 32 dense trees then sparse pieces [32,64) and [64,128).
-    const bool pooled = p.treeDepth == 2 && !getenv("ACF_HIP_TILE2");
+    // (depths 3, 4 — and 1 with ACF_HIP_TILED_POOLED1: stumps reject slowly, half of a tile's windows are still alive at tree 32 and
+    // the staged queue's lanes = windows form beats items = windows x trees there (26 against 37 us per 1080p frame) —:
+    // k_cascade_tile3D, the same stages on float cells, for models of at least 32 trees; ACF_HIP_TILED_STAGED keeps k_cascade_tileD +
+    // the staged queue)
+    const bool pooledD = allowPooledD && !rank && ((p.treeDepth == 1 && getenv("ACF_HIP_TILED_POOLED1")) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
+        !getenv("ACF_HIP_TILED_STAGED");
+    const bool pooled = (p.treeDepth == 2 && !getenv("ACF_HIP_TILE2")) || pooledD;
     int bounds[5] = { 0, 32, 32, 64, 128 };
     if (pooled)
     {
@@ -1422,11 +1430,12 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
         }
         // k_cascade_tile3: leaf table + footprint + list 1 (later the codes of 64 windows) + list 2
         const int64_t nwin = int64_t(nw) * 64;
+        const int64_t leafBytes = pooledD ? int64_t(128) * 4 * (int64_t(1) << p.treeDepth) : int64_t(TILE3_LEAF_BYTES);
         if (int64_t(nChns) * rowsP * cols > 65535)
         {
             return int64_t(1) << 40; // (its list entries hold a window's first cell in 16 bits)
         }
-        return int64_t(TILE3_LEAF_BYTES) + int64_t(nChns) * rowsP * cols * cellBytes + ((std::max<int64_t>(nwin * 8, passW * int64_t(g.pitchC)) + 15) / 16 * 16) + nwin * 8 + 64;
+        return leafBytes + int64_t(nChns) * rowsP * cols * cellBytes + ((std::max<int64_t>(nwin * 8, passW * int64_t(g.pitchC)) + 15) / 16 * 16) + nwin * 8 + 64;
     };
     int nw = 0;
     if (const char* e = getenv(rank ? "ACF_HIP_RTILE_TR" : "ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
@@ -1456,7 +1465,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     }
     if (!nw)
     {
-        return ACF_HIP_OK;
+        return pooledD ? buildTileSet(c, lv, nChns, rank, out, false) : ACF_HIP_OK;
     }
     g.NW = nw;
     g.W = W;
@@ -1532,6 +1541,27 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
             for (int j = 0; j < NL; j++)
             {
                 memcpy(&d[2 * TB * NN + tq * NL + j], &c->hs[q + NN + j], 4);
+            }
+        }
+        if (g.pooled)
+        {
+            if (t1 != 32 || p.nTreeNodes < NN + NL || g.tileFloats > 65535)
+            {
+                return buildTileSet(c, lv, nChns, rank, out, false); // (k_cascade_tileD + the staged queue)
+            }
+            std::vector<uint32_t> to(size_t(p.nTrees) * p.nTreeNodes, 0u);
+            for (int t = 0; t < p.nTrees; t++)
+            {
+                for (int k = 0; k < NN; k++)
+                {
+                    const uint32_t f = c->fids[size_t(t) * p.nTreeNodes + k];
+                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
+                    to[size_t(t) * p.nTreeNodes + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
+                }
+            }
+            if ((rc = devUpload(c, &out.d_tileOffD, to)))
+            {
+                return rc;
             }
         }
         out.g = g;
@@ -1781,6 +1811,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             cs.t1D = tsD.t1D;
             cs.geomD = tsD.g;
             cs.d_nodesD = tsD.d_nodesD;
+            cs.d_tileOffD = tsD.d_tileOffD;
         }
     }
     if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
@@ -2305,7 +2336,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         q.pitch = rankPitch(l.hP);
         q.off = rankOff;
         padJobsR.push_back(q);
-        c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * l.hP * l.wP);
+        c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * (int64_t(l.wP) * (l.hP - l.hC) + int64_t(l.wP - l.wC) * l.hC)); // border cells
         rankOffs.push_back(rankOff);
         rankOff += int64_t(pl.nChns) * rankPitch(l.hP) * l.wP;
     }
@@ -4275,15 +4306,17 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
         // later stages see a shrinking survivor set; grid-stride loops cover any count
         const int qGrid[3] = { std::max(1, blocksPerFrame / 2), std::max(1, blocksPerFrame / 8), std::max(1, std::min(blocksPerFrame, 64)) };
         int firstStage = 0;
+        bool pooledTail = false; // k_cascade_tile3D has written the tail's leaf codes: no k_tail_codesD
         if (c->cs.useTileD && !c->noTiles)
         {
             // depths 1, 3, 4: trees [0, t1D) of every window from LDS tiles (k_cascade_tileD) instead of the first stages'
             // per-lane gathers from the pyramid; its survivors enter the queue of the stage that ends at t1D
             const auto& cs = c->cs;
             int sD = -1;
+            const int endD = cs.geomD.pooled ? cs.geomD.b[4] : cs.t1D; // last tree the tile kernel evaluates
             for (int i = 0; i < nStages; i++)
             {
-                if (bounds[size_t(i)] == cs.t1D)
+                if (bounds[size_t(i)] == endD)
                 {
                     sD = i;
                 }
@@ -4311,9 +4344,63 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                 at.maxHits = c->maxHits;
                 const int64_t total = int64_t(at.nTiles) * nF;
                 const int64_t perX = (total + 7) / 8;
+                int rcl = 0;
+                if (at.g.pooled)
+                {
+                    // k_cascade_tile3D: everything up to tree b[4]; the tail's codes come from its stage E
+                    at.tileOff = cs.d_tileOffD;
+                    at.thrs = c->cs.d_thrs;
+                    at.hs = c->cs.d_hs;
+                    at.nTrees = p.nTrees;
+                    at.nTreeNodes = p.nTreeNodes;
+                    pooledTail = !at.last && cs.codeCapD > 0;
+                    at.codes = pooledTail ? cs.d_codesD : nullptr;
+                    at.codeCap = pooledTail ? cs.codeCapD : 0;
+                    at.codePitch = cs.codePitchD;
+                    const size_t nwin = size_t(at.g.NW) * 64;
+                    const size_t lds = size_t(128) * 4 * (size_t(1) << p.treeDepth) + size_t(at.g.tileFloats) * 4 +
+                        ((std::max(nwin * 8, size_t(at.g.passW) * size_t(at.g.pitchC)) + 15) / 16 * 16) + nwin * 8;
+                    const int64_t resident = int64_t(256) * std::max<int64_t>(1, int64_t(160 * 1024) / int64_t((lds + 1279) / 1280 * 1280));
+                    const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
+                    const bool persist = c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
+                    // (the staged path's counters [stage][frame] start at d_qcounts; the tile counters sit behind them)
+                    at.tileNext = persist ? cs.d_qcounts + size_t(8) * c->maxBatch : nullptr;
+                    if (persist)
+                    {
+                        HIPCHK(c, hipMemsetAsync(at.tileNext, 0, sizeof(int32_t) * 8, c->stream));
+                    }
+                    dim3 grid((unsigned int)(persist ? (gridP + 7) / 8 * 8 : perX * 8)), block(at.g.NW * 64);
+                    prof(c, "k_cascade_tile");
+#define TILE3D_LAUNCH(N, DD, TT)                                                                         \
+    {                                                                                                    \
+        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT>), lds)))       \
+            return rcl;                                                                                  \
+        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT>), grid, block, lds, c->stream, at);              \
+    }
+#define TILE3D_DEPTH(N)                                    \
+    switch (p.treeDepth)                                   \
+    {                                                      \
+        case 1: TILE3D_LAUNCH(N, 1, 4); break;             \
+        case 3: TILE3D_LAUNCH(N, 3, 2); break;             \
+        default: TILE3D_LAUNCH(N, 4, 1); break;            \
+    }
+                    if (at.g.NW == 8)
+                    {
+                        TILE3D_DEPTH(8)
+                    }
+                    else
+                    {
+                        TILE3D_DEPTH(4)
+                    }
+#undef TILE3D_DEPTH
+#undef TILE3D_LAUNCH
+                    LAUNCHCHK(c, "k_cascade_tile3D");
+                    prof(c, "k_cascade");
+                }
+                else
+                {
                 const size_t lds = size_t(at.g.tileFloats) * 4;
                 dim3 grid((unsigned int)(perX * 8)), block(at.g.NW * 64);
-                int rcl = 0;
 #define TILED_LAUNCH(N, DD, TT)                                                                          \
     {                                                                                                    \
         if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tileD<N, DD, TT>), lds)))        \
@@ -4338,6 +4425,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
 #undef TILED_DEPTH
 #undef TILED_LAUNCH
                 LAUNCHCHK(c, "k_cascade_tileD");
+                }
                 firstStage = sD + 1;
             }
         }
@@ -4380,8 +4468,11 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                     a.codes = c->cs.d_codesD;
                     a.codeCap = c->cs.codeCapD;
                     a.codePitch = c->cs.codePitchD;
-                    hipLaunchKernelGGL(k_tail_codesD, grid, dim3(64), winBytes, c->stream, a);
-                    LAUNCHCHK(c, "k_tail_codesD");
+                    if (!pooledTail)
+                    {
+                        hipLaunchKernelGGL(k_tail_codesD, grid, dim3(64), winBytes, c->stream, a);
+                        LAUNCHCHK(c, "k_tail_codesD");
+                    }
                     const int nT = a.t1 - a.t0, NL = 1 << p.treeDepth;
                     const size_t ldsS = size_t((nT + 15) / 16 * 16) * NL * sizeof(float);
                     dim3 gridS(nF * ((a.codeCap + 255) / 256));

@@ -1089,24 +1089,38 @@ __device__ __forceinline__ int reflect_idx(int i, int n)
     return i;
 }
 
+// One thread per BORDER cell (a thread per cell of the padded level, the interior ones leaving at once, was the largest kernel of
+// cfg 4: pad [16 12] on 30 scales per octave, 4.3 ms per 192 VGA frames).  Per plane the items are: for every column x the
+// hP - hC rows above and below the interior (item = x * nb + k), then the hC interior rows of the wP - wC columns left and
+// right of it.
 template <class T> // float: the fused pyramid; uint16_t: its threshold-rank cells (a copied cell keeps its rank)
 __global__ void __launch_bounds__(256) k_pad_reflect(T* __restrict__ pyr, const PadJob* __restrict__ jobs, int64_t fs)
 {
     const PadJob j = jobs[blockIdx.y];
-    const int64_t cells = int64_t(j.hP) * j.wP;
+    const int nb = j.hP - j.hC, nc = j.wP - j.wC;
+    const int partA = j.wP * nb, perPlane = partA + nc * j.hC;
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= cells * j.nplanes)
+    if (e >= int64_t(perPlane) * j.nplanes)
     {
         return;
     }
-    const int c = int(e / cells);
-    const int rem = int(e - int64_t(c) * cells);
-    const int x = rem / j.hP, y = rem - x * j.hP;
-    const int sx = x - j.px, sy = y - j.py;
-    if (sx >= 0 && sx < j.wC && sy >= 0 && sy < j.hC)
+    const int c = int(e / perPlane);
+    const int item = int(e - int64_t(c) * perPlane);
+    int x, y;
+    if (item < partA)
     {
-        return; // interior
+        x = item / nb;
+        const int k = item - x * nb;
+        y = k < j.py ? k : j.hC + k;
     }
+    else
+    {
+        const int it = item - partA;
+        const int q = it / j.hC;
+        x = q < j.px ? q : j.wC + q;
+        y = j.py + (it - q * j.hC);
+    }
+    const int sx = x - j.px, sy = y - j.py;
     T* P = pyr + int64_t(blockIdx.z) * fs + j.off + int64_t(c) * j.pitch * j.wP;
     const int rx = reflect_idx(sx, j.wC) + j.px, ry = reflect_idx(sy, j.hC) + j.py;
     P[int64_t(x) * j.pitch + y] = P[int64_t(rx) * j.pitch + ry];
@@ -5949,6 +5963,15 @@ struct TileDArgs
     acf_hip_hit* hits;
     int32_t* counts;
     int32_t maxHits;
+    // k_cascade_tile3D (pooled survivors, see k_cascade_tile3): the model's heap-ordered nodes [tree][nTreeNodes] — tile offsets of
+    // the internal nodes, thresholds, leaves (hs: the last 2^D of a tree's entries) —, the leaf codes of the tail trees
+    const uint32_t* tileOff;
+    const float* thrs;
+    const float* hs;
+    int32_t nTrees, nTreeNodes;
+    uint8_t* codes; // [frame][codeCap][codePitch]: 4 * leaf index of every tree >= g.b[4] for the first codeCap queue entries
+    int32_t codeCap, codePitch;
+    int32_t* tileNext; // [8] per-XCD tile counters (persistent workgroups), or nullptr: one tile per workgroup
 };
 
 template <int D, int TB>
@@ -6113,6 +6136,358 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tileD(TileDArgs a)
         {
             a.qout[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
         }
+    }
+}
+
+// ------------------------------------------------------------------------
+// k_cascade_tile3D: k_cascade_tile3's pooled stages for the fixed depths other than 2 (acfDetect1.cpp:201-228 runs depth 1..8
+// through one body), on float cells.  A1 trees [0, b1) on every window and A2 trees [b1, b2) on the workgroup's pooled
+// survivors with tile_eval_d (all 2^D - 1 node compares of a tree as wave masks, the 2^D leaf adds under EXEC); S trees
+// [b2, b4) as leaf codes (a thread per (window, tree): the D-level walk with the tree's nodes in registers, picked by
+// select trees — no node record is fetched inside the walk) and ONE wave's ordered chain through the leaf table in LDS;
+// E the codes of the tail trees [b4, nTrees) for the windows that enter the tail queue (k_tail_scanD adds them up).
+// Before this kernel the depths 1, 3, 4 took trees [32, 128) from global memory (k_cascade_queue) and re-read every tail
+// window's footprint for its codes (k_tail_codesD): 86 us per 1080p frame at depth 3, 278 us at depth 4 against depth 2's 25.
+// ------------------------------------------------------------------------
+template <int N, class T>
+__device__ __forceinline__ T sel_pow2(const T* a, uint32_t j)
+{
+    if constexpr (N == 1)
+    {
+        return a[0];
+    }
+    else
+    {
+        const T lo = sel_pow2<N / 2, T>(a, j), hi = sel_pow2<N / 2, T>(a + N / 2, j);
+        return (j & uint32_t(N / 2)) ? hi : lo;
+    }
+}
+
+// the leaf a window reaches in one tree: o[] / th[] = the tree's internal nodes in heap order (node k's children 2k + 1 for
+// ftr < thr, 2k + 2 otherwise: getChild, acfDetect1.cpp:100-107); returns the leaf index 0 .. 2^D - 1, left to right
+template <int D, int L>
+__device__ __forceinline__ uint32_t walk_from(const float* win, const uint32_t (&o)[(1 << D) - 1], const float (&th)[(1 << D) - 1], uint32_t p)
+{
+    if constexpr (L == D)
+    {
+        return p;
+    }
+    else
+    {
+        // level L: p holds the L decisions so far, the node is the p-th of the level's 2^L (heap index 2^L - 1 + p)
+        const uint32_t off = sel_pow2<(1 << L), uint32_t>(o + ((1 << L) - 1), p);
+        const float thr = sel_pow2<(1 << L), float>(th + ((1 << L) - 1), p);
+        return walk_from<D, L + 1>(win, o, th, 2u * p + (win[off] < thr ? 0u : 1u));
+    }
+}
+template <int D>
+__device__ __forceinline__ uint32_t walk_tree(const float* win, const uint32_t (&o)[(1 << D) - 1], const float (&th)[(1 << D) - 1])
+{
+    return walk_from<D, 0>(win, o, th, 0u);
+}
+
+template <int NW, int D, int TB>
+__global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
+{
+    constexpr int NT = NW * 64, NN = (1 << D) - 1, NL = 1 << D, LB = 4 * NL, REC = TB * (2 * NN + NL);
+    constexpr int LEAF_BYTES = 128 * LB;
+    extern __shared__ float lds[];
+    __shared__ int s_n[4];
+    __shared__ int s_next[2];
+    float* leafT = lds;
+    float* tileF = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + LEAF_BYTES);
+    const int NWIN = a.g.TR * a.g.TC;
+    char* r1 = reinterpret_cast<char*>(tileF) + size_t(a.g.tileFloats) * 4;
+    const int passW = a.g.passW;
+    const int r1Bytes = (max(NWIN * 8, passW * a.g.pitchC) + 15) & ~15;
+    uint2* l1 = reinterpret_cast<uint2*>(r1);
+    uint8_t* codes = reinterpret_cast<uint8_t*>(r1);
+    uint2* l2 = reinterpret_cast<uint2*>(r1 + r1Bytes);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t total = int64_t(a.nTiles) * a.nFrames;
+    const int perX = int((total + 7) >> 3);
+    const int xcd = blockIdx.x & 7;
+    const bool persist = a.tileNext != nullptr;
+    if (tid == 0)
+    {
+        s_next[0] = persist ? atomicAdd(a.tileNext + xcd, 1) : int(blockIdx.x >> 3);
+    }
+    __syncthreads();
+    int li = s_next[0];
+    int par = 1;
+    const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
+    const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
+    const bool lastAll = tEnd == a.nTrees;
+    const bool wantE = !lastAll && a.codeCap > 0;
+    const float thrC = a.cascThr;
+    // the sparse stage: this thread's tree, its nodes in registers; the stage's leaf table
+    const int Ts = tEnd - b2, TsPad = (Ts + 15) & ~15;
+    const int tlShift = TsPad <= 32 ? 5 : (TsPad <= 64 ? 6 : 7);
+    const int pos = tid & ((1 << tlShift) - 1);
+    uint32_t so[NN];
+    float sth[NN];
+    {
+        const int64_t q = int64_t(b2 + min(pos, max(Ts, 1) - 1)) * a.nTreeNodes;
+#pragma unroll
+        for (int k = 0; k < NN; k++)
+        {
+            so[k] = Ts > 0 ? a.tileOff[q + k] : 0u;
+            sth[k] = Ts > 0 ? a.thrs[q + k] : 0.f;
+        }
+        for (int x = tid; x < TsPad * NL; x += NT)
+        {
+            const int t = x / NL, j = x - t * NL;
+            leafT[x] = t < Ts ? a.hs[int64_t(b2 + t) * a.nTreeNodes + NN + j] : -0.0f; // (padding: h + -0.0f == h for every h)
+        }
+    }
+    for (;;)
+    {
+        const int64_t id = int64_t(xcd) * perX + li;
+        if (li >= perX || id >= total) // (workgroup-uniform)
+        {
+            break;
+        }
+        int liNext = perX;
+        if (tid == 0 && persist)
+        {
+            liNext = atomicAdd(a.tileNext + xcd, 1);
+        }
+        const int frame = int(id / a.nTiles);
+        const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+        const int lvl = T.level;
+        const CascLevel L = a.levels[lvl];
+        if (tid < 4)
+        {
+            s_n[tid] = 0;
+        }
+        // ---- fill (k_cascade_tileD's)
+        {
+            const int colsT = a.g.colsT;
+            const int gr0 = T.r0 * step, gc0 = T.c0 * step;
+            const int colPitch = L.hP;
+            const int area = colPitch * L.wP;
+            const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+            const int colsValid = min(colsT, L.wP - gc0);
+            const uint32_t cps = uint32_t(rowsP) / 4u;
+            const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
+            const int ccMax = colsValid - 1;
+            for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
+            {
+                const uint32_t q = q0 + lane;
+                if (q < nChunks)
+                {
+                    const uint32_t seg = __umulhi(q, a.g.cpsMagic);
+                    const uint32_t j = q - seg * cps;
+                    const uint32_t z = __umulhi(seg, a.g.colsMagic);
+                    const int cc = int(seg - z * uint32_t(colsT));
+                    const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + 4u * j;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+                }
+            }
+        }
+        if (tid == 0)
+        {
+            s_next[par] = liNext;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nWinR = L.nWinR;
+        auto emit = [&](bool alive, uint32_t tw, float h) -> int {
+            const int tag = int(tw & 0xffffu);
+            const int rl = tag % TR, cl = tag / TR;
+            const EmitDst dst{ a.hits, a.counts, a.qout, a.qoutCount, a.maxHits, a.qcap };
+            return tile_emit3(dst, lastAll, frame, alive, lvl, (T.c0 + cl) * nWinR + (T.r0 + rl), nWinR, h);
+        };
+        auto finish = [&](bool alive, uint32_t tw, float h) {
+            const int slot = emit(alive, tw, h);
+            if (wantE)
+            {
+                const unsigned long long m = __ballot(alive);
+                if (m)
+                {
+                    int base = 0;
+                    if (lane == 0)
+                    {
+                        base = atomicAdd(&s_n[3], __popcll(m));
+                    }
+                    base = __shfl(base, 0);
+                    if (alive)
+                    {
+                        l2[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slot), tw);
+                    }
+                }
+            }
+        };
+        auto append = [&](bool alive, uint32_t tw, float h, uint2* list, int* cnt) {
+            const unsigned long long m = __ballot(alive);
+            if (m)
+            {
+                int base = 0;
+                if (lane == 0)
+                {
+                    base = atomicAdd(cnt, __popcll(m));
+                }
+                base = __shfl(base, 0);
+                if (alive)
+                {
+                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(__float_as_uint(h), tw);
+                }
+            }
+        };
+        // ---- A1
+        {
+            const int r_l = lane % TR, c_l = (lane / TR) * NW + wv;
+            bool alive = (T.r0 + r_l) < nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / TR) * TR;
+            float h = 0.f;
+            const uint32_t woff = uint32_t((min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step);
+            tile_eval_d<D, TB>(tileF + woff, a.nodesD, b1 / TB, thrC, h, alive);
+            const uint32_t tw = uint32_t(c_l * TR + r_l) | (woff << 16);
+            if (b1 == tEnd)
+            {
+                finish(alive, tw, h);
+            }
+            else
+            {
+                append(alive, tw, h, b1 == b2 ? l2 : l1, b1 == b2 ? &s_n[1] : &s_n[0]);
+            }
+        }
+        __syncthreads();
+        // ---- A2
+        if (b1 < b2)
+        {
+            const int n1 = s_n[0];
+            for (int e0 = wv * 64; e0 < n1; e0 += NT)
+            {
+                const int e = e0 + lane;
+                bool alive = e < n1;
+                const uint2 en = l1[alive ? e : e0];
+                float h = __uint_as_float(en.x);
+                tile_eval_d<D, TB>(tileF + (en.y >> 16), a.nodesD + size_t(b1 / TB) * REC, (b2 - b1) / TB, thrC, h, alive);
+                if (b2 == tEnd)
+                {
+                    finish(alive, en.y, h);
+                }
+                else
+                {
+                    append(alive, en.y, h, l2, &s_n[1]);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- S
+        if (b2 < tEnd)
+        {
+            const int n2 = s_n[1];
+            const int wpr = NT >> tlShift;
+            const int pitchC = a.g.pitchC;
+            int nE = 0;
+            for (int p0 = 0; p0 < n2; p0 += passW)
+            {
+                const int nP = min(passW, n2 - p0);
+                for (int wi = tid >> tlShift; wi < nP; wi += wpr)
+                {
+                    const float* win = tileF + (l2[p0 + wi].y >> 16);
+                    const uint32_t leaf = walk_tree<D>(win, so, sth);
+                    if (pos < TsPad)
+                    {
+                        codes[wi * pitchC + pos] = pos < Ts ? uint8_t(4u * leaf) : uint8_t(0);
+                    }
+                }
+                __syncthreads();
+                if (wv == 0)
+                {
+                    const bool valid = lane < nP;
+                    const uint2 en = l2[p0 + (valid ? lane : 0)];
+                    float h = __uint_as_float(en.x);
+                    float hMin = __builtin_inff();
+                    const uint8_t* crow = codes + (valid ? lane : 0) * pitchC;
+                    const char* lt = reinterpret_cast<const char*>(leafT);
+                    uint32_t cb[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                    {
+                        cb[k] = crow[k];
+                    }
+                    for (int t = 0; t < TsPad; t += 16)
+                    {
+                        float lf[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                        {
+                            lf[k] = *reinterpret_cast<const float*>(lt + LB * (t + k) + cb[k]);
+                        }
+                        const int tn = min(t + 16, TsPad - 16);
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                        {
+                            cb[k] = crow[tn + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; k += 2)
+                        {
+                            const float h1 = h + lf[k];
+                            const float h2 = h1 + lf[k + 1];
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
+                            h = h2;
+                        }
+                    }
+                    const bool alive = valid && hMin > thrC;
+                    const int slot = emit(alive, en.y, h);
+                    if (wantE)
+                    {
+                        const unsigned long long m = __ballot(alive);
+                        __builtin_amdgcn_wave_barrier();
+                        if (alive)
+                        {
+                            l2[nE + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slot), en.y);
+                        }
+                        nE += __popcll(m);
+                    }
+                }
+                __syncthreads();
+            }
+            if (wantE && tid == 0)
+            {
+                s_n[3] = nE;
+            }
+        }
+        __syncthreads();
+        li = s_next[par];
+        par ^= 1;
+        if (!wantE)
+        {
+            continue;
+        }
+        // ---- E: the codes of the tail trees for this tile's queue entries: lanes = trees, one 64-tree batch per wave at a time
+        const int nTail = s_n[3];
+        if (nTail != 0)
+        {
+            const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
+            for (int b = wv; b < nB; b += NW)
+            {
+                uint32_t eo[NN];
+                float eth[NN];
+                const int64_t q = int64_t(tEnd + min(b * 64 + lane, nT - 1)) * a.nTreeNodes;
+#pragma unroll
+                for (int k = 0; k < NN; k++)
+                {
+                    eo[k] = a.tileOff[q + k];
+                    eth[k] = a.thrs[q + k];
+                }
+                for (int s = 0; s < nTail; s++)
+                {
+                    const uint2 en = l2[s];
+                    const int slot = int(en.x);
+                    if (slot < 0 || slot >= a.codeCap)
+                    {
+                        continue; // no code row: k_cascade_tail takes this entry
+                    }
+                    const uint32_t leaf = walk_tree<D>(tileF + (en.y >> 16), eo, eth);
+                    a.codes[(int64_t(frame) * a.codeCap + slot) * a.codePitch + b * 64 + lane] = b * 64 + lane < nT ? uint8_t(4u * leaf) : uint8_t(0);
+                }
+            }
+        }
+        __syncthreads(); // (the next tile's fill rewrites the cells stage E reads)
     }
 }
 

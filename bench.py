@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--no-nms", action="store_true", help="export the raw detections (scale, column, row order) instead of the survivors of the "
                     "device bbNms + prune (Detector::operator()'s default: maxg, overlap .65 / min, at most 10 per frame)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
+    ap.add_argument("--turns", type=int, default=-1, help="A/B: option cascade_turns of every context (default: what DetectorPool sets, 5 with several contexts)")
+    ap.add_argument("--persist", type=int, default=-1, help="A/B: option tile_persist of every context (default: what DetectorPool sets, 0 with several contexts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
@@ -321,6 +323,10 @@ def main():
             # several contexts side by side already fill each other's gaps: a context's real scales stay on its one stream
             # (acf_hip.h, scale_streams; measured: 3 contexts 12.1k frames/s with 0, 11.6k with 1; one context 9.8k / 10.5k)
             det.set_option("scale_streams", 0)
+        if args.turns >= 0:
+            det.set_option("cascade_turns", args.turns)
+        if args.persist >= 0:
+            det.set_option("tile_persist", args.persist)
         if not args.keep_pyramid and args.config != 5:
             det.set_option("keep_pyramid", 0)
         if not args.no_profile:

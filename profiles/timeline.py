@@ -12,7 +12,7 @@ for r in rows:
     n = r["Kernel_Name"].replace("acfhip::", "").split("(")[0].replace("void ", "")
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n))
 ev.sort()
-tiles = [e for e in ev if "k_cascade_tile2" in e[2]]
+tiles = [e for e in ev if "k_cascade_tile" in e[2]]
 # the timed region: the last 12 tile launches (4 steps x 3 contexts)
 t0 = tiles[-12][0] - 8_000_000
 t1 = tiles[-1][1] + 1_000_000

@@ -52,6 +52,9 @@ VARIANTS = [
     "ACF_HIP_GRAPH=1",
 ]
 LDCF_VARIANTS = ["", "ACF_HIP_LDCF_UNFUSED=1", "ACF_HIP_LDCF_UNFUSED=1 ACF_HIP_RESAMPLE_GENERIC=1"]
+# fixed depths other than 2: the pooled tile kernel (k_cascade_tile3D) and the forms an environment variable selects instead
+DEPTH_VARIANTS = [(1, ""), (1, "ACF_HIP_TILED_POOLED1=1"), (1, "ACF_HIP_TILED_POOLED1=1 ACF_HIP_TILE_PERSIST=0"), (3, ""), (3, "ACF_HIP_TILED_STAGED=1"),
+                  (3, "ACF_HIP_TILE_PERSIST=0"), (3, "ACF_HIP_TILE_NW=4"), (3, "ACF_HIP_NO_TAIL_CODES=1"), (4, ""), (4, "ACF_HIP_TILED_STAGED=1"), (4, "ACF_HIP_TILE_PERSIST=0")]
 
 
 def _run(setting, *args):
@@ -73,3 +76,9 @@ def test_environment_selected_form_matches_the_oracle(setting):
 def test_environment_selected_ldcf_form_matches_the_oracle(setting):
     r = _run(setting, "ldcf")
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (setting, r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("depth,setting", DEPTH_VARIANTS)
+def test_fixed_depth_forms_match_the_oracle(depth, setting):
+    r = _run(setting, "depth%d" % depth)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (depth, setting, r.stdout[-1500:], r.stderr[-1500:])

@@ -18,12 +18,15 @@ def main():
     ldcf = len(sys.argv) > 1 and sys.argv[1] == "ldcf"
     H, W, nF = 480, 640, 2
     kw = dict(name="FACE80", nTrees=300, cascThr=-3.0)
+    if len(sys.argv) > 1 and sys.argv[1].startswith("depth"):
+        d = int(sys.argv[1][5:])
+        kw = dict(name="FACE80", nTrees=300, cascThr=-3.0 if d == 1 else -2.0, treeDepth=d)
     if ldcf:
         kw = dict(name="FACE80", nTrees=256, ldcfK=4, cascThr=-2.0)  # (tests/test_gpu_pipeline.py, face80_k4_vga)
     model = synth.make_model(seed=11, **kw)
     frames = np.stack([synth.make_frame(900 + i, H, W, "luv") for i in range(nF)])
     plan = ob.Plan(model, H, W, 3)
-    det = HipDetector(model, H, W, 3, max_batch=nF, max_hits=1 << 15)
+    det = HipDetector(model, H, W, 3, max_batch=nF, max_hits=1 << 17)
     det.run(torch.from_numpy(frames).cuda(), nF)
     total = 0
     for f in range(nF):
@@ -32,7 +35,7 @@ def main():
             lvL, pyrL, _ = ob.ldcf(plan, pyr)
             want, wh = ob.detect_ldcf(plan, lvL, pyrL)
         else:
-            want, wh = ob.detect(plan, pyr)
+            want, wh = ob.detect(plan, pyr, cap=1 << 17)
         got, gh = det.detections(f)
         if not np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)):
             print("pyramid differs, frame", f)
