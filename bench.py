@@ -61,6 +61,7 @@ def kernel_bytes_per_frame(det, model):
     b["k_tri_x"] = sum(2 * n * 4 for n in np_real)
     b["k_tri_y"] = sum(2 * n * 4 for n in np_real)
     b["k_chns"] = sum(3 * n * 4 + (nC - d) * (n // (sh * sh)) * 4 for n in np_real)  # M, S, O in; magnitude + histogram channels out
+    b["k_triy_chns"] = b["k_chns"]  # the fused y pass: U (instead of S), M, O in; the same channels out
     b["k_resample(image)"] = sum(d * 4 * np_real[1] + d * 4 * np_real[i] for i in range(2, len(np_real))) if len(np_real) > 2 else 0
     b["k_level(fused)"] = raw_real + pyr          # real levels' raw channels in, padded pyramid out
     b["k_level(smooth)"] = 2 * pyr
@@ -81,11 +82,11 @@ def kernel_bytes_per_frame(det, model):
     return b
 
 
-PMC_FILE = "profiles/r03_pmc_traffic.json"
+PMC_FILE = "profiles/r04_pmc_traffic.json"
 
 
 def pmc_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary (PMC_FILE, produced by profiles/r03_profile.sh:
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC summary (PMC_FILE, produced by profiles/r04_profile.sh:
     FETCH_SIZE x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KB -> bytes), or None.  Not measured
     in this run: the line says so (roofline.traffic_source)."""
     try:
@@ -512,36 +513,50 @@ def main():
             kb = kernel_bytes_per_frame(det, model)
             dom = max(prof, key=lambda k: prof[k][0])
             launches = max(prof[dom][1], 1)
-            avg_ms = prof[dom][0] / launches
+            # a kernel may take several launches per batch (one per real scale): its figures are per BATCH of B frames — the
+            # summed duration of the launches one batch needs — so that bytes and time cover the same frames
+            batches = C * args.steps
+            avg_ms = prof[dom][0] / batches
             frames_per_launch = C * B * args.steps / launches
-            # dominant kernel of the TIMED REGION: its algorithmic bytes per launch / its average launch duration there (HIP
-            # events on the launch stream; with C contexts the launch shares the machine with other contexts' kernels, which
+            # dominant kernel of the TIMED REGION: its algorithmic bytes per batch / its duration per batch there (HIP
+            # events on the launch stream; with C contexts the launches share the machine with other contexts' kernels, which
             # is how it runs in the product and what produced `value`)
-            ach = kb.get(dom, 0) * frames_per_launch / (avg_ms * 1e-3) / 1e9
+            ach = kb.get(dom, 0) * B / (avg_ms * 1e-3) / 1e9
             # whole hot path: B = B_in + 2*B_pyr per frame over the wall clock of the timed region (kernel times of
             # concurrent contexts overlap, so their sum is not elapsed time)
             path = b_frame * C * B * args.steps / dt / 1e9
+
+            def kernel_line(k):
+                ms_b = prof[k][0] / batches
+                a_ = kb.get(k, 0) * B / (ms_b * 1e-3) / 1e9
+                tr = pmc_traffic(k, B)
+                return {"kernel": k, "ms_per_batch": ms_b, "launches_per_batch": prof[k][1] / batches, "achieved": a_, "frac": a_ / HBM_PEAK_GBS,
+                        "bytes_moved_frac": (tr / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
             roof.update({
                 "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
-                # what the kernel really moves (PMC bytes of the committed pass) over its launch time here, as a fraction of peak:
-                # the rank-cell tile kernel reads half of the 4 bytes per cell that `achieved` charges (SURVEY.md 8d's figure)
-                "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (pmc_traffic(dom, B) and frames_per_launch == B) else None,
-                "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_share": prof[dom][0] / tot_ms,
-                "kernel_bytes_per_launch": kb.get(dom, 0) * frames_per_launch,
-                "measured": "inside the timed region (%d contexts sharing the GPU)" % C,
+                # what the kernel really moves (PMC bytes of the committed pass, all its launches of a batch) over its duration per
+                # batch here, as a fraction of peak: e.g. the rank-cell tile kernel reads half of the 4 bytes per cell that `achieved`
+                # charges it (SURVEY.md 8d's figure)
+                "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_traffic(dom, B) else None,
+                "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_launches_per_batch": launches / batches, "kernel_share": prof[dom][0] / tot_ms,
+                "kernel_bytes_per_launch": kb.get(dom, 0) * B,
+                "measured": "inside the timed region (%d contexts sharing the GPU); per batch of %d frames" % (C, B),
                 "path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
+                # the three largest kernels of the region, same figures (two of them are within a few percent of each other)
+                "top_kernels": [kernel_line(k) for k in sorted(prof, key=lambda k: -prof[k][0])[:3]],
                 # summed over the C contexts of a step (they run concurrently: the sum exceeds ms_per_step when C > 1)
                 "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             })
             if solo.get(dom):
                 # the same kernel with the GPU to itself (same process, buffers and event mechanism; 3 launches right after the
                 # timed region): a property of the kernel, next to the figure of the configuration that produced `value`
-                s_ms = solo[dom][0] / max(solo[dom][1], 1)
+                s_ms = solo[dom][0] / 3  # per batch: 3 solo runs
                 s_ach = kb.get(dom, 0) * B / (s_ms * 1e-3) / 1e9
-                roof["solo"] = {"note": "same kernel, one context alone on the GPU, 3 launches after the timed region",
+                roof["solo"] = {"note": "same kernel, one context alone on the GPU, 3 batches after the timed region; per batch",
                                 "kernel_avg_ms": s_ms, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
                                 "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_traffic(dom, B) else None,
-                                "kernels_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])}}
+                                "kernels_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])},
+                                "kernels_ms_per_batch": {k: round(v[0] / 3, 4) for k, v in sorted(solo.items(), key=lambda kv: -kv[1][0])}}
                 # every kernel's HBM rate alone: committed PMC traffic of all its launches in a step (profiles/r02_pmc_traffic.json,
                 # measured with this batch size) over the time of those launches here; GB/s (fraction of the 8 TB/s peak)
                 rates = {}

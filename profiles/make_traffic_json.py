@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Build profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
 
-usage: make_traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <frames_per_step> > profiles/r02_pmc_traffic.json
+usage: make_traffic_json.py <fetch counter_collection.csv> <write counter_collection.csv> <frames_per_step> > profiles/r04_pmc_traffic.json
 Bytes per launch = FETCH_SIZE*f + WRITE_SIZE (KB -> bytes); f = 2 for kernels whose reads are 16 B/lane streams (gfx950's
 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md §HBM), 1 otherwise (uncalibrated).  Launches of one bench
 "kernel" (prof name) are summed: k_level(fused) = all k_level<R,mode> launches of a step, etc.
