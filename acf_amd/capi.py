@@ -218,7 +218,7 @@ def load():
         "acf_hip_op_conv_tri": ([ctx, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "acf_hip_op_gradient_mag": ([ctx, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "acf_hip_selftest_gradmag": ([ctx, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)], C.c_int),
-        "acf_hip_op_gradient_hist": ([ctx, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+        "acf_hip_op_gradient_hist": ([ctx, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "acf_hip_op_im_resample": ([ctx, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double], C.c_int),
         "acf_hip_op_acf_detect1": ([ctx, fp, C.c_int, C.c_int, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
         "acf_hip_op_acf_detect1_u8": ([ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),

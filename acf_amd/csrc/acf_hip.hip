@@ -2931,6 +2931,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     const int64_t np0 = int64_t(H) * W;
     c->pyramidValid = c->detectValid = false;
     int rc;
+    bool ingestConverted = false; // the 8-bit ingest wrote the converted colour planes itself
     PackedSrc reduced{};
     if (u8 && c->rz.on)
     {
@@ -2952,7 +2953,8 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     {
         // 8-bit ingest (ACF.cpp:114-119,137; MatP.cpp:51-73), fused with the colour conversion below when there is one
         prof(c, "k_ingest_u8");
-        if (c->d_color)
+        ingestConverted = c->d_color && p.colorSpace != ACF_HIP_CS_HSV; // (hsv: planar ingest, then k_rgb2hsv like a float frame)
+        if (ingestConverted)
         {
             if ((rc = launchIngest(c, *u8, nF, c->d_color, int64_t(d) * np0, true)))
             {
@@ -2979,7 +2981,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     const float* cur = frames; // "I"
     int64_t cur_fs = int64_t(d_in) * np0;
     int curH = H, curW = W;
-    if (c->d_color && u8)
+    if (ingestConverted)
     {
         cur = c->d_color;
         cur_fs = int64_t(d) * np0;
@@ -3012,6 +3014,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             {
                 hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs, mr, mg, mb);
             }
+        }
+        else if (p.colorSpace == ACF_HIP_CS_HSV)
+        {
+            hipLaunchKernelGGL(k_rgb2hsv, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs); // (d_in == 3: the plan checked)
         }
         else // ORIG / RGB with a 1-plane input: replicate
         {
@@ -3415,6 +3421,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         a.nOrients = p.nOrients;
         a.doNorm = p.normRad != 0;
         a.full = p.full;
+        a.hardBin = p.softBin < 0;
         a.normConst = float(p.normConst);
         a.rq_y = shrinkGainY(shrink);
         // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
@@ -5697,6 +5704,10 @@ int acf_hip_op_rgb_convert(acf_hip_ctx* c, const float* in, float* out, int h, i
         const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
         hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, (const float*)di, dout, n, int64_t(0), int64_t(0), mr, mg, mb);
     }
+    else if (flag == ACF_HIP_CS_HSV)
+    {
+        hipLaunchKernelGGL(k_rgb2hsv, grid, block, 0, c->stream, (const float*)di, dout, n, int64_t(0), int64_t(0));
+    }
     else
     {
         return fail(c, ACF_HIP_E_UNSUPPORTED, "op_rgb_convert: flag");
@@ -5844,12 +5855,16 @@ int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O,
     return ACF_HIP_OK;
 }
 
-int acf_hip_op_gradient_hist(acf_hip_ctx* c, const float* M, const float* O, float* H, int h, int w, int bin, int nOrients, int full)
+int acf_hip_op_gradient_hist(acf_hip_ctx* c, const float* M, const float* O, float* H, int h, int w, int bin, int nOrients, int softBin, int full)
 {
     OP_PROLOGUE(c);
     if (!M || !O || !H || h <= 0 || w <= 0 || nOrients < 1 || nOrients > 12)
     {
         return fail(c, ACF_HIP_E_INVALID, "op_gradient_hist: arguments");
+    }
+    if (softBin % 2 != 0)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_gradient_hist: odd softBin (trilinear spatial binning) is not built");
     }
     if ((bin != 2 && bin != 4) || h % bin || w % bin)
     {
@@ -5873,6 +5888,7 @@ int acf_hip_op_gradient_hist(acf_hip_ctx* c, const float* M, const float* O, flo
     a.histEnabled = 1;
     a.nOrients = nOrients;
     a.full = full;
+    a.hardBin = softBin < 0;
     a.rq_y = shrinkGainY(bin);
     int rc = launchChns(c, a, bin, 1);
     if (rc)

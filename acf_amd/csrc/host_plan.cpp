@@ -341,9 +341,11 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
         err = "plan: binSize != shrink";
         return ACF_HIP_E_UNSUPPORTED;
     }
-    if (p.softBin != 0)
+    // gradHist's branches (gradientMex.cpp:391-509): softBin even — orientation interpolated (>= 0) or nearest bin (< 0), no spatial
+    // interpolation — are built; odd softBin is the trilinear form (HOG / FHOG features, not an ACF channel set)
+    if (p.softBin % 2 != 0)
     {
-        err = "plan: softBin != 0";
+        err = "plan: odd softBin (trilinear spatial binning) is not built";
         return ACF_HIP_E_UNSUPPORTED;
     }
     if (p.nApprox > 0 && p.nLambdas != 3 && p.nLambdas != 0)
@@ -356,10 +358,16 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
         err = "plan: no channels enabled";
         return ACF_HIP_E_INVALID;
     }
-    if (p.colorSpace != ACF_HIP_CS_LUV && p.colorSpace != ACF_HIP_CS_GRAY && p.colorSpace != ACF_HIP_CS_ORIG && p.colorSpace != ACF_HIP_CS_RGB)
+    if (p.colorSpace != ACF_HIP_CS_LUV && p.colorSpace != ACF_HIP_CS_GRAY && p.colorSpace != ACF_HIP_CS_ORIG && p.colorSpace != ACF_HIP_CS_RGB &&
+        p.colorSpace != ACF_HIP_CS_HSV)
     {
         err = "plan: colour space";
         return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.isLuv && p.colorSpace == ACF_HIP_CS_HSV)
+    {
+        err = "plan: isLuv with hsv (rgbConvert.cpp:150-155)";
+        return ACF_HIP_E_INVALID;
     }
     if (d_in == 1 && !(p.colorSpace == ACF_HIP_CS_GRAY || p.colorSpace == ACF_HIP_CS_ORIG))
     {

@@ -104,6 +104,58 @@ __global__ void __launch_bounds__(256) k_rgb2gray(const float* __restrict__ in, 
 }
 
 // Replicate one plane to three (chnsPyramid.cpp:242-243), colorSpace "orig".
+// rgb2hsv (toolbox/rgbConvertMex.cpp:194-238), nrm = 1: three planes in, H, S, V out.  IEEE divisions; h * float(1 / 6.0).
+__global__ void __launch_bounds__(256) k_rgb2hsv(const float* __restrict__ in, float* __restrict__ out, int n, int64_t in_fs, int64_t out_fs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    const float* I = in + int64_t(blockIdx.z) * in_fs;
+    float* J = out + int64_t(blockIdx.z) * out_fs;
+    const float r = I[i], g = I[n + i], b = I[2 * int64_t(n) + i];
+    float h, s, v;
+    if (r == g && g == b)
+    {
+        h = 0.f;
+        s = 0.f;
+        v = r * 1.0f;
+    }
+    else
+    {
+        float maxv, minv;
+        if (r >= g && r >= b)
+        {
+            maxv = r;
+            minv = g < b ? g : b;
+            h = (g - b) / (maxv - minv) + 6;
+            if (h >= 6)
+            {
+                h -= 6;
+            }
+        }
+        else if (g >= r && g >= b)
+        {
+            maxv = g;
+            minv = r < b ? r : b;
+            h = (b - r) / (maxv - minv) + 2;
+        }
+        else
+        {
+            maxv = b;
+            minv = r < g ? r : g;
+            h = (r - g) / (maxv - minv) + 4;
+        }
+        h *= (float)(1 / 6.0);
+        s = 1 - minv / maxv;
+        v = maxv * 1.0f;
+    }
+    J[i] = h;
+    J[n + i] = s;
+    J[2 * int64_t(n) + i] = v;
+}
+
 __global__ void __launch_bounds__(256) k_replicate3(const float* __restrict__ in, float* __restrict__ out, int n, int64_t in_fs, int64_t out_fs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1914,6 +1966,7 @@ struct ChnsArgs
     int64_t sm_fs, m_fs, chns_fs;
     int32_t h, w, d;
     int32_t colorEnabled, magEnabled, histEnabled, nOrients, doNorm, full;
+    int32_t hardBin;   // softBin < 0: the nearest orientation bin takes the whole magnitude (gradQuantize's interpolate == false, gradientMex.cpp:316-327,355-370)
     int32_t colorDone; // the colour channels were already written by k_smooth_vec: skip them, keep their slots
     float normConst, rq; // rq = (1/S)/(1+1e-6) then /S in the y pass (imResampleMex.cpp:145-157,316)
     float rq_y;
@@ -2081,8 +2134,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     _Pragma("unroll") for (int yy = 0; yy < 4; yy++)                                        \
                     {                                                                                       \
                         const float ob_ = ov[xx][yy] * oMult;                                               \
-                        int o0_ = (int)ob_;                                                                 \
-                        const float od_ = ob_ - (float)o0_;                                                 \
+                        /* hardBin: o0 = (int)(o + .5f), M0 = m, M1 = 0 — adding that +0.0f to a bin changes no bit */ \
+                        int o0_ = ca.hardBin ? (int)(ob_ + .5f) : (int)ob_;                                 \
+                        const float od_ = ca.hardBin ? 0.f : ob_ - (float)o0_;                              \
                         o0_ = (o0_ >= nO) ? 0 : o0_;                                                        \
                         int o1_ = o0_ + 1;                                                                  \
                         o1_ = (o1_ == nO) ? 0 : o1_;                                                        \
@@ -2400,8 +2454,9 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
             for (int yy = 0; yy < S; yy++)
             {
                 const float o = ov[xx][yy] * oMult;
-                int o0 = (int)o;
-                const float od = o - (float)o0;
+                // (hardBin: the nearest bin takes everything; m1 = +0.0f changes no bit of the bin it is added to)
+                int o0 = a.hardBin ? (int)(o + .5f) : (int)o;
+                const float od = a.hardBin ? 0.f : o - (float)o0;
                 if (o0 >= nO)
                 {
                     o0 = 0; // o0*nb >= oMax

@@ -303,12 +303,12 @@ class HipDetector:
         self._chk(self.lib.acf_hip_op_gradient_mag(self.ctx, capi.fptr(a), capi.fptr(M), capi.fptr(O), capi.fptr(S), h, w, normRad, normConst, full))
         return M, O, S
 
-    def op_gradient_hist(self, M, O, bin=4, nOrients=6, full=0):
+    def op_gradient_hist(self, M, O, bin=4, nOrients=6, full=0, softBin=0):
         M = np.ascontiguousarray(M, dtype=np.float32)
         O = np.ascontiguousarray(O, dtype=np.float32)
         w, h = M.shape
         H = np.zeros((nOrients, w // bin, h // bin), dtype=np.float32)
-        self._chk(self.lib.acf_hip_op_gradient_hist(self.ctx, capi.fptr(M), capi.fptr(O), capi.fptr(H), h, w, bin, nOrients, full))
+        self._chk(self.lib.acf_hip_op_gradient_hist(self.ctx, capi.fptr(M), capi.fptr(O), capi.fptr(H), h, w, bin, nOrients, softBin, full))
         return H
 
     def op_im_resample(self, a, hb, wb, nrm=1.0):

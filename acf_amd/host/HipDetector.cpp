@@ -982,7 +982,7 @@ int HipDetector::gradientMag(const MatP& I, MatP& M, MatP& O, int normRad, doubl
     return 0;
 }
 
-int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full)
+int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full, int softBin)
 {
     if (!m_ctx)
     {
@@ -990,7 +990,7 @@ int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize
         check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
     }
     H.create(M.rows() / binSize, M.cols() / binSize, nOrients);
-    check(m_api->acf_hip_op_gradient_hist(m_ctx, M.data(), O.data(), H.data(), M.cols(), M.rows(), binSize, nOrients, full), "acf_hip_op_gradient_hist");
+    check(m_api->acf_hip_op_gradient_hist(m_ctx, M.data(), O.data(), H.data(), M.cols(), M.rows(), binSize, nOrients, softBin, full), "acf_hip_op_gradient_hist");
     return 0;
 }
 

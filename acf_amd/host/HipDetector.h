@@ -302,7 +302,7 @@ public:
     int rgbConvert(const MatP& I, MatP& J, const std::string& colorSpace);
     int convTri(const MatP& I, MatP& J, double r, bool inPlaceSemantics = false);
     int gradientMag(const MatP& I, MatP& M, MatP& O, int normRad, double normConst, int full);
-    int gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full);
+    int gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize, int nOrients, int full, int softBin = 0); // softBin even (gradientMex.cpp:391-509)
 
     acf_hip_ctx* context() { return m_ctx; }
 

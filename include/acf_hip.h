@@ -56,7 +56,7 @@ enum {
     ACF_HIP_CS_GRAY = 0,
     ACF_HIP_CS_RGB = 1,
     ACF_HIP_CS_LUV = 2,
-    ACF_HIP_CS_HSV = 3, /* unsupported */
+    ACF_HIP_CS_HSV = 3,
     ACF_HIP_CS_ORIG = 4
 };
 
@@ -418,9 +418,11 @@ ACF_HIP_API int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float
  * every float bit pattern first_bits .. last_bits taken as m2: *mismatches = how many differ in either result,
  * *first_bad_bits = the smallest such pattern.  0 .. 0x7f7fffff (every finite m2 >= 0) must give 0. */
 ACF_HIP_API int acf_hip_selftest_gradmag(acf_hip_ctx* ctx, uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, uint32_t* first_bad_bits);
-/* Detector::gradientHist (gradientHist.cpp:92-115), softBin 0. */
+/* Detector::gradientHist (gradientHist.cpp:92-115) -> gradHist (gradientMex.cpp:375-509): soft_bin even — >= 0 the magnitude
+ * is shared between the two nearest orientation bins, < 0 the nearest bin takes it; no spatial interpolation.  Odd soft_bin
+ * (trilinear: HOG / FHOG features) is ACF_HIP_E_UNSUPPORTED. */
 ACF_HIP_API int acf_hip_op_gradient_hist(acf_hip_ctx* ctx, const float* M, const float* O, float* H,
-    int h, int w, int bin, int nOrients, int full);
+    int h, int w, int bin, int nOrients, int soft_bin, int full);
 /* imResample (imResampleMex.cpp:385-420). */
 ACF_HIP_API int acf_hip_op_im_resample(acf_hip_ctx* ctx, const float* in, float* out, int ha, int wa, int hb, int wb, int d, double nrm);
 /* Detector::acfDetect1 on one host channel buffer [nChns][wP][hP] (acfDetect1.cpp:309-335). */

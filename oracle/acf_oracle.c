@@ -558,6 +558,54 @@ ACFO_API void acfo_rgb2luv(const float* I, float* J, int n)
 }
 
 /* rgb2gray — T/rgbConvertMex.cpp:241-252 (nrm = 1) */
+/* rgb2hsv<float,float>, nrm = 1 — T/rgbConvertMex.cpp:194-238 */
+ACFO_API void acfo_rgb2hsv(const float* I, float* J, int n)
+{
+    float *H = J, *S = H + n, *V = S + n;
+    const float *R = I, *G = R + n, *B = G + n;
+    const float nrm = 1.0f;
+    for (int i = 0; i < n; i++)
+    {
+        const float r = R[i], g = G[i], b = B[i];
+        float h, s, v, minv, maxv;
+        if (r == g && g == b)
+        {
+            H[i] = 0;
+            S[i] = 0;
+            V[i] = r * nrm;
+            continue;
+        }
+        else if (r >= g && r >= b)
+        {
+            maxv = r;
+            minv = g < b ? g : b;
+            h = (g - b) / (maxv - minv) + 6;
+            if (h >= 6)
+            {
+                h -= 6;
+            }
+        }
+        else if (g >= r && g >= b)
+        {
+            maxv = g;
+            minv = r < b ? r : b;
+            h = (b - r) / (maxv - minv) + 2;
+        }
+        else
+        {
+            maxv = b;
+            minv = r < g ? r : g;
+            h = (r - g) / (maxv - minv) + 4;
+        }
+        h *= (float)(1 / 6.0);
+        s = 1 - minv / maxv;
+        v = maxv * nrm;
+        H[i] = h;
+        S[i] = s;
+        V[i] = v;
+    }
+}
+
 ACFO_API void acfo_rgb2gray(const float* I, float* J, int n)
 {
     const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
@@ -961,15 +1009,18 @@ ACFO_API void acfo_grad_mag_norm(float* M, const float* S, int h, int w, float n
 }
 
 /* ------------------------------------------------------------------------
- * a8  gradQuantize + gradHist, softBin >= 0 and even ("interpolate w.r.t.
- * orientation only") — T/gradientMex.cpp:278-372, 375-391, 451-509.
+ * a8  gradQuantize + gradHist — T/gradientMex.cpp:278-372, 375-509: softBin even, >= 0 ("interpolate w.r.t. orientation
+ * only", :451-509) or < 0 ("no interpolation w.r.t. either orientation or spatial bin", :391-450).  Odd softBin (trilinear
+ * spatial binning, :511 on, and the 8/7 boundary normalisation :636-662 — HOG / FHOG features) is not restated.
  * ---------------------------------------------------------------------- */
 ACFO_API int acfo_grad_hist(const float* M, const float* O, float* H, int h, int w, int bin, int nOrients, int softBin, int full)
 {
-    if (softBin < 0 || softBin % 2 != 0)
+    if (softBin % 2 != 0)
     {
-        return ACF_HIP_E_UNSUPPORTED;
+        return ACF_HIP_E_UNSUPPORTED; /* trilinear (:511 on) and the 8/7 boundary normalisation of odd softBin (:636-662) */
     }
+    const int interpolate = softBin >= 0;           /* gradQuantize(..., softBin >= 0), :391 */
+    const int second = !(softBin < 0 && softBin % 2 == 0); /* the branch that also adds M1 into O1 (:451) */
     const int hb = h / bin, wb = w / bin, h0 = hb * bin, w0 = wb * bin, nb = wb * hb;
     const float s = (float)bin, sInv2 = 1 / s / s;
     const float oMult = (float)nOrients / (full ? 2 * ACFO_PI : ACFO_PI);
@@ -982,7 +1033,7 @@ ACFO_API int acfo_grad_hist(const float* M, const float* O, float* H, int h, int
     {
         const float* Oc = O + (size_t)x * h;
         const float* Mc = M + (size_t)x * h;
-        for (int i = 0; i < h0; i++) /* gradQuantize, interpolate=true :296-313,331-353 */
+        for (int i = 0; i < h0 && interpolate; i++) /* gradQuantize, interpolate=true :296-313,331-353 */
         {
             float o = Oc[i] * oMult;
             int o0 = (int)o;
@@ -1003,13 +1054,30 @@ ACFO_API int acfo_grad_hist(const float* M, const float* O, float* H, int h, int
             M1[i] = od * m;
             M0[i] = m - M1[i];
         }
+        for (int i = 0; i < h0 && !interpolate; i++) /* interpolate=false :316-327,355-370 */
+        {
+            float o = Oc[i] * oMult;
+            int o0 = (int)(o + .5f);
+            o0 *= nb;
+            if (o0 >= oMax)
+            {
+                o0 = 0;
+            }
+            O0[i] = o0;
+            M0[i] = Mc[i] * sInv2;
+            M1[i] = 0;
+            O1[i] = 0;
+        }
         float* H1 = H + (size_t)(x / bin) * hb; /* :454 */
         for (int y = 0; y < h0;)
         {
             for (int y1 = 0; y1 < bin; y1++)
             {
                 H1[O0[y]] += M0[y];
-                H1[O1[y]] += M1[y];
+                if (second)
+                {
+                    H1[O1[y]] += M1[y];
+                }
                 y++;
             }
             H1++;
@@ -1494,9 +1562,9 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
     {
         return ACF_HIP_E_INVALID; /* CV_Assert(is.size() >= 2), :351 */
     }
-    if (p->softBin != 0)
+    if (p->softBin % 2 != 0)
     {
-        return ACF_HIP_E_UNSUPPORTED;
+        return ACF_HIP_E_UNSUPPORTED; /* trilinear spatial binning (odd softBin): not restated */
     }
     const int shrink = p->shrink;
     const size_t np0 = (size_t)H * W;
@@ -1537,6 +1605,18 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
         {
             I = (float*)xmalloc(sizeof(float) * np0 * 3);
             acfo_rgb2luv(pI, I, (int)np0);
+            free(pI);
+            d = 3;
+        }
+        else if (cs == ACF_HIP_CS_HSV)
+        {
+            if (p->isLuv || d_in != 3)
+            {
+                free(pI);
+                return ACF_HIP_E_INVALID; /* CV_Assert(flag == 2) :150-155; CV_Assert(flag == 0) for one plane :140-148 */
+            }
+            I = (float*)xmalloc(sizeof(float) * np0 * 3);
+            acfo_rgb2hsv(pI, I, (int)np0);
             free(pI);
             d = 3;
         }

@@ -46,6 +46,8 @@ def lib():
         o.acfo_acos_table.restype = fp
         o.acfo_rgb2luv.argtypes = [fp, fp, C.c_int]
         o.acfo_rgb2gray.argtypes = [fp, fp, C.c_int]
+        o.acfo_rgb2hsv.argtypes = [fp, fp, C.c_int]
+        o.acfo_rgb2hsv.restype = None
         o.acfo_ingest_u8.argtypes = [C.c_void_p] + [C.c_int] * 7 + [fp, C.c_int]
         o.acfo_ingest_u8.restype = None
         o.acfo_conv_tri1.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]

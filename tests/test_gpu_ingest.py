@@ -72,6 +72,7 @@ INGEST_CASES = [
     ("gray_gray", 240, 320, capi.PIX_GRAY, 0, dict(name="FACE64", nTrees=128, cascThr=-2.5), 1),                     # 1 plane, rgb2gray of the replicated plane
     ("rgb_to_gray", 120, 160, capi.PIX_RGB, 0, dict(name="FACE64", nTrees=128, cascThr=-4.0, minDs_h=32, minDs_w=32), 3),
     ("rgba_passthrough", 96, 128, capi.PIX_RGBA, 0, dict(name="TINY", nTrees=96, cascThr=-3.0), 3),     # isLuv model: planes taken as they are
+    ("bgr_hsv", 120, 160, capi.PIX_BGR, 0, dict(name="INRIA", nTrees=64, cascThr=-3.0, nOctUp=0, colorSpace=capi.CS_HSV), 3),  # planar ingest, then k_rgb2hsv
 ]
 
 

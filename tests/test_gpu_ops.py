@@ -139,14 +139,19 @@ def test_gradient_mag_normalised(dev, oracle, h, w):
 @pytest.mark.parametrize("h,w", [(64, 48), (120, 160), (1080, 64)])
 @pytest.mark.parametrize("bin", [4, 2])
 @pytest.mark.parametrize("full", [0, 1])
-def test_gradient_hist(dev, oracle, h, w, bin, full):
+@pytest.mark.parametrize("softBin", [0, 2, -2])
+def test_gradient_hist(dev, oracle, h, w, bin, full, softBin):
     M = rnd(h + w + bin, (w, h), 0, 0.6)
     hi = 2 * np.pi if full else np.pi
     O = rnd(h + w + bin + 1, (w, h), 0.0, float(hi) - 1e-6)
-    got = dev.op_gradient_hist(M, O, bin, 6, full)
+    got = dev.op_gradient_hist(M, O, bin, 6, full, softBin)
     want = np.zeros_like(got)
-    assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(want), h, w, bin, 6, 0, full) == 0
+    assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(want), h, w, bin, 6, softBin, full) == 0
     assert np.array_equal(bits(got), bits(want))
+    if softBin < 0:
+        soft = np.zeros_like(got)
+        assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(soft), h, w, bin, 6, 0, full) == 0
+        assert not np.array_equal(bits(soft), bits(want))  # (the two branches do differ on this input)
 
 
 RESAMPLE_CASES = [
@@ -179,6 +184,12 @@ def test_rgb2luv(dev, oracle, h, w):
     wg = np.zeros((1, w, h), np.float32)
     oracle.lib().acfo_rgb2gray(oracle.F(a), oracle.F(wg), h * w)
     assert np.array_equal(bits(g), bits(wg))
+    a[:, :3, :5] = np.float32(0.5)  # grey pixels: rgb2hsv's first branch
+    a[0, 3:6, :5] = a[1, 3:6, :5]   # r == g ties
+    hsv = dev.op_rgb_convert(a, capi.CS_HSV)
+    wh = np.zeros_like(a)
+    oracle.lib().acfo_rgb2hsv(oracle.F(a), oracle.F(wh), h * w)
+    assert np.array_equal(bits(hsv), bits(wh))
 
 
 @pytest.mark.parametrize("tiles", [1, 0])

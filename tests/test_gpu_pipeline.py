@@ -23,6 +23,11 @@ CONFIGS = {
     "all_real": (120, 160, "luv", 3, dict(name="TINY", nTrees=64, nApprox=0, minDs_h=32, minDs_w=32)),
     "shrink2": (96, 128, "luv", 3, dict(name="TINY", nTrees=64, shrink=2, modelDsPad_h=16, modelDsPad_w=16, minDs_h=32, minDs_w=32)),
     "face80_vga": (480, 640, "luv", 3, dict(name="FACE80", nTrees=512)),
+    # gradHist's other even-softBin branch (nearest orientation bin, gradientMex.cpp:391-450) and a positive even value (same branch as 0)
+    "hardbin_vga": (480, 640, "luv", 3, dict(name="FACE80", nTrees=256, softBin=-2, cascThr=-2.0)),
+    "softbin2": (200, 260, "luv", 3, dict(name="TINY", nTrees=128, softBin=2, cascThr=-2.5)),
+    # rgbConvert to HSV (rgbConvertMex.cpp:194-238)
+    "rgb_hsv": (240, 320, "rgb", 3, dict(name="INRIA", nTrees=128, colorSpace=capi.CS_HSV, cascThr=-3.0)),
 }
 
 

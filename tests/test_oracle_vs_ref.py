@@ -133,17 +133,30 @@ def test_grad_mag_norm_within_rcp_bound(oracle, refk, h, w):
 
 @pytest.mark.parametrize("h,w", SIZES)
 @pytest.mark.parametrize("full", [0, 1])
-def test_grad_hist_bit_exact(oracle, refk, h, w, full):
-    """Same M,O in -> identical histograms (accumulation order x-major, y-minor, O0 then O1)."""
+@pytest.mark.parametrize("softBin", [0, 2, -2])
+def test_grad_hist_bit_exact(oracle, refk, h, w, full, softBin):
+    """Same M,O in -> identical histograms (accumulation order x-major, y-minor, O0 then O1), in both even-softBin branches of
+    gradHist (gradientMex.cpp:391-509): orientation interpolated (>= 0), nearest bin (< 0)."""
     M = oracle.aligned_copy(rnd(h * w + 5, (w, h), 0.0, 0.6))
     hi = 2 * np.pi if full else np.pi
     O = oracle.aligned_copy(rnd(h * w + 6, (w, h), 0.0, float(hi) - 1e-6))
     hb, wb = h // 4, w // 4
     H_r, H_o = oracle.aligned((6, wb, hb)), oracle.aligned((6, wb, hb))
-    refk.ref_gradHist(oracle.F(M), oracle.F(O), oracle.F(H_r), h, w, 4, 6, 0, full)
-    assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(H_o), h, w, 4, 6, 0, full) == 0
+    refk.ref_gradHist(oracle.F(M), oracle.F(O), oracle.F(H_r), h, w, 4, 6, softBin, full)
+    assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(H_o), h, w, 4, 6, softBin, full) == 0
     assert np.array_equal(H_r.view(np.uint32), H_o.view(np.uint32))
     assert H_r.sum() > 0
+
+
+def test_grad_hist_odd_soft_bin_is_refused(oracle):
+    """Odd softBin is the trilinear form with its 8/7 boundary normalisation (gradientMex.cpp:511-662): refused by the restatement
+    (and by the library), not approximated."""
+    h, w = 24, 20
+    M = oracle.aligned_copy(rnd(991, (w, h), 0.0, 0.6))
+    O = oracle.aligned_copy(rnd(992, (w, h), 0.0, float(np.pi) - 1e-6))
+    for bin_, softBin in ((4, 1), (4, -1), (1, 1)):
+        H_o = oracle.aligned((6, w // bin_, h // bin_))
+        assert oracle.lib().acfo_grad_hist(oracle.F(M), oracle.F(O), oracle.F(H_o), h, w, bin_, 6, softBin, 0) != 0
 
 
 def test_chain_with_reference_kernels(oracle, refk):
@@ -268,6 +281,22 @@ def test_luv_table_bit_exact_through_the_reference(oracle, refk2):
     oracle.lib().acfo_rgb2luv(oracle.F(src), oracle.F(out_o), n)
     assert np.array_equal(out_r[0].view(np.uint32), out_o[0].view(np.uint32))
     assert len(np.unique(out_r[0])) > 1000
+
+
+@pytest.mark.parametrize("n", [16, 250, 4099])
+def test_rgb2hsv_bit_exact(oracle, refk2, n):
+    """rgb2hsv (rgbConvertMex.cpp:194-238) through the reference's own rgbConvert(flag 3): every branch — grey pixels, each
+    channel the maximum, ties between channels, h wrapping at 6 — bit for bit."""
+    src = oracle.aligned_copy(rnd(79 + n, (3, n)))
+    src[:, 0:4] = np.float32(0.25)            # r == g == b
+    src[0, 4:8] = src[1, 4:8]                 # r == g
+    src[1, 8:12] = src[2, 8:12]               # g == b
+    src[0, 12:16] = np.maximum(src[1, 12:16], src[2, 12:16])  # r == max of the others
+    out_r, out_o = oracle.aligned((3, n)), oracle.aligned((3, n))
+    assert refk2.ref_rgbConvert(oracle.F(src), oracle.F(out_r), n, 3, 3, 1.0) == 0
+    oracle.lib().acfo_rgb2hsv(oracle.F(src), oracle.F(out_o), n)
+    assert np.array_equal(out_r.view(np.uint32), out_o.view(np.uint32))
+    assert len(np.unique(out_r[0])) > 3
 
 
 @pytest.mark.parametrize("n", [16, 250, 4096])
