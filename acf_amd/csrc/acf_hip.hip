@@ -78,6 +78,12 @@ struct CascState
     bool useTileD = false;
     CascTile* d_tilesD = nullptr;
     uint32_t* d_tileOffD = nullptr;
+    // the same tiles over rank cells (k_cascade_tile3D<.., CellRank>)
+    bool useRankD = false;
+    TileGeom geomDR{};
+    CascTile* d_tilesDR = nullptr;
+    int nTilesDR = 0;
+    uint32_t *d_nodesDR = nullptr, *d_tileOffDR = nullptr, *d_thrsRankD = nullptr;
     int nTilesD = 0, tbD = 0, t1D = 0;
     TileGeom geomD{};
     uint32_t* d_nodesD = nullptr;
@@ -1358,6 +1364,7 @@ struct TileSet
     uint32_t* d_nodesD = nullptr;
     int tbD = 0, t1D = 0;
     uint32_t* d_tileOffD = nullptr; // k_cascade_tile3D: tile offsets of every node, [tree][nTreeNodes]
+    uint32_t* d_thrsRankD = nullptr; // ... and, on rank cells, the thresholds' rank indices in the same layout
 };
 
 static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out, bool allowPooledD = true)
@@ -1377,7 +1384,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     // the staged queue's lanes = windows form beats items = windows x trees there (26 against 37 us per 1080p frame) —:
     // k_cascade_tile3D, the same stages on float cells, for models of at least 32 trees; ACF_HIP_TILED_STAGED keeps k_cascade_tileD +
     // the staged queue)
-    const bool pooledD = allowPooledD && !rank && ((p.treeDepth == 1 && getenv("ACF_HIP_TILED_POOLED1")) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
+    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && getenv("ACF_HIP_TILED_POOLED1")) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
         !getenv("ACF_HIP_TILED_STAGED");
     const bool pooled = (p.treeDepth == 2 && !getenv("ACF_HIP_TILE2")) || pooledD;
     int bounds[5] = { 0, 32, 32, 64, 128 };
@@ -1515,9 +1522,9 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
         // k_cascade_tileD: stage 0 of the staged path, trees [0, 32) (the staged path's second boundary), on float tiles.
         // Records per batch of TB trees: {off[TB][NN], thr[TB][NN], hs[TB][NL]}, nodes in heap order, leaves left to right.
         const int D = p.treeDepth;
-        if (rank || D < 1 || D > 4 || D == 2)
+        if ((rank && !g.pooled) || D < 1 || D > 4 || D == 2)
         {
-            return ACF_HIP_OK;
+            return ACF_HIP_OK; // (rank cells: k_cascade_tile3D only)
         }
         const int NN = (1 << D) - 1, NL = 1 << D, TB = D == 1 ? 4 : (D == 3 ? 2 : 1);
         const int t1 = std::min(32, p.nTrees) / TB * TB;
@@ -1536,7 +1543,14 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
                 const uint32_t f = c->fids[q + k];
                 const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
                 d[tq * NN + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
-                memcpy(&d[TB * NN + tq * NN + k], &c->thrs[q + k], 4);
+                if (rank)
+                {
+                    d[TB * NN + tq * NN + k] = rank->rankOfThreshold(int(z), c->thrs[q + k]);
+                }
+                else
+                {
+                    memcpy(&d[TB * NN + tq * NN + k], &c->thrs[q + k], 4);
+                }
             }
             for (int j = 0; j < NL; j++)
             {
@@ -1549,7 +1563,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
             {
                 return buildTileSet(c, lv, nChns, rank, out, false); // (k_cascade_tileD + the staged queue)
             }
-            std::vector<uint32_t> to(size_t(p.nTrees) * p.nTreeNodes, 0u);
+            std::vector<uint32_t> to(size_t(p.nTrees) * p.nTreeNodes, 0u), tr(rank ? size_t(p.nTrees) * p.nTreeNodes : 0, 0u);
             for (int t = 0; t < p.nTrees; t++)
             {
                 for (int k = 0; k < NN; k++)
@@ -1557,9 +1571,13 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
                     const uint32_t f = c->fids[size_t(t) * p.nTreeNodes + k];
                     const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
                     to[size_t(t) * p.nTreeNodes + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
+                    if (rank)
+                    {
+                        tr[size_t(t) * p.nTreeNodes + k] = rank->rankOfThreshold(int(z), c->thrs[size_t(t) * p.nTreeNodes + k]);
+                    }
                 }
             }
-            if ((rc = devUpload(c, &out.d_tileOffD, to)))
+            if ((rc = devUpload(c, &out.d_tileOffD, to)) || (rank && (rc = devUpload(c, &out.d_thrsRankD, tr))))
             {
                 return rc;
             }
@@ -1765,6 +1783,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     cs.useTiles = false;
     cs.useRank = false;
     cs.useTileD = false;
+    cs.useRankD = false;
     cs.codeCapD = 0;
     if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.nTrees > 128 && !getenv("ACF_HIP_NO_TAIL_CODES"))
     {
@@ -1795,6 +1814,38 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             }
         }
     }
+    // the rank pyramid of a plan: per level nChns planes [wP][pitchR], pitchR = hP rounded up to 8 cells (16 bytes); bucket tables on
+    // the device; the level table again with the rank layout
+    auto setupRankPyramid = [&](const RankTables& rt) -> int {
+        std::vector<RankJob> jobs(lv.size());
+        int64_t off = 0;
+        cs.rankMaxWP = 0;
+        for (size_t i = 0; i < lv.size(); i++)
+        {
+            const int pitch = rankPitch(lv[i].hP);
+            cl[i].offR = off;
+            cl[i].pitchR = pitch;
+            jobs[i].src_off = lv[i].offset;
+            jobs[i].dst_off = off;
+            jobs[i].hP = lv[i].hP;
+            jobs[i].wP = lv[i].wP;
+            jobs[i].pitchR = pitch;
+            off += int64_t(nChns) * pitch * lv[i].wP;
+            cs.rankMaxWP = std::max(cs.rankMaxWP, lv[i].wP);
+        }
+        cs.pyrRCells = off;
+        cs.rankMaxRec = rt.maxRec;
+        int rcl;
+        // + slack: a tile's 16-byte fill chunks run up to rowsP cells past the last column of the last plane
+        if ((rcl = devUpload(c, &cs.d_rankChan, rt.chan)) || (rcl = devUpload(c, &cs.d_rankRec, rt.rec)) || (rcl = devUpload(c, &cs.d_rankJobs, jobs)) ||
+            (rcl = devAlloc(c, &cs.d_pyrR, size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096)))
+        {
+            return rcl;
+        }
+        HIPCHK(c, hipMemset(cs.d_pyrR, 0, (size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096) * sizeof(uint16_t))); // pitch padding cells: defined
+        HIPCHK(c, hipMemcpy(*d_levels, cl.data(), cl.size() * sizeof(CascLevel), hipMemcpyHostToDevice));
+        return ACF_HIP_OK;
+    };
     if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.stride % p.shrink == 0 && p.stride >= p.shrink)
     {
         TileSet tsD;
@@ -1812,6 +1863,42 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             cs.geomD = tsD.g;
             cs.d_nodesD = tsD.d_nodesD;
             cs.d_tileOffD = tsD.d_tileOffD;
+            // ---- the pooled kernel on threshold-rank cells (the rank tables do not depend on the depth): half the fill, three
+            // workgroups per CU.  The float pyramid is still written for these depths (the queue's overflow path reads it).
+            if (tsD.g.pooled && wantRank && !getenv("ACF_HIP_NO_RANK"))
+            {
+                const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
+                std::vector<int32_t> chnOfNode(nNodes, -1);
+                for (size_t q = 0; q < nNodes; q++)
+                {
+                    if (internal[q])
+                    {
+                        chnOfNode[q] = int32_t(c->fids[q] / uint32_t(mWc * mHc));
+                    }
+                }
+                RankTables rt;
+                buildRankTables(c->thrs.data(), chnOfNode.data(), nNodes, nChns, rt);
+                TileSet tsR;
+                if (rt.ok && (rc = buildTileSet(c, lv, nChns, &rt, tsR)))
+                {
+                    return rc;
+                }
+                if (rt.ok && tsR.ok && tsR.g.pooled && tsR.d_thrsRankD && (tsR.g.NW == 8 || tsR.g.NW == 4))
+                {
+                    if ((rc = setupRankPyramid(rt)))
+                    {
+                        return rc;
+                    }
+                    cs.geomDR = tsR.g;
+                    cs.d_tilesDR = tsR.d_tiles;
+                    cs.nTilesDR = tsR.nTiles;
+                    cs.d_nodesDR = tsR.d_nodesD;
+                    cs.d_tileOffDR = tsR.d_tileOffD;
+                    cs.d_thrsRankD = tsR.d_thrsRankD;
+                    cs.useRank = true;
+                    cs.useRankD = true;
+                }
+            }
         }
     }
     if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
@@ -1926,24 +2013,10 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 }
                 if (rt.ok && tsR.ok)
                 {
-                    // rank pyramid layout: per level nChns planes [wP][pitchR], pitchR = hP rounded up to 8 cells (16 bytes)
-                    std::vector<RankJob> jobs(lv.size());
-                    int64_t off = 0;
-                    cs.rankMaxWP = 0;
-                    for (size_t i = 0; i < lv.size(); i++)
+                    if ((rc = setupRankPyramid(rt)))
                     {
-                        const int pitch = rankPitch(lv[i].hP);
-                        cl[i].offR = off;
-                        cl[i].pitchR = pitch;
-                        jobs[i].src_off = lv[i].offset;
-                        jobs[i].dst_off = off;
-                        jobs[i].hP = lv[i].hP;
-                        jobs[i].wP = lv[i].wP;
-                        jobs[i].pitchR = pitch;
-                        off += int64_t(nChns) * pitch * lv[i].wP;
-                        cs.rankMaxWP = std::max(cs.rankMaxWP, lv[i].wP);
+                        return rc;
                     }
-                    cs.pyrRCells = off;
                     std::vector<TreeNode> tailR(static_cast<size_t>(p.nTrees));
                     for (int t = 0; t < p.nTrees; t++)
                     {
@@ -1972,16 +2045,6 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                     cs.nTilesR = tsR.nTiles;
                     cs.d_tileNodesR = tsR.d_tileNodes;
                     cs.d_tileNodesSR = tsR.d_tileNodesS;
-                    cs.rankMaxRec = rt.maxRec;
-                    // + slack: a tile's 16-byte fill chunks run up to rowsP cells past the last column of the last plane
-                    if ((rc = devUpload(c, &cs.d_rankChan, rt.chan)) || (rc = devUpload(c, &cs.d_rankRec, rt.rec)) ||
-                        (rc = devUpload(c, &cs.d_rankJobs, jobs)) || (rc = devAlloc(c, &cs.d_pyrR, size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096)))
-                    {
-                        return rc;
-                    }
-                    HIPCHK(c, hipMemset(cs.d_pyrR, 0, (size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096) * sizeof(uint16_t))); // pitch padding cells: defined
-                    // the level table again, now with the rank layout
-                    HIPCHK(c, hipMemcpy(*d_levels, cl.data(), cl.size() * sizeof(CascLevel), hipMemcpyHostToDevice));
                     cs.useRank = true;
                 }
             }
@@ -3549,8 +3612,9 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             // what the levels leave as: floats (always, unless the caller has declared the float pyramid unneeded), and the
             // cascade's 16-bit rank cells when every level goes through this one launch
             // (the rank cells have one reader, the tile kernel: a plan or option that routes the cascade elsewhere keeps floats)
-            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps && c->cs.useTiles && !c->noTiles;
-            const bool emitF32 = !(emitRank && !c->keepPyramid && !c->autoLambdas);
+            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps && (c->cs.useTiles || c->cs.useRankD) && !c->noTiles;
+            // (depths other than 2 keep the floats: their queue's overflow path reads them)
+            const bool emitF32 = !(emitRank && !c->keepPyramid && !c->autoLambdas) || c->cs.useRankD;
             wroteRank = emitRank;
             wroteF32 = emitF32;
             if (nAll > 0)
@@ -4349,14 +4413,41 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                 at.hits = cs.d_hits;
                 at.counts = cs.d_counts;
                 at.maxHits = c->maxHits;
-                const int64_t total = int64_t(at.nTiles) * nF;
-                const int64_t perX = (total + 7) / 8;
                 int rcl = 0;
+                const bool rankD = at.g.pooled && cs.useRankD && !c->noRank && pyr == c->d_pyr;
+                const int64_t total = int64_t(rankD ? cs.nTilesDR : at.nTiles) * nF;
+                const int64_t perX = (total + 7) / 8;
+                if (rankD && !c->ranksValid)
+                {
+                    // the float pyramid -> threshold-rank cells (levels whose kernels did not emit them)
+                    const size_t ldsR = size_t(cs.rankMaxRec) * sizeof(RankRec);
+                    if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_rank), ldsR)))
+                    {
+                        return rcl;
+                    }
+                    prof(c, "k_rank");
+                    hipLaunchKernelGGL(k_rank, dim3(cdiv(cs.rankMaxWP, RANK_CHUNK_COLS), int(c->plan.levels.size()) * nChns, nF), dim3(256), ldsR, c->stream, pyr, pyr_fs,
+                        cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const RankRec*)cs.d_rankRec);
+                    LAUNCHCHK(c, "k_rank");
+                    c->ranksValid = true;
+                    prof(c, "k_cascade");
+                }
                 if (at.g.pooled)
                 {
                     // k_cascade_tile3D: everything up to tree b[4]; the tail's codes come from its stage E
                     at.tileOff = cs.d_tileOffD;
                     at.thrs = c->cs.d_thrs;
+                    if (rankD)
+                    {
+                        at.g = cs.geomDR;
+                        at.tiles = cs.d_tilesDR;
+                        at.nTiles = cs.nTilesDR;
+                        at.nodesD = cs.d_nodesDR;
+                        at.tileOff = cs.d_tileOffDR;
+                        at.thrs = reinterpret_cast<const float*>(cs.d_thrsRankD);
+                        at.pyrR = cs.d_pyrR;
+                        at.pyrR_fs = cs.pyrRCells;
+                    }
                     at.hs = c->cs.d_hs;
                     at.nTrees = p.nTrees;
                     at.nTreeNodes = p.nTreeNodes;
@@ -4365,7 +4456,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                     at.codeCap = pooledTail ? cs.codeCapD : 0;
                     at.codePitch = cs.codePitchD;
                     const size_t nwin = size_t(at.g.NW) * 64;
-                    const size_t lds = size_t(128) * 4 * (size_t(1) << p.treeDepth) + size_t(at.g.tileFloats) * 4 +
+                    const size_t lds = size_t(128) * 4 * (size_t(1) << p.treeDepth) + size_t(at.g.tileFloats) * (rankD ? 2 : 4) +
                         ((std::max(nwin * 8, size_t(at.g.passW) * size_t(at.g.pitchC)) + 15) / 16 * 16) + nwin * 8;
                     const int64_t resident = int64_t(256) * std::max<int64_t>(1, int64_t(160 * 1024) / int64_t((lds + 1279) / 1280 * 1280));
                     const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
@@ -4378,11 +4469,18 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                     }
                     dim3 grid((unsigned int)(persist ? (gridP + 7) / 8 * 8 : perX * 8)), block(at.g.NW * 64);
                     prof(c, "k_cascade_tile");
-#define TILE3D_LAUNCH(N, DD, TT)                                                                         \
-    {                                                                                                    \
-        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT>), lds)))       \
-            return rcl;                                                                                  \
-        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT>), grid, block, lds, c->stream, at);              \
+#define TILE3D_LAUNCH(N, DD, TT)                                                                                   \
+    if (rankD)                                                                                                     \
+    {                                                                                                              \
+        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT, CellRank>), lds)))       \
+            return rcl;                                                                                            \
+        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT, CellRank>), grid, block, lds, c->stream, at);              \
+    }                                                                                                              \
+    else                                                                                                           \
+    {                                                                                                              \
+        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT, CellF32>), lds)))        \
+            return rcl;                                                                                            \
+        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT, CellF32>), grid, block, lds, c->stream, at);               \
     }
 #define TILE3D_DEPTH(N)                                    \
     switch (p.treeDepth)                                   \

@@ -6021,16 +6021,18 @@ struct TileDArgs
     // k_cascade_tile3D (pooled survivors, see k_cascade_tile3): the model's heap-ordered nodes [tree][nTreeNodes] — tile offsets of
     // the internal nodes, thresholds, leaves (hs: the last 2^D of a tree's entries) —, the leaf codes of the tail trees
     const uint32_t* tileOff;
-    const float* thrs;
+    const float* thrs;       // float cells: the thresholds; rank cells (CellRank): their rank indices as uint32 bit patterns
     const float* hs;
+    const uint16_t* pyrR;    // CellRank: the rank pyramid (CascLevel::offR / pitchR)
+    int64_t pyrR_fs;
     int32_t nTrees, nTreeNodes;
     uint8_t* codes; // [frame][codeCap][codePitch]: 4 * leaf index of every tree >= g.b[4] for the first codeCap queue entries
     int32_t codeCap, codePitch;
     int32_t* tileNext; // [8] per-XCD tile counters (persistent workgroups), or nullptr: one tile per workgroup
 };
 
-template <int D, int TB>
-__device__ __forceinline__ void tile_eval_d(const float* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
+template <int D, int TB, class CT = CellF32>
+__device__ __forceinline__ void tile_eval_d(const typename CT::cell_t* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
 {
     constexpr int NN = (1 << D) - 1, NL = 1 << D, REC = TB * (2 * NN + NL);
     cu32p_t p = (cu32p_t)(uintptr_t)tab;
@@ -6044,11 +6046,11 @@ __device__ __forceinline__ void tile_eval_d(const float* win, const uint32_t* __
     float hMin = __builtin_inff();
     for (int b = 0; b < nBatches; b++)
     {
-        float f[TB * NN];
+        typename CT::val_t f[TB * NN];
 #pragma unroll
         for (int i = 0; i < TB * NN; i++)
         {
-            f[i] = win[o[i]];
+            f[i] = typename CT::val_t(win[o[i]]);
         }
         cu32p_t pb = p + REC * b;
         uint32_t th[TB * NN], hv[TB * NL];
@@ -6080,7 +6082,7 @@ __device__ __forceinline__ void tile_eval_d(const float* win, const uint32_t* __
 #pragma unroll
             for (int k = 0; k < NN; k++)
             {
-                m[k] = __builtin_amdgcn_ballot_w64(f[t * NN + k] < __uint_as_float(th[t * NN + k]));
+                m[k] = __builtin_amdgcn_ballot_w64(f[t * NN + k] < CT::thr(th[t * NN + k]));
             }
             float hOut = h;
 #pragma unroll
@@ -6220,8 +6222,8 @@ __device__ __forceinline__ T sel_pow2(const T* a, uint32_t j)
 
 // the leaf a window reaches in one tree: o[] / th[] = the tree's internal nodes in heap order (node k's children 2k + 1 for
 // ftr < thr, 2k + 2 otherwise: getChild, acfDetect1.cpp:100-107); returns the leaf index 0 .. 2^D - 1, left to right
-template <int D, int L>
-__device__ __forceinline__ uint32_t walk_from(const float* win, const uint32_t (&o)[(1 << D) - 1], const float (&th)[(1 << D) - 1], uint32_t p)
+template <int D, int L, class CT>
+__device__ __forceinline__ uint32_t walk_from(const typename CT::cell_t* win, const uint32_t (&o)[(1 << D) - 1], const uint32_t (&th)[(1 << D) - 1], uint32_t p)
 {
     if constexpr (L == D)
     {
@@ -6231,28 +6233,30 @@ __device__ __forceinline__ uint32_t walk_from(const float* win, const uint32_t (
     {
         // level L: p holds the L decisions so far, the node is the p-th of the level's 2^L (heap index 2^L - 1 + p)
         const uint32_t off = sel_pow2<(1 << L), uint32_t>(o + ((1 << L) - 1), p);
-        const float thr = sel_pow2<(1 << L), float>(th + ((1 << L) - 1), p);
-        return walk_from<D, L + 1>(win, o, th, 2u * p + (win[off] < thr ? 0u : 1u));
+        const uint32_t thr = sel_pow2<(1 << L), uint32_t>(th + ((1 << L) - 1), p); // (threshold bits: CT::thr)
+        return walk_from<D, L + 1, CT>(win, o, th, 2u * p + (typename CT::val_t(win[off]) < CT::thr(thr) ? 0u : 1u));
     }
 }
-template <int D>
-__device__ __forceinline__ uint32_t walk_tree(const float* win, const uint32_t (&o)[(1 << D) - 1], const float (&th)[(1 << D) - 1])
+template <int D, class CT>
+__device__ __forceinline__ uint32_t walk_tree(const typename CT::cell_t* win, const uint32_t (&o)[(1 << D) - 1], const uint32_t (&th)[(1 << D) - 1])
 {
-    return walk_from<D, 0>(win, o, th, 0u);
+    return walk_from<D, 0, CT>(win, o, th, 0u);
 }
 
-template <int NW, int D, int TB>
+template <int NW, int D, int TB, class CT>
 __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
 {
+    typedef typename CT::cell_t cell_t;
+    constexpr int CPB = CT::CPB;
     constexpr int NT = NW * 64, NN = (1 << D) - 1, NL = 1 << D, LB = 4 * NL, REC = TB * (2 * NN + NL);
     constexpr int LEAF_BYTES = 128 * LB;
     extern __shared__ float lds[];
     __shared__ int s_n[4];
     __shared__ int s_next[2];
     float* leafT = lds;
-    float* tileF = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + LEAF_BYTES);
+    cell_t* tileF = reinterpret_cast<cell_t*>(reinterpret_cast<char*>(lds) + LEAF_BYTES);
     const int NWIN = a.g.TR * a.g.TC;
-    char* r1 = reinterpret_cast<char*>(tileF) + size_t(a.g.tileFloats) * 4;
+    char* r1 = reinterpret_cast<char*>(tileF) + size_t(a.g.tileFloats) * sizeof(cell_t);
     const int passW = a.g.passW;
     const int r1Bytes = (max(NWIN * 8, passW * a.g.pitchC) + 15) & ~15;
     uint2* l1 = reinterpret_cast<uint2*>(r1);
@@ -6279,15 +6283,14 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
     const int Ts = tEnd - b2, TsPad = (Ts + 15) & ~15;
     const int tlShift = TsPad <= 32 ? 5 : (TsPad <= 64 ? 6 : 7);
     const int pos = tid & ((1 << tlShift) - 1);
-    uint32_t so[NN];
-    float sth[NN];
+    uint32_t so[NN], sth[NN];
     {
         const int64_t q = int64_t(b2 + min(pos, max(Ts, 1) - 1)) * a.nTreeNodes;
 #pragma unroll
         for (int k = 0; k < NN; k++)
         {
             so[k] = Ts > 0 ? a.tileOff[q + k] : 0u;
-            sth[k] = Ts > 0 ? a.thrs[q + k] : 0.f;
+            sth[k] = Ts > 0 ? __float_as_uint(a.thrs[q + k]) : 0u;
         }
         for (int x = tid; x < TsPad * NL; x += NT)
         {
@@ -6319,11 +6322,12 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
         {
             const int colsT = a.g.colsT;
             const int gr0 = T.r0 * step, gc0 = T.c0 * step;
-            const int colPitch = L.hP;
+            const int colPitch = CT::RANK ? L.pitchR : L.hP;
             const int area = colPitch * L.wP;
-            const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
+            const cell_t* __restrict__ src0 = (CT::RANK ? reinterpret_cast<const cell_t*>(a.pyrR) + int64_t(frame) * a.pyrR_fs + L.offR
+                                                        : reinterpret_cast<const cell_t*>(a.pyr) + int64_t(frame) * a.pyr_fs + L.off) + gr0;
             const int colsValid = min(colsT, L.wP - gc0);
-            const uint32_t cps = uint32_t(rowsP) / 4u;
+            const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
             const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
             const int ccMax = colsValid - 1;
             for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
@@ -6335,8 +6339,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
                     const uint32_t j = q - seg * cps;
                     const uint32_t z = __umulhi(seg, a.g.colsMagic);
                     const int cc = int(seg - z * uint32_t(colsT));
-                    const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + 4u * j;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + 4u * q0), 16, 0, 0);
+                    const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + uint32_t(CPB) * q0), 16, 0, 0);
                 }
             }
         }
@@ -6395,7 +6399,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
             bool alive = (T.r0 + r_l) < nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / TR) * TR;
             float h = 0.f;
             const uint32_t woff = uint32_t((min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step);
-            tile_eval_d<D, TB>(tileF + woff, a.nodesD, b1 / TB, thrC, h, alive);
+            tile_eval_d<D, TB, CT>(tileF + woff, a.nodesD, b1 / TB, thrC, h, alive);
             const uint32_t tw = uint32_t(c_l * TR + r_l) | (woff << 16);
             if (b1 == tEnd)
             {
@@ -6417,7 +6421,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
                 bool alive = e < n1;
                 const uint2 en = l1[alive ? e : e0];
                 float h = __uint_as_float(en.x);
-                tile_eval_d<D, TB>(tileF + (en.y >> 16), a.nodesD + size_t(b1 / TB) * REC, (b2 - b1) / TB, thrC, h, alive);
+                tile_eval_d<D, TB, CT>(tileF + (en.y >> 16), a.nodesD + size_t(b1 / TB) * REC, (b2 - b1) / TB, thrC, h, alive);
                 if (b2 == tEnd)
                 {
                     finish(alive, en.y, h);
@@ -6441,8 +6445,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
                 const int nP = min(passW, n2 - p0);
                 for (int wi = tid >> tlShift; wi < nP; wi += wpr)
                 {
-                    const float* win = tileF + (l2[p0 + wi].y >> 16);
-                    const uint32_t leaf = walk_tree<D>(win, so, sth);
+                    const cell_t* win = tileF + (l2[p0 + wi].y >> 16);
+                    const uint32_t leaf = walk_tree<D, CT>(win, so, sth);
                     if (pos < TsPad)
                     {
                         codes[wi * pitchC + pos] = pos < Ts ? uint8_t(4u * leaf) : uint8_t(0);
@@ -6520,14 +6524,13 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
             const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
             for (int b = wv; b < nB; b += NW)
             {
-                uint32_t eo[NN];
-                float eth[NN];
+                uint32_t eo[NN], eth[NN];
                 const int64_t q = int64_t(tEnd + min(b * 64 + lane, nT - 1)) * a.nTreeNodes;
 #pragma unroll
                 for (int k = 0; k < NN; k++)
                 {
                     eo[k] = a.tileOff[q + k];
-                    eth[k] = a.thrs[q + k];
+                    eth[k] = __float_as_uint(a.thrs[q + k]);
                 }
                 for (int s = 0; s < nTail; s++)
                 {
@@ -6537,7 +6540,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
                     {
                         continue; // no code row: k_cascade_tail takes this entry
                     }
-                    const uint32_t leaf = walk_tree<D>(tileF + (en.y >> 16), eo, eth);
+                    const uint32_t leaf = walk_tree<D, CT>(tileF + (en.y >> 16), eo, eth);
                     a.codes[(int64_t(frame) * a.codeCap + slot) * a.codePitch + b * 64 + lane] = b * 64 + lane < nT ? uint8_t(4u * leaf) : uint8_t(0);
                 }
             }
