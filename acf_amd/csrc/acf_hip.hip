@@ -36,6 +36,9 @@ struct RealScale
     int src_h = 0, src_w = 0;
     int descIndex = -1;
     ResampleTiling tiling;          // k_resample_tile plan of the image resample (rows == 0: not eligible)
+    // k_resample_march2: this scale's image and the next real scale's from one pass over their common source
+    int pairNext = 0;               // 1: the next real scale is produced together with this one
+    int pairRows = 0, pairCols = 0, pairTileY = 0, pairTileX = 0; // the union tiles' largest extent; the next scale's half-size tile tables
     float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
     int64_t uFloats = 0, moFloats = 0; // floats per frame of U and of M, O (room for the blocked layouts' padding)
 };
@@ -2323,6 +2326,82 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         c->real.push_back(rs);
     }
     c->nImgDescs = int(c->h_descs.size());
+    // Two consecutive real scales resampled from the same source (the two small scales of a 1080p pyramid, both from the half-size
+    // smoothed image), the second about half the first: one pass over the source for both (k_resample_march2).  The second scale's
+    // tiles are half the first's in rows and columns; the kernel loads the union of the two source ranges.
+    for (size_t k = 0; k + 1 < c->real.size() && !getenv("ACF_HIP_RESAMPLE_NO_PAIR"); k++)
+    {
+        RealScale& ra = c->real[k];
+        RealScale& rb = c->real[k + 1];
+        if (!ra.resampled || !rb.resampled || ra.adoptAsI || ra.src_h != rb.src_h || ra.src_w != rb.src_w || ra.tiling.rows == 0 || ra.tiling.xo % 2 ||
+            (k > 0 && c->real[k - 1].pairNext))
+        {
+            continue;
+        }
+        const ResampleDesc& da = c->h_descs[ra.descIndex];
+        const ResampleDesc& db = c->h_descs[rb.descIndex];
+        const bool down = (db.xmode == RS_DOWN || db.xmode == RS_EXACT) && (db.ymode == RS_DOWN || db.ymode == RS_EXACT);
+        const int xo = ra.tiling.xo, xoB = xo / 2, ryB = RT_YO / 2;
+        const int ntY = cdiv(da.hb, RT_YO), ntX = cdiv(da.wb, xo), ntYB = cdiv(db.hb, ryB), ntXB = cdiv(db.wb, xoB);
+        if (!down || db.nplanes != da.nplanes || ntYB > ntY || ntXB > ntX || ntX < 4)
+        {
+            continue;
+        }
+        std::vector<int32_t> ty, tx;
+        int maxR = 0, maxC = 0;
+        {
+            const int32_t* it = arena.ints.data();
+            for (int t = 0; t < ntY; t++)
+            {
+                int lo = it[ra.tiling.tile_y + 2 * t], hi = it[ra.tiling.tile_y + 2 * t + 1];
+                if (t < ntYB)
+                {
+                    const int yb0 = t * ryB, yb1 = std::min(yb0 + ryB, db.hb);
+                    int lob, hib;
+                    if (db.ymode == RS_EXACT)
+                    {
+                        lob = db.yk * yb0;
+                        hib = db.yk * (yb1 - 1) + db.yk - 1;
+                    }
+                    else
+                    {
+                        lob = it[db.y_src + it[db.y_start + yb0]];
+                        hib = std::max(it[db.y_src + it[db.y_start + yb1 - 1]] + db.ybd0 - 1, it[db.y_src + it[db.y_start + yb1] - 1]);
+                    }
+                    ty.push_back(lob);
+                    ty.push_back(hib);
+                    lo = std::min(lo, lob);
+                    hi = std::max(hi, hib);
+                }
+                maxR = std::max(maxR, hi - lo + 1);
+            }
+            for (int t = 0; t < ntX; t++)
+            {
+                int lo = it[ra.tiling.tile_x + 2 * t], hi = it[ra.tiling.tile_x + 2 * t + 1];
+                if (t < ntXB)
+                {
+                    const int xb0 = t * xoB, xb1 = std::min(xb0 + xoB, db.wb);
+                    const int lob = it[db.x_col + 8 * xb0], hib = it[db.x_col + 8 * (xb1 - 1)] + it[db.x_col + 8 * (xb1 - 1) + 1] - 1;
+                    tx.push_back(lob);
+                    tx.push_back(hib);
+                    lo = std::min(lo, lob);
+                    hi = std::max(hi, hib);
+                }
+                maxC = std::max(maxC, hi - lo + 1);
+            }
+        }
+        if ((2 * int64_t(maxC) + xo) * maxR * 4 > int64_t(48) * 1024)
+        {
+            continue; // (the union tiles would cost the kernel its workgroups per CU)
+        }
+        ra.pairNext = 1;
+        ra.pairRows = maxR;
+        ra.pairCols = maxC;
+        ra.pairTileY = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), ty.begin(), ty.end());
+        ra.pairTileX = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
+    }
 
     // approximated levels (chnsPyramid.cpp:385-397)
     const int nColor = p.colorEnabled ? d : 0;
@@ -3096,7 +3175,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     // which real scale's smoothed image each real scale is resampled from (-1: the input frame), following the
     // reference's I = I1 adoption (chnsPyramid.cpp:313-316)
     std::vector<int> srcIdx(c->real.size(), -1);
-    std::vector<char> halfDone(c->real.size(), 0);
+    std::vector<char> halfDone(c->real.size(), 0), pairDone(c->real.size() + 1, 0);
     {
         int curIdx = -1;
         for (size_t k = 0; k < c->real.size(); k++)
@@ -3162,9 +3241,26 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             }
             prof(c, "k_resample(image)");
             const ResampleDesc& hd = c->h_descs[rs.descIndex];
-            if (halfDone[k])
+            if (halfDone[k] || pairDone[k])
             {
-                // already produced by the previous scale's k_smooth_vec
+                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_march2)
+            }
+            else if (rs.pairNext && rs.tiling.rows > 0 && !resampleGenericOnly() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar)
+            {
+                // (with the scales on their own streams the next scale's chain would need one more event: the pair is for the one-stream order)
+                pairDone[k + 1] = 1;
+                const ResampleTiling& tl = rs.tiling;
+                const size_t ldsMarch = (2 * size_t(rs.pairCols) + tl.xo) * rs.pairRows * 4;
+                const int ntX = cdiv(hd.wb, tl.xo), rowJobs = cdiv(hd.hb, RT_YO) * hd.nplanes;
+                const int nSplit = std::max(1, std::min(ntX / 4, cdiv(2048, rowJobs * nF)));
+                MarchPair mp{ c->real[k + 1].descIndex, rs.pairTileY, rs.pairTileX };
+                if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_march2), ldsMarch)))
+                {
+                    return rc;
+                }
+                hipLaunchKernelGGL(k_resample_march2, dim3(rowJobs * nSplit, 1, nF), dim3(256), ldsMarch, c->stream, cur, rs.img, c->real[k + 1].img,
+                    (const ResampleDesc*)c->d_descs, rs.descIndex, mp, (const int32_t*)c->d_it, (const float*)c->d_ft, rs.pairRows, rs.pairCols, tl.xo,
+                    tl.tile_y, tl.tile_x, nSplit);
             }
             else if (hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
                 hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&

@@ -3993,6 +3993,107 @@ __global__ void __launch_bounds__(256) k_resample_march(const float* __restrict_
     }
 }
 
+// k_resample_march for TWO outputs of one source: the two small real scales of a pyramid are both resampled from the half-size
+// smoothed image (chnsPyramid.cpp:313-316: I = I1 once, at s = .5), the second about half the first in both axes.  A workgroup
+// marches over the column tiles of output A's (plane, row tile) and, from the SAME source tile in LDS, also produces output B's
+// tile of half as many rows and columns (its own tables; the tile loaded is the union of the two source ranges), so the source is
+// read once (4.8 MB per 1080p frame less, one launch less).  Passes and tables are rt_passes' for each output: bit-identical.
+struct MarchPair
+{
+    int32_t descB;            // B's descriptor index
+    int32_t tile_yB, tile_xB; // B's tile tables: row tiles of RT_YO / 2 rows, column tiles of xo / 2 columns
+};
+__global__ void __launch_bounds__(256) k_resample_march2(const float* __restrict__ src, float* __restrict__ dstA, float* __restrict__ dstB,
+    const ResampleDesc* __restrict__ descs, int descA, MarchPair pb, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols,
+    int xo, int tile_y, int tile_x, int nSplit)
+{
+    extern __shared__ float rt_lds[];
+    const ResampleDesc& d = descs[descA];
+    const ResampleDesc& e = descs[pb.descB];
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int ntY = (hb + RT_YO - 1) / RT_YO;
+    const int ntX = (wb + xo - 1) / xo;
+    const int xoB = xo / 2, ntXB = (e.wb + xoB - 1) / xoB, ntYB = (e.hb + RT_YO / 2 - 1) / (RT_YO / 2);
+    int t = blockIdx.x;
+    const int part = t % nSplit;
+    t /= nSplit;
+    const int ytile = t % ntY;
+    const int z = t / ntY;
+    if (z >= d.nplanes)
+    {
+        return;
+    }
+    const int perPart = (ntX + nSplit - 1) / nSplit;
+    const int xt0 = part * perPart, xt1 = min(xt0 + perPart, ntX);
+    if (xt0 >= xt1)
+    {
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
+    const bool haveBy = ytile < ntYB;
+    const int ybB0 = ytile * (RT_YO / 2), ybB1 = haveBy ? min(ybB0 + RT_YO / 2, e.hb) : ybB0;
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty], rk = d.rk[ty], rB = e.r[ty], rkB = e.rk[ty];
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ BA = dstA + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+    float* __restrict__ BB = dstB + int64_t(blockIdx.z) * e.dst_frame_stride + e.dst_off + int64_t(z) * e.hb * e.wb;
+    const int rowLoA = it[tile_y + 2 * ytile], rowHiA = it[tile_y + 2 * ytile + 1];
+    const int rowLoB = haveBy ? it[pb.tile_yB + 2 * ytile] : rowLoA, rowHiB = haveBy ? it[pb.tile_yB + 2 * ytile + 1] : rowHiA;
+    const int rowLo = min(rowLoA, rowLoB);
+    const int nRows = min(max(rowHiA, rowHiB) - rowLo + 1, maxRows);
+    float* const Tb[2] = { rt_lds, rt_lds + size_t(maxCols) * maxRows };
+    float* C = rt_lds + 2 * size_t(maxCols) * maxRows;
+    const RtTaps tpA = rt_taps(d, it, ft, yb0 + lane, yb1, r);
+    const RtTaps tpB = rt_taps(e, it, ft, haveBy ? ybB0 + lane : 0, haveBy ? ybB1 : 1, rB); // (no B tile here: its taps are never used)
+    const int nR64 = (nRows + 63) >> 6;
+    auto range = [&](int xtile, int& colLo, int& nCols) {
+        const int loA = it[tile_x + 2 * xtile], hiA = it[tile_x + 2 * xtile + 1];
+        const bool hb_ = xtile < ntXB;
+        const int loB = hb_ ? it[pb.tile_xB + 2 * xtile] : loA, hiB = hb_ ? it[pb.tile_xB + 2 * xtile + 1] : hiA;
+        colLo = min(loA, loB);
+        nCols = min(max(hiA, hiB) - colLo + 1, maxCols);
+    };
+    auto fill = [&](int xtile, float* T) {
+        int colLo, nCols;
+        range(xtile, colLo, nCols);
+        for (int cc = wv; cc < nCols; cc += 4)
+        {
+            const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
+            for (int k = 0; k < nR64; k++)
+            {
+                const int r0 = 64 * k;
+                if (r0 + lane < nRows)
+                {
+                    __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
+                }
+            }
+        }
+    };
+    fill(xt0, Tb[0]);
+    for (int xtile = xt0; xtile < xt1; xtile++)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = (xtile - xt0) & 1;
+        if (xtile + 1 < xt1)
+        {
+            fill(xtile + 1, Tb[cur ^ 1]);
+        }
+        int colLo, nCols;
+        range(xtile, colLo, nCols);
+        const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
+        rt_passes(d, it, ft, Tb[cur], C, BA, tpA, yb0 + lane, xb0, xb1, rowLo, colLo, nRows, r, rk);
+        if (haveBy && xtile < ntXB) // (workgroup-uniform)
+        {
+            __syncthreads(); // A's y pass has read C
+            const int xB0 = xtile * xoB, xB1 = min(xB0 + xoB, e.wb);
+            rt_passes(e, it, ft, Tb[cur], C, BB, tpB, ybB0 + lane, xB0, xB1, rowLo, colLo, nRows, rB, rkB);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------
 // LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
 // tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
