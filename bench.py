@@ -73,6 +73,7 @@ def kernel_bytes_per_frame(det, model):
         casc = 4 * sum(nC * k * l.hP * l.wP for l in det.ldcf_levels)
         b["k_ldcf_conv"] = pyr + 4 * casc  # the plain pyramid in, k filtered full-resolution levels out
         b["k_resample(ldcf)"] = 4 * casc + casc
+        b["k_ldcf_tile"] = pyr + casc             # the fused form: the plain pyramid in, the k filtered and halved levels out
     b["k_cascade_tile"] = casc                    # every cell of the cascade's pyramid read once at SURVEY §8d's 4 bytes per cell (halo re-reads are L2 hits); the rank-cell form moves half of it
     b["k_cascade"] = casc
     b["k_tail_scan"] = 0                          # data dependent: (windows alive after tree 128) x (tail trees) code bytes
