@@ -114,10 +114,14 @@ def test_plan_rejects_unsupported():
     lib = capi.load()
     lv = (capi.Level * 8)()
     n, nc = C.c_int(), C.c_int()
-    for over, code in ((dict(softBin=1), 2), (dict(shrink=3, modelDsPad_h=15, modelDsPad_w=15), 2), (dict(lambdas=[0.1, 0.1]), 1),
-                       (dict(colorSpace=capi.CS_HSV), 2), (dict(colorChn=5), 1)):
+    # odd softBin = trilinear HOG binning (not built); an unknown colour space; hsv on planes declared LUV (rgbConvert.cpp:150-155: CV_Assert)
+    for over, code in ((dict(softBin=1), 2), (dict(softBin=-1), 2), (dict(shrink=3, modelDsPad_h=15, modelDsPad_w=15), 2), (dict(lambdas=[0.1, 0.1]), 1),
+                       (dict(colorSpace=7), 2), (dict(colorSpace=capi.CS_HSV, isLuv=1), 1), (dict(colorChn=5), 1)):
         params, keep = capi.make_params(synth.make_model(name="TINY", nTrees=4, **over))
         assert lib.acf_hip_plan_levels(C.byref(params), 96, 128, 3, lv, 8, C.byref(n), C.byref(nc)) == code, over
+    for over in (dict(softBin=2), dict(softBin=-2), dict(colorSpace=capi.CS_HSV, isLuv=0)):  # built since round 4
+        params, keep = capi.make_params(synth.make_model(name="TINY", nTrees=4, **over))
+        assert lib.acf_hip_plan_levels(C.byref(params), 96, 128, 3, lv, 8, C.byref(n), C.byref(nc)) == 0, over
     params, keep = capi.make_params(synth.make_model(name="FACE80", nTrees=4))
     assert lib.acf_hip_plan_levels(C.byref(params), 40, 40, 3, lv, 8, C.byref(n), C.byref(nc)) == 1  # smaller than minDs: no scales
 
