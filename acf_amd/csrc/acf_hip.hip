@@ -1383,11 +1383,11 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     // Stage boundaries.  k_cascade_tile3 (pooled survivors, the default for depth 2): dense [0,16) on every window, dense
     // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.  k_cascade_tile2
     // (ACF_HIP_TILE2: every wave keeps its own windows): 32 dense trees then sparse pieces [32,64) and [64,128).
-    // (depths 3, 4 — and 1 with ACF_HIP_TILED_POOLED1: stumps reject slowly, half of a tile's windows are still alive at tree 32 and
-    // the staged queue's lanes = windows form beats items = windows x trees there (26 against 37 us per 1080p frame) —:
-    // k_cascade_tile3D, the same stages on float cells, for models of at least 32 trees; ACF_HIP_TILED_STAGED keeps k_cascade_tileD +
-    // the staged queue)
-    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && getenv("ACF_HIP_TILED_POOLED1")) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
+    // (depths 3, 4, and 1 on rank cells: k_cascade_tile3D, the same stages, for models of at least 32 trees.  Depth 1 on FLOAT cells keeps
+    // k_cascade_tileD + the staged queue: stumps reject slowly, half of a tile's windows are still alive at tree 32, and with the float
+    // tile's two workgroups per CU the queue's lanes = windows form beats items = windows x trees (26 against 37 us per 1080p frame; on
+    // rank cells the pooled kernel takes 19) — ACF_HIP_TILED_POOLED1 pools it there too; ACF_HIP_TILED_STAGED keeps the staged form everywhere)
+    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && (rank || getenv("ACF_HIP_TILED_POOLED1"))) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
         !getenv("ACF_HIP_TILED_STAGED");
     const bool pooled = (p.treeDepth == 2 && !getenv("ACF_HIP_TILE2")) || pooledD;
     int bounds[5] = { 0, 32, 32, 64, 128 };
@@ -1868,7 +1868,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             cs.d_tileOffD = tsD.d_tileOffD;
             // ---- the pooled kernel on threshold-rank cells (the rank tables do not depend on the depth): half the fill, three
             // workgroups per CU.  The float pyramid is still written for these depths (the queue's overflow path reads it).
-            if (tsD.g.pooled && wantRank && !getenv("ACF_HIP_NO_RANK"))
+            if ((tsD.g.pooled || p.treeDepth == 1) && wantRank && !getenv("ACF_HIP_NO_RANK") && !getenv("ACF_HIP_TILED_STAGED"))
             {
                 const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
                 std::vector<int32_t> chnOfNode(nNodes, -1);
@@ -4480,7 +4480,9 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
             // per-lane gathers from the pyramid; its survivors enter the queue of the stage that ends at t1D
             const auto& cs = c->cs;
             int sD = -1;
-            const int endD = cs.geomD.pooled ? cs.geomD.b[4] : cs.t1D; // last tree the tile kernel evaluates
+            const bool rankD = cs.useRankD && !c->noRank && pyr == c->d_pyr;
+            const bool pooledRun = rankD || cs.geomD.pooled;
+            const int endD = rankD ? cs.geomDR.b[4] : (cs.geomD.pooled ? cs.geomD.b[4] : cs.t1D); // last tree the tile kernel evaluates
             for (int i = 0; i < nStages; i++)
             {
                 if (bounds[size_t(i)] == endD)
@@ -4510,7 +4512,6 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                 at.counts = cs.d_counts;
                 at.maxHits = c->maxHits;
                 int rcl = 0;
-                const bool rankD = at.g.pooled && cs.useRankD && !c->noRank && pyr == c->d_pyr;
                 const int64_t total = int64_t(rankD ? cs.nTilesDR : at.nTiles) * nF;
                 const int64_t perX = (total + 7) / 8;
                 if (rankD && !c->ranksValid)
@@ -4528,7 +4529,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                     c->ranksValid = true;
                     prof(c, "k_cascade");
                 }
-                if (at.g.pooled)
+                if (pooledRun)
                 {
                     // k_cascade_tile3D: everything up to tree b[4]; the tail's codes come from its stage E
                     at.tileOff = cs.d_tileOffD;

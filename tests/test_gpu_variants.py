@@ -55,7 +55,8 @@ VARIANTS = [
 ]
 LDCF_VARIANTS = ["", "ACF_HIP_LDCF_UNFUSED=1", "ACF_HIP_LDCF_UNFUSED=1 ACF_HIP_RESAMPLE_GENERIC=1"]
 # fixed depths other than 2: the pooled tile kernel (k_cascade_tile3D) and the forms an environment variable selects instead
-DEPTH_VARIANTS = [(1, ""), (1, "ACF_HIP_TILED_POOLED1=1"), (1, "ACF_HIP_TILED_POOLED1=1 ACF_HIP_TILE_PERSIST=0"), (3, ""), (3, "ACF_HIP_TILED_STAGED=1"),
+DEPTH_VARIANTS = [(1, ""), (1, "ACF_HIP_NO_RANK=1"), (1, "ACF_HIP_TILED_STAGED=1"), (1, "ACF_HIP_NO_RANK=1 ACF_HIP_TILED_POOLED1=1"), (1, "ACF_HIP_TILE_PERSIST=0"),
+                  (3, "ACF_HIP_NO_RANK=1"), (4, "ACF_HIP_NO_RANK=1"), (3, ""), (3, "ACF_HIP_TILED_STAGED=1"),
                   (3, "ACF_HIP_TILE_PERSIST=0"), (3, "ACF_HIP_TILE_NW=4"), (3, "ACF_HIP_NO_TAIL_CODES=1"), (4, ""), (4, "ACF_HIP_TILED_STAGED=1"), (4, "ACF_HIP_TILE_PERSIST=0")]
 
 
