@@ -2891,6 +2891,13 @@ static bool resampleGenericOnly()
     return v;
 }
 
+// k_resample_up applies: both axes up-sampled, whole quads of output rows, 16-byte aligned planes
+static bool resampleUpOk(const ResampleDesc& d)
+{
+    static const bool off = getenv("ACF_HIP_RESAMPLE_NO_UP") != nullptr; // A/B: the generic kernel
+    return !off && d.xmode == RS_UP && d.ymode == RS_UP && d.hb % 4 == 0 && d.ha >= 4 && d.dst_off % 4 == 0 && d.dst_frame_stride % 4 == 0;
+}
+
 namespace
 {
 // packed 8-bit source of a batch (acf_hip_pyramid_u8)
@@ -3300,6 +3307,13 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     hipLaunchKernelGGL(k_resample_tile, dim3(nb, 1, nF), dim3(256), ldsBytes, c->stream, cur, rs.img,
                         (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
                 }
+            }
+            else if (resampleUpOk(hd) && !resampleGenericOnly() && (uintptr_t(rs.img) & 15) == 0)
+            {
+                // nOctUp > 0: the frame up-sampled (cfg 4)
+                const int nw = hd.nplanes * cdiv(hd.hb, 256) * cdiv(hd.wb, RSU_XC);
+                hipLaunchKernelGGL(k_resample_up, dim3(cdiv(nw, 4), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
+                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
             }
             else
             {
@@ -6134,6 +6148,11 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
         }
         hipLaunchKernelGGL(k_resample_tile, dim3(cdiv(hb, RT_YO) * cdiv(wb, tl.xo) * d, 1, 1), dim3(256), ldsBytes, c->stream, (const float*)di, dout,
             (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
+    }
+    else if (resampleUpOk(dd) && !resampleGenericOnly())
+    {
+        hipLaunchKernelGGL(k_resample_up, dim3(cdiv(d * cdiv(hb, 256) * cdiv(wb, RSU_XC), 4), 1, 1), dim3(256), 0, c->stream, (const float*)di, dout,
+            (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft);
     }
     else
     {

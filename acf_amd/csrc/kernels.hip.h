@@ -2709,6 +2709,113 @@ __global__ void __launch_bounds__(256) k_resample(const float* __restrict__ src,
 }
 
 // ------------------------------------------------------------------------
+// imResample, both axes UP-sampling (imResampleMex.cpp:264-280 x pass, :357-373 y pass): the frame of a model with nOctUp > 0
+// (BASELINE cfg 4: 640 x 480 -> 1280 x 960).  The generic kernel above spent 3.1 ms per 192 VGA frames on it (one dword store
+// per lane, a branch per tap).  Here a lane owns FOUR consecutive output rows of its column (one 16-byte store); their y taps
+// are rows ya[k], ya[k] + 1 with ya[3] <= ya[0] + 3 (an up-sampled axis advances at most one source row per output row), so the
+// five source rows ya[0] .. ya[0] + 4 of the two source columns are loaded once per output column, the x pass runs on those five
+// rows, and the y pass picks its rows with selects on loop-invariant conditions.  Straight-line code: clamped addresses, no
+// branch around a load.  Operands and order are k_resample's (rs_C, then the UP branch of the y pass): bit-identical.
+// Needs hb % 4 == 0.  blockIdx.x = (plane, tile of 256 output rows, chunk of RSU_XC output columns), a wave per chunk.
+// ------------------------------------------------------------------------
+#define RSU_XC 32
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));
+__global__ void __launch_bounds__(256) k_resample_up(const float* __restrict__ src, float* __restrict__ dst, const ResampleDesc* __restrict__ descs,
+    const int32_t* __restrict__ it, const float* __restrict__ ft)
+{
+    const ResampleDesc& d = descs[blockIdx.y];
+    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntY = (hb + 255) >> 8, ntX = (wb + RSU_XC - 1) / RSU_XC;
+    int t = blockIdx.x * 4 + wv;
+    const int xchunk = t % ntX;
+    t /= ntX;
+    const int ytile = t % ntY;
+    const int z = t / ntY;
+    if (z >= d.nplanes)
+    {
+        return;
+    }
+    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
+    const float r = d.r[ty];
+    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
+    const int yb0 = ytile * 256 + 4 * lane;
+    const bool act = yb0 < hb; // (hb % 4 == 0: a lane's four rows are inside the plane together)
+    int i0[4];
+    float wy0[4], wy1[4];
+    bool one[4];
+    int rlo = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int ybc = min(yb0 + k, hb - 1);
+        const int ya = it[d.y_src + ybc];
+        if (k == 0)
+        {
+            rlo = ya;
+        }
+        i0[k] = min(max(ya - rlo, 0), 3);
+        wy0[k] = ft[d.y_wt + ybc] * r;
+        wy1[k] = r - wy0[k];
+        one[k] = ybc < d.ybd0 || ybc >= hb - d.ybd1;
+    }
+    // the lane's five source rows: clamped addresses; rows >= ha read as 0 in the x pass's result (C[ha .. ha + 3] = 0, :133-137)
+    const int r4 = min(rlo + 4, ha - 1), r03 = min(rlo, max(ha - 4, 0)); // a 4-row load that stays inside the column
+    const int sh = rlo - r03;                                           // (rows rlo + i = loaded row sh + i while that is < 4)
+    bool live[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+    {
+        live[i] = rlo + i < ha;
+    }
+    typedef uint32_t rs_u32x8 __attribute__((ext_vector_type(8)));
+    typedef const __attribute__((address_space(4))) rs_u32x8* rs_cptr8;
+    rs_cptr8 xrec = (rs_cptr8)(uintptr_t)(it + d.x_col);
+    const int xb0 = xchunk * RSU_XC, xb1 = min(xb0 + RSU_XC, wb);
+    for (int xb = xb0; xb < xb1; xb++)
+    {
+        const rs_u32x8 xr = xrec[xb];
+        const int xa = int(xr[0]);
+        const bool border = xr[3] != 0;
+        const float w0 = __uint_as_float(xr[4]), w1 = __uint_as_float(xr[5]);
+        const float* Ac0 = A + int64_t(xa) * ha;
+        const float* Ac1 = A + int64_t(min(xa + 1, wa - 1)) * ha;
+        const f4u_t a4 = *reinterpret_cast<const f4u_t*>(Ac0 + r03), b4 = *reinterpret_cast<const f4u_t*>(Ac1 + r03);
+        const float a5 = Ac0[r4], b5 = Ac1[r4];
+        // rows rlo .. rlo + 4 from the 4-row load (shifted by sh when the column's end forced it back) and the fifth row
+        float ar[5], br[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+        {
+            const int j = sh + i; // wave-varying, loop-invariant
+            ar[i] = j == 0 ? a4.x : (j == 1 ? a4.y : (j == 2 ? a4.z : (j == 3 ? a4.w : a5)));
+            br[i] = j == 0 ? b4.x : (j == 1 ? b4.y : (j == 2 ? b4.z : (j == 3 ? b4.w : b5)));
+        }
+        float C[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+        {
+            const float c = border ? ar[i] : ar[i] * w0 + br[i] * w1; // rs_C, UP
+            C[i] = live[i] ? c : 0.f;
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const float c0 = i0[k] == 0 ? C[0] : (i0[k] == 1 ? C[1] : (i0[k] == 2 ? C[2] : C[3]));
+            const float c1 = i0[k] == 0 ? C[1] : (i0[k] == 1 ? C[2] : (i0[k] == 2 ? C[3] : C[4]));
+            const float o1 = c0 * wy0[k];
+            v[k] = one[k] ? o1 : o1 + c1 * wy1[k];
+        }
+        if (act)
+        {
+            *reinterpret_cast<float4*>(B + int64_t(xb) * hb + yb0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // Threshold-rank cells (host_plan.h): rank(v) = number of the channel's distinct node thresholds <= v, the 16-bit cell
 // the cascade tile kernel reads.  `rec` = the CHANNEL's bucket records in LDS: one 16-byte read per cell.
 // ------------------------------------------------------------------------

@@ -159,7 +159,8 @@ RESAMPLE_CASES = [
     (64, 48, 32, 24), (60, 48, 20, 16), (64, 48, 16, 12), (64, 48, 32, 12),
     (100, 80, 71, 57), (100, 80, 51, 41), (135, 240, 124, 220), (540, 960, 136, 240), (540, 96, 68, 12),
     (64, 48, 91, 67), (48, 64, 96, 128), (68, 121, 62, 110), (30, 40, 33, 37), (270, 480, 248, 441),
-    (540, 960, 272, 484), (400, 90, 100, 18), (333, 77, 65, 70), (130, 700, 17, 60),  # LDS-tiled path: ~2x, exact /4 tall, 5+ taps in y with up in x (generic), 7+ taps
+    (540, 960, 272, 484), (400, 90, 100, 18), (333, 77, 65, 70), (130, 700, 17, 60),
+    (480, 640, 960, 1280), (61, 47, 100, 64), (50, 30, 52, 31), (7, 9, 28, 36), (120, 33, 124, 66),  # both axes up, whole quads of rows: k_resample_up (x2, odd ratios, barely up, x4)  # LDS-tiled path: ~2x, exact /4 tall, 5+ taps in y with up in x (generic), 7+ taps
 ]
 
 

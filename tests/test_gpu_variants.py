@@ -41,6 +41,7 @@ VARIANTS = [
     "ACF_HIP_RT_XO=32",
     "ACF_HIP_RESAMPLE_NO_MARCH=1",
     "ACF_HIP_RESAMPLE_NO_PAIR=1",
+    "ACF_HIP_RESAMPLE_NO_UP=1",
     "ACF_HIP_SCALES_SERIAL=1 ACF_HIP_RT_XO=16",
     "ACF_HIP_RESAMPLE_GENERIC=1",
     "ACF_HIP_TRIY_UNFUSED=1",
