@@ -3765,7 +3765,7 @@ __global__ void __launch_bounds__(256) k_resample_half(const float* __restrict__
 // LDCF decorrelation filters (BASELINE cfg 5; no reference counterpart — definition in include/acf_hip.h): one level's
 // nChns planes convolved with k filters of 5x5 each, zero-padded 'same' true convolution:
 //   out[f*nChns + c](y, x) = sum_{dx=-2..2} sum_{dy=-2..2} in[c](y - dy, x - dx) * filt[f][c][dx + 2][dy + 2]
-// taps added in that order from 0 (f32, no contraction).  A thread produces one output cell; lanes run along image-y.
+// taps added in that order from 0 as one chain of f32 fused multiply-adds (acc = fmaf(v, w, acc)).  A thread produces one output cell; lanes run along image-y.
 // ------------------------------------------------------------------------
 struct LdcfJob
 {
@@ -3801,7 +3801,7 @@ __global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr
             const int xx = x - dx, yy = y - dy;
             const bool ok = xx >= 0 && xx < w && yy >= 0 && yy < h;
             const float v = ok ? in[int64_t(min(max(xx, 0), w - 1)) * h + min(max(yy, 0), h - 1)] : 0.f;
-            acc = acc + v * f[(dx + 2) * 5 + (dy + 2)];
+            acc = __builtin_fmaf(v, f[(dx + 2) * 5 + (dy + 2)], acc); // (LDCF's taps are one chain of fused multiply-adds: this repo's definition)
         }
     }
     out[int64_t(frame) * out_fs + J.outOff + int64_t(pc) * h * w + i] = acc;
@@ -3963,6 +3963,140 @@ __device__ __forceinline__ void rt_passes(const ResampleDesc& d, const int32_t* 
             }
         }
         B[int64_t(xb0 + c) * hb + yb] = v;
+    }
+}
+
+// rt_passes for tiles of at most 16 output columns (k_ldcf_tile), arranged for memory-level parallelism: a wave's four columns
+// are in flight together and every tap read is unconditional (a tap beyond m / ny is read from wherever the index lands inside
+// the workgroup's LDS and dropped by a select), where rt_passes' branches serialised one LDS round trip per tap.  Same products,
+// same sums in the same order: bit-identical to rt_passes.  xrecTile: the tile's column records, in LDS.
+__device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const float* T, float* C,
+    float* __restrict__ B, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int colLo, int nRows, float r, float rk, const int32_t* xrecTile)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ha = d.ha, hb = d.hb;
+    const int xmode = d.xmode, ymode = d.ymode;
+    const int nXo = xb1 - xb0;
+    int toff[4], m[4], wofs[4];
+    float w[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int32_t* rec = xrecTile + 8 * min(wv + 4 * k, nXo - 1);
+        toff[k] = (rec[0] - colLo) * nRows;
+        m[k] = rec[1];
+        wofs[k] = rec[2];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            w[k][j] = (xmode == RS_EXACT) ? 1.f : __int_as_float(rec[4 + j]);
+        }
+    }
+    for (int rr = lane; rr < nRows; rr += 64)
+    {
+        const bool below = rowLo + rr >= ha; // C[ha .. ha+3] = 0 (imResampleMex.cpp:133-137)
+        float t[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                t[k][j] = T[toff[k] + j * nRows + rr];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int c = wv + 4 * k;
+            float s;
+            if (xmode == RS_EXACT)
+            {
+                s = t[k][0] + t[k][1];
+                const float s2 = s + t[k][2];
+                s = m[k] > 2 ? s2 : s;
+                const float s3 = s + t[k][3];
+                s = m[k] > 3 ? s3 : s;
+            }
+            else
+            {
+                s = t[k][0] * w[k][0];
+                const float s1 = s + t[k][1] * w[k][1];
+                s = m[k] > 1 ? s1 : s;
+                const float s2 = s + t[k][2] * w[k][2];
+                s = m[k] > 2 ? s2 : s;
+                const float s3 = s + t[k][3] * w[k][3];
+                s = m[k] > 3 ? s3 : s;
+                for (int j = 4; j < m[k]; j++)
+                {
+                    s = s + T[toff[k] + j * nRows + rr] * ft[wofs[k] + j];
+                }
+            }
+            if (c < nXo)
+            {
+                C[c * nRows + rr] = below ? 0.f : s;
+            }
+        }
+    }
+    __syncthreads();
+    // y pass: lane = output row, the wave's four columns together
+    if (!tp.act)
+    {
+        return;
+    }
+    const int ya = tp.ya, ny = tp.ny;
+    if (tp.ySlow)
+    {
+        for (int c = wv; c < nXo; c += 4)
+        {
+            const float* Cc = C + c * nRows - rowLo;
+            float v = 0.f;
+            for (int q = tp.q0; q < tp.q1; q++)
+            {
+                v = v + Cc[it[d.y_src + q]] * (ft[d.y_wt + q] * r);
+            }
+            B[int64_t(xb0 + c) * hb + yb] = v;
+        }
+        return;
+    }
+    float u[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const float* Cc = C + min(wv + 4 * k, nXo - 1) * nRows - rowLo;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            u[k][j] = Cc[ya + j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int c = wv + 4 * k;
+        float v;
+        if (ymode == RS_EXACT)
+        {
+            float sacc = u[k][0] + u[k][1];
+            const float s2 = sacc + u[k][2];
+            sacc = ny > 2 ? s2 : sacc;
+            const float s3 = sacc + u[k][3];
+            sacc = ny > 3 ? s3 : sacc;
+            v = sacc * rk;
+        }
+        else
+        {
+            v = u[k][0] * tp.wy[0];
+            v = v + u[k][1] * tp.wy[1];
+            const float v2 = v + u[k][2] * tp.wy[2];
+            v = ny > 2 ? v2 : v;
+            const float v3 = v + u[k][3] * tp.wy[3];
+            v = ny > 3 ? v3 : v;
+        }
+        if (c < nXo)
+        {
+            B[int64_t(xb0 + c) * hb + yb] = v;
+        }
     }
 }
 
@@ -4248,13 +4382,28 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
     const int yb = yb0 + lane;
     const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
     const float* __restrict__ A = pyr + int64_t(blockIdx.z) * pyr_fs + L.inOff + int64_t(c) * ha * wa;
-    for (int i = threadIdx.x; i < (nCols + 4) * pR; i += 256)
+    // LDS-DMA, 64 consecutive tile cells per wave instruction: the whole tile is in flight at once (a load -> ds_write loop
+    // exposed one memory round trip per 256 cells); cells outside the plane are written as zeros by their lanes
+    const int nP = (nCols + 4) * pR;
+    for (int i0 = (threadIdx.x >> 6) * 64; i0 < nP; i0 += 256)
     {
+        const int i = i0 + lane;
         const int cc = i / pR, rr = i - cc * pR;
         const int x = colLo + cc - 2, y = rowLo + rr - 2;
         const bool ok = x >= 0 && x < wa && y >= 0 && y < ha;
-        P[i] = ok ? A[int64_t(x) * ha + y] : 0.f;
+        if (i < nP)
+        {
+            if (ok)
+            {
+                __builtin_amdgcn_global_load_lds((gptr_t)(A + int64_t(x) * ha + y), (lptr_t)(P + i0), 4, 0, 0);
+            }
+            else
+            {
+                P[i] = 0.f;
+            }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int f = 0; f < K; f++)
     {
@@ -4267,10 +4416,11 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
         for (int k = 0; k < 25; k++)
         {
             w[k] = fw[k];
+            ACF_PIN_V(w[k]); // (in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without, and each tap multiplies four times)
         }
         // a thread takes four consecutive COLUMNS at one tile row (lanes along the rows: conflict-free LDS reads): the 8 x 5
         // cells they share are read once, 10 LDS reads per output instead of 25; per output the taps are still added dx
-        // then dy ascending (k_ldcf_conv's order)
+        // then dy ascending, as ONE chain of fused multiply-adds starting from 0 (k_ldcf_conv's order; v_fma_f32 = C's fmaf)
         const int nQ = (nCols + 3) >> 2;
         for (int i = threadIdx.x; i < nQ * nRows; i += 256)
         {
@@ -4297,7 +4447,7 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
 #pragma unroll
                     for (int dy = -2; dy <= 2; dy++)
                     {
-                        acc = acc + v[j + 2 - dx][2 - dy] * w[(dx + 2) * 5 + (dy + 2)];
+                        acc = __builtin_fmaf(v[j + 2 - dx][2 - dy], w[(dx + 2) * 5 + (dy + 2)], acc);
                     }
                 }
                 if (cc + j < nCols)
@@ -4308,8 +4458,9 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
         }
         __syncthreads();
         float* __restrict__ B = out + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(pc) * hb * wb;
-        rt_passes(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk, recL);
-        __syncthreads(); // T and C are rewritten by the next filter
+        // (no barrier after the y pass: it reads C only, the next filter's conv writes T only, and the x pass that rewrites C
+        // comes after the barrier that follows that conv)
+        rt_passes16(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk, recL);
     }
 }
 

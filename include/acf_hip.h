@@ -113,7 +113,8 @@ typedef struct acf_hip_params
      *   level    = imResample(C, .5)                                                 (size round(.5 * size))
      * and the cascade then runs with shrink*2 over nChns*k channels (fids index nChns*k*(modelDsPad/(2*shrink))^2 cells).
      * ldcfFilters: [k][nChns][5][5] floats in the MATLAB memory order of fs(:,:,c,f): tap (dy, dx) at dy + 5*dx.
-     * The summation order of the 25 taps (dx ascending, then dy ascending, accumulating from 0) is this repo's own.
+     * The summation order of the 25 taps (dx ascending, then dy ascending, one chain of
+     * fused multiply-adds acc = fmaf(v, w, acc) from 0: a single rounding per tap) is this repo's own.
      * ldcfK == 0 or ldcfFilters == NULL: off. */
     int32_t ldcfK;
     const float* ldcfFilters;

@@ -1927,7 +1927,7 @@ ACFO_API float acfo_evaluate(const float* chns, int hP, int wP, int nChns, const
  * acfDetectImg — per level C(:,:,j) = conv2(chns(:,:,mod(j-1,nC)+1), fs(:,:,j), 'same'); P.data{i} = imResample(C, .5);
  * cascade with shrink*2.  Planes are [w][h] with h contiguous (= MATLAB's column-major (h, w)); filter tap (dy, dx) of
  * filter f, channel c at filt[((f*nC + c)*5 + dx)*5 + dy].  Tap order (this repo's own choice): dx ascending, dy
- * ascending, accumulated from 0 in f32 without contraction.  Parity unpinned by construction.
+ * ascending, ONE chain of fused multiply-adds from 0 in f32 (acc = fmaf(v, w, acc): each step rounds once).  Parity unpinned by construction.
  * ---------------------------------------------------------------------- */
 static int round_half_away(double v)
 {
@@ -1947,7 +1947,7 @@ ACFO_API void acfo_ldcf_conv(const float* in, float* out, int h, int w, const fl
                 {
                     const int xx = x - dx, yy = y - dy;
                     const float v = (xx >= 0 && xx < w && yy >= 0 && yy < h) ? in[(size_t)xx * h + yy] : 0.f;
-                    acc = acc + v * f[(dx + 2) * 5 + (dy + 2)];
+                    acc = fmaf(v, f[(dx + 2) * 5 + (dy + 2)], acc); /* one chain of fused multiply-adds (exactly rounded: == the device's v_fma_f32) */
                 }
             }
             out[(size_t)x * h + y] = acc;
