@@ -5076,6 +5076,39 @@ struct CascTile
     int16_t r0, c0; // first window row / column of the tile
 };
 
+static_assert(sizeof(CascTile) == 8, "k_cascade_tile3 reads a CascTile as two dwords");
+static_assert(offsetof(CascLevel, nWinR) == 8 && offsetof(CascLevel, off) == 24 && offsetof(CascLevel, offR) == 40 && offsetof(CascLevel, pitchR) == 48,
+    "k_cascade_tile3 reads a CascLevel as dwords");
+
+// A tile's / a level's record through the scalar unit (read-only tables at workgroup-uniform addresses): the pooled tile kernels take
+// their pointers inside an argument struct, where the compiler cannot prove the tables read-only and would issue vector loads +
+// v_readfirstlane — two dependent L2 round trips at the head of every tile.  (As dwords: a CascTile's own alignment is 2.)
+typedef const __attribute__((address_space(4))) uint32_t* cu32_k;
+__device__ __forceinline__ CascTile load_tile_k(const CascTile* p)
+{
+    cu32_k tp = (cu32_k)(uintptr_t)p;
+    const uint32_t w0 = tp[0], w1 = tp[1];
+    CascTile T;
+    T.level = int16_t(w0 & 0xffffu);
+    T.pad_ = 0;
+    T.r0 = int16_t(w1 & 0xffffu);
+    T.c0 = int16_t(w1 >> 16);
+    return T;
+}
+__device__ __forceinline__ CascLevel load_level_k(const CascLevel* p) // (the fields the tile kernels use)
+{
+    cu32_k lp = (cu32_k)(uintptr_t)p;
+    CascLevel L;
+    L.hP = int32_t(lp[0]);
+    L.wP = int32_t(lp[1]);
+    L.nWinR = int32_t(lp[2]);
+    L.nWinC = int32_t(lp[3]);
+    L.off = int64_t(uint64_t(lp[6]) | (uint64_t(lp[7]) << 32));
+    L.offR = int64_t(uint64_t(lp[10]) | (uint64_t(lp[11]) << 32));
+    L.pitchR = int32_t(lp[12]);
+    return L;
+}
+
 struct __attribute__((aligned(16))) TreeNode
 {
     uint32_t off[4]; // float offset of nodes 0,1,2 relative to the window's first cell; [3] unused
@@ -5988,12 +6021,16 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     const int xcd = blockIdx.x & 7;
     __shared__ int s_next[2]; // (two slots: a wave that is late reading tile n's successor never meets tile n + 1's write)
     const bool persist = a.tileNext != nullptr; // else: one tile per workgroup, blockIdx.x -> tile as k_cascade_tile2
-    if (tid == 0)
+    int li = int(blockIdx.x >> 3);
+    if (persist) // (a kernel argument: workgroup-uniform)
     {
-        s_next[0] = persist ? atomicAdd(a.tileNext + xcd, 1) : int(blockIdx.x >> 3);
+        if (tid == 0)
+        {
+            s_next[0] = atomicAdd(a.tileNext + xcd, 1);
+        }
+        __syncthreads();
+        li = __builtin_amdgcn_readfirstlane(s_next[0]);
     }
-    __syncthreads();
-    int li = s_next[0];
     int par = 1;
     const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
     const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
@@ -6008,16 +6045,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
         const uint4 o = np[0], tq = np[1];
         so0 = o.x, so1 = o.y, so2 = o.z;
         st0 = tq.x, st1 = tq.y, st2 = tq.z;
-        for (int t = tid; t < TsPad; t += NT)
-        {
-            float4 hv = make_float4(-0.f, -0.f, -0.f, -0.f); // rows past the last tree: h + -0.0f == h for every h
-            if (t < Ts)
-            {
-                hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
-            }
-            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
-        }
     }
+    bool leavesDone = Ts <= 0; // (the leaf table is copied once, behind the first tile's fill requests: its loads ride on the fill's latency)
     for (;;)
     {
     const int64_t id = int64_t(xcd) * perX + li;
@@ -6030,9 +6059,14 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     {
         liNext = atomicAdd(a.tileNext + xcd, 1); // (returns during the fill)
     }
+    // tile and level records through the scalar unit (read-only tables, workgroup-uniform addresses): two short dependent s_loads
+    // where vector loads + v_readfirstlane were two L2 round trips; everything the window test needs arrives with them, so
+    // nothing is re-read behind the fill's barrier
     const int frame = int(id / a.nTiles);
-    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+    const CascTile T = load_tile_k(a.tiles + (id - int64_t(frame) * a.nTiles));
     const int lvl = T.level;
+    const CascLevel L = load_level_k(a.levels + lvl);
+    const int nWinR = L.nWinR;
     if (tid < 4)
     {
         s_n[tid] = 0;
@@ -6040,7 +6074,6 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     TILE_STAMP(0);
     // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
     {
-        const CascLevel L = a.levels[lvl];
         const int colsT = a.g.colsT;
         const int gr0 = T.r0 * step, gc0 = T.c0 * step;
         const int colPitch = CT::RANK ? L.pitchR : L.hP;
@@ -6069,12 +6102,27 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     {
         s_next[par] = liNext; // (read after this tile's last barrier)
     }
+    // stage A1's window of this lane: wave w takes the window columns w, w + NW, ... (conflict-free feature reads)
+    const int r_l = lane % TR, c_l = (lane / TR) * NW + wv;
+    const bool aliveA1 = (T.r0 + r_l) < nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / TR) * TR;
+    if (!leavesDone)
+    {
+        for (int t = tid; t < TsPad; t += NT)
+        {
+            float4 hv = make_float4(-0.f, -0.f, -0.f, -0.f); // rows past the last tree: h + -0.0f == h for every h
+            if (t < Ts)
+            {
+                hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
+            }
+            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
+        }
+        leavesDone = true;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     TILE_STAMP(1);
 
     const float thrC = a.cascThr;
-    const int nWinR = a.levels[lvl].nWinR;
     // survivors of the model's last tile tree: hits (model exhausted) or the frame's tail queue + stage E's list {slot, tag | offset}
     auto finish = [&](tile_args_k A, bool alive, uint32_t tw, float h) {
         const int tag = int(tw & 0xffffu);
@@ -6128,8 +6176,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
 
     // ---- A1: lanes = windows, trees [0, b1).  Wave w takes the window columns w, w + NW, ... (conflict-free feature reads)
     {
-        const int r_l = lane % TR, c_l = (lane / TR) * NW + wv;
-        bool alive = (T.r0 + r_l) < nWinR && (T.c0 + c_l) < a.levels[lvl].nWinC && lane < (64 / TR) * TR;
+        bool alive = aliveA1;
         float h = 0.f;
         const uint32_t woff = uint32_t((min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step);
         dense(tileF + woff, 0, b1, h, alive);
@@ -6270,7 +6317,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     }
     TILE_STAMP(5);
     __syncthreads(); // (stage E's list is complete; every wave is done with the codes and the lists' other uses)
-    li = s_next[par];
+    li = __builtin_amdgcn_readfirstlane(s_next[par]);
     par ^= 1;
     if (!wantE)
     {
@@ -6626,12 +6673,16 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
     const int perX = int((total + 7) >> 3);
     const int xcd = blockIdx.x & 7;
     const bool persist = a.tileNext != nullptr;
-    if (tid == 0)
+    int li = int(blockIdx.x >> 3);
+    if (persist) // (a kernel argument: workgroup-uniform)
     {
-        s_next[0] = persist ? atomicAdd(a.tileNext + xcd, 1) : int(blockIdx.x >> 3);
+        if (tid == 0)
+        {
+            s_next[0] = atomicAdd(a.tileNext + xcd, 1);
+        }
+        __syncthreads();
+        li = __builtin_amdgcn_readfirstlane(s_next[0]);
     }
-    __syncthreads();
-    int li = s_next[0];
     int par = 1;
     const int step = a.g.step, rowsP = a.g.rowsP, TR = a.g.TR;
     const int b1 = a.g.b[1], b2 = a.g.b[2], tEnd = a.g.b[4];
@@ -6651,12 +6702,8 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
             so[k] = Ts > 0 ? a.tileOff[q + k] : 0u;
             sth[k] = Ts > 0 ? __float_as_uint(a.thrs[q + k]) : 0u;
         }
-        for (int x = tid; x < TsPad * NL; x += NT)
-        {
-            const int t = x / NL, j = x - t * NL;
-            leafT[x] = t < Ts ? a.hs[int64_t(b2 + t) * a.nTreeNodes + NN + j] : -0.0f; // (padding: h + -0.0f == h for every h)
-        }
     }
+    bool leavesDone = false; // (the leaf table is copied once, behind the first tile's fill requests)
     for (;;)
     {
         const int64_t id = int64_t(xcd) * perX + li;
@@ -6670,9 +6717,9 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
             liNext = atomicAdd(a.tileNext + xcd, 1);
         }
         const int frame = int(id / a.nTiles);
-        const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
+        const CascTile T = load_tile_k(a.tiles + (id - int64_t(frame) * a.nTiles));
         const int lvl = T.level;
-        const CascLevel L = a.levels[lvl];
+        const CascLevel L = load_level_k(a.levels + lvl);
         if (tid < 4)
         {
             s_n[tid] = 0;
@@ -6706,6 +6753,15 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
         if (tid == 0)
         {
             s_next[par] = liNext;
+        }
+        if (!leavesDone)
+        {
+            for (int x = tid; x < TsPad * NL; x += NT)
+            {
+                const int t = x / NL, j = x - t * NL;
+                leafT[x] = t < Ts ? a.hs[int64_t(b2 + t) * a.nTreeNodes + NN + j] : -0.0f; // (padding: h + -0.0f == h for every h)
+            }
+            leavesDone = true;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -6870,7 +6926,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3D(TileDArgs a)
             }
         }
         __syncthreads();
-        li = s_next[par];
+        li = __builtin_amdgcn_readfirstlane(s_next[par]);
         par ^= 1;
         if (!wantE)
         {
