@@ -6228,7 +6228,6 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
         const int n2 = s_n[1];
         const int wpr = NT >> tlShift; // windows per round
         const int pitchC = ak->g.pitchC;
-        int nE = 0; // (wave 0) entries of stage E's list so far
         for (int p0 = 0; p0 < n2; p0 += passW)
         {
             const int nP = min(passW, n2 - p0);
@@ -6253,66 +6252,114 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
                 }
             }
             __syncthreads();
-            if (wv == 0)
+            // the ordered chain, FOUR lanes per window (a wave takes 16 windows; waves 0 .. 3 a pass of 64): lane j of a window
+            // fetches the leaves of trees 4j .. 4j + 3 of every group of 16 — one dword of code bytes, four table reads — and the
+            // window's score is added up in tree order with the leaves broadcast inside the quad (DPP quad_perm), identically
+            // in its four lanes: evaluate()'s additions in evaluate()'s order.  (One lane per window read 16 + 16 times per
+            // group and its wave ran alone: 2.7k of a tile's 18k cycles.)  Next group's leaves and the code dword after that
+            // are requested before a group is added.
+            constexpr int CH = NW >= 4 ? 1 : 4 / NW; // chunks of 16 windows per wave (a pass is at most 64 windows)
+            bool aliveS[CH];
+            int slotS[CH];
+            uint32_t tagS[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++)
             {
-                const bool valid = lane < nP;
-                const uint2 en = l2[p0 + (valid ? lane : 0)];
+                aliveS[ch] = false;
+                slotS[ch] = -1;
+                tagS[ch] = 0;
+                const int w0 = (ch * NW + wv) * 16;
+                if (w0 >= nP || w0 >= 64) // (wave-uniform)
+                {
+                    continue;
+                }
+                const int wl = w0 + (lane >> 2), j = lane & 3;
+                const bool valid = wl < nP;
+                const uint2 en = l2[p0 + (valid ? wl : 0)];
                 float h = __uint_as_float(en.x);
                 float hMin = __builtin_inff();
-                const uint8_t* crow = codes + (valid ? lane : 0) * pitchC;
-                const char* lt = reinterpret_cast<const char*>(leafT);
-                // the code bytes of group g + 1 are requested before group g's leaves are added
-                uint32_t cb[16];
+                const char* crow = reinterpret_cast<const char*>(codes) + (valid ? wl : 0) * pitchC + 4 * j;
+                const char* lt = reinterpret_cast<const char*>(leafT) + 64 * j; // tree 16 g + 4 j + k: row at 256 g + 64 j + 16 k
+                const int nG = TsPad >> 4;
+                uint32_t cw = *reinterpret_cast<const uint32_t*>(crow);
+                float lf[4];
 #pragma unroll
-                for (int k = 0; k < 16; k++)
+                for (int k = 0; k < 4; k++)
                 {
-                    cb[k] = crow[k];
+                    lf[k] = *reinterpret_cast<const float*>(lt + 16 * k + ((cw >> (8 * k)) & 0xffu));
                 }
-                for (int t = 0; t < TsPad; t += 16)
+                cw = *reinterpret_cast<const uint32_t*>(crow + 16 * min(1, nG - 1));
+                for (int g = 0; g < nG; g++)
                 {
-                    float lf[16];
+                    float cur[4], nx[4];
+                    const char* ltN = lt + 256 * min(g + 1, nG - 1);
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
+                    for (int k = 0; k < 4; k++)
                     {
-                        lf[k] = *reinterpret_cast<const float*>(lt + 16 * (t + k) + cb[k]);
+                        cur[k] = lf[k];
+                        nx[k] = *reinterpret_cast<const float*>(ltN + 16 * k + ((cw >> (8 * k)) & 0xffu));
                     }
-                    const int tn = min(t + 16, TsPad - 16);
+                    const uint32_t cwN = *reinterpret_cast<const uint32_t*>(crow + 16 * min(g + 2, nG - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+#define ACF_QUAD_BCAST(x, q) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), (q) * 0x55, 0xf, 0xf, true))
+#define ACF_CHAIN_QUAD(q)                                                            \
+    {                                                                                \
+        const float h1 = h + ACF_QUAD_BCAST(cur[0], q);                              \
+        const float h2 = h1 + ACF_QUAD_BCAST(cur[1], q);                             \
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));            \
+        const float h3 = h2 + ACF_QUAD_BCAST(cur[2], q);                             \
+        const float h4 = h3 + ACF_QUAD_BCAST(cur[3], q);                             \
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h3), "v"(h4));            \
+        h = h4;                                                                      \
+    }
+                        ACF_CHAIN_QUAD(0)
+                        ACF_CHAIN_QUAD(1)
+                        ACF_CHAIN_QUAD(2)
+                        ACF_CHAIN_QUAD(3)
+#undef ACF_CHAIN_QUAD
+#undef ACF_QUAD_BCAST
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
+                    for (int k = 0; k < 4; k++)
                     {
-                        cb[k] = crow[tn + k];
+                        lf[k] = nx[k];
                     }
-#pragma unroll
-                    for (int k = 0; k < 16; k += 2)
-                    {
-                        const float h1 = h + lf[k];
-                        const float h2 = h1 + lf[k + 1];
-                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
-                        h = h2;
-                    }
+                    cw = cwN;
                 }
-                const bool alive = valid && hMin > thrC;
-                const int tag = int(en.y & 0xffffu);
-                const int rl = tag % TR, cl = tag / TR;
-                const EmitDst dst{ ak->hits, ak->counts, ak->q, ak->qcount, ak->maxHits, ak->qcap };
-                const int slot = tile_emit3(dst, lastAll, frame, alive, lvl, (T.c0 + cl) * nWinR + (T.r0 + rl), nWinR, h);
-                if (wantE)
+                aliveS[ch] = valid && j == 0 && hMin > thrC;
+                tagS[ch] = en.y;
+                if (__ballot(aliveS[ch])) // (most chunks end with no window alive: none of the index arithmetic then)
                 {
-                    // in place: nE + (survivors of this pass) <= p0 + nP, and this pass's entries are in registers
-                    const unsigned long long m = __ballot(alive);
-                    __builtin_amdgcn_wave_barrier();
-                    if (alive)
-                    {
-                        l2[nE + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slot), en.y);
-                    }
-                    nE += __popcll(m);
+                    const int tag = int(en.y & 0xffffu);
+                    const int rl = tag % TR, cl = tag / TR;
+                    const EmitDst dst{ ak->hits, ak->counts, ak->q, ak->qcount, ak->maxHits, ak->qcap };
+                    slotS[ch] = tile_emit3(dst, lastAll, frame, aliveS[ch], lvl, (T.c0 + cl) * nWinR + (T.r0 + rl), nWinR, h);
                 }
             }
-            __syncthreads(); // (the next pass rewrites the codes)
-        }
-        if (wantE && tid == 0)
-        {
-            s_n[3] = nE;
+            __syncthreads(); // (the next pass rewrites the codes; every chain wave has read its entries of list 2)
+            if (wantE)
+            {
+                // stage E's list, in place at the head of list 2: (entries so far) + (survivors of this pass) <= p0 + nP, this
+                // pass's entries are in registers, and the next pass reads from p0 + passW on
+#pragma unroll
+                for (int ch = 0; ch < CH; ch++)
+                {
+                    const unsigned long long m = __ballot(aliveS[ch]);
+                    if (m)
+                    {
+                        int base = 0;
+                        if (lane == 0)
+                        {
+                            base = atomicAdd(&s_n[3], __popcll(m));
+                        }
+                        base = __shfl(base, 0);
+                        if (aliveS[ch])
+                        {
+                            l2[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(slotS[ch]), tagS[ch]);
+                        }
+                    }
+                }
+            }
         }
     }
     TILE_STAMP(5);
@@ -6323,7 +6370,6 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     {
         continue;
     }
-    TILE_STAMP(6);
     // ---- E: leaf codes of every tail tree for the windows now in the tail queue (k_cascade_tile2's stage E over one list)
     const int nTail = s_n[3];
 #ifdef ACF_HIP_STAMPS
