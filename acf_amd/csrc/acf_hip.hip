@@ -57,6 +57,10 @@ struct CascState
     uint32_t* d_fids = nullptr;
     CascNode2* d_nodes2 = nullptr;
     acf_hip_hit *d_hits = nullptr, *d_sorted = nullptr;
+    // stride < shrink: the cascade runs on the grid of distinct window offsets (kernels.hip.h, k_expand_hits)
+    int dedupQ = 1;                  // shrink / stride when that is an integer > 1, else 1
+    int2* d_realWin = nullptr;       // [level] {nWinR, nWinC} of the real window grid
+    acf_hip_hit* d_hitsX = nullptr;  // the expanded hits (k_sort_map's input)
     acf_hip_detection* d_dets = nullptr;
     int32_t* d_counts = nullptr;
     uint2* d_queue[2] = { nullptr, nullptr }; // survivor queues between cascade stages
@@ -1696,6 +1700,8 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         }
     }
     int block = 0;
+    cs.dedupQ = (p.stride < p.shrink && p.shrink % p.stride == 0 && !getenv("ACF_HIP_NO_DEDUP")) ? p.shrink / p.stride : 1;
+    std::vector<int2> realWin(lv.size());
     for (size_t i = 0; i < lv.size(); i++)
     {
         CascLevel& L = cl[i];
@@ -1703,6 +1709,13 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         L.wP = lv[i].wP;
         L.nWinR = lv[i].nWinR;
         L.nWinC = lv[i].nWinC;
+        realWin[i] = make_int2(L.nWinR, L.nWinC);
+        if (cs.dedupQ > 1)
+        {
+            // distinct offsets r * stride / shrink of the windows r = 0 .. nWinR - 1
+            L.nWinR = L.nWinR > 0 ? (L.nWinR - 1) / cs.dedupQ + 1 : 0;
+            L.nWinC = L.nWinC > 0 ? (L.nWinC - 1) / cs.dedupQ + 1 : 0;
+        }
         L.nWin = L.nWinR * L.nWinC;
         L.off = lv[i].offset;
         L.firstBlock = block;
@@ -1766,6 +1779,10 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     }
     *blocksPerFrame = block;
     int rc;
+    if (cs.dedupQ > 1 && (rc = devUpload(c, &cs.d_realWin, realWin)))
+    {
+        return rc;
+    }
     if ((rc = devUpload(c, d_levels, cl)))
     {
         return rc;
@@ -2750,6 +2767,10 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         box[i].bw = int(std::lrint(double(p.modelDs_w) / pl.levels[i].scale));
     }
     if ((rc = devUpload(c, &c->d_boxLevels, box)))
+    {
+        return rc;
+    }
+    if (c->cs.dedupQ > 1 && (rc = devAlloc(c, &c->cs.d_hitsX, size_t(B) * max_hits)))
     {
         return rc;
     }
@@ -4471,7 +4492,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
         a.nTrees = p.nTrees;
         a.nTreeNodes = p.nTreeNodes;
         a.treeDepth = p.treeDepth;
-        a.stride = p.stride;
+        a.stride = c->cs.dedupQ > 1 ? p.shrink : p.stride; // (the grid of distinct offsets: its windows are one cell apart)
         a.shrink = p.shrink;
         a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
         a.cidAll = d_cidAll;
@@ -4745,8 +4766,20 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
     // shift = (modelDsPad - modelDs)/2 - pad (ACF.cpp:275; cv::Size integer arithmetic)
     const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
     const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
+    const acf_hip_hit* hitsForSort = c->cs.d_hits;
+    if (c->cs.dedupQ > 1)
+    {
+        if (!c->cs.d_hitsX || !c->cs.d_realWin)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "detect: no buffer for the windows that share an offset (stride < shrink)");
+        }
+        hipLaunchKernelGGL(k_expand_hits, dim3(nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, c->cs.d_counts, c->cs.d_hitsX, c->maxHits,
+            (const int2*)c->cs.d_realWin, c->cs.dedupQ);
+        LAUNCHCHK(c, "k_expand_hits");
+        hitsForSort = c->cs.d_hitsX;
+    }
     prof(c, "k_sort_map");
-    hipLaunchKernelGGL(k_sort_map, dim3(SM_BLOCKS, nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, (const int32_t*)c->cs.d_counts, c->maxHits,
+    hipLaunchKernelGGL(k_sort_map, dim3(SM_BLOCKS, nF), dim3(256), 0, c->stream, hitsForSort, (const int32_t*)c->cs.d_counts, c->maxHits,
         d_box, p.stride, shift_h, shift_w, c->cs.d_sorted, c->cs.d_dets);
     LAUNCHCHK(c, "k_sort_map");
     if (c->nmsOn && c->nms.type != 0)
@@ -6287,6 +6320,10 @@ static int opAcfDetect1(acf_hip_ctx* c, const void* chns, bool u8, int hP, int w
     if (!rc)
     {
         rc = devAlloc(c, &c->cs.d_hits, size_t(cap));
+    }
+    if (!rc && c->cs.dedupQ > 1)
+    {
+        rc = devAlloc(c, &c->cs.d_hitsX, size_t(cap));
     }
     if (!rc)
     {

@@ -7667,6 +7667,54 @@ __device__ __forceinline__ void sort_map_body(const acf_hip_hit* __restrict__ H,
     }
 }
 
+// stride < shrink (LDCF's default: stride 4 on cells of 8 pixels): acfDetect1 places window (r, c) at cell offset
+// (r * stride / shrink, c * stride / shrink) — integer division (acfDetect1.cpp:88-96) —, so shrink / stride consecutive rows
+// and columns of windows read the SAME cells and get the same score.  The cascade then runs once per distinct offset (CascLevel
+// carries the distinct grid, CascArgs::stride = shrink) and this kernel writes every window of a surviving offset: hit (r', c')
+// of the distinct grid -> windows r' q .. r' q + q - 1 (< nWinR), c' q .. (< nWinC), q = shrink / stride, all with its score.
+// One workgroup per frame; k_sort_map orders the result by (level, c, r) whatever order it was written in.
+__global__ void __launch_bounds__(256) k_expand_hits(const acf_hip_hit* __restrict__ in, int32_t* __restrict__ counts, acf_hip_hit* __restrict__ out, int maxHits,
+    const int2* __restrict__ realWin, int q)
+{
+    __shared__ int s_total;
+    const int frame = blockIdx.x;
+    const int n = counts[frame], m = min(n, maxHits);
+    if (threadIdx.x == 0)
+    {
+        s_total = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256)
+    {
+        const acf_hip_hit hd = in[int64_t(frame) * maxHits + i];
+        const int2 rw = realWin[hd.scale];
+        const int r0 = hd.r * q, c0 = hd.c * q;
+        const int nr = min(q, rw.x - r0), nc = min(q, rw.y - c0);
+        const int base = atomicAdd(&s_total, nr * nc);
+        for (int dc = 0; dc < nc; dc++)
+        {
+            for (int dr = 0; dr < nr; dr++)
+            {
+                const int idx = base + dc * nr + dr;
+                if (idx < maxHits)
+                {
+                    acf_hip_hit h;
+                    h.scale = hd.scale;
+                    h.c = c0 + dc;
+                    h.r = r0 + dr;
+                    h.score = hd.score;
+                    out[int64_t(frame) * maxHits + idx] = h;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        counts[frame] = n > maxHits ? max(n, s_total) : s_total; // (a count above maxHits is the caller's overflow signal either way)
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sort_map(const acf_hip_hit* __restrict__ hits, const int32_t* __restrict__ counts,
     int maxHits, const BoxLevel* __restrict__ bl, int stride, int shift_h, int shift_w,
     acf_hip_hit* __restrict__ sortedHits, acf_hip_detection* __restrict__ dets)

@@ -321,16 +321,25 @@ def test_acf_detect1_u8(dev, oracle, depth, explicit_thrs):
     assert np.array_equal(bits(got["score"]), bits(want["score"]))
 
 
-@pytest.mark.parametrize("case", ["stride8", "wide_model", "tall_plane", "one_window", "permissive"])
+@pytest.mark.parametrize("case", ["stride8", "wide_model", "tall_plane", "one_window", "permissive", "stride2", "stride1", "stride2_odd", "stride3"])
 def test_acf_detect1_tiled_geometries(dev, oracle, case):
     """Tile edge cases of the LDS-tiled cascade: step 2 between windows, a non-square model, a plane with
     many tiles along r, a plane that holds exactly one window, and a threshold nothing is rejected by
-    (every window reaches the tail queue)."""
+    (every window reaches the tail queue).  stride < shrink (acfDetect1.cpp:88-96: window (r, c) sits at cell
+    r * stride / shrink, so shrink / stride windows share an offset): the cascade runs once per distinct offset and
+    k_expand_hits writes every window of it (stride 2 and 1 on cells of 4; a grid whose last offset has fewer windows;
+    stride 3, which does not divide the shrink and keeps one evaluation per window)."""
     nC = 10
     kw = dict(name="TINY", nTrees=160, cascThr=-3.0)
     wP, hP = 70, 50
     if case == "stride8":
         kw.update(stride=8)
+    elif case in ("stride2", "stride1", "stride3"):
+        kw.update(stride=int(case[-1]), cascThr=-1.5)
+        wP, hP = 40, 33
+    elif case == "stride2_odd":
+        kw.update(stride=2, cascThr=-1.5)
+        wP, hP = 31, 28
     elif case == "wide_model":
         kw.update(modelDs_h=16, modelDs_w=40, modelDsPad_h=16, modelDsPad_w=40)
     elif case == "tall_plane":
@@ -355,7 +364,7 @@ def test_acf_detect1_tiled_geometries(dev, oracle, case):
                                       C.byref(params), want.ctypes.data_as(C.POINTER(capi.Hit)), 1 << 16, 0)
     want = want[:n]
     assert n > 0, n
-    assert len(got) == n
+    assert len(got) == n, (len(got), n)
     for k in ("scale", "c", "r"):
         assert np.array_equal(got[k], want[k]), k
     assert np.array_equal(bits(got["score"]), bits(want["score"]))

@@ -54,7 +54,7 @@ VARIANTS = [
     "ACF_HIP_CASCADE_TURNS=5",
     "ACF_HIP_GRAPH=1",
 ]
-LDCF_VARIANTS = ["", "ACF_HIP_LDCF_UNFUSED=1", "ACF_HIP_LDCF_UNFUSED=1 ACF_HIP_RESAMPLE_GENERIC=1"]
+LDCF_VARIANTS = ["", "ACF_HIP_LDCF_UNFUSED=1", "ACF_HIP_LDCF_UNFUSED=1 ACF_HIP_RESAMPLE_GENERIC=1", "ACF_HIP_NO_DEDUP=1"]
 # fixed depths other than 2: the pooled tile kernel (k_cascade_tile3D) and the forms an environment variable selects instead
 DEPTH_VARIANTS = [(1, ""), (1, "ACF_HIP_NO_RANK=1"), (1, "ACF_HIP_TILED_STAGED=1"), (1, "ACF_HIP_NO_RANK=1 ACF_HIP_TILED_POOLED1=1"), (1, "ACF_HIP_TILE_PERSIST=0"),
                   (3, "ACF_HIP_NO_RANK=1"), (4, "ACF_HIP_NO_RANK=1"), (3, ""), (3, "ACF_HIP_TILED_STAGED=1"),
