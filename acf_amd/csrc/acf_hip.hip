@@ -904,6 +904,7 @@ int acf_hip_abi_version(void)
 // two streams that share a queue never overlap: with seven streams per context the main streams of three contexts
 // shared queues (rocprofv3 timeline: never more than two kernels at once; profiles/timeline.py).
 constexpr int ACF_SIDE_STREAMS = 6;
+constexpr int LEVEL_MAX_R_REAL = 9; // k_level<R, LM_REAL> is instantiated up to nine rows per lane (a 4K frame's 540-cell level), resampling forms up to eight
 static void ensureSide(acf_hip_ctx* c)
 {
     while (int(c->side.size()) < std::min<int>(ACF_SIDE_STREAMS, int(c->evJoin.size())))
@@ -2508,7 +2509,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             LevelJob j;
         };
         std::vector<Keyed> fusedJobs, rawJobs;
-        c->fusedOk = p.smooth > 0 && c->finalMaxH <= 64 * 8;
+        c->fusedOk = p.smooth > 0 && c->finalMaxH <= 64 * LEVEL_MAX_R_REAL;
         int ai = 0;
         for (size_t i = 0; i < pl.levels.size(); i++)
         {
@@ -2538,6 +2539,10 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                     c->fusedOk = false; // more than three taps on an axis or an exact 1/k ratio: separate launches
                 }
                 mode = dd.xmode == RS_DOWN ? (dd.ymode == RS_DOWN ? LM_DD : LM_DU) : (dd.ymode == RS_DOWN ? LM_UD : LM_UU);
+                if (R > 8)
+                {
+                    c->fusedOk = false; // (only copies of real levels are instantiated beyond eight rows per lane)
+                }
                 if (dd.ha >= 64 * (dd.ymode == RS_DOWN ? (3 * R + 1) / 2 : R))
                 {
                     // more source rows than LevelWindow's registers hold (ratio beyond 2^(1/2)), or no row left in the
@@ -3700,7 +3705,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         float* const chnsF = c->d_chns + int64_t(f0) * pl.raw_floats;
         float* const pyrF = c->d_pyr + int64_t(f0) * pl.pyr_floats;
         const int nL = int(pl.levels.size());
-        const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * 8 && c->levelMode != 0;
+        const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * LEVEL_MAX_R_REAL && c->levelMode != 0;
         const bool fused = waveSmooth && c->fusedOk && c->levelMode == 1;
         if (!fused && c->nApproxDescs > 0)
         {
@@ -3857,7 +3862,15 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     case 5: LV_MODES(5); break;
                     case 6: LV_MODES(6); break;
                     case 7: LV_MODES(7); break;
-                    default: LV_MODES(8); break;
+                    case 8: LV_MODES(8); break;
+                    default:
+                        // nine rows per lane: the full-resolution level of a 4K frame (540 cells); a real level's copy + smoothing only
+                        if (g.R != LEVEL_MAX_R_REAL || g.mode != LM_REAL)
+                        {
+                            return fail(c, ACF_HIP_E_UNSUPPORTED, "pyramid: level taller than the level kernels' rows per lane");
+                        }
+                        LV_LAUNCH(9, LM_REAL);
+                        break;
                 }
     #undef LV_MODES
     #undef LV_LAUNCH
