@@ -3356,7 +3356,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         bool colorDone = false;
         bool gradFused = false, gradBlocked = false; // M and O written by k_smooth_grad, in blocks
         const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 4 == 0 && rs.w >= 16 &&
-            rs.h / 4 <= 8 * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
+            rs.h / 4 <= SV_MAXW * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
         if (fuseSm)
         {
             // k_smooth_vec: smoothing + the level's colour channels (+ the next real scale's image when it is an exact half
@@ -3399,7 +3399,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             }
             prof(c, "k_smooth_vec");
             const int nq = rs.h / 4, nt = cdiv(nq, SV_OWN) * 64; // a wave owns SV_OWN row quads and shadows SV_K of each neighbour
-            const size_t ldsB = size_t(2) * 8 * 2 * SV_K * 4 * sizeof(float);
+            const size_t ldsB = size_t(2) * SV_MAXW * 2 * SV_K * 4 * sizeof(float);
             {
                 uint32_t fullMask = 0;
                 for (int z = 0; z < d; z++)

@@ -682,6 +682,7 @@ __device__ __forceinline__ float wave_ror1(float v)
 #define SV_CH 8
 constexpr int SV_K = 2;              // halo quads per side: 4 * SV_K rows = SV_CH columns of independence
 constexpr int SV_OWN = 64 - 2 * SV_K; // quads a wave owns
+constexpr int SV_MAXW = 10;          // waves per plane at most: planes of up to 4 * SV_MAXW * SV_OWN = 2400 rows (a 4K frame: 9 waves)
 // Speculative segments.  The recursion along image-x is a contraction: column i depends on column i - 1 through
 // nrm * (1, 2, 1) = a factor 1/4 (convConst.cpp:445-525 with p = 2), so the influence of whatever a chain STARTED from
 // shrinks fourfold per column and is below the last bit of every float after ~15-25 columns; once two chains agree in
@@ -900,7 +901,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
 #define SV_REFRESH(I0)                                                                            \
     if (nWv > 1)                                                                                  \
     {                                                                                             \
-        float* xs = lds + (((I0) >> 3) & 1) * (8 * 2 * SV_K * 4);                                 \
+        float* xs = lds + (((I0) >> 3) & 1) * (SV_MAXW * 2 * SV_K * 4);                                 \
         if (ownEdge)                                                                              \
         {                                                                                         \
             *reinterpret_cast<float4*>(xs + ((wv * 2 + ownSide) * SV_K + ownIdx) * 4) = make_float4(prev[0], prev[1], prev[2], prev[3]); \
@@ -1002,9 +1003,9 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
 // lasts as long as one plane whatever the number of planes.  The flag is workgroup-uniform: each specialisation keeps
 // its branch-free column loop.
 template <bool HALF>
-__global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fullMask)
+__global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_vec(SmoothVecArgs a, uint32_t fullMask)
 {
-    extern __shared__ float lds[]; // [2 chunk parities][8 waves][2 sides][SV_K quads][4]: the waves' edge state
+    extern __shared__ float lds[]; // [2 chunk parities][SV_MAXW waves][2 sides][SV_K quads][4]: the waves' edge state
     int z = a.plane0 + blockIdx.x;
     if (a.skipZ >= 0 && z >= a.skipZ)
     {
@@ -1029,7 +1030,7 @@ __global__ void __launch_bounds__(512) k_smooth_vec(SmoothVecArgs a, uint32_t fu
 // frame and scale 0; it is still written at a scale later scales are resampled from).  Its workgroups carry the acos table
 // (80 KB of LDS), which is why the other planes stay in k_smooth_vec's launch (a launch has ONE LDS size).
 template <bool HALF>
-__global__ void __launch_bounds__(512) k_smooth_grad(SmoothVecArgs a, uint32_t fullMask)
+__global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, uint32_t fullMask)
 {
     extern __shared__ float lds[]; // the waves' edge state (k_smooth_vec), then the acos table
     const int z = a.plane0;
@@ -1037,7 +1038,7 @@ __global__ void __launch_bounds__(512) k_smooth_grad(SmoothVecArgs a, uint32_t f
     {
         return;
     }
-    float* acosL = lds + 2 * 8 * 2 * SV_K * 4;
+    float* acosL = lds + 2 * SV_MAXW * 2 * SV_K * 4;
     for (int i = threadIdx.x; i < GM_ACOS_N; i += blockDim.x)
     {
         acosL[i] = a.acos[i];
