@@ -2077,7 +2077,9 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
 // Tiling of a down-sampling descriptor for k_resample_tile: output columns per tile (the largest of 32/16/8 whose
 // source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
 // int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
-static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena, int forceXo = 0, int64_t ldsBudget = int64_t(64) * 1024)
+// (yo: output rows per tile — RT_YO for the resample kernels, k_ldcf_tile chooses its own; forceXo may be any column count)
+static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena, int forceXo = 0, int64_t ldsBudget = int64_t(64) * 1024, int yo = RT_YO,
+    int maxRows = 1 << 30, int maxCols = 1 << 30)
 {
     ResampleTiling tl;
     if (!((dd.xmode == RS_DOWN || dd.xmode == RS_EXACT) && (dd.ymode == RS_DOWN || dd.ymode == RS_EXACT)))
@@ -2088,9 +2090,9 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
     int maxR = 0;
     {
         const int32_t* it = arena.ints.data();
-        for (int yb0 = 0; yb0 < dd.hb; yb0 += RT_YO)
+        for (int yb0 = 0; yb0 < dd.hb; yb0 += yo)
         {
-            const int yb1 = std::min(yb0 + RT_YO, dd.hb);
+            const int yb1 = std::min(yb0 + yo, dd.hb);
             int lo, hi;
             if (dd.ymode == RS_EXACT)
             {
@@ -2107,7 +2109,7 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
             maxR = std::max(maxR, hi - lo + 1);
         }
     }
-    for (int xo : { 32, 16, 8 })
+    for (int xo : { forceXo ? forceXo : 32, 16, 8 })
     {
         if (forceXo && xo != forceXo)
         {
@@ -2124,7 +2126,7 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
             tx.push_back(hi);
             maxC = std::max(maxC, hi - lo + 1);
         }
-        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= ldsBudget)
+        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= ldsBudget && maxR <= maxRows && maxC <= maxCols)
         {
             tl.rows = maxR;
             tl.cols = maxC;
@@ -2666,7 +2668,31 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             for (size_t i = 0; i < c->ldcfLevels.size() && ok; i++)
             {
                 const ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
-                const ResampleTiling tl = resampleTilePlan(dd, arena, 16, int64_t(40) * 1024);
+                // the largest tile of at most 64 x 16 outputs whose source tile is at most 128 rows x 32 columns: the filter
+                // stage then has exactly two tile rows per lane and eight column quads (k_ldcf_tile)
+                ResampleTiling tl;
+                int yo = 0, xo = 0;
+                {
+                    std::vector<std::pair<int, int>> cand;
+                    for (int y = RT_YO; y >= 32; y--)
+                    {
+                        for (int x = 16; x >= 8; x--)
+                        {
+                            cand.push_back({ y, x });
+                        }
+                    }
+                    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first * a.second > b.first * b.second; });
+                    for (const auto& yx : cand)
+                    {
+                        tl = resampleTilePlan(dd, arena, yx.second, int64_t(40) * 1024, yx.first, 128, 32);
+                        if (tl.rows > 0)
+                        {
+                            yo = yx.first;
+                            xo = yx.second;
+                            break;
+                        }
+                    }
+                }
                 if (tl.rows <= 0)
                 {
                     ok = false;
@@ -2674,7 +2700,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                 }
                 maxR = std::max(maxR, tl.rows);
                 maxC = std::max(maxC, tl.cols);
-                const int ntY = cdiv(dd.hb, RT_YO), ntX = cdiv(dd.wb, 16);
+                const int ntY = cdiv(dd.hb, yo), ntX = cdiv(dd.wb, xo);
                 for (int x = 0; x < ntX; x++)
                 {
                     for (int y = 0; y < ntY; y++)
@@ -2685,6 +2711,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                         j.xtile = x;
                         j.tile_y = tl.tile_y;
                         j.tile_x = tl.tile_x;
+                        j.yo = yo;
+                        j.xo = xo;
                         tj.push_back(j);
                     }
                 }

@@ -4349,9 +4349,10 @@ __global__ void __launch_bounds__(256) k_resample_march2(const float* __restrict
 struct LdcfTileJob
 {
     int32_t level;          // level = LDCF descriptor index
-    int32_t ytile, xtile;   // output tile (RT_YO rows x xo columns)
+    int32_t ytile, xtile;   // output tile (yo rows x xo columns)
     int32_t tile_y, tile_x; // int-arena offsets of the level's {rowLo,rowHi} / {colLo,colHi} tables
-    int32_t pad_[3];
+    int32_t yo, xo;         // output rows / columns per tile of this level (<= 64 x 16, source tile <= 128 rows x 32 columns)
+    int32_t pad_;
 };
 
 __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
@@ -4365,8 +4366,8 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
     const int c = blockIdx.y;
     const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
     const int lane = threadIdx.x & 63;
-    const int yb0 = J.ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
-    const int xb0 = J.xtile * xo, xb1 = min(xb0 + xo, wb);
+    const int yb0 = J.ytile * J.yo, yb1 = min(yb0 + J.yo, hb);
+    const int xb0 = J.xtile * J.xo, xb1 = min(xb0 + J.xo, wb);
     const float r = d.r[0], rk = d.rk[0];
     const int rowLo = it[J.tile_y + 2 * J.ytile], rowHi = it[J.tile_y + 2 * J.ytile + 1];
     const int colLo = it[J.tile_x + 2 * J.xtile], colHi = it[J.tile_x + 2 * J.xtile + 1];
@@ -4409,54 +4410,100 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
     for (int f = 0; f < K; f++)
     {
         const int pc = f * nChns + c;
-        // 25 taps through the scalar unit (wave-uniform address)
+        // 25 taps through the scalar unit (wave-uniform address), kept as 13 VGPR pairs {w[2k], w[2k + 1]}: a packed operation
+        // picks the half it needs for BOTH of its results (op_sel / op_sel_hi), so no {w, w} copies are held
         typedef const __attribute__((address_space(4))) float* cfp_t;
+        typedef float f2_t __attribute__((ext_vector_type(2)));
         cfp_t fw = (cfp_t)(uintptr_t)(filt + int64_t(pc) * 25);
-        float w[25];
+        f2_t wp[13];
 #pragma unroll
-        for (int k = 0; k < 25; k++)
+        for (int k = 0; k < 13; k++)
         {
-            w[k] = fw[k];
-            ACF_PIN_V(w[k]); // (in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without, and each tap multiplies four times)
+            wp[k] = f2_t{ fw[2 * k], k < 12 ? fw[2 * k + 1] : 0.f };
+            asm volatile("" : "+v"(wp[k])); // (in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without)
         }
-        // a thread takes four consecutive COLUMNS at one tile row (lanes along the rows: conflict-free LDS reads): the 8 x 5
-        // cells they share are read once, 10 LDS reads per output instead of 25; per output the taps are still added dx
-        // then dy ascending, as ONE chain of fused multiply-adds starting from 0 (k_ldcf_conv's order; v_fma_f32 = C's fmaf)
+        // A thread takes four consecutive COLUMNS at tile rows rr and rr + 64 (lanes along the rows: conflict-free LDS reads; the
+        // plan keeps a tile within 128 rows x 32 columns, so the workgroup's 512 items are the whole tile).  The two rows are the
+        // halves of packed f32 operations: a column's five cell pairs arrive as ds_read2_b32 {row, row + 64} and every tap is one
+        // v_pk_fma_f32 for both outputs.  Per output the taps are still added dx then dy ascending, as ONE chain of fused
+        // multiply-adds starting from 0 (k_ldcf_conv's order; each half of v_pk_fma_f32 = C's fmaf): columns are therefore
+        // consumed from cc + 7 down to cc — output j meets column q at dx = j + 2 - q —, each read once, two columns ahead of
+        // its use (the scheduling barriers keep three columns live instead of all eight), and dropped.
+#define LDCF_PKFMA(ACC, V, K)                                                                                                              \
+    if ((K) & 1)                                                                                                                           \
+    {                                                                                                                                      \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ACC) : "v"(V), "v"(wp[(K) >> 1]));                    \
+    }                                                                                                                                      \
+    else                                                                                                                                   \
+    {                                                                                                                                      \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(ACC) : "v"(V), "v"(wp[(K) >> 1]));                    \
+    }
+#define LDCF_LOAD(Q)                                                                       \
+    {                                                                                      \
+        const float* pc0 = P + min(cc + (Q), nCols + 3) * pR + rr;                         \
+        _Pragma("unroll") for (int t = 0; t < 5; t++)                                      \
+        {                                                                                  \
+            v[Q][t] = f2_t{ pc0[t], pc0[t + r2] };                                         \
+        }                                                                                  \
+    }
         const int nQ = (nCols + 3) >> 2;
-        for (int i = threadIdx.x; i < nQ * nRows; i += 256)
+        for (int i = threadIdx.x; i < nQ * 64; i += 256)
         {
-            const int cq = i / nRows, rr = i - cq * nRows, cc = cq * 4;
-            // output (x, y) = (colLo + cc + j, rowLo + rr); tap (dx, dy) reads P[cc + j + 2 - dx][rr + 2 - dy]
-            float v[8][5];
-#pragma unroll
-            for (int q = 0; q < 8; q++)
+            const int cq = i >> 6, rr = i & 63, cc = cq * 4;
+            const bool two = rr + 64 < nRows;
+            const int r2 = two ? 64 : 0; // (no second row: the first one again, never stored)
+            if (rr >= nRows)
             {
-                const float* pc0 = P + min(cc + q, nCols + 3) * pR + rr; // columns cc .. cc + 7 of the padded tile (clamped past its end: never stored)
+                continue;
+            }
+            f2_t acc[4];
 #pragma unroll
-                for (int t = 0; t < 5; t++)
+            for (int j = 0; j < 4; j++)
+            {
+                acc[j] = f2_t{ 0.f, 0.f };
+            }
+            f2_t v[8][5]; // [column cc + q of the padded tile (clamped past its end: never stored)][padded rows rr + t = y - 2 + t]
+            LDCF_LOAD(7);
+            LDCF_LOAD(6);
+#pragma unroll
+            for (int q = 7; q >= 0; q--)
+            {
+                if (q >= 2)
                 {
-                    v[q][t] = pc0[t]; // padded rows rr .. rr + 4 = y - 2 .. y + 2
+                    LDCF_LOAD(q - 2);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const int dx = j + 2 - q;
+                    if (dx < -2 || dx > 2)
+                    {
+                        continue;
+                    }
+#pragma unroll
+                    for (int dy = -2; dy <= 2; dy++)
+                    {
+                        LDCF_PKFMA(acc[j], v[q][2 - dy], (dx + 2) * 5 + (dy + 2));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                float acc = 0.f;
-#pragma unroll
-                for (int dx = -2; dx <= 2; dx++)
-                {
-#pragma unroll
-                    for (int dy = -2; dy <= 2; dy++)
-                    {
-                        acc = __builtin_fmaf(v[j + 2 - dx][2 - dy], w[(dx + 2) * 5 + (dy + 2)], acc);
-                    }
-                }
                 if (cc + j < nCols)
                 {
-                    T[(cc + j) * nRows + rr] = acc;
+                    T[(cc + j) * nRows + rr] = acc[j].x;
+                    if (two)
+                    {
+                        T[(cc + j) * nRows + rr + 64] = acc[j].y;
+                    }
                 }
             }
         }
+#undef LDCF_LOAD
+#undef LDCF_PKFMA
         __syncthreads();
         float* __restrict__ B = out + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(pc) * hb * wb;
         // (no barrier after the y pass: it reads C only, the next filter's conv writes T only, and the x pass that rewrites C
