@@ -18,7 +18,7 @@ for it in range(N):
     kw = dict(name="TINY", nTrees=nTrees, treeDepth=depth, cascThr=-1.0 if nTrees < 300 else -3.0,
               nPerOct=int(rng.choice([4, 8, 8, 12])), nApprox=int(rng.choice([0, 3, 7, -1])), full=int(rng.rand() < 0.2),
               colorChn=int(rng.choice([0, 0, 1, 2])), pad_h=int(rng.choice([0, 0, 4, 8])), pad_w=int(rng.choice([0, 0, 4, 12])),
-              softBin=int(rng.choice([0, 0, 0, -2, 2])))
+              softBin=int(rng.choice([0, 0, 0, -2, 2])), stride=int(rng.choice([4, 4, 4, 4, 8, 2, 1])))  # (stride < shrink: one evaluation per distinct offset)
     if kw["nApprox"] < 0:
         kw["nApprox"] = kw["nPerOct"] - 1
     nF = int(rng.choice([1, 2, 3]))
