@@ -4422,13 +4422,13 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
             wp[k] = f2_t{ fw[2 * k], k < 12 ? fw[2 * k + 1] : 0.f };
             asm volatile("" : "+v"(wp[k])); // (in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without)
         }
-        // A thread takes four consecutive COLUMNS at tile rows rr and rr + 64 (lanes along the rows: conflict-free LDS reads; the
-        // plan keeps a tile within 128 rows x 32 columns, so the workgroup's 512 items are the whole tile).  The two rows are the
+        // A thread takes eight consecutive COLUMNS at tile rows rr and rr + 64 (lanes along the rows: conflict-free LDS reads; the
+        // plan keeps a tile within 128 rows x 32 columns, so the workgroup's 256 items are the whole tile).  The two rows are the
         // halves of packed f32 operations: a column's five cell pairs arrive as ds_read2_b32 {row, row + 64} and every tap is one
         // v_pk_fma_f32 for both outputs.  Per output the taps are still added dx then dy ascending, as ONE chain of fused
         // multiply-adds starting from 0 (k_ldcf_conv's order; each half of v_pk_fma_f32 = C's fmaf): columns are therefore
-        // consumed from cc + 7 down to cc — output j meets column q at dx = j + 2 - q —, each read once, two columns ahead of
-        // its use (the scheduling barriers keep three columns live instead of all eight), and dropped.
+        // consumed from cc + 11 down to cc — output j meets column q at dx = j + 2 - q —, each read once, two columns ahead of
+        // its use (the scheduling barriers keep three columns live instead of all twelve), and dropped.
 #define LDCF_PKFMA(ACC, V, K)                                                                                                              \
     if ((K) & 1)                                                                                                                           \
     {                                                                                                                                      \
@@ -4446,27 +4446,28 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
             v[Q][t] = f2_t{ pc0[t], pc0[t + r2] };                                         \
         }                                                                                  \
     }
-        const int nQ = (nCols + 3) >> 2;
+        constexpr int LN = 8; // output columns per thread: LN + 4 tile columns are read for them (12 for 8; quads read 8 for 4)
+        const int nQ = (nCols + LN - 1) / LN;
         for (int i = threadIdx.x; i < nQ * 64; i += 256)
         {
-            const int cq = i >> 6, rr = i & 63, cc = cq * 4;
+            const int cq = i >> 6, rr = i & 63, cc = cq * LN;
             const bool two = rr + 64 < nRows;
             const int r2 = two ? 64 : 0; // (no second row: the first one again, never stored)
             if (rr >= nRows)
             {
                 continue;
             }
-            f2_t acc[4];
+            f2_t acc[LN];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < LN; j++)
             {
                 acc[j] = f2_t{ 0.f, 0.f };
             }
-            f2_t v[8][5]; // [column cc + q of the padded tile (clamped past its end: never stored)][padded rows rr + t = y - 2 + t]
-            LDCF_LOAD(7);
-            LDCF_LOAD(6);
+            f2_t v[LN + 4][5]; // [column cc + q of the padded tile (clamped past its end: never stored)][padded rows rr + t = y - 2 + t]
+            LDCF_LOAD(LN + 3);
+            LDCF_LOAD(LN + 2);
 #pragma unroll
-            for (int q = 7; q >= 0; q--)
+            for (int q = LN + 3; q >= 0; q--)
             {
                 if (q >= 2)
                 {
@@ -4474,7 +4475,7 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int j = 0; j < LN; j++)
                 {
                     const int dx = j + 2 - q;
                     if (dx < -2 || dx > 2)
@@ -4490,7 +4491,7 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < LN; j++)
             {
                 if (cc + j < nCols)
                 {
