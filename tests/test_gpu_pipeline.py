@@ -134,6 +134,33 @@ def test_capacity_error_is_reported():
     det.close()
 
 
+@pytest.mark.parametrize("max_hits", [128, 1 << 16])
+def test_windows_sharing_an_offset(oracle, max_hits):
+    """stride < shrink: the cascade runs once per distinct cell offset and k_expand_hits writes every window of a surviving
+    offset (T/acfDetect1.cpp:88-96: r * stride / shrink).  With room for them the detections equal the oracle's, one hit per
+    WINDOW; with max_hits between the distinct survivors and the windows they stand for the call reports the overflow."""
+    import torch
+    from acf_amd.detector import HipDetector, HipError
+    H, W, kind, d_in, kw = CONFIGS["tiny_luv"]
+    model = synth.make_model(seed=3, **dict(kw, stride=2, cascThr=-1.2))
+    frame = synth.make_frame(1, H, W, kind)
+    plan = oracle.Plan(model, H, W, d_in)
+    pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    want, want_hits = oracle.detect(plan, pyr)
+    distinct = len({(int(h["scale"]), int(h["r"]) // 2, int(h["c"]) // 2) for h in want_hits})
+    assert distinct <= 128 < len(want), (distinct, len(want))  # (the small capacity holds the offsets, not the windows)
+    det = HipDetector(model, H, W, d_in, max_batch=1, max_hits=max_hits)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    if max_hits < len(want):
+        with pytest.raises(HipError) as e:
+            det.detections(0)
+        assert e.value.code == 7
+    else:
+        got, got_hits = det.detections(0)
+        assert got.tobytes() == want.tobytes() and got_hits.tobytes() == want_hits.tobytes()
+    det.close()
+
+
 def test_export_detections_layout(oracle):
     import torch
     det, model, (H, W, kind, d_in) = build("tiny_luv", batch=2, taps=False)
