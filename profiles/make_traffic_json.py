@@ -51,6 +51,8 @@ def main():
            "frames_per_step": frames,
            "kernels": {g: int((ft.get(g, 0) + wt.get(g, 0)) / steps) for g in sorted(set(ft) | set(wt))}}
     out["MB_per_frame"] = {g: round(v / frames / 1e6, 2) for g, v in out["kernels"].items()}
+    out["fetch_MB_per_frame"] = {g: round(v / steps / frames / 1e6, 2) for g, v in sorted(ft.items())}  # (after the wide-load correction)
+    out["write_MB_per_frame"] = {g: round(v / steps / frames / 1e6, 2) for g, v in sorted(wt.items())}
     out["total_MB_per_frame"] = round(sum(out["MB_per_frame"].values()), 1)
     print(json.dumps(out, indent=1))
 
