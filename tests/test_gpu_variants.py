@@ -24,6 +24,8 @@ VARIANTS = [
     "ACF_HIP_RTILE_TR=16",
     "ACF_HIP_RTILE_NW=4",
     "ACF_HIP_RTILE_NW=16",
+    "ACF_HIP_RTILE_WG=4",
+    "ACF_HIP_RTILE_WG=2",
     "ACF_HIP_NO_RANK=1",
     "ACF_HIP_NO_RANK=1 ACF_HIP_TILE_TR=16",
     "ACF_HIP_NO_RANK=1 ACF_HIP_TILE_NW=4",
