@@ -11,6 +11,7 @@ for (k, d, g), v in byd.items():
     if k not in best or g > best[k][0]:
         best[k] = (g, v)
 names = sorted({r["Counter_Name"] for r in rows})
-print("kernel,grid," + ",".join(names))
+w = csv.writer(sys.stdout)  # (kernel names hold commas: quoted)
+w.writerow(["kernel", "grid"] + names)
 for k, (g, v) in sorted(best.items(), key=lambda kv: -kv[1][1].get("SQ_WAVE_CYCLES", 0)):
-    print(k + "," + str(g) + "," + ",".join("%.4g" % v.get(n, 0) for n in names))
+    w.writerow([k, g] + ["%.4g" % v.get(n, 0) for n in names])
