@@ -572,6 +572,23 @@ def main():
             path = b_frame * fps / world / 1e9
             roof.update({"path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
                          "note": "per-kernel events disabled: whole path on the wall clock only"})
+        # what this box delivers to a plain stream: a device-to-device copy of 256 MiB (read + write), outside the timed region —
+        # the practical ceiling beside the 8 TB/s of `peak` (profiles/ubench/copy_bw.py: ~4.8 TB/s)
+        try:
+            cx = torch.empty(1 << 26, dtype=torch.float32, device=dev)
+            cy = torch.empty_like(cx)
+            for _ in range(2):
+                cy.copy_(cx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                cy.copy_(cx)
+            e1.record()
+            torch.cuda.synchronize()
+            roof["stream_copy_GBps"] = round(8 * 2 * cx.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del cx, cy
+        except Exception:  # (a reported extra, never a reason to lose the line)
+            roof["stream_copy_GBps"] = None
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, base_np, H, W)
