@@ -19,10 +19,10 @@
  *    specific; this oracle uses exact 1/sqrt and 1/x at those three sites
  *    ("T-exact").  Pinned against _ref within the rcp/rsqrt bound (1.5*2^-12
  *    relative per op).
- *  - resample / rgb2luv (T/imResampleMex.cpp, T/rgbConvertMex.cpp): those two
- *    files include OpenCV headers that are absent from this image, so they are
- *    unbuildable here: PARITY UNPINNED for these two functions (restated line
- *    by line; checked only through analytic properties).
+ *  - resample / rgb2luv / rgb2gray / rgb2hsv (T/imResampleMex.cpp, T/rgbConvertMex.cpp): the two files include
+ *    OpenCV headers that are absent from this image; their OpenCV-free function bodies are compiled from the
+ *    reference text BY LINE RANGE (oracle/Makefile) and this restatement is BIT-EXACT against them
+ *    (rgb2luv_sse's U/V within its one _mm_rcp_ps: the T-exact contract above).
  *  - getScales / chnsPyramid / chnsCompute / acfDetect1 / box mapping: integer
  *    and double control logic restated from OpenCV-typed code that cannot be
  *    compiled here; the reference's tests hold no golden vectors for them
@@ -41,12 +41,47 @@
 
 static void* xmalloc(size_t n)
 {
-    void* p = malloc(n ? n : 1);
+    /* 64-byte aligned like cv::Mat storage (CV_MALLOC_ALIGN): the reference's kernels choose their SSE or scalar
+     * bodies by pointer alignment (T/gradientMex.cpp:262, T/rgbConvertMex.cpp:92,343), which matters in T-ref mode below. */
+    void* p = aligned_alloc(64, (n ? n + 63 : 64) & ~(size_t)63);
     if (!p)
     {
         abort();
     }
     return p;
+}
+
+/* ------------------------------------------------------------------------
+ * T-ref mode (build container only; tests/golden/make_tref.py, tests/test_tref_end_to_end.py).
+ * The orchestration below (chnsCompute, chnsPyramid) normally calls this file's T-exact restatements of the toolbox
+ * kernels.  With a table installed by acfo_set_ref_kernels it calls, at the same places and with the same arguments,
+ * the reference's OWN compiled kernels (oracle/_ref/libacfref.so: rsqrtps / rcpps and all), so that a whole pyramid
+ * and the detections on it can be compared between the two arithmetic tiers.  The table holds plain function
+ * addresses handed in by the test (ctypes; a null entry keeps the restatement for that kernel, which is how the test
+ * shows that the bit-exact stages alone reproduce the T-exact pyramid bit for bit); this file never loads _ref itself,
+ * and nothing of it reaches the product.
+ * ---------------------------------------------------------------------- */
+typedef struct acfo_ref_kernels
+{
+    void (*convTri)(float* I, float* O, int h, int w, int d, int r, int s);
+    void (*convTri1)(float* I, float* O, int h, int w, int d, float p, int s);
+    void (*gradMag)(float* I, float* M, float* O, int h, int w, int d, int full);
+    void (*gradMagNorm)(float* M, float* S, int h, int w, float norm);
+    void (*gradHist)(float* M, float* O, float* H, int h, int w, int bin, int nOrients, int softBin, int full);
+    void (*resample)(float* A, float* B, int ha, int hb, int wa, int wb, int d, float r);
+    int (*rgbConvert)(float* I, float* J, int n, int d, int flag, float nrm);
+} acfo_ref_kernels;
+
+static __thread acfo_ref_kernels g_refk;
+static __thread int g_refOn = 0;
+
+ACFO_API void acfo_set_ref_kernels(const acfo_ref_kernels* k)
+{
+    g_refOn = k != NULL;
+    if (k)
+    {
+        g_refk = *k;
+    }
 }
 
 /* ------------------------------------------------------------------------
@@ -807,6 +842,11 @@ ACFO_API int acfo_conv_tri_dispatch(float* I, float* J, int h, int w, int d, dou
     if ((r > 0) && (r <= 1.0) && (s <= 2))
     {
         float p = (float)(12.0 / r / (r + 2.0) - 2.0);
+        if (g_refOn && g_refk.convTri1)
+        {
+            g_refk.convTri1(I, J, h, w, d, p, s);
+            return ACF_HIP_OK;
+        }
         return acfo_conv_tri1(I, J, h, w, d, p, s);
     }
     float pf = (float)r;
@@ -818,6 +858,11 @@ ACFO_API int acfo_conv_tri_dispatch(float* I, float* J, int h, int w, int d, dou
     if (I == J)
     {
         return ACF_HIP_E_INVALID; /* the pyramid never calls convTri(r>1) in place */
+    }
+    if (g_refOn && g_refk.convTri)
+    {
+        g_refk.convTri(I, J, h, w, d, ri, s);
+        return ACF_HIP_OK;
     }
     return acfo_conv_tri(I, J, h, w, d, ri, s);
 }
@@ -1090,6 +1135,66 @@ ACFO_API int acfo_grad_hist(const float* M, const float* O, float* H, int h, int
     return ACF_HIP_OK;
 }
 
+/* The toolbox kernels as the orchestration below calls them: this file's T-exact restatements, or — in T-ref mode —
+ * the reference's own compiled functions with the same arguments (see acfo_set_ref_kernels). */
+static int st_resample(float* A, float* B, int ha, int hb, int wa, int wb, int d, float r)
+{
+    if (g_refOn && g_refk.resample)
+    {
+        g_refk.resample(A, B, ha, hb, wa, wb, d, r);
+        return ACF_HIP_OK;
+    }
+    return acfo_resample(A, B, ha, hb, wa, wb, d, r);
+}
+static int st_grad_mag(float* I, float* M, float* O, int h, int w, int d, int full)
+{
+    if (g_refOn && g_refk.gradMag)
+    {
+        g_refk.gradMag(I, M, O, h, w, d, full);
+        return ACF_HIP_OK;
+    }
+    return acfo_grad_mag(I, M, O, h, w, d, full);
+}
+static void st_grad_mag_norm(float* M, float* S, int h, int w, float norm)
+{
+    if (g_refOn && g_refk.gradMagNorm)
+    {
+        g_refk.gradMagNorm(M, S, h, w, norm);
+        return;
+    }
+    acfo_grad_mag_norm(M, S, h, w, norm);
+}
+static int st_grad_hist(float* M, float* O, float* H, int h, int w, int bin, int nOrients, int softBin, int full)
+{
+    if (g_refOn && g_refk.gradHist)
+    {
+        g_refk.gradHist(M, O, H, h, w, bin, nOrients, softBin, full);
+        return ACF_HIP_OK;
+    }
+    return acfo_grad_hist(M, O, H, h, w, bin, nOrients, softBin, full);
+}
+/* flag as rgbConvertMex.cpp:389-393: 0 gray, 2 luv, 3 hsv; nrm = 1.0f (rgbConvert.cpp:164) */
+static int st_rgb_convert(float* I, float* J, int n, int flag)
+{
+    if (g_refOn && g_refk.rgbConvert)
+    {
+        return g_refk.rgbConvert(I, J, n, 3, flag, 1.0f) ? ACF_HIP_E_INVALID : ACF_HIP_OK;
+    }
+    if (flag == 2)
+    {
+        acfo_rgb2luv(I, J, n);
+    }
+    else if (flag == 3)
+    {
+        acfo_rgb2hsv(I, J, n);
+    }
+    else
+    {
+        acfo_rgb2gray(I, J, n);
+    }
+    return ACF_HIP_OK;
+}
+
 /* ------------------------------------------------------------------------
  * Plan: scale list, real/approx split, per-level geometry.
  * chnsPyramid.cpp:270-292 + acfDetect1.cpp:258-259.
@@ -1246,7 +1351,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
         }
         else
         {
-            rc = acfo_resample(I, o, h, hs, w, ws, d, 1.0f);
+            rc = st_resample(I, o, h, hs, w, ws, d, 1.0f);
             if (rc)
             {
                 return rc;
@@ -1267,7 +1372,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
         free(O);
         return ACF_HIP_E_INVALID;
     }
-    rc = acfo_grad_mag(I + np * (size_t)p->colorChn, M, O, h, w, 1, p->full); /* gradientMag.cpp:90-98: d = 1 */
+    rc = st_grad_mag(I + np * (size_t)p->colorChn, M, O, h, w, 1, p->full); /* gradientMag.cpp:90-98: d = 1 */
     if (rc)
     {
         free(M);
@@ -1293,7 +1398,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
             free(O);
             return rc;
         }
-        acfo_grad_mag_norm(M, S, h, w, (float)p->normConst);
+        st_grad_mag_norm(M, S, h, w, (float)p->normConst);
         if (taps && taps->S)
         {
             memcpy(taps->S, S, sizeof(float) * np);
@@ -1312,7 +1417,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
         }
         else
         {
-            rc = acfo_resample(M, o, h, hs, w, ws, 1, 1.0f);
+            rc = st_resample(M, o, h, hs, w, ws, 1, 1.0f);
         }
         o += ns;
     }
@@ -1326,7 +1431,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
         else
         {
             memset(o, 0, sizeof(float) * ns * (size_t)p->nOrients); /* gradientHist.cpp:94-95 */
-            rc = acfo_grad_hist(M, O, o, h, w, binSize, p->nOrients, p->softBin, p->full);
+            rc = st_grad_hist(M, O, o, h, w, binSize, p->nOrients, p->softBin, p->full);
         }
     }
     free(M);
@@ -1604,7 +1709,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
         else if (cs == ACF_HIP_CS_LUV)
         {
             I = (float*)xmalloc(sizeof(float) * np0 * 3);
-            acfo_rgb2luv(pI, I, (int)np0);
+            rc = st_rgb_convert(pI, I, (int)np0, 2);
             free(pI);
             d = 3;
         }
@@ -1616,7 +1721,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
                 return ACF_HIP_E_INVALID; /* CV_Assert(flag == 2) :150-155; CV_Assert(flag == 0) for one plane :140-148 */
             }
             I = (float*)xmalloc(sizeof(float) * np0 * 3);
-            acfo_rgb2hsv(pI, I, (int)np0);
+            rc = st_rgb_convert(pI, I, (int)np0, 3);
             free(pI);
             d = 3;
         }
@@ -1628,7 +1733,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
                 return ACF_HIP_E_INVALID; /* CV_Assert(flag == 2) :150-155 */
             }
             I = (float*)xmalloc(sizeof(float) * np0);
-            acfo_rgb2gray(pI, I, (int)np0);
+            rc = st_rgb_convert(pI, I, (int)np0, 0);
             free(pI);
             d = 1;
         }
@@ -1678,7 +1783,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
         else
         {
             I1 = (float*)xmalloc(sizeof(float) * (size_t)h1 * w1 * d);
-            rc = acfo_resample(I, I1, Ih, h1, Iw, w1, d, 1.0f);
+            rc = st_resample(I, I1, Ih, h1, Iw, w1, d, 1.0f);
             if (rc)
             {
                 free(I1);
@@ -1749,7 +1854,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
                 continue;
             }
             double ratio = pow(lv[i].scale / lv[iR].scale, -lambdas[j]);
-            rc = acfo_resample(data[iR] + offA, data[i] + offB, ha, hb, wa, wb, nTypeCh[j], (float)ratio);
+            rc = st_resample(data[iR] + offA, data[i] + offB, ha, hb, wa, wb, nTypeCh[j], (float)ratio);
             offA += (size_t)nTypeCh[j] * ha * wa;
             offB += (size_t)nTypeCh[j] * hb * wb;
         }

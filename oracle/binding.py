@@ -132,6 +132,35 @@ def ref():
     return _r
 
 
+class RefKernels(C.Structure):
+    """acfo_ref_kernels (oracle/acf_oracle.c): addresses of the reference's own compiled toolbox kernels."""
+    _fields_ = [(n, C.c_void_p) for n in ("convTri", "convTri1", "gradMag", "gradMagNorm", "gradHist", "resample", "rgbConvert")]
+
+
+TREF_ALL = ("convTri", "convTri1", "gradMag", "gradMagNorm", "gradHist", "resample", "rgbConvert")
+TREF_APPROX = ("gradMag", "gradMagNorm", "rgbConvert")  # the kernels that hold an _mm_rsqrt_ps / _mm_rcp_ps
+
+
+def set_tref(on, only=TREF_ALL):
+    """T-ref mode of the oracle's orchestration (build container only): chns_pyramid() on THIS thread calls the reference's
+    own compiled kernels (oracle/_ref: rsqrtps / rcpps and all) instead of the T-exact restatements — all of them, or the
+    ones named in `only`.  set_tref(False) restores."""
+    o = lib()
+    o.acfo_set_ref_kernels.argtypes = [C.c_void_p]
+    o.acfo_set_ref_kernels.restype = None
+    if not on:
+        o.acfo_set_ref_kernels(None)
+        return
+    r = ref()
+    k = RefKernels()
+    for name, fn in (("convTri", r.ref_convTri), ("convTri1", r.ref_convTri1), ("gradMag", r.ref_gradMag),
+                     ("gradMagNorm", r.ref_gradMagNorm), ("gradHist", r.ref_gradHist), ("resample", r.ref_resample),
+                     ("rgbConvert", r.ref_rgbConvert)):
+        if name in only:
+            setattr(k, name, C.cast(fn, C.c_void_p).value)
+    o.acfo_set_ref_kernels(C.byref(k))
+
+
 def aligned(shape, dtype=np.float32, align=64):
     """numpy array whose data pointer is `align`-byte aligned (the reference's
     SSE paths require 16-byte alignment, like cv::Mat storage)."""

@@ -97,3 +97,39 @@ def test_cfg5_ldcf_full_size(oracle):
     assert gh.tobytes() == wh.tobytes()
     assert got.tobytes() == want.tobytes()
     det.close()
+
+
+TREF_CFG = {
+    "cfg1_vga_gray_face64": ("gray", "FACE64"),
+    "cfg2_1080p_luv_face80": ("luv", "FACE80"),
+    "cfg4_vga_rgb_inria": ("rgb", "INRIA"),
+}
+
+
+@pytest.mark.parametrize("cfg", list(TREF_CFG))
+def test_hip_hits_are_the_texact_side_of_the_tref_study(cfg):
+    """tests/golden/tref_study.npz holds, per frame, the cascade's hits of the oracle (T-exact) and of the reference's own compiled
+    SSE kernels under the same orchestration (T-ref; made in the build container by tests/golden/make_tref.py).  The HIP path must
+    be the T-exact side bit for bit — then DESIGN.md section 2's T-ref table (windows in one tier only, score differences) is a
+    statement about the HIP path against the reference's arithmetic, measured rather than argued."""
+    import os
+    import torch
+    from acf_amd.detector import HipDetector
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tref_study.npz"))
+    H, W, d_in, nframes, seed0, mseed = [int(v) for v in fix[cfg + "_meta"]]
+    kind, preset = TREF_CFG[cfg]
+    model = synth.make_model(seed=mseed, name=preset)
+    n = min(nframes, 4)
+    frames = np.stack([synth.make_frame(seed0 + f, H, W, kind) for f in range(n)])
+    det = HipDetector(model, H, W, d_in, max_batch=n, max_hits=1 << 15)
+    det.run(torch.from_numpy(frames).cuda())
+    for f in range(n):
+        _, gh = det.detections(f)
+        want = fix["%s_f%d_hits_exact" % (cfg, f)]
+        assert gh.tobytes() == want.tobytes(), (cfg, f)
+        ref = fix["%s_f%d_hits_ref" % (cfg, f)]
+        kg = (gh["scale"].astype(np.int64) << 40) | (gh["c"].astype(np.int64) << 20) | gh["r"].astype(np.int64)
+        kr = (ref["scale"].astype(np.int64) << 40) | (ref["c"].astype(np.int64) << 20) | ref["r"].astype(np.int64)
+        common = np.intersect1d(kg, kr)
+        assert len(common) >= 0.95 * max(len(kg), len(kr)), (cfg, f, len(kg), len(kr), len(common))
+    det.close()
