@@ -377,6 +377,23 @@ int devUpload(acf_hip_ctx* c, T** out, const std::vector<T>& v)
     return ACF_HIP_OK;
 }
 
+// one buffer of devAlloc / devUpload given back before the context's teardown (the caller has made sure nothing in flight reads it)
+template <class T>
+void devRelease(acf_hip_ctx* c, T*& p)
+{
+    if (!p)
+    {
+        return;
+    }
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), static_cast<void*>(p));
+    if (it != c->allocs.end())
+    {
+        c->allocs.erase(it);
+        (void)hipFree(p);
+    }
+    p = nullptr;
+}
+
 void freeAll(acf_hip_ctx* c)
 {
     for (void* p : c->allocs)
@@ -4084,6 +4101,11 @@ int acf_hip_set_input_resize(acf_hip_ctx* c, int srcRows, int srcCols, double sc
         c->rz.on = false;
         return ACF_HIP_OK;
     }
+    if (c->rz.d_out && c->rz.rows == srcRows && c->rz.cols == srcCols && c->rz.scale == scale)
+    {
+        c->rz.on = true; // same geometry as the tables already on the device (a re-opened stream): nothing to build
+        return ACF_HIP_OK;
+    }
     acf_hip_ctx::InputResize rz;
     if (buildResizeTables(srcRows, srcCols, scale, rz.t) || rz.t.drows != c->plan.H || rz.t.dcols != c->plan.W)
     {
@@ -4093,11 +4115,25 @@ int acf_hip_set_input_resize(acf_hip_ctx* c, int srcRows, int srcCols, double sc
     rz.cols = srcCols;
     rz.scale = scale;
     HIPCHK(c, hipSetDevice(c->device));
+    auto release = [&](acf_hip_ctx::InputResize& r) {
+        devRelease(c, r.d_xlin);
+        devRelease(c, r.d_ylin);
+        devRelease(c, r.d_xrun);
+        devRelease(c, r.d_yrun);
+        devRelease(c, r.d_xtap);
+        devRelease(c, r.d_ytap);
+        devRelease(c, r.d_out);
+    };
     int rc;
     if ((rc = uploadResizeTables(c, rz)) || (rc = devAlloc(c, &rz.d_out, size_t(c->maxBatch) * c->plan.H * c->plan.W * 4)))
     {
+        release(rz); // (what was uploaded before the failure)
         return rc;
     }
+    // the previous geometry's tables: a batch in flight may still read them
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rz.on = false;
+    release(c->rz);
     rz.on = true;
     c->rz = rz;
     return ACF_HIP_OK;
@@ -4108,6 +4144,12 @@ int acf_hip_op_resize_u8(acf_hip_ctx* c, const uint8_t* src, int rows, int cols,
     if (!c || !src || !dst || cpp < 1 || cpp > 4)
     {
         return c ? fail(c, ACF_HIP_E_INVALID, "op_resize_u8: arguments") : ACF_HIP_E_INVALID;
+    }
+    if (cpp == 2)
+    {
+        // OpenCV's 2 x 2 area path rounds two-channel pixels with saturate_cast(sum * 0.25f) (half to even), not (sum + 2) >> 2 as for
+        // 1, 3 and 4 channels; no pixel format of the path has two channels (ACF_HIP_PIX_*), so the form is not restated
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "op_resize_u8: two-channel images are not supported (1, 3 or 4 bytes per pixel)");
     }
     acf_hip_ctx::InputResize rz;
     if (buildResizeTables(rows, cols, scale, rz.t) || rz.t.drows != dstRows || rz.t.dcols != dstCols)

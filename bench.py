@@ -83,7 +83,8 @@ def kernel_bytes_per_frame(det, model):
     return b
 
 
-PMC_FILE = "profiles/r04_pmc_traffic.json"
+PMC_FILES = ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json")  # the newest committed pass that exists
+PMC_FILE = next((f for f in PMC_FILES if os.path.exists(os.path.join(ROOT, f))), PMC_FILES[-1])
 
 
 def pmc_traffic(kernel, batch):
@@ -96,6 +97,18 @@ def pmc_traffic(kernel, batch):
         if t.get("frames_per_step") != batch:
             return None
         return t["kernels"].get(kernel)
+    except Exception:
+        return None
+
+
+def pmc_path_bytes_per_frame(batch):
+    """HBM bytes per frame of the WHOLE path (every kernel of a step) from the same committed PMC passes, or None."""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            t = json.load(f)
+        if t.get("frames_per_step") != batch:
+            return None
+        return sum(t["kernels"].values()) / float(batch)
     except Exception:
         return None
 
@@ -251,6 +264,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
     ap.add_argument("--keep-pyramid", action="store_true", help="also materialise the float pyramid (acf_hip option keep_pyramid = 1); by default the timed "
                     "call is detection only — Detector::operator()(image) — and the levels leave the level kernel as 16-bit threshold-rank cells")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions behind `value_repeats` (profiling passes)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of three timed frames against the oracle")
     ap.add_argument("--dry-launch", action="store_true", help="launch plumbing only (spawn, rendezvous, max-over-ranks clock, per-rank gather) "
                     "with no detector work: runs without a GPU over gloo (tests/test_bench_launch.py); never a measurement")
@@ -385,12 +399,37 @@ def main():
     if world > 1:
         dist.all_reduce(rank_fps, op=dist.ReduceOp.SUM)
 
+    # the first region above is `value` (the contract's K steps, MAX over ranks).  Boxes of the pool differ by +-4 %, and a region
+    # is ~0.4 s: two more regions of the same K steps, timed the same way, say how far a single region of THIS box moves
+    prof_first = None
+    if not args.no_profile:
+        prof_first = [d_.profile() for d_ in dets]  # (the per-kernel figures stay those of the first region)
+    repeat_fps = [C * B * world * args.steps / dt]
+    for _ in range(0 if args.no_repeats else 2):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        repeat_fps.append(C * B * world * args.steps / float(tr.item()))
+    if not args.no_profile:
+        for d_ in dets:
+            d_.profile()  # (drop the repeats' events)
+
     det = dets[0]
     prof, solo = {}, {}
     latency_ms = None
     if not args.no_profile:
-        for d_ in dets:
-            for k_, (ms_, n_) in d_.profile().items():
+        for pf in prof_first:
+            for k_, (ms_, n_) in pf.items():
                 a_ = prof.get(k_, (0.0, 0))
                 prof[k_] = (a_[0] + ms_, a_[1] + n_)
         # outside the timed region: the same launches with one context alone on the machine, so that a kernel's own speed
@@ -472,7 +511,36 @@ def main():
             if not args.no_profile:
                 for d_ in dets:
                     d_.profile()
+    batch8 = None
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_latency and not args.frames_total and B >= 8:
+        # one GPU's share of BASELINE cfg 3 AS WORDED (64 frames per step over 8 GPUs = 8 frames per GPU and step): one context,
+        # 8 frames per call, the scales' chains beside each other, the call replayed as one HIP graph; submit -> synchronise per step
+        dets[0].set_option("scale_streams", 1)
+        dets[0].set_option("profile", 0)
+        dets[0].set_option("cascade_turns", 0)
+        dets[0].set_option("graph", 1)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(4):
+                dets[0].run(frames[:8], 8)
+                dets[0].export_detections(pipes[0].rec[0], args.cap)
+            dets[0].synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                dets[0].run(frames[:8], 8)
+                dets[0].export_detections(pipes[0].rec[0], args.cap)
+                dets[0].synchronize()
+            batch8 = 8 * 20 / (time.perf_counter() - t1)
+        dets[0].set_option("graph", 0)
+        dets[0].set_option("profile", 0 if args.no_profile else 1)
+        if not args.no_profile:
+            dets[0].profile()
     if rank == 0:
+        if world > 1:
+            # the first real multi-GPU run must not silently report one rank: every rank's frames of the last step arrived
+            assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+            assert gathered is not None and int(gathered.shape[0]) == world * B, \
+                "gather: %s rows on rank 0, expected %d ranks x %d frames" % (None if gathered is None else int(gathered.shape[0]), world, B)
+            assert all(float(x) > 0 for x in rank_fps.cpu().numpy()), "a rank reported no frames"
         frames_total = C * B * world * args.steps
         fps = frames_total / dt
         b_in = 3 * 4 * H * W
@@ -485,6 +553,10 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the same K steps timed three times back to back on this box (the first is `value`): box-to-box differences of the pool
+            # are +-4 %, a region is short; min / median / max say what a single region is worth
+            "value_repeats": [round(v, 1) for v in repeat_fps], "value_median": float(np.median(repeat_fps)),
+            "value_min": float(min(repeat_fps)), "value_max": float(max(repeat_fps)),
             "latency_ms_batch1": latency_ms,
             "verified_frames": verified,
             "config": {"workload": "%s; %d frames resident in HBM per GPU per step (%d detector contexts x %d frames)" % (cfg["what"], C * B, C, B),
@@ -499,11 +571,16 @@ def main():
                        # BASELINE cfg 2 as worded ("single frame") and cfg 3 as worded (64 frames per step, here on ONE GPU)
                        "cfg2_single_frame_latency_ms": latency_ms, "cfg2_single_frame_fps": (1e3 / latency_ms) if latency_ms else None,
                        "cfg3_64_frames_per_step_fps_1gpu": strong64,
+                       # one GPU's share of cfg 3 as worded (8 frames per GPU and step), measured on this GPU: 8 x this figure bounds what
+                       # eight GPUs give for 64 frames per step (the gather of 8 x 772 bytes per rank comes on top)
+                       "batch8_fps_1gpu": batch8,
+                       "cfg3_as_worded_8gpu_estimate_fps": (8 * batch8) if batch8 else None,
                        # the Pyramid-returning call (float levels written as well as the rank cells), same steps, timed the same way
                        "keep_pyramid_fps": keep_fps,
                        "cfg3_scaling_expectation": "weak scaling (--gpus N: every GPU its own 3 x 96 frames, one 772-byte record gather per frame) is "
                                                    "expected near-linear; strong scaling of cfg 3 as worded (64 frames per step over 8 GPUs = 8 per GPU) is bound by "
-                                                   "per-launch floors: estimate 1.4x of one GPU, not 8x.  No multi-GPU node was available: neither is measured."},
+                                                   "per-launch floors: 8 x batch8_fps_1gpu (measured on one GPU) against this line's value.  No multi-GPU node was "
+                                                   "available: neither curve is measured."},
         }
         if args.frames_total:
             out["config"]["frames_total_per_step"] = args.frames_total
@@ -512,7 +589,11 @@ def main():
         if prof:
             tot_ms = sum(v[0] for v in prof.values())
             kb = kernel_bytes_per_frame(det, model)
-            dom = max(prof, key=lambda k: prof[k][0])
+            # the kernel the roofline block is about: the largest one ALONE on the machine (a property of the kernels, stable from run
+            # to run); which kernel has the largest launch-to-finish time beside the other contexts flips between runs and is
+            # reported next to it (region_dominant_kernel)
+            region_dom = max(prof, key=lambda k: prof[k][0])
+            dom = max((k for k in solo if k in prof), key=lambda k: solo[k][0]) if solo else region_dom
             launches = max(prof[dom][1], 1)
             # a kernel may take several launches per batch (one per real scale): its figures are per BATCH of B frames — the
             # summed duration of the launches one batch needs — so that bytes and time cover the same frames
@@ -539,10 +620,15 @@ def main():
                 # batch here, as a fraction of peak: e.g. the rank-cell tile kernel reads half of the 4 bytes per cell that `achieved`
                 # charges it (SURVEY.md 8d's figure)
                 "kernel_bytes_moved_frac": (pmc_traffic(dom, B) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_traffic(dom, B) else None,
-                "kernel": dom, "kernel_avg_ms": avg_ms, "kernel_launches_per_batch": launches / batches, "kernel_share": prof[dom][0] / tot_ms,
+                "kernel": dom, "region_dominant_kernel": region_dom, "kernel_avg_ms": avg_ms, "kernel_launches_per_batch": launches / batches, "kernel_share": prof[dom][0] / tot_ms,
                 "kernel_bytes_per_launch": kb.get(dom, 0) * B,
                 "measured": "inside the timed region (%d contexts sharing the GPU); per batch of %d frames" % (C, B),
                 "path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
+                # what the whole path really moves per frame (every kernel of a step, same committed PMC passes as `traffic`) and how
+                # that compares with SURVEY 8d's algorithmic bytes: > 1 = intermediates and re-reads, the first thing to cut
+                "traffic_path_bytes_per_frame": pmc_path_bytes_per_frame(B),
+                "wasted_traffic_ratio": (pmc_path_bytes_per_frame(B) / b_frame) if pmc_path_bytes_per_frame(B) else None,
+                "path_bytes_moved_frac": (pmc_path_bytes_per_frame(B) * C * B * args.steps / dt / 1e9 / HBM_PEAK_GBS) if pmc_path_bytes_per_frame(B) else None,
                 # the three largest kernels of the region, same figures (two of them are within a few percent of each other)
                 "top_kernels": [kernel_line(k) for k in sorted(prof, key=lambda k: -prof[k][0])[:3]],
                 # summed over the C contexts of a step (they run concurrently: the sum exceeds ms_per_step when C > 1)
