@@ -28,6 +28,15 @@ struct ResampleTiling
     int rows = 0, cols = 0, xo = 0, tile_y = 0, tile_x = 0;
 };
 
+// k_resample_strip plan of a down-sampling image resample, alone or together with the next real scale's (same source)
+struct StripPlan
+{
+    bool ok = false;
+    int yt = 0, nty = 0, nSteps = 0, ntyB = 0, nStepsB = 0, tileY = 0, tileX = 0, rowsP = 0, maxCols = 0, slowRows = 0, fillRounds = 0, tileFloats = 0;
+    uint32_t magic = 0;
+    size_t lds = 0;
+};
+
 struct RealScale
 {
     int level = 0, h = 0, w = 0;
@@ -39,6 +48,7 @@ struct RealScale
     // k_resample_march2: this scale's image and the next real scale's from one pass over their common source
     int pairNext = 0;               // 1: the next real scale is produced together with this one
     int pairRows = 0, pairCols = 0, pairTileY = 0, pairTileX = 0; // the union tiles' largest extent; the next scale's half-size tile tables
+    StripPlan strip, stripPair;     // k_resample_strip: this scale's image alone / together with the next real scale's (stripPair.ok)
     float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
     int64_t uFloats = 0, moFloats = 0; // floats per frame of U and of M, O (room for the blocked layouts' padding)
 };
@@ -141,6 +151,12 @@ struct acf_hip_ctx
     // option "tile_persist": the pooled tile kernel runs as persistent workgroups that draw tiles from a counter (best alone on the
     // device: -8 % on that kernel) or one short-lived workgroup per tile (best beside other contexts' kernels, which then find free LDS)
     int tilePersist = getenv("ACF_HIP_TILE_PERSIST") ? atoi(getenv("ACF_HIP_TILE_PERSIST")) : 1;
+    // the device as hipGetDeviceProperties describes it (acf_hip_create): the persistent grids are sized from these.  The
+    // counters the persistent workgroups draw tiles from are eight (blockIdx.x & 7: one per XCD of an MI355X, whose
+    // dispatcher deals consecutive workgroups to consecutive XCDs); on a part with another XCD count the ranges still
+    // cover every tile, only their locality is lost.
+    int numCus = 256;
+    size_t ldsPerCu = size_t(160) * 1024;
     int noTiles = 0; // option "cascade_tiles" = 0: force the global-memory staged cascade (A/B and parity of both paths)
     int noRank = 0;  // option "rank_cells" = 0: the tile kernel reads the float pyramid (A/B and parity of both forms)
     bool ranksValid = false; // the rank pyramid of the last batch has been written (by the level kernels or by k_rank)
@@ -226,9 +242,12 @@ struct acf_hip_ctx
     float *d_lvSpec = nullptr, *d_lvTrue = nullptr;
     int32_t* d_lvRedo = nullptr;
     int levelSegFrames = 0, levelSegCap = 0, levelHMax = 0;
-    // The level chains' segments are OFF by default (option level_segments = n > 1 turns them on): a level is at most 480 columns,
-    // so they only pay with warm-ups of ~32 columns (one frame: 412 -> 205 us), and channel planes have exactly-zero regions
-    // wherever the image is flat (no gradient) — with the plane-level repair one such plane costs the whole chain again.
+    // The level chains' segments: option level_segments 0 (default) = AUTO — batches of at most levelSegFrames (8) frames run the
+    // speculative segmented k_level_all + k_level_verify + the repair launch, bigger batches one chain per plane; 1 = off; n > 1 =
+    // n segments whatever the batch.  A level is at most 480 columns, so segments only pay with warm-ups of ~32 columns (option
+    // level_warm; one frame: 372 -> 124 us), and channel planes have exactly-zero regions wherever the image is flat (no
+    // gradient): a plane whose hand-over differs costs its whole chain again in the repair launch (tests/test_gpu_segments.py
+    // counts the repairs of a frame with flat bands so that this cost stays visible).
     int levelSegments = getenv("ACF_HIP_LEVEL_SEGMENTS") ? atoi(getenv("ACF_HIP_LEVEL_SEGMENTS")) : 0; // option level_segments: 0 = auto (small batches only), 1 = off
     int levelWarm = getenv("ACF_HIP_LEVEL_WARM") ? atoi(getenv("ACF_HIP_LEVEL_WARM")) : 32; // option level_warm
     // option count_repairs: planes the repair launches had to recompute (synchronises after every verify: measurements only)
@@ -958,6 +977,14 @@ int acf_hip_create(int device, void* stream, acf_hip_ctx** out)
         return ACF_HIP_E_HIP;
     }
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        {
+            c->numCus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : c->numCus;
+            c->ldsPerCu = prop.maxSharedMemoryPerMultiProcessor > 0 ? size_t(prop.maxSharedMemoryPerMultiProcessor) : c->ldsPerCu;
+        }
+    }
     if (stream)
     {
         c->stream = reinterpret_cast<hipStream_t>(stream);
@@ -2091,6 +2118,175 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     return ACF_HIP_OK;
 }
 
+// k_resample_strip's plan (kernels.hip.h): row tiles of `yt` output rows of A (yt / 2 of B), steps of RS_XO output columns of A
+// (RS_XO / 2 of B); per row tile / per step the union of the two outputs' source ranges, appended to the int arena.
+static StripPlan stripPlan(const ResampleDesc& da, const ResampleDesc* db, TableArena& arena)
+{
+    StripPlan sp;
+    auto down = [](const ResampleDesc& d) { return (d.xmode == RS_DOWN || d.xmode == RS_EXACT) && (d.ymode == RS_DOWN || d.ymode == RS_EXACT); };
+    if (!down(da) || (db && !down(*db)) || da.ha % 4 || da.ha < 8 || da.src_frame_stride % 4 || da.src_off % 4 ||
+        (db && (db->ha != da.ha || db->wa != da.wa || db->nplanes != da.nplanes || db->src_frame_stride != da.src_frame_stride || db->src_off != da.src_off)))
+    {
+        return sp;
+    }
+    const int32_t* it = arena.ints.data();
+    auto rowRange = [&](const ResampleDesc& d, int yb0, int yb1, int& lo, int& hi) {
+        if (d.ymode == RS_EXACT)
+        {
+            lo = d.yk * yb0;
+            hi = d.yk * (yb1 - 1) + d.yk - 1;
+        }
+        else
+        {
+            lo = it[d.y_src + it[d.y_start + yb0]];
+            hi = std::max(it[d.y_src + it[d.y_start + yb1 - 1]] + d.ybd0 - 1, it[d.y_src + it[d.y_start + yb1] - 1]);
+        }
+    };
+    auto colRange = [&](const ResampleDesc& d, int xb0, int xb1, int& lo, int& hi) {
+        lo = it[d.x_col + 8 * xb0];
+        hi = lo;
+        for (int x = xb0; x < xb1; x++)
+        {
+            lo = std::min(lo, it[d.x_col + 8 * x]);
+            hi = std::max(hi, it[d.x_col + 8 * x] + it[d.x_col + 8 * x + 1] - 1);
+        }
+    };
+    // the y pass's slow form (more than four taps) keeps a row's taps in registers: at most 8, each within 15 rows of the first
+    auto slowOk = [&](const ResampleDesc& d) {
+        if (!(d.ymode == RS_DOWN && d.ybd0 > 4))
+        {
+            return true;
+        }
+        for (int yb = 0; yb < d.hb; yb++)
+        {
+            const int q0 = it[d.y_start + yb], q1 = it[d.y_start + yb + 1];
+            if (q1 - q0 > 8)
+            {
+                return false;
+            }
+            for (int q = q0; q < q1; q++)
+            {
+                const int off = it[d.y_src + q] - it[d.y_src + q0];
+                if (off < 0 || off > 15)
+                {
+                    return false;
+                }
+            }
+        }
+        return true;
+    };
+    if (!slowOk(da) || (db && !slowOk(*db)))
+    {
+        return sp;
+    }
+    auto fourTaps = [&](const ResampleDesc& d) {
+        for (int x = 0; x < d.wb; x++)
+        {
+            if (it[d.x_col + 8 * x + 1] > 4)
+            {
+                return false;
+            }
+        }
+        return true;
+    };
+    if (!fourTaps(da) || (db && !fourTaps(*db)))
+    {
+        return sp; // (x ratios above 4: the generic kernels)
+    }
+    const int nSteps = cdiv(da.wb, RS_XO), nStepsB = db ? cdiv(db->wb, RS_XO / 2) : 0;
+    if (nStepsB > nSteps)
+    {
+        return sp;
+    }
+    std::vector<int32_t> tx;
+    int maxC = 0;
+    for (int st = 0; st < nSteps; st++)
+    {
+        int lo, hi;
+        colRange(da, st * RS_XO, std::min((st + 1) * RS_XO, da.wb), lo, hi);
+        if (st < nStepsB)
+        {
+            int lob, hib;
+            colRange(*db, st * (RS_XO / 2), std::min((st + 1) * (RS_XO / 2), db->wb), lob, hib);
+            lo = std::min(lo, lob);
+            hi = std::max(hi, hib);
+        }
+        tx.push_back(lo);
+        tx.push_back(hi - lo + 1);
+        maxC = std::max(maxC, hi - lo + 1);
+    }
+    for (int nty = 1; nty <= 64; nty++)
+    {
+        const int yt = (cdiv(da.hb, nty) + 1) / 2 * 2;
+        const int ntyA = cdiv(da.hb, yt), ntyB = db ? cdiv(db->hb, yt / 2) : 0;
+        if (ntyA != nty || ntyB > nty)
+        {
+            continue;
+        }
+        std::vector<int32_t> tyv;
+        int maxR = 0;
+        for (int t = 0; t < nty; t++)
+        {
+            int lo, hi;
+            rowRange(da, t * yt, std::min((t + 1) * yt, da.hb), lo, hi);
+            if (t < ntyB)
+            {
+                int lob, hib;
+                rowRange(*db, t * (yt / 2), std::min((t + 1) * (yt / 2), db->hb), lob, hib);
+                lo = std::min(lo, lob);
+                hi = std::max(hi, hib);
+            }
+            lo = lo / 4 * 4;
+            tyv.push_back(lo);
+            tyv.push_back(hi - lo + 1);
+            maxR = std::max(maxR, hi - lo + 1);
+        }
+        const int rowsP = (maxR + 3) / 4 * 4;
+        const int64_t items = int64_t(RS_XO) * std::min(yt, da.hb) + (db ? int64_t(RS_XO / 2) * (yt / 2) : 0);
+        const bool slowA = da.ymode == RS_DOWN && da.ybd0 > 4, slowB = db && db->ymode == RS_DOWN && db->ybd0 > 4;
+        const int slowRows = (slowA ? yt : 0) + (slowB ? yt / 2 : 0);
+        // a tile's requests: whole rounds of RS_NT chunks of 16 bytes (the kernel issues a fixed number per wave)
+        const int fillRounds = cdiv(int64_t(maxC) * (rowsP / 4), RS_NT);
+        const int tileFloats = fillRounds * RS_NT * 4;
+        const size_t lds = (size_t(2) * tileFloats + size_t(RS_XO + RS_XO / 2) * RS_CP) * sizeof(float) + size_t(2) * RS_REC * 4 +
+            size_t(std::max(slowRows, 1)) * 8 * sizeof(float);
+        if (rowsP > 64 * RS_KCH || fillRounds > 4 || items > int64_t(RS_ITEMS) * RS_NT || lds + size_t(8) * (nSteps + 2) > size_t(52) * 1024)
+        {
+            continue;
+        }
+        const uint32_t cps = uint32_t(rowsP / 4);
+        const uint32_t magic = uint32_t(((uint64_t(1) << 32) + cps - 1) / cps);
+        bool ok = cps > 1;
+        for (uint32_t q = 0; q < uint32_t(maxC) * cps && ok; q++)
+        {
+            ok = uint32_t((uint64_t(q) * magic) >> 32) == q / cps;
+        }
+        if (!ok)
+        {
+            continue;
+        }
+        sp.ok = true;
+        sp.yt = yt;
+        sp.nty = nty;
+        sp.ntyB = ntyB;
+        sp.nSteps = nSteps;
+        sp.nStepsB = nStepsB;
+        sp.rowsP = rowsP;
+        sp.maxCols = maxC;
+        sp.magic = magic;
+        sp.lds = lds;
+        sp.slowRows = slowRows;
+        sp.fillRounds = fillRounds;
+        sp.tileFloats = tileFloats;
+        sp.tileY = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), tyv.begin(), tyv.end());
+        sp.tileX = int(arena.ints.size());
+        arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
+        return sp;
+    }
+    return sp;
+}
+
 // Tiling of a down-sampling descriptor for k_resample_tile: output columns per tile (the largest of 32/16/8 whose
 // source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
 // int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
@@ -2438,6 +2634,29 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         arena.ints.insert(arena.ints.end(), ty.begin(), ty.end());
         ra.pairTileX = int(arena.ints.size());
         arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
+    }
+
+    // k_resample_strip (the march over strips of output columns) for every down-sampling image resample, and for two consecutive
+    // real scales that share their source — the two small scales of a 1080p pyramid — in one pass (A/B: ACF_HIP_RESAMPLE_NO_STRIP)
+    if (!getenv("ACF_HIP_RESAMPLE_NO_STRIP"))
+    {
+        for (size_t k = 0; k < c->real.size(); k++)
+        {
+            RealScale& ra = c->real[k];
+            if (!ra.resampled)
+            {
+                continue;
+            }
+            ra.strip = stripPlan(c->h_descs[ra.descIndex], nullptr, arena);
+            if (k + 1 < c->real.size() && !getenv("ACF_HIP_RESAMPLE_NO_PAIR"))
+            {
+                const RealScale& rb = c->real[k + 1];
+                if (rb.resampled && !ra.adoptAsI && ra.src_h == rb.src_h && ra.src_w == rb.src_w && !(k > 0 && c->real[k - 1].stripPair.ok) && rb.w <= ra.w && rb.h <= ra.h)
+                {
+                    ra.stripPair = stripPlan(c->h_descs[ra.descIndex], &c->h_descs[rb.descIndex], arena);
+                }
+            }
+        }
     }
 
     // approximated levels (chnsPyramid.cpp:385-397)
@@ -3319,9 +3538,80 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             }
             prof(c, "k_resample(image)");
             const ResampleDesc& hd = c->h_descs[rs.descIndex];
+            const bool exactHalf = hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
+                hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&
+                (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0; // (k_resample_half's case: one thread per output pair)
             if (halfDone[k] || pairDone[k])
             {
-                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_march2)
+                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_strip / k_resample_march2)
+            }
+            else if (rs.strip.ok && !exactHalf && !resampleGenericOnly() && (uintptr_t(cur) & 15) == 0)
+            {
+                // (with the scales on their own streams the next scale's chain would need one more event: the pair is for the one-stream order)
+                const bool pair = rs.stripPair.ok && k + 1 < c->real.size() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar;
+                const StripPlan& sp = pair ? rs.stripPair : rs.strip;
+                StripArgs sa{};
+                sa.src = cur;
+                sa.dstA = rs.img;
+                sa.dstB = pair ? c->real[k + 1].img : nullptr;
+                sa.descs = c->d_descs;
+                sa.it = c->d_it;
+                sa.ft = c->d_ft;
+                sa.descA = rs.descIndex;
+                sa.descB = pair ? c->real[k + 1].descIndex : -1;
+                sa.yt = sp.yt;
+                sa.nty = sp.nty;
+                sa.nSteps = sp.nSteps;
+                sa.tileY = sp.tileY;
+                sa.tileX = sp.tileX;
+                sa.rowsP = sp.rowsP;
+                sa.maxCols = sp.maxCols;
+                sa.ntyB = sp.ntyB;
+                sa.nStepsB = sp.nStepsB;
+                sa.cpsMagic = sp.magic;
+                sa.slowRows = sp.slowRows;
+                sa.fillRounds = sp.fillRounds;
+                sa.tileFloats = sp.tileFloats;
+                sa.dump = c->d_dump;
+                // column segments: enough workgroups for ~4 per CU (a resample has no history along x: segments are free), each at least 8 steps long
+                // column segments (a resample has no history along x: segments are free), each at least 8 steps long: the count that
+                // minimises (rounds of workgroups over what the device holds at once) x (steps per workgroup)
+                const size_t ldsS = sp.lds + size_t(8) * (sp.nSteps + 2);
+                const int64_t wgs = int64_t(hd.nplanes) * sp.nty * nF;
+                const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, std::min<int64_t>(4, int64_t(c->ldsPerCu) / int64_t((ldsS + 1279) / 1280 * 1280)));
+                int64_t bestCost = -1;
+                sa.nSplit = 1;
+                for (int n = 1; n <= std::max(1, sp.nSteps / 8); n++)
+                {
+                    const int64_t cost = ((wgs * n + resident - 1) / resident) * (cdiv(sp.nSteps, n) + 2);
+                    if (bestCost < 0 || cost < bestCost)
+                    {
+                        bestCost = cost;
+                        sa.nSplit = n;
+                    }
+                }
+                if (pair)
+                {
+                    pairDone[k + 1] = 1;
+                }
+                const dim3 sgrid(hd.nplanes * sp.nty * sa.nSplit, 1, nF);
+                const bool slow = sp.slowRows > 0;
+                if (pair && slow)
+                {
+                    hipLaunchKernelGGL((k_resample_strip<true, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+                }
+                else if (pair)
+                {
+                    hipLaunchKernelGGL((k_resample_strip<true, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+                }
+                else if (slow)
+                {
+                    hipLaunchKernelGGL((k_resample_strip<false, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((k_resample_strip<false, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+                }
             }
             else if (rs.pairNext && rs.tiling.rows > 0 && !resampleGenericOnly() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar)
             {
@@ -3340,9 +3630,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     (const ResampleDesc*)c->d_descs, rs.descIndex, mp, (const int32_t*)c->d_it, (const float*)c->d_ft, rs.pairRows, rs.pairCols, tl.xo,
                     tl.tile_y, tl.tile_x, nSplit);
             }
-            else if (hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
-                hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&
-                (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0)
+            else if (exactHalf)
             {
                 const int64_t items = int64_t(hd.hb / 2) * hd.wb * hd.nplanes;
                 hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
@@ -4299,8 +4587,9 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8 + padKb * 1024
                                      : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8 + padKb * 1024;
         // k_cascade_tile3: persistent workgroups (as many as the CUs hold at once) that draw their tiles from one counter per XCD
-        // (tilePersist: 0 one workgroup per tile, 1 as many workgroups as the 256 CUs hold at once, n > 1 that many)
-        const int64_t resident = int64_t(256) * std::max<int64_t>(1, int64_t(160 * 1024) / int64_t((lds + 1279) / 1280 * 1280));
+        // (tilePersist: 0 one workgroup per tile, 1 as many workgroups as the device's CUs hold at once, n > 1 that many, rounded up
+        // to a multiple of 8 = the tile counters)
+        const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, int64_t(c->ldsPerCu) / int64_t((lds + 1279) / 1280 * 1280));
         const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
         const bool persist = gt.pooled && c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
         if (!persist)
@@ -4673,7 +4962,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
                     const size_t nwin = size_t(at.g.NW) * 64;
                     const size_t lds = size_t(128) * 4 * (size_t(1) << p.treeDepth) + size_t(at.g.tileFloats) * (rankD ? 2 : 4) +
                         ((std::max(nwin * 8, size_t(at.g.passW) * size_t(at.g.pitchC)) + 15) / 16 * 16) + nwin * 8;
-                    const int64_t resident = int64_t(256) * std::max<int64_t>(1, int64_t(160 * 1024) / int64_t((lds + 1279) / 1280 * 1280));
+                    const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, int64_t(c->ldsPerCu) / int64_t((lds + 1279) / 1280 * 1280));
                     const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
                     const bool persist = c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
                     // (the staged path's counters [stage][frame] start at d_qcounts; the tile counters sit behind them)

@@ -4337,6 +4337,364 @@ __global__ void __launch_bounds__(256) k_resample_march2(const float* __restrict
 }
 
 // ------------------------------------------------------------------------
+// k_resample_strip: the down-sampling image resamples (chnsPyramid.cpp:310) as a march over STRIPS of output columns.
+// k_resample_march2 spent its time in a tile's dependent round trips (53 scalar loads, 135 branches, 1650 wave instructions per
+// 8 x 64-output tile: 0.58 ms per 96 1080p frames for 8 MB per frame, 12 % of what the bytes need).  Here a workgroup takes a
+// row tile of up to ~140 output rows (the whole source height of the tile: ~280 rows, one LDS column of `rowsP` floats) of one
+// plane and walks its output columns RS_XO = 4 at a time (half as many of output B when the next real scale comes from the
+// same source):
+//   * the step's source columns arrive by LDS-DMA in 16-byte chunks, requested one step ahead into the other of two buffers;
+//   * x pass: wave w = output column w of the step (its 32-byte column record one vector load, requested a step ahead), lanes =
+//     source rows, every tap read issued before the first product; B's columns on wave pairs;
+//   * y pass: (column, row) items dealt to the 256 threads once (a thread's rows — hence its taps — are the same in every step:
+//     looked up before the march), one barrier between the passes, no table read inside the march.
+// The products and sums are rt_passes' (= rs_C's and k_resample's: x pass then y pass, taps ascending), bit for bit.
+// ------------------------------------------------------------------------
+constexpr int RS_XO = 4;     // output columns of A per step (B: RS_XO / 2)
+constexpr int RS_NT = 256;   // threads per workgroup
+constexpr int RS_ITEMS = 3;  // y-pass items per thread at most ((RS_XO * yt + RS_XO / 2 * yt / 2) / RS_NT, rounded up)
+constexpr int RS_KCH = 5;    // 64-row chunks of a source column at most (rowsP <= 320)
+constexpr int RS_CP = 64 * (RS_KCH + 1);        // pitch of an x-pass column in LDS (every chunk's store, B's sixth included, lands in its own column)
+constexpr int RS_REC = (RS_XO + RS_XO / 2) * 8; // ints of a step's column records
+struct StripArgs
+{
+    const float* src;
+    float* dstA;
+    float* dstB;
+    float* dump;            // >= RS_NT floats nobody reads
+    const ResampleDesc* descs;
+    const int32_t* it;
+    const float* ft;
+    int32_t descA, descB;   // descB < 0: one output
+    int32_t yt, nty;        // A's output rows per row tile (even; B's tile: yt / 2 rows), row tiles
+    int32_t nSteps, nSplit; // steps of RS_XO output columns of A; column segments per (plane, row tile)
+    int32_t tileY;          // int arena: per row tile {rowLo (a multiple of 4), nRows (<= rowsP)}: the union of A's and B's source rows
+    int32_t tileX;          // int arena: per step {colLo, nCols (<= maxCols)}
+    int32_t rowsP, maxCols; // a source tile in LDS is [maxCols][rowsP] floats, rowsP % 4 == 0
+    int32_t tileFloats;     // floats of one tile buffer: the requests of a tile, RS_NT chunks of 16 bytes per round, rounded up to whole rounds
+    int32_t fillRounds;     // requests per wave and tile (a constant: the rounds past a tile's last chunk repeat it into the buffer's slack)
+    int32_t ntyB, nStepsB;  // B's row tiles and steps (<= A's)
+    int32_t slowRows;       // rows of the slow y pass's tap table in LDS (0: neither output takes it)
+    uint32_t cpsMagic;      // ceil(2^32 / (rowsP / 4)): chunk index -> column by mulhi (checked on the host for every index)
+};
+
+// what one y-pass item needs in every step (looked up once): its rows of C, its taps
+struct StripItem
+{
+    int32_t crow;     // float offset in C of the first tap: column * RS_CP + source row - rowLo
+    int32_t ny;       // taps
+    uint32_t offs;    // slow path: 4 bits per tap, tap j reads row crow + ((offs >> 4j) & 15) (fillers repeat a source row)
+    int32_t col;      // column of the step: 0 .. RS_XO - 1 (A), RS_XO .. (B); -1: no item
+    int32_t dst;      // yb (output row)
+    int32_t slowRow;  // slow path: row of the tap table in LDS
+    float w[4];       // the (at most four) weights; 1 for the exact form, whose sum is scaled by `gain` (r / k), else gain = 1
+    float gain;
+    uint32_t voff;    // byte offset of the item's output in its plane at step 0: (col * hb + yb) * 4 (the step adds a scalar)
+};
+
+// x pass of one output column for the NK row chunks k0, k0 + kStep, ... of the source tile T ([cols][rowsP], first column colLo)
+// into the LDS column Cc (pitch RS_CP): rt_passes' products and sums, straight-line — every tap read issued before the first
+// product; a tap beyond m reads the last real tap's column and is dropped by a select; the exact form (sums of k columns,
+// imResampleMex.cpp:198-215) is the weighted form with weights 1: t * 1.f == t for every t, so the sums are the same floats.
+template <int NK>
+__device__ __forceinline__ void strip_xpass(const float* T, float* Cc, bool exact, const int4& r0, const int4& r1, int colLo, int k0, int kStep, int rowsP,
+    int rowLo, int ha)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = r0.y;
+    const int toff = (r0.x - colLo) * rowsP;
+    const float w0 = exact ? 1.f : __int_as_float(r1.x), w1 = exact ? 1.f : __int_as_float(r1.y), w2 = exact ? 1.f : __int_as_float(r1.z),
+                w3 = exact ? 1.f : __int_as_float(r1.w);
+    const int j1 = min(1, m - 1) * rowsP, j2 = min(2, m - 1) * rowsP, j3 = min(3, m - 1) * rowsP;
+    float tv[NK][4];
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+    {
+        const int rr = min(lane + 64 * (k0 + k * kStep), rowsP - 1);
+        tv[k][0] = T[toff + rr];
+        tv[k][1] = T[toff + j1 + rr];
+        tv[k][2] = T[toff + j2 + rr];
+        tv[k][3] = T[toff + j3 + rr];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+    {
+        const int rr = lane + 64 * (k0 + k * kStep);
+        float sv = tv[k][0] * w0;
+        const float q1 = sv + tv[k][1] * w1;
+        sv = m > 1 ? q1 : sv;
+        const float q2 = sv + tv[k][2] * w2;
+        sv = m > 2 ? q2 : sv;
+        const float q3 = sv + tv[k][3] * w3;
+        sv = m > 3 ? q3 : sv;
+        Cc[rr] = (rowLo + rr >= ha) ? 0.f : sv; // C[ha .. ha+3] = 0 (imResampleMex.cpp:133-137); rows past the tile: never read
+    }
+}
+
+template <bool HAVEB, bool SLOW>
+__global__ void __launch_bounds__(RS_NT) k_resample_strip(StripArgs a)
+{
+    extern __shared__ float rs_lds[];
+    const ResampleDesc& dA = a.descs[a.descA];
+    const ResampleDesc& dB = a.descs[HAVEB ? a.descB : a.descA];
+    const int32_t* __restrict__ it = a.it;
+    const float* __restrict__ ft = a.ft;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = blockIdx.x;
+    const int part = t % a.nSplit;
+    t /= a.nSplit;
+    const int ytile = t % a.nty;
+    const int z = t / a.nty;
+    const int perPart = (a.nSteps + a.nSplit - 1) / a.nSplit;
+    const int s0 = part * perPart, s1 = min(s0 + perPart, a.nSteps);
+    if (z >= dA.nplanes || s0 >= s1)
+    {
+        return;
+    }
+    // (every descriptor field the march needs, by value: a field selected between the two descriptors inside the loop would be
+    // re-read from memory there — and an ordinary load's result used while LDS-DMA requests are in flight drains them all)
+    const int ha = dA.ha, wa = dA.wa, hbA = dA.hb, wbA = dA.wb, hbB = dB.hb, wbB = dB.wb;
+    const int xcolA = dA.x_col, xcolB = dB.x_col;
+    const bool exA = dA.xmode == RS_EXACT, exB = dB.xmode == RS_EXACT;
+    const int rowsP = a.rowsP, cps = rowsP >> 2;
+    const int ty = z < dA.c1 ? 0 : (z < dA.c2 ? 1 : 2);
+    const float rA = dA.r[ty], rkA = dA.rk[ty], rB = dB.r[ty], rkB = dB.rk[ty];
+    const float* __restrict__ S = a.src + int64_t(blockIdx.z) * dA.src_frame_stride + dA.src_off + int64_t(z) * ha * wa;
+    float* __restrict__ OA = a.dstA + int64_t(blockIdx.z) * dA.dst_frame_stride + dA.dst_off + int64_t(z) * hbA * wbA;
+    float* __restrict__ OB = HAVEB ? a.dstB + int64_t(blockIdx.z) * dB.dst_frame_stride + dB.dst_off + int64_t(z) * hbB * wbB : a.dump;
+    const srd_t Ssrd = make_srd(S, int64_t(ha) * wa * 4), Isrd = make_srd(it, int64_t(1) << 32);
+    const srd_t OAsrd = make_srd(OA, int64_t(hbA) * wbA * 4), OBsrd = make_srd(OB, HAVEB ? int64_t(hbB) * wbB * 4 : 4);
+    const int rowLo = it[a.tileY + 2 * ytile];
+    const int ybA0 = ytile * a.yt, ytA = min(a.yt, hbA - ybA0);
+    const bool tileB = HAVEB && ytile < a.ntyB;
+    const int ybB0 = ytile * (a.yt >> 1), ytB = tileB ? min(a.yt >> 1, hbB - ybB0) : 0;
+    const int nItA = RS_XO * ytA, nItB = (RS_XO / 2) * ytB;
+    // LDS: two source tiles, the step's x-pass columns, two sets of column records, the slow y pass's taps, the step table
+    float* const Tb0 = rs_lds;
+    float* const C = rs_lds + 2 * size_t(a.tileFloats); // [RS_XO + RS_XO / 2][RS_CP]
+    int32_t* const recL = reinterpret_cast<int32_t*>(C + (RS_XO + RS_XO / 2) * RS_CP); // [2][RS_REC]
+    float* const slowW = reinterpret_cast<float*>(recL + 2 * RS_REC);                   // [max(slowRows, 1)][8]
+    int32_t* const stepL = reinterpret_cast<int32_t*>(slowW + 8 * max(a.slowRows, 1));  // [steps of this segment + 2]{colLo, nCols}
+    const bool slowA = SLOW && dA.ymode == RS_DOWN && dA.ybd0 > 4, slowB = SLOW && dB.ymode == RS_DOWN && dB.ybd0 > 4;
+
+    // ---- this thread's y-pass items (a thread's rows are the same in every step)
+    StripItem item[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++)
+    {
+        StripItem& q = item[k];
+        const int i = tid + RS_NT * k;
+        const bool isA = i < nItA, isB = !isA && i - nItA < nItB;
+        q.col = -1;
+        q.crow = 0;
+        q.ny = 2;
+        q.offs = 0;
+        q.dst = 0;
+        q.slowRow = 0;
+        q.w[0] = q.w[1] = q.w[2] = q.w[3] = 0.f;
+        q.gain = 1.f;
+        if (isA || isB)
+        {
+            const ResampleDesc& d = isA ? dA : dB;
+            const int yt_ = isA ? ytA : ytB, i_ = isA ? i : i - nItA;
+            const int c = i_ / yt_, row = i_ - c * yt_;
+            const int yb = (isA ? ybA0 : ybB0) + row;
+            const float r = isA ? rA : rB;
+            q.col = isA ? c : RS_XO + c;
+            q.dst = yb;
+            if (d.ymode == RS_EXACT)
+            {
+                q.ny = d.yk;
+                q.crow = d.yk * yb - rowLo;
+                q.w[0] = q.w[1] = q.w[2] = q.w[3] = 1.f; // (c * 1.f == c: the sums of imResampleMex.cpp:286,:309,:316)
+                q.gain = isA ? rkA : rkB;
+            }
+            else
+            {
+                const int q0 = it[d.y_start + yb], q1 = it[d.y_start + yb + 1];
+                const int ya = it[d.y_src + q0];
+                q.crow = ya - rowLo;
+                if (SLOW && d.ybd0 > 4)
+                {
+                    // more than four taps (the reference's generic loop, imResampleMex.cpp:357-370): weights in the LDS table, one row
+                    // per output row of the tile (A's rows first), written by the item of the row's first column
+                    q.ny = q1 - q0; // (<= 8, each within 15 rows of the first: the host planned it)
+                    q.slowRow = (isA ? 0 : (slowA ? ytA : 0)) + row;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                    {
+                        float wj = 0.f;
+                        if (j < q1 - q0)
+                        {
+                            wj = ft[d.y_wt + q0 + j] * r;
+                            q.offs |= uint32_t(it[d.y_src + q0 + j] - ya) << (4 * j);
+                        }
+                        if (c == 0)
+                        {
+                            slowW[q.slowRow * 8 + j] = wj;
+                        }
+                    }
+                }
+                else
+                {
+                    q.ny = d.ybd0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        if (j < d.ybd0)
+                        {
+                            q.w[j] = ft[d.y_wt + q0 + j] * r; // ywts[y] *= r (:158-161)
+                        }
+                    }
+                }
+            }
+            q.crow += q.col * RS_CP;
+            q.voff = uint32_t(c * (isA ? hbA : hbB) + yb) * 4u;
+        }
+    }
+    // which of the thread's item slots hold an item of the slow form anywhere in this WAVE (wave-uniform: the slow form's extra
+    // reads are skipped where no lane needs them — A's items fill the first slots, B's the last)
+    bool slowK[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++)
+    {
+        const bool mine = SLOW && item[k].col >= 0 && (item[k].col >= RS_XO ? slowB : slowA);
+        slowK[k] = __builtin_amdgcn_ballot_w64(mine) != 0;
+    }
+    // fill: a lane's chunk of a round is the same (column of the tile, rows) in every step
+    uint32_t fCol[4], fRow[4]; // (a.fillRounds <= 4: the host planned it)
+#pragma unroll
+    for (int rnd = 0; rnd < 4; rnd++)
+    {
+        const uint32_t q = uint32_t(rnd * RS_NT + wv * 64 + lane);
+        const uint32_t col = __umulhi(q, a.cpsMagic);
+        const uint32_t ch = q - col * uint32_t(cps);
+        fCol[rnd] = col;
+        fRow[rnd] = uint32_t(min(rowLo + 4 * int(ch), ha - 4)) * 4u; // rows past the image: clamped duplicates (the x pass zeroes them)
+    }
+    const uint32_t colBytes = uint32_t(ha) * 4u;
+    // the segment's step table {colLo, nCols} into LDS (two entries past the end repeat the last step)
+    for (int i = tid; i < 2 * (s1 - s0 + 2); i += RS_NT)
+    {
+        stepL[i] = it[a.tileX + 2 * min(s0 + (i >> 1), a.nSteps - 1) + (i & 1)];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // (the step table and the slow taps are every wave's)
+
+    // ---- the march.  No ordinary load, no branch inside: a tile's requests are a fixed number per wave (a.fillRounds, + one for
+    // wave 0's column records), its stores RS_ITEMS per wave.
+    auto fill = [&](int s, float* T) {
+        const float* stepF = reinterpret_cast<const float*>(stepL); // (as floats: see the column records below)
+        const int colLo = __builtin_amdgcn_readfirstlane(__float_as_int(stepF[2 * (s - s0)])),
+                  nCols = __builtin_amdgcn_readfirstlane(__float_as_int(stepF[2 * (s - s0) + 1]));
+#pragma unroll
+        for (int rnd = 0; rnd < 4; rnd++)
+        {
+            if (rnd < a.fillRounds) // (uniform)
+            {
+                // (a chunk past the tile's last column: the last column's rows again, into the buffer's slack)
+                const uint32_t x = uint32_t(min(colLo + int(min(fCol[rnd], uint32_t(nCols - 1))), wa - 1));
+                // (the BUFFER form: after a global_load_lds the compiler drains every request before the kernel's next LDS access — it
+                // cannot tell the tile buffers apart — and the look-ahead is gone; k_level's ring has the same reason)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(Ssrd, (lptr_t)(T + 4u * uint32_t(rnd * RS_NT + wv * 64)), 16, x * colBytes + fRow[rnd], 0, 0, 0);
+            }
+        }
+        // the step's column records — A's columns RS_XO s .., then B's (clamped to the last column: computed, not stored) — one dword per
+        // lane of wave 0
+        if (wv == 0 && lane < RS_REC) // (the request writes LDS at dst + 4 * lane: the lanes past the records must not take part)
+        {
+            const int e = lane, cIdx = e >> 3, wIdx = e & 7;
+            const bool forB = cIdx >= RS_XO;
+            const int x = forB ? min((RS_XO / 2) * s + cIdx - RS_XO, wbB - 1) : min(RS_XO * s + cIdx, wbA - 1);
+            int32_t* dst = recL + ((s - s0) & 1) * RS_REC;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Isrd, (lptr_t)dst, 4, uint32_t((forB ? xcolB : xcolA) + 8 * x + wIdx) * 4u, 0, 0, 0);
+        }
+        return colLo;
+    };
+    int colLoNext = fill(s0, Tb0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int s = s0; s < s1; s++)
+    {
+        // Tile s has arrived: this wave's requests for it are older than its RS_ITEMS stores of the previous step's y pass and
+        // requests complete in order, so the stores may stay in flight; the barrier makes the arrival every wave's.  Every wave is
+        // also past the previous step's y pass: C, the other tile buffer and the other record set may be written again.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS_ITEMS * (HAVEB ? 2 : 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int cur = (s - s0) & 1;
+        const int colLoCur = colLoNext;
+        // the next tile (past the last step: the table's repeat of it, into the buffer nobody reads any more)
+        colLoNext = fill(s + 1, Tb0 + (cur ^ 1) * a.tileFloats);
+        const float* T = Tb0 + cur * a.tileFloats;
+        // (read as FLOATS: the compiler orders an LDS read behind every LDS-DMA request in flight unless type-based alias analysis
+        // separates the two, and the requests are typed as ints — an int4 read here costs an s_waitcnt vmcnt(0), i.e. the look-ahead)
+        const float* rl = reinterpret_cast<const float*>(recL) + cur * RS_REC;
+        auto rec4 = [&](int i) { return make_int4(__float_as_int(rl[4 * i]), __float_as_int(rl[4 * i + 1]), __float_as_int(rl[4 * i + 2]), __float_as_int(rl[4 * i + 3])); };
+        // x pass: A's column wv; B's column wv >> 1, the even / odd row chunks on the two waves of a pair
+        {
+            const int4 r0 = rec4(2 * wv), r1 = rec4(2 * wv + 1);
+            strip_xpass<RS_KCH>(T, C + wv * RS_CP, exA, r0, r1, colLoCur, 0, 1, rowsP, rowLo, ha);
+        }
+        const bool stepB = HAVEB && tileB && s < a.nStepsB;
+        if (HAVEB)
+        {
+            const int4 r0 = rec4(2 * (RS_XO + (wv >> 1))), r1 = rec4(2 * (RS_XO + (wv >> 1)) + 1);
+            strip_xpass<(RS_KCH + 1) / 2>(T, C + (RS_XO + (wv >> 1)) * RS_CP, exB, r0, r1, colLoCur, wv & 1, 2, rowsP, rowLo, ha);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // y pass: exactly RS_ITEMS stores per output, wave and step
+        const int xbA = RS_XO * s, xbB = (RS_XO / 2) * s;
+        const uint32_t stepA = uint32_t(xbA * hbA) * 4u, stepB4 = uint32_t(xbB * hbB) * 4u; // (scalar offsets of the step's first columns)
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; k++)
+        {
+            const StripItem& q = item[k];
+            const bool isB = q.col >= RS_XO;
+            const int cA = xbA + q.col, cB = xbB + q.col - RS_XO;
+            const bool on = q.col >= 0 && (isB ? (stepB && cB < wbB) : cA < wbA);
+            const float* Cc = C + q.crow;
+            const int ny = q.ny;
+            const float c0 = Cc[0], c1 = Cc[1], c2 = Cc[min(2, ny - 1)], c3 = Cc[min(3, ny - 1)];
+            float v = c0 * q.w[0];
+            v = v + c1 * q.w[1];
+            const float v2 = v + c2 * q.w[2];
+            v = ny > 2 ? v2 : v;
+            const float v3 = v + c3 * q.w[3];
+            v = ny > 3 ? v3 : v;
+            v = v * q.gain; // (1.f unless the exact form: v * 1.f == v)
+            if (SLOW && slowK[k]) // (wave-uniform)
+            {
+                // both forms for every lane of such a wave, one select (a wave's items may be of both outputs: no divergent branch)
+                float c[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {
+                    c[j] = Cc[(q.offs >> (4 * j)) & 15u];
+                }
+                const float* wr = slowW + q.slowRow * 8; // (scalar float reads: a float4 read is ordered behind the requests in flight, see above)
+                const float w8[8] = { wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], wr[6], wr[7] };
+                float vs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                {
+                    const float vj = vs + c[j] * w8[j]; // from 0.f, taps ascending (imResampleMex.cpp:357-370)
+                    vs = j < ny ? vj : vs;
+                }
+                v = (isB ? slowB : slowA) ? vs : v;
+            }
+            // BUFFER stores, one per output: requests of one kind complete in order, which the counted wait at the top of the step
+            // relies on (a global_store between buffer loads may overtake them); a lane without an item of that output stores
+            // beyond the descriptor's range, i.e. nowhere
+            buf_st(OAsrd, (on && !isB) ? q.voff : 0xfffffff0u, stepA, v);
+            if (HAVEB)
+            {
+                buf_st(OBsrd, (on && isB) ? q.voff : 0xfffffff0u, stepB4, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
 // LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
 // tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
 //   C_f = conv2(plane, filter_f, 'same')  (zero padded, taps in k_ldcf_conv's order: dx then dy ascending)

@@ -218,8 +218,24 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * frame at a time from a fixed buffer; not with "profile", taps, image-specific
  * lambdas, "cascade_turns" or sub-batch contexts ("streams" > 1), where the call runs
  * plainly; any set_* / plan call drops the graph),
+ * "level_segments" (0, default = auto: batches of at most 8 frames cut every level's column
+ * chain into speculative segments that are verified bit for bit on the device and repaired by a
+ * whole-chain launch where a hand-over differs — a single frame's latency 1.05 -> 0.78 ms;
+ * bigger batches run one chain per plane; 1: never; n > 1: n segments whatever the batch),
+ * "level_warm" (32, default: warm-up columns of a level segment, a positive multiple of 4),
+ * "smooth_segments" / "smooth_warm" (the same for the image smoothing: 0 = as many segments as
+ * fill the device, 64 warm-up columns), "count_repairs" (1: acf_hip_get_repairs counts the
+ * planes the repair launches recomputed; synchronises, measurements only),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
- * switches; all forms give identical results). */
+ * switches; all forms give identical results).
+ *
+ * Capacity: `max_hits` of acf_hip_plan bounds the hits kept per frame.  With stride < shrink
+ * (the cascade then runs once per distinct cell offset and k_expand_hits writes every window
+ * of a surviving offset) a frame whose EXPANDED total exceeds max_hits reports the overflow
+ * in its count as always, but WHICH of its hits are retained is unspecified (slots are
+ * reserved in thread order; a q x q group may be partly written).  "keep_pyramid" = 0 has no
+ * effect for LDCF models, for stride < shrink and for tree depths 1, 3 and 4 on rank cells:
+ * those paths read the float pyramid (their overflow queues do), so it is always written. */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.

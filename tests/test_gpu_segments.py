@@ -90,3 +90,29 @@ def test_widths_that_are_not_multiples_of_eight(oracle, W, segments, fused_grad)
         pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
         assert np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)), (W, f)
     det.close()
+
+
+def test_default_level_segments_on_a_single_frame_with_flat_bands(oracle, capsys):
+    """The defaults at batch 1 (level_segments 0 = auto: the level chains are cut, level_warm 32) on frames with black and flat
+    bands, where channel planes are exactly zero and a segment's warm-up may not reproduce the chain's state: results stay the
+    oracle's, and the number of planes the repair launch had to recompute is counted so that the cost of that path stays visible."""
+    from acf_amd.detector import HipDetector
+    H, W = 480, 640
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
+    total = [0, 0, 0, 0]
+    for k in range(3):
+        frame = synth.make_frame(91 + k, H, W, "luv")[None].copy()
+        if k == 0:
+            frame[0, :, 200:330, :] = 0.0            # a black band of columns
+        elif k == 1:
+            frame[0, :, :, 100:260] = 0.25           # a flat band of rows (no gradient: zero magnitude / histogram cells)
+        det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 15)
+        det.set_option("count_repairs", 1)
+        _check(oracle, det, frame, model, H, W)
+        r = det.repairs()
+        assert r[2] > 0, "batch 1 should cut the level chains into segments by default"
+        total = [a + b for a, b in zip(total, r)]
+        det.close()
+    with capsys.disabled():
+        print("\nlevel-chain planes repaired at batch 1 with the defaults: %d of %d (image smoothing: %d of %d)" % (total[3], total[2], total[1], total[0]))
+    assert total[3] <= total[2] // 4, "more than a quarter of the level planes needed the repair launch: the default warm-up is too short"
