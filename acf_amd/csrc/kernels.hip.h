@@ -6487,6 +6487,10 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
         const int area = colPitch * L.wP;
         const cell_t* __restrict__ src0 = (CT::RANK ? reinterpret_cast<const cell_t*>(a.pyrR) + int64_t(frame) * a.pyrR_fs + L.offR
                                                     : reinterpret_cast<const cell_t*>(a.pyr) + int64_t(frame) * a.pyr_fs + L.off) + gr0;
+        // (the BUFFER form of the LDS-DMA: behind a global_load_lds the compiler waits for every request in flight before the
+        // kernel's next LDS access — here the write of the next tile's index — so that the leaf table's loads below were requested
+        // only after the fill had ARRIVED: two memory round trips in sequence at the head of every one-tile workgroup)
+        const srd_t fsrd = make_srd(src0, int64_t(a.nChns) * area * int64_t(sizeof(cell_t)));
         const int colsValid = min(colsT, L.wP - gc0);
         const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
         const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
@@ -6501,13 +6505,9 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
                 const uint32_t z = __umulhi(seg, a.g.colsMagic);
                 const int cc = int(seg - z * uint32_t(colsT));
                 const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + uint32_t(CPB) * q0), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(fsrd, (lptr_t)(tileF + uint32_t(CPB) * q0), 16, soff * uint32_t(sizeof(cell_t)), 0, 0, 0);
             }
         }
-    }
-    if (tid == 0)
-    {
-        s_next[par] = liNext; // (read after this tile's last barrier)
     }
     // stage A1's window of this lane: wave w takes the window columns w, w + NW, ... (conflict-free feature reads)
     const int r_l = lane % TR, c_l = (lane / TR) * NW + wv;
@@ -6521,11 +6521,20 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
             {
                 hv = *reinterpret_cast<const float4*>(a.tileNodes[b2 + t].hs);
             }
-            *reinterpret_cast<float4*>(leafT + 4 * t) = hv;
+            // (four float stores, not one float4 store: type-based alias analysis is what tells the compiler that an LDS access
+            // does not touch what the fill's requests write — a float4 access is ordered behind them, i.e. drains the fill first)
+            leafT[4 * t] = hv.x;
+            leafT[4 * t + 1] = hv.y;
+            leafT[4 * t + 2] = hv.z;
+            leafT[4 * t + 3] = hv.w;
         }
         leavesDone = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0)
+    {
+        s_next[par] = liNext; // (read after this tile's last barrier; written here, behind the wait: an LDS write in the fill's shadow would drain it)
+    }
     __syncthreads();
     TILE_STAMP(1);
 
