@@ -22,7 +22,7 @@ struct DevBuf
     size_t bytes = 0;
 };
 
-// k_resample_tile plan of a down-sampling descriptor (resampleTilePlan)
+// LDS-tile plan of a down-sampling descriptor (resampleTilePlan; k_ldcf_tile)
 struct ResampleTiling
 {
     int rows = 0, cols = 0, xo = 0, tile_y = 0, tile_x = 0;
@@ -44,10 +44,6 @@ struct RealScale
     bool adoptAsI = false;  // after this scale, I := smoothed image of this scale
     int src_h = 0, src_w = 0;
     int descIndex = -1;
-    ResampleTiling tiling;          // k_resample_tile plan of the image resample (rows == 0: not eligible)
-    // k_resample_march2: this scale's image and the next real scale's from one pass over their common source
-    int pairNext = 0;               // 1: the next real scale is produced together with this one
-    int pairRows = 0, pairCols = 0, pairTileY = 0, pairTileX = 0; // the union tiles' largest extent; the next scale's half-size tile tables
     StripPlan strip, stripPair;     // k_resample_strip: this scale's image alone / together with the next real scale's (stripPair.ok)
     float *img = nullptr, *sm = nullptr, *M = nullptr, *O = nullptr, *U = nullptr, *S = nullptr, *Mn = nullptr;
     int64_t uFloats = 0, moFloats = 0; // floats per frame of U and of M, O (room for the blocked layouts' padding)
@@ -81,14 +77,14 @@ struct CascState
     CascTile* d_tiles = nullptr;
     int nTiles = 0;
     TreeNode* d_tileNodes = nullptr; // offsets in the tile's LDS layout, every tree
-    uint32_t* d_tileNodesS = nullptr; // stage A of k_cascade_tile2: 40 dwords per batch of four trees
-    int aTB = 4;                      // trees per stage-A batch of k_cascade_tile2
+    uint32_t* d_tileNodesS = nullptr; // stage A of k_cascade_tile3: 40 dwords per batch of four trees
+    int aTB = 4;                      // trees per stage-A batch of the tile kernels
     TreeNode* d_tailNodes = nullptr; // offsets = feature ids (window-local layout), all trees
     TileGeom geom{};
     int tailWaves = 0;
     float* d_tailScratch = nullptr; // k_cascade_tail3 leaf matrices: [blocks][tailWaves][TAIL_G][tailPad]
     int tailPad = 0, tailSlab = 0, tailBlocks = 0, tailNodesLds = 0;
-    // stage E of k_cascade_tile2 + k_tail_scan: leaf codes of the first codeCap queue entries per frame
+    // stage E of the tile kernels + k_tail_scan: leaf codes of the first codeCap queue entries per frame
     uint8_t* d_tailCodes = nullptr;
     int codeCap = 0, codePitch = 0;
     // fixed depths other than 2 (k_cascade_tileD): stage 0 of the staged path on float tiles
@@ -704,15 +700,7 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     prof(c, "k_tri_y");
     if (rad == 5 && h % 4 == 0 && h >= 48 && fs % 4 == 0 && ((uintptr_t(U) | uintptr_t(S)) & 15) == 0)
     {
-        static const bool direct = getenv("ACF_HIP_TRIY_DIRECT") != nullptr; // A/B: lane-per-column accesses straight from global memory
-        if (direct)
-        {
-            hipLaunchKernelGGL(k_tri_y5, dim3(cdiv(w, 64), 1, nFrames), dim3(64), 0, c->stream, (const float*)U, S, h, w, fs);
-        }
-        else
-        {
-            hipLaunchKernelGGL(k_tri_y5s, dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, S, h, w, fs);
-        }
+        hipLaunchKernelGGL(k_tri_y5s, dim3(cdiv(w, 256), 1, nFrames), dim3(256), 0, c->stream, (const float*)U, S, h, w, fs);
     }
     else
     {
@@ -1430,15 +1418,14 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     g.TR = 32;
     g.winFloats = nChns * mW * mH;
     // Stage boundaries.  k_cascade_tile3 (pooled survivors, the default for depth 2): dense [0,16) on every window, dense
-    // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.  k_cascade_tile2
-    // (ACF_HIP_TILE2: every wave keeps its own windows): 32 dense trees then sparse pieces [32,64) and [64,128).
+    // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.
     // (depths 3, 4, and 1 on rank cells: k_cascade_tile3D, the same stages, for models of at least 32 trees.  Depth 1 on FLOAT cells keeps
     // k_cascade_tileD + the staged queue: stumps reject slowly, half of a tile's windows are still alive at tree 32, and with the float
     // tile's two workgroups per CU the queue's lanes = windows form beats items = windows x trees (26 against 37 us per 1080p frame; on
     // rank cells the pooled kernel takes 19) — ACF_HIP_TILED_POOLED1 pools it there too; ACF_HIP_TILED_STAGED keeps the staged form everywhere)
     const bool pooledD = allowPooledD && ((p.treeDepth == 1 && (rank || getenv("ACF_HIP_TILED_POOLED1"))) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
         !getenv("ACF_HIP_TILED_STAGED");
-    const bool pooled = (p.treeDepth == 2 && !getenv("ACF_HIP_TILE2")) || pooledD;
+    const bool pooled = p.treeDepth == 2 || pooledD;
     int bounds[5] = { 0, 32, 32, 64, 128 };
     if (pooled)
     {
@@ -1482,7 +1469,7 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
         const int tc = nw * W * (64 / g.TR);
         const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
         const int64_t rowsP = (rows + CPB - 1) / CPB * CPB;
-        // k_cascade_tile2: footprint + one survivor list segment per wave (+ its few static words)
+        // k_cascade_tileD (depths other than 2 on float cells): footprint + one survivor list segment per wave (+ its few static words)
         if (!g.pooled)
         {
             return int64_t(nChns) * rowsP * cols * cellBytes + int64_t(nw) * 64 * 8 + 64;
@@ -1671,9 +1658,9 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
         }
         tileNodes[size_t(t)] = a;
     }
-    // stage A of k_cascade_tile2 reads its trees aTB at a time through the scalar unit
-    // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC: ACF_HIP_TILE_TB8 for the A/B)
-    const int aTB = (!g.pooled && g.b[1] % 8 == 0 && g.b[1] > 0 && getenv("ACF_HIP_TILE_TB8")) ? 8 : 4;
+    // stage A of the tile kernels reads its trees four at a time through the scalar unit
+    // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC)
+    const int aTB = 4;
     const int nTreesS = (g.pooled ? g.b[2] : g.b[1]) / aTB * aTB; // (k_cascade_tile3: both dense stages read batches)
     std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
     for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
@@ -1844,7 +1831,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     {
         return rc;
     }
-    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile2 + stage E + k_tail_scan, k_cascade_tail3 for queue overflow)
+    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile3 + stage E + k_tail_scan, k_cascade_tail3 for queue overflow)
     cs.useTiles = false;
     cs.useRank = false;
     cs.useTileD = false;
@@ -2287,7 +2274,71 @@ static StripPlan stripPlan(const ResampleDesc& da, const ResampleDesc* db, Table
     return sp;
 }
 
-// Tiling of a down-sampling descriptor for k_resample_tile: output columns per tile (the largest of 32/16/8 whose
+// k_resample_strip for one output (descB < 0) or two outputs of one source
+static void launchStrip(acf_hip_ctx* c, const StripPlan& sp, const ResampleDesc* d_descs, int descA, int descB, int nplanes, const float* src, float* dstA,
+    float* dstB, const int32_t* d_it, const float* d_ft, int nF)
+{
+    const bool pair = descB >= 0;
+    StripArgs sa{};
+    sa.src = src;
+    sa.dstA = dstA;
+    sa.dstB = dstB;
+    sa.descs = d_descs;
+    sa.it = d_it;
+    sa.ft = d_ft;
+    sa.descA = descA;
+    sa.descB = descB;
+    sa.yt = sp.yt;
+    sa.nty = sp.nty;
+    sa.nSteps = sp.nSteps;
+    sa.tileY = sp.tileY;
+    sa.tileX = sp.tileX;
+    sa.rowsP = sp.rowsP;
+    sa.maxCols = sp.maxCols;
+    sa.ntyB = sp.ntyB;
+    sa.nStepsB = sp.nStepsB;
+    sa.cpsMagic = sp.magic;
+    sa.slowRows = sp.slowRows;
+    sa.fillRounds = sp.fillRounds;
+    sa.tileFloats = sp.tileFloats;
+    sa.dump = c->d_dump;
+    // column segments (a resample has no history along x: segments are free), each at least 8 steps long: the count that
+    // minimises (rounds of workgroups over what the device holds at once) x (steps per workgroup)
+    const size_t ldsS = sp.lds + size_t(8) * (sp.nSteps + 2);
+    const int64_t wgs = int64_t(nplanes) * sp.nty * nF;
+    const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, std::min<int64_t>(4, int64_t(c->ldsPerCu) / int64_t((ldsS + 1279) / 1280 * 1280)));
+    int64_t bestCost = -1;
+    sa.nSplit = 1;
+    for (int n = 1; n <= std::max(1, sp.nSteps / 8); n++)
+    {
+        const int64_t cost = ((wgs * n + resident - 1) / resident) * (cdiv(sp.nSteps, n) + 2);
+        if (bestCost < 0 || cost < bestCost)
+        {
+            bestCost = cost;
+            sa.nSplit = n;
+        }
+    }
+    const dim3 sgrid(nplanes * sp.nty * sa.nSplit, 1, nF);
+    const bool slow = sp.slowRows > 0;
+    if (pair && slow)
+    {
+        hipLaunchKernelGGL((k_resample_strip<true, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+    }
+    else if (pair)
+    {
+        hipLaunchKernelGGL((k_resample_strip<true, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+    }
+    else if (slow)
+    {
+        hipLaunchKernelGGL((k_resample_strip<false, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+    }
+    else
+    {
+        hipLaunchKernelGGL((k_resample_strip<false, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
+    }
+}
+
+// Tiling of a down-sampling descriptor for the passes on LDS tiles (k_ldcf_tile): output columns per tile (the largest of 32/16/8 whose
 // source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
 // int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
 // (yo: output rows per tile — RT_YO for the resample kernels, k_ldcf_tile chooses its own; forceXo may be any column count)
@@ -2500,13 +2551,6 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             dd.dst_frame_stride = int64_t(d) * np;
             rs.descIndex = int(c->h_descs.size());
             c->h_descs.push_back(dd);
-            // 8 output columns per tile: the image resamples are bound by the latency of a tile's fill, and small tiles put more
-            // of them on a CU (13 KB of LDS instead of 40: 0.65 -> 0.57 ms per 96 frames for the two small real scales); env: A/B
-            rs.tiling = resampleTilePlan(dd, arena, getenv("ACF_HIP_RT_XO") ? atoi(getenv("ACF_HIP_RT_XO")) : 8);
-            if (rs.tiling.rows == 0)
-            {
-                rs.tiling = resampleTilePlan(dd, arena);
-            }
             if ((rc = devAlloc(c, &rs.img, size_t(B) * d * np)))
             {
                 return rc;
@@ -2559,83 +2603,6 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         c->real.push_back(rs);
     }
     c->nImgDescs = int(c->h_descs.size());
-    // Two consecutive real scales resampled from the same source (the two small scales of a 1080p pyramid, both from the half-size
-    // smoothed image), the second about half the first: one pass over the source for both (k_resample_march2).  The second scale's
-    // tiles are half the first's in rows and columns; the kernel loads the union of the two source ranges.
-    for (size_t k = 0; k + 1 < c->real.size() && !getenv("ACF_HIP_RESAMPLE_NO_PAIR"); k++)
-    {
-        RealScale& ra = c->real[k];
-        RealScale& rb = c->real[k + 1];
-        if (!ra.resampled || !rb.resampled || ra.adoptAsI || ra.src_h != rb.src_h || ra.src_w != rb.src_w || ra.tiling.rows == 0 || ra.tiling.xo % 2 ||
-            (k > 0 && c->real[k - 1].pairNext))
-        {
-            continue;
-        }
-        const ResampleDesc& da = c->h_descs[ra.descIndex];
-        const ResampleDesc& db = c->h_descs[rb.descIndex];
-        const bool down = (db.xmode == RS_DOWN || db.xmode == RS_EXACT) && (db.ymode == RS_DOWN || db.ymode == RS_EXACT);
-        const int xo = ra.tiling.xo, xoB = xo / 2, ryB = RT_YO / 2;
-        const int ntY = cdiv(da.hb, RT_YO), ntX = cdiv(da.wb, xo), ntYB = cdiv(db.hb, ryB), ntXB = cdiv(db.wb, xoB);
-        if (!down || db.nplanes != da.nplanes || ntYB > ntY || ntXB > ntX || ntX < 4)
-        {
-            continue;
-        }
-        std::vector<int32_t> ty, tx;
-        int maxR = 0, maxC = 0;
-        {
-            const int32_t* it = arena.ints.data();
-            for (int t = 0; t < ntY; t++)
-            {
-                int lo = it[ra.tiling.tile_y + 2 * t], hi = it[ra.tiling.tile_y + 2 * t + 1];
-                if (t < ntYB)
-                {
-                    const int yb0 = t * ryB, yb1 = std::min(yb0 + ryB, db.hb);
-                    int lob, hib;
-                    if (db.ymode == RS_EXACT)
-                    {
-                        lob = db.yk * yb0;
-                        hib = db.yk * (yb1 - 1) + db.yk - 1;
-                    }
-                    else
-                    {
-                        lob = it[db.y_src + it[db.y_start + yb0]];
-                        hib = std::max(it[db.y_src + it[db.y_start + yb1 - 1]] + db.ybd0 - 1, it[db.y_src + it[db.y_start + yb1] - 1]);
-                    }
-                    ty.push_back(lob);
-                    ty.push_back(hib);
-                    lo = std::min(lo, lob);
-                    hi = std::max(hi, hib);
-                }
-                maxR = std::max(maxR, hi - lo + 1);
-            }
-            for (int t = 0; t < ntX; t++)
-            {
-                int lo = it[ra.tiling.tile_x + 2 * t], hi = it[ra.tiling.tile_x + 2 * t + 1];
-                if (t < ntXB)
-                {
-                    const int xb0 = t * xoB, xb1 = std::min(xb0 + xoB, db.wb);
-                    const int lob = it[db.x_col + 8 * xb0], hib = it[db.x_col + 8 * (xb1 - 1)] + it[db.x_col + 8 * (xb1 - 1) + 1] - 1;
-                    tx.push_back(lob);
-                    tx.push_back(hib);
-                    lo = std::min(lo, lob);
-                    hi = std::max(hi, hib);
-                }
-                maxC = std::max(maxC, hi - lo + 1);
-            }
-        }
-        if ((2 * int64_t(maxC) + xo) * maxR * 4 > int64_t(48) * 1024)
-        {
-            continue; // (the union tiles would cost the kernel its workgroups per CU)
-        }
-        ra.pairNext = 1;
-        ra.pairRows = maxR;
-        ra.pairCols = maxC;
-        ra.pairTileY = int(arena.ints.size());
-        arena.ints.insert(arena.ints.end(), ty.begin(), ty.end());
-        ra.pairTileX = int(arena.ints.size());
-        arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
-    }
-
     // k_resample_strip (the march over strips of output columns) for every down-sampling image resample, and for two consecutive
     // real scales that share their source — the two small scales of a 1080p pyramid — in one pass (A/B: ACF_HIP_RESAMPLE_NO_STRIP)
     if (!getenv("ACF_HIP_RESAMPLE_NO_STRIP"))
@@ -3543,129 +3510,24 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0; // (k_resample_half's case: one thread per output pair)
             if (halfDone[k] || pairDone[k])
             {
-                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_strip / k_resample_march2)
+                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_strip)
             }
             else if (rs.strip.ok && !exactHalf && !resampleGenericOnly() && (uintptr_t(cur) & 15) == 0)
             {
                 // (with the scales on their own streams the next scale's chain would need one more event: the pair is for the one-stream order)
                 const bool pair = rs.stripPair.ok && k + 1 < c->real.size() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar;
-                const StripPlan& sp = pair ? rs.stripPair : rs.strip;
-                StripArgs sa{};
-                sa.src = cur;
-                sa.dstA = rs.img;
-                sa.dstB = pair ? c->real[k + 1].img : nullptr;
-                sa.descs = c->d_descs;
-                sa.it = c->d_it;
-                sa.ft = c->d_ft;
-                sa.descA = rs.descIndex;
-                sa.descB = pair ? c->real[k + 1].descIndex : -1;
-                sa.yt = sp.yt;
-                sa.nty = sp.nty;
-                sa.nSteps = sp.nSteps;
-                sa.tileY = sp.tileY;
-                sa.tileX = sp.tileX;
-                sa.rowsP = sp.rowsP;
-                sa.maxCols = sp.maxCols;
-                sa.ntyB = sp.ntyB;
-                sa.nStepsB = sp.nStepsB;
-                sa.cpsMagic = sp.magic;
-                sa.slowRows = sp.slowRows;
-                sa.fillRounds = sp.fillRounds;
-                sa.tileFloats = sp.tileFloats;
-                sa.dump = c->d_dump;
-                // column segments: enough workgroups for ~4 per CU (a resample has no history along x: segments are free), each at least 8 steps long
-                // column segments (a resample has no history along x: segments are free), each at least 8 steps long: the count that
-                // minimises (rounds of workgroups over what the device holds at once) x (steps per workgroup)
-                const size_t ldsS = sp.lds + size_t(8) * (sp.nSteps + 2);
-                const int64_t wgs = int64_t(hd.nplanes) * sp.nty * nF;
-                const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, std::min<int64_t>(4, int64_t(c->ldsPerCu) / int64_t((ldsS + 1279) / 1280 * 1280)));
-                int64_t bestCost = -1;
-                sa.nSplit = 1;
-                for (int n = 1; n <= std::max(1, sp.nSteps / 8); n++)
-                {
-                    const int64_t cost = ((wgs * n + resident - 1) / resident) * (cdiv(sp.nSteps, n) + 2);
-                    if (bestCost < 0 || cost < bestCost)
-                    {
-                        bestCost = cost;
-                        sa.nSplit = n;
-                    }
-                }
                 if (pair)
                 {
                     pairDone[k + 1] = 1;
                 }
-                const dim3 sgrid(hd.nplanes * sp.nty * sa.nSplit, 1, nF);
-                const bool slow = sp.slowRows > 0;
-                if (pair && slow)
-                {
-                    hipLaunchKernelGGL((k_resample_strip<true, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-                }
-                else if (pair)
-                {
-                    hipLaunchKernelGGL((k_resample_strip<true, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-                }
-                else if (slow)
-                {
-                    hipLaunchKernelGGL((k_resample_strip<false, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-                }
-                else
-                {
-                    hipLaunchKernelGGL((k_resample_strip<false, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-                }
-            }
-            else if (rs.pairNext && rs.tiling.rows > 0 && !resampleGenericOnly() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar)
-            {
-                // (with the scales on their own streams the next scale's chain would need one more event: the pair is for the one-stream order)
-                pairDone[k + 1] = 1;
-                const ResampleTiling& tl = rs.tiling;
-                const size_t ldsMarch = (2 * size_t(rs.pairCols) + tl.xo) * rs.pairRows * 4;
-                const int ntX = cdiv(hd.wb, tl.xo), rowJobs = cdiv(hd.hb, RT_YO) * hd.nplanes;
-                const int nSplit = std::max(1, std::min(ntX / 4, cdiv(2048, rowJobs * nF)));
-                MarchPair mp{ c->real[k + 1].descIndex, rs.pairTileY, rs.pairTileX };
-                if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_march2), ldsMarch)))
-                {
-                    return rc;
-                }
-                hipLaunchKernelGGL(k_resample_march2, dim3(rowJobs * nSplit, 1, nF), dim3(256), ldsMarch, c->stream, cur, rs.img, c->real[k + 1].img,
-                    (const ResampleDesc*)c->d_descs, rs.descIndex, mp, (const int32_t*)c->d_it, (const float*)c->d_ft, rs.pairRows, rs.pairCols, tl.xo,
-                    tl.tile_y, tl.tile_x, nSplit);
+                launchStrip(c, pair ? rs.stripPair : rs.strip, c->d_descs, rs.descIndex, pair ? c->real[k + 1].descIndex : -1, hd.nplanes, cur, rs.img,
+                    pair ? c->real[k + 1].img : nullptr, c->d_it, c->d_ft, nF);
             }
             else if (exactHalf)
             {
                 const int64_t items = int64_t(hd.hb / 2) * hd.wb * hd.nplanes;
                 hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
                     (const ResampleDesc*)(c->d_descs + rs.descIndex));
-            }
-            else if (rs.tiling.rows > 0 && !resampleGenericOnly())
-            {
-                const ResampleTiling& tl = rs.tiling;
-                const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
-                const size_t ldsMarch = (2 * size_t(tl.cols) + tl.xo) * tl.rows * 4;
-                static const bool noMarch = getenv("ACF_HIP_RESAMPLE_NO_MARCH") != nullptr; // A/B: one workgroup per tile
-                const int ntX = cdiv(hd.wb, tl.xo), rowJobs = cdiv(hd.hb, RT_YO) * hd.nplanes;
-                if (!noMarch && ldsMarch <= size_t(80) * 1024 && ntX >= 4)
-                {
-                    // a workgroup marches over the column tiles of its (plane, row tile): the next tile's fill in flight during
-                    // the current tile's passes; column segments so that a small batch still spreads over the machine
-                    const int nSplit = std::max(1, std::min(ntX / 4, cdiv(2048, rowJobs * nF)));
-                    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_march), ldsMarch)))
-                    {
-                        return rc;
-                    }
-                    hipLaunchKernelGGL(k_resample_march, dim3(rowJobs * nSplit, 1, nF), dim3(256), ldsMarch, c->stream, cur, rs.img,
-                        (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y,
-                        tl.tile_x, nSplit);
-                }
-                else
-                {
-                    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes)))
-                    {
-                        return rc;
-                    }
-                    const int nb = cdiv(hd.hb, RT_YO) * cdiv(hd.wb, tl.xo) * hd.nplanes;
-                    hipLaunchKernelGGL(k_resample_tile, dim3(nb, 1, nF), dim3(256), ldsBytes, c->stream, cur, rs.img,
-                        (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
-                }
             }
             else if (resampleUpOk(hd) && !resampleGenericOnly() && (uintptr_t(rs.img) & 15) == 0)
             {
@@ -4603,25 +4465,11 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             return rc;
         }
         prof(c, "k_cascade_tile");
-        static const bool occ8 = getenv("ACF_HIP_TILE_OCC8") != nullptr;
 #define TILE2_LAUNCH(N, CT)                                                                           \
-    if (gt.pooled)                                                                                    \
     {                                                                                                 \
         if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<N, CT>), lds)))          \
             return rc;                                                                                \
         hipLaunchKernelGGL((k_cascade_tile3<N, CT>), grid, block, lds, c->stream, at);                \
-    }                                                                                                 \
-    else if (occ8 && N == 8)                                                                          \
-    {                                                                                                 \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<8, CT, 8>), lds)))       \
-            return rc;                                                                                \
-        hipLaunchKernelGGL((k_cascade_tile2<8, CT, 8>), grid, block, lds, c->stream, at);             \
-    }                                                                                                 \
-    else                                                                                              \
-    {                                                                                                 \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile2<N, CT>), lds)))          \
-            return rc;                                                                                \
-        hipLaunchKernelGGL((k_cascade_tile2<N, CT>), grid, block, lds, c->stream, at);                \
     }
 #define TILE3_LAUNCH16(CT)                                                                        \
     if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<16, CT>), lds)))             \
@@ -6534,25 +6382,20 @@ int acf_hip_op_im_resample(acf_hip_ctx* c, const float* in, float* out, int ha, 
     Scratch s;
     float* di = s.upload(in, size_t(d) * ha * wa);
     float* dout = s.alloc<float>(size_t(d) * hb * wb);
+    dd.src_frame_stride = int64_t(d) * ha * wa;
+    dd.dst_frame_stride = int64_t(d) * hb * wb;
+    const StripPlan sp = stripPlan(dd, nullptr, arena); // appends its tile ranges to the int arena
     ResampleDesc* ddesc = s.upload(&dd, 1);
-    const ResampleTiling tl = resampleTilePlan(dd, arena); // appends its tile ranges to the int arena
     int32_t* dit = s.upload(arena.ints.data(), arena.ints.size());
     float* dft = s.upload(arena.floats.data(), arena.floats.size());
     if (!di || !dout || !ddesc || !dit || !dft)
     {
         return fail(c, ACF_HIP_E_HIP, "op_im_resample: allocation");
     }
-    if (tl.rows > 0 && !resampleGenericOnly())
+    if (sp.ok && !resampleGenericOnly() && (rc = ensureConstTables(c)) == 0)
     {
-        // the LDS-tiled kernel the pyramid uses for its down-sampled real scales
-        const size_t ldsBytes = (size_t(tl.cols) + tl.xo) * tl.rows * 4;
-        int rc2 = allowLds(c, reinterpret_cast<const void*>(&k_resample_tile), ldsBytes);
-        if (rc2)
-        {
-            return rc2;
-        }
-        hipLaunchKernelGGL(k_resample_tile, dim3(cdiv(hb, RT_YO) * cdiv(wb, tl.xo) * d, 1, 1), dim3(256), ldsBytes, c->stream, (const float*)di, dout,
-            (const ResampleDesc*)ddesc, (const int32_t*)dit, (const float*)dft, tl.rows, tl.cols, tl.xo, tl.tile_y, tl.tile_x);
+        // the strip march the pyramid uses for its down-sampled real scales
+        launchStrip(c, sp, ddesc, 0, -1, d, di, dout, nullptr, dit, dft, 1);
     }
     else if (resampleUpOk(dd) && !resampleGenericOnly())
     {

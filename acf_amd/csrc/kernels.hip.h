@@ -1655,141 +1655,14 @@ __global__ void __launch_bounds__(64) k_tri_y(const float* __restrict__ Ui, floa
     }
 }
 
-// convTriY for radius 5 (the normalisation radius every model uses), h % 4 == 0,
-// h >= 48: streaming version.  One LANE owns one image column and walks down
-// it; the 64 lanes of a wave own 64 adjacent columns.  A lane reads its
-// column as aligned float4 groups (each lane a different 128-byte line, eight
-// groups per line) into a 16-slot register ring that holds rows j-8 .. j+7:
-// step j needs rows j-7 (a), j-1 (c) and j+5 (b), so with the loop unrolled 16x
-// every ring index is static and each input is read from memory exactly once.
-// Loads for the next 16 rows are issued one iteration ahead.  No LDS, no
-// barriers, one wave per block: thousands of independent waves hide the HBM
-// latency, and the recurrence itself (2 dependent adds per row) is exactly the
-// reference's u += t += a + b - 2c.
-__global__ void __launch_bounds__(64) k_tri_y5(const float* __restrict__ Ui, float* __restrict__ So, int h, int w, int64_t fs)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= w)
-    {
-        return;
-    }
-    const float* __restrict__ col = Ui + int64_t(blockIdx.z) * fs + int64_t(x) * h;
-    float* __restrict__ out = So + int64_t(blockIdx.z) * fs + int64_t(x) * h;
-    const float4* __restrict__ col4 = reinterpret_cast<const float4*>(col);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(out);
-    constexpr int r = 6, r0 = 5, r1 = 7, h0 = 7;
-    const int r2 = 2 * h - r, h1 = h - r + 1;
-    float t, u;
-    // rows 0..15: the reference's head (reflected taps), straight from memory
-    u = t = col[0];
-#pragma unroll
-    for (int q = 1; q < r; q++)
-    {
-        t += col[q];
-        u += t;
-    }
-    u = 2 * u - t;
-    t = 0;
-    float o[4];
-    o[0] = u;
-#pragma unroll
-    for (int j = 1; j < 16; j++)
-    {
-        const float a = (j < h0) ? col[r - j] : col[j - r1];
-        const float b = col[r0 + j];
-        t += a + b - 2 * col[j - 1];
-        u += t;
-        o[j & 3] = u;
-        if ((j & 3) == 3)
-        {
-            out4[j >> 2] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    // ring: slot (row & 15); holds rows J-8 .. J+7 at the top of an iteration
-    float ring[16];
-    {
-        const float4 g0 = col4[2], g1 = col4[3], g2 = col4[4], g3 = col4[5]; // rows 8..23
-        ring[8] = g0.x, ring[9] = g0.y, ring[10] = g0.z, ring[11] = g0.w;
-        ring[12] = g1.x, ring[13] = g1.y, ring[14] = g1.z, ring[15] = g1.w;
-        ring[0] = g2.x, ring[1] = g2.y, ring[2] = g2.z, ring[3] = g2.w;
-        ring[4] = g3.x, ring[5] = g3.y, ring[6] = g3.z, ring[7] = g3.w;
-    }
-    int J = 16;
-    // groups for rows J+8 .. J+23 of the current iteration
-    float4 nx[4];
-    const int lastFast = h - 24; // J + 23 <= h - 1 and every j <= J + 15 < h1
-    if (J <= lastFast)
-    {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            nx[q] = col4[(J + 8) / 4 + q];
-        }
-    }
-    for (; J <= lastFast; J += 16)
-    {
-        float4 nn[4];
-        const bool more = J + 16 <= lastFast;
-        if (more)
-        {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-            {
-                nn[q] = col4[(J + 24) / 4 + q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            float ov[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-            {
-                const int jj = 4 * q + s; // j = J + jj, J % 16 == 0
-                if (s == 3)
-                {
-                    // rows J+8+4q .. J+11+4q replace rows J-8+4q .. J-5+4q (last used as `a` one step ago)
-                    ring[(8 + 4 * q) & 15] = nx[q].x;
-                    ring[(9 + 4 * q) & 15] = nx[q].y;
-                    ring[(10 + 4 * q) & 15] = nx[q].z;
-                    ring[(11 + 4 * q) & 15] = nx[q].w;
-                }
-                const float a = ring[(jj - 7) & 15];
-                const float b = ring[(jj + 5) & 15];
-                const float cc = ring[(jj - 1) & 15];
-                t += a + b - 2 * cc;
-                u += t;
-                ov[s] = u;
-            }
-            out4[(J >> 2) + q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-        }
-        if (more)
-        {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-            {
-                nx[q] = nn[q];
-            }
-        }
-    }
-    // remaining rows (the reflected tail), from memory
-    for (int j = J; j < h; j++)
-    {
-        const float a = col[j - r1];
-        const float b = (j < h1) ? col[r0 + j] : col[r2 - j];
-        t += a + b - 2 * col[j - 1];
-        u += t;
-        out[j] = u;
-    }
-}
-
-// k_tri_y5 with its global accesses staged through LDS.  With a lane per column every float4 load of k_tri_y5 touches
-// 64 different 128-byte lines, 8 KB of lines per wave; with ~28 waves per CU they do not survive in the L1 between the
+// convTriY for radius 5 (the normalisation radius every model uses; toolbox/convConst.cpp:269-344: the second-order running
+// sums u += t += I[j - r1] + I[r2 - j] - 2 * I[j - 1] down a column, reflected taps at both ends), h % 4 == 0, h >= 48: one lane
+// owns one image column and walks down it, its last 16 rows in a register ring; global accesses are staged through LDS.  With
+// a lane per column a float4 load straight from memory (round 1's k_tri_y5, deleted in round 5) touches 64 different 128-byte lines, 8 KB of lines per wave; with ~28 waves per CU they do not survive in the L1 between the
 // eight loads that use them, so each 16-byte access re-fetched its line from L2 (PMC: 2x the algorithmic HBM traffic,
 // L2->L1 traffic ~8x).  Here a wave (64 adjacent columns) moves 16 rows at a time with lanes along image-y — 4 columns
 // x 64 contiguous bytes per instruction — through a [64 columns][20 floats] LDS buffer, and each lane then takes its
-// own column's 16 rows as four ds_read_b128 (20-float pitch: conflict-free).  Outputs go back the same way.  The
-// recurrence, the ring and every value are those of k_tri_y5.
+// own column's 16 rows as four ds_read_b128 (20-float pitch: conflict-free).  Outputs go back the same way.
 constexpr int TY_PITCH = 20;
 __global__ void __launch_bounds__(256) k_tri_y5s(const float* __restrict__ Ui, float* __restrict__ So, int h, int w, int64_t fs)
 {
@@ -3809,17 +3682,14 @@ __global__ void __launch_bounds__(256) k_ldcf_conv(const float* __restrict__ pyr
 }
 
 // ------------------------------------------------------------------------
-// imResample for the down-sampling real scales of the image pyramid (chnsPyramid.cpp:310): a workgroup produces a
-// 64-row x `xo`-column output tile from a source tile staged once in LDS — x pass for every source row of the tile
-// into a second LDS buffer, then the y pass — instead of re-reading JX*NY taps per output through the L1 (the
-// generic k_resample: ~1 TB/s on the 960x540 -> 484x272 and -> 240x136 resamples).  Arithmetic and association order
-// are rs_C's and k_resample's (x pass then y pass), so results are bit-identical.  Modes: x and y each DOWN or EXACT.
+// imResample on a source tile staged in LDS (k_ldcf_tile's halving of the filtered level; the image pyramid's down-sampled
+// real scales take k_resample_strip below): x pass for every source row of the tile into a second LDS buffer, then the y pass.
+// Arithmetic and association order are rs_C's and k_resample's (x pass then y pass), so results are bit-identical.
 // ------------------------------------------------------------------------
 constexpr int RT_YO = 64;
 
-// The two passes of k_resample_tile on a source tile already in LDS (T: [nCols][nRows], source rows rowLo.. / columns colLo..;
-// C: [xo][nRows] x-pass buffer).  Shared with k_ldcf_tile, whose source tile is the 5x5-filtered level.  Must be called by
-// every thread of the (256-thread) workgroup; lanes without an output row return after the x pass.
+// A lane's y taps for the two passes on a source tile in LDS (T: [nCols][nRows], source rows rowLo.. / columns colLo..;
+// C: [xo][nRows] x-pass buffer).
 struct RtTaps
 {
     int ya, q0, q1, ny;
@@ -3860,117 +3730,10 @@ __device__ __forceinline__ RtTaps rt_taps(const ResampleDesc& d, const int32_t* 
     return t;
 }
 
-__device__ __forceinline__ void rt_passes(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const float* T, float* C,
-    float* __restrict__ B, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int colLo, int nRows, float r, float rk,
-    const int32_t* xrecTile = nullptr) // optional: the tile's column records {8 ints per output column from xb0 on} already in LDS
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ha = d.ha, hb = d.hb;
-    const int xmode = d.xmode, ymode = d.ymode;
-    const int ya = tp.ya, q0 = tp.q0, q1 = tp.q1, ny = tp.ny;
-    const bool act = tp.act, ySlow = tp.ySlow;
-    const float wy[4] = { tp.wy[0], tp.wy[1], tp.wy[2], tp.wy[3] };
-    // x pass (rs_C): a wave per output column, lanes along the source rows
-    const int32_t* xrec = xrecTile ? xrecTile - 8 * xb0 : it + d.x_col;
-    const int nXo = xb1 - xb0;
-    for (int c = wv; c < nXo; c += 4)
-    {
-        const int32_t* rec = xrec + 8 * (xb0 + c);
-        const int xa = rec[0], m = rec[1];
-        const float w0 = __int_as_float(rec[4]), w1 = __int_as_float(rec[5]), w2 = __int_as_float(rec[6]), w3 = __int_as_float(rec[7]);
-        const int wofs = rec[2];
-        const float* Tc = T + (xa - colLo) * nRows;
-        for (int rr = lane; rr < nRows; rr += 64)
-        {
-            const float* T0 = Tc + rr;
-            float s;
-            if (xmode == RS_EXACT)
-            {
-                s = T0[0] + T0[nRows];
-                if (m > 2)
-                {
-                    s = s + T0[2 * nRows];
-                }
-                if (m > 3)
-                {
-                    s = s + T0[3 * nRows];
-                }
-            }
-            else
-            {
-                s = T0[0] * w0;
-                if (m > 1)
-                {
-                    s = s + T0[nRows] * w1;
-                }
-                if (m > 2)
-                {
-                    s = s + T0[2 * nRows] * w2;
-                }
-                if (m > 3)
-                {
-                    s = s + T0[3 * nRows] * w3;
-                }
-                for (int j = 4; j < m; j++)
-                {
-                    s = s + T0[j * nRows] * ft[wofs + j];
-                }
-            }
-            C[c * nRows + rr] = (rowLo + rr >= ha) ? 0.f : s; // C[ha .. ha+3] = 0 (imResampleMex.cpp:133-137)
-        }
-    }
-    __syncthreads();
-    // y pass: lane = output row, a wave per output column
-    if (!act)
-    {
-        return;
-    }
-    for (int c = wv; c < nXo; c += 4)
-    {
-        const float* Cc = C + c * nRows - rowLo;
-        float v;
-        if (ymode == RS_EXACT)
-        {
-            float sacc = Cc[ya] + Cc[ya + 1];
-            if (ny > 2)
-            {
-                sacc = sacc + Cc[ya + 2];
-            }
-            if (ny > 3)
-            {
-                sacc = sacc + Cc[ya + 3];
-            }
-            v = sacc * rk;
-        }
-        else if (!ySlow)
-        {
-            v = Cc[ya] * wy[0];
-            v = v + Cc[ya + 1] * wy[1];
-            if (ny > 2)
-            {
-                v = v + Cc[ya + 2] * wy[2];
-            }
-            if (ny > 3)
-            {
-                v = v + Cc[ya + 3] * wy[3];
-            }
-        }
-        else
-        {
-            v = 0.f;
-            for (int q = q0; q < q1; q++)
-            {
-                v = v + Cc[it[d.y_src + q]] * (ft[d.y_wt + q] * r);
-            }
-        }
-        B[int64_t(xb0 + c) * hb + yb] = v;
-    }
-}
-
-// rt_passes for tiles of at most 16 output columns (k_ldcf_tile), arranged for memory-level parallelism: a wave's four columns
+// The two passes on a source tile in LDS, for tiles of at most 16 output columns (k_ldcf_tile), arranged for memory-level parallelism: a wave's four columns
 // are in flight together and every tap read is unconditional (a tap beyond m / ny is read from wherever the index lands inside
-// the workgroup's LDS and dropped by a select), where rt_passes' branches serialised one LDS round trip per tap.  Same products,
-// same sums in the same order: bit-identical to rt_passes.  xrecTile: the tile's column records, in LDS.
+// the workgroup's LDS and dropped by a select).  Products and sums in rs_C's / k_resample's order (x pass then y pass, taps ascending).
+// xrecTile: the tile's column records, in LDS.
 __device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const float* T, float* C,
     float* __restrict__ B, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int colLo, int nRows, float r, float rk, const int32_t* xrecTile)
 {
@@ -4102,244 +3865,12 @@ __device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t
 }
 
 
-// tile_y / tile_x (int arena, written by resampleTilePlan on the host): per output-row tile {rowLo, rowHi}, per
-// output-column tile {colLo, colHi}; xo = output columns per tile.
-__global__ void __launch_bounds__(256) k_resample_tile(const float* __restrict__ src, float* __restrict__ dst,
-    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
-    int tile_y, int tile_x)
-{
-    extern __shared__ float rt_lds[];
-    const ResampleDesc& d = descs[blockIdx.y];
-    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
-    const int ntY = (hb + RT_YO - 1) / RT_YO;
-    const int ntX = (wb + xo - 1) / xo;
-    int t = blockIdx.x;
-    const int ytile = t % ntY;
-    t /= ntY;
-    const int xtile = t % ntX;
-    const int z = t / ntX;
-    if (z >= d.nplanes)
-    {
-        return;
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
-    const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
-    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
-    const float r = d.r[ty], rk = d.rk[ty];
-    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
-    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
-    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
-    const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
-    const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
-    float* T = rt_lds;                             // [nCols][nRows] source tile
-    float* C = rt_lds + size_t(maxCols) * maxRows; // [xo][nRows] x-pass columns
-    // this lane's y taps (global table reads: issued before the tile load so their latency overlaps it)
-    const int yb = yb0 + lane;
-    const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
-    // source tile: a wave per source column, lanes along the rows (coalesced), straight into LDS by LDS-DMA so that the
-    // whole tile is in flight at once (a load -> ds_write loop exposed one memory round trip per 64 floats).  Rows
-    // >= ha hold clamped duplicates: the x pass zeroes those rows itself.
-    for (int cc = wv; cc < nCols; cc += 4)
-    {
-        const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
-        for (int r0 = 0; r0 < nRows; r0 += 64)
-        {
-            if (r0 + lane < nRows)
-            {
-                __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    rt_passes(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk);
-}
-
-// k_resample_tile with the column tiles of one (plane, row tile, frame) taken IN SEQUENCE by one workgroup, the next
-// tile's source columns requested (LDS-DMA into the other of two tile buffers) before the current tile's two passes run.
-// A tile of k_resample_tile is ~500 outputs for 256 threads: the 960 x 540 -> 484 x 272 / 240 x 136 resamples of a 1080p
-// batch were 88 k / 26 k workgroups per launch, each one fill latency + two barriers long, at 1.4 TB/s (round 3:
-// 310 + 247 us per 96 frames, and nothing else runs beside them: every wave slot of the machine holds one of their
-// short-lived waves).  blockIdx.x = (plane, row tile) x column segment (nSplit segments of the column tiles, so that small
-// batches still fill the machine).  Same passes (rt_passes), same tables: bit-identical.
-__global__ void __launch_bounds__(256) k_resample_march(const float* __restrict__ src, float* __restrict__ dst,
-    const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols, int xo,
-    int tile_y, int tile_x, int nSplit)
-{
-    extern __shared__ float rt_lds[];
-    const ResampleDesc& d = descs[blockIdx.y];
-    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
-    const int ntY = (hb + RT_YO - 1) / RT_YO;
-    const int ntX = (wb + xo - 1) / xo;
-    int t = blockIdx.x;
-    const int part = t % nSplit;
-    t /= nSplit;
-    const int ytile = t % ntY;
-    const int z = t / ntY;
-    if (z >= d.nplanes)
-    {
-        return;
-    }
-    const int perPart = (ntX + nSplit - 1) / nSplit;
-    const int xt0 = part * perPart, xt1 = min(xt0 + perPart, ntX);
-    if (xt0 >= xt1)
-    {
-        return;
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
-    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
-    const float r = d.r[ty], rk = d.rk[ty];
-    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
-    float* __restrict__ B = dst + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
-    const int rowLo = it[tile_y + 2 * ytile], rowHi = it[tile_y + 2 * ytile + 1];
-    const int nRows = min(rowHi - rowLo + 1, maxRows);
-    float* const Tb[2] = { rt_lds, rt_lds + size_t(maxCols) * maxRows }; // two source tiles [nCols][nRows]
-    float* C = rt_lds + 2 * size_t(maxCols) * maxRows;                    // [xo][nRows] x-pass columns
-    const int yb = yb0 + lane;
-    const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
-    // this lane's source rows of a column (clamped: rows >= ha are zeroed by the x pass)
-    const int nR64 = (nRows + 63) >> 6;
-    auto fill = [&](int xtile, float* T) {
-        const int colLo = it[tile_x + 2 * xtile], colHi = it[tile_x + 2 * xtile + 1];
-        const int nCols = min(colHi - colLo + 1, maxCols);
-        for (int cc = wv; cc < nCols; cc += 4)
-        {
-            const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
-            for (int k = 0; k < nR64; k++)
-            {
-                const int r0 = 64 * k;
-                if (r0 + lane < nRows)
-                {
-                    __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
-                }
-            }
-        }
-    };
-    fill(xt0, Tb[0]);
-    for (int xtile = xt0; xtile < xt1; xtile++)
-    {
-        // tile `xtile` has arrived (and the stores of the previous tile have left); every wave is past the previous tile's
-        // y pass: the other tile buffer (read by the previous x pass) and C may be written again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = (xtile - xt0) & 1;
-        if (xtile + 1 < xt1)
-        {
-            fill(xtile + 1, Tb[cur ^ 1]);
-        }
-        const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
-        const int colLo = it[tile_x + 2 * xtile];
-        rt_passes(d, it, ft, Tb[cur], C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk);
-    }
-}
-
-// k_resample_march for TWO outputs of one source: the two small real scales of a pyramid are both resampled from the half-size
-// smoothed image (chnsPyramid.cpp:313-316: I = I1 once, at s = .5), the second about half the first in both axes.  A workgroup
-// marches over the column tiles of output A's (plane, row tile) and, from the SAME source tile in LDS, also produces output B's
-// tile of half as many rows and columns (its own tables; the tile loaded is the union of the two source ranges), so the source is
-// read once (4.8 MB per 1080p frame less, one launch less).  Passes and tables are rt_passes' for each output: bit-identical.
-struct MarchPair
-{
-    int32_t descB;            // B's descriptor index
-    int32_t tile_yB, tile_xB; // B's tile tables: row tiles of RT_YO / 2 rows, column tiles of xo / 2 columns
-};
-__global__ void __launch_bounds__(256) k_resample_march2(const float* __restrict__ src, float* __restrict__ dstA, float* __restrict__ dstB,
-    const ResampleDesc* __restrict__ descs, int descA, MarchPair pb, const int32_t* __restrict__ it, const float* __restrict__ ft, int maxRows, int maxCols,
-    int xo, int tile_y, int tile_x, int nSplit)
-{
-    extern __shared__ float rt_lds[];
-    const ResampleDesc& d = descs[descA];
-    const ResampleDesc& e = descs[pb.descB];
-    const int ha = d.ha, hb = d.hb, wa = d.wa, wb = d.wb;
-    const int ntY = (hb + RT_YO - 1) / RT_YO;
-    const int ntX = (wb + xo - 1) / xo;
-    const int xoB = xo / 2, ntXB = (e.wb + xoB - 1) / xoB, ntYB = (e.hb + RT_YO / 2 - 1) / (RT_YO / 2);
-    int t = blockIdx.x;
-    const int part = t % nSplit;
-    t /= nSplit;
-    const int ytile = t % ntY;
-    const int z = t / ntY;
-    if (z >= d.nplanes)
-    {
-        return;
-    }
-    const int perPart = (ntX + nSplit - 1) / nSplit;
-    const int xt0 = part * perPart, xt1 = min(xt0 + perPart, ntX);
-    if (xt0 >= xt1)
-    {
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int yb0 = ytile * RT_YO, yb1 = min(yb0 + RT_YO, hb);
-    const bool haveBy = ytile < ntYB;
-    const int ybB0 = ytile * (RT_YO / 2), ybB1 = haveBy ? min(ybB0 + RT_YO / 2, e.hb) : ybB0;
-    const int ty = z < d.c1 ? 0 : (z < d.c2 ? 1 : 2);
-    const float r = d.r[ty], rk = d.rk[ty], rB = e.r[ty], rkB = e.rk[ty];
-    const float* __restrict__ A = src + int64_t(blockIdx.z) * d.src_frame_stride + d.src_off + int64_t(z) * ha * wa;
-    float* __restrict__ BA = dstA + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(z) * hb * wb;
-    float* __restrict__ BB = dstB + int64_t(blockIdx.z) * e.dst_frame_stride + e.dst_off + int64_t(z) * e.hb * e.wb;
-    const int rowLoA = it[tile_y + 2 * ytile], rowHiA = it[tile_y + 2 * ytile + 1];
-    const int rowLoB = haveBy ? it[pb.tile_yB + 2 * ytile] : rowLoA, rowHiB = haveBy ? it[pb.tile_yB + 2 * ytile + 1] : rowHiA;
-    const int rowLo = min(rowLoA, rowLoB);
-    const int nRows = min(max(rowHiA, rowHiB) - rowLo + 1, maxRows);
-    float* const Tb[2] = { rt_lds, rt_lds + size_t(maxCols) * maxRows };
-    float* C = rt_lds + 2 * size_t(maxCols) * maxRows;
-    const RtTaps tpA = rt_taps(d, it, ft, yb0 + lane, yb1, r);
-    const RtTaps tpB = rt_taps(e, it, ft, haveBy ? ybB0 + lane : 0, haveBy ? ybB1 : 1, rB); // (no B tile here: its taps are never used)
-    const int nR64 = (nRows + 63) >> 6;
-    auto range = [&](int xtile, int& colLo, int& nCols) {
-        const int loA = it[tile_x + 2 * xtile], hiA = it[tile_x + 2 * xtile + 1];
-        const bool hb_ = xtile < ntXB;
-        const int loB = hb_ ? it[pb.tile_xB + 2 * xtile] : loA, hiB = hb_ ? it[pb.tile_xB + 2 * xtile + 1] : hiA;
-        colLo = min(loA, loB);
-        nCols = min(max(hiA, hiB) - colLo + 1, maxCols);
-    };
-    auto fill = [&](int xtile, float* T) {
-        int colLo, nCols;
-        range(xtile, colLo, nCols);
-        for (int cc = wv; cc < nCols; cc += 4)
-        {
-            const float* __restrict__ Ac = A + int64_t(min(colLo + cc, wa - 1)) * ha;
-            for (int k = 0; k < nR64; k++)
-            {
-                const int r0 = 64 * k;
-                if (r0 + lane < nRows)
-                {
-                    __builtin_amdgcn_global_load_lds((gptr_t)(Ac + min(rowLo + r0 + lane, ha - 1)), (lptr_t)(T + cc * nRows + r0), 4, 0, 0);
-                }
-            }
-        }
-    };
-    fill(xt0, Tb[0]);
-    for (int xtile = xt0; xtile < xt1; xtile++)
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = (xtile - xt0) & 1;
-        if (xtile + 1 < xt1)
-        {
-            fill(xtile + 1, Tb[cur ^ 1]);
-        }
-        int colLo, nCols;
-        range(xtile, colLo, nCols);
-        const int xb0 = xtile * xo, xb1 = min(xb0 + xo, wb);
-        rt_passes(d, it, ft, Tb[cur], C, BA, tpA, yb0 + lane, xb0, xb1, rowLo, colLo, nRows, r, rk);
-        if (haveBy && xtile < ntXB) // (workgroup-uniform)
-        {
-            __syncthreads(); // A's y pass has read C
-            const int xB0 = xtile * xoB, xB1 = min(xB0 + xoB, e.wb);
-            rt_passes(e, it, ft, Tb[cur], C, BB, tpB, ybB0 + lane, xB0, xB1, rowLo, colLo, nRows, rB, rkB);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------
 // k_resample_strip: the down-sampling image resamples (chnsPyramid.cpp:310) as a march over STRIPS of output columns.
-// k_resample_march2 spent its time in a tile's dependent round trips (53 scalar loads, 135 branches, 1650 wave instructions per
-// 8 x 64-output tile: 0.58 ms per 96 1080p frames for 8 MB per frame, 12 % of what the bytes need).  Here a workgroup takes a
+// Rounds 3-4 had a workgroup per 8 x 64-output tile (k_resample_tile, then a march over a row tile's column tiles with the next
+// fill in flight, k_resample_march / _march2: deleted in round 5); it spent its time in a tile's dependent round trips (53 scalar
+// loads, 135 branches, 1650 wave instructions per tile: 0.58 ms per 96 1080p frames for 8 MB per frame, 12 % of what the bytes
+// need).  Here a workgroup takes a
 // row tile of up to ~140 output rows (the whole source height of the tile: ~280 rows, one LDS column of `rowsP` floats) of one
 // plane and walks its output columns RS_XO = 4 at a time (half as many of output B when the next real scale comes from the
 // same source):
@@ -4348,7 +3879,7 @@ __global__ void __launch_bounds__(256) k_resample_march2(const float* __restrict
 //     source rows, every tap read issued before the first product; B's columns on wave pairs;
 //   * y pass: (column, row) items dealt to the 256 threads once (a thread's rows — hence its taps — are the same in every step:
 //     looked up before the march), one barrier between the passes, no table read inside the march.
-// The products and sums are rt_passes' (= rs_C's and k_resample's: x pass then y pass, taps ascending), bit for bit.
+// The products and sums are rs_C's and k_resample's (x pass then y pass, taps ascending), bit for bit.
 // ------------------------------------------------------------------------
 constexpr int RS_XO = 4;     // output columns of A per step (B: RS_XO / 2)
 constexpr int RS_NT = 256;   // threads per workgroup
@@ -4393,7 +3924,7 @@ struct StripItem
 };
 
 // x pass of one output column for the NK row chunks k0, k0 + kStep, ... of the source tile T ([cols][rowsP], first column colLo)
-// into the LDS column Cc (pitch RS_CP): rt_passes' products and sums, straight-line — every tap read issued before the first
+// into the LDS column Cc (pitch RS_CP): rs_C's products and sums, straight-line — every tap read issued before the first
 // product; a tap beyond m reads the last real tap's column and is dropped by a select; the exact form (sums of k columns,
 // imResampleMex.cpp:198-215) is the weighted form with weights 1: t * 1.f == t for every t, so the sums are the same floats.
 template <int NK>
@@ -4698,7 +4229,7 @@ __global__ void __launch_bounds__(RS_NT) k_resample_strip(StripArgs a)
 // LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
 // tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
 //   C_f = conv2(plane, filter_f, 'same')  (zero padded, taps in k_ldcf_conv's order: dx then dy ascending)
-//   out_f = imResample(C_f, .5)           (k_resample_tile's x pass / y pass: rt_passes)
+//   out_f = imResample(C_f, .5)           (the x pass / y pass on a tile in LDS: rt_passes16)
 // The plane tile (+2 cells of halo, zeros outside the plane) is read once into LDS, each filter's conv result is
 // written to the LDS source tile of the resample and never reaches HBM: the separate k_ldcf_conv + k_resample pair
 // wrote and re-read k full-resolution copies of the pyramid (760 MB per 4K frame at k = 4).  A job is one output tile of
@@ -5468,7 +4999,7 @@ __global__ void __launch_bounds__(256) k_tail_scanD(CascArgs a)
 //            conflict-free), node records through the scalar unit;
 //   sparse stages [b1,b2) [b2,b3) [b3,b4): items = survivors x trees, the score accumulated in tree order by a DPP chain;
 //   stage E  the leaf codes of every remaining tree for the windows that reach the tail (k_tail_scan adds them up).
-//   (k_cascade_tile2 below; round 1's k_cascade_tile, one lane per window in every stage, is gone.)
+//   (k_cascade_tile3 below.)
 //
 // Scores are those of ParallelDetectionBody::evaluate (acfDetect1.cpp:123-138):
 // every window adds the same leaves in the same order and stops at the first
@@ -5542,14 +5073,14 @@ struct TileArgs
 {
     const float* pyr;
     int64_t pyr_fs;
-    const uint16_t* pyrR; // threshold-rank cells (host_plan.h): what k_cascade_tile2<NW, CellRank> reads instead of `pyr`
+    const uint16_t* pyrR; // threshold-rank cells (host_plan.h): what the tile kernels reads instead of `pyr`
     int64_t pyrR_fs;
     const CascLevel* levels;
     const CascTile* tiles;
     int32_t nTiles, nFrames, nChns, mH, mW, nTrees;
     TileGeom g;
     const TreeNode* tileNodes;   // tile-layout offsets of every tree
-    const uint32_t* tileNodesS;  // k_cascade_tile2 stage A: 10 * aTB dwords per batch of aTB trees {off[aTB][3], thr[aTB][3], hs[aTB][4]}
+    const uint32_t* tileNodesS;  // stage A of the tile kernels: 10 * aTB dwords per batch of aTB trees {off[aTB][3], thr[aTB][3], hs[aTB][4]}
     int32_t aTB;                 // trees per stage-A batch (4 or 8)
     const TreeNode* tailNodes;
     float cascThr;
@@ -5568,7 +5099,7 @@ struct TileArgs
     float* tailScratch;
     int32_t tailPad, tailSlab;
     int32_t tailNodesLds; // the tail's node table fits in LDS next to the footprint slabs (floats reserved at the start of LDS, else 0)
-    // stage E of k_cascade_tile2 / k_tail_scan: leaf codes [frame][codeCap][codePitch] bytes (4 * leaf index of every tail tree of a queued window)
+    // stage E of the tile kernels / k_tail_scan: leaf codes [frame][codeCap][codePitch] bytes (4 * leaf index of every tail tree of a queued window)
     uint8_t* tailCodes;
     int32_t codeCap, codePitch;
 };
@@ -5592,33 +5123,11 @@ struct LaneNode
 #endif
 
 // ------------------------------------------------------------------------
-// k_cascade_tile2: the tile kernel with (i) stage A's node records on the scalar unit, (ii) item-parallel sparse
-// stages and (iii) the tail's leaf codes computed while the tile is still in LDS.
-//
-// What the round-1 kernel (one lane per window in every stage, node table in LDS) spent per 512-window tile, from its own phase stamps: fill 4.5k
-// cycles, stage A (16 trees, every lane) 5.9k, the list stages B+C 9.0k, stage D 2.4k.
-//  * Stage A was bound by LDS bandwidth, and 10 of its 16 LDS cycles per tree and wave were the NODE reads (every
-//    wave re-reads the same 40 bytes per tree as 64-lane broadcasts).  Here a batch of four trees is 160 contiguous
-//    bytes read with s_load (scalar cache, no LDS, no VALU); the next batch's offsets are requested while the current
-//    batch's feature reads are in flight.
-//  * B, C, D walked their trees one lane per surviving window: 2, then 1, then a fraction of a wave doing 16 + 32 + 64
-//    dependent LDS round trips while the other waves of the workgroup (and its 73 KB of LDS) idled.  A leaf does not
-//    depend on the running score, so a stage is now ITEMS = survivors x trees: TL lanes per window (TL = 16, 32, 64
-//    trees), every lane one tree, all leaves of a round in two LDS round trips.  The score is then accumulated in tree
-//    order ACROSS the TL lanes with a DPP chain (lane j takes lane j-1's prefix and adds its own leaf: the additions
-//    and their order are evaluate()'s, acfDetect1.cpp:123-138), and a window survives when every prefix stays above
-//    cascThr.
-//  * With a workgroup barrier around every sparse piece, a tile spent 5.9k cycles in them plus 2.2k waiting for the slowest
-//    wave of stage A.  Every wave now keeps ITS OWN 64 windows from stage A to stage E (private list segments, no barrier,
-//    no LDS atomics), and a wave's columns are interleaved with the other waves' (w, w + NW: survivors come in clusters;
-//    it also makes stage A's reads conflict-free: 8 * rowsP = 32 banks apart).  Measured, not kept: stage A split in two
-//    with a compaction in between (the second half on two waves is a latency chain: slower), a dense form of the pieces
-//    for long lists, two rounds per iteration side by side, an L2 warm-up of a later tile by 4-byte LDS-DMA requests
-//    (+10 %: the fill is not waiting for HBM latency), 16 x 16-window tiles with three workgroups per CU (+50 %).
-//  * The ~930 windows per 1080p frame that outlive tree 128 used to be re-fetched from HBM as 16 KB footprints by the
-//    tail kernel (k_cascade_tail3: 11.5 us per frame; a stand-alone code kernel: 5.5 us, bound by those 80-byte column runs).  Their
-//    features are in this tile already: stage E evaluates every remaining tree for them (lanes = trees, nodes streamed
-//    from L2 once per tile, not per window) and writes one code byte per tree; k_tail_scan finishes them.
+// The cascade on LDS tiles.  Rounds 1-3 kept every wave on its own 64 windows from the dense trees to the sparse pieces
+// (k_cascade_tile, k_cascade_tile2: deleted in round 5; DESIGN.md 3.1b has what was measured on them); what they established and
+// k_cascade_tile3 keeps: stage A's node records through the scalar unit (a batch of four trees is 160 contiguous bytes read with
+// s_load while the batch's feature reads are in flight), sparse stages as ITEMS = survivors x trees with the score accumulated in
+// tree order, and the tail's leaf codes computed while the tile is still in LDS (stage E + k_tail_scan).
 // ------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) uint32_t* cu32p_t;
 
@@ -5642,103 +5151,6 @@ struct CellRank
     static constexpr bool RANK = true;
     static __device__ __forceinline__ val_t thr(uint32_t bits) { return bits; }
 };
-
-// Stage A.  tab: per batch of TB trees 10 * TB dwords {off[TB][3], thr[TB][3], hs[TB][4]} (host: buildCascadeTables).
-// All 3 * TB feature reads of a batch are issued before anything is resolved; the thresholds and leaf values arrive
-// (s_load) while those reads are in flight, and the next batch's offsets while this batch is resolved.
-template <int TB, class CT>
-__device__ __forceinline__ void tile_eval_s(const typename CT::cell_t* win, const uint32_t* __restrict__ tab, int nBatches, float thrC, float& h, bool& alive)
-{
-    typedef typename CT::val_t val_t;
-    cu32p_t p = (cu32p_t)(uintptr_t)tab;
-    uint32_t o[3 * TB];
-#pragma unroll
-    for (int i = 0; i < 3 * TB; i++)
-    {
-        o[i] = p[i];
-    }
-    const unsigned long long execAll = __builtin_amdgcn_read_exec(); // every lane of the wave is here (callers: wave-uniform control flow only)
-    float hMin = __builtin_inff();
-    for (int b = 0; b < nBatches; b++)
-    {
-        val_t f[3 * TB];
-#pragma unroll
-        for (int i = 0; i < 3 * TB; i++)
-        {
-            f[i] = val_t(win[o[i]]);
-        }
-        cu32p_t pb = p + 10 * TB * b;
-        uint32_t th[3 * TB], hv4[4 * TB];
-#pragma unroll
-        for (int i = 0; i < 3 * TB; i++)
-        {
-            th[i] = pb[3 * TB + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4 * TB; i++)
-        {
-            hv4[i] = pb[6 * TB + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 3 * TB; i++)
-        {
-            ACF_PIN_V(f[i]);
-        }
-        cu32p_t pn = p + 10 * TB * min(b + 1, nBatches - 1);
-#pragma unroll
-        for (int i = 0; i < 3 * TB; i++)
-        {
-            o[i] = pn[i];
-        }
-        // Per tree: thresholds are compared straight from SGPRs (one scalar operand per VALU instruction on gfx9), the three
-        // compares produce wave masks, and the leaf is added UNDER EXEC: the four leaf masks (root & left child, root & ~left,
-        // ~root & right, ~(root | right)) partition the wave, so four `v_add_f32 hNew, leaf_k (SGPR), hOld` with EXEC = mask_k
-        // write every lane of hNew exactly once with hOld + its leaf — no v_mov of the leaf values into VGPRs, no v_cndmask
-        // chain, no separate add (8 VALU -> 4; the masks are 4 SALU instructions).  hOld/hNew alternate between two
-        // registers, so that one v_min3 per PAIR of trees keeps the minimum over the prefixes (evaluate()'s early exit:
-        // a window is rejected as soon as one prefix is <= cascThr, acfDetect1.cpp:123-138).  10.5 VALU per tree and window
-        // instead of 15 (three v_cndmask on four v_mov'ed leaves + add + compare): 31.4 -> 30.1 us per frame with batches of 4.
-#pragma unroll
-        for (int g = 0; g < TB; g += 2)
-        {
-            float h1, h2;
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-            {
-                const int t = g + q;
-                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(f[3 * t] < CT::thr(th[3 * t]));
-                const unsigned long long mA = __builtin_amdgcn_ballot_w64(f[3 * t + 1] < CT::thr(th[3 * t + 1]));
-                const unsigned long long mB = __builtin_amdgcn_ballot_w64(f[3 * t + 2] < CT::thr(th[3 * t + 2]));
-                float hOut;
-                const float hIn = q == 0 ? h : h1;
-                asm volatile("s_and_b64 exec, %[m0], %[mA]\n\t"
-                             "v_add_f32 %[o], %[A], %[i]\n\t"
-                             "s_andn2_b64 exec, %[m0], %[mA]\n\t"
-                             "v_add_f32 %[o], %[B], %[i]\n\t"
-                             "s_andn2_b64 exec, %[mB], %[m0]\n\t"
-                             "v_add_f32 %[o], %[C], %[i]\n\t"
-                             "s_nor_b64 exec, %[m0], %[mB]\n\t"
-                             "v_add_f32 %[o], %[D], %[i]\n\t"
-                             "s_mov_b64 exec, %[ex]"
-                             : [o] "=&v"(hOut)
-                             : [i] "v"(hIn), [m0] "s"(m0), [mA] "s"(mA), [mB] "s"(mB), [A] "s"(hv4[4 * t]), [B] "s"(hv4[4 * t + 1]),
-                             [C] "s"(hv4[4 * t + 2]), [D] "s"(hv4[4 * t + 3]), [ex] "s"(execAll)
-                             : "scc");
-                if (q == 0)
-                {
-                    h1 = hOut;
-                }
-                else
-                {
-                    h2 = hOut;
-                }
-            }
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(hMin) : "v"(h1), "v"(h2));
-            h = h2; // a rejected window's score is never read again
-        }
-    }
-    alive = alive && (hMin > thrC);
-}
 
 // one tree at a time through the TreeNode table (stage A trees beyond the last full batch of four)
 template <class CT>
@@ -5765,46 +5177,8 @@ __device__ __forceinline__ void tile_eval_s1(const typename CT::cell_t* win, con
 }
 
 // Survivors of the last tile stage -> hits (model exhausted) or the frame's tail queue; returns the queue slot / hit index
-// of this lane's entry (-1: not emitted).  One global atomic per wave.
-__device__ __forceinline__ int tile_emit2(const TileArgs& a, bool final_, int frame, bool alive, int lvl, int n, int nWinR, float h)
-{
-    const unsigned long long mask = __ballot(alive);
-    if (!mask)
-    {
-        return -1;
-    }
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0)
-    {
-        base = atomicAdd((final_ ? a.counts : a.qcount) + frame, __popcll(mask));
-    }
-    base = __shfl(base, 0);
-    int idx = -1;
-    if (alive)
-    {
-        idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (final_)
-        {
-            if (idx < a.maxHits)
-            {
-                acf_hip_hit hit;
-                hit.scale = lvl;
-                hit.c = n / nWinR;
-                hit.r = n - hit.c * nWinR;
-                hit.score = h;
-                a.hits[int64_t(frame) * a.maxHits + idx] = hit;
-            }
-        }
-        else if (idx < a.qcap)
-        {
-            a.q[int64_t(frame) * a.qcap + idx] = make_uint2((uint32_t(lvl) << 24) | uint32_t(n), __float_as_uint(h));
-        }
-    }
-    return idx;
-}
-
-// tile_emit2 with the destination fields passed one by one (k_cascade_tile3 reads them from the kernarg segment at the call)
+// of this lane's entry (-1: not emitted).  One global atomic per wave.  (The destination fields are passed one by one:
+// k_cascade_tile3 reads them from the kernarg segment at the call.)
 struct EmitDst
 {
     acf_hip_hit* hits;
@@ -5851,14 +5225,6 @@ __device__ __forceinline__ int tile_emit3(const EmitDst& d, bool final_, int fra
     return idx;
 }
 
-struct TileCtx
-{
-    const void* tileF; // the tile's cells (CT::cell_t)
-    int step, rowsP, TR;
-    float thrC;
-    int frame, lvl, r0, c0, nWinR;
-};
-
 template <int N>
 __device__ __forceinline__ float dpp_row_shr(float v) // lane l <- lane l - N of its 16-lane row (0 where there is none)
 {
@@ -5883,394 +5249,13 @@ __device__ __forceinline__ void row_chain(float leaf, float& a, float& m)
 }
 #undef ACF_ROW_STEP
 
-struct SparseNode
-{
-    uint32_t o0, o1, o2;
-    uint32_t t0, t1, t2; // threshold bits (CT::thr)
-    float h0, h1, h2, h3;
-};
-
-// this lane's tree of a sparse stage over [t0, t0 + T) with 2^tlShift lanes per window (clamped: lanes past T are masked)
-__device__ __forceinline__ SparseNode sparse_node(const TreeNode* __restrict__ nodes, int t0, int T, int tlShift)
-{
-    const int pos = int(threadIdx.x & 63) & ((1 << tlShift) - 1);
-    const uint4* np = reinterpret_cast<const uint4*>(nodes + t0 + min(pos, max(T, 1) - 1));
-    const uint4 o = np[0], tq = np[1], hq = np[2];
-    SparseNode n;
-    n.o0 = o.x;
-    n.o1 = o.y;
-    n.o2 = o.z;
-    n.t0 = tq.x;
-    n.t1 = tq.y;
-    n.t2 = tq.z;
-    n.h0 = __uint_as_float(hq.x);
-    n.h1 = __uint_as_float(hq.y);
-    n.h2 = __uint_as_float(hq.z);
-    n.h3 = __uint_as_float(hq.w);
-    return n;
-}
-
-// One sparse piece over trees [t0, t0 + T), T <= 64, for ONE WAVE's own survivors (list: the wave's private segment,
-// compacted in place — a round has read its 64 / TL entries before it writes at most as many at or below them; no
-// barrier, no atomics): TL = 2^tlShift >= T lanes per listed window, every lane one tree.
-// The score is accumulated in tree order by lane 15 of each 16-lane row (row_chain), rows of one window in sequence
-// (row_bcast:15 hands the prefix to the next row).  Lanes past T contribute +0.0f: h is a sum that starts at +0.0f, so
-// it is never -0.0f and h + 0.0f == h bit for bit.  `last`: survivors go to the hit list / tail queue (their
-// {tag, slot} to the list for stage E), else {tag, h}.  Returns the number of entries now in the list.
-template <class CT>
-__device__ __forceinline__ int tile_sparse_wave(const TileArgs& a, const TileCtx& X, uint2* list, int nIn, const SparseNode& nd,
-    int T, int tlShift, bool last, bool lastAll)
-{
-    typedef typename CT::val_t val_t;
-    typedef typename CT::cell_t cell_t;
-    const int lane = threadIdx.x & 63;
-    const int TL = 1 << tlShift, G = 64 >> tlShift, K = TL >> 4;
-    const int pos = lane & (TL - 1), g = lane >> tlShift;
-    const int rowInWin = (lane >> 4) & (K - 1);
-    const bool act = pos < T;
-    // the node in registers, opaquely: otherwise `c ? nd.x : nd.y` becomes a load from a selected address of the struct,
-    // which keeps the struct in scratch memory
-    uint32_t o0 = nd.o0, o1 = nd.o1, o2 = nd.o2;
-    uint32_t t0 = nd.t0, t1 = nd.t1, t2 = nd.t2;
-    float h0 = nd.h0, h1 = nd.h1, h2 = nd.h2, h3 = nd.h3;
-    ACF_PIN_V(o0);
-    ACF_PIN_V(o1);
-    ACF_PIN_V(o2);
-    ACF_PIN_V(t0);
-    ACF_PIN_V(t1);
-    ACF_PIN_V(t2);
-    ACF_PIN_V(h0);
-    ACF_PIN_V(h1);
-    ACF_PIN_V(h2);
-    ACF_PIN_V(h3);
-    int nOut = 0;
-    for (int base = 0; base < nIn; base += G)
-    {
-        const int wi = base + g;
-        const bool valid = wi < nIn;
-        const uint2 e = list[valid ? wi : base];
-        const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
-        const cell_t* win = static_cast<const cell_t*>(X.tileF) + (cl * X.step) * X.rowsP + rl * X.step;
-        const val_t f0 = val_t(win[o0]);
-        const bool lt0 = f0 < CT::thr(t0);
-        const val_t fc = val_t(win[lt0 ? o1 : o2]);
-        const val_t th1 = CT::thr(lt0 ? t1 : t2);
-        const bool lt1 = fc < th1;
-        float leaf = lt0 ? (lt1 ? h0 : h1) : (lt1 ? h2 : h3);
-        leaf = act ? leaf : 0.f;
-        const float hin = __uint_as_float(e.y);
-        float acc = hin, mm = hin;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            if (k < K) // wave-uniform
-            {
-                float sa = k == 0 ? hin : dpp_row_bcast15(acc);
-                float sm = k == 0 ? hin : dpp_row_bcast15(mm);
-                row_chain(leaf, sa, sm);
-                const bool mine = rowInWin == k;
-                acc = mine ? sa : acc;
-                mm = mine ? sm : mm;
-            }
-        }
-        // lane 15 of a window's last row: its final score and the minimum over all its prefixes (evaluate()'s early exit)
-        const bool emitLane = valid && (lane & 15) == 15 && rowInWin == K - 1 && (mm > X.thrC) && (acc > X.thrC);
-        float val = acc;
-        if (last)
-        {
-            const int n = (X.c0 + cl) * X.nWinR + (X.r0 + rl);
-            val = __int_as_float(tile_emit2(a, lastAll, X.frame, emitLane, X.lvl, n, X.nWinR, acc));
-        }
-        const unsigned long long m = __ballot(emitLane);
-        if (emitLane)
-        {
-            list[nOut + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(e.x, __float_as_uint(val));
-        }
-        nOut += __popcll(m);
-    }
-    return nOut;
-}
-
-// OCC: waves per SIMD the register allocation must allow (1: whatever the code needs, currently 7; 8: at most 64 VGPRs —
-// four 8-wave workgroups per CU when their LDS fits four times)
-template <int NW, class CT, int OCC = 1>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC))) k_cascade_tile2(TileArgs a)
-{
-    typedef typename CT::cell_t cell_t;
-    typedef typename CT::val_t val_t;
-    constexpr int CPB = CT::CPB;
-    extern __shared__ float lds[];
-    __shared__ int s_cnt[8];
-    cell_t* tileF = reinterpret_cast<cell_t*>(lds);
-    // (tileFloats counts CELLS; cells * sizeof(cell_t) is a multiple of 16 bytes: rowsP is a multiple of CPB)
-    uint2* listA = reinterpret_cast<uint2*>(reinterpret_cast<char*>(lds) + size_t(a.g.tileFloats) * sizeof(cell_t)); // NW segments of 64 entries, one per wave
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    // block -> (frame, tile), one contiguous range of frame-major tiles per XCD (see k_cascade_tile)
-    const int64_t total = int64_t(a.nTiles) * a.nFrames;
-    const int64_t perX = (total + 7) >> 3;
-    const int64_t id = int64_t(blockIdx.x & 7) * perX + (blockIdx.x >> 3);
-    if (id >= total || (blockIdx.x >> 3) >= perX)
-    {
-        return;
-    }
-    const int frame = int(id / a.nTiles);
-    const CascTile T = a.tiles[id - int64_t(frame) * a.nTiles];
-    const int lvl = T.level;
-    const CascLevel L = a.levels[lvl];
-    const int step = a.g.step, rowsP = a.g.rowsP, colsT = a.g.colsT;
-    const int gr0 = T.r0 * step, gc0 = T.c0 * step;
-    const int colPitch = CT::RANK ? L.pitchR : L.hP;
-    const int area = colPitch * L.wP;
-    const cell_t* __restrict__ src0 = (CT::RANK ? reinterpret_cast<const cell_t*>(a.pyrR) + int64_t(frame) * a.pyrR_fs + L.offR
-                                                : reinterpret_cast<const cell_t*>(a.pyr) + int64_t(frame) * a.pyr_fs + L.off) + gr0;
-    const int colsValid = min(colsT, L.wP - gc0);
-    if (tid < 8)
-    {
-        s_cnt[tid] = 0;
-    }
-    TILE_STAMP(0);
-    // ---- fill (k_cascade_tile's: 16-byte LDS-DMA chunks, everything in flight at once)
-    {
-        const uint32_t cps = uint32_t(rowsP) / uint32_t(CPB);
-        const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
-        const int ccMax = colsValid - 1;
-        for (uint32_t q0 = uint32_t(wv) * 64u; q0 < nChunks; q0 += NW * 64u)
-        {
-            const uint32_t q = q0 + lane;
-            if (q < nChunks)
-            {
-                const uint32_t seg = __umulhi(q, a.g.cpsMagic);
-                const uint32_t j = q - seg * cps;
-                const uint32_t z = __umulhi(seg, a.g.colsMagic);
-                const int cc = int(seg - z * uint32_t(colsT));
-                const uint32_t soff = z * uint32_t(area) + uint32_t(gc0 + min(cc, ccMax)) * uint32_t(colPitch) + uint32_t(CPB) * j;
-                __builtin_amdgcn_global_load_lds((gptr_t)(src0 + soff), (lptr_t)(tileF + uint32_t(CPB) * q0), 16, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    TILE_STAMP(1);
-#ifdef ACF_HIP_STAMPS
-    if (a.debug & 2)
-    {
-        return; // timing experiment: the fill alone
-    }
-    const long long tS1 = (a.debug & 4) ? __builtin_amdgcn_s_memtime() : 0;
-#define TILE_STAMP_REL(k)                                                                  \
-    if ((a.debug & 4) && threadIdx.x == 0)                                                  \
-    {                                                                                      \
-        a.stamps[int64_t(blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime() - tS1;       \
-    }
-#else
-#define TILE_STAMP_REL(k)
-#endif
-
-    TileCtx X;
-    X.tileF = tileF;
-    X.step = step;
-    X.rowsP = rowsP;
-    X.TR = a.g.TR;
-    X.thrC = a.cascThr;
-    X.frame = frame;
-    X.lvl = lvl;
-    X.r0 = T.r0;
-    X.c0 = T.c0;
-    X.nWinR = L.nWinR;
-    const int tEnd = a.g.b[4];
-    const bool lastAll = tEnd == a.nTrees;
-    // nodes of the sparse stages' first pieces: requested now, used after stage A
-    int pT[3], pShift[3];
-    SparseNode pN[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-    {
-        pT[k] = min(64, a.g.b[k + 2] - a.g.b[k + 1]);
-        pShift[k] = pT[k] <= 16 ? 4 : (pT[k] <= 32 ? 5 : 6);
-        pN[k] = sparse_node(a.tileNodes, min(a.g.b[k + 1], a.nTrees - 1), pT[k], pShift[k]);
-    }
-    TILE_STAMP_REL(5);
-    // ---- stage A: lanes = windows, trees [0,b1) for every window of the tile
-    // wave w takes the window columns w, w + NW, ... (64 / TR of them): survivors come in spatial clusters, and a cluster
-    // that sits in one wave's columns would serialise that wave's sparse pieces while the other waves wait at stage E
-    const int r_l = lane % a.g.TR, c_l = (lane / a.g.TR) * NW + wv;
-    const int wr = T.r0 + r_l;
-    // (TR need not divide 64: the lanes past the wave's last whole column of windows idle)
-    bool alive = wr < L.nWinR && (T.c0 + c_l) < L.nWinC && lane < (64 / a.g.TR) * a.g.TR;
-    float h = 0.f;
-    {
-        const cell_t* win = tileF + (min(c_l, a.g.TC - 1) * step) * rowsP + r_l * step;
-        const int nb = a.g.b[1] / a.aTB;
-        if (nb > 0)
-        {
-            if (a.aTB == 8)
-            {
-                tile_eval_s<8, CT>(win, a.tileNodesS, nb, X.thrC, h, alive);
-            }
-            else
-            {
-                tile_eval_s<4, CT>(win, a.tileNodesS, nb, X.thrC, h, alive);
-            }
-        }
-        tile_eval_s1<CT>(win, a.tileNodes, nb * a.aTB, a.g.b[1], X.thrC, h, alive);
-    }
-    asm volatile("" ::"v"(h));
-    TILE_STAMP_REL(6);
-#ifdef ACF_HIP_STAMPS
-    if (a.debug & 1)
-    {
-        if (h == 12345.678f)
-        {
-            a.stamps[0] = 1; // (keeps stage A alive)
-        }
-        return; // timing experiment: fill + stage A
-    }
-#endif
-    // ---- from here to stage E every wave works on ITS OWN 64 windows: its survivors go to its private list segment and
-    // through the sparse pieces [b1,b2) [b2,b3) [b3,b4) (each cut into pieces of at most 64 trees) without a workgroup
-    // barrier — the pieces are latency chains (two LDS round trips + a 16..64-step add chain per round) that now overlap
-    // the other waves' stage A instead of idling the whole workgroup three times (measured with barriers: 5.9k cycles
-    // for the pieces + 2.2k waiting for the slowest wave of stage A, per tile).
-    uint2* seg = listA + wv * 64;
-    int nIn;
-    {
-        float val = h;
-        if (a.g.b[1] == tEnd)
-        {
-            val = __int_as_float(tile_emit2(a, lastAll, frame, alive, lvl, (T.c0 + c_l) * L.nWinR + wr, L.nWinR, h));
-        }
-        const unsigned long long m = __ballot(alive);
-        if (alive)
-        {
-            seg[__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(uint32_t(c_l * a.g.TR + r_l), __float_as_uint(val));
-        }
-        nIn = __popcll(m);
-    }
-    TILE_STAMP_REL(7);
-    if (a.g.b[1] < tEnd)
-    {
-#pragma unroll
-        for (int stage = 1; stage <= 3; stage++)
-        {
-            for (int t0 = a.g.b[stage]; t0 < a.g.b[stage + 1]; t0 += 64)
-            {
-                const int Tn = min(64, a.g.b[stage + 1] - t0);
-                const int tlShift = Tn <= 16 ? 4 : (Tn <= 32 ? 5 : 6);
-                const bool last = t0 + Tn == tEnd;
-                __builtin_amdgcn_wave_barrier(); // (the list written above is read across lanes below: keep the order)
-                if (nIn > 0)
-                {
-                    if (t0 == a.g.b[stage])
-                    {
-                        nIn = tile_sparse_wave<CT>(a, X, seg, nIn, pN[stage - 1], Tn, tlShift, last, lastAll);
-                    }
-                    else
-                    {
-                        const SparseNode nd = sparse_node(a.tileNodes, t0, Tn, tlShift);
-                        nIn = tile_sparse_wave<CT>(a, X, seg, nIn, nd, Tn, tlShift, last, lastAll);
-                    }
-                }
-            }
-        }
-    }
-    if (lastAll || a.codeCap <= 0)
-    {
-        TILE_STAMP(4);
-        return;
-    }
-    // ---- stage E: leaf codes of every tail tree for the windows now in the tail queue ({tag, queue slot} in the waves'
-    // segments).  lanes = trees; a wave takes four 64-tree batches at a time (nodes in registers, their reads of one
-    // window's features issued together), windows in the inner loop: the node stream is read once per tile, not per window.
-    if (lane == 0)
-    {
-        s_cnt[wv] = nIn;
-    }
-    TILE_STAMP(2);
-    __syncthreads();
-    TILE_STAMP(3);
-    int cntW[NW], nTail = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-    {
-        cntW[w] = s_cnt[w];
-        nTail += cntW[w];
-    }
-    if (nTail == 0)
-    {
-        TILE_STAMP(4);
-        return;
-    }
-    const uint2* listE = listA; // wave w's entries: 64 * w ...
-    {
-        const int nT = a.nTrees - tEnd, nB = (nT + 63) >> 6;
-        for (int b0 = wv; b0 < nB; b0 += 4 * NW)
-        {
-            uint32_t o0[4], o1[4], o2[4];
-            val_t t0[4], t1[4], t2[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                const int b = min(b0 + k * NW, nB - 1);
-                const uint4* np = reinterpret_cast<const uint4*>(a.tileNodes + tEnd + min(b * 64 + lane, nT - 1));
-                const uint4 o = np[0], tq = np[1];
-                o0[k] = o.x;
-                o1[k] = o.y;
-                o2[k] = o.z;
-                t0[k] = CT::thr(tq.x);
-                t1[k] = CT::thr(tq.y);
-                t2[k] = CT::thr(tq.z);
-            }
-#pragma unroll
-            for (int w = 0; w < NW; w++)
-            {
-                for (int s = 0; s < cntW[w]; s++)
-                {
-                    const uint2 e = listE[w * 64 + s];
-                    const int slot = int(e.y);
-                    if (slot < 0 || slot >= a.codeCap)
-                    {
-                        continue; // no code row: k_cascade_tail3 takes this entry
-                    }
-                    const int rl = int(e.x) % X.TR, cl = int(e.x) / X.TR;
-                    const cell_t* win = tileF + (cl * step) * rowsP + rl * step;
-                    uint8_t* __restrict__ row = a.tailCodes + (int64_t(frame) * a.codeCap + slot) * a.codePitch + lane;
-                    val_t f0[4], fc[4];
-                    bool lt0[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        f0[k] = val_t(win[o0[k]]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        lt0[k] = f0[k] < t0[k];
-                        fc[k] = val_t(win[lt0[k] ? o1[k] : o2[k]]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        const bool lt1 = fc[k] < (lt0[k] ? t1[k] : t2[k]);
-                        if (b0 + k * NW < nB) // wave-uniform
-                        {
-                            row[(b0 + k * NW) * 64] = uint8_t((lt0[k] ? 0 : 8) + (lt1 ? 0 : 4));
-                        }
-                    }
-                }
-            }
-        }
-    }
-    TILE_STAMP(4);
-}
-
 // ------------------------------------------------------------------------
 // k_cascade_tile3: the tile kernel with the survivors POOLED over the workgroup.
 //
-// k_cascade_tile2 keeps every wave on its own 64 windows: 32 dense trees for each of them (the mean window needs 14), then
+// Round 3 kept every wave on its own 64 windows: 32 dense trees for each of them (the mean window needs 14), then
 // sparse pieces on the wave's ~2 survivors whose rounds cost a wave ~300 instructions however few of its lanes hold an item —
 // together 849 VALU instructions per wave, of which the kernel's time is the issue time (profiles/r03_pmc_sq_*).  Here:
-//  A1  trees [0, b1) (16): lanes = the wave's own windows, as before (tile_eval_s: records through the scalar unit, leaves
+//  A1  trees [0, b1) (16): lanes = the wave's own windows (tile_eval_p: records through the scalar unit, leaves
 //      added under EXEC).  Survivors {window, score} go to ONE list of the workgroup (a ballot and one LDS atomic per wave).
 //  A2  trees [b1, b2) (16..32): the same dense evaluation with lanes = list entries: ceil(n1 / 64) waves run it, the others
 //      go to the barrier and leave the SIMD's issue slots to the CU's other workgroups.
@@ -6278,7 +5263,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
 //      round: two dependent LDS reads give the leaf's code byte (4 * leaf index, as stage E's), written to codes[window][tree];
 //      then ONE wave, lanes = windows, adds the leaves in tree order — code byte -> leaf table in LDS -> h += leaf, min over the
 //      prefixes — which is evaluate()'s chain (acfDetect1.cpp:123-138) for up to 64 windows at once.
-//  E   as in k_cascade_tile2 (leaf codes of the tail trees for the windows that enter the tail queue).
+//  E   leaf codes (round 2.s stage E: of the tail trees for the windows that enter the tail queue).
 // A window's score is the same chain of f32 additions in the same order in every stage (A: v_add under EXEC per tree; S: the
 // one-wave chain; rows of -0.0f pad the leaf table to 16 trees, the identity of float addition).
 // LDS: [leaf table 2 KB][tile cells][R1: list 1 = h[NWIN] f32 + tag[NWIN] u16, later the codes 64 x pitchC][R2: list 2, same
@@ -6287,7 +5272,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OC
 #define TILE3_LEAF_BYTES 2048 // 128 trees x 4 leaves x 4 bytes
 typedef const __attribute__((address_space(4))) TileArgs* tile_args_k; // the kernel's argument block in the kernarg segment
 
-// Stage A of k_cascade_tile3: tile_eval_s<4> with a tree's three compares inside the asm block of its four leaf adds, so that
+// Stage A of k_cascade_tile3: a batch of four trees per scalar load, a tree's three compares inside the asm block of its four leaf adds, so that
 // a tree's wave masks live for seven instructions instead of a batch (24 SGPRs fewer across the loop: the kernel's later
 // phases keep their scalars in registers instead of v_writelane / v_readlane round trips, which are VALU instructions).
 template <class CT>
@@ -6427,7 +5412,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     const int perX = int((total + 7) >> 3);
     const int xcd = blockIdx.x & 7;
     __shared__ int s_next[2]; // (two slots: a wave that is late reading tile n's successor never meets tile n + 1's write)
-    const bool persist = a.tileNext != nullptr; // else: one tile per workgroup, blockIdx.x -> tile as k_cascade_tile2
+    const bool persist = a.tileNext != nullptr; // else: one tile per workgroup, blockIdx.x -> tile
     int li = int(blockIdx.x >> 3);
     if (persist) // (a kernel argument: workgroup-uniform)
     {
@@ -6786,7 +5771,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
     {
         continue;
     }
-    // ---- E: leaf codes of every tail tree for the windows now in the tail queue (k_cascade_tile2's stage E over one list)
+    // ---- E: leaf codes of every tail tree for the windows now in the tail queue (stage E over one list)
     const int nTail = s_n[3];
 #ifdef ACF_HIP_STAMPS
     if ((a.debug & 4) && threadIdx.x == 0)
@@ -6860,7 +5845,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
 // slab.  run = z * mW + cc  ->  win[run * mH + rr].
 // ------------------------------------------------------------------------
 // k_cascade_tileD: the first trees of a fixed-depth model OTHER than depth 2 (acfDetect1.cpp:201-228 dispatches depth
-// 1..8 through one body) on LDS tiles.  Same tiles, fill and window mapping as k_cascade_tile2 (float cells); stage A is
+// 1..8 through one body) on LDS tiles.  Same tiles, fill and window mapping as the depth-2 tile kernel (float cells); stage A is
 // generalised to depth D: a tree's 2^D - 1 node features are all read (the walk would be D dependent LDS round trips), the
 // compares give wave masks, the 2^D leaf masks are ANDs along the paths (scalar unit), and every leaf is added under EXEC
 // to the lanes of its mask — the additions and their order are evaluate()'s (:123-138).  Nodes are in heap order (node k's
@@ -7002,7 +5987,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tileD(TileDArgs a)
     const int area = colPitch * L.wP;
     const float* __restrict__ src0 = a.pyr + int64_t(frame) * a.pyr_fs + L.off + gr0;
     const int colsValid = min(colsT, L.wP - gc0);
-    // ---- fill (k_cascade_tile2's: 16-byte LDS-DMA chunks, everything in flight at once)
+    // ---- fill (16-byte LDS-DMA chunks, everything in flight at once)
     {
         const uint32_t cps = uint32_t(rowsP) / 4u;
         const uint32_t nChunks = uint32_t(a.nChns * colsT) * cps;
@@ -7807,7 +6792,7 @@ __global__ void __launch_bounds__(64) k_cascade_tail_rank(TileArgs a, const Tree
 
 // ------------------------------------------------------------------------
 // k_tail_scan: the ordered part of the tail [tEnd, nTrees).  Which LEAF a tree selects does not depend on the running
-// score — only the early exit does (acfDetect1.cpp:123-138) — so k_cascade_tile2's stage E writes one byte per tail tree
+// score — only the early exit does (acfDetect1.cpp:123-138) — so the tile kernels' stage E writes one byte per tail tree
 // of every window that reaches the tail (4 * (leaf index - 3)), and this kernel does what is sequential: lanes = windows,
 // h = h + hs[leaf] strictly in tree order, 16 code bytes per 16-byte load, the leaf values of tree t read from an LDS
 // table at [t][code] (all lanes of a wave hit the same 16 bytes); a lane dies at the first prefix <= cascThr.  Scores are

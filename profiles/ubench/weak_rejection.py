@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The pooled tile kernel when early rejection is weak (a low cascThr keeps many windows alive past tree 32): k_cascade_tile3
-against k_cascade_tile2 (ACF_HIP_TILE2=1 in the environment), us per 1080p frame of cascade, over a sweep of cascThr."""
+against round 3.s k_cascade_tile2 (deleted in round 5: the figures in DESIGN.md 3.0 were taken with ACF_HIP_TILE2=1 on the round-4 library), us per 1080p frame of cascade, over a sweep of cascThr."""
 import json
 import os
 import sys

@@ -11,12 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = [
     "",  # the defaults, as the baseline of this file
-    "ACF_HIP_TILE2=1",
-    "ACF_HIP_TILE2=1 ACF_HIP_TILE_TB8=1",
-    "ACF_HIP_TILE2=1 ACF_HIP_TILE_OCC8=1",
-    "ACF_HIP_TILE2=1 ACF_HIP_CASC_BOUNDS=16,32,64,128",
-    "ACF_HIP_TILE2=1 ACF_HIP_NO_RANK=1",
-    "ACF_HIP_TILE2=1 ACF_HIP_TAIL3=1",
     "ACF_HIP_CASC_BOUNDS=8,24,24,96",
     "ACF_HIP_CASC_BOUNDS=32,32,32,128",
     "ACF_HIP_TILE_PERSIST=0",
@@ -39,16 +33,12 @@ VARIANTS = [
     "ACF_HIP_NO_FUSED_GRAD=1",
     "ACF_HIP_FUSED_GRAD=1 ACF_HIP_FUSED_GRAD_MINPX=1000 ACF_HIP_FUSED_GRAD_MINF=1",
     "ACF_HIP_GMV_BLOCKS=64",
-    "ACF_HIP_RT_XO=16",
-    "ACF_HIP_RT_XO=32",
-    "ACF_HIP_RESAMPLE_NO_MARCH=1",
     "ACF_HIP_RESAMPLE_NO_PAIR=1",
+    "ACF_HIP_RESAMPLE_NO_STRIP=1",
+    "ACF_HIP_SCALES_SERIAL=1 ACF_HIP_RESAMPLE_NO_PAIR=1",
     "ACF_HIP_RESAMPLE_NO_UP=1",
-    "ACF_HIP_SCALES_SERIAL=1 ACF_HIP_RT_XO=16",
     "ACF_HIP_RESAMPLE_GENERIC=1",
     "ACF_HIP_TRIY_UNFUSED=1",
-    "ACF_HIP_TRIY_DIRECT=1",
-    "ACF_HIP_TRIY_UNFUSED=1 ACF_HIP_TRIY_DIRECT=1",
     "ACF_HIP_MOU_PLAIN=1",
     "ACF_HIP_LEVEL_GROUPS=1",
     "ACF_HIP_LEVEL_SEGMENTS=4 ACF_HIP_LEVEL_WARM=16",
