@@ -1829,6 +1829,34 @@ __global__ void __launch_bounds__(256) k_tri_y5s(const float* __restrict__ Ui, f
 // contribution then O1; orientation bins are selected with compares so the six
 // accumulators stay in registers.
 // ------------------------------------------------------------------------
+// gradHist's two bin updates of one pixel (gradientMex.cpp:451-509: H[o0] += m0, H[o1] += m1 with o1 = o0 + 1 wrapped at nO)
+// for bins held in registers.  A select per bin and addend — v_cmp, (two wait states,) v_cndmask, v_add: the cost of 3.6 + 1 plain
+// instructions on gfx950 (profiles/ubench/valu_rate.hip: `cmp_cnd`) — was more than half of the y pass kernel's issue time.  Here the bin
+// takes H + (mask & m) for every b: the mask is all ones for the pixel's bin and 0 elsewhere (a sign-extended bit of 1 << o0:
+// v_bfe_i32), so the chosen bin gets the reference's addition and every other bin gets + 0.0f, which changes no bit of a bin —
+// they start at +0.0f and only ever add values >= +0 (m0 = m - od * m with 0 <= od < 1, m1 = od * m), so no bin is ever -0.0f.
+// o1's masks are o0's moved up by one bin; bin 0 takes bit nO - 1.  (hardBin: m1 = +0.0f, the same argument.)
+template <int MAXO>
+__device__ __forceinline__ void hist_add2(float (&H)[MAXO], int o0, int nO, float m0, float m1)
+{
+    const int A = 1 << o0;
+    int mk[MAXO];
+#pragma unroll
+    for (int b = 0; b < MAXO; b++)
+    {
+        mk[b] = __builtin_amdgcn_sbfe(A, b, 1); // bit b of A, sign-extended: -1 or 0
+    }
+    const int mkW = __builtin_amdgcn_sbfe(A, nO - 1, 1); // o0 == nO - 1: o1 wraps to bin 0
+    const int b0 = __float_as_int(m0), b1 = __float_as_int(m1);
+#pragma unroll
+    for (int b = 0; b < MAXO; b++)
+    {
+        const float a0 = __int_as_float(mk[b] & b0);
+        const float a1 = __int_as_float((b == 0 ? mkW : mk[b - 1]) & b1);
+        H[b] = (H[b] + a0) + a1;
+    }
+}
+
 struct ChnsArgs
 {
     const float* sm;   // smoothed colour planes [d][w][h]
@@ -2017,14 +2045,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                         const float m_ = mn[xx][yy] * sInv2;                                                \
                         const float m1_ = od_ * m_;                                                         \
                         const float m0_ = m_ - m1_;                                                         \
-                        _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                    \
-                        {                                                                                   \
-                            H_[b] = (b == o0_) ? H_[b] + m0_ : H_[b];                                       \
-                        }                                                                                   \
-                        _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                    \
-                        {                                                                                   \
-                            H_[b] = (b == o1_) ? H_[b] + m1_ : H_[b];                                       \
-                        }                                                                                   \
+                        hist_add2<MAXO>(H_, o0_, nO, m0_, m1_);                                             \
                     }                                                                                       \
                 }                                                                                           \
                 const int chH_ = chMag + (ca.magEnabled ? 1 : 0);                                            \
@@ -2343,16 +2364,7 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
                 const float m = mn[xx][yy] * sInv2;
                 const float m1 = od * m;
                 const float m0 = m - m1;
-#pragma unroll
-                for (int b = 0; b < MAXO; b++)
-                {
-                    H[b] = (b == o0) ? H[b] + m0 : H[b];
-                }
-#pragma unroll
-                for (int b = 0; b < MAXO; b++)
-                {
-                    H[b] = (b == o1) ? H[b] + m1 : H[b];
-                }
+                hist_add2<MAXO>(H, o0, nO, m0, m1);
             }
         }
 #pragma unroll
