@@ -85,6 +85,37 @@ ACFO_API void acfo_set_ref_kernels(const acfo_ref_kernels* k)
 }
 
 /* ------------------------------------------------------------------------
+ * A third arithmetic tier, for the T-ref study only (tests/golden/make_tref.py): "T-approx".  Where the reference uses
+ * _mm_rsqrt_ps / _mm_rcp_ps (three sites: gradMag, gradMagNorm, rgb2luv_sse) Intel's manual promises |relative error| <=
+ * 1.5 * 2^-12 and nothing else: the bits differ between CPU vendors and generations.  acfo_set_approx(mode) makes those
+ * three sites return the exact value squeezed to a 12-bit mantissa — mode 1 rounded to nearest (error <= 2^-13), mode 2
+ * truncated (error < 2^-12) — two more approximations that meet that promise.  How far detections move between two such
+ * conforming approximations is how far the reference's own detections move from one conforming CPU to another: the
+ * yardstick for the T-ref / T-exact gap.  mode 0 (the default, everything else): the exact tier.
+ * ---------------------------------------------------------------------- */
+static __thread int g_approx = 0;
+ACFO_API void acfo_set_approx(int mode)
+{
+    g_approx = mode;
+}
+static inline float approx12(float v)
+{
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    if ((b & 0x7f800000u) == 0x7f800000u || (b & 0x7f800000u) == 0)
+    {
+        return v; /* inf, NaN, zero, subnormal: as they are */
+    }
+    if (g_approx == 1)
+    {
+        b += 0x400u; /* round to nearest at bit 11 (a carry into the exponent is the right result) */
+    }
+    b &= 0xfffff800u; /* 12 mantissa bits kept */
+    memcpy(&v, &b, 4);
+    return v;
+}
+
+/* ------------------------------------------------------------------------
  * a1  Detector::getScales — chnsPyramid.cpp:461-529.
  * Upright naming: H = image height (reference sz.width, because the image is
  * transposed: chnsPyramid.cpp:232, ACF.cpp:137), W = image width (sz.height).
@@ -566,6 +597,10 @@ ACFO_API void acfo_rgb2luv(const float* I, float* J, int n)
             float y = (r * mr[1] + g * mg[1]) + b * mb[1];
             float z = (r * mr[2] + g * mg[2]) + b * mb[2];
             float zz = 1.0f / (x + (1e-35f + (15.0f * y + 3.0f * z))); /* :161, RCP -> exact */
+            if (g_approx)
+            {
+                zz = approx12(zz); /* T-approx (acfo_set_approx) */
+            }
             float lf = 1024.0f * y;                                   /* :162 */
             float u = (52.0f * x) * zz - cun;                         /* :163 */
             float v = (117.0f * y) * zz - cvn;                        /* :164 */
@@ -987,7 +1022,29 @@ ACFO_API int acfo_grad_mag(const float* I, float* M, float* O, int h, int w, int
         }
         /* :209-219; RCPSQRT/RCP -> exact.  Written so that gcc vectorises it (IEEE sqrtps / divps, -fno-math-errno): the
          * reference's loop is SSE too, and bench.py's cpu_baseline times this function. */
-        if (O)
+        if (g_approx)
+        {
+            /* T-approx: RCPSQRT and RCP as 12-bit approximations (see acfo_set_approx); the rest as below */
+            for (int y = 0; y < h; y++)
+            {
+                float m = approx12(1.0f / sqrtf(M2[y]));
+                m = m < 1e10f ? m : 1e10f;
+                M2[y] = approx12(1.0f / m);
+                if (O)
+                {
+                    float g = (Gx[y] * m) * acMult;
+                    uint32_t gb, yb;
+                    memcpy(&gb, &g, 4);
+                    memcpy(&yb, &Gy[y], 4);
+                    gb ^= yb & 0x80000000u;
+                    memcpy(&g, &gb, 4);
+                    g = g < upper ? g : upper;
+                    g = g > lower ? g : lower;
+                    Gx[y] = g;
+                }
+            }
+        }
+        else if (O)
         {
             for (int y = 0; y < h; y++)
             {
@@ -1043,6 +1100,13 @@ ACFO_API int acfo_grad_mag(const float* I, float* M, float* O, int h, int w, int
 ACFO_API void acfo_grad_mag_norm(float* M, const float* S, int h, int w, float norm)
 {
     int i = 0, n = h * w, n4 = n / 4;
+    if (g_approx)
+    {
+        for (; i < n4 * 4; i++)
+        {
+            M[i] = M[i] * approx12(1.0f / (S[i] + norm)); /* T-approx (acfo_set_approx) */
+        }
+    }
     for (; i < n4 * 4; i++)
     {
         M[i] = M[i] * (1.0f / (S[i] + norm));

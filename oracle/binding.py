@@ -161,6 +161,15 @@ def set_tref(on, only=TREF_ALL):
     o.acfo_set_ref_kernels(C.byref(k))
 
 
+def set_approx(mode):
+    """T-approx tier of the oracle on THIS thread (tests/golden/make_tref.py): 0 exact (default), 1 / 2 the three rsqrt / rcp sites as
+    12-bit approximations (rounded / truncated), two more implementations within _mm_rsqrt_ps's documented error bound."""
+    o = lib()
+    o.acfo_set_approx.argtypes = [C.c_int]
+    o.acfo_set_approx.restype = None
+    o.acfo_set_approx(int(mode))
+
+
 def aligned(shape, dtype=np.float32, align=64):
     """numpy array whose data pointer is `align`-byte aligned (the reference's
     SSE paths require 16-byte alignment, like cv::Mat storage)."""

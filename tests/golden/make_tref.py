@@ -41,12 +41,16 @@ MODEL_SEED = 1
 NMS = dict(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10, pruneRatio=0.0)  # Detector::operator()'s defaults
 
 
-def run_tier(plan, frame, tref):
+def run_tier(plan, frame, tref, approx=0):
+    """tref: the reference's compiled kernels; approx 1 / 2: the oracle with its three rsqrt / rcp sites as 12-bit approximations
+    (rounded / truncated: acfo_set_approx) — two more implementations inside _mm_rsqrt_ps's documented error bound."""
     ob.set_tref(tref)
+    ob.set_approx(approx)
     try:
         pyr, _, _ = ob.chns_pyramid(plan, frame)
     finally:
         ob.set_tref(False)
+        ob.set_approx(0)
     det, hits = ob.detect(plan, pyr)
     return pyr, det, hits
 
@@ -77,10 +81,22 @@ def study(nframes):
         plan = ob.Plan(model, H, W, d_in)
         rows = []
         alld = []
+        yard = {}
         for f in range(nframes):
             frame = synth.make_frame(FRAME_SEED0 + f, H, W, kind)
             pe, de, he = run_tier(plan, frame, False)
             pr, dr, hr = run_tier(plan, frame, True)
+            _, _, h1 = run_tier(plan, frame, False, 1)
+            _, _, h2 = run_tier(plan, frame, False, 2)
+            for pn, (ha_, hb_) in (("approx_round_vs_ref", (h1, hr)), ("approx_trunc_vs_ref", (h2, hr)), ("approx_round_vs_approx_trunc", (h1, h2)),
+                                   ("exact_vs_ref", (he, hr))):
+                nc_, oa_, ob_, _, d_ = compare_hits(ha_, hb_)
+                t_ = yard.setdefault(pn, dict(common=0, only_first=0, only_second=0, gt=0, dmax=0.0))
+                t_["common"] += nc_
+                t_["only_first"] += oa_
+                t_["only_second"] += ob_
+                t_["gt"] += int((d_ > 1e-4).sum())
+                t_["dmax"] = max(t_["dmax"], float(d_.max()) if len(d_) else 0.0)
             nc, oe, orr, dmax, d = compare_hits(he, hr)
             alld.append(d)
             fe, fr = final_boxes(de, nms), final_boxes(dr, nms)
@@ -100,6 +116,10 @@ def study(nframes):
         tot["median_abs_dscore_common"] = float(np.median(alld)) if len(alld) else 0.0
         tot["p99_abs_dscore_common"] = float(np.quantile(alld, 0.99)) if len(alld) else 0.0
         tot["pyramid_max_abs_diff"] = max(r["pyramid_max_abs_diff"] for r in rows)
+        # the yardstick: the same comparison between pairs of CONFORMING approximations (the reference's own kernels on this host, and
+        # the oracle's arithmetic with 12-bit rsqrt / rcp results, rounded or truncated): what one conforming CPU differs from another by
+        tot["yardstick_pairs"] = {k: dict(common=v["common"], only_first=v["only_first"], only_second=v["only_second"],
+                                          frac_common_gt_1e4=round(v["gt"] / max(v["common"], 1), 3), max_abs_dscore=round(v["dmax"], 4)) for k, v in yard.items()}
         table[name] = dict(frames=nframes, totals=tot, per_frame=rows)
         store[name + "_meta"] = np.asarray([H, W, d_in, nframes, FRAME_SEED0, MODEL_SEED], np.int64)
     return table, store

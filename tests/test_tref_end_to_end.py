@@ -115,3 +115,29 @@ def test_tref_table(fix, capsys):
         assert np.median(d) < 1e-4, rows[cfg]
     with capsys.disabled():
         print("\nT-ref vs T-exact, end to end:\n" + json.dumps(rows, indent=1))
+
+
+def test_approx_tiers_are_conforming_and_leave_no_trace(oracle):
+    """acfo_set_approx: the oracle's three rsqrt / rcp sites squeezed to 12 mantissa bits (the yardstick of the T-ref study: two more
+    approximations inside _mm_rsqrt_ps's documented error bound).  gradMag's M under either mode stays within the bound of two
+    chained approximations of the exact M, differs from it, and mode 0 afterwards is the exact tier again, bit for bit."""
+    h, w = 64, 48
+    img = oracle.aligned_copy((synth.uniform(11, h * w, 5).astype(np.float32) * 0.9 + 0.05).reshape(1, w, h))
+    o = oracle.lib()
+
+    def gm():
+        M, O = oracle.aligned((w, h)), oracle.aligned((w, h))
+        assert o.acfo_grad_mag(oracle.F(img), oracle.F(M), oracle.F(O), h, w, 1, 0) == 0
+        return np.array(M)
+
+    exact = gm()
+    for mode, eps in ((1, 2.0 ** -13), (2, 2.0 ** -12)):
+        oracle.set_approx(mode)
+        try:
+            got = gm()
+        finally:
+            oracle.set_approx(0)
+        nz = exact > 1e-6
+        rel = np.abs(got[nz] - exact[nz]) / exact[nz]
+        assert rel.max() <= 2.1 * eps and (got != exact).any(), (mode, rel.max())
+    assert np.array_equal(gm().view(np.uint32), exact.view(np.uint32))
