@@ -52,7 +52,7 @@ CLASSES = [
     ("gradmag", r"k_grad_mag_vec"),
     ("tri_x", r"k_tri_x5v"),
     ("triy_chns", r"k_triy_chns"),
-    ("resample", r"k_resample_(march2|march|half|tile)"),
+    ("resample", r"k_resample_(strip|half)"),
     ("level", r"k_level_all"),
     ("tile", r"k_cascade_tile3"),
 ]
