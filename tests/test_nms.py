@@ -76,7 +76,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 2, 63, 300, 1025, 2048])
+@pytest.mark.parametrize("n", [1, 2, 63, 300, 512, 513, 1025, 2048])
 @pytest.mark.parametrize("typ,ovr,overlap,quant", [("maxg", "min", 0.65, 0.5), ("max", "union", 0.5, 0.5), ("maxg", "union", 0.3, 0), ("max", "min", 0.2, 2.0)])
 def test_gpu_op_nms_matches_oracle(dev, oracle, n, typ, ovr, overlap, quant):
     boxes, scores = boxes_scores(100 + n, n, quant, span=(1900, 1060))
