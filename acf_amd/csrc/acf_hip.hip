@@ -2868,6 +2868,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             std::vector<LdcfTileJob> tj;
             int maxR = 0, maxC = 0;
             bool ok = !getenv("ACF_HIP_LDCF_UNFUSED");
+            const int xoMax = 16; // output columns per tile at most (source tile: twice as many columns)
             for (size_t i = 0; i < c->ldcfLevels.size() && ok; i++)
             {
                 const ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
@@ -2879,7 +2880,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                     std::vector<std::pair<int, int>> cand;
                     for (int y = RT_YO; y >= 32; y--)
                     {
-                        for (int x = 16; x >= 8; x--)
+                        for (int x = xoMax; x >= xoMax / 2; x--)
                         {
                             cand.push_back({ y, x });
                         }
@@ -2887,7 +2888,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
                     std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first * a.second > b.first * b.second; });
                     for (const auto& yx : cand)
                     {
-                        tl = resampleTilePlan(dd, arena, yx.second, int64_t(40) * 1024, yx.first, 128, 32);
+                        tl = resampleTilePlan(dd, arena, yx.second, int64_t(40) * 1024, yx.first, 128, 2 * xoMax);
                         if (tl.rows > 0)
                         {
                             yo = yx.first;
@@ -5055,15 +5056,16 @@ int acf_hip_detect(acf_hip_ctx* c)
         {
             // filters + half resample in one kernel: the filtered full-resolution planes stay in LDS
             prof(c, "k_ldcf_tile");
-            const size_t ldsB = (size_t(c->ldcfTileCols) * c->ldcfTileRows + size_t(16) * c->ldcfTileRows +
-                                 size_t(c->ldcfTileCols + 4) * (c->ldcfTileRows + 4) + 16 * 8) * sizeof(float);
-            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_ldcf_tile), ldsB)))
+            const int xoT = 16;
+            const size_t ldsB = ldcfTileLdsFloats(c->ldcfTileRows, c->ldcfTileCols, xoT) * sizeof(float);
+            auto kern = &k_ldcf_tile<8, 4>;
+            if ((rc = allowLds(c, reinterpret_cast<const void*>(kern), ldsB)))
             {
                 return rc;
             }
-            hipLaunchKernelGGL(k_ldcf_tile, dim3(c->ldcfTiles, pl.nChns, nF), dim3(256), ldsB, c->stream, (const float*)c->d_pyr, c->d_ldcfPyr,
+            hipLaunchKernelGGL(kern, dim3(c->ldcfTiles, pl.nChns, nF), dim3(256), ldsB, c->stream, (const float*)c->d_pyr, c->d_ldcfPyr,
                 (const float*)c->d_ldcfFilt, (const LdcfTileJob*)c->d_ldcfTileJobs, (const LdcfJob*)c->d_ldcfJobs,
-                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, c->ldcfTileRows, c->ldcfTileCols, 16,
+                (const ResampleDesc*)(c->d_descs + c->ldcfDescBase), (const int32_t*)c->d_it, (const float*)c->d_ft, c->ldcfTileRows, c->ldcfTileCols, xoT,
                 c->p.ldcfK, pl.nChns, pl.pyr_floats);
             LAUNCHCHK(c, "k_ldcf_tile");
         }

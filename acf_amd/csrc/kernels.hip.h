@@ -3742,75 +3742,95 @@ __device__ __forceinline__ RtTaps rt_taps(const ResampleDesc& d, const int32_t* 
     return t;
 }
 
-// The two passes on a source tile in LDS, for tiles of at most 16 output columns (k_ldcf_tile), arranged for memory-level parallelism: a wave's four columns
-// are in flight together and every tap read is unconditional (a tap beyond m / ny is read from wherever the index lands inside
-// the workgroup's LDS and dropped by a select).  Products and sums in rs_C's / k_resample's order (x pass then y pass, taps ascending).
-// xrecTile: the tile's column records, in LDS.
-__device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const float* T, float* C,
-    float* __restrict__ B, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int colLo, int nRows, float r, float rk, const int32_t* xrecTile)
+// The two passes on a source tile in LDS, for tiles of at most 16 output columns (k_ldcf_tile), on TWO planes at once: a cell of T / C is the
+// pair {plane A, plane B} (k_ldcf_tile: two filters of one channel), every LDS access is 8 bytes and the arithmetic is packed f32 — per half
+// exactly rs_C's / k_resample's products and sums (x pass then y pass, taps ascending; no fused multiply-add here).  Arranged for memory-level
+// parallelism: a wave's four columns are in flight together and every tap read is unconditional (a tap beyond m / ny is read from wherever
+// the index lands inside the workgroup's LDS and dropped by a select).  tP: row pitch of T and C in cells; BB == nullptr: plane B is not stored.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// a wave's KX output columns (wv + 4 k) of a tile: first source column (as an offset into T), tap count, weights — the same for every plane
+// pair of the tile, so k_ldcf_tile reads them from the tile's records once
+template <int KX>
+struct RtCols
+{
+    int toff[KX], m[KX], wofs[KX];
+    float w[KX][4];
+};
+template <int KX>
+__device__ __forceinline__ RtCols<KX> rt_cols(const ResampleDesc& d, const int32_t* xrecTile, int nXo, int colLo, int tP)
+{
+    RtCols<KX> xc;
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KX; k++)
+    {
+        const int32_t* rec = xrecTile + 8 * min(wv + 4 * k, nXo - 1);
+        xc.toff[k] = (rec[0] - colLo) * tP;
+        xc.m[k] = rec[1];
+        xc.wofs[k] = rec[2];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            xc.w[k][j] = (d.xmode == RS_EXACT) ? 1.f : __int_as_float(rec[4 + j]);
+        }
+    }
+    return xc;
+}
+template <int KX> // output columns per wave: tiles of up to 4 * KX output columns
+__device__ __forceinline__ void rt_passes16x2(const ResampleDesc& d, const int32_t* __restrict__ it, const float* __restrict__ ft, const f2_t* T, f2_t* C,
+    float* __restrict__ BA, float* __restrict__ BB, const RtTaps& tp, int yb, int xb0, int xb1, int rowLo, int nRows, int tP, float r, float rk, const RtCols<KX>& xc)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ha = d.ha, hb = d.hb;
     const int xmode = d.xmode, ymode = d.ymode;
     const int nXo = xb1 - xb0;
-    int toff[4], m[4], wofs[4];
-    float w[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-        const int32_t* rec = xrecTile + 8 * min(wv + 4 * k, nXo - 1);
-        toff[k] = (rec[0] - colLo) * nRows;
-        m[k] = rec[1];
-        wofs[k] = rec[2];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-        {
-            w[k][j] = (xmode == RS_EXACT) ? 1.f : __int_as_float(rec[4 + j]);
-        }
-    }
+    const auto& toff = xc.toff;
+    const auto& m = xc.m;
+    const auto& wofs = xc.wofs;
+    const auto& w = xc.w;
     for (int rr = lane; rr < nRows; rr += 64)
     {
         const bool below = rowLo + rr >= ha; // C[ha .. ha+3] = 0 (imResampleMex.cpp:133-137)
-        float t[4][4];
+        f2_t t[KX][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < KX; k++)
         {
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                t[k][j] = T[toff[k] + j * nRows + rr];
+                t[k][j] = T[toff[k] + j * tP + rr];
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < KX; k++)
         {
             const int c = wv + 4 * k;
-            float s;
+            f2_t s;
             if (xmode == RS_EXACT)
             {
                 s = t[k][0] + t[k][1];
-                const float s2 = s + t[k][2];
+                const f2_t s2 = s + t[k][2];
                 s = m[k] > 2 ? s2 : s;
-                const float s3 = s + t[k][3];
+                const f2_t s3 = s + t[k][3];
                 s = m[k] > 3 ? s3 : s;
             }
             else
             {
                 s = t[k][0] * w[k][0];
-                const float s1 = s + t[k][1] * w[k][1];
+                const f2_t s1 = s + t[k][1] * w[k][1];
                 s = m[k] > 1 ? s1 : s;
-                const float s2 = s + t[k][2] * w[k][2];
+                const f2_t s2 = s + t[k][2] * w[k][2];
                 s = m[k] > 2 ? s2 : s;
-                const float s3 = s + t[k][3] * w[k][3];
+                const f2_t s3 = s + t[k][3] * w[k][3];
                 s = m[k] > 3 ? s3 : s;
                 for (int j = 4; j < m[k]; j++)
                 {
-                    s = s + T[toff[k] + j * nRows + rr] * ft[wofs[k] + j];
+                    s = s + T[toff[k] + j * tP + rr] * ft[wofs[k] + j];
                 }
             }
             if (c < nXo)
             {
-                C[c * nRows + rr] = below ? 0.f : s;
+                C[c * tP + rr] = below ? f2_t{ 0.f, 0.f } : s;
             }
         }
     }
@@ -3825,21 +3845,25 @@ __device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t
     {
         for (int c = wv; c < nXo; c += 4)
         {
-            const float* Cc = C + c * nRows - rowLo;
-            float v = 0.f;
+            const f2_t* Cc = C + c * tP - rowLo;
+            f2_t v = f2_t{ 0.f, 0.f };
             for (int q = tp.q0; q < tp.q1; q++)
             {
                 v = v + Cc[it[d.y_src + q]] * (ft[d.y_wt + q] * r);
             }
-            B[int64_t(xb0 + c) * hb + yb] = v;
+            BA[int64_t(xb0 + c) * hb + yb] = v.x;
+            if (BB)
+            {
+                BB[int64_t(xb0 + c) * hb + yb] = v.y;
+            }
         }
         return;
     }
-    float u[4][4];
+    f2_t u[KX][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < KX; k++)
     {
-        const float* Cc = C + min(wv + 4 * k, nXo - 1) * nRows - rowLo;
+        const f2_t* Cc = C + min(wv + 4 * k, nXo - 1) * tP - rowLo;
 #pragma unroll
         for (int j = 0; j < 4; j++)
         {
@@ -3847,16 +3871,16 @@ __device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < KX; k++)
     {
         const int c = wv + 4 * k;
-        float v;
+        f2_t v;
         if (ymode == RS_EXACT)
         {
-            float sacc = u[k][0] + u[k][1];
-            const float s2 = sacc + u[k][2];
+            f2_t sacc = u[k][0] + u[k][1];
+            const f2_t s2 = sacc + u[k][2];
             sacc = ny > 2 ? s2 : sacc;
-            const float s3 = sacc + u[k][3];
+            const f2_t s3 = sacc + u[k][3];
             sacc = ny > 3 ? s3 : sacc;
             v = sacc * rk;
         }
@@ -3864,14 +3888,18 @@ __device__ __forceinline__ void rt_passes16(const ResampleDesc& d, const int32_t
         {
             v = u[k][0] * tp.wy[0];
             v = v + u[k][1] * tp.wy[1];
-            const float v2 = v + u[k][2] * tp.wy[2];
+            const f2_t v2 = v + u[k][2] * tp.wy[2];
             v = ny > 2 ? v2 : v;
-            const float v3 = v + u[k][3] * tp.wy[3];
+            const f2_t v3 = v + u[k][3] * tp.wy[3];
             v = ny > 3 ? v3 : v;
         }
         if (c < nXo)
         {
-            B[int64_t(xb0 + c) * hb + yb] = v;
+            BA[int64_t(xb0 + c) * hb + yb] = v.x;
+            if (BB)
+            {
+                BB[int64_t(xb0 + c) * hb + yb] = v.y;
+            }
         }
     }
 }
@@ -4241,11 +4269,14 @@ __global__ void __launch_bounds__(RS_NT) k_resample_strip(StripArgs a)
 // LDCF (BASELINE cfg 5: "k 5x5 per-channel decorrelation filters fused into the pyramid kernel"): one workgroup turns a
 // tile of ONE channel plane of one pyramid level into the k filtered AND halved planes of the LDCF pyramid —
 //   C_f = conv2(plane, filter_f, 'same')  (zero padded, taps in k_ldcf_conv's order: dx then dy ascending)
-//   out_f = imResample(C_f, .5)           (the x pass / y pass on a tile in LDS: rt_passes16)
+//   out_f = imResample(C_f, .5)           (the x pass / y pass on a tile in LDS: rt_passes16x2)
 // The plane tile (+2 cells of halo, zeros outside the plane) is read once into LDS, each filter's conv result is
 // written to the LDS source tile of the resample and never reaches HBM: the separate k_ldcf_conv + k_resample pair
 // wrote and re-read k full-resolution copies of the pyramid (760 MB per 4K frame at k = 4).  A job is one output tile of
 // one level (flat list built at plan time: no empty blocks); blockIdx.y = input channel, blockIdx.z = frame.
+// The filters of a channel are taken TWO AT A TIME, as the halves of packed f32 (round 5; rounds 3-4 packed two tile rows of one
+// filter): both filters read the same plane cells, so a cell is read from LDS once for the pair, a thread's cells arrive as
+// 8-byte row pairs, and the pair's results travel through the resample's passes as {filter A, filter B} cells.
 // ------------------------------------------------------------------------
 struct LdcfTileJob
 {
@@ -4256,11 +4287,19 @@ struct LdcfTileJob
     int32_t pad_;
 };
 
+// floats of LDS k_ldcf_tile needs for source tiles of at most maxRows x maxCols cells and xo output columns
+__host__ __device__ inline size_t ldcfTileLdsFloats(int maxRows, int maxCols, int xo)
+{
+    const size_t tP = size_t(maxRows + 1) & ~size_t(1);
+    return 2 * size_t(maxCols) * tP + 2 * size_t(xo) * tP + 8 * size_t(xo) + size_t(maxCols + 4) * (size_t(maxRows + 6) & ~size_t(1)) + 64;
+}
+
+template <int LN, int KX> // LN: output columns per thread of the filter stage (LN + 4 tile columns are read for them); KX: rt_passes16x2's
 __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr, float* __restrict__ out, const float* __restrict__ filt,
     const LdcfTileJob* __restrict__ jobs, const LdcfJob* __restrict__ levels, const ResampleDesc* __restrict__ descs, const int32_t* __restrict__ it,
     const float* __restrict__ ft, int maxRows, int maxCols, int xo, int K, int nChns, int64_t pyr_fs)
 {
-    extern __shared__ float lt_lds[];
+    extern __shared__ __attribute__((aligned(16))) float lt_lds[];
     const LdcfTileJob J = jobs[blockIdx.x];
     const ResampleDesc& d = descs[J.level];
     const LdcfJob L = levels[J.level];
@@ -4273,11 +4312,12 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
     const int rowLo = it[J.tile_y + 2 * J.ytile], rowHi = it[J.tile_y + 2 * J.ytile + 1];
     const int colLo = it[J.tile_x + 2 * J.xtile], colHi = it[J.tile_x + 2 * J.xtile + 1];
     const int nRows = min(rowHi - rowLo + 1, maxRows), nCols = min(colHi - colLo + 1, maxCols);
-    float* T = lt_lds;                              // [nCols][nRows] filtered tile = source tile of the resample
-    float* C = lt_lds + size_t(maxCols) * maxRows;  // [xo][nRows] x-pass columns
-    float* P = C + size_t(xo) * maxRows;            // [nCols + 4][nRows + 4] plane tile with halo
-    int32_t* recL = reinterpret_cast<int32_t*>(P + size_t(maxCols + 4) * (maxRows + 4)); // [xo][8] x-pass column records of this tile
-    const int pR = nRows + 4;
+    const int tP = (maxRows + 1) & ~1;                                        // row pitch of T and C (cells; even: a row pair is 16 aligned bytes)
+    f2_t* T = reinterpret_cast<f2_t*>(lt_lds);                                // [nCols][tP] filtered tile {filter A, filter B} = source tile of the resample
+    f2_t* C = T + size_t(maxCols) * tP;                                       // [xo][tP] x-pass columns
+    int32_t* recL = reinterpret_cast<int32_t*>(C + size_t(xo) * tP);          // [xo][8] x-pass column records of this tile
+    float* P = reinterpret_cast<float*>(recL + 8 * xo);                       // [nCols + 4][pR] plane tile with halo (+ 64 floats of slack behind it)
+    const int pR = (nRows + 6) & ~1;                                          // >= nRows + 5 (the second row of the last pair reads one row further), even
     if (int(threadIdx.x) < 8 * (xb1 - xb0))
     {
         recL[threadIdx.x] = it[d.x_col + 8 * xb0 + threadIdx.x]; // read once: every filter's x pass uses them
@@ -4285,86 +4325,99 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
     const int yb = yb0 + lane;
     const RtTaps tp = rt_taps(d, it, ft, yb, yb1, r);
     const float* __restrict__ A = pyr + int64_t(blockIdx.z) * pyr_fs + L.inOff + int64_t(c) * ha * wa;
-    // LDS-DMA, 64 consecutive tile cells per wave instruction: the whole tile is in flight at once (a load -> ds_write loop
-    // exposed one memory round trip per 256 cells); cells outside the plane are written as zeros by their lanes
-    const int nP = (nCols + 4) * pR;
-    for (int i0 = (threadIdx.x >> 6) * 64; i0 < nP; i0 += 256)
+    // LDS-DMA, 64 consecutive tile cells per wave instruction, the whole tile in flight at once (a load -> ds_write loop exposed one
+    // memory round trip per 256 cells).  Buffer form: a cell outside the plane gets an offset beyond the descriptor's range and
+    // arrives as 0 — no LDS writes between the requests (each one made the compiler drain the requests before it: DESIGN 3.0)
+#ifndef ACF_LDCF_NO_FILL
     {
-        const int i = i0 + lane;
-        const int cc = i / pR, rr = i - cc * pR;
-        const int x = colLo + cc - 2, y = rowLo + rr - 2;
-        const bool ok = x >= 0 && x < wa && y >= 0 && y < ha;
-        if (i < nP)
+        // a wave instruction = 64 rows of ONE padded column: the column's byte offset is scalar, a lane's row offset one of three
+        // values — no per-cell index arithmetic (the flat form spent 42 instructions per request on i / pR)
+        const srd_t Asrd = make_srd(A, int64_t(ha) * wa * 4);
+        const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+        uint32_t yoff[3];
+#pragma unroll
+        for (int part = 0; part < 3; part++)
         {
-            if (ok)
+            const int y = rowLo + 64 * part + lane - 2;
+            yoff[part] = (y >= 0 && y < ha) ? uint32_t(y) * 4u : 0xfffffff0u;
+        }
+        for (int cc = wv; cc < nCols + 4; cc += 4)
+        {
+            const int x = colLo + cc - 2;
+            const bool xok = x >= 0 && x < wa;
+            const uint32_t soff = xok ? uint32_t(x) * uint32_t(ha) * 4u : 0u;
+            float* Pc = P + cc * pR;
+#pragma unroll
+            for (int part = 0; part < 3; part++)
             {
-                __builtin_amdgcn_global_load_lds((gptr_t)(A + int64_t(x) * ha + y), (lptr_t)(P + i0), 4, 0, 0);
-            }
-            else
-            {
-                P[i] = 0.f;
+                if (64 * part + lane < pR) // (the last part's lanes beyond the column write nothing: the next column starts there)
+                {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(Asrd, (lptr_t)(Pc + 64 * part), 4, xok ? yoff[part] : 0xfffffff0u, soff, 0, 0);
+                }
             }
         }
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int f = 0; f < K; f++)
+    const int RPN = (nRows + 1) >> 1; // row pairs of the tile (<= 64)
+    const RtCols<KX> xc = rt_cols<KX>(d, recL, xb1 - xb0, colLo, tP);
+    for (int f = 0; f < K; f += 2)
     {
-        const int pc = f * nChns + c;
-        // 25 taps through the scalar unit (wave-uniform address), kept as 13 VGPR pairs {w[2k], w[2k + 1]}: a packed operation
-        // picks the half it needs for BOTH of its results (op_sel / op_sel_hi), so no {w, w} copies are held
+        const bool haveB = f + 1 < K; // (an odd k: the last pair's second filter has zero taps and is not stored)
+        const int pcA = f * nChns + c, pcB = (haveB ? f + 1 : f) * nChns + c;
+        // 2 x 25 taps through the scalar unit (wave-uniform addresses), kept as 25 VGPR pairs {filter A's tap, filter B's tap}
         typedef const __attribute__((address_space(4))) float* cfp_t;
-        typedef float f2_t __attribute__((ext_vector_type(2)));
-        cfp_t fw = (cfp_t)(uintptr_t)(filt + int64_t(pc) * 25);
-        f2_t wp[13];
+        cfp_t fwA = (cfp_t)(uintptr_t)(filt + int64_t(pcA) * 25), fwB = (cfp_t)(uintptr_t)(filt + int64_t(pcB) * 25);
+        f2_t wp[25];
 #pragma unroll
-        for (int k = 0; k < 13; k++)
+        for (int k = 0; k < 25; k++)
         {
-            wp[k] = f2_t{ fw[2 * k], k < 12 ? fw[2 * k + 1] : 0.f };
+            wp[k] = f2_t{ fwA[k], haveB ? fwB[k] : 0.f };
             asm volatile("" : "+v"(wp[k])); // (in VGPRs: a VALU instruction with an SGPR operand issues at 1.7x the cost of one without)
         }
-        // A thread takes eight consecutive COLUMNS at tile rows rr and rr + 64 (lanes along the rows: conflict-free LDS reads; the
-        // plan keeps a tile within 128 rows x 32 columns, so the workgroup's 256 items are the whole tile).  The two rows are the
-        // halves of packed f32 operations: a column's five cell pairs arrive as ds_read2_b32 {row, row + 64} and every tap is one
-        // v_pk_fma_f32 for both outputs.  Per output the taps are still added dx then dy ascending, as ONE chain of fused
-        // multiply-adds starting from 0 (k_ldcf_conv's order; each half of v_pk_fma_f32 = C's fmaf): columns are therefore
-        // consumed from cc + 11 down to cc — output j meets column q at dx = j + 2 - q —, each read once, two columns ahead of
-        // its use (the scheduling barriers keep three columns live instead of all twelve), and dropped.
-#define LDCF_PKFMA(ACC, V, K)                                                                                                              \
-    if ((K) & 1)                                                                                                                           \
-    {                                                                                                                                      \
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(ACC) : "v"(V), "v"(wp[(K) >> 1]));                    \
-    }                                                                                                                                      \
-    else                                                                                                                                   \
-    {                                                                                                                                      \
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(ACC) : "v"(V), "v"(wp[(K) >> 1]));                    \
+        // A thread takes LN consecutive COLUMNS at the tile's row pair {2 lp, 2 lp + 1} (lanes along the rows: conflict-free 8-byte LDS
+        // reads; the plan keeps a tile within 128 rows x 32 columns, so the workgroup's 256 items are the whole tile at LN = 8).  A column's
+        // six cells (padded rows 2 lp .. 2 lp + 5) arrive as three aligned pairs; a tap is one v_pk_fma_f32 per output cell: the cell's half
+        // of its pair broadcast to both halves (op_sel), times {A's tap, B's tap}.  Per output the taps are still added dx then dy ascending,
+        // as ONE chain of fused multiply-adds starting from 0 (k_ldcf_conv's order; each half of v_pk_fma_f32 = C's fmaf): columns are
+        // therefore consumed from cc + LN + 3 down to cc — output j meets column q at dx = j + 2 - q —, each read once, two columns ahead
+        // of its use (the scheduling barriers keep three columns live), and dropped.
+#define LDCF_PKFMA(ACC, V, HALF, K)                                                                                                      \
+    if ((HALF) & 1)                                                                                                                      \
+    {                                                                                                                                    \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(ACC) : "v"(V), "v"(wp[K]));                          \
+    }                                                                                                                                    \
+    else                                                                                                                                 \
+    {                                                                                                                                    \
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(ACC) : "v"(V), "v"(wp[K]));                          \
     }
-#define LDCF_LOAD(Q)                                                                       \
-    {                                                                                      \
-        const float* pc0 = P + min(cc + (Q), nCols + 3) * pR + rr;                         \
-        _Pragma("unroll") for (int t = 0; t < 5; t++)                                      \
-        {                                                                                  \
-            v[Q][t] = f2_t{ pc0[t], pc0[t + r2] };                                         \
-        }                                                                                  \
+#define LDCF_LOAD(Q)                                                                                                 \
+    {                                                                                                                \
+        const f2_t* pc0 = reinterpret_cast<const f2_t*>(P + min(cc + (Q), nCols + 3) * pR + 2 * lp);                 \
+        v[Q][0] = pc0[0];                                                                                            \
+        v[Q][1] = pc0[1];                                                                                            \
+        v[Q][2] = pc0[2];                                                                                            \
     }
-        constexpr int LN = 8; // output columns per thread: LN + 4 tile columns are read for them (12 for 8; quads read 8 for 4)
+#ifdef ACF_LDCF_NO_CONV
+        const int nQ = 0;
+#else
         const int nQ = (nCols + LN - 1) / LN;
+#endif
         for (int i = threadIdx.x; i < nQ * 64; i += 256)
         {
-            const int cq = i >> 6, rr = i & 63, cc = cq * LN;
-            const bool two = rr + 64 < nRows;
-            const int r2 = two ? 64 : 0; // (no second row: the first one again, never stored)
-            if (rr >= nRows)
+            const int cq = i >> 6, lp = i & 63, cc = cq * LN;
+            if (lp >= RPN)
             {
                 continue;
             }
-            f2_t acc[LN];
+            f2_t acc[LN][2]; // [output column][row of the pair] = {filter A, filter B}
 #pragma unroll
             for (int j = 0; j < LN; j++)
             {
-                acc[j] = f2_t{ 0.f, 0.f };
+                acc[j][0] = acc[j][1] = f2_t{ 0.f, 0.f };
             }
-            f2_t v[LN + 4][5]; // [column cc + q of the padded tile (clamped past its end: never stored)][padded rows rr + t = y - 2 + t]
+            f2_t v[LN + 4][3]; // [column cc + q of the padded tile (clamped past its end: never stored)][padded rows 2 lp + {0 1, 2 3, 4 5}]
             LDCF_LOAD(LN + 3);
             LDCF_LOAD(LN + 2);
 #pragma unroll
@@ -4386,7 +4439,9 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
 #pragma unroll
                     for (int dy = -2; dy <= 2; dy++)
                     {
-                        LDCF_PKFMA(acc[j], v[q][2 - dy], (dx + 2) * 5 + (dy + 2));
+                        // tile row y meets padded row y + 2 - dy: the pair's first row reads cell 2 - dy of the six, its second 3 - dy
+                        LDCF_PKFMA(acc[j][0], v[q][(2 - dy) >> 1], (2 - dy) & 1, (dx + 2) * 5 + (dy + 2));
+                        LDCF_PKFMA(acc[j][1], v[q][(3 - dy) >> 1], (3 - dy) & 1, (dx + 2) * 5 + (dy + 2));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -4396,21 +4451,21 @@ __global__ void __launch_bounds__(256) k_ldcf_tile(const float* __restrict__ pyr
             {
                 if (cc + j < nCols)
                 {
-                    T[(cc + j) * nRows + rr] = acc[j].x;
-                    if (two)
-                    {
-                        T[(cc + j) * nRows + rr + 64] = acc[j].y;
-                    }
+                    // (a last odd row's partner is written too — inside the pitch, never read)
+                    typedef float f4_t __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<f4_t*>(T + (cc + j) * tP + 2 * lp) = f4_t{ acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y };
                 }
             }
         }
 #undef LDCF_LOAD
 #undef LDCF_PKFMA
         __syncthreads();
-        float* __restrict__ B = out + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off + int64_t(pc) * hb * wb;
-        // (no barrier after the y pass: it reads C only, the next filter's conv writes T only, and the x pass that rewrites C
+        float* __restrict__ B0 = out + int64_t(blockIdx.z) * d.dst_frame_stride + d.dst_off;
+        // (no barrier after the y pass: it reads C only, the next pair's conv writes T only, and the x pass that rewrites C
         // comes after the barrier that follows that conv)
-        rt_passes16(d, it, ft, T, C, B, tp, yb, xb0, xb1, rowLo, colLo, nRows, r, rk, recL);
+#ifndef ACF_LDCF_NO_PASSES
+        rt_passes16x2<KX>(d, it, ft, T, C, B0 + int64_t(pcA) * hb * wb, haveB ? B0 + int64_t(pcB) * hb * wb : nullptr, tp, yb, xb0, xb1, rowLo, nRows, tP, r, rk, xc);
+#endif
     }
 }
 

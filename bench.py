@@ -248,7 +248,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2: the metric's; 4, 5: extra bench lines)")
-    ap.add_argument("--batch", type=int, default=0, help="frames per detector context per launch (default: 96 at cfg 2, 192 at cfg 4, 16 at cfg 5)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per detector context per launch (default: 96 at cfg 2, 192 at cfg 4, 24 at cfg 5)")
     ap.add_argument("--contexts", type=int, default=3, help="detector contexts per GPU, each on its own HIP stream; a step runs one batch on each "
                     "(the cascade of one batch overlaps the pyramid of another)")
     ap.add_argument("--frames-total", type=int, default=0, help="cfg 3 as worded: this many frames per step shared by all GPUs (strong scaling); "
@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="sub-batch contexts per GPU (acf_hip_set_option streams): chunks of the batch run concurrently")
     ap.add_argument("--turns", type=int, default=-1, help="A/B: option cascade_turns of every context (default: what DetectorPool sets, 5 with several contexts)")
     ap.add_argument("--persist", type=int, default=-1, help="A/B: option tile_persist of every context (default: what DetectorPool sets, 0 with several contexts)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="A/B: acf_hip_set_option(KEY, INT) on every context (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
@@ -301,7 +302,7 @@ def main():
     dev = torch.device("cuda", local)
     cfg = CONFIGS[args.config]
     H, W, C = cfg["H"], cfg["W"], max(1, args.contexts)
-    B = args.batch or {2: 96, 4: 192, 5: 16}[args.config]
+    B = args.batch or {2: 96, 4: 192, 5: 24}[args.config]
     scaling = "weak"
     if args.frames_total:
         per_gpu = args.frames_total // world
@@ -343,6 +344,8 @@ def main():
             det.set_option("cascade_turns", args.turns)
         if args.persist >= 0:
             det.set_option("tile_persist", args.persist)
+        for kv in args.opt:
+            det.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         if not args.keep_pyramid and args.config != 5:
             det.set_option("keep_pyramid", 0)
         if not args.no_profile:
@@ -511,7 +514,7 @@ def main():
             if not args.no_profile:
                 for d_ in dets:
                     d_.profile()
-    batch8 = None
+    batch8 = batch8_pipe = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_latency and not args.frames_total and B >= 8:
         # one GPU's share of BASELINE cfg 3 AS WORDED (64 frames per step over 8 GPUs = 8 frames per GPU and step): one context,
         # 8 frames per call, the scales' chains beside each other, the call replayed as one HIP graph; submit -> synchronise per step
@@ -530,6 +533,30 @@ def main():
                 dets[0].export_detections(pipes[0].rec[0], args.cap)
                 dets[0].synchronize()
             batch8 = 8 * 20 / (time.perf_counter() - t1)
+        # the same 8-frame calls with consecutive steps in flight at once (every context its own call, no synchronisation between
+        # steps): what a rank sustains when step k+1 is submitted while step k still runs
+        for d_ in dets:
+            d_.set_option("scale_streams", 1)
+            d_.set_option("profile", 0)
+            d_.set_option("cascade_turns", 0)  # (a captured call takes no turns)
+            d_.set_option("graph", 1)
+        def step8():
+            for i in range(C):
+                with torch.cuda.stream(streams[i]):
+                    dets[i].run(frames[i * B:i * B + 8], 8)
+                    dets[i].export_detections(pipes[i].rec[0], args.cap)
+        for _ in range(4):
+            step8()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            step8()
+        torch.cuda.synchronize()
+        batch8_pipe = 8 * C * 20 / (time.perf_counter() - t1)
+        for d_ in dets:
+            d_.set_option("graph", 0)
+            d_.set_option("scale_streams", 0 if C > 1 else 1)
+            d_.set_option("profile", 0 if args.no_profile else 1)
         dets[0].set_option("graph", 0)
         dets[0].set_option("profile", 0 if args.no_profile else 1)
         if not args.no_profile:
@@ -574,6 +601,7 @@ def main():
                        # one GPU's share of cfg 3 as worded (8 frames per GPU and step), measured on this GPU: 8 x this figure bounds what
                        # eight GPUs give for 64 frames per step (the gather of 8 x 772 bytes per rank comes on top)
                        "batch8_fps_1gpu": batch8,
+                       "batch8_pipelined_fps_1gpu": batch8_pipe,   # C contexts x 8 frames in flight, no synchronisation between steps
                        "cfg3_as_worded_8gpu_estimate_fps": (8 * batch8) if batch8 else None,
                        # the Pyramid-returning call (float levels written as well as the rank cells), same steps, timed the same way
                        "keep_pyramid_fps": keep_fps,
