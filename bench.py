@@ -534,12 +534,13 @@ def main():
                 dets[0].synchronize()
             batch8 = 8 * 20 / (time.perf_counter() - t1)
         # the same 8-frame calls with consecutive steps in flight at once (every context its own call, no synchronisation between
-        # steps): what a rank sustains when step k+1 is submitted while step k still runs
+        # steps, the headline's settings: plain launches, a context's scales on its one stream, the cascades taking turns): what a
+        # rank sustains when step k+1 is submitted while step k still runs
+        dets[0].set_option("graph", 0)
         for d_ in dets:
-            d_.set_option("scale_streams", 1)
+            d_.set_option("scale_streams", 0 if C > 1 else 1)
             d_.set_option("profile", 0)
-            d_.set_option("cascade_turns", 0)  # (a captured call takes no turns)
-            d_.set_option("graph", 1)
+            d_.set_option("cascade_turns", args.turns if args.turns >= 0 else (5 if C > 1 else 0))
         def step8():
             for i in range(C):
                 with torch.cuda.stream(streams[i]):
@@ -554,8 +555,6 @@ def main():
         torch.cuda.synchronize()
         batch8_pipe = 8 * C * 20 / (time.perf_counter() - t1)
         for d_ in dets:
-            d_.set_option("graph", 0)
-            d_.set_option("scale_streams", 0 if C > 1 else 1)
             d_.set_option("profile", 0 if args.no_profile else 1)
         dets[0].set_option("graph", 0)
         dets[0].set_option("profile", 0 if args.no_profile else 1)
