@@ -22,3 +22,14 @@ def test_random_cases_match_the_oracle(seed):
     words = last.split()
     ran, checked = int(words[words.index("ran") + 1]), int(words[words.index("frames_checked") + 1])
     assert ran >= 10 and checked >= ran, last
+
+
+def test_random_ldcf_cases_match_the_oracle():
+    """tests/fuzz_ldcf.py: the LDCF post-stage (k_ldcf_tile) on random frame sizes, k = 1 .. 5, strides, scales per octave."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_ldcf.py"), "11", "16"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("cases 16") and last.endswith("mismatches 0"), out.stdout[-2000:]
+    words = last.split()
+    ran, checked = int(words[words.index("ran") + 1]), int(words[words.index("frames_checked") + 1])
+    assert ran >= 8 and checked >= ran, last
