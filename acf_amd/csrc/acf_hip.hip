@@ -233,6 +233,7 @@ struct acf_hip_ctx
     // at 64+ on frames with black and flat bands); at 96 frames per launch 48 / 64 / 96 columns cost the same (0.36-0.38 ms)
     int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 64, smoothForceRedo = 0; // (profiles/r03_repair_rates.json: no repair from 64 columns on)
     float *d_specState = nullptr, *d_trueState = nullptr;
+    bool countersZeroed = false; // acf_hip_run has cleared the tiled cascade's counters in front of the pyramid's launches
     int32_t* d_redo = nullptr;
     // the same for the level chains (k_level_all<OUT, 1>), for batches of at most levelSegFrames frames
     float *d_lvSpec = nullptr, *d_lvTrue = nullptr;
@@ -2966,6 +2967,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             return rc;
         }
+        HIPCHK(c, hipMemset(c->d_redo, 0, sizeof(int32_t) * size_t(B) * d)); // (zero between calls: the repair launch takes its flags down)
     }
     {
         // k_level_all's column segments: only small batches are bound by a level's chain length
@@ -2978,6 +2980,7 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             return rc;
         }
+        HIPCHK(c, hipMemset(c->d_lvRedo, 0, sizeof(int32_t) * size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns));
     }
     // cascade
     // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
@@ -3739,10 +3742,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     }
                 };
                 const int nSegMax = std::max(nSeg, wantGrad ? nSegG : nSeg);
-                if (nSegMax > 1)
-                {
-                    HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * size_t(nF) * d, c->stream));
-                }
+                // (the repair flags are zero here: set by k_smooth_verify, taken down by the repair launch that reads them)
                 launchSv(dim3(d, nSeg, nF));
                 LAUNCHCHK(c, "k_smooth_vec");
                 if (nSegMax > 1)
@@ -3985,7 +3985,6 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     {                                                                                                                       \
         if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT, 1>), ldsL)))                                  \
             return rc;                                                                                                      \
-        HIPCHK(c, hipMemsetAsync(c->d_lvRedo, 0, sizeof(int32_t) * size_t(nLF) * nAll * pl.nChns, c->stream));              \
         hipLaunchKernelGGL((k_level_all<OUT, 1>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd, \
             (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa); \
         hipLaunchKernelGGL(k_level_verify, dim3(nAll * nSegL, pl.nChns, nLF), dim3(64), 0, c->stream, (const float*)c->d_lvSpec,  \
@@ -4368,7 +4367,10 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
     const acf_hip_params& p = c->p;
     const CascState& cs = c->cs;
     const TileGeom& g = cs.geom;
-    HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * (2 * size_t(c->maxBatch) + 8), c->stream));
+    if (!c->countersZeroed)
+    {
+        HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * (2 * size_t(c->maxBatch) + 8), c->stream));
+    }
     TileArgs a{};
     a.pyr = pyr;
     a.pyr_fs = pyr_fs;
@@ -4676,7 +4678,10 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
         // (options changed between acf_hip_pyramid and acf_hip_detect: the float cells this path reads were never written)
         return fail(c, ACF_HIP_E_INVALID, "detect: the float pyramid of this batch was not written (keep_pyramid = 0) and the selected cascade reads floats");
     }
-    HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
+    if (!c->countersZeroed)
+    {
+        HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
+    }
     if (c->cs.useTiles && !c->noTiles)
     {
         int rc = runCascadeTiled(c, pyr, pyr_fs, nF, nChns);
@@ -5105,6 +5110,23 @@ static void graphRunState(acf_hip_ctx* c, const acf_hip_ctx::GraphSlot& gs)
     c->countsFetched = false; // the counts on the host are the previous run's
 }
 
+// acf_hip_run knows that the cascade follows the pyramid: the tiled cascade's counters (hit counts; its queue's count and head and the
+// tile counters) are cleared in front of the pyramid's launches instead of between the level kernel and the cascade, where a single
+// frame waits for every node of the chain (runCascade / runCascadeTiled then skip their own memsets)
+static int preZeroCounters(acf_hip_ctx* c, int nF)
+{
+    if (!c || !c->hasPlan || !c->kids.empty() || !(c->cs.useTiles && !c->noTiles) || c->p.ldcfK > 0 || !c->cs.d_counts || !c->cs.d_qcounts || nF <= 0 ||
+        nF > c->maxBatch)
+    {
+        return ACF_HIP_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->cs.d_qcounts, 0, sizeof(int32_t) * (2 * size_t(c->maxBatch) + 8), c->stream));
+    c->countersZeroed = true;
+    return ACF_HIP_OK;
+}
+
 int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
 {
     if (c && !c->kids.empty())
@@ -5160,11 +5182,16 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
         int rcc = ACF_HIP_OK;
         if (ok)
         {
-            rcc = acf_hip_pyramid(c, frames, nF);
+            rcc = preZeroCounters(c, nF);
+            if (!rcc)
+            {
+                rcc = acf_hip_pyramid(c, frames, nF);
+            }
             if (!rcc)
             {
                 rcc = acf_hip_detect(c);
             }
+            c->countersZeroed = false;
             ok = hipStreamEndCapture(c->stream, &g) == hipSuccess && g != nullptr && !rcc;
         }
         if (ok)
@@ -5190,12 +5217,21 @@ int acf_hip_run(acf_hip_ctx* c, const float* frames, int nF)
         gs = acf_hip_ctx::GraphSlot();
         c->graphBroken = 1; // (fall through: the plain path below does the work)
     }
-    int rc = acf_hip_pyramid(c, frames, nF);
+    int rc = preZeroCounters(c, nF);
+    if (!rc)
+    {
+        rc = acf_hip_pyramid(c, frames, nF);
+    }
     if (rc)
     {
+        if (c)
+        {
+            c->countersZeroed = false;
+        }
         return rc;
     }
     rc = acf_hip_detect(c);
+    c->countersZeroed = false;
     if (!rc && c)
     {
         c->plainRuns++;

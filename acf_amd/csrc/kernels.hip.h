@@ -651,7 +651,7 @@ struct SmoothVecArgs
     int32_t segStride;   // segments per plane in the state buffers (>= nSeg: the two launches of a scale may cut their planes differently)
     float* specState; // [frame][plane][segment][h]: a segment's state after its warm-up = its guess of column x0 - 1
     float* trueState; // [frame][plane][segment][h]: the previous segment's output column x0 - 1
-    const int32_t* redo; // repair launch (nSeg == 1): [frame][plane] != 0 -> this plane is recomputed as one segment; NULL: every plane
+    int32_t* redo;       // repair launch (nSeg == 1): [frame][plane] != 0 -> this plane is recomputed as one segment; NULL: every plane
     int32_t skipZ;       // >= 0: this launch leaves plane skipZ out (k_smooth_grad runs it); blockIdx.x counts the others
     // GRAD (k_smooth_grad): gradMag of the smoothed plane from the chain's registers — M and O of column i - 1 leave when
     // column i has been smoothed; the smoothed plane itself is then only written where a later scale is resampled from it
@@ -1011,9 +1011,19 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_vec(SmoothVecArgs a, ui
     {
         z++; // (that plane is k_smooth_grad's)
     }
-    if (a.redo && a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+    if (a.redo)
     {
-        return; // repair launch: this plane's segments agreed
+        // repair launch (one workgroup per plane and frame): nothing to do when the plane's segments agreed; otherwise the flag is
+        // taken down again for the next call — the flags are zero between calls, so no launch has to clear them first
+        if (a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+        {
+            return;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            a.redo[int64_t(blockIdx.z) * a.nPlanes + z] = 0;
+        }
     }
     if ((fullMask >> z) & 1u)
     {
@@ -1034,9 +1044,17 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, u
 {
     extern __shared__ float lds[]; // the waves' edge state (k_smooth_vec), then the acos table
     const int z = a.plane0;
-    if (a.redo && a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+    if (a.redo)
     {
-        return;
+        if (a.redo[int64_t(blockIdx.z) * a.nPlanes + z] == 0)
+        {
+            return;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            a.redo[int64_t(blockIdx.z) * a.nPlanes + z] = 0; // (k_smooth_vec)
+        }
     }
     float* acosL = lds + 2 * SV_MAXW * 2 * SV_K * 4;
     for (int i = threadIdx.x; i < GM_ACOS_N; i += blockDim.x)
@@ -3511,7 +3529,7 @@ struct LevelSegArgs
     int32_t nSeg, warm, hMax, nJobs;
     float* spec;          // [frame][job][channel][segment][hMax]
     float* tru;
-    const int32_t* redo;  // repair launch (nSeg == 1): [frame][job][channel] != 0 -> recompute this plane; NULL: every plane
+    int32_t* redo;        // repair launch (nSeg == 1): [frame][job][channel] != 0 -> recompute this plane; NULL: every plane
 };
 template <int OUT, int SEG>
 __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(4))) k_level_all(const float* __restrict__ chns, float* __restrict__ pyr, float* __restrict__ rawOut,
@@ -3545,9 +3563,18 @@ __global__ void __launch_bounds__(64 * LEVEL_WAVES) __attribute__((amdgpu_waves_
     if (SEG)
     {
         const int64_t plane = (int64_t(f) * sa.nJobs + job) * nChns + blockIdx.x;
-        if (sa.redo && sa.redo[plane] == 0)
+        if (sa.redo)
         {
-            return; // repair launch: this plane's segments agreed
+            // repair launch (one wave per plane): nothing to do when the plane's segments agreed; otherwise the flag is taken down
+            // again for the next call (the flags are zero between calls: no launch clears them first)
+            if (sa.redo[plane] == 0)
+            {
+                return;
+            }
+            if ((threadIdx.x & 63) == 0)
+            {
+                sa.redo[plane] = 0;
+            }
         }
         const int seg = int(blockIdx.z) - job * sa.nSeg;
         const int nSegJ = max(1, min(sa.nSeg, J.wC / (2 * sa.warm)));
