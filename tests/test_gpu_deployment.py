@@ -53,3 +53,30 @@ def test_three_contexts_detection_only_with_device_nms():
     assert n == 6
     assert sum(int(r[:, 0].sum()) for r in recs) > 0
     pool.close()
+
+
+def test_bench_line_contract():
+    """`python bench.py` (a small step: 2 contexts x 8 frames, no CPU leg) prints ONE JSON line with the fields the driver reads: the
+    metric and unit, value = frames of the timed steps / time, the repeats, the roofline block with its kernel, the as-worded figures."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--contexts", "2", "--batch", "8", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("detector FPS @1080p") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert len(d["value_repeats"]) == 3 and d["value_min"] <= d["value_median"] <= d["value_max"]
+    assert d["verified_frames"] == 3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    cfg = d["config"]
+    assert "workload" in cfg and cfg["contexts"] == 2 and cfg["frames_per_launch"] == 8
+    assert cfg["batch8_fps_1gpu"] > 0 and cfg["batch8_pipelined_fps_1gpu"] > 0 and d["latency_ms_batch1"] > 0
+    assert d["cpu_baseline"] is None or "value" in d["cpu_baseline"]
