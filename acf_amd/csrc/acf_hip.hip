@@ -144,6 +144,16 @@ struct acf_hip_ctx
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
     // (k_smooth_grad) where that pays (big planes, many frames), 2 = wherever k_smooth_grad applies
     int fusedGrad = getenv("ACF_HIP_NO_FUSED_GRAD") ? 0 : (getenv("ACF_HIP_FUSED_GRAD") ? atoi(getenv("ACF_HIP_FUSED_GRAD")) : 1);
+    // option "fused_tri": convTri's x pass over M inside that chain as well (k_smooth_grad_tri; the gradient plane is then ONE segment):
+    // 0 = never (k_tri_x5v), 1 = where k_smooth_grad runs in batches of >= 64 frames of a context that shares its device, 2 = wherever
+    // k_smooth_grad runs
+    int fusedTri = getenv("ACF_HIP_FUSED_TRI") ? atoi(getenv("ACF_HIP_FUSED_TRI")) : 1;
+    // option "shared_device": this context runs beside other contexts on the same device (the pools set it).  Kernel forms are then
+    // chosen for the least WORK instead of the shortest time alone: a lone context cuts the smoothing chains into segments to fill the
+    // machine (20 % more columns, a verify and a repair launch per scale) and keeps the x pass a kernel of its own; beside other
+    // contexts a thin chain's latency is covered by their kernels and only its work counts (3 x 96 frames at 1080p: +4.3 % frames/s;
+    // alone, 96 frames: -7 %)
+    int sharedDevice = getenv("ACF_HIP_SHARED_DEVICE") ? atoi(getenv("ACF_HIP_SHARED_DEVICE")) : 0;
     // option "tile_persist": the pooled tile kernel runs as persistent workgroups that draw tiles from a counter (best alone on the
     // device: -8 % on that kernel) or one short-lived workgroup per tile (best beside other contexts' kernels, which then find free LDS)
     int tilePersist = getenv("ACF_HIP_TILE_PERSIST") ? atoi(getenv("ACF_HIP_TILE_PERSIST")) : 1;
@@ -630,8 +640,9 @@ static TriPlan triPlan(const float* in, const float* U, int h, int w, int rad, i
 
 // uCapacity / moCapacity: floats per frame the U and the M, O buffers hold (>= fs); blocked: M and O ARE in the blocked layout
 // (the caller ran k_grad_mag_vec<true> after asking triPlan)
+// xDone: U is there already (k_smooth_grad_tri wrote it, blocked)
 int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w, int rad, int64_t fs, int nFrames, ChnsArgs* fuse = nullptr,
-    bool* fused = nullptr, int64_t uCapacity = 0, int64_t moCapacity = 0, bool blocked = false)
+    bool* fused = nullptr, int64_t uCapacity = 0, int64_t moCapacity = 0, bool blocked = false, bool xDone = false)
 {
     if (rad > 15)
     {
@@ -645,6 +656,15 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     const bool vecX = tp.vecX, doFuse = tp.doFuse, ut = blocked;
     const int nyb = (h + 8 + 15) / 16, nybM = (h + 15) / 16;
     const int64_t ufs = uBlockedFloats(h, w), mfs = moBlockedFloats(h, w);
+    if (xDone)
+    {
+        if (!ut || !doFuse)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "convTri: the x pass rode on the smoothing chain, but the y pass does not read its blocks");
+        }
+    }
+    else
+    {
     prof(c, "k_tri_x");
     if (vecX)
     {
@@ -662,6 +682,7 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
         hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
     }
     LAUNCHCHK(c, "k_tri_x");
+    }
     if (fused)
     {
         *fused = false;
@@ -1156,6 +1177,16 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "fused_grad"))
     {
         c->fusedGrad = value;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "fused_tri"))
+    {
+        c->fusedTri = value;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "shared_device"))
+    {
+        c->sharedDevice = value != 0;
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "cascade_tiles"))
@@ -2461,6 +2492,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             k->countRepairs = c->countRepairs;
             k->noFusedSmooth = c->noFusedSmooth;
             k->fusedGrad = c->fusedGrad;
+            k->fusedTri = c->fusedTri;
+            k->sharedDevice = c->sharedDevice;
             k->noFused = c->noFused;
             k->levelMode = c->levelMode;
             k->scaleStreams = c->scaleStreams;
@@ -3554,6 +3587,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
         bool colorDone = false;
         bool gradFused = false, gradBlocked = false; // M and O written by k_smooth_grad, in blocks
+        bool triXFused = false;                      // ... and U by k_smooth_grad_tri
         const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 4 == 0 && rs.w >= 16 &&
             rs.h / 4 <= SV_MAXW * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
         if (fuseSm)
@@ -3615,6 +3649,10 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 const int warm = std::max(16, c->smoothWarm);
                 auto segmentsFor = [&](int planesOf, int& segW_) {
                     int n = c->smoothSegments;
+                    if (n == 0 && c->sharedDevice && nF >= 64)
+                    {
+                        n = 1; // (beside other contexts: the plain chain — no warm-up columns, nothing to verify or repair)
+                    }
                     if (n == 0)
                     {
                         const int64_t waves = int64_t(std::max(planesOf, 1)) * nF * (nt / 64);
@@ -3672,6 +3710,16 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     {
                         fullMask &= ~(1u << p.colorChn);
                     }
+                    // convTri's x pass on the same chain: running sums have no warm-up, so the gradient plane is then one segment
+                    // (96 workgroups for 96 frames: slower alone, faster beside other contexts' kernels — DESIGN.md 3.0)
+                    static const int triMinF = getenv("ACF_HIP_FUSED_TRI_MINF") ? atoi(getenv("ACF_HIP_FUSED_TRI_MINF")) : 64;
+                    if (blocked0 && p.normRad == 5 && rs.w >= 48 && nt <= 512 && (c->fusedTri >= 2 || (c->fusedTri == 1 && c->sharedDevice && nF >= triMinF)))
+                    {
+                        triXFused = true;
+                        sa.tU = rs.U;
+                        sa.u_fs = uBlockedFloats(rs.h, rs.w);
+                        sa.nybU = (rs.h + 8 + 15) / 16;
+                    }
                 }
                 // the two launches cut their planes on their own: the gradient plane's launch has a third of the chains (more
                 // segments), the other planes' launch two thirds; ACF_HIP_GRAD_SEGMENTS = n fixes the former's (A/B)
@@ -3681,7 +3729,12 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     static const int gradSegEnv = getenv("ACF_HIP_GRAD_SEGMENTS") ? atoi(getenv("ACF_HIP_GRAD_SEGMENTS")) : 0;
                     nSeg = segmentsFor(d - 1, segW);
                     nSegG = segmentsFor(1, segWG);
-                    if (gradSegEnv > 0)
+                    if (triXFused)
+                    {
+                        nSegG = 1;
+                        segWG = cdiv(rs.w, 16) * 16;
+                    }
+                    else if (gradSegEnv > 0)
                     {
                         nSegG = std::max(1, std::min(gradSegEnv, std::min(c->segCap, rs.w / 16)));
                         segWG = cdiv(cdiv(rs.w, nSegG), 16) * 16;
@@ -3692,11 +3745,21 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     sa.segStride = std::max(nSeg, nSegG);
                 }
                 const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float);
+                if (wantGrad && d == 1 && triXFused)
+                {
+                    nSeg = nSegG = 1; // (one launch: the gradient plane's)
+                    segW = segWG = cdiv(rs.w, 16) * 16;
+                    sa.segW = segW;
+                    sa.nSeg = 1;
+                    sa.segStride = 1;
+                }
                 if (wantGrad)
                 {
                     int rcl = 0;
                     if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true>), ldsG)) ||
-                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false>), ldsG)))
+                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false>), ldsG)) ||
+                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<true>), ldsG)) ||
+                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<false>), ldsG)))
                     {
                         return rcl;
                     }
@@ -3717,7 +3780,22 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                                 grid.y = unsigned(nSegG);
                             }
                         }
-                        if (halfNext)
+                        if (sa.redo && nSegG == 1)
+                        {
+                            // (nothing to repair: the plane was one chain)
+                        }
+                        else if (triXFused)
+                        {
+                            if (halfNext)
+                            {
+                                hipLaunchKernelGGL((k_smooth_grad_tri<true>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                            }
+                            else
+                            {
+                                hipLaunchKernelGGL((k_smooth_grad_tri<false>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                            }
+                        }
+                        else if (halfNext)
                         {
                             hipLaunchKernelGGL((k_smooth_grad<true>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
                         }
@@ -3869,7 +3947,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             // convTri(M, normRad): x running sums, then the y pass — fused with the channel cells when the level allows it
             // (S then never reaches HBM), else S is written for k_chns
             if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, (shrink == 4 && !c->taps) ? &a : nullptr, &cellsDone, rs.uFloats, rs.moFloats,
-                     blockedMO)))
+                     blockedMO, triXFused)))
             {
                 return rc;
             }

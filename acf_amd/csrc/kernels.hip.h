@@ -660,6 +660,10 @@ struct SmoothVecArgs
     const float* acos;   // GM_ACOS_N floats (index 0 of the table = entry 10010)
     int64_t mo_fs;       // frame stride of M / O in floats
     int32_t nybM, full;
+    // TRIX (k_smooth_grad_tri): convTri's x pass (r = 5) over M rides on the same chain — U leaves in k_tri_x5v<true>'s blocked layout
+    float* tU;           // [frame] U blocks
+    int64_t u_fs;        // frame stride of U in floats
+    int32_t nybU;        // (h + 8 + 15) / 16
 };
 
 __device__ __forceinline__ float wave_rol1(float v)
@@ -754,7 +758,7 @@ __global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigne
         atomicMin(&bad[1], lo);
     }
 }
-template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false>
+template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false, bool TRIX = false>
 __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
@@ -789,12 +793,77 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         gMq = a.gM + f * a.mo_fs + qo;
         gOq = a.gO + f * a.mo_fs + qo;
     }
+    // TRIX: convTri's x pass over M (convConst.cpp:347-442 with r = 5, s = 1; k_tri_x5v's arithmetic per row: T += Il + Ir - 2 * Im,
+    // U += nrm * T) on the chain that produces M — ONE segment only (running sums have no warm-up).  M's column c enters a ring of
+    // sixteen columns (slot c & 15: static, the loop advances 16 columns per iteration and I0 % 16 is the chunk's PH) and at once
+    // pays for output column j = c - 5 = {M[c - 12], M[c - 6], M[c]}.  The head: column 0 when M[0..5] are there (c == 5), and the
+    // reflected left taps of j = 1 .. 6 (M[6 - j]) are put into the slots those steps read (10 .. 15: written with their own
+    // columns only later).  The last six columns (right taps reflected) re-read M from memory behind the chain.
+    float4 ring[16];
+    float tT[4] = { 0.f, 0.f, 0.f, 0.f }, tUu[4] = { 0.f, 0.f, 0.f, 0.f };
+    float* __restrict__ tUq = nullptr;
+    const float triN = 1.0f / (6 * 6 * 6 * 6);
+    if (TRIX)
+    {
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+        {
+            ring[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        tUq = a.tU + f * a.u_fs + int64_t(((uint32_t(4 * qc + 8) >> 4) << 10) + (uint32_t(4 * qc + 8) & 15u));
+    }
+#define SV_TRI_ADDR(col) (tUq + int64_t((((uint32_t(col) >> 6) * uint32_t(a.nybU)) << 10) + ((uint32_t(col) & 63u) << 4)))
+#define SV_TRI_STEP(A_, B_, C_, J_, OKJ_)                                                          \
+    {                                                                                             \
+        const float a4_[4] = { A_.x, A_.y, A_.z, A_.w };                                          \
+        const float b4_[4] = { B_.x, B_.y, B_.z, B_.w };                                          \
+        const float c4_[4] = { C_.x, C_.y, C_.z, C_.w };                                          \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
+        {                                                                                         \
+            tT[k] += a4_[k] + b4_[k] - 2 * c4_[k];                                                \
+            tUu[k] += triN * tT[k];                                                               \
+        }                                                                                         \
+        *reinterpret_cast<float4*>((valid && (OKJ_)) ? SV_TRI_ADDR(J_) : a.dump + 4 * lane) = make_float4(tUu[0], tUu[1], tUu[2], tUu[3]); \
+    }
+    // M's column x_ (slot SLOT = x_ & 15, compile-time) has just been computed
+#define SV_TRI_PUSH(SLOT, x_, mo)                                                                 \
+    {                                                                                             \
+        constexpr int s_ = (SLOT);                                                                \
+        const float4 mv_ = make_float4(mo[0], mo[1], mo[2], mo[3]);                               \
+        ring[s_] = mv_;                                                                           \
+        /* (slots <= 5 and 15 are also those of the chain's first columns, where there is no output column yet) */ \
+        SV_TRI_STEP(ring[(s_ - 12) & 15], mv_, ring[(s_ - 6) & 15], (x_) - 5, (s_ <= 5 || s_ == 15) ? (x_) >= 6 : true) \
+        if (s_ == 5 && (x_) == 5)                                                                 \
+        {                                                                                         \
+            const float4 e0_ = ring[0];                                                           \
+            tT[0] = tUu[0] = e0_.x, tT[1] = tUu[1] = e0_.y, tT[2] = tUu[2] = e0_.z, tT[3] = tUu[3] = e0_.w; \
+            _Pragma("unroll") for (int m_ = 1; m_ < 6; m_++)                                      \
+            {                                                                                     \
+                const float e_[4] = { ring[m_].x, ring[m_].y, ring[m_].z, ring[m_].w };           \
+                _Pragma("unroll") for (int k = 0; k < 4; k++)                                     \
+                {                                                                                 \
+                    tT[k] += e_[k];                                                               \
+                    tUu[k] += tT[k];                                                              \
+                }                                                                                 \
+            }                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < 4; k++)                                         \
+            {                                                                                     \
+                tUu[k] = triN * (2 * tUu[k] - tT[k]);                                             \
+                tT[k] = 0;                                                                        \
+            }                                                                                     \
+            *reinterpret_cast<float4*>(valid ? SV_TRI_ADDR(0) : a.dump + 4 * lane) = make_float4(tUu[0], tUu[1], tUu[2], tUu[3]); \
+            _Pragma("unroll") for (int m_ = 0; m_ < 6; m_++)                                      \
+            {                                                                                     \
+                ring[10 + m_] = ring[5 - m_];                                                     \
+            }                                                                                     \
+        }                                                                                         \
+    }
     float4 c0[SV_CH], c1[SV_CH];
     // gradMag of smoothed column X (gradientMex.cpp:17-87,168-251; k_grad_mag_vec's arithmetic per pixel): LFT / CUR / RGT =
     // the lane's quad in columns max(X - 1, 0), X, min(X + 1, w - 1).  The rows above and below the quad are the
     // neighbouring lanes' (halo lanes hold the neighbouring waves' quads: exact for the nearest row at every step, see
     // SV_REFRESH).  OK_: wave-uniform, false = compute but store to the dump slot (no branch in the column loop).
-#define SV_GRAD(X, LFT, CUR, RGT, OK_)                                                            \
+#define SV_GRAD(X, LFT, CUR, RGT, OK_, SLOT)                                                         \
     {                                                                                             \
         const int x_ = (X);                                                                       \
         const float rx = (x_ == 0 || x_ == w - 1) ? 1.f : .5f;                                    \
@@ -826,6 +895,10 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         const bool st_ = valid && (OK_);                                                          \
         *reinterpret_cast<float4*>(st_ ? gMq + co : a.dump + 4 * lane) = make_float4(mo[0], mo[1], mo[2], mo[3]); \
         *reinterpret_cast<float4*>(st_ ? gOq + co : a.dump + 4 * lane) = make_float4(oo[0], oo[1], oo[2], oo[3]); \
+        if (TRIX && (SLOT) >= 0)                                                                  \
+        {                                                                                         \
+            SV_TRI_PUSH((SLOT) & 15, x_, mo)                                                      \
+        }                                                                                         \
     }
 #define SV_LOAD(BUF, I0)                                                                          \
     _Pragma("unroll") for (int j = 0; j < SV_CH; j++)                                             \
@@ -833,7 +906,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         BUF[j] = *reinterpret_cast<const float4*>(I + int64_t(min((I0) + j, w - 1)) * h);         \
     }
     // column i = I0 + JJ (JJ compile-time, I0 % 8 == 0): CUR = column i, NXT = column min(i+1, w-1)
-#define SV_COL(EMIT, I0, JJ, CUR, NXT)                                                            \
+#define SV_COL(EMIT, I0, JJ, CUR, NXT, PH)                                                           \
     {                                                                                             \
         const int i_ = (I0) + (JJ);                                                               \
         const float im[4] = { CUR.x, CUR.y, CUR.z, CUR.w };                                       \
@@ -885,7 +958,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             /* column i - 1: left neighbour pp (for column 0: itself, see below), right neighbour o = column i; the    */ \
             /* segment's first step has no column i - 1 of its own (the previous segment's extra step emits it):      */ \
             /* computed, not stored                                                                                   */ \
-            SV_GRAD(i_ - 1, pp, prev, o, i_ > x0)                                                 \
+            SV_GRAD(i_ - 1, pp, prev, o, i_ > x0, ((JJ) - 1 + (PH)) & 15)                                             \
         }                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
         {                                                                                         \
@@ -913,9 +986,10 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             prev[0] = v_.x, prev[1] = v_.y, prev[2] = v_.z, prev[3] = v_.w;                       \
         }                                                                                         \
     }
-#define SV_CHUNK(EMIT, I0, A_, B_)                                                                \
-    SV_COL(EMIT, I0, 0, A_[0], A_[1]) SV_COL(EMIT, I0, 1, A_[1], A_[2]) SV_COL(EMIT, I0, 2, A_[2], A_[3]) SV_COL(EMIT, I0, 3, A_[3], A_[4]) \
-    SV_COL(EMIT, I0, 4, A_[4], A_[5]) SV_COL(EMIT, I0, 5, A_[5], A_[6]) SV_COL(EMIT, I0, 6, A_[6], A_[7]) SV_COL(EMIT, I0, 7, A_[7], B_[0]) \
+    // PH = I0 % 16 (compile-time: TRIX's ring slots; the loops below advance 16 columns per iteration from a multiple of 16)
+#define SV_CHUNK(EMIT, I0, A_, B_, PH)                                                            \
+    SV_COL(EMIT, I0, 0, A_[0], A_[1], PH) SV_COL(EMIT, I0, 1, A_[1], A_[2], PH) SV_COL(EMIT, I0, 2, A_[2], A_[3], PH) SV_COL(EMIT, I0, 3, A_[3], A_[4], PH) \
+    SV_COL(EMIT, I0, 4, A_[4], A_[5], PH) SV_COL(EMIT, I0, 5, A_[5], A_[6], PH) SV_COL(EMIT, I0, 6, A_[6], A_[7], PH) SV_COL(EMIT, I0, 7, A_[7], B_[0], PH) \
     SV_REFRESH(I0)
     const int64_t stateOff = ((f * a.nPlanes + z) * a.segStride) * int64_t(h) + 4 * qc;
     SV_LOAD(c0, xs);
@@ -924,9 +998,9 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     for (; i < x0; i += 2 * SV_CH)
     {
         SV_LOAD(c1, i + SV_CH);
-        SV_CHUNK(false, i, c0, c1);
+        SV_CHUNK(false, i, c0, c1, 0);
         SV_LOAD(c0, i + 2 * SV_CH);
-        SV_CHUNK(false, i + SV_CH, c1, c0);
+        SV_CHUNK(false, i + SV_CH, c1, c0, 8);
     }
     if (seg > 0 && valid)
     {
@@ -935,26 +1009,26 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     for (; i + 2 * SV_CH <= x1; i += 2 * SV_CH)
     {
         SV_LOAD(c1, i + SV_CH);
-        SV_CHUNK(true, i, c0, c1);
+        SV_CHUNK(true, i, c0, c1, 0);
         SV_LOAD(c0, i + 2 * SV_CH); // clamped to the last column past the end
-        SV_CHUNK(true, i + SV_CH, c1, c0);
+        SV_CHUNK(true, i + SV_CH, c1, c0, 8);
     }
     // what is left of the last segment: a chunk (w % 16 >= 8) and / or four columns (w % 8 == 4; column w - 1's right
     // neighbour is itself: the loads are clamped to w - 1)
-#define SV_TAIL4(I0, A_) SV_COL(true, I0, 0, A_[0], A_[1]) SV_COL(true, I0, 1, A_[1], A_[2]) SV_COL(true, I0, 2, A_[2], A_[3]) SV_COL(true, I0, 3, A_[3], A_[4])
+#define SV_TAIL4(I0, A_, PH) SV_COL(true, I0, 0, A_[0], A_[1], PH) SV_COL(true, I0, 1, A_[1], A_[2], PH) SV_COL(true, I0, 2, A_[2], A_[3], PH) SV_COL(true, I0, 3, A_[3], A_[4], PH)
     if (i + SV_CH <= x1)
     {
         SV_LOAD(c1, i + SV_CH);
-        SV_CHUNK(true, i, c0, c1);
+        SV_CHUNK(true, i, c0, c1, 0);
         i += SV_CH;
         if (i < x1)
         {
-            SV_TAIL4(i, c1);
+            SV_TAIL4(i, c1, 8);
         }
     }
     else if (i < x1)
     {
-        SV_TAIL4(i, c0);
+        SV_TAIL4(i, c0, 0);
     }
 #undef SV_TAIL4
     if (seg + 1 < a.nSeg && valid)
@@ -968,7 +1042,19 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         // holds the input columns x1, x1 + 1 (segW is a multiple of 16: the loop's last prefetch) — for nothing else.
         if (x1 == w)
         {
-            SV_GRAD(w - 1, pp, prev, prev, true)
+            SV_GRAD(w - 1, pp, prev, prev, true, -1)
+            if (TRIX)
+            {
+                // output columns w - 6 .. w - 1: M's columns back from memory (each lane re-reads what it wrote itself); the right tap
+                // of column j > w - 6 is the reflected M[2w - 6 - j] (convConst.cpp:408-411)
+#define SV_TRI_LD(col) (*reinterpret_cast<const float4*>(gMq + (a.nybM > 0 ? int64_t((((uint32_t(col) >> 6) * uint32_t(a.nybM)) << 10) + ((uint32_t(col) & 63u) << 4)) : int64_t(col) * h)))
+                for (int j = w - 6; j < w; j++)
+                {
+                    const float4 ta = SV_TRI_LD(j - 7), tc = SV_TRI_LD(j - 1), tb = SV_TRI_LD(j > w - 6 ? 2 * w - 6 - j : j + 5);
+                    SV_TRI_STEP(ta, tb, tc, j, true)
+                }
+#undef SV_TRI_LD
+            }
         }
         else
         {
@@ -987,10 +1073,13 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             o[1] = T[0] + p * T[1] + T[2];
             o[2] = T[1] + p * T[2] + T[3];
             o[3] = last ? T[2] + p1 * T[3] : T[2] + p * T[3] + dn;
-            SV_GRAD(x1 - 1, pp, prev, o, true)
+            SV_GRAD(x1 - 1, pp, prev, o, true, -1)
         }
     }
 #undef SV_GRAD
+#undef SV_TRI_PUSH
+#undef SV_TRI_STEP
+#undef SV_TRI_ADDR
 #undef SV_LOAD
 #undef SV_COL
 #undef SV_REFRESH
@@ -1069,6 +1158,30 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, u
     else
     {
         smooth_vec_body<false, HALF, true, true>(a, lds, z, acosL + 10010);
+    }
+}
+
+// k_smooth_grad with convTri's x pass over M on the same chain (smooth_vec_body's TRIX): M is written once and not read back by a
+// separate x pass (8.3 MB per 1080p frame and one launch less per scale).  One segment per plane; up to 8 waves (1920 rows): the
+// ring of sixteen M columns costs 64 registers, which a workgroup of ten waves cannot have.
+template <bool HALF>
+__global__ void __launch_bounds__(512) k_smooth_grad_tri(SmoothVecArgs a, uint32_t fullMask)
+{
+    extern __shared__ float lds[]; // (k_smooth_grad's)
+    const int z = a.plane0;
+    float* acosL = lds + 2 * SV_MAXW * 2 * SV_K * 4;
+    for (int i = threadIdx.x; i < GM_ACOS_N; i += blockDim.x)
+    {
+        acosL[i] = a.acos[i];
+    }
+    __syncthreads();
+    if ((fullMask >> z) & 1u)
+    {
+        smooth_vec_body<true, HALF, true, true, true>(a, lds, z, acosL + 10010);
+    }
+    else
+    {
+        smooth_vec_body<false, HALF, true, true, true>(a, lds, z, acosL + 10010);
     }
 }
 

@@ -365,9 +365,12 @@ class DetectorPool:
             # memory-bound pyramid kernels and not beside another of its kind (acf_hip.h, option cascade_turns): +4 % frames/s
             # and the tile kernel runs one workgroup per tile: persistent workgroups hold every CU's LDS for the whole kernel and
             # keep the other contexts' kernels out (3 contexts: 14.0k against 13.4k frames/s; alone it is the other way round)
+            # and kernel forms are chosen for the least work, not the shortest time alone (option shared_device: the smoothing chains
+            # uncut, convTri's x pass on the gradient plane's chain; 3 contexts x 96 frames: +4.3 % frames/s)
             for d in self.dets:
                 d.set_option("cascade_turns", 5)
                 d.set_option("tile_persist", 0)
+                d.set_option("shared_device", 1)
 
     def __len__(self):
         return len(self.dets)

@@ -1021,6 +1021,7 @@ static void poolTurns(const std::vector<int>& devices, std::vector<std::unique_p
         {
             dets[i]->setOption("cascade_turns", 5);
             dets[i]->setOption("tile_persist", 0); // (short-lived tile workgroups leave LDS for the other contexts' kernels)
+            dets[i]->setOption("shared_device", 1); // (kernel forms with the least work: the other contexts cover a thin chain's latency)
         }
     }
 }

@@ -212,6 +212,17 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * chain — the smoothed plane then makes no round trip through memory — for planes of
  * >= 2^20 pixels in batches of >= 16 frames, where that pays; 2: wherever that kernel
  * applies; 0: always as its own kernel),
+ * "fused_tri" (1, default: convTri's x pass over M — chnsCompute.cpp:283's convTri(M, S,
+ * normRad) — rides on that chain as well, so M is written once and not read back by a
+ * kernel of its own, in batches of >= 64 frames of a context with "shared_device" set; 2:
+ * wherever "fused_grad"'s kernel runs; 0: never.  The gradient plane is then one uncut
+ * chain of column steps per frame),
+ * "shared_device" (0, default; 1: this context runs beside other contexts on the same
+ * device — acf::HipDetectorPool and the Python DetectorPool set it.  Kernel forms are then
+ * chosen for the least total work instead of the shortest time alone: the smoothing
+ * chains of batches >= 64 frames stay uncut — no warm-up columns, no verify / repair
+ * launch — and "fused_tri" applies; 3 contexts x 96 frames at 1080p: +4.3 % frames/s,
+ * one context alone: -7 %),
  * "graph" (0, default; 1: acf_hip_run captures its own launches into a HIP graph the
  * second time it is called with the same frames pointer and batch size, and replays it
  * from then on — one host call instead of ~45 launches, for callers that feed one

@@ -22,7 +22,7 @@ for it in range(N):
     if kw["nApprox"] < 0:
         kw["nApprox"] = kw["nPerOct"] - 1
     nF = int(rng.choice([1, 2, 3]))
-    opts = dict(fused_grad=int(rng.choice([0, 1, 2, 2])), smooth_segments=int(rng.choice([0, 1, 3, 5])), smooth_warm=int(rng.choice([16, 32, 96])),
+    opts = dict(fused_grad=int(rng.choice([0, 1, 2, 2])), fused_tri=int(rng.choice([0, 1, 2, 2])), smooth_segments=int(rng.choice([0, 1, 3, 5])), smooth_warm=int(rng.choice([16, 32, 96])),
                 scale_streams=int(rng.rand() < 0.5), keep_pyramid=int(rng.rand() < 0.7), rank_cells=int(rng.rand() < 0.7), graph=int(rng.rand() < 0.3),
                 cascade_tiles=int(rng.rand() < 0.8), level_segments=int(rng.choice([0, 1, 4])), tile_persist=int(rng.choice([0, 1, 1, 8])))
     try:

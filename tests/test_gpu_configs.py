@@ -52,8 +52,10 @@ def test_full_size_config_bit_exact(oracle, cfg):
     det.close()
 
 
-@pytest.mark.parametrize("fused_grad", [1, 2])   # 2: gradMag inside the smoothing chain at every scale (what batches >= 16 frames get at scale 0)
-def test_cfg3_batch_of_1080p_frames(oracle, fused_grad):
+# fused_grad 2: gradMag inside the smoothing chain at every scale (what batches >= 16 frames get at scale 0); fused_tri 2: convTri's x pass
+# on that chain as well (k_smooth_grad_tri: what batches >= 64 frames get)
+@pytest.mark.parametrize("fused_grad,fused_tri", [(1, 0), (2, 0), (2, 2)])
+def test_cfg3_batch_of_1080p_frames(oracle, fused_grad, fused_tri):
     import torch
     from acf_amd.detector import HipDetector
     H, W = 1080, 1920
@@ -62,6 +64,7 @@ def test_cfg3_batch_of_1080p_frames(oracle, fused_grad):
     frames = np.stack([synth.make_frame(100 + i, H, W, "luv") for i in range(n)])
     det = HipDetector(model, H, W, 3, max_batch=n, max_hits=1 << 15)
     det.set_option("fused_grad", fused_grad)
+    det.set_option("fused_tri", fused_tri)
     det.run(torch.from_numpy(frames).cuda())
     plan = oracle.Plan(model, H, W, 3)
     for f in (0, 3, 7):

@@ -216,7 +216,7 @@ def test_sub_batch_streams(oracle, streams):
     det.close()
 
 
-@pytest.mark.parametrize("fused_smooth", [1, 0])
+@pytest.mark.parametrize("fused_smooth", [2, 1, 0])   # 2: with convTri's x pass on the gradient plane's chain as well (k_smooth_grad_tri)
 @pytest.mark.parametrize("H,W,kw", [
     (256, 384, dict(name="TINY", nTrees=96)),                       # fused: exact-half next scale, colour channels from registers
     (256, 384, dict(name="TINY", nTrees=96, full=1, colorChn=1)),   # orientation over 2 pi, gradient plane 1 (k_smooth_grad takes that plane)
@@ -241,7 +241,8 @@ def test_fused_smoothing_paths(oracle, H, W, kw, fused_smooth):
     model = synth.make_model(seed=3, **kw)
     frame = synth.make_frame(23, H, W, "luv")
     det = HipDetector(model, H, W, 3, max_batch=2, max_hits=1 << 15)
-    det.set_option("fused_smooth", fused_smooth)
+    det.set_option("fused_smooth", min(fused_smooth, 1))
+    det.set_option("fused_tri", 2 if fused_smooth == 2 else 0)
     det.set_option("fused_grad", 2 if fused_smooth else 0)  # gradMag inside the gradient plane's smoothing chain at every scale it applies to / its own kernel
     det.set_option("scale_streams", fused_smooth)  # real scales on their own streams / all on the context's stream
     det.run(torch.from_numpy(np.stack([frame, frame])).cuda())

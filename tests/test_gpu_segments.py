@@ -23,9 +23,10 @@ def _check(oracle, det, frames, model, H, W):
         assert d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes()
 
 
-@pytest.mark.parametrize("fused_grad", [0, 2])   # gradMag as its own kernel / inside the gradient plane's chain (k_smooth_grad)
+# gradMag as its own kernel / inside the gradient plane's chain (k_smooth_grad) / with convTri's x pass there too (k_smooth_grad_tri: that plane is one segment)
+@pytest.mark.parametrize("fused_grad,fused_tri", [(0, 0), (2, 0), (2, 2)])
 @pytest.mark.parametrize("segments,warm,force", [(0, 48, 0), (1, 48, 0), (4, 48, 0), (7, 32, 0), (16, 16, 0), (5, 48, 1)])
-def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force, fused_grad):
+def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force, fused_grad, fused_tri):
     from acf_amd.detector import HipDetector
     H, W = 256, 512   # w % 8 == 0, h % 4 == 0: the vector smoothing kernel; every level goes through the fused level kernel
     model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
@@ -38,6 +39,7 @@ def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force, fused_g
     det.set_option("smooth_warm", warm)
     det.set_option("smooth_force_redo", force)
     det.set_option("fused_grad", fused_grad)
+    det.set_option("fused_tri", fused_tri)
     # the level chains' segments too (off by default): as many as the smoothing's, with a warm-up short enough to miss sometimes
     det.set_option("level_segments", 0 if segments == 0 else min(segments, 8))
     det.set_option("level_warm", min(warm, 32))
@@ -46,11 +48,43 @@ def test_segmented_smoothing_is_bit_exact(oracle, segments, warm, force, fused_g
     r = det.repairs()
     assert r[0] > 0 or segments == 1
     if force:
-        assert r[1] == r[0] and r[3] > 0           # every smoothing plane and every level plane with more than one segment was repaired
+        # every smoothing plane and every level plane with more than one segment was repaired (k_smooth_grad_tri's plane is one chain)
+        assert (r[1] == r[0] if not fused_tri else r[0] * 2 // 3 <= r[1] < r[0]) and r[3] > 0
     if segments > 1:
         assert r[2] > 0                            # the level chains were cut too
     if segments == 16:
         assert r[1] > 0                            # 16-column warm-ups DO miss: the repair is what makes the result right
+    det.close()
+
+
+def test_shared_device_forms_are_bit_exact(oracle):
+    """Option shared_device (what the pools set on contexts that share a device): batches of >= 64 frames keep their smoothing chains
+    uncut — nothing is verified or repaired — and convTri's x pass rides on the gradient plane's chain (k_smooth_grad_tri)."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 256, 512
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
+    base = [synth.make_frame(51 + i, H, W, "luv") for i in range(4)]
+    base[1][:, 160:290, :] = 0.0
+    frames = np.stack([base[i % 4] for i in range(64)])
+    det = HipDetector(model, H, W, 3, max_batch=64, max_hits=1 << 15)
+    det.set_option("shared_device", 1)
+    det.set_option("fused_grad", 2)       # (planes this small are below the default's 2^20 pixels)
+    det.set_option("level_segments", 1)
+    det.set_option("count_repairs", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    assert det.repairs()[0] == 0          # no smoothing plane had a hand-over to check
+    plan = oracle.Plan(model, H, W, 3)
+    for f in (0, 1, 62, 63):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want, whits = oracle.detect(plan, pyr)
+        assert np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)), f
+        d, h = det.detections(f)
+        assert d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes()
+    # the same batch with the lone context's forms: segments, k_tri_x5v
+    det.set_option("shared_device", 0)
+    det.run(torch.from_numpy(frames).cuda())
+    assert det.repairs()[0] > 0
     det.close()
 
 
@@ -71,9 +105,9 @@ def test_segmented_smoothing_rgb_and_sub_batches(oracle):
     det.close()
 
 
-@pytest.mark.parametrize("fused_grad", [0, 2])
-@pytest.mark.parametrize("W,segments", [(484, 0), (484, 3), (492, 1), (20, 0), (36, 2)])
-def test_widths_that_are_not_multiples_of_eight(oracle, W, segments, fused_grad):
+@pytest.mark.parametrize("fused_grad,fused_tri", [(0, 0), (2, 0), (2, 2)])
+@pytest.mark.parametrize("W,segments", [(484, 0), (484, 3), (492, 1), (488, 1), (496, 0), (48, 0), (52, 1), (20, 0), (36, 2)])
+def test_widths_that_are_not_multiples_of_eight(oracle, W, segments, fused_grad, fused_tri):
     """w % 8 == 4: the vector smoothing kernel's four-column tail (the third real scale of a 1080p frame is 484 columns wide)."""
     from acf_amd.detector import HipDetector
     H = 136 if W > 100 else 64
@@ -83,6 +117,7 @@ def test_widths_that_are_not_multiples_of_eight(oracle, W, segments, fused_grad)
     det.set_option("smooth_segments", segments)
     det.set_option("smooth_warm", 16)
     det.set_option("fused_grad", fused_grad)
+    det.set_option("fused_tri", fused_tri)
     import torch
     det.run(torch.from_numpy(frames).cuda())
     plan = oracle.Plan(model, H, W, 3)
