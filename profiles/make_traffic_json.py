@@ -8,7 +8,10 @@ FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md §HBM), 1 otherwis
 """
 import csv, json, sys, collections
 
-WIDE = ("k_cascade_tile", "k_cascade_tail3", "k_grad_mag_vec", "k_tri_x5v", "k_tri_y5(", "k_chns", "k_resample_half", "k_resample_strip", "k_smooth_vec", "k_smooth_grad", "k_tail_scan")
+# (k_triy_chns<.., true> — M, O, U in blocks, four 16-byte loads per lane and plane — was missing from this list until the end of round 5: its reads
+# were reported at half their size, 17 MB per 1080p frame; totals of earlier files are that much too small)
+WIDE = ("k_cascade_tile", "k_cascade_tail3", "k_grad_mag_vec", "k_tri_x5v", "k_tri_y5(", "k_chns", "k_resample_half", "k_resample_strip", "k_smooth_vec", "k_smooth_grad", "k_tail_scan",
+        "k_triy_chns<6, true>", "k_triy_chns<12, true>")
 GROUP = [("k_cascade_tile", "k_cascade_tile"), ("k_cascade_tail", "k_cascade_tail3"), ("k_tail_scan", "k_tail_scan"), ("k_level", "k_level(fused)"),
          ("k_triy_chns", "k_triy_chns"), ("k_sort_map", "k_sort_map"), ("k_nms", "k_nms"), ("k_export", "k_export"),
          ("k_chns", "k_chns"), ("k_smooth_vec", "k_smooth_vec"), ("k_smooth_grad", "k_smooth_vec"), ("k_smooth_tri1", "k_smooth_tri1(image)"), ("k_grad_mag", "k_grad_mag"), ("k_tri_x", "k_tri_x"),
