@@ -1442,6 +1442,17 @@ template <int MAXO, bool UT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca, int64_t ufs, int nyb)
 {
     __shared__ float ty_lds[4][UT ? 1 : 2][64 * TY_PITCH];
+    // STG: the cells of FOUR steps (16 cell rows of the wave's 16 cell columns, per channel) are collected in LDS and leave as 64
+    // contiguous bytes per cell column and channel — a step alone writes 16-byte pieces, which L2 evicts before the next steps
+    // complete their lines: 14.7 MB written per 1080p frame for 4.8 MB of cells (WRITE_SIZE, profiles/r05_ab/triy_nt_level_fm.txt)
+#ifdef ACF_TRIY_DIRECT
+    constexpr bool STG = false;
+#else
+    constexpr bool STG = MAXO <= 6;
+#endif
+    constexpr int CB_P = 20, NCB = MAXO + 1; // row pitch of a (channel, cell column) of the buffer; slots: the magnitude, the bins
+    __shared__ float ty_cb[4][STG ? NCB * 16 * CB_P : 1];
+    int cs = 0, cr0 = 0; // steps in the buffer; cell row of its row 0
     const int h = ca.h, w = ca.w;
     const int64_t fs = ca.m_fs;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1551,7 +1562,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 {                                                                                           \
                     C_[yy] = ((mn[0][yy] + mn[1][yy]) + mn[2][yy]) + mn[3][yy];                             \
                 }                                                                                           \
-                outc[int64_t(chMag) * cellsN] = (((C_[0] + C_[1]) + C_[2]) + C_[3]) * ca.rq_y;               \
+                const float cv_ = (((C_[0] + C_[1]) + C_[2]) + C_[3]) * ca.rq_y;                            \
+                if (STG)                                                                                    \
+                {                                                                                           \
+                    ty_cb[wv][xcL * CB_P + 4 * cs + ycL] = cv_;                                             \
+                }                                                                                           \
+                else                                                                                        \
+                {                                                                                           \
+                    outc[int64_t(chMag) * cellsN] = cv_;                                                    \
+                }                                                                                           \
             }                                                                                               \
             if (ca.histEnabled)                                                                              \
             {                                                                                               \
@@ -1580,13 +1599,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int chH_ = chMag + (ca.magEnabled ? 1 : 0);                                            \
                 _Pragma("unroll") for (int b = 0; b < MAXO; b++)                                            \
                 {                                                                                           \
-                    if (b < nO)                                                                             \
+                    if (STG)                                                                                \
+                    {                                                                                       \
+                        ty_cb[wv][((1 + b) * 16 + xcL) * CB_P + 4 * cs + ycL] = H_[b];                      \
+                    }                                                                                       \
+                    else if (b < nO)                                                                        \
                     {                                                                                       \
                         outc[int64_t(chH_ + b) * cellsN] = H_[b];                                           \
                     }                                                                                       \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
+        if (STG)                                                                                            \
+        {                                                                                                   \
+            cs++;                                                                                           \
+            if (cs == 4)                                                                                    \
+            {                                                                                               \
+                TY_FLUSH();                                                                                 \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+    // the buffer's rows leave: lane (cell column xcL, k = lane & 3) takes rows 4k .. 4k + 3 of every channel as one 16-byte store
+    // (8-byte aligned when the cell column's start is: hc need not be a multiple of 4); rows past the plane's last stay behind
+#define TY_FLUSH()                                                                                          \
+    {                                                                                                       \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        const int rows_ = min(4 * cs, hc - cr0), k4_ = 4 * ycL;                                             \
+        if (x0 + 4 * xcL < w && k4_ < rows_)                                                                \
+        {                                                                                                   \
+            float* dst_ = chn + (uint32_t((x0 >> 2) + xcL) * uint32_t(hc) + uint32_t(cr0 + k4_));           \
+            const int nv_ = min(4, rows_ - k4_);                                                            \
+            const int chH_ = chMag + (ca.magEnabled ? 1 : 0);                                               \
+            _Pragma("unroll") for (int sl = 0; sl < NCB; sl++)                                              \
+            {                                                                                               \
+                if (sl == 0 ? ca.magEnabled != 0 : (ca.histEnabled && sl - 1 < nO))                         \
+                {                                                                                           \
+                    const float4 v_ = *reinterpret_cast<const float4*>(&ty_cb[wv][(sl * 16 + xcL) * CB_P + k4_]); \
+                    float* d_ = dst_ + int64_t(sl == 0 ? chMag : chH_ + sl - 1) * cellsN;                   \
+                    if (nv_ == 4)                                                                           \
+                    {                                                                                       \
+                        typedef float f4u_ __attribute__((ext_vector_type(4), aligned(4)));                 \
+                        f4u_ o4_ = { v_.x, v_.y, v_.z, v_.w };                                              \
+                        *reinterpret_cast<f4u_*>(d_) = o4_;                                                 \
+                    }                                                                                       \
+                    else                                                                                    \
+                    {                                                                                       \
+                        d_[0] = v_.x;                                                                       \
+                        if (nv_ > 1)                                                                        \
+                        {                                                                                   \
+                            d_[1] = v_.y;                                                                   \
+                        }                                                                                   \
+                        if (nv_ > 2)                                                                        \
+                        {                                                                                   \
+                            d_[2] = v_.z;                                                                   \
+                        }                                                                                   \
+                    }                                                                                       \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_wave_barrier();                                                                    \
+        cr0 += 4 * cs;                                                                                      \
+        cs = 0;                                                                                             \
     }
     // request rows R0..R0+15 of the wave's 64 columns: plain layout — 16 coalesced loads into G[], handed to the owning lanes
     // through LDS by TY_TAKE; blocked layout (R0 = J + 8: exactly one block row) — four 16-byte loads per lane, already home
@@ -1735,6 +1808,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         TY_CELLS(oqA, J, nr, J + 16);
     }
+    if (STG && cs > 0)
+    {
+        TY_FLUSH();
+    }
+#undef TY_FLUSH
 #undef TY_U
 #undef TY_MO_OFF
 #undef TY_M_FETCH
