@@ -32,6 +32,8 @@ VARIANTS = [
     "ACF_HIP_FUSED_GRAD=2",
     "ACF_HIP_NO_FUSED_GRAD=1",
     "ACF_HIP_FUSED_GRAD=1 ACF_HIP_FUSED_GRAD_MINPX=1000 ACF_HIP_FUSED_GRAD_MINF=1",
+    "ACF_HIP_FUSED_GRAD=2 ACF_HIP_FUSED_TRI=2",                                                  # k_smooth_grad_tri at every scale it fits
+    "ACF_HIP_FUSED_GRAD=2 ACF_HIP_SHARED_DEVICE=1 ACF_HIP_FUSED_TRI_MINF=1",                     # the pools' option as the process default
     "ACF_HIP_GMV_BLOCKS=64",
     "ACF_HIP_RESAMPLE_NO_PAIR=1",
     "ACF_HIP_RESAMPLE_NO_STRIP=1",
