@@ -237,6 +237,8 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * "smooth_segments" / "smooth_warm" (the same for the image smoothing: 0 = as many segments as
  * fill the device, 64 warm-up columns), "count_repairs" (1: acf_hip_get_repairs counts the
  * planes the repair launches recomputed; synchronises, measurements only),
+ * "smooth_force_redo" (tests: 1 = every plane with more than one segment is marked for the
+ * repair launch whatever the verification found),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
  * switches; all forms give identical results).
  *

@@ -26,6 +26,19 @@ def test_header_symbols_exported():
     assert lib.acf_hip_abi_version() == 8
 
 
+def test_every_option_the_library_accepts_is_documented_in_the_header():
+    """acf_hip_set_option's keys (the strcmp chain of acf_hip.hip) against include/acf_hip.h: an option without a description
+    there is an undocumented part of the boundary."""
+    import re
+    src = open(os.path.join(ROOT, "acf_amd", "csrc", "acf_hip.hip")).read()
+    body = src[src.index("int acf_hip_set_option"):]
+    body = body[:body.index("unknown option")]
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body)))
+    hdr = open(os.path.join(ROOT, "include", "acf_hip.h")).read()
+    assert len(keys) >= 20
+    assert [k for k in keys if '"%s"' % k not in hdr] == []
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU the product must refuse, not compute on the CPU."""
     import torch
