@@ -665,23 +665,23 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
     }
     else
     {
-    prof(c, "k_tri_x");
-    if (vecX)
-    {
-        if (ut)
+        prof(c, "k_tri_x");
+        if (vecX)
         {
-            hipLaunchKernelGGL((k_tri_x5v<true>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, mfs, ufs, nyb, nybM);
+            if (ut)
+            {
+                hipLaunchKernelGGL((k_tri_x5v<true>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, mfs, ufs, nyb, nybM);
+            }
+            else
+            {
+                hipLaunchKernelGGL((k_tri_x5v<false>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, fs, fs, 0, 0);
+            }
         }
         else
         {
-            hipLaunchKernelGGL((k_tri_x5v<false>), dim3(cdiv(h / 4, 64), 1, nFrames), dim3(64), 0, c->stream, in, U, h, w, fs, fs, 0, 0);
+            hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
         }
-    }
-    else
-    {
-        hipLaunchKernelGGL(k_tri_x, dim3(cdiv(h, 256), 1, nFrames), dim3(256), 0, c->stream, in, U, h, w, rad, fs);
-    }
-    LAUNCHCHK(c, "k_tri_x");
+        LAUNCHCHK(c, "k_tri_x");
     }
     if (fused)
     {
