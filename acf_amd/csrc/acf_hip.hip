@@ -4589,8 +4589,8 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
             HIPCHK(c, hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
             if (gt.pooled)
             {
-                double acc[6] = { 0, 0, 0, 0, 0, 0 }, n1 = 0, n2 = 0, nE = 0;
-                long long nb = 0;
+                double acc[6] = { 0, 0, 0, 0, 0, 0 }, n1 = 0, n2 = 0, nE = 0, accE = 0;
+                long long nb = 0, nbE = 0;
                 for (size_t b = 0; b < size_t(grid.x); b++)
                 {
                     if (st[b * 8 + 5] > st[b * 8])
@@ -4603,10 +4603,15 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
                         n2 += double((st[b * 8 + 7] >> 16) & 0xffff);
                         nE += double(st[b * 8 + 7] >> 32);
                         nb++;
+                        if ((st[b * 8 + 7] >> 32) > 0 && st[b * 8 + 6] > st[b * 8 + 5]) // (tiles with windows in the tail queue: stage E ran)
+                        {
+                            accE += double(st[b * 8 + 6] - st[b * 8 + 5]);
+                            nbE++;
+                        }
                     }
                 }
-                fprintf(stderr, "[casc stamps, pooled] blocks %lld  fill %.0f  A1 (thread 0) %.0f  barrier %.0f  A2 + barrier %.0f  S %.0f cycles;  survivors per tile: A1 %.1f  A2 %.1f  S %.2f\n",
-                    nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, n1 / nb, n2 / nb, nE / nb);
+                fprintf(stderr, "[casc stamps, pooled] blocks %lld  fill %.0f  A1 (thread 0) %.0f  barrier %.0f  A2 + barrier %.0f  S %.0f cycles;  survivors per tile: A1 %.1f  A2 %.1f  S %.2f;  E %.0f cycles in %.1f %% of the tiles\n",
+                    nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, n1 / nb, n2 / nb, nE / nb, nbE ? accE / nbE : 0.0, 100.0 * nbE / std::max<long long>(nb, 1));
             }
             else
             {

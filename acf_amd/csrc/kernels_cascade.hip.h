@@ -1435,6 +1435,7 @@ __global__ void __launch_bounds__(NW * 64) k_cascade_tile3(TileArgs a)
             }
         }
     }
+    TILE_STAMP(6);
     __syncthreads(); // (the next tile's fill rewrites the cells stage E reads)
     }
 }
