@@ -88,6 +88,32 @@ def test_shared_device_forms_are_bit_exact(oracle):
     det.close()
 
 
+@pytest.mark.parametrize("fused_tri", [0, 2])
+@pytest.mark.parametrize("H,W", [(256, 512), (136, 484)])
+def test_one_plane_input_with_its_colour_channel(oracle, H, W, fused_tri):
+    """A grey frame whose one plane is both the colour channel and the gradient plane (8 channels): the scale's smoothing is then
+    k_smooth_grad's launch alone (no k_smooth_vec beside it) — with convTri's x pass on the chain as well."""
+    import torch
+    from acf_amd import capi
+    from acf_amd.detector import HipDetector
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0, colorSpace=capi.CS_GRAY, isLuv=0)
+    frames = np.stack([synth.make_frame(91 + i, H, W, "gray") for i in range(2)])
+    det = HipDetector(model, H, W, 1, max_batch=2, max_hits=1 << 15)
+    det.set_option("fused_grad", 2)
+    det.set_option("fused_tri", fused_tri)
+    det.set_option("smooth_segments", 3)
+    det.set_option("smooth_warm", 32)
+    det.run(torch.from_numpy(frames).cuda())
+    plan = oracle.Plan(model, H, W, 1)
+    for f in range(2):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want, whits = oracle.detect(plan, pyr)
+        assert np.array_equal(det.read_pyramid(f).view(np.uint32), pyr.view(np.uint32)), f
+        d, h = det.detections(f)
+        assert d.tobytes() == want.tobytes() and h.tobytes() == whits.tobytes()
+    det.close()
+
+
 def test_segmented_smoothing_rgb_and_sub_batches(oracle):
     """RGB input (the smoothing follows rgb2luv), sub-batch contexts (option streams) and the rank-cell cascade together."""
     import torch
