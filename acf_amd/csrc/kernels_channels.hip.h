@@ -256,6 +256,9 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             }                                                                                     \
         }                                                                                         \
     }
+    float gLo = -10009.0f, gHi = 10009.0f; // (SV_GRAD's clamp: VOP3 takes no literal on gfx950)
+    ACF_PIN_V(gLo);
+    ACF_PIN_V(gHi);
     float4 c0[SV_CH], c1[SV_CH];
     // gradMag of smoothed column X (gradientMex.cpp:17-87,168-251; k_grad_mag_vec's arithmetic per pixel): LFT / CUR / RGT =
     // the lane's quad in columns max(X - 1, 0), X, min(X + 1, w - 1).  The rows above and below the quad are the
@@ -280,8 +283,10 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             gm_inv_fast(m2, m, mo[k]);                                                            \
             float g = (gx * m) * 10000.0f;                                                        \
             g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));            \
-            g = g < 10009.0f ? g : 10009.0f;                                                      \
-            g = g > -10009.0f ? g : -10009.0f;                                                    \
+            /* g < 10009 ? g : 10009, then > -10009 (gradientMex.cpp:224-226) as ONE v_med3_f32: the two selects compile to  */ \
+            /* v_min / v_max with a canonicalising v_max in front of each (5 instructions per pixel of a chain that is bound */ \
+            /* by its instruction stream); g is finite (|gx| * m * 1e4 with m <= 1e10), where the median is the clamp         */ \
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(gLo), "v"(gHi));                   \
             float ov = acosT[(int)g];                                                             \
             if (a.full)                                                                           \
             {                                                                                     \
@@ -312,7 +317,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
         float T[4];                                                                               \
         _Pragma("unroll") for (int k = 0; k < 4; k++)                                             \
         {                                                                                         \
-            const float il = (i_ == xs) ? im[k] : prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507); a later segment's warm-up starts the same way */ \
+            const float il = prev[k]; /* Il = Im at i == 0 (convConst.cpp:503-507; a later segment's warm-up starts the same way): `prev` is the chain's first input column when it starts */ \
             T[k] = nrm * (il + p * im[k] + ir[k]);                                                \
         }                                                                                         \
         const float up = wave_ror1(T[3]); /* row 4q-1: the previous lane's last row */            \
@@ -391,6 +396,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
     SV_REFRESH(I0)
     const int64_t stateOff = ((f * a.nPlanes + z) * a.segStride) * int64_t(h) + 4 * qc;
     SV_LOAD(c0, xs);
+    prev[0] = c0[0].x, prev[1] = c0[0].y, prev[2] = c0[0].z, prev[3] = c0[0].w; // (the first step's left tap is its middle tap)
     int i = xs;
     // warm-up of a later segment (x0 - xs is a multiple of 16): same arithmetic, nothing leaves
     for (; i < x0; i += 2 * SV_CH)
