@@ -116,6 +116,168 @@ static inline float approx12(float v)
 }
 
 /* ------------------------------------------------------------------------
+ * The T-ref tier as a TABLE: acfo_set_approx(3).  _mm_rcp_ps / _mm_rsqrt_ps (T/sse.hpp:185-192) are, on the CPUs probed so far
+ * (tests/golden/make_x86_tables.py, which checks it for all 2^32 inputs), pure functions of few input bits:
+ *   rcp(x)   = sign | 2^(127 - e) scaled RCP[m >> 12]            2048 entries: the results for x in [1, 2), by the top 11 mantissa bits
+ *   rsqrt(x) = 2^(-(e - 127 - odd) / 2) scaled RSQ[odd][m >> 13]  2 x 1024 entries: the results for x in [1, 2) and [2, 4)
+ * with zero / subnormal inputs -> inf of the input's sign (the instruction treats subnormals as zero), inf -> 0, NaN -> quiet NaN,
+ * results below the normal range flushed to zero, rsqrt of a negative -> the default NaN (0xffc00000).  With the tables of a
+ * CPU installed (acfo_set_x86_tables) the three sites below return that CPU's bits: gradMag, gradMagNorm and rgb2luv_sse become
+ * BIT-EXACT against the reference's own compiled kernels on that CPU (tests/test_oracle_vs_ref.py), and the whole path reproduces
+ * the reference's detections (tests/test_tref_end_to_end.py).  acfo_x86_probe reads the tables from the CPU this runs on.
+ * ---------------------------------------------------------------------- */
+static uint32_t g_x86Rcp[2048], g_x86Rsq[2048];
+static int g_x86Set = 0;
+ACFO_API void acfo_set_x86_tables(const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+{
+    memcpy(g_x86Rcp, rcp2048, sizeof(g_x86Rcp));
+    memcpy(g_x86Rsq, rsqrt2048, sizeof(g_x86Rsq));
+    g_x86Set = 1;
+}
+ACFO_API uint32_t acfo_x86_rcp_bits(uint32_t u)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : s; /* NaN quieted; 1 / inf = 0 of the same sign */
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u; /* zero and subnormals: inf */
+    }
+    const uint32_t t = g_x86Rcp[m >> 12];
+    const int re = (int)((t >> 23) & 0xffu) + 127 - (int)e;
+    if (re <= 0)
+    {
+        return s; /* underflow: flushed to zero */
+    }
+    return s | ((uint32_t)re << 23) | (t & 0x7fffffu);
+}
+ACFO_API uint32_t acfo_x86_rsqrt_bits(uint32_t u)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : (s ? 0xffc00000u : 0u);
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    if (s)
+    {
+        return 0xffc00000u;
+    }
+    const int ue = (int)e - 127, odd = ue & 1, half = (ue - odd) / 2; /* x = 4^half * [1, 4) */
+    const uint32_t t = g_x86Rsq[(odd << 10) | (m >> 13)];
+    const int re = (int)((t >> 23) & 0xffu) - half;
+    return ((uint32_t)re << 23) | (t & 0x7fffffu);
+}
+static inline float x86_rcp(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = acfo_x86_rcp_bits(u);
+    memcpy(&x, &u, 4);
+    return x;
+}
+static inline float x86_rsqrt(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = acfo_x86_rsqrt_bits(u);
+    memcpy(&x, &u, 4);
+    return x;
+}
+/* The approximation tiers' two operations: mode 3 the installed CPU's bits, modes 1 / 2 the exact value squeezed to 12 bits. */
+static inline float ap_rcp(float x)
+{
+    return g_approx == 3 ? x86_rcp(x) : approx12(1.0f / x);
+}
+static inline float ap_rsqrt(float x)
+{
+    return g_approx == 3 ? x86_rsqrt(x) : approx12(1.0f / sqrtf(x));
+}
+/* A position-mixed 64-bit digest of both functions over the bit patterns first, first + stride, ... (count of them): how the
+ * device's table functions are compared with this file's for EVERY input without moving 2^32 results (tests/test_gpu_arith.py). */
+ACFO_API void acfo_x86_digest(uint32_t first, uint64_t count, uint32_t stride, uint64_t out[2])
+{
+    uint64_t a = 0, b = 0;
+    for (uint64_t i = 0; i < count; i++)
+    {
+        const uint32_t u = first + (uint32_t)(i * stride);
+        const uint64_t k = ((uint64_t)u * 0x9e3779b97f4a7c15ull) | 1ull;
+        a += k * acfo_x86_rcp_bits(u);
+        b += k * acfo_x86_rsqrt_bits(u);
+    }
+    out[0] = a;
+    out[1] = b;
+}
+#if defined(__SSE__)
+#include <xmmintrin.h>
+static inline uint32_t hw_rcp_bits(uint32_t u)
+{
+    float f, o;
+    memcpy(&f, &u, 4);
+    o = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(f)));
+    memcpy(&u, &o, 4);
+    return u;
+}
+static inline uint32_t hw_rsqrt_bits(uint32_t u)
+{
+    float f, o;
+    memcpy(&f, &u, 4);
+    o = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(f)));
+    memcpy(&u, &o, 4);
+    return u;
+}
+/* The tables of the CPU this runs on: _mm_rcp_ps over [1, 2) and _mm_rsqrt_ps over [1, 4) at the first input of every table cell. */
+ACFO_API int acfo_x86_probe(uint32_t* rcp2048, uint32_t* rsqrt2048)
+{
+    for (uint32_t i = 0; i < 2048; i++)
+    {
+        rcp2048[i] = hw_rcp_bits((127u << 23) | (i << 12));
+    }
+    for (uint32_t i = 0; i < 1024; i++)
+    {
+        rsqrt2048[i] = hw_rsqrt_bits((127u << 23) | (i << 13));
+        rsqrt2048[1024 + i] = hw_rsqrt_bits((128u << 23) | (i << 13));
+    }
+    return 1;
+}
+/* The installed tables against the instructions of the CPU this runs on, over first, first + stride, ...: the numbers of inputs
+ * whose table result differs (0 / 0 over all 2^32 inputs is what makes the table a statement about the instruction). */
+ACFO_API int acfo_x86_verify(uint32_t first, uint64_t count, uint32_t stride, uint64_t bad[2])
+{
+    uint64_t b0 = 0, b1 = 0;
+    for (uint64_t i = 0; i < count; i++)
+    {
+        const uint32_t u = first + (uint32_t)(i * stride);
+        b0 += hw_rcp_bits(u) != acfo_x86_rcp_bits(u);
+        b1 += hw_rsqrt_bits(u) != acfo_x86_rsqrt_bits(u);
+    }
+    bad[0] = b0;
+    bad[1] = b1;
+    return 1;
+}
+#else
+ACFO_API int acfo_x86_probe(uint32_t* rcp2048, uint32_t* rsqrt2048)
+{
+    (void)rcp2048;
+    (void)rsqrt2048;
+    return 0;
+}
+ACFO_API int acfo_x86_verify(uint32_t first, uint64_t count, uint32_t stride, uint64_t bad[2])
+{
+    (void)first;
+    (void)count;
+    (void)stride;
+    bad[0] = bad[1] = 0;
+    return 0;
+}
+#endif
+
+/* ------------------------------------------------------------------------
  * a1  Detector::getScales — chnsPyramid.cpp:461-529.
  * Upright naming: H = image height (reference sz.width, because the image is
  * transposed: chnsPyramid.cpp:232, ACF.cpp:137), W = image width (sz.height).
@@ -599,7 +761,7 @@ ACFO_API void acfo_rgb2luv(const float* I, float* J, int n)
             float zz = 1.0f / (x + (1e-35f + (15.0f * y + 3.0f * z))); /* :161, RCP -> exact */
             if (g_approx)
             {
-                zz = approx12(zz); /* T-approx (acfo_set_approx) */
+                zz = ap_rcp(x + (1e-35f + (15.0f * y + 3.0f * z))); /* T-approx / the table tier (acfo_set_approx) */
             }
             float lf = 1024.0f * y;                                   /* :162 */
             float u = (52.0f * x) * zz - cun;                         /* :163 */
@@ -1027,9 +1189,9 @@ ACFO_API int acfo_grad_mag(const float* I, float* M, float* O, int h, int w, int
             /* T-approx: RCPSQRT and RCP as 12-bit approximations (see acfo_set_approx); the rest as below */
             for (int y = 0; y < h; y++)
             {
-                float m = approx12(1.0f / sqrtf(M2[y]));
+                float m = ap_rsqrt(M2[y]);
                 m = m < 1e10f ? m : 1e10f;
-                M2[y] = approx12(1.0f / m);
+                M2[y] = ap_rcp(m);
                 if (O)
                 {
                     float g = (Gx[y] * m) * acMult;
@@ -1104,7 +1266,7 @@ ACFO_API void acfo_grad_mag_norm(float* M, const float* S, int h, int w, float n
     {
         for (; i < n4 * 4; i++)
         {
-            M[i] = M[i] * approx12(1.0f / (S[i] + norm)); /* T-approx (acfo_set_approx) */
+            M[i] = M[i] * ap_rcp(S[i] + norm); /* T-approx / the table tier (acfo_set_approx) */
         }
     }
     for (; i < n4 * 4; i++)

@@ -163,11 +163,90 @@ def set_tref(on, only=TREF_ALL):
 
 def set_approx(mode):
     """T-approx tier of the oracle on THIS thread (tests/golden/make_tref.py): 0 exact (default), 1 / 2 the three rsqrt / rcp sites as
-    12-bit approximations (rounded / truncated), two more implementations within _mm_rsqrt_ps's documented error bound."""
+    12-bit approximations (rounded / truncated), two more implementations within _mm_rsqrt_ps's documented error bound; 3 the sites
+    as the TABLES of one CPU's _mm_rcp_ps / _mm_rsqrt_ps (set_x86_tables first): that CPU's T-ref bits."""
     o = lib()
     o.acfo_set_approx.argtypes = [C.c_int]
     o.acfo_set_approx.restype = None
     o.acfo_set_approx(int(mode))
+
+
+X86_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "x86_rcp_rsqrt.npz")
+u32p = C.POINTER(C.c_uint32)
+
+
+def _x86_lib():
+    o = lib()
+    if not getattr(o, "_x86_bound", False):
+        o.acfo_set_x86_tables.argtypes = [u32p, u32p]
+        o.acfo_set_x86_tables.restype = None
+        o.acfo_x86_probe.argtypes = [u32p, u32p]
+        o.acfo_x86_probe.restype = C.c_int
+        o.acfo_x86_verify.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+        o.acfo_x86_verify.restype = C.c_int
+        o.acfo_x86_digest.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+        o.acfo_x86_digest.restype = None
+        o.acfo_x86_rcp_bits.argtypes = [C.c_uint32]
+        o.acfo_x86_rcp_bits.restype = C.c_uint32
+        o.acfo_x86_rsqrt_bits.argtypes = [C.c_uint32]
+        o.acfo_x86_rsqrt_bits.restype = C.c_uint32
+        o._x86_bound = True
+    return o
+
+
+def x86_probe():
+    """(rcp[2048], rsqrt[2048]) uint32 tables of the CPU THIS process runs on (_mm_rcp_ps over [1, 2), _mm_rsqrt_ps over [1, 4)),
+    or None where the oracle was not built for an SSE host."""
+    o = _x86_lib()
+    rcp, rsq = np.zeros(2048, np.uint32), np.zeros(2048, np.uint32)
+    if not o.acfo_x86_probe(rcp.ctypes.data_as(u32p), rsq.ctypes.data_as(u32p)):
+        return None
+    return rcp, rsq
+
+
+def x86_fixture():
+    """The committed tables (tests/golden/x86_rcp_rsqrt.npz, made by tests/golden/make_x86_tables.py on the build host): the
+    arithmetic tests/golden/tref_study.npz's T-ref hits and ref_ops.npz's gradMag / gradMagNorm / rgb2luv_sse bytes were made with."""
+    z = np.load(X86_FIXTURE)
+    return np.ascontiguousarray(z["rcp"], np.uint32), np.ascontiguousarray(z["rsqrt"], np.uint32)
+
+
+def set_x86_tables(rcp, rsq):
+    """Install the tables acfo_set_approx(3) evaluates (process-wide)."""
+    o = _x86_lib()
+    rcp = np.ascontiguousarray(rcp, np.uint32)
+    rsq = np.ascontiguousarray(rsq, np.uint32)
+    assert rcp.shape == (2048,) and rsq.shape == (2048,)
+    o.acfo_set_x86_tables(rcp.ctypes.data_as(u32p), rsq.ctypes.data_as(u32p))
+
+
+def x86_verify(first, count, stride=1):
+    """(#rcp mismatches, #rsqrt mismatches) of the installed tables against the live instructions over first + i * stride."""
+    o = _x86_lib()
+    bad = (C.c_uint64 * 2)()
+    if not o.acfo_x86_verify(C.c_uint32(first), C.c_uint64(count), C.c_uint32(stride), bad):
+        return None
+    return int(bad[0]), int(bad[1])
+
+
+def x86_digest(first, count, stride=1):
+    """Position-mixed 64-bit digests (rcp, rsqrt) of the installed tables' functions over first + i * stride (acfo_x86_digest)."""
+    o = _x86_lib()
+    out = (C.c_uint64 * 2)()
+    o.acfo_x86_digest(C.c_uint32(first), C.c_uint64(count), C.c_uint32(stride), out)
+    return int(out[0]), int(out[1])
+
+
+def x86_rcp(x):
+    o = _x86_lib()
+    b = np.ascontiguousarray(x, np.float32).view(np.uint32).ravel()
+    return np.asarray([o.acfo_x86_rcp_bits(int(v)) for v in b], np.uint32).view(np.float32)
+
+
+def x86_rsqrt(x):
+    o = _x86_lib()
+    b = np.ascontiguousarray(x, np.float32).view(np.uint32).ravel()
+    return np.asarray([o.acfo_x86_rsqrt_bits(int(v)) for v in b], np.uint32).view(np.float32)
 
 
 def aligned(shape, dtype=np.float32, align=64):
