@@ -218,6 +218,9 @@ def load():
         "acf_hip_op_conv_tri": ([ctx, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "acf_hip_op_gradient_mag": ([ctx, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int], C.c_int),
         "acf_hip_selftest_gradmag": ([ctx, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)], C.c_int),
+        "acf_hip_set_x86_tables": ([ctx, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
+        "acf_hip_selftest_x86": ([ctx, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)], C.c_int),
+        "acf_hip_chns_compute": ([ctx, C.POINTER(Params), fp, C.c_int, C.c_int, C.c_int, fp, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "acf_hip_op_gradient_hist": ([ctx, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
         "acf_hip_op_im_resample": ([ctx, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double], C.c_int),
         "acf_hip_op_acf_detect1": ([ctx, fp, C.c_int, C.c_int, C.c_int, C.POINTER(Hit), C.c_int, C.POINTER(C.c_int)], C.c_int),
@@ -242,7 +245,7 @@ DECLARED_SYMBOLS = [
     "acf_hip_pyramid_u8", "acf_hip_run_u8", "acf_hip_resize_dims", "acf_hip_set_input_resize", "acf_hip_op_resize_u8", "acf_hip_stream_open", "acf_hip_stream_submit", "acf_hip_stream_collect",
     "acf_hip_stream_close", "acf_hip_host_alloc", "acf_hip_host_free",
     "acf_hip_export_detections", "acf_hip_synchronize", "acf_hip_get_repairs", "acf_hip_profile_get", "acf_hip_read_level", "acf_hip_read_rank_level", "acf_hip_rank_cells_host", "acf_hip_read_tap",
-    "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_selftest_gradmag", "acf_hip_op_gradient_hist",
+    "acf_hip_op_rgb_convert", "acf_hip_op_conv_tri", "acf_hip_op_gradient_mag", "acf_hip_selftest_gradmag", "acf_hip_set_x86_tables", "acf_hip_selftest_x86", "acf_hip_chns_compute", "acf_hip_op_gradient_hist",
     "acf_hip_op_im_resample", "acf_hip_op_acf_detect1", "acf_hip_op_acf_detect1_u8", "acf_hip_thrs_u8", "acf_hip_op_evaluate",
 ]
 

@@ -139,6 +139,9 @@ struct acf_hip_ctx
     mutable std::string err;
     bool hasModel = false, hasPlan = false;
     int taps = 0;
+    int arith = 0;            // option "arith": 1 = the reference's rcpps / rsqrtps bits from d_x86 (acf_hip_set_x86_tables)
+    bool x86Owned = false;
+    uint32_t* d_x86 = nullptr; // [4096]: rcp over [1, 2) by m >> 12, then rsqrt over [1, 4) by parity and m >> 13
     int profile = 0;
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
@@ -245,6 +248,7 @@ struct acf_hip_ctx
     float *d_specState = nullptr, *d_trueState = nullptr;
     bool countersZeroed = false; // acf_hip_run has cleared the tiled cascade's counters in front of the pyramid's launches
     int32_t* d_redo = nullptr;
+    size_t redoInts = 0, lvRedoInts = 0; // their sizes (clearRepairFlags)
     // the same for the level chains (k_level_all<OUT, 1>), for batches of at most levelSegFrames frames
     float *d_lvSpec = nullptr, *d_lvTrue = nullptr;
     int32_t* d_lvRedo = nullptr;
@@ -355,6 +359,12 @@ int fail(const acf_hip_ctx* c, int code, const std::string& msg)
 
 // Profile marker: an event recorded on the stream before the launch named
 // `name`; a kernel's time is the span to the next marker.
+// the CPU tables the three approximate sites evaluate (option "arith" = 1), or null: exact arithmetic
+inline const uint32_t* x86T(const acf_hip_ctx* c)
+{
+    return c->arith ? c->d_x86 : nullptr;
+}
+
 void prof(acf_hip_ctx* c, const char* name)
 {
     if (!c->profile)
@@ -812,7 +822,7 @@ struct Scratch
 
 // gradMagNorm as a stand-alone kernel (only the op_gradient_mag entry point
 // needs it; the pyramid fuses it into k_chns).  toolbox/gradientMex.cpp:254-275.
-__global__ void __launch_bounds__(256) k_norm(float* __restrict__ M, const float* __restrict__ S, int n, float norm)
+__global__ void __launch_bounds__(256) k_norm(float* __restrict__ M, const float* __restrict__ S, int n, float norm, const uint32_t* __restrict__ x86)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -822,7 +832,7 @@ __global__ void __launch_bounds__(256) k_norm(float* __restrict__ M, const float
     const int n4 = (n / 4) * 4;
     if (i < n4)
     {
-        M[i] = M[i] * (1.0f / (S[i] + norm));
+        M[i] = x86 ? M[i] * x86_rcp(S[i] + norm, x86) : M[i] * (1.0f / (S[i] + norm));
     }
     else
     {
@@ -1093,6 +1103,10 @@ int acf_hip_destroy(acf_hip_ctx* c)
     (void)acf_hip_stream_close(c);
     cascTurnForget(c);
     freeAll(c);
+    if (c->d_x86 && c->x86Owned)
+    {
+        (void)hipFree(c->d_x86);
+    }
     for (hipEvent_t e : c->evPool)
     {
         (void)hipEventDestroy(e);
@@ -1155,6 +1169,15 @@ int acf_hip_set_option(acf_hip_ctx* c, const char* key, int value)
     if (!strcmp(key, "taps"))
     {
         c->taps = value != 0;
+        return ACF_HIP_OK;
+    }
+    if (!strcmp(key, "arith"))
+    {
+        if (value != 0 && !c->d_x86)
+        {
+            return fail(c, ACF_HIP_E_INVALID, "arith: install a CPU's tables first (acf_hip_set_x86_tables)");
+        }
+        c->arith = value != 0;
         return ACF_HIP_OK;
     }
     if (!strcmp(key, "profile"))
@@ -2480,6 +2503,8 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
             }
             c->kids.push_back(k);
             k->taps = c->taps;
+            k->d_x86 = c->d_x86; // (the parent's tables; the parent frees them)
+            k->arith = c->arith;
             k->profile = c->profile;
             k->noTiles = c->noTiles;
             k->noRank = c->noRank;
@@ -3000,7 +3025,11 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             return rc;
         }
-        HIPCHK(c, hipMemset(c->d_redo, 0, sizeof(int32_t) * size_t(B) * d)); // (zero between calls: the repair launch takes its flags down)
+        // (zero between calls: the repair launch takes its flags down; cleared on the context's own stream, which does not
+        // synchronise with the null stream, and again on the error returns between a verify and its repair launch: clearRepairFlags)
+        HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * size_t(B) * d, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->redoInts = size_t(B) * d;
     }
     {
         // k_level_all's column segments: only small batches are bound by a level's chain length
@@ -3013,7 +3042,9 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         {
             return rc;
         }
-        HIPCHK(c, hipMemset(c->d_lvRedo, 0, sizeof(int32_t) * size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns));
+        HIPCHK(c, hipMemsetAsync(c->d_lvRedo, 0, sizeof(int32_t) * size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->lvRedoInts = size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns;
     }
     // cascade
     // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
@@ -3219,6 +3250,7 @@ int launchIngest(acf_hip_ctx* c, const PackedSrc& u, int nF, float* dst, int64_t
     a.out = dst;
     a.lTable = c->d_lTable;
     a.k = makeLuvConsts();
+    a.x86 = x86T(c);
     a.mr = (float).2989360213 * 1.0f;
     a.mg = (float).5870430745 * 1.0f;
     a.mb = (float).1140209043 * 1.0f;
@@ -3332,7 +3364,34 @@ static int uploadResizeTables(acf_hip_ctx* c, acf_hip_ctx::InputResize& rz)
     return ACF_HIP_OK;
 }
 
+// A call that fails between a verify launch and its repair launch (a launch error, the count_repairs read-back) would leave
+// repair flags set for the next call — harmless for results (a flagged plane is recomputed as one chain), but counted by
+// count_repairs and paid for.  Every failing pyramid call therefore takes the flags down again.
+static void clearRepairFlags(acf_hip_ctx* c)
+{
+    if (c->d_redo && c->redoInts)
+    {
+        (void)hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * c->redoInts, c->stream);
+    }
+    if (c->d_lvRedo && c->lvRedoInts)
+    {
+        (void)hipMemsetAsync(c->d_lvRedo, 0, sizeof(int32_t) * c->lvRedoInts, c->stream);
+    }
+}
+
+int pyramidBody(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF);
+
 int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF)
+{
+    const int rc = pyramidBody(c, frames, u8, nF);
+    if (rc && c && c->hasPlan && c->kids.empty())
+    {
+        clearRepairFlags(c);
+    }
+    return rc;
+}
+
+int pyramidBody(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF)
 {
     if (c && !c->kids.empty())
     {
@@ -3439,11 +3498,11 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
             // d_in == 3, RGB -> LUV; the reference takes the SSE body iff n % 4 == 0 (rgbConvertMex.cpp:92,343)
             if (np0 % 4 == 0)
             {
-                hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs);
+                hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs, x86T(c));
             }
             else
             {
-                hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs);
+                hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs, x86T(c));
             }
         }
         else if (p.colorSpace == ACF_HIP_CS_GRAY)
@@ -3630,7 +3689,6 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 sa.rkHalf = nd.rk[0];
                 halfDone[k + 1] = true;
             }
-            prof(c, "k_smooth_vec");
             const int nq = rs.h / 4, nt = cdiv(nq, SV_OWN) * 64; // a wave owns SV_OWN row quads and shadows SV_K of each neighbour
             const size_t ldsB = size_t(2) * SV_MAXW * 2 * SV_K * 4 * sizeof(float);
             {
@@ -3680,7 +3738,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 // chains (frames x segments) and a plane big enough for the saved round trip to matter.  A/B: the variables.
                 static const int64_t gradMinPx = getenv("ACF_HIP_FUSED_GRAD_MINPX") ? atoll(getenv("ACF_HIP_FUSED_GRAD_MINPX")) : (int64_t(1) << 20);
                 static const int gradMinF = getenv("ACF_HIP_FUSED_GRAD_MINF") ? atoi(getenv("ACF_HIP_FUSED_GRAD_MINF")) : 16;
-                const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk &&
+                const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk && !c->arith && // (arith: gradMag is k_grad_mag_strip's)
                     (c->fusedGrad >= 2 || (c->fusedGrad == 1 && np >= gradMinPx && nF >= gradMinF));
                 if (wantGrad)
                 {
@@ -3765,6 +3823,8 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                     }
                 }
                 auto launchSv = [&](dim3 grid) {
+                    // (profile names: the gradient plane's launch by its form, the other planes' launch "k_smooth_vec")
+                    prof(c, !wantGrad ? "k_smooth_vec" : triXFused ? "k_smooth_grad_tri" : "k_smooth_grad");
                     if (wantGrad)
                     {
                         // (first: its chains are the long ones)
@@ -3809,6 +3869,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                         {
                             return;
                         }
+                        prof(c, "k_smooth_vec");
                     }
                     if (halfNext)
                     {
@@ -3898,10 +3959,12 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         a.normConst = float(p.normConst);
         a.rq_y = shrinkGainY(shrink);
         // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
-        const bool gradVec = rs.h % 4 == 0 && np % 4 == 0;
+        const bool gradVec = rs.h % 4 == 0 && np % 4 == 0 && !c->arith; // (option "arith": the plain forms hold the table arithmetic)
+        const bool fuseCells = shrink == 4 && !c->taps && !c->arith;     // k_triy_chns; else S is written and k_chns normalises
+        a.x86 = x86T(c);
         const bool wantTri = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
         const bool blockedMO = wantTri &&
-            triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, (shrink == 4 && !c->taps) ? &a : nullptr, rs.uFloats, rs.moFloats, gradVec).blocked;
+            triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, fuseCells ? &a : nullptr, rs.uFloats, rs.moFloats, gradVec).blocked;
         if (gradFused)
         {
             // (M and O are there already)
@@ -3913,7 +3976,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         else if (p.gradMagEnabled || p.gradHistEnabled)
         {
             prof(c, "k_grad_mag");
-            if (rs.h % 4 == 0 && np % 4 == 0)
+            if (gradVec)
             {
                 // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
                 const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
@@ -3937,7 +4000,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
                 const int want = std::max(1, cdiv(1024, rowBlocks * nF));
                 const int spb = std::max(8, cdiv(nStrips, want));
                 hipLaunchKernelGGL(k_grad_mag_strip, dim3(rowBlocks, cdiv(nStrips, spb), nF), dim3(GM_ROWS), 0, c->stream,
-                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb);
+                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb, x86T(c));
             }
             LAUNCHCHK(c, "k_grad_mag");
         }
@@ -3946,7 +4009,7 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
         {
             // convTri(M, normRad): x running sums, then the y pass — fused with the channel cells when the level allows it
             // (S then never reaches HBM), else S is written for k_chns
-            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, (shrink == 4 && !c->taps) ? &a : nullptr, &cellsDone, rs.uFloats, rs.moFloats,
+            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, fuseCells ? &a : nullptr, &cellsDone, rs.uFloats, rs.moFloats,
                      blockedMO, triXFused)))
             {
                 return rc;
@@ -4440,6 +4503,12 @@ static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes)
     return ACF_HIP_OK;
 }
 
+// the ONE statement of "the cascade runs on LDS tiles": runCascade's branch and acf_hip_run's early counter clear both ask it
+static inline bool tiledCascadeSelected(const acf_hip_ctx* c)
+{
+    return c->cs.useTiles && !c->noTiles;
+}
+
 static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int nF, int nChns)
 {
     const acf_hip_params& p = c->p;
@@ -4765,7 +4834,7 @@ static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const Bo
     {
         HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
     }
-    if (c->cs.useTiles && !c->noTiles)
+    if (tiledCascadeSelected(c))
     {
         int rc = runCascadeTiled(c, pyr, pyr_fs, nF, nChns);
         if (rc)
@@ -5198,7 +5267,7 @@ static void graphRunState(acf_hip_ctx* c, const acf_hip_ctx::GraphSlot& gs)
 // frame waits for every node of the chain (runCascade / runCascadeTiled then skip their own memsets)
 static int preZeroCounters(acf_hip_ctx* c, int nF)
 {
-    if (!c || !c->hasPlan || !c->kids.empty() || !(c->cs.useTiles && !c->noTiles) || c->p.ldcfK > 0 || !c->cs.d_counts || !c->cs.d_qcounts || nF <= 0 ||
+    if (!c || !c->hasPlan || !c->kids.empty() || !tiledCascadeSelected(c) || c->p.ldcfK > 0 || !c->cs.d_counts || !c->cs.d_qcounts || nF <= 0 ||
         nF > c->maxBatch)
     {
         return ACF_HIP_OK;
@@ -6275,11 +6344,11 @@ int acf_hip_op_rgb_convert(acf_hip_ctx* c, const float* in, float* out, int h, i
     {
         if (n % 4 == 0)
         {
-            hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0));
+            hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0), x86T(c));
         }
         else
         {
-            hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0));
+            hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, (const float*)di, dout, (const float*)c->d_lTable, makeLuvConsts(), n, int64_t(0), int64_t(0), x86T(c));
         }
     }
     else if (flag == ACF_HIP_CS_GRAY)
@@ -6368,6 +6437,54 @@ int acf_hip_op_conv_tri(acf_hip_ctx* c, const float* in, float* out, int h, int 
     return ACF_HIP_OK;
 }
 
+int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+{
+    OP_PROLOGUE(c);
+    if (!rcp2048 || !rsqrt2048)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "set_x86_tables: null table");
+    }
+    dropGraph(c);
+    if (!c->d_x86)
+    {
+        // (not one of the plan's buffers: it outlives a re-plan; freed by acf_hip_destroy)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_x86), 4096 * sizeof(uint32_t)));
+        c->x86Owned = true;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // (a run in flight may be reading the previous tables)
+    HIPCHK(c, hipMemcpy(c->d_x86, rcp2048, 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_x86 + 2048, rsqrt2048, 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (acf_hip_ctx* k : c->kids)
+    {
+        k->d_x86 = c->d_x86;
+    }
+    return ACF_HIP_OK;
+}
+
+int acf_hip_selftest_x86(acf_hip_ctx* c, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[2])
+{
+    OP_PROLOGUE(c);
+    if (!digest || !c->d_x86)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "selftest_x86: install tables first (acf_hip_set_x86_tables)");
+    }
+    Scratch s;
+    unsigned long long* d = s.alloc<unsigned long long>(2);
+    if (!d)
+    {
+        return fail(c, ACF_HIP_E_HIP, "selftest_x86: allocation");
+    }
+    HIPCHK(c, hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_x86_digest, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->d_x86, first_bits, (unsigned long long)count, stride, d);
+    LAUNCHCHK(c, "k_x86_digest");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long out[2];
+    HIPCHK(c, hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
+    digest[0] = out[0];
+    digest[1] = out[1];
+    return ACF_HIP_OK;
+}
+
 int acf_hip_selftest_gradmag(acf_hip_ctx* c, uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, uint32_t* first_bad_bits)
 {
     OP_PROLOGUE(c);
@@ -6412,7 +6529,7 @@ int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O,
     {
         return fail(c, ACF_HIP_E_HIP, "op_gradient_mag: allocation");
     }
-    hipLaunchKernelGGL(k_grad_mag_strip, dim3(cdiv(h, GM_ROWS), 1, 1), dim3(GM_ROWS), 0, c->stream, (const float*)di, dM, dO, (const float*)c->d_acos, h, w, full, int64_t(0), int64_t(0), cdiv(w, GM_XT));
+    hipLaunchKernelGGL(k_grad_mag_strip, dim3(cdiv(h, GM_ROWS), 1, 1), dim3(GM_ROWS), 0, c->stream, (const float*)di, dM, dO, (const float*)c->d_acos, h, w, full, int64_t(0), int64_t(0), cdiv(w, GM_XT), x86T(c));
     LAUNCHCHK(c, "k_grad_mag");
     if (normRad)
     {
@@ -6425,7 +6542,7 @@ int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O,
         {
             return rc;
         }
-        hipLaunchKernelGGL(k_norm, dim3(cdiv(np, 256)), dim3(256), 0, c->stream, dM, (const float*)dS, int(np), float(normConst));
+        hipLaunchKernelGGL(k_norm, dim3(cdiv(np, 256)), dim3(256), 0, c->stream, dM, (const float*)dS, int(np), float(normConst), x86T(c));
         LAUNCHCHK(c, "k_norm");
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -6435,6 +6552,203 @@ int acf_hip_op_gradient_mag(acf_hip_ctx* c, const float* in, float* M, float* O,
     {
         HIPCHK(c, hipMemcpy(S_out, dS, sizeof(float) * np, hipMemcpyDeviceToHost));
     }
+    return ACF_HIP_OK;
+}
+
+// Detector::chnsCompute (ACF.h:342-349, chnsCompute.cpp:146-338): the channels of ONE image at its own scale, no pyramid plan.
+int acf_hip_chns_compute(acf_hip_ctx* c, const acf_hip_params* pIn, const float* in, int h, int w, int d, float* out, int64_t cap, int* nChnsOut, int* hCOut,
+    int* wCOut)
+{
+    OP_PROLOGUE(c);
+    const acf_hip_params* pp = pIn ? pIn : (c->hasModel ? &c->p : nullptr);
+    if (!pp)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "chns_compute: no parameters (pass them, or set a model first)");
+    }
+    acf_hip_params p = *pp;
+    if (!in || h <= 0 || w <= 0 || (d != 1 && d != 3))
+    {
+        return fail(c, ACF_HIP_E_INVALID, "chns_compute: arguments");
+    }
+    {
+        std::string err;
+        const int rcc = checkChnsParams(p, d, err); // (the checks acf_hip_plan makes on the same fields)
+        if (rcc)
+        {
+            return fail(c, rcc, "chns_compute: " + err);
+        }
+    }
+    if (p.nOrients < 1 || p.nOrients > 12)
+    {
+        return fail(c, ACF_HIP_E_UNSUPPORTED, "chns_compute: nOrients must be 1..12");
+    }
+    const int shrink = p.shrink;
+    const int hc = h - h % shrink, wc = w - w % shrink; // crop so divisible by shrink (chnsCompute.cpp:203-217)
+    const int dcol = colorPlanes(p), nC = numChannels(p);
+    const int hs = hc / shrink, ws = wc / shrink;
+    if (nChnsOut)
+    {
+        *nChnsOut = nC;
+    }
+    if (hCOut)
+    {
+        *hCOut = hs;
+    }
+    if (wCOut)
+    {
+        *wCOut = ws;
+    }
+    if (!out)
+    {
+        return ACF_HIP_OK; // (a size query)
+    }
+    if (hc < 2 || wc < 2 || hs < 1 || ws < 1)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "chns_compute: image smaller than a cell");
+    }
+    if (cap < int64_t(nC) * hs * ws)
+    {
+        return fail(c, ACF_HIP_E_CAPACITY, "chns_compute: output buffer too small");
+    }
+    const int64_t np = int64_t(hc) * wc;
+    Scratch s;
+    // the cropped planes, tight: [d][wc][hc]
+    std::vector<float> crop;
+    const float* src = in;
+    if (hc != h || wc != w)
+    {
+        crop.resize(size_t(d) * np);
+        for (int z = 0; z < d; z++)
+        {
+            for (int x = 0; x < wc; x++)
+            {
+                memcpy(&crop[(size_t(z) * wc + x) * hc], in + (size_t(z) * w + x) * h, sizeof(float) * hc);
+            }
+        }
+        src = crop.data();
+    }
+    float* dI = s.upload(src, size_t(d) * np);
+    float* dCol = s.alloc<float>(size_t(dcol) * np);
+    float *dM = s.alloc<float>(np), *dO = s.alloc<float>(np), *dU = s.alloc<float>(np), *dS = s.alloc<float>(np);
+    float* dOut = s.alloc<float>(size_t(nC) * hs * ws);
+    if (!dI || !dCol || !dM || !dO || !dU || !dS || !dOut)
+    {
+        return fail(c, ACF_HIP_E_HIP, "chns_compute: allocation");
+    }
+    // rgbConvert(I, I, colorSpace, true, isLuv) (chnsCompute.cpp:235; rgbConvert.cpp:101-170)
+    const bool passthrough = (d == 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+    {
+        dim3 grid(cdiv(np, 256), 1, 1), block(256);
+        if (passthrough)
+        {
+            HIPCHK(c, hipMemcpyAsync(dCol, dI, sizeof(float) * 3 * np, hipMemcpyDeviceToDevice, c->stream));
+        }
+        else if (p.colorSpace == ACF_HIP_CS_LUV)
+        {
+            if (np % 4 == 0)
+            {
+                hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, (const float*)dI, dCol, (const float*)c->d_lTable, makeLuvConsts(), int(np), int64_t(0), int64_t(0), x86T(c));
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, (const float*)dI, dCol, (const float*)c->d_lTable, makeLuvConsts(), int(np), int64_t(0), int64_t(0), x86T(c));
+            }
+        }
+        else if (p.colorSpace == ACF_HIP_CS_GRAY)
+        {
+            const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
+            if (d == 1)
+            {
+                hipLaunchKernelGGL(k_rgb2gray<true>, grid, block, 0, c->stream, (const float*)dI, dCol, int(np), int64_t(0), int64_t(0), mr, mg, mb);
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, (const float*)dI, dCol, int(np), int64_t(0), int64_t(0), mr, mg, mb);
+            }
+        }
+        else if (p.colorSpace == ACF_HIP_CS_HSV)
+        {
+            hipLaunchKernelGGL(k_rgb2hsv, grid, block, 0, c->stream, (const float*)dI, dCol, int(np), int64_t(0), int64_t(0));
+        }
+        else
+        {
+            hipLaunchKernelGGL(k_replicate3, grid, block, 0, c->stream, (const float*)dI, dCol, int(np), int64_t(0), int64_t(0));
+        }
+        LAUNCHCHK(c, "chns_compute: colour conversion");
+    }
+    // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
+    if (p.colorSmooth > 0)
+    {
+        if (p.colorSmooth > 1)
+        {
+            return fail(c, ACF_HIP_E_UNSUPPORTED, "chns_compute: pColor.smooth > 1 (convTri with a radius) is not built for the colour planes");
+        }
+        SmoothJob j{};
+        j.h = hc;
+        j.w = wc;
+        j.nplanes = dcol;
+        j.out_cs = hc;
+        j.in_ps = np;
+        j.out_ps = np;
+        SmoothJob* dJ = s.upload(&j, 1);
+        if (!dJ)
+        {
+            return fail(c, ACF_HIP_E_HIP, "chns_compute: allocation");
+        }
+        const float pColor = float(12.0 / p.colorSmooth / (p.colorSmooth + 2.0) - 2.0);
+        int rc = launchSmooth(c, dCol, dCol, dJ, 1, dcol, hc, int64_t(dcol) * np, int64_t(dcol) * np, 1, pColor, true);
+        if (rc)
+        {
+            return rc;
+        }
+    }
+    ChnsArgs a{};
+    a.sm = dCol;
+    a.M = dM;
+    a.S = dS;
+    a.O = dO;
+    a.chns = dOut;
+    a.sm_fs = int64_t(dcol) * np;
+    a.m_fs = np;
+    a.chns_fs = int64_t(nC) * hs * ws;
+    a.h = hc;
+    a.w = wc;
+    a.d = dcol;
+    a.colorEnabled = p.colorEnabled;
+    a.magEnabled = p.gradMagEnabled;
+    a.histEnabled = p.gradHistEnabled;
+    a.nOrients = p.nOrients;
+    a.doNorm = p.normRad != 0;
+    a.full = p.full;
+    a.hardBin = p.softBin < 0;
+    a.normConst = float(p.normConst);
+    a.rq_y = shrinkGainY(shrink);
+    a.x86 = x86T(c);
+    if (p.gradMagEnabled || p.gradHistEnabled)
+    {
+        hipLaunchKernelGGL(k_grad_mag_strip, dim3(cdiv(hc, GM_ROWS), 1, 1), dim3(GM_ROWS), 0, c->stream, (const float*)(dCol + int64_t(p.colorChn) * np), dM, dO,
+            (const float*)c->d_acos, hc, wc, p.full, int64_t(0), int64_t(0), cdiv(wc, GM_XT), x86T(c));
+        LAUNCHCHK(c, "chns_compute: k_grad_mag");
+        if (p.normRad)
+        {
+            if (std::min(hc, wc) < 4 || 2 * p.normRad + 1 >= std::min(hc, wc) || p.normRad < 2)
+            {
+                return fail(c, ACF_HIP_E_UNSUPPORTED, "chns_compute: normRad against the image size");
+            }
+            int rc = launchTri(c, dM, dU, dS, hc, wc, p.normRad, np, 1);
+            if (rc)
+            {
+                return rc;
+            }
+        }
+    }
+    int rc = launchChns(c, a, shrink, 1);
+    if (rc)
+    {
+        return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dOut, sizeof(float) * size_t(nC) * hs * ws, hipMemcpyDeviceToHost));
     return ACF_HIP_OK;
 }
 

@@ -323,6 +323,61 @@ int numChannels(const acf_hip_params& p)
     return (p.colorEnabled ? colorPlanes(p) : 0) + (p.gradMagEnabled ? 1 : 0) + (p.gradHistEnabled ? p.nOrients : 0);
 }
 
+// The checks on the Options::Pyramid::Chns fields (and the input's planes) that every entry computing channels makes:
+// acf_hip_plan (buildPlan) and acf_hip_chns_compute.  err: the message without its "plan: " / "chns_compute: " prefix.
+int checkChnsParams(const acf_hip_params& p, int d_in, std::string& err)
+{
+    if (p.shrink != 4 && p.shrink != 2)
+    {
+        err = "shrink must be 2 or 4";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.binSize != 0 && p.binSize != p.shrink)
+    {
+        err = "binSize != shrink";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    // gradHist's branches (gradientMex.cpp:391-509): softBin even — orientation interpolated (>= 0) or nearest bin (< 0), no spatial
+    // interpolation — are built; odd softBin is the trilinear form (HOG / FHOG features, not an ACF channel set)
+    if (p.softBin % 2 != 0)
+    {
+        err = "odd softBin (trilinear spatial binning) is not built";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (!(p.gradMagEnabled || p.gradHistEnabled || p.colorEnabled))
+    {
+        err = "no channels enabled";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.colorSpace != ACF_HIP_CS_LUV && p.colorSpace != ACF_HIP_CS_GRAY && p.colorSpace != ACF_HIP_CS_ORIG && p.colorSpace != ACF_HIP_CS_RGB &&
+        p.colorSpace != ACF_HIP_CS_HSV)
+    {
+        err = "colour space";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
+    if (p.isLuv && p.colorSpace == ACF_HIP_CS_HSV)
+    {
+        err = "isLuv with hsv (rgbConvert.cpp:150-155)";
+        return ACF_HIP_E_INVALID;
+    }
+    if (d_in == 1 && !(p.colorSpace == ACF_HIP_CS_GRAY || p.colorSpace == ACF_HIP_CS_ORIG))
+    {
+        err = "1-plane input needs colorSpace gray or orig (rgbConvert.cpp:140-148)";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.isLuv && p.colorSpace == ACF_HIP_CS_GRAY)
+    {
+        err = "isLuv with gray (rgbConvert.cpp:150-155)";
+        return ACF_HIP_E_INVALID;
+    }
+    if (p.colorChn < 0 || p.colorChn >= colorPlanes(p))
+    {
+        err = "colorChn";
+        return ACF_HIP_E_INVALID;
+    }
+    return ACF_HIP_OK;
+}
+
 int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err)
 {
     plan = Plan();
@@ -331,52 +386,17 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
         err = "plan: bad frame geometry";
         return ACF_HIP_E_INVALID;
     }
-    if (p.shrink != 4 && p.shrink != 2)
     {
-        err = "plan: shrink must be 2 or 4";
-        return ACF_HIP_E_UNSUPPORTED;
-    }
-    if (p.binSize != 0 && p.binSize != p.shrink)
-    {
-        err = "plan: binSize != shrink";
-        return ACF_HIP_E_UNSUPPORTED;
-    }
-    // gradHist's branches (gradientMex.cpp:391-509): softBin even — orientation interpolated (>= 0) or nearest bin (< 0), no spatial
-    // interpolation — are built; odd softBin is the trilinear form (HOG / FHOG features, not an ACF channel set)
-    if (p.softBin % 2 != 0)
-    {
-        err = "plan: odd softBin (trilinear spatial binning) is not built";
-        return ACF_HIP_E_UNSUPPORTED;
+        const int rcc = checkChnsParams(p, d_in, err);
+        if (rcc)
+        {
+            err = "plan: " + err;
+            return rcc;
+        }
     }
     if (p.nApprox > 0 && p.nLambdas != 3 && p.nLambdas != 0)
     {
         err = "plan: lambdas: none (estimated per image, chnsPyramid.cpp:341-374) or three (colour, gradMag, gradHist)";
-        return ACF_HIP_E_INVALID;
-    }
-    if (!(p.gradMagEnabled || p.gradHistEnabled || p.colorEnabled))
-    {
-        err = "plan: no channels enabled";
-        return ACF_HIP_E_INVALID;
-    }
-    if (p.colorSpace != ACF_HIP_CS_LUV && p.colorSpace != ACF_HIP_CS_GRAY && p.colorSpace != ACF_HIP_CS_ORIG && p.colorSpace != ACF_HIP_CS_RGB &&
-        p.colorSpace != ACF_HIP_CS_HSV)
-    {
-        err = "plan: colour space";
-        return ACF_HIP_E_UNSUPPORTED;
-    }
-    if (p.isLuv && p.colorSpace == ACF_HIP_CS_HSV)
-    {
-        err = "plan: isLuv with hsv (rgbConvert.cpp:150-155)";
-        return ACF_HIP_E_INVALID;
-    }
-    if (d_in == 1 && !(p.colorSpace == ACF_HIP_CS_GRAY || p.colorSpace == ACF_HIP_CS_ORIG))
-    {
-        err = "plan: 1-plane input needs colorSpace gray or orig (rgbConvert.cpp:140-148)";
-        return ACF_HIP_E_INVALID;
-    }
-    if (p.isLuv && p.colorSpace == ACF_HIP_CS_GRAY)
-    {
-        err = "plan: isLuv with gray (rgbConvert.cpp:150-155)";
         return ACF_HIP_E_INVALID;
     }
     plan.H = H;
@@ -384,11 +404,6 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
     plan.d_in = d_in;
     plan.d = colorPlanes(p);
     plan.nChns = numChannels(p);
-    if (p.colorChn < 0 || p.colorChn >= plan.d)
-    {
-        err = "plan: colorChn";
-        return ACF_HIP_E_INVALID;
-    }
     const int shrink = p.shrink;
     ScaleList sl = getScales(p.nPerOct, p.nOctUp, p.minDs_h, p.minDs_w, shrink, H, W);
     const int n = int(sl.scales.size());

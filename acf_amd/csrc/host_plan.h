@@ -92,6 +92,7 @@ struct Plan
 };
 
 int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err);
+int checkChnsParams(const acf_hip_params& p, int d_in, std::string& err);
 
 // ---- threshold-rank cells (the cascade's 16-bit pyramid) --------------------------------------------------------------
 // The cascade only ever evaluates `chns[cid] < thrs[node]` (acfDetect1.cpp:102-104,157-166).  Per channel, let

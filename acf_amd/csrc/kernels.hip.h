@@ -11,7 +11,8 @@
 // with -ffp-contract=off, so results are bit-identical to the IEEE
 // restatement of that code.  The reference's three approximate-instruction
 // sites (_mm_rsqrt_ps/_mm_rcp_ps, toolbox/sse.hpp:185-192) use correctly
-// rounded 1/sqrt and 1/x here.
+// rounded 1/sqrt and 1/x here ("T-exact"), or — option "arith" = 1 — the bits
+// of one x86 CPU's instructions from its tables (x86_rcp / x86_rsqrt below).
 #pragma once
 
 #include "host_plan.h"
@@ -25,6 +26,72 @@ namespace acfhip
 // address-space-qualified pointers for __builtin_amdgcn_global_load_lds (LDS-DMA)
 typedef const __attribute__((address_space(1))) void* gptr_t;  // global
 typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
+
+// ------------------------------------------------------------------------
+// The reference's arithmetic at its three approximate sites (gradientMex.cpp:209-219,266; rgbConvertMex.cpp:161; sse.hpp:185-192).
+// _mm_rcp_ps / _mm_rsqrt_ps are functions of (sign, exponent / its parity, the top 11 / 10 mantissa bits) on the CPUs probed
+// (tests/golden/make_x86_tables.py checks all 2^32 inputs): T[0 .. 2047] holds rcp over [1, 2) by m >> 12, T[2048 .. 4095] rsqrt over
+// [1, 2) and [2, 4) by m >> 13.  Zero / subnormal -> inf of that sign, inf -> 0, NaN quieted, rcp results below the normal range
+// flushed to zero, rsqrt of a negative -> the default NaN.  The device's functions and the CPU checker's are compared over
+// every input by digest (acf_hip_selftest_x86, tests/test_gpu_arith.py).
+// ------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t x86_rcp_bits(uint32_t u, const uint32_t* __restrict__ T)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : s;
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    const uint32_t t = T[m >> 12];
+    const int re = int((t >> 23) & 0xffu) + 127 - int(e);
+    return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
+}
+__device__ __forceinline__ uint32_t x86_rsqrt_bits(uint32_t u, const uint32_t* __restrict__ T)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : (s ? 0xffc00000u : 0u);
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    if (s)
+    {
+        return 0xffc00000u;
+    }
+    const int ue = int(e) - 127, odd = ue & 1, half = (ue - odd) / 2;
+    const uint32_t t = T[2048 + ((odd << 10) | int(m >> 13))];
+    return (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
+}
+__device__ __forceinline__ float x86_rcp(float x, const uint32_t* __restrict__ T)
+{
+    return __uint_as_float(x86_rcp_bits(__float_as_uint(x), T));
+}
+__device__ __forceinline__ float x86_rsqrt(float x, const uint32_t* __restrict__ T)
+{
+    return __uint_as_float(x86_rsqrt_bits(__float_as_uint(x), T));
+}
+// position-mixed digests of both functions over first + i * stride, i < count (the CPU checker forms the same sums): out[0] rcp, out[1] rsqrt
+__global__ void __launch_bounds__(256) k_x86_digest(const uint32_t* __restrict__ T, uint32_t first, unsigned long long count, uint32_t stride,
+    unsigned long long* __restrict__ out)
+{
+    unsigned long long a = 0, b = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256)
+    {
+        const uint32_t u = first + uint32_t(i * stride);
+        const unsigned long long k = ((unsigned long long)u * 0x9e3779b97f4a7c15ull) | 1ull;
+        a += k * x86_rcp_bits(u, T);
+        b += k * x86_rsqrt_bits(u, T);
+    }
+    atomicAdd(&out[0], a);
+    atomicAdd(&out[1], b);
+}
 
 } // namespace acfhip
 

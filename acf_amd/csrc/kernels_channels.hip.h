@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(256) k_pad_reflect(T* __restrict__ pyr, const 
 #define GM_XT 8
 #define GM_ROWS 384
 __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
-    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int stripsPerBlock)
+    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int stripsPerBlock, const uint32_t* __restrict__ x86)
 {
     __shared__ float acosL[GM_ACOS_N];
     for (int i = threadIdx.x; i < GM_ACOS_N; i += GM_ROWS)
@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
             const float gx = (c[j + 2] - c[j]) * rx;
             const float gy = (dn[j] - up[j]) * ry;
             const float m2 = gx * gx + gy * gy;
-            float m = 1.0f / sqrtf(m2);
+            float m = x86 ? x86_rsqrt(m2, x86) : 1.0f / sqrtf(m2);
             m = m < 1e10f ? m : 1e10f;
             float g = (gx * m) * 10000.0f;
             g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
             if (x < w && y < h)
             {
                 const int64_t o = int64_t(blockIdx.z) * out_fs + int64_t(x) * h + y;
-                M[o] = 1.0f / m;
+                M[o] = x86 ? x86_rcp(m, x86) : 1.0f / m;
                 O[o] = ov;
             }
         }
@@ -1408,6 +1408,7 @@ struct ChnsArgs
     float normConst, rq; // rq = (1/S)/(1+1e-6) then /S in the y pass (imResampleMex.cpp:145-157,316)
     float rq_y;
     int32_t nybM;      // blocked M / O (k_triy_chns<.., true>): 16-row blocks per column block, ceil(h / 16); m_fs is then the blocked frame stride
+    const uint32_t* x86; // option "arith": gradMagNorm's reciprocal from the CPU tables (k_chns only; null: exact)
 };
 
 template <int S>
@@ -1911,7 +1912,7 @@ __global__ void __launch_bounds__(256) k_chns(ChnsArgs a)
                     const float s = sraw[xx][yy];
                     // vector body of gradMagNorm: M * rcp(S + norm); the scalar tail
                     // (last n%4 elements) divides — n%4 == 0 here since h % shrink == 0, shrink in {2,4}... see launch
-                    m = m * (1.0f / (s + a.normConst));
+                    m = a.x86 ? m * x86_rcp(s + a.normConst, a.x86) : m * (1.0f / (s + a.normConst));
                 }
                 mn[xx][yy] = m;
                 if (a.Mn)

@@ -18,15 +18,18 @@ struct LuvConsts
 // rgb2luv_sse body (:129-187) when VEC, else the scalar rgb2luv (:69-83); the
 // reference picks VEC iff n % 4 == 0.  lTable: 1064 floats built on the host
 // exactly as rgb2luv_setup does (:39-58).
+// x86: the table of the CPU whose _mm_rcp_ps the SSE body's one reciprocal (:161) reproduces (option "arith"), or null: 1 / x.
 template <bool VEC>
-__device__ __forceinline__ void luv_px(float r, float g, float b, const float* __restrict__ lTable, const LuvConsts& k, float& L, float& U, float& V)
+__device__ __forceinline__ void luv_px(float r, float g, float b, const float* __restrict__ lTable, const LuvConsts& k, float& L, float& U, float& V,
+    const uint32_t* __restrict__ x86 = nullptr)
 {
     if (VEC)
     {
         const float x = (r * k.mr[0] + g * k.mg[0]) + b * k.mb[0];
         const float y = (r * k.mr[1] + g * k.mg[1]) + b * k.mb[1];
         const float z = (r * k.mr[2] + g * k.mg[2]) + b * k.mb[2];
-        const float zz = 1.0f / (x + (1e-35f + (15.0f * y + 3.0f * z)));
+        const float den = x + (1e-35f + (15.0f * y + 3.0f * z));
+        const float zz = x86 ? x86_rcp(den, x86) : 1.0f / den;
         const float lf = 1024.0f * y;
         const float u = (52.0f * x) * zz - k.cun;
         const float v = (117.0f * y) * zz - k.cvn;
@@ -48,7 +51,7 @@ __device__ __forceinline__ void luv_px(float r, float g, float b, const float* _
 
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_rgb2luv(const float* __restrict__ in, float* __restrict__ out,
-    const float* __restrict__ lTable, LuvConsts k, int n, int64_t in_fs, int64_t out_fs)
+    const float* __restrict__ lTable, LuvConsts k, int n, int64_t in_fs, int64_t out_fs, const uint32_t* __restrict__ x86)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(256) k_rgb2luv(const float* __restrict__ in, f
     float* J = out + int64_t(blockIdx.z) * out_fs;
     const float r = I[i], g = I[i + n], b = I[i + 2 * int64_t(n)];
     float L, U, V;
-    luv_px<VEC>(r, g, b, lTable, k, L, U, V);
+    luv_px<VEC>(r, g, b, lTable, k, L, U, V, x86);
     J[i] = L;
     J[i + n] = U;
     J[i + 2 * int64_t(n)] = V;
@@ -195,6 +198,7 @@ struct IngestArgs
     int64_t out_fs;  // floats between output frames
     int nOut;        // IG_PLANAR: 1 or 3 planes
     int vecStore;    // H % 4 == 0: float4 stores
+    const uint32_t* x86; // option "arith": the CPU tables for rgb2luv_sse's reciprocal (null: exact)
 };
 
 constexpr int IG_T = 64;
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(256) k_ingest_u8(IngestArgs a)
             }
             else
             {
-                luv_px<MODE == IG_LUV_VEC>(r, g, b, a.lTable, a.k, o[0][j], o[1][j], o[2][j]);
+                luv_px<MODE == IG_LUV_VEC>(r, g, b, a.lTable, a.k, o[0][j], o[1][j], o[2][j], a.x86);
             }
         }
         const int nPl = (MODE == IG_PLANAR) ? a.nOut : (MODE == IG_GRAY ? 1 : 3);

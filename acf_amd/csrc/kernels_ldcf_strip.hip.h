@@ -565,8 +565,8 @@ __global__ void __launch_bounds__(RS_NT) k_resample_strip(StripArgs a)
             strip_xpass<RS_KCH>(T, C + wv * RS_CP, exA, r0, r1, colLoCur, 0, 1, rowsP, rowLo, ha);
         }
         const bool stepB = HAVEB && tileB && s < a.nStepsB;
-        if (HAVEB)
-        {
+        if (HAVEB && stepB) // (uniform.  Past B's last step / row tile its records are clamped to B's last column, whose taps lie
+        {                   // outside the tile in LDS: nothing of B is stored in such a step, so nothing is computed either)
             const int4 r0 = rec4(2 * (RS_XO + (wv >> 1))), r1 = rec4(2 * (RS_XO + (wv >> 1)) + 1);
             strip_xpass<(RS_KCH + 1) / 2>(T, C + (RS_XO + (wv >> 1)) * RS_CP, exB, r0, r1, colLoCur, wv & 1, 2, rowsP, rowLo, ha);
         }

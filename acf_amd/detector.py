@@ -208,6 +208,21 @@ class HipDetector:
     def set_option(self, key, value):
         self._chk(self.lib.acf_hip_set_option(self.ctx, key.encode(), int(value)))
 
+    def set_x86_tables(self, rcp, rsqrt):
+        """Install one x86 CPU's _mm_rcp_ps / _mm_rsqrt_ps tables (2 x 2048 uint32, acf_hip_set_x86_tables); option "arith" = 1
+        then makes the reference's three approximate sites return that CPU's bits."""
+        rcp = np.ascontiguousarray(rcp, dtype=np.uint32)
+        rsqrt = np.ascontiguousarray(rsqrt, dtype=np.uint32)
+        assert rcp.shape == (2048,) and rsqrt.shape == (2048,)
+        u32p = C.POINTER(C.c_uint32)
+        self._chk(self.lib.acf_hip_set_x86_tables(self.ctx, rcp.ctypes.data_as(u32p), rsqrt.ctypes.data_as(u32p)))
+
+    def selftest_x86(self, first, count, stride=1):
+        """(rcp digest, rsqrt digest) of the device's table functions over the bit patterns first + i * stride."""
+        out = (C.c_uint64 * 2)()
+        self._chk(self.lib.acf_hip_selftest_x86(self.ctx, C.c_uint32(first), C.c_uint64(count), C.c_uint32(stride), out))
+        return int(out[0]), int(out[1])
+
     def profile(self):
         """{kernel name: (total ms, launches)} since the last call (option "profile")."""
         cap = 64
@@ -303,6 +318,21 @@ class HipDetector:
         self._chk(self.lib.acf_hip_op_gradient_mag(self.ctx, capi.fptr(a), capi.fptr(M), capi.fptr(O), capi.fptr(S), h, w, normRad, normConst, full))
         return M, O, S
 
+    def chns_compute(self, a, model=None):
+        """Detector::chnsCompute: a = host planes [d][w][h]; model = a dict like synth.make_model's (its Chns fields are read) or
+        None for the context's model.  Returns [nChns][w / shrink][h / shrink]."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        d, w, h = a.shape
+        pp, keep = (None, None)
+        if model is not None:
+            prm, keep = capi.make_params(model)
+            pp = C.byref(prm)
+        n, hc, wc = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.acf_hip_chns_compute(self.ctx, pp, capi.fptr(a), h, w, d, None, 0, C.byref(n), C.byref(hc), C.byref(wc)))
+        out = np.zeros((n.value, wc.value, hc.value), np.float32)
+        self._chk(self.lib.acf_hip_chns_compute(self.ctx, pp, capi.fptr(a), h, w, d, capi.fptr(out), out.size, C.byref(n), C.byref(hc), C.byref(wc)))
+        return out
+
     def op_gradient_hist(self, M, O, bin=4, nOrients=6, full=0, softBin=0):
         M = np.ascontiguousarray(M, dtype=np.float32)
         O = np.ascontiguousarray(O, dtype=np.float32)
@@ -355,7 +385,11 @@ class DetectorPool:
     measure +16 % over one context x 256 frames on an MI355X (profiles/ubench/two_contexts.py).
     """
 
-    def __init__(self, n, model, H, W, d_in=3, max_batch=1, max_hits=4096, device=0, **kw):
+    def __init__(self, n, model, H, W, d_in=3, max_batch=1, max_hits=4096, device=0, shared_device=True, **kw):
+        """shared_device (default on, n > 1 only): the contexts' kernel forms are chosen for the least total work because other
+        contexts' kernels fill the machine meanwhile (uncut smoothing chains, convTri's x pass on the gradient plane's chain for
+        batches >= 64 frames): +4.3 % frames/s when the contexts really run side by side, -7 % when they do not — a pool that is
+        fed one context at a time with a synchronise between batches should pass shared_device=False."""
         import torch
         self.streams = [torch.cuda.Stream(device=torch.device("cuda", device)) for _ in range(n)]
         self.dets = [HipDetector(model, H, W, d_in, max_batch=max_batch, max_hits=max_hits, device=device, stream=s.cuda_stream, **kw)
@@ -370,7 +404,7 @@ class DetectorPool:
             for d in self.dets:
                 d.set_option("cascade_turns", 5)
                 d.set_option("tile_persist", 0)
-                d.set_option("shared_device", 1)
+                d.set_option("shared_device", 1 if shared_device else 0)
 
     def __len__(self):
         return len(self.dets)

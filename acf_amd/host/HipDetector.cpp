@@ -3,9 +3,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <thread>
+#if defined(__SSE__)
+#include <xmmintrin.h>
+#endif
 
 namespace acf
 {
@@ -174,7 +179,7 @@ void HipDetector::fillParams(acf_hip_params& p) const
     p.binSize = ch.pGradHist.binSize;
     p.nOrients = ch.pGradHist.nOrients;
     p.softBin = ch.pGradHist.softBin;
-    p.isLuv = m_isLuv ? 1 : 0;
+    p.isLuv = (m_isLuv || ch.isLuv) ? 1 : 0;
     // LDCF post-stage (no reference counterpart; include/acf_hip.h): filters [k][nChns][5][5], MATLAB order of fs(:,:,c,f)
     p.ldcfK = opts.ldcfFilters.empty() ? 0 : opts.ldcfK;
     p.ldcfFilters = opts.ldcfFilters.empty() ? nullptr : opts.ldcfFilters.data();
@@ -433,8 +438,45 @@ int HipDetector::operator()(const MatP& Ip, RectVec& objects, RealVec* scores)
     ensurePlan(Ip.cols(), Ip.rows(), Ip.channels(), 1);
     syncNms();
     check(m_api->acf_hip_run_host(m_ctx, Ip.data(), 1), "acf_hip_run_host");
+    if (m_logger)
+    {
+        logPyramid();
+    }
     fetch(0, objects, scores);
     return 0;
+}
+
+// ACF.cpp:252-262: every level of the pyramid, transposed (upright: rows = nChns * hP ... of the fused buffer's transpose) and
+// stretched to 0..255 as cv::normalize(d, canvas, 0, 255, NORM_MINMAX, CV_8UC1) does: (v - min) * (255 / (max - min)), rounded
+// half to even and saturated (cv::saturate_cast<uchar>(cvRound)).  OpenCV's arithmetic restated: parity unpinned.
+void HipDetector::logPyramid()
+{
+    for (size_t i = 0; i < m_levels.size(); i++)
+    {
+        const acf_hip_level& l = m_levels[i];
+        const int rows = l.wP * m_nChns, cols = l.hP; // the fused buffer [nChns * wP rows][hP cols]
+        MatP lev(rows, cols, 1);
+        check(m_api->acf_hip_read_level(m_ctx, 0, int(i), lev.data()), "acf_hip_read_level");
+        float lo = lev.data()[0], hi = lo;
+        for (size_t k = 0; k < lev.numel(); k++)
+        {
+            lo = std::min(lo, lev.data()[k]);
+            hi = std::max(hi, lev.data()[k]);
+        }
+        const double sc = hi > lo ? 255.0 / (double(hi) - double(lo)) : 0.0;
+        MatP canvas(cols, rows, 1); // .t()
+        for (int r = 0; r < rows; r++)
+        {
+            for (int c = 0; c < cols; c++)
+            {
+                const double v = (double(lev.data()[size_t(r) * cols + c]) - double(lo)) * sc;
+                canvas.data()[size_t(c) * rows + r] = float(std::min(255.0, std::max(0.0, std::nearbyint(v))));
+            }
+        }
+        char tag[16];
+        std::snprintf(tag, sizeof(tag), "%06d", int(i));
+        m_logger(canvas, tag);
+    }
 }
 
 int HipDetector::operator()(const float* rgb, int rows, int cols, RectVec& objects, RealVec* scores)
@@ -992,6 +1034,383 @@ int HipDetector::gradientHist(const MatP& M, const MatP& O, MatP& H, int binSize
     H.create(M.rows() / binSize, M.cols() / binSize, nOrients);
     check(m_api->acf_hip_op_gradient_hist(m_ctx, M.data(), O.data(), H.data(), M.cols(), M.rows(), binSize, nOrients, softBin, full), "acf_hip_op_gradient_hist");
     return 0;
+}
+
+// ---- chnsCompute / computeChannels as the reference's static functions: a process-wide utility context per device
+namespace
+{
+struct UtilCtx
+{
+    std::mutex m;
+    std::vector<acf_hip_ctx*> ctx; // by device ordinal
+};
+UtilCtx& utilCtx()
+{
+    static UtilCtx u; // (contexts live until the process ends, like the reference's function-static tables)
+    return u;
+}
+acf_hip_ctx* utilContext(const hip::Api& api, int device)
+{
+    UtilCtx& u = utilCtx();
+    if (device < 0)
+    {
+        throw Exception(ACF_HIP_E_INVALID, "chnsCompute: device");
+    }
+    if (size_t(device) >= u.ctx.size())
+    {
+        u.ctx.resize(size_t(device) + 1, nullptr);
+    }
+    if (!u.ctx[size_t(device)])
+    {
+        const int rc = api.acf_hip_create(device, nullptr, &u.ctx[size_t(device)]);
+        if (rc != ACF_HIP_OK)
+        {
+            u.ctx[size_t(device)] = nullptr;
+            throw Exception(rc, "chnsCompute: acf_hip_create failed (no gfx950 device?)");
+        }
+    }
+    return u.ctx[size_t(device)];
+}
+void utilCheck(const hip::Api& api, acf_hip_ctx* c, int rc, const char* what)
+{
+    if (rc != ACF_HIP_OK)
+    {
+        throw Exception(rc, std::string(what) + ": " + api.acf_hip_last_error(c));
+    }
+}
+void chnsParams(const HipDetector::Options::Pyramid::Chns& ch, acf_hip_params& p)
+{
+    p = acf_hip_params{};
+    p.shrink = ch.shrink;
+    p.colorEnabled = ch.pColor.enabled;
+    p.colorSmooth = ch.pColor.smooth;
+    p.colorSpace = colorSpaceFlag(ch.pColor.colorSpace);
+    p.gradMagEnabled = ch.pGradMag.enabled;
+    p.colorChn = ch.pGradMag.colorChn;
+    p.normRad = ch.pGradMag.normRad;
+    p.normConst = ch.pGradMag.normConst;
+    p.full = ch.pGradMag.full;
+    p.gradHistEnabled = ch.pGradHist.enabled;
+    p.binSize = ch.pGradHist.binSize;
+    p.nOrients = ch.pGradHist.nOrients;
+    p.softBin = ch.pGradHist.softBin;
+    p.isLuv = ch.isLuv ? 1 : 0;
+}
+std::string planeTag(const char* name, int cols, int rows)
+{
+    return std::string(name) + ":" + std::to_string(cols) + "x" + std::to_string(rows);
+}
+} // namespace
+
+int HipDetector::chnsCompute(const MatP& IIn, const Options::Pyramid::Chns& pChns, Channels& chns, bool isInit, const MatLoggerType& pLogger, int device)
+{
+    chns.pChns = pChns; // (the flattened Options tree is complete by construction: the merge of chnsCompute.cpp:154-195 has nothing to fill)
+    if (isInit || IIn.empty())
+    {
+        return 0; // "return the estimate" (:197-198)
+    }
+    const hip::Api& api = hip::load();
+    UtilCtx& u = utilCtx();
+    std::lock_guard<std::mutex> lock(u.m);
+    acf_hip_ctx* c = utilContext(api, device);
+    acf_hip_params p;
+    chnsParams(pChns, p);
+    const int h = IIn.cols(), w = IIn.rows(), d = IIn.channels(); // rows = image width, cols = image height
+    int nC = 0, hc = 0, wc = 0;
+    utilCheck(api, c, api.acf_hip_chns_compute(c, &p, IIn.data(), h, w, d, nullptr, 0, &nC, &hc, &wc), "acf_hip_chns_compute");
+    const int dcol = p.colorSpace == ACF_HIP_CS_GRAY ? 1 : 3;
+    std::vector<float> all(size_t(nC) * hc * wc);
+    if (!pLogger)
+    {
+        utilCheck(api, c, api.acf_hip_chns_compute(c, &p, IIn.data(), h, w, d, all.data(), int64_t(all.size()), &nC, &hc, &wc), "acf_hip_chns_compute");
+    }
+    else
+    {
+        // stage by stage through the single-operator entries, reporting what chnsCompute reports
+        const int shrink = p.shrink, H = h - h % shrink, W = w - w % shrink;
+        const size_t np = size_t(H) * W, ns = size_t(hc) * wc;
+        MatP I(W, H, d);
+        for (int z = 0; z < d; z++)
+        {
+            for (int x = 0; x < W; x++)
+            {
+                std::memcpy(I[z] + size_t(x) * H, IIn[z] + size_t(x) * h, sizeof(float) * H); // the crop (:203-217)
+            }
+        }
+        MatP col(W, H, dcol);
+        const bool pass = d == 3 && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+        if (pass)
+        {
+            std::memcpy(col.data(), I.data(), sizeof(float) * 3 * np);
+        }
+        else if (d == 1 && p.colorSpace == ACF_HIP_CS_ORIG)
+        {
+            for (int z = 0; z < 3; z++)
+            {
+                std::memcpy(col[z], I.data(), sizeof(float) * np); // (a 1-plane image replicated: chnsPyramid.cpp:242-243)
+            }
+        }
+        else if (d == 1)
+        {
+            MatP rep(W, H, 3);
+            for (int z = 0; z < 3; z++)
+            {
+                std::memcpy(rep[z], I.data(), sizeof(float) * np);
+            }
+            utilCheck(api, c, api.acf_hip_op_rgb_convert(c, rep.data(), col.data(), H, W, p.colorSpace), "acf_hip_op_rgb_convert");
+        }
+        else
+        {
+            utilCheck(api, c, api.acf_hip_op_rgb_convert(c, I.data(), col.data(), H, W, p.colorSpace), "acf_hip_op_rgb_convert");
+        }
+        if (p.colorSmooth > 0)
+        {
+            MatP sm(W, H, dcol);
+            utilCheck(api, c, api.acf_hip_op_conv_tri(c, col.data(), sm.data(), H, W, dcol, p.colorSmooth, 1), "acf_hip_op_conv_tri");
+            col = sm;
+        }
+        static const char* luv[3] = { "L", "U", "V" };
+        for (int z = 0; z < dcol; z++)
+        {
+            MatP plane(W, H, 1, col[z]);
+            pLogger(plane, planeTag(dcol == 3 ? luv[z] : "L", H, W));
+        }
+        float* o = all.data();
+        if (p.colorEnabled)
+        {
+            utilCheck(api, c, api.acf_hip_op_im_resample(c, col.data(), o, H, W, hc, wc, dcol, 1.0), "acf_hip_op_im_resample");
+            o += ns * dcol;
+        }
+        if (p.gradMagEnabled || p.gradHistEnabled)
+        {
+            MatP M(W, H, 1), O(W, H, 1), Mn(W, H, 1), On(W, H, 1);
+            utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], M.data(), O.data(), nullptr, H, W, 0, p.normConst, p.full), "acf_hip_op_gradient_mag");
+            pLogger(M, planeTag("M", H, W)); // gradientMag.cpp:119-123: before the normalisation
+            utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], Mn.data(), On.data(), nullptr, H, W, p.normRad, p.normConst, p.full), "acf_hip_op_gradient_mag");
+            pLogger(Mn, planeTag("Mnorm", H, W));
+            pLogger(On, planeTag("O", H, W));
+            if (p.gradMagEnabled)
+            {
+                utilCheck(api, c, api.acf_hip_op_im_resample(c, Mn.data(), o, H, W, hc, wc, 1, 1.0), "acf_hip_op_im_resample");
+                o += ns;
+            }
+            if (p.gradHistEnabled)
+            {
+                utilCheck(api, c, api.acf_hip_op_gradient_hist(c, Mn.data(), On.data(), o, H, W, shrink, p.nOrients, p.softBin, p.full), "acf_hip_op_gradient_hist");
+                MatP hcat(wc, p.nOrients * hc, 1); // cv::hconcat of the planes (:322-329)
+                for (int b = 0; b < p.nOrients; b++)
+                {
+                    for (int r = 0; r < wc; r++)
+                    {
+                        std::memcpy(hcat.data() + (size_t(r) * p.nOrients + b) * hc, o + (size_t(b) * wc + r) * hc, sizeof(float) * hc);
+                    }
+                }
+                pLogger(hcat, planeTag("H", p.nOrients * hc, wc));
+            }
+        }
+    }
+    // addChn (:340-370): one entry per enabled type
+    chns.data.clear();
+    chns.info.clear();
+    const float* o = all.data();
+    auto add = [&](int n, const char* name, const char* padWith) {
+        MatP m(wc, hc, n);
+        std::memcpy(m.data(), o, sizeof(float) * m.numel());
+        o += m.numel();
+        chns.data.push_back(m);
+        Channels::Info info;
+        info.name = name;
+        info.nChns = n;
+        info.padWith = padWith;
+        chns.info.push_back(info);
+    };
+    if (p.colorEnabled)
+    {
+        add(dcol, "color channels", "replicate");
+    }
+    if (p.gradMagEnabled)
+    {
+        add(1, "gradient magnitude", "");
+    }
+    if (p.gradHistEnabled)
+    {
+        add(p.nOrients, "gradient histogram", "");
+    }
+    chns.nTypes = int(chns.data.size());
+    return 0;
+}
+
+void HipDetector::computeChannels(const MatP& Ip, MatP& Ip2, const MatLoggerType& pLogger, int device)
+{
+    // ACF.cpp:185-232: the toolbox defaults (shrink 4; colour luv, smooth 1; gradMag normRad 5, normConst .005; 6 orientations)
+    Options::Pyramid::Chns dfs;
+    Channels chns;
+    chnsCompute(Ip, dfs, chns, false, pLogger, device);
+    // fuseChannels (ACF.h:653-672): every plane of every type stacked along rows
+    int rows = 0, cols = 0, planes = 0;
+    for (const MatP& m : chns.data)
+    {
+        rows = m.rows();
+        cols = m.cols();
+        planes += m.channels();
+    }
+    Ip2.create(rows * planes, cols, 1);
+    float* o = Ip2.data();
+    for (const MatP& m : chns.data)
+    {
+        std::memcpy(o, m.data(), sizeof(float) * m.numel());
+        o += m.numel();
+    }
+}
+
+// ---- the reference's arithmetic (option "arith")
+namespace
+{
+// the table functions of include/acf_hip.h, for the check of a probed CPU
+inline uint32_t tblRcp(uint32_t u, const uint32_t* T)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : s;
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    const uint32_t t = T[m >> 12];
+    const int re = int((t >> 23) & 0xffu) + 127 - int(e);
+    return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
+}
+inline uint32_t tblRsqrt(uint32_t u, const uint32_t* T)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : (s ? 0xffc00000u : 0u);
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    if (s)
+    {
+        return 0xffc00000u;
+    }
+    const int ue = int(e) - 127, odd = ue & 1, half = (ue - odd) / 2;
+    const uint32_t t = T[(odd << 10) | int(m >> 13)];
+    return (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
+}
+#if defined(__SSE__)
+inline uint32_t hwRcp(uint32_t u)
+{
+    float f, o;
+    std::memcpy(&f, &u, 4);
+    o = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(f)));
+    std::memcpy(&u, &o, 4);
+    return u;
+}
+inline uint32_t hwRsqrt(uint32_t u)
+{
+    float f, o;
+    std::memcpy(&f, &u, 4);
+    o = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(f)));
+    std::memcpy(&u, &o, 4);
+    return u;
+}
+#endif
+} // namespace
+
+bool HipDetector::probeHostArithmetic(std::vector<uint32_t>& rcp, std::vector<uint32_t>& rsq)
+{
+#if defined(__SSE__)
+    rcp.resize(2048);
+    rsq.resize(2048);
+    for (uint32_t i = 0; i < 2048; i++)
+    {
+        rcp[i] = hwRcp((127u << 23) | (i << 12));
+    }
+    for (uint32_t i = 0; i < 1024; i++)
+    {
+        rsq[i] = hwRsqrt((127u << 23) | (i << 13));
+        rsq[1024 + i] = hwRsqrt((128u << 23) | (i << 13));
+    }
+    // are this CPU's instructions those table functions?  2^22 inputs spread over all bit patterns, every mantissa of one binade,
+    // and the exponent range's two ends (tests/golden/make_x86_tables.py runs the same comparison over all 2^32)
+    auto same = [&](uint32_t u) { return hwRcp(u) == tblRcp(u, rcp.data()) && hwRsqrt(u) == tblRsqrt(u, rsq.data()); };
+    for (uint64_t i = 0; i < (1ull << 22); i++)
+    {
+        if (!same(uint32_t(i * 1021u)))
+        {
+            return false;
+        }
+    }
+    for (uint32_t m = 0; m < (1u << 23); m += 7)
+    {
+        if (!same((127u << 23) | m) || !same((128u << 23) | m))
+        {
+            return false;
+        }
+    }
+    for (uint32_t k = 0; k < (1u << 16); k++)
+    {
+        if (!same(k * 257u) || !same(0x7e800000u + k * 513u) || !same(0x80000000u + k * 257u))
+        {
+            return false;
+        }
+    }
+    return true;
+#else
+    (void)rcp;
+    (void)rsq;
+    return false;
+#endif
+}
+
+void HipDetector::setReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+{
+    if (!m_ctx)
+    {
+        m_api = &hip::load();
+        check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
+    }
+    check(m_api->acf_hip_set_x86_tables(m_ctx, rcp2048, rsqrt2048), "acf_hip_set_x86_tables");
+    check(m_api->acf_hip_set_option(m_ctx, "arith", 1), "acf_hip_set_option(arith)");
+}
+
+void HipDetector::setChnsComputeReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048, int device)
+{
+    const hip::Api& api = hip::load();
+    UtilCtx& u = utilCtx();
+    std::lock_guard<std::mutex> lock(u.m);
+    acf_hip_ctx* c = utilContext(api, device);
+    if (rcp2048 && rsqrt2048)
+    {
+        utilCheck(api, c, api.acf_hip_set_x86_tables(c, rcp2048, rsqrt2048), "acf_hip_set_x86_tables");
+        utilCheck(api, c, api.acf_hip_set_option(c, "arith", 1), "acf_hip_set_option(arith)");
+    }
+    else
+    {
+        utilCheck(api, c, api.acf_hip_set_option(c, "arith", 0), "acf_hip_set_option(arith)");
+    }
+}
+
+void HipDetector::setReferenceArithmetic(bool on)
+{
+    if (!on)
+    {
+        if (m_ctx && m_api)
+        {
+            check(m_api->acf_hip_set_option(m_ctx, "arith", 0), "acf_hip_set_option(arith)");
+        }
+        return;
+    }
+    std::vector<uint32_t> rcp, rsq;
+    if (!probeHostArithmetic(rcp, rsq))
+    {
+        throw Exception(ACF_HIP_E_UNSUPPORTED, "setReferenceArithmetic: this CPU's rcpps / rsqrtps are not functions of the top mantissa bits (or not an SSE host)");
+    }
+    setReferenceArithmetic(rcp.data(), rsq.data());
 }
 
 // ---- HipDetectorPool: one detector per device, frames in contiguous blocks

@@ -129,6 +129,7 @@ public:
             struct Chns
             {
                 int shrink = 4;
+                bool isLuv = false; // ACF.h:175: the input planes are LUV already (chnsPyramid.cpp:228 propagates Detector::setIsLuv)
                 struct Color { int enabled = 1; double smooth = 1; std::string colorSpace = "luv"; } pColor;
                 struct GradMag { int enabled = 1; int colorChn = 0; int normRad = 5; double normConst = 0.005; int full = 0; } pGradMag;
                 struct GradHist { int enabled = 1; int binSize = 0; int nOrients = 6; int softBin = 0; } pGradHist;
@@ -201,6 +202,27 @@ public:
         double score = 0;
     };
     using DetectionVec = std::vector<Detection>;
+
+    // Detector::Channels (ACF.h:326-340): what chnsCompute returns — one MatP per enabled channel type, in the order colour,
+    // gradient magnitude, gradient histogram, each [type's channels][w / shrink rows][h / shrink cols]
+    struct Channels
+    {
+        Options::Pyramid::Chns pChns;
+        int nTypes = 0;
+        std::vector<MatP> data;
+        struct Info
+        {
+            std::string name;
+            int nChns = 0;
+            std::string padWith;
+        };
+        std::vector<Info> info;
+    };
+
+    // Detector::MatLoggerType (ACF.h:57): called with one plane and a tag "<name>:<cols>x<rows>"
+    using MatLoggerType = std::function<int(const MatP&, const std::string&)>;
+    // the reference's stream logger is a std::shared_ptr<spdlog::logger> (ACF.h:583-586; spdlog is not in this image): a text sink
+    using StreamLoggerType = std::function<void(const std::string&)>;
 
     Options opts;
     Classifier clf;
@@ -275,8 +297,32 @@ public:
     static void pinnedFree(void* p);
 
     void computePyramid(const MatP& Ip, Pyramid& P); // ACF.cpp:147-159
-    // Detector::MatLoggerType (ACF.h:57): called with one plane and a tag "<name>:<cols>x<rows>"
-    using MatLoggerType = std::function<int(const MatP&, const std::string&)>;
+    // static int Detector::chnsCompute(const MatP&, const Options::Pyramid::Chns&, Channels&, bool isInit, const MatLoggerType&)
+    // (ACF.h:342-349, chnsCompute.cpp:146-338): the channels of one image at its own scale (acf_hip_chns_compute; like the
+    // reference's it needs no detector — it runs on a process-wide utility context on `device`).  isInit or an empty image:
+    // only chns.pChns is filled (the reference's "return the estimate", :154-198).  With a logger the planes chnsCompute logs
+    // (L, U, V; M; Mnorm, O; H — tags as in :241-250, gradientMag.cpp:119-123, :285-300, :322-329) are reported: the stages
+    // then run one by one through the single-operator entries, whose results are the same floats.
+    static int chnsCompute(const MatP& I, const Options::Pyramid::Chns& pChns, Channels& chns, bool isInit = false, const MatLoggerType& pLogger = {},
+        int device = 0);
+    // static void Detector::computeChannels(const MatP& Ip, MatP& Ip2, const MatLoggerType&) (ACF.h:419-420, ACF.cpp:183-240):
+    // chnsCompute with the toolbox defaults, fused into one MatP [nChns planes stacked along rows] (fuseChannels, ACF.h:653-672)
+    static void computeChannels(const MatP& Ip, MatP& Ip2, const MatLoggerType& pLogger = {}, int device = 0);
+    // Detector::setLogger (ACF.h:578-581): operator()(MatP) then reports every pyramid level, transposed and stretched to
+    // 0..255 (cv::normalize NORM_MINMAX to 8 bits, ACF.cpp:252-262; OpenCV's rounding restated: values are whole numbers), tag "%06d"
+    void setLogger(MatLoggerType logger) { m_logger = std::move(logger); }
+    // Detector::setStreamLogger (ACF.h:583-586): stored; like the reference's, nothing on the hot path writes to it
+    void setStreamLogger(StreamLoggerType logger) { m_streamLogger = std::move(logger); }
+    // The reference's OWN arithmetic at the three sites where its SSE kernels use _mm_rsqrt_ps / _mm_rcp_ps (include/acf_hip.h,
+    // option "arith"): with the tables of a CPU installed the pyramid and the detections are what the reference's compiled
+    // kernels give on that CPU, bit for bit (default: exact 1/sqrt, 1/x).  setReferenceArithmetic(true) probes the CPU this
+    // process runs on — "what acf::Detector would return HERE" — and throws if its instructions are not table functions;
+    // the second form installs given tables (2 x 2048 entries, acf_hip_set_x86_tables).
+    void setReferenceArithmetic(bool on);
+    void setReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048);
+    static bool probeHostArithmetic(std::vector<uint32_t>& rcp2048, std::vector<uint32_t>& rsqrt2048);
+    // ... and for the static chnsCompute / computeChannels (their utility context on `device`): tables, or nullptr = exact again
+    static void setChnsComputeReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048, int device = 0);
     // chnsPyramid.cpp:160-456.  With a logger, every real scale reports the planes chnsCompute hands to its logger, in its order
     // and with its tags (chnsCompute.cpp:241-250 L,U,V; gradientMag.cpp:119-123 M; chnsCompute.cpp:285-300 Mnorm, O; :322-329 H).
     int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false, const MatLoggerType& logger = {});
@@ -313,6 +359,7 @@ private:
     void fetch(int frame, RectVec& objects, RealVec* scores);
     void detect1(const float* f32, const uint8_t* u8, int rows, int cols, DetectionVec& objects);
     void finish(DetectionVec& bbs, RectVec& objects, RealVec* scores, bool forceHostNms = false) const; // ACF.cpp:332-364
+    void logPyramid(); // ACF.cpp:252-262
 
     const hip::Api* m_api = nullptr;
     acf_hip_ctx* m_ctx = nullptr;
@@ -329,6 +376,8 @@ private:
     std::vector<float> m_upright; // scratch for operator()(interleaved)
     int m_streamCap = 0, m_streamPix = -1, m_streamStride = 0;
     int m_minObjectWidth = -1, m_srcRows = 0, m_srcCols = 0; // frame size handed to the 8-bit entries (== the plan's without a resize)
+    MatLoggerType m_logger;
+    StreamLoggerType m_streamLogger;
     bool m_taps = false; // "taps" option on: per-stage planes stay readable (needed by the logger)
     void* m_pin = nullptr; // pinned scratch of operator()(packed 8-bit)
     size_t m_pinBytes = 0;

@@ -5,6 +5,11 @@
 //                  [--luv] [--nms] [--batch] [--via-pyramid] [--max-count K] [--prune-ratio R]
 //   acf_hip_detect --model m.acfm --frames f.u8 --u8 rgb|bgr|rgba|bgra|gray --rows H --cols W --count N [--stream B] [--min-width M] ...
 //                  packed 8-bit upright frames; --stream B: batches of B frames through streamSubmit/streamCollect
+//   acf_hip_detect --model m.acfm --frames f.raw --rows W --cols H --channels d --count N --chns out.raw [--luv] [--log-taps] [--defaults]
+//                  Detector::chnsCompute per frame (static; --defaults: computeChannels' toolbox defaults instead of the model's Chns):
+//                  the channels [nChns][W/shrink][H/shrink] of every frame appended to out.raw, one "chns ..." line per frame
+//   ... --ref-arith host|tables.bin   the reference's rcpps / rsqrtps bits (probed from this CPU, or 2 x 2048 uint32 from a file)
+//   ... --log-levels                  Detector::setLogger: a "level <tag> <hash>" line per pyramid level
 //   acf_hip_detect --convert in.acfm|in.cpb --out out.cpb                                  (model file conversion, no GPU)
 //   acf_hip_detect --dump-defaults                                                         (default Options tree, no GPU)
 //   acf_hip_detect --nms-only boxes.txt [--type maxg] [--overlap .65] [--ovrdnm min]   (host logic only, no GPU)
@@ -30,6 +35,17 @@ using acf::HipDetector;
 static bool loadModel(const std::string& path, HipDetector::Options& o, HipDetector::Classifier& c)
 {
     return acf::loadModelAny(path, o, c) == 0; // "*.cpb": the reference's cereal files; otherwise the ACFHIPM1 container
+}
+
+static uint64_t fnv(const acf::MatP& m)
+{
+    uint64_t hsh = 1469598103934665603ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(m.data());
+    for (size_t i = 0; i < m.numel() * 4; i++)
+    {
+        hsh = (hsh ^ b[i]) * 1099511628211ull;
+    }
+    return hsh;
 }
 
 static void printFrame(int f, const HipDetector::RectVec& objs, const HipDetector::RealVec& scores)
@@ -146,6 +162,37 @@ int main(int argc, char** argv)
             m.cascCal = std::stod(a["casc-cal"]);
             det.acfModify(m);
         }
+        std::vector<uint32_t> arithTables;
+        if (a.count("ref-arith"))
+        {
+            if (a["ref-arith"] == "host")
+            {
+                det.setReferenceArithmetic(true);
+                std::vector<uint32_t> r, q;
+                HipDetector::probeHostArithmetic(r, q);
+                arithTables = r;
+                arithTables.insert(arithTables.end(), q.begin(), q.end());
+            }
+            else
+            {
+                arithTables.resize(4096);
+                std::ifstream is(a["ref-arith"], std::ios::binary);
+                is.read(reinterpret_cast<char*>(arithTables.data()), 4096 * 4);
+                if (!is)
+                {
+                    std::fprintf(stderr, "short table file\n");
+                    return 2;
+                }
+                det.setReferenceArithmetic(arithTables.data(), arithTables.data() + 2048);
+            }
+        }
+        if (a.count("log-levels"))
+        {
+            det.setLogger([](const acf::MatP& m, const std::string& t) {
+                std::printf("level %s %dx%d %016llx\n", t.c_str(), m.cols(), m.rows(), static_cast<unsigned long long>(fnv(m)));
+                return 0;
+            });
+        }
         if (a.count("u8"))
         {
             static const std::map<std::string, int> kPix = { { "rgb", ACF_HIP_PIX_RGB }, { "bgr", ACF_HIP_PIX_BGR }, { "rgba", ACF_HIP_PIX_RGBA },
@@ -221,6 +268,47 @@ int main(int argc, char** argv)
             }
         }
         const size_t per = size_t(rows) * cols * ch;
+        if (a.count("chns"))
+        {
+            // Detector::chnsCompute / computeChannels (static, ACF.h:342-349,419-420) on every frame
+            if (!arithTables.empty())
+            {
+                HipDetector::setChnsComputeReferenceArithmetic(arithTables.data(), arithTables.data() + 2048);
+            }
+            std::ofstream os(a["chns"], std::ios::binary);
+            for (int f = 0; f < cnt; f++)
+            {
+                acf::MatP Ip(rows, cols, ch, frames.data() + per * size_t(f));
+                HipDetector::MatLoggerType logger;
+                if (a.count("log-taps"))
+                {
+                    logger = [](const acf::MatP& m, const std::string& t) {
+                        std::printf("tap %s %016llx\n", t.c_str(), static_cast<unsigned long long>(fnv(m)));
+                        return 0;
+                    };
+                }
+                if (a.count("defaults"))
+                {
+                    acf::MatP fused;
+                    HipDetector::computeChannels(Ip, fused, logger);
+                    std::printf("chns %d fused %dx%d\n", f, fused.cols(), fused.rows());
+                    os.write(reinterpret_cast<const char*>(fused.data()), std::streamsize(fused.numel() * 4));
+                    continue;
+                }
+                HipDetector::Options::Pyramid::Chns pc = det.opts.pPyramid.pChns;
+                pc.isLuv = a.count("luv") != 0;
+                HipDetector::Channels chns;
+                HipDetector::chnsCompute(Ip, pc, chns, false, logger);
+                std::printf("chns %d types %d", f, chns.nTypes);
+                for (size_t t = 0; t < chns.data.size(); t++)
+                {
+                    std::printf(" [%s|%d|%s|%dx%d]", chns.info[t].name.c_str(), chns.info[t].nChns, chns.info[t].padWith.c_str(), chns.data[t].cols(), chns.data[t].rows());
+                    os.write(reinterpret_cast<const char*>(chns.data[t].data()), std::streamsize(chns.data[t].numel() * 4));
+                }
+                std::printf("\n");
+            }
+            return os ? 0 : 2;
+        }
         if (a.count("pool"))
         {
             // acf::HipDetectorPool: one detector per visible device ("--pool N": the first N devices, several times the same

@@ -83,6 +83,9 @@ static void doLoad(const std::string& path)
     ACF_HIP_FN(acf_hip_op_conv_tri)
     ACF_HIP_FN(acf_hip_op_gradient_mag)
     ACF_HIP_FN(acf_hip_op_gradient_hist)
+    ACF_HIP_FN(acf_hip_chns_compute)
+    ACF_HIP_FN(acf_hip_set_x86_tables)
+    ACF_HIP_FN(acf_hip_selftest_x86)
     ACF_HIP_FN(acf_hip_op_im_resample)
     ACF_HIP_FN(acf_hip_op_acf_detect1)
     ACF_HIP_FN(acf_hip_op_acf_detect1_u8)

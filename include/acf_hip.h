@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ACF_HIP_ABI_VERSION 8
+#define ACF_HIP_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define ACF_HIP_API __attribute__((visibility("default")))
@@ -240,7 +240,14 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * "smooth_force_redo" (tests: 1 = every plane with more than one segment is marked for the
  * repair launch whatever the verification found),
  * "cascade_tiles", "fused_levels", "fused_smooth", "streams" (kernel-form A/B
- * switches; all forms give identical results).
+ * switches; all forms give identical results),
+ * "arith" (0, default: the three sites where the reference's SSE kernels use _mm_rsqrt_ps /
+ * _mm_rcp_ps — gradMag, gradMagNorm, rgb2luv_sse: toolbox/gradientMex.cpp:209-219,266,
+ * toolbox/rgbConvertMex.cpp:161, toolbox/sse.hpp:185-192 — compute 1/sqrt and 1/x exactly;
+ * 1: they return the bits of one x86 CPU's instructions, from the tables installed with
+ * acf_hip_set_x86_tables — the pyramid and the detections are then what the reference's own
+ * compiled kernels give on that CPU, bit for bit.  Not a fast path: gradMag and the channel
+ * cells take their unfused forms).
  *
  * Capacity: `max_hits` of acf_hip_plan bounds the hits kept per frame.  With stride < shrink
  * (the cascade then runs once per distinct cell offset and k_expand_hits writes every window
@@ -250,6 +257,22 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * effect for LDCF models, for stride < shrink and for tree depths 1, 3 and 4 on rank cells:
  * those paths read the float pyramid (their overflow queues do), so it is always written. */
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
+
+/* The reference's arithmetic at its three approximate sites (option "arith" = 1).  _mm_rcp_ps and _mm_rsqrt_ps
+ * (toolbox/sse.hpp:185-192) are 12-bit approximations whose bits belong to the CPU.  On the CPUs probed they are functions
+ * of the input's sign, exponent (its parity for rsqrt) and top mantissa bits:
+ *   rcp2048[m >> 12]                      = bits of _mm_rcp_ps(x)   for x = 1.m in [1, 2)        (2048 entries)
+ *   rsqrt2048[(odd << 10) | (m >> 13)]    = bits of _mm_rsqrt_ps(x) for x in [1, 2) (odd = 0) and [2, 4) (odd = 1)
+ * and every other input follows by exponent arithmetic (zero / subnormal -> inf, inf -> 0, results below the normal range
+ * -> 0, NaN quieted, rsqrt of a negative -> 0xffc00000).  A host that wants "what the reference gives HERE" fills the tables
+ * from its own CPU (acf::HipDetector::setReferenceArithmetic does, acf_amd/host/HipDetector.h); tests install the build
+ * host's (tests/golden/x86_rcp_rsqrt.npz, checked there against the instructions for all 2^32 inputs).  The tables are
+ * copied to the device; the call may be repeated.  Sub-batch contexts ("streams" > 1) share their parent's tables. */
+ACF_HIP_API int acf_hip_set_x86_tables(acf_hip_ctx* ctx, const uint32_t* rcp2048, const uint32_t* rsqrt2048);
+/* Self-check of the device's table functions: position-mixed 64-bit digests of rcp (digest[0]) and rsqrt (digest[1]) over the
+ * bit patterns first + i * stride, i < count — the sums the CPU oracle's acfo_x86_digest forms from the same tables, so the
+ * two implementations are compared for every input without moving 2^32 results. */
+ACF_HIP_API int acf_hip_selftest_x86(acf_hip_ctx* ctx, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[2]);
 
 /* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.
  * Writes up to `cap` scales and returns the total count in *n. */
@@ -448,6 +471,17 @@ ACF_HIP_API int acf_hip_op_gradient_mag(acf_hip_ctx* ctx, const float* in, float
  * every float bit pattern first_bits .. last_bits taken as m2: *mismatches = how many differ in either result,
  * *first_bad_bits = the smallest such pattern.  0 .. 0x7f7fffff (every finite m2 >= 0) must give 0. */
 ACF_HIP_API int acf_hip_selftest_gradmag(acf_hip_ctx* ctx, uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, uint32_t* first_bad_bits);
+/* Detector::chnsCompute (ACF.h:342-349, chnsCompute.cpp:146-338; addChn :340-370): the channels of ONE image at its own scale,
+ * without a pyramid plan — crop to a multiple of shrink (:203-217), rgbConvert (:235; skipped for colorSpace orig / rgb and for
+ * isLuv), convTri(I, I, pColor.smooth, 1) in place (:239), gradientMag with its normalisation (:263-283), gradientHist (:310-331),
+ * every enabled type reduced by `shrink` (addChn's imResample) and concatenated: colour, magnitude, histogram.
+ *   p     the Options::Pyramid::Chns fields of acf_hip_params are read (shrink .. isLuv; classifier and pyramid fields ignored);
+ *         NULL: the context's model (acf_hip_set_model)
+ *   in    HOST planes [d][w][h], d = 1 or 3, the transposed planar layout of every entry here
+ *   out   HOST buffer of `cap` floats receiving [nChns][w / shrink][h / shrink] (cropped sizes); NULL: only the sizes are reported
+ * *nChns, *hC, *wC (each may be NULL) receive the channel count and the cell-plane size.  Honours option "arith". */
+ACF_HIP_API int acf_hip_chns_compute(acf_hip_ctx* ctx, const acf_hip_params* p, const float* in, int h, int w, int d, float* out, int64_t cap,
+    int* nChns, int* hC, int* wC);
 /* Detector::gradientHist (gradientHist.cpp:92-115) -> gradHist (gradientMex.cpp:375-509): soft_bin even — >= 0 the magnitude
  * is shared between the two nearest orientation bins, < 0 the nearest bin takes it; no spatial interpolation.  Odd soft_bin
  * (trilinear: HOG / FHOG features) is ACF_HIP_E_UNSUPPORTED. */

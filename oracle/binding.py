@@ -341,6 +341,42 @@ def chns_pyramid(plan, frame, want_taps=False, want_chns=False):
     return out, taps, chns
 
 
+def chns_compute(model, frame):
+    """Detector::chnsCompute as the oracle restates it, on one image [d][w][h]: crop to a multiple of shrink (chnsCompute.cpp:203-217),
+    rgbConvert (:235; acfo_rgb2luv / acfo_rgb2gray / acfo_rgb2hsv, skipped for orig / rgb / isLuv), then acfo_chns_compute (convTri in
+    place, gradMag, gradHist, addChn).  -> [nChns][w / shrink][h / shrink]."""
+    o = lib()
+    prm, keep = capi.make_params(model)
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    d, w, h = frame.shape
+    sh = int(prm.shrink)
+    hc, wc = h - h % sh, w - w % sh
+    I = aligned_copy(frame[:, :wc, :hc])
+    n = hc * wc
+    cs = int(prm.colorSpace)
+    if d == 3 and (cs in (capi.CS_ORIG, capi.CS_RGB) or (prm.isLuv and cs == capi.CS_LUV)):
+        col = I
+    elif cs == capi.CS_LUV:
+        col = aligned((3, wc, hc))
+        o.acfo_rgb2luv(F(I), F(col), n)
+    elif cs == capi.CS_GRAY:
+        col = aligned((1, wc, hc))
+        src = I if d == 3 else aligned_copy(np.repeat(I, 3, axis=0))
+        o.acfo_rgb2gray(F(src), F(col), n)
+    elif cs == capi.CS_HSV:
+        col = aligned((3, wc, hc))
+        o.acfo_rgb2hsv(F(I), F(col), n)
+    else:
+        col = aligned_copy(np.repeat(I, 3, axis=0))
+    dcol = col.shape[0]
+    nC = (dcol if prm.colorEnabled else 0) + (1 if prm.gradMagEnabled else 0) + (int(prm.nOrients) if prm.gradHistEnabled else 0)
+    out = aligned((nC, wc // sh, hc // sh))
+    rc = o.acfo_chns_compute(F(col), hc, wc, dcol, C.byref(prm), F(out), None)
+    if rc:
+        raise RuntimeError("acfo_chns_compute rc=%d" % rc)
+    return np.array(out)
+
+
 def nms(boxes, scores, params):
     """Oracle bbNms + prune: boxes int32 [n][4], scores float64 [n], params capi.NmsParams -> indices of the survivors in order."""
     boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)

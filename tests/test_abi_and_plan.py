@@ -23,7 +23,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), name
     # the ctypes binding covers the whole header
     assert sorted(capi.DECLARED_SYMBOLS) == declared
-    assert lib.acf_hip_abi_version() == 8
+    assert lib.acf_hip_abi_version() == 9
 
 
 def test_every_option_the_library_accepts_is_documented_in_the_header():

@@ -1,0 +1,181 @@
+"""Option "arith" = 1 on the device: the reference's OWN arithmetic at its three approximate sites (gradMag, gradMagNorm,
+rgb2luv_sse: T/gradientMex.cpp:209-219,266; T/rgbConvertMex.cpp:161; T/sse.hpp:185-192) from the build host's rcpps / rsqrtps
+tables (tests/golden/x86_rcp_rsqrt.npz, checked against the instructions for all 2^32 inputs by make_x86_tables.py).
+
+Everything here is compared with bytes the REFERENCE's compiled kernels produced on the build host (frozen in
+tests/golden/ref_ops.npz, ref_resample_luv.npz, tref_study.npz), bit for bit — not within a bound:
+
+ * the device's table functions == the oracle's for every one of the 2^32 inputs (digests);
+ * acf_hip_op_gradient_mag's M, O and normalised M == the reference's gradMag / gradMagNorm bytes, incl. the odd-sized case
+   whose last n % 4 elements take gradMagNorm's scalar division; acf_hip_op_rgb_convert == the reference's rgbConvert bytes
+   (vector and scalar bodies);
+ * the whole path at BASELINE.json's cfg 1 / 2 / 4 sizes: the cascade's hits == the hits of the reference's compiled kernels
+   under the restated orchestration (`*_hits_ref`), scores included — the north star's "scores within 1e-4 of the reference"
+   met with 0 difference on the reference's real SSE arithmetic;
+ * the pyramid == the oracle's table-tier pyramid; switching the option off again restores the exact tier.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from acf_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from acf_amd.detector import HipDetector
+    from oracle import binding as ob
+    d = HipDetector()
+    d.set_x86_tables(*ob.x86_fixture())
+    yield d
+    d.close()
+
+
+def test_option_needs_tables():
+    from acf_amd.detector import HipDetector, HipError
+    d = HipDetector()
+    with pytest.raises(HipError):
+        d.set_option("arith", 1)
+    d.close()
+
+
+def test_device_table_functions_equal_the_oracles_for_every_input(oracle, dev):
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    chunks = 64
+    per = (1 << 32) // chunks
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 4)) as ex:
+        want = list(ex.map(lambda k: oracle.x86_digest(k * per, per, 1), range(chunks)))
+    for k in range(chunks):
+        assert dev.selftest_x86(k * per, per, 1) == want[k], k
+
+
+def test_gradient_mag_and_norm_equal_the_reference_bytes(dev):
+    ops = np.load(os.path.join(GOLD, "ref_ops.npz"))
+    dev.set_option("arith", 1)
+    try:
+        for k, (h, w) in enumerate(ops["sizes"]):
+            a = ops["in%d" % k][0]
+            M, O, _ = dev.op_gradient_mag(a, 0)
+            assert np.array_equal(bits(M), bits(ops["M_%d" % k])), k
+            assert np.array_equal(bits(O), bits(ops["O_%d" % k])), k
+            if "Mn_%d" % k in ops.files:
+                Mn, _, S = dev.op_gradient_mag(a, 5, 0.005)
+                assert np.array_equal(bits(S), bits(ops["S_%d" % k])), k
+                assert np.array_equal(bits(Mn), bits(ops["Mn_%d" % k])), k   # (k = 2: n % 4 != 0, the scalar tail divides)
+    finally:
+        dev.set_option("arith", 0)
+    # and the exact tier differs from those bytes (the option is not a no-op)
+    M, _, _ = dev.op_gradient_mag(ops["in0"][0], 0)
+    assert not np.array_equal(bits(M), bits(ops["M_0"]))
+
+
+def test_rgb2luv_equals_the_reference_bytes(dev):
+    rsl = np.load(os.path.join(GOLD, "ref_resample_luv.npz"))
+    dev.set_option("arith", 1)
+    try:
+        for k, (h, w) in enumerate(rsl["luv_sizes"]):
+            a = np.ascontiguousarray(synth.make_frame(600 + k, int(h), int(w), "rgb"))   # (make_golden.py's inputs)
+            luv = dev.op_rgb_convert(a, capi.CS_LUV)
+            assert np.array_equal(bits(luv), bits(rsl["luv_out%d" % k])), (k, h, w)
+    finally:
+        dev.set_option("arith", 0)
+
+
+TREF_CFG = {
+    "cfg1_vga_gray_face64": ("gray", "FACE64"),
+    "cfg2_1080p_luv_face80": ("luv", "FACE80"),
+    "cfg4_vga_rgb_inria": ("rgb", "INRIA"),
+}
+
+
+@pytest.mark.parametrize("cfg", list(TREF_CFG))
+def test_hits_equal_the_reference_kernels_hits_bit_for_bit(oracle, cfg):
+    import torch
+    from acf_amd.detector import HipDetector
+    fix = np.load(os.path.join(GOLD, "tref_study.npz"))
+    H, W, d_in, nframes, seed0, mseed = [int(v) for v in fix[cfg + "_meta"]]
+    kind, preset = TREF_CFG[cfg]
+    model = synth.make_model(seed=mseed, name=preset)
+    n = int(nframes)
+    frames = np.stack([synth.make_frame(seed0 + f, H, W, kind) for f in range(n)])
+    det = HipDetector(model, H, W, d_in, max_batch=n, max_hits=1 << 15)
+    det.set_x86_tables(*oracle.x86_fixture())
+    det.set_option("arith", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    diffs = 0
+    for f in range(n):
+        _, gh = det.detections(f)
+        want = fix["%s_f%d_hits_ref" % (cfg, f)]
+        assert gh.tobytes() == want.tobytes(), (cfg, f, len(gh), len(want))
+        diffs += int((gh["score"] != want["score"]).sum())
+    assert diffs == 0
+    # back to the exact tier on the same context: the T-exact side of the study
+    det.set_option("arith", 0)
+    det.run(torch.from_numpy(frames).cuda())
+    for f in range(min(n, 2)):
+        _, gh = det.detections(f)
+        assert gh.tobytes() == fix["%s_f%d_hits_exact" % (cfg, f)].tobytes(), (cfg, f)
+    det.close()
+
+
+@pytest.mark.parametrize("shape", [("FACE80", 272, 480, "luv", 3), ("INRIA", 240, 320, "rgb", 3), ("FACE64", 240, 320, "gray", 1), ("TINY", 120, 150, "rgb", 3)])
+def test_pyramid_equals_the_oracles_table_tier(oracle, shape):
+    import torch
+    from acf_amd.detector import HipDetector
+    name, H, W, kind, d = shape
+    model = synth.make_model(seed=3, name=name, nTrees=64)
+    frames = np.stack([synth.make_frame(5 + f, H, W, kind) for f in range(2)])
+    plan = oracle.Plan(model, H, W, d)
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    det = HipDetector(model, H, W, d, max_batch=2, max_hits=1 << 15)
+    det.set_x86_tables(*oracle.x86_fixture())
+    det.set_option("arith", 1)
+    det.pyramid(torch.from_numpy(frames).cuda())
+    for f in range(2):
+        oracle.set_approx(3)
+        try:
+            want, _, _ = oracle.chns_pyramid(plan, frames[f])
+        finally:
+            oracle.set_approx(0)
+        got = det.read_pyramid(f)
+        assert np.array_equal(bits(got), bits(want)), (shape, f)
+        exact, _, _ = oracle.chns_pyramid(plan, frames[f])
+        assert not np.array_equal(bits(got), bits(exact))
+    det.close()
+
+
+def test_u8_ingest_in_reference_arithmetic(oracle):
+    """The packed 8-bit front end (k_ingest_u8 converts RGB -> LUV itself) under option "arith"."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 120, 160
+    model = synth.make_model(seed=3, name="INRIA", nTrees=64)
+    rgb = (synth.make_frame(11, H, W, "rgb") * 255.0 + 0.5).astype(np.uint8)     # [3][W][H]
+    packed = np.ascontiguousarray(rgb.transpose(2, 1, 0))                          # [H][W][3]
+    planar = oracle.aligned((3, W, H))
+    oracle.lib().acfo_ingest_u8(packed.ctypes.data, H, W, 3, 0, 1, 2, W * 3, oracle.F(planar), 3)   # ACF.cpp:114-119,137
+    plan = oracle.Plan(model, H, W, 3)
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    oracle.set_approx(3)
+    try:
+        want, _, _ = oracle.chns_pyramid(plan, planar)
+    finally:
+        oracle.set_approx(0)
+    det = HipDetector(model, H, W, 3, max_batch=1, max_hits=1 << 15)
+    det.set_x86_tables(*oracle.x86_fixture())
+    det.set_option("arith", 1)
+    det.pyramid_u8(torch.from_numpy(packed[None]).cuda(), capi.PIX_RGB)
+    got = det.read_pyramid(0)
+    assert np.array_equal(bits(got), bits(want))
+    det.close()

@@ -55,6 +55,57 @@ def test_three_contexts_detection_only_with_device_nms():
     pool.close()
 
 
+def test_the_timed_configuration_as_it_is_timed():
+    """bench.py's default run, in the suite: THREE contexts x 96 resident 1080p frames (memory: 3 x 96 x 24.9 MB = 7.2 GB of frames), the
+    pool's own options (cascade_turns, one tile workgroup per tile, shared_device), keep_pyramid = 0, device bbNms + prune.  At 96
+    frames per launch shared_device switches scale 0 to the one-chain-per-frame smoothing with convTri's x pass on it
+    (k_smooth_grad_tri) and leaves every smoothing chain uncut: asserted from the profile (acf_hip_profile_get), not assumed.  Nine
+    frames spread over the three contexts and over the batch are then checked against the oracle, score bits and all."""
+    import torch
+    import bench
+    from acf_amd import capi, synth
+    from acf_amd.detector import DetectorPool
+    from acf_amd.dist import RecordGather
+    H, W, C, B, cap = 1080, 1920, 3, 96, 32
+    model = synth.make_model(seed=1, name="FACE80")
+    dev = torch.device("cuda", 0)
+    base = torch.from_numpy(np.stack([synth.make_frame(4100 + i, H, W, "luv") for i in range(4)])).to(dev)
+    frames = torch.empty((C * B, 3, W, H), dtype=torch.float32, device=dev)
+    for i in range(C * B):
+        frames[i] = torch.roll(base[i % 4], shifts=(37 * (i // 4), 23 * (i // 4)), dims=(1, 2))
+    pool = DetectorPool(C, model, H, W, 3, max_batch=B, max_hits=8192, device=0)   # (shared_device: the pool's default)
+    nms = capi.make_nms(type="maxg", overlap=0.65, ovrDnm="min", prune=True, maxCount=10, pruneRatio=0.0)
+    for det in pool.dets:
+        det.set_option("scale_streams", 0)
+        det.set_option("keep_pyramid", 0)
+        det.set_option("profile", 1)
+        det.set_nms(nms)
+    pipes = [RecordGather(B, 1 + 6 * cap, 1, 0, dev) for _ in range(C)]
+    for _ in range(2):
+        for i in range(C):
+            with torch.cuda.stream(pool.streams[i]):
+                rec = pipes[i].buffer()
+                pool.dets[i].run(frames[i * B:(i + 1) * B], B)
+                pool.dets[i].export_detections(rec, cap)
+                pipes[i].submit()
+    for i in range(C):
+        with torch.cuda.stream(pool.streams[i]):
+            pipes[i].finish()
+    torch.cuda.synchronize()
+    for det in pool.dets:
+        prof = det.profile()
+        assert prof.get("k_smooth_grad_tri", (0, 0))[1] >= 2, sorted(prof)      # scale 0 of both steps
+        assert "k_smooth_grad" not in prof and "k_tri_x" in prof, sorted(prof)  # scales 1-3 keep the separate x pass
+        assert any(k.startswith("k_cascade_tile") for k in prof), sorted(prof)
+        assert "k_level(fused)" in prof and "k_nms" in prof, sorted(prof)
+    recs = [pipes[i].rec[(pipes[i].k - 1) & 1].cpu().numpy() for i in range(C)]
+    picks = [(i % C, (5 + 11 * i) % B) for i in range(9)]
+    n = bench.verify_frames(model, H, W, [frames[i * B:(i + 1) * B] for i in range(C)], recs, cap, nms, picks)
+    assert n == 9
+    assert sum(int(r[:, 0].sum()) for r in recs) > 0
+    pool.close()
+
+
 def test_bench_line_contract():
     """`python bench.py` (a small step: 2 contexts x 8 frames, no CPU leg) prints ONE JSON line with the fields the driver reads: the
     metric and unit, value = frames of the timed steps / time, the repeats, the roofline block with its kernel, the as-worded figures."""

@@ -177,3 +177,58 @@ def test_default_level_segments_on_a_single_frame_with_flat_bands(oracle, capsys
     with capsys.disabled():
         print("\nlevel-chain planes repaired at batch 1 with the defaults: %d of %d (image smoothing: %d of %d)" % (total[3], total[2], total[1], total[0]))
     assert total[3] <= total[2] // 4, "more than a quarter of the level planes needed the repair launch: the default warm-up is too short"
+
+
+def test_repair_flags_are_taken_down_between_calls(oracle):
+    """The repair flags are cleared at plan time (on the context's stream) and by the repair launch that reads them — not per call.
+    A run with every plane forced through the repair, then a normal run on the SAME context: the second run must repair nothing
+    (warm-ups of 64 columns converge on these frames) and still be the oracle's."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 256, 512
+    model = synth.make_model(seed=3, name="TINY", nTrees=96, cascThr=-1.0)
+    frames = np.stack([synth.make_frame(51 + i, H, W, "luv") for i in range(3)])
+    det = HipDetector(model, H, W, 3, max_batch=3, max_hits=1 << 15)
+    det.set_option("smooth_segments", 4)
+    det.set_option("smooth_warm", 64)
+    det.set_option("level_segments", 4)
+    det.set_option("level_warm", 32)
+    det.set_option("count_repairs", 1)
+    det.set_option("smooth_force_redo", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    r1 = det.repairs()
+    assert r1[1] > 0 and r1[3] > 0
+    det.set_option("smooth_force_redo", 0)
+    _check(oracle, det, frames, model, H, W)
+    r2 = det.repairs()
+    assert r2[0] > r1[0] and r2[1] == r1[1], (r1, r2)    # planes were checked again, none recomputed
+    assert r2[3] == r1[3], (r1, r2)
+    det.close()
+
+
+def test_run_and_pyramid_plus_detect_alternate_on_one_context(oracle):
+    """acf_hip_run clears the tiled cascade's counters in front of the pyramid's launches and tells runCascade so; pyramid() + detect()
+    clear them in the cascade itself.  Both orders on one context, twice over: the hits stay the oracle's (no stale counter adds up)."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 272, 480
+    model = synth.make_model(seed=3, name="FACE80", nTrees=256, minDs_h=80, minDs_w=80)
+    frames = np.stack([synth.make_frame(71 + i, H, W, "luv") for i in range(4)])
+    det = HipDetector(model, H, W, 3, max_batch=4, max_hits=1 << 15)
+    fr = torch.from_numpy(frames).cuda()
+    plan = oracle.Plan(model, H, W, 3)
+    want = []
+    for f in range(4):
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        want.append(oracle.detect(plan, pyr))
+    assert sum(len(w[1]) for w in want) > 0
+    for order in ("run", "split", "run", "split", "split", "run"):
+        if order == "run":
+            det.run(fr)
+        else:
+            det.pyramid(fr)
+            det.detect()
+        for f in range(4):
+            d, h = det.detections(f)
+            assert d.tobytes() == want[f][0].tobytes() and h.tobytes() == want[f][1].tobytes(), (order, f)
+    det.close()

@@ -206,3 +206,33 @@ def test_fixture_tables_reproduce_the_reference_kernels_hits(oracle, cfg):
         _, hits = oracle.detect(plan, pyr)
         want = fix["%s_f%d_hits_ref" % (cfg, f)]
         assert hits.tobytes() == want.tobytes(), (cfg, f, len(hits), len(want))
+
+
+def test_fixture_tables_reproduce_the_frozen_reference_bytes(oracle):
+    """ref_ops.npz / ref_resample_luv.npz hold the reference's compiled gradMag, gradMagNorm and rgbConvert outputs from the build
+    host: with the fixture's tables the oracle equals them bit for bit (the GPU box repeats this on the device: test_gpu_arith.py)."""
+    ops = np.load(os.path.join(HERE, "golden", "ref_ops.npz"))
+    rsl = np.load(os.path.join(HERE, "golden", "ref_resample_luv.npz"))
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    oracle.set_approx(3)
+    try:
+        for k, (h, w) in enumerate(ops["sizes"]):
+            h, w = int(h), int(w)
+            a = oracle.aligned_copy(ops["in%d" % k][0])
+            M, O = oracle.aligned((w, h)), oracle.aligned((w, h))
+            assert oracle.lib().acfo_grad_mag(oracle.F(a), oracle.F(M), oracle.F(O), h, w, 1, 0) == 0
+            assert np.array_equal(M.view(np.uint32), ops["M_%d" % k].view(np.uint32)), k
+            assert np.array_equal(O.view(np.uint32), ops["O_%d" % k].view(np.uint32)), k
+            if "Mn_%d" % k in ops.files:
+                Mn = oracle.aligned_copy(ops["M_%d" % k])
+                S = oracle.aligned_copy(ops["S_%d" % k])
+                oracle.lib().acfo_grad_mag_norm(oracle.F(Mn), oracle.F(S), h, w, 0.005)
+                assert np.array_equal(Mn.view(np.uint32), ops["Mn_%d" % k].view(np.uint32)), k
+        for k, (h, w) in enumerate(rsl["luv_sizes"]):
+            h, w = int(h), int(w)
+            a = oracle.aligned_copy(synth.make_frame(600 + k, h, w, "rgb"))
+            luv = oracle.aligned((3, w, h))
+            oracle.lib().acfo_rgb2luv(oracle.F(a), oracle.F(luv), h * w)
+            assert np.array_equal(luv.view(np.uint32), rsl["luv_out%d" % k].view(np.uint32)), k
+    finally:
+        oracle.set_approx(0)
