@@ -119,7 +119,7 @@ def test_chns_compute_uses_the_contexts_model_and_reports_sizes(oracle):
     out = np.zeros(10, np.float32)
     n, hc, wc = C.c_int(), C.c_int(), C.c_int()
     rc = dev.lib.acf_hip_chns_compute(dev.ctx, None, capi.fptr(frame), 96, 128, 3, capi.fptr(out), out.size, C.byref(n), C.byref(hc), C.byref(wc))
-    assert rc == 4 and (n.value, hc.value, wc.value) == (10, 24, 32)   # ACF_HIP_E_CAPACITY, sizes still reported
+    assert rc == capi.E_CAPACITY and (n.value, hc.value, wc.value) == (10, 24, 32)   # sizes still reported
     bad = dict(model)
     bad["softBin"] = 1
     with pytest.raises(HipError):
@@ -198,13 +198,13 @@ def test_cli_reference_arithmetic_and_level_logger(cli, oracle, tmp_path):
     """setReferenceArithmetic(tables): detections == the oracle's table tier; setLogger: one normalised level per scale."""
     H, W = 112, 96
     model = synth.make_model(seed=3, name="INRIA", nTrees=64, cascThr=-1.5)
-    frames = [synth.make_frame(40 + i, H, W, "rgb") for i in range(2)]
+    frames = [synth.make_frame(40 + i, H, W, "rgb") for i in range(3)]
     write_model(str(tmp_path / "m.acfm"), model)
     (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
     rcp, rsq = oracle.x86_fixture()
     (tmp_path / "t.bin").write_bytes(rcp.tobytes() + rsq.tobytes())
     p = run(cli, ["--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H), "--channels", "3",
-                  "--count", "2", "--ref-arith", str(tmp_path / "t.bin"), "--log-levels"])
+                  "--count", "3", "--ref-arith", str(tmp_path / "t.bin"), "--log-levels"])
     plan = oracle.Plan(model, H, W, 3)
     oracle.set_x86_tables(rcp, rsq)
     got, cur = [], None
@@ -215,8 +215,8 @@ def test_cli_reference_arithmetic_and_level_logger(cli, oracle, tmp_path):
             got.append(cur)
         elif t[0] != "level":
             cur.append((int(t[0]), int(t[1]), int(t[2]), int(t[3]), int(t[5], 16)))
-    nexact = 0
-    for f in range(2):
+    total = 0
+    for f in range(3):
         oracle.set_approx(3)
         try:
             pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
@@ -224,13 +224,11 @@ def test_cli_reference_arithmetic_and_level_logger(cli, oracle, tmp_path):
             oracle.set_approx(0)
         det, _ = oracle.detect(plan, pyr)
         want = [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det]
-        assert len(want) > 0 and got[f] == want
-        pe, _, _ = oracle.chns_pyramid(plan, frames[f])
-        de, _ = oracle.detect(plan, pe)
-        nexact += [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in de] == want
-    assert nexact < 2   # (the two tiers do differ on these frames)
+        assert got[f] == want, f
+        total += len(want)
+    assert total > 0
     levels = [l.split() for l in p.stdout.splitlines() if l.startswith("level ")]
-    assert len(levels) == 2 * plan.nScales
+    assert len(levels) == 3 * plan.nScales
     assert [l[1] for l in levels[:plan.nScales]] == ["%06d" % i for i in range(plan.nScales)]
     l0 = plan.levels[0]
     assert levels[0][2] == "%dx%d" % (plan.nChns * l0.wP, l0.hP)     # transposed: cols x rows of the canvas
