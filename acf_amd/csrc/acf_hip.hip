@@ -146,20 +146,20 @@ struct acf_hip_ctx
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
     // (k_smooth_grad) where that pays (big planes, many frames), 2 = wherever k_smooth_grad applies
-    int fusedGrad = getenv("ACF_HIP_NO_FUSED_GRAD") ? 0 : (getenv("ACF_HIP_FUSED_GRAD") ? atoi(getenv("ACF_HIP_FUSED_GRAD")) : 1);
+    int fusedGrad = 1;
     // option "fused_tri": convTri's x pass over M inside that chain as well (k_smooth_grad_tri; the gradient plane is then ONE segment):
     // 0 = never (k_tri_x5v), 1 = where k_smooth_grad runs in batches of >= 64 frames of a context that shares its device, 2 = wherever
     // k_smooth_grad runs
-    int fusedTri = getenv("ACF_HIP_FUSED_TRI") ? atoi(getenv("ACF_HIP_FUSED_TRI")) : 1;
+    int fusedTri = 1;
     // option "shared_device": this context runs beside other contexts on the same device (the pools set it).  Kernel forms are then
     // chosen for the least WORK instead of the shortest time alone: a lone context cuts the smoothing chains into segments to fill the
     // machine (20 % more columns, a verify and a repair launch per scale) and keeps the x pass a kernel of its own; beside other
     // contexts a thin chain's latency is covered by their kernels and only its work counts (3 x 96 frames at 1080p: +4.3 % frames/s;
     // alone, 96 frames: -7 %)
-    int sharedDevice = getenv("ACF_HIP_SHARED_DEVICE") ? atoi(getenv("ACF_HIP_SHARED_DEVICE")) : 0;
+    int sharedDevice = 0;
     // option "tile_persist": the pooled tile kernel runs as persistent workgroups that draw tiles from a counter (best alone on the
     // device: -8 % on that kernel) or one short-lived workgroup per tile (best beside other contexts' kernels, which then find free LDS)
-    int tilePersist = getenv("ACF_HIP_TILE_PERSIST") ? atoi(getenv("ACF_HIP_TILE_PERSIST")) : 1;
+    int tilePersist = 1;
     // the device as hipGetDeviceProperties describes it (acf_hip_create): the persistent grids are sized from these.  The
     // counters the persistent workgroups draw tiles from are eight (blockIdx.x & 7: one per XCD of an MI355X, whose
     // dispatcher deals consecutive workgroups to consecutive XCDs); on a part with another XCD count the ranges still
@@ -179,7 +179,7 @@ struct acf_hip_ctx
     // option cascade_turns: the tile kernels of the contexts of one device take turns (each waits for the tile kernel submitted
     // before it on that device, whichever context's): contexts that run in phase otherwise run their cascades — bound by
     // LDS and VALU, not by memory — beside each other instead of beside the other contexts' memory-bound pyramid kernels
-    int cascTurns = getenv("ACF_HIP_CASCADE_TURNS") ? atoi(getenv("ACF_HIP_CASCADE_TURNS")) : 0;
+    int cascTurns = 0;
     hipEvent_t evTurn[2] = { nullptr, nullptr }; // [0] tile kernel, [1] level kernel (bit 1 of the option: own turns; bit 2: the tile kernels' turns)
 
     acf_hip_params p{};
@@ -239,12 +239,12 @@ struct acf_hip_ctx
     PadJob* d_padJobsR = nullptr; // the same borders in the rank pyramid's layout
     bool levelsEmitRank = false;  // every level goes through k_level_all: the level kernels can write the rank cells themselves
     // k_smooth_vec's speculative column segments (kernels.hip.h): options smooth_segments (0 auto, 1 off, n), smooth_warm, smooth_force_redo
-    int smoothSegments = getenv("ACF_HIP_SMOOTH_SEGMENTS") ? atoi(getenv("ACF_HIP_SMOOTH_SEGMENTS")) : 0; // (env: A/B default)
+    int smoothSegments = 0;
     // 96 warm-up columns: a value decays fourfold per column, so 12-25 columns settle the last bit of ordinary values — but where
     // the image turns exactly 0 (a black bar) the true chain carries a tail that only reaches 0 by underflow, after ~75 columns,
     // while a warm-up started inside the bar is 0 at once (profiles/r03_repair_rates.json: 3 % of planes repaired at 48, none
     // at 64+ on frames with black and flat bands); at 96 frames per launch 48 / 64 / 96 columns cost the same (0.36-0.38 ms)
-    int smoothWarm = getenv("ACF_HIP_SMOOTH_WARM") ? atoi(getenv("ACF_HIP_SMOOTH_WARM")) : 64, smoothForceRedo = 0; // (profiles/r03_repair_rates.json: no repair from 64 columns on)
+    int smoothWarm = 64, smoothForceRedo = 0; // (profiles/r03_repair_rates.json: no repair from 64 columns on)
     float *d_specState = nullptr, *d_trueState = nullptr;
     bool countersZeroed = false; // acf_hip_run has cleared the tiled cascade's counters in front of the pyramid's launches
     int32_t* d_redo = nullptr;
@@ -259,13 +259,13 @@ struct acf_hip_ctx
     // level_warm; one frame: 372 -> 124 us), and channel planes have exactly-zero regions wherever the image is flat (no
     // gradient): a plane whose hand-over differs costs its whole chain again in the repair launch (tests/test_gpu_segments.py
     // counts the repairs of a frame with flat bands so that this cost stays visible).
-    int levelSegments = getenv("ACF_HIP_LEVEL_SEGMENTS") ? atoi(getenv("ACF_HIP_LEVEL_SEGMENTS")) : 0; // option level_segments: 0 = auto (small batches only), 1 = off
-    int levelWarm = getenv("ACF_HIP_LEVEL_WARM") ? atoi(getenv("ACF_HIP_LEVEL_WARM")) : 32; // option level_warm
+    int levelSegments = 0; // option level_segments: 0 = auto (small batches only), 1 = off
+    int levelWarm = 32; // option level_warm
     // option count_repairs: planes the repair launches had to recompute (synchronises after every verify: measurements only)
     int countRepairs = 0;
     // option "graph": acf_hip_run replays a HIP graph captured from its own launches (same frames pointer, same batch size):
     // one host call instead of ~45 launches per frame — what a single frame's latency is made of when the kernels take 20 us
-    int useGraph = getenv("ACF_HIP_GRAPH") ? atoi(getenv("ACF_HIP_GRAPH")) : 0;
+    int useGraph = 0;
     // option "graph": captured runs keyed by (input pointer, batch size); a caller that alternates between a few input buffers
     // (double / triple buffering) replays one graph per buffer instead of re-capturing on every call
     struct GraphSlot
@@ -350,6 +350,69 @@ struct acf_hip_ctx
 
 namespace
 {
+
+// ACF_HIP_FORCE_FALLBACK: the library's ONE form-selecting environment switch (read once per process).  Every stage keeps one
+// fallback form for the shapes its default form does not cover; a comma-separated list of the names below makes those fallbacks
+// run where the default would, so that tests/test_gpu_variants.py can hold each of them against the oracle on ordinary frames.
+// All forms give identical results.  (The other two variables, ACF_HIP_CASC_BOUNDS and ACF_HIP_TILE_TR / _NW, are the tile
+// kernels' tuning knobs: stage boundaries and tile geometry.)
+enum : uint32_t
+{
+    FB_TRIY_UNFUSED = 1u << 0,      // convTri's y pass writes S, k_chns forms the cells (instead of k_triy_chns)
+    FB_MOU_PLAIN = 1u << 1,         // M, O, U as plain planes (instead of 64 x 16 blocks)
+    FB_RESAMPLE_NO_STRIP = 1u << 2, // image resamples without k_resample_strip
+    FB_RESAMPLE_NO_PAIR = 1u << 3,  // ... without the two small scales in one pass
+    FB_RESAMPLE_NO_UP = 1u << 4,    // up-sampling (nOctUp > 0) through the generic k_resample
+    FB_RESAMPLE_GENERIC = 1u << 5,  // every resample through the generic k_resample
+    FB_LEVEL_GROUPS = 1u << 6,      // the levels as one k_level launch per (rows per lane, mode) run instead of k_level_all
+    FB_LDCF_UNFUSED = 1u << 7,      // LDCF as k_ldcf_conv + k_resample instead of k_ldcf_tile
+    FB_NO_DEDUP = 1u << 8,          // stride < shrink: one cascade evaluation per window instead of one per distinct offset
+    FB_NO_TAIL_CODES = 1u << 9,     // the tail without leaf codes (k_cascade_tail3 / _tail_rank on every tail window)
+    FB_TAIL3 = 1u << 10,            // every tail window through k_cascade_tail3
+    FB_TILED_STAGED = 1u << 11,     // depths 1, 3, 4: the staged queue instead of the pooled tile kernel
+    FB_TILED_POOLED1 = 1u << 12,    // depth 1 on float cells: the pooled tile kernel instead of the staged queue
+};
+uint32_t fallbackMask()
+{
+    static const uint32_t mask = [] {
+        static const struct { const char* name; uint32_t bit; } kNames[] = {
+            { "triy_unfused", FB_TRIY_UNFUSED }, { "mou_plain", FB_MOU_PLAIN }, { "resample_no_strip", FB_RESAMPLE_NO_STRIP },
+            { "resample_no_pair", FB_RESAMPLE_NO_PAIR }, { "resample_no_up", FB_RESAMPLE_NO_UP }, { "resample_generic", FB_RESAMPLE_GENERIC },
+            { "level_groups", FB_LEVEL_GROUPS }, { "ldcf_unfused", FB_LDCF_UNFUSED }, { "no_dedup", FB_NO_DEDUP }, { "no_tail_codes", FB_NO_TAIL_CODES },
+            { "tail3", FB_TAIL3 }, { "tiled_staged", FB_TILED_STAGED }, { "tiled_pooled1", FB_TILED_POOLED1 } };
+        uint32_t m = 0;
+        const char* e = getenv("ACF_HIP_FORCE_FALLBACK");
+        std::string s = e ? e : "";
+        size_t i = 0;
+        while (i < s.size())
+        {
+            size_t j = s.find(',', i);
+            j = j == std::string::npos ? s.size() : j;
+            const std::string tok = s.substr(i, j - i);
+            bool known = tok.empty();
+            for (const auto& n : kNames)
+            {
+                if (tok == n.name)
+                {
+                    m |= n.bit;
+                    known = true;
+                }
+            }
+            if (!known)
+            {
+                fprintf(stderr, "acf_hip: ACF_HIP_FORCE_FALLBACK: unknown name '%s'\n", tok.c_str());
+                abort(); // (a test that names a form that does not exist must not pass on the default form)
+            }
+            i = j + 1;
+        }
+        return m;
+    }();
+    return mask;
+}
+inline bool fallbackForced(uint32_t which)
+{
+    return (fallbackMask() & which) != 0;
+}
 
 int fail(const acf_hip_ctx* c, int code, const std::string& msg)
 {
@@ -637,8 +700,7 @@ struct TriPlan
 static TriPlan triPlan(const float* in, const float* U, int h, int w, int rad, int64_t fs, const ChnsArgs* fuse, int64_t uCapacity, int64_t moCapacity,
     bool gradVec)
 {
-    static const bool noFuse = getenv("ACF_HIP_TRIY_UNFUSED") != nullptr; // A/B
-    static const bool plain = getenv("ACF_HIP_MOU_PLAIN") != nullptr;
+    const bool noFuse = fallbackForced(FB_TRIY_UNFUSED), plain = fallbackForced(FB_MOU_PLAIN);
     TriPlan t;
     t.vecX = rad == 5 && h % 4 == 0 && w >= 48 && fs % 4 == 0 && ((uintptr_t(in) | uintptr_t(U)) & 15) == 0;
     t.doFuse = fuse && !noFuse && rad == 5 && h % 4 == 0 && h >= 48 && w % 4 == 0 && fs % 4 == 0 && (uintptr_t(U) & 15) == 0 && fuse->doNorm &&
@@ -1478,8 +1540,8 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
     // k_cascade_tileD + the staged queue: stumps reject slowly, half of a tile's windows are still alive at tree 32, and with the float
     // tile's two workgroups per CU the queue's lanes = windows form beats items = windows x trees (26 against 37 us per 1080p frame; on
     // rank cells the pooled kernel takes 19) — ACF_HIP_TILED_POOLED1 pools it there too; ACF_HIP_TILED_STAGED keeps the staged form everywhere)
-    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && (rank || getenv("ACF_HIP_TILED_POOLED1"))) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
-        !getenv("ACF_HIP_TILED_STAGED");
+    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && (rank || fallbackForced(FB_TILED_POOLED1))) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
+        !fallbackForced(FB_TILED_STAGED);
     const bool pooled = p.treeDepth == 2 || pooledD;
     int bounds[5] = { 0, 32, 32, 64, 128 };
     if (pooled)
@@ -1539,14 +1601,13 @@ static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, in
         return leafBytes + int64_t(nChns) * rowsP * cols * cellBytes + ((std::max<int64_t>(nwin * 8, passW * int64_t(g.pitchC)) + 15) / 16 * 16) + nwin * 8 + 64;
     };
     int nw = 0;
-    if (const char* e = getenv(rank ? "ACF_HIP_RTILE_TR" : "ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
+    if (const char* e = getenv("ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
     {
         const int v = atoi(e);
         g.TR = (v >= 8 && v <= 64) ? v : g.TR; // (a value that does not divide 64 leaves 64 % TR lanes of a wave idle in stage A)
     }
-    // ACF_HIP_RTILE_WG = n: the footprint + lists must fit n times into a CU's LDS (default: three with rank cells)
-    const int wgPerCu = (rank && getenv("ACF_HIP_RTILE_WG")) ? std::max(1, atoi(getenv("ACF_HIP_RTILE_WG"))) : 3;
-    const char* nwEnv = getenv(rank ? "ACF_HIP_RTILE_NW" : "ACF_HIP_TILE_NW");
+    const int wgPerCu = 3; // the footprint + lists must fit three times into a CU's LDS with rank cells
+    const char* nwEnv = getenv("ACF_HIP_TILE_NW");
     const int nwForce = nwEnv ? atoi(nwEnv) : 0;
     for (int64_t limit : { rank ? int64_t(160 * 1024 / wgPerCu / 1280 * 1280) : int64_t(80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
     {
@@ -1787,7 +1848,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
         }
     }
     int block = 0;
-    cs.dedupQ = (p.stride < p.shrink && p.shrink % p.stride == 0 && !getenv("ACF_HIP_NO_DEDUP")) ? p.shrink / p.stride : 1;
+    cs.dedupQ = (p.stride < p.shrink && p.shrink % p.stride == 0 && !fallbackForced(FB_NO_DEDUP)) ? p.shrink / p.stride : 1;
     std::vector<int2> realWin(lv.size());
     for (size_t i = 0; i < lv.size(); i++)
     {
@@ -1892,7 +1953,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
     cs.useTileD = false;
     cs.useRankD = false;
     cs.codeCapD = 0;
-    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.nTrees > 128 && !getenv("ACF_HIP_NO_TAIL_CODES"))
+    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.nTrees > 128 && !fallbackForced(FB_NO_TAIL_CODES))
     {
         // the staged path's last stage [128, nTrees) as leaf codes + ordered scan: the first codeCapD queue entries of a frame
         // (sized like the depth-2 path's), when the scan's leaf table fits a workgroup's LDS
@@ -1972,7 +2033,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             cs.d_tileOffD = tsD.d_tileOffD;
             // ---- the pooled kernel on threshold-rank cells (the rank tables do not depend on the depth): half the fill, three
             // workgroups per CU.  The float pyramid is still written for these depths (the queue's overflow path reads it).
-            if ((tsD.g.pooled || p.treeDepth == 1) && wantRank && !getenv("ACF_HIP_NO_RANK") && !getenv("ACF_HIP_TILED_STAGED"))
+            if ((tsD.g.pooled || p.treeDepth == 1) && wantRank && !c->noRank && !fallbackForced(FB_TILED_STAGED))
             {
                 const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
                 std::vector<int32_t> chnOfNode(nNodes, -1);
@@ -2067,7 +2128,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
                 return rc;
             }
             cs.codeCap = 0;
-            if (g.b[4] < p.nTrees && !getenv("ACF_HIP_TAIL3")) // A/B: ACF_HIP_TAIL3 sends every tail window to k_cascade_tail3
+            if (g.b[4] < p.nTrees && !fallbackForced(FB_TAIL3)) // (forced: every tail window goes to k_cascade_tail3)
             {
                 const int nT = p.nTrees - g.b[4];
                 cs.codePitch = (nT + 63) / 64 * 64; // stage E writes whole 64-tree batches
@@ -2101,7 +2162,7 @@ static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& 
             }
             cs.useTiles = true;
             // ---- the same tiles over threshold-rank cells (16 bits per cell): half the fill, half the LDS
-            if (wantRank && !getenv("ACF_HIP_NO_RANK"))
+            if (wantRank && !c->noRank)
             {
                 std::vector<int32_t> chnOfNode(nNodes, -1);
                 for (size_t q = 0; q < nNodes; q++)
@@ -2460,6 +2521,8 @@ static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena
     return tl;
 }
 
+#include "plan_build.hip.h" // acf_hip_plan's stages (PlanBuild), after the helpers they call
+
 int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_hits)
 {
     if (!c)
@@ -2538,7 +2601,6 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
         c->lastBatch = 0;
         return ACF_HIP_OK;
     }
-    Plan& pl = c->plan;
     // smoothing radii the recursion kernel implements (convTri.cpp:215-218)
     for (double r : { p.colorSmooth, p.smooth })
     {
@@ -2557,546 +2619,13 @@ int acf_hip_plan(acf_hip_ctx* c, int H, int W, int d_in, int max_batch, int max_
     }
     c->maxBatch = max_batch;
     c->maxHits = max_hits;
-    const int B = max_batch;
-    const int shrink = p.shrink;
-    const int d = pl.d;
-    const int64_t np0 = int64_t(H) * W;
-
-    // colour conversion buffer (chnsPyramid.cpp:230-263)
-    const bool passthrough = (d_in == 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
-    if (!passthrough)
-    {
-        if ((rc = devAlloc(c, &c->d_color, size_t(B) * d * np0)))
-        {
-            return rc;
-        }
-    }
-
-    // real scales: mirror the reference's shallow-copy bookkeeping (chnsPyramid.cpp:297-338)
-    TableArena arena;
-    c->h_descs.clear();
-    c->real.clear();
-    int curH = H, curW = W;
-    std::vector<SmoothJob> realJobs;
-    for (size_t k = 0; k < pl.real.size(); k++)
-    {
-        RealScale rs;
-        rs.level = pl.real[k];
-        rs.h = pl.real_h[k];
-        rs.w = pl.real_w[k];
-        const double s = pl.levels[rs.level].scale;
-        const bool same = (H == rs.h && W == rs.w); // sz == sz1 (:303), compared against the ORIGINAL size
-        if (same && (curH != H || curW != W))
-        {
-            return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: scale order");
-        }
-        rs.resampled = !same;
-        rs.src_h = curH;
-        rs.src_w = curW;
-        const int64_t np = int64_t(rs.h) * rs.w;
-        if (rs.resampled)
-        {
-            ResampleDesc dd;
-            if ((rc = buildResample(curH, curW, rs.h, rs.w, dd, arena)))
-            {
-                return fail(c, rc, "plan: degenerate resample geometry");
-            }
-            const double one[3] = { 1.0, 1.0, 1.0 };
-            setResampleGain(dd, one, d, d);
-            dd.nplanes = d;
-            dd.src_off = 0;
-            dd.dst_off = 0;
-            dd.src_frame_stride = int64_t(d) * curH * curW;
-            dd.dst_frame_stride = int64_t(d) * np;
-            rs.descIndex = int(c->h_descs.size());
-            c->h_descs.push_back(dd);
-            if ((rc = devAlloc(c, &rs.img, size_t(B) * d * np)))
-            {
-                return rc;
-            }
-        }
-        const bool halfCond = (s == 0.5) && ((p.nApprox > 0) || (p.nPerOct == 1)); // :313-316
-        rs.adoptAsI = same || halfCond;
-        if (rs.adoptAsI)
-        {
-            curH = rs.h;
-            curW = rs.w;
-        }
-        if ((rc = devAlloc(c, &rs.sm, size_t(B) * d * np)))
-        {
-            return rc;
-        }
-        if (p.gradMagEnabled || p.gradHistEnabled)
-        {
-            rs.moFloats = std::max<int64_t>(np, moBlockedFloats(rs.h, rs.w));
-            if ((rc = devAlloc(c, &rs.M, size_t(B) * size_t(rs.moFloats))) || (rc = devAlloc(c, &rs.O, size_t(B) * size_t(rs.moFloats))))
-            {
-                return rc;
-            }
-            if (p.normRad)
-            {
-                rs.uFloats = std::max<int64_t>(np, uBlockedFloats(rs.h, rs.w));
-                if ((rc = devAlloc(c, &rs.U, size_t(B) * size_t(rs.uFloats))) || (rc = devAlloc(c, &rs.S, size_t(B) * np)))
-                {
-                    return rc;
-                }
-            }
-            if (c->taps)
-            {
-                if ((rc = devAlloc(c, &rs.Mn, size_t(B) * np)))
-                {
-                    return rc;
-                }
-            }
-        }
-        SmoothJob j{};
-        j.h = rs.h;
-        j.w = rs.w;
-        j.nplanes = d;
-        j.out_cs = rs.h;
-        j.in_off = 0;
-        j.out_off = 0;
-        j.in_ps = np;
-        j.out_ps = np;
-        realJobs.push_back(j);
-        c->real.push_back(rs);
-    }
-    c->nImgDescs = int(c->h_descs.size());
-    // k_resample_strip (the march over strips of output columns) for every down-sampling image resample, and for two consecutive
-    // real scales that share their source — the two small scales of a 1080p pyramid — in one pass (A/B: ACF_HIP_RESAMPLE_NO_STRIP)
-    if (!getenv("ACF_HIP_RESAMPLE_NO_STRIP"))
-    {
-        for (size_t k = 0; k < c->real.size(); k++)
-        {
-            RealScale& ra = c->real[k];
-            if (!ra.resampled)
-            {
-                continue;
-            }
-            ra.strip = stripPlan(c->h_descs[ra.descIndex], nullptr, arena);
-            if (k + 1 < c->real.size() && !getenv("ACF_HIP_RESAMPLE_NO_PAIR"))
-            {
-                const RealScale& rb = c->real[k + 1];
-                if (rb.resampled && !ra.adoptAsI && ra.src_h == rb.src_h && ra.src_w == rb.src_w && !(k > 0 && c->real[k - 1].stripPair.ok) && rb.w <= ra.w && rb.h <= ra.h)
-                {
-                    ra.stripPair = stripPlan(c->h_descs[ra.descIndex], &c->h_descs[rb.descIndex], arena);
-                }
-            }
-        }
-    }
-
-    // approximated levels (chnsPyramid.cpp:385-397)
-    const int nColor = p.colorEnabled ? d : 0;
-    const int nMag = p.gradMagEnabled ? 1 : 0;
-    c->approxMaxBlocks = 0;
-    for (size_t i = 0; i < pl.levels.size(); i++)
-    {
-        const acf_hip_level& l = pl.levels[i];
-        if (l.isReal)
-        {
-            continue;
-        }
-        const acf_hip_level& lr = pl.levels[l.realIndex];
-        ResampleDesc dd;
-        if ((rc = buildResample(lr.hC, lr.wC, l.hC, l.wC, dd, arena)))
-        {
-            return fail(c, rc, "plan: degenerate resample geometry (approximated level)");
-        }
-        double ratio[3];
-        for (int j = 0; j < 3; j++)
-        {
-            ratio[j] = std::pow(l.scale / lr.scale, -(p.nLambdas == 3 ? p.lambdas[j] : 0.0)); // :393 (image-specific lambdas: rewritten per frame)
-        }
-        setResampleGain(dd, ratio, nColor, nColor + nMag);
-        dd.nplanes = pl.nChns;
-        dd.src_off = pl.raw_off[l.realIndex];
-        dd.dst_off = pl.raw_off[i];
-        dd.src_frame_stride = pl.raw_floats;
-        dd.dst_frame_stride = pl.raw_floats;
-        c->h_descs.push_back(dd);
-        c->approxMaxBlocks = std::max(c->approxMaxBlocks, resampleBlocks(dd));
-    }
-    c->nApproxDescs = int(c->h_descs.size()) - c->nImgDescs;
-    c->autoLambdas = p.nApprox > 0 && p.nLambdas != 3;
-    c->h_lambdas.assign(size_t(B) * 3, 0.0);
-    if (c->autoLambdas && (rc = devAlloc(c, &c->d_planeSums, size_t(B) * 2 * pl.nChns)))
+    PlanBuild b(c, H, W, d_in, max_batch, max_hits);
+    if ((rc = b.colourBuffer()) || (rc = b.realScales()) || (rc = b.imageStrips()) || (rc = b.approxLevels()) || (rc = b.finalJobs()) || (rc = b.levelJobs()) ||
+        (rc = b.ldcf()) || (rc = b.uploadAndScratch()) || (rc = b.cascade()))
     {
         return rc;
     }
-
-    // final smoothing + padding jobs (chnsPyramid.cpp:399-435)
-    std::vector<SmoothJob> finalJobs;
-    std::vector<int64_t> rankOffs;
-    std::vector<PadJob> padJobs, padJobsR;
-    int64_t rankOff = 0; // the rank pyramid's layout (rankPitch): levels in order, nChns planes [wP][pitch] each
-    c->finalMaxH = 0;
-    c->padMaxElems = 0;
-    const int py = p.pad_h / shrink, px = p.pad_w / shrink;
-    for (size_t i = 0; i < pl.levels.size(); i++)
-    {
-        const acf_hip_level& l = pl.levels[i];
-        SmoothJob j{};
-        j.h = l.hC;
-        j.w = l.wC;
-        j.nplanes = pl.nChns;
-        j.out_cs = l.hP;
-        j.in_off = pl.raw_off[i];
-        j.out_off = l.offset + int64_t(px) * l.hP + py;
-        j.in_ps = int64_t(l.hC) * l.wC;
-        j.out_ps = int64_t(l.hP) * l.wP;
-        finalJobs.push_back(j);
-        c->finalMaxH = std::max(c->finalMaxH, l.hC);
-        PadJob q{};
-        q.hC = l.hC;
-        q.wC = l.wC;
-        q.hP = l.hP;
-        q.wP = l.wP;
-        q.py = py;
-        q.px = px;
-        q.nplanes = pl.nChns;
-        q.pitch = l.hP;
-        q.off = l.offset;
-        padJobs.push_back(q);
-        q.pitch = rankPitch(l.hP);
-        q.off = rankOff;
-        padJobsR.push_back(q);
-        c->padMaxElems = std::max<int64_t>(c->padMaxElems, int64_t(pl.nChns) * (int64_t(l.wP) * (l.hP - l.hC) + int64_t(l.wP - l.wC) * l.hC)); // border cells
-        rankOffs.push_back(rankOff);
-        rankOff += int64_t(pl.nChns) * rankPitch(l.hP) * l.wP;
-    }
-    // level jobs (k_level): every level, real ones read their raw channels, approximated ones resample on the
-    // fly; sorted into runs of equal (rows-per-lane R, mode) because both are template parameters of the kernel
-    {
-        struct Keyed
-        {
-            int key;
-            LevelJob j;
-        };
-        std::vector<Keyed> fusedJobs, rawJobs;
-        c->fusedOk = p.smooth > 0 && c->finalMaxH <= 64 * LEVEL_MAX_R_REAL;
-        int ai = 0;
-        for (size_t i = 0; i < pl.levels.size(); i++)
-        {
-            const acf_hip_level& l = pl.levels[i];
-            LevelJob j{};
-            j.hC = l.hC;
-            j.wC = l.wC;
-            j.out_cs = l.hP;
-            j.in_off = pl.raw_off[i];
-            j.raw_off = pl.raw_off[i];
-            j.out_off = l.offset + int64_t(px) * l.hP + py;
-            j.in_ps = int64_t(l.hC) * l.wC;
-            j.out_ps = int64_t(l.hP) * l.wP;
-            j.rank_cs = rankPitch(l.hP);
-            j.rank_ps = int64_t(j.rank_cs) * l.wP;
-            j.rank_off = rankOffs[i] + int64_t(px) * j.rank_cs + py;
-            j.desc = -1;
-            const int R = (l.hC + 63) / 64;
-            int mode = LM_REAL;
-            rawJobs.push_back({ R * 8 + LM_REAL, j });
-            if (!l.isReal)
-            {
-                j.desc = ai;
-                const ResampleDesc& dd = c->h_descs[size_t(c->nImgDescs + ai)];
-                if ((dd.ymode == RS_DOWN && dd.ybd0 > 3) || (dd.xmode == RS_DOWN && dd.xbd0 > 3) || dd.ymode == RS_EXACT || dd.xmode == RS_EXACT)
-                {
-                    c->fusedOk = false; // more than three taps on an axis or an exact 1/k ratio: separate launches
-                }
-                mode = dd.xmode == RS_DOWN ? (dd.ymode == RS_DOWN ? LM_DD : LM_DU) : (dd.ymode == RS_DOWN ? LM_UD : LM_UU);
-                if (R > 8)
-                {
-                    c->fusedOk = false; // (only copies of real levels are instantiated beyond eight rows per lane)
-                }
-                if (dd.ha >= 64 * (dd.ymode == RS_DOWN ? (3 * R + 1) / 2 : R))
-                {
-                    // more source rows than LevelWindow's registers hold (ratio beyond 2^(1/2)), or no row left in the
-                    // column buffer for the zeros that taps beyond the source's last row read (level_column)
-                    c->fusedOk = false;
-                }
-                if (mode == LM_DU || mode == LM_UD)
-                {
-                    // one axis up, the other down: cannot happen with getScales' isotropic scales (an exhaustive scan of
-                    // 64..330 x 64..330 frames finds none), so the fused kernel is not instantiated for it
-                    c->fusedOk = false;
-                }
-                ai++;
-            }
-            fusedJobs.push_back({ R * 8 + mode, j });
-        }
-        auto pack = [&](std::vector<Keyed>& v, std::vector<acf_hip_ctx::LevelGroup>& groups, LevelJob** dst, int* nAll) {
-            auto jobCost = [](const Keyed& k) {
-                // one wave walks wC column steps; a step costs ~R row registers x (1 for a copy, 3 for a resampled column) + the recursion
-                const int R = k.key / 8, mode = k.key % 8;
-                return double(k.j.wC) * (R * (mode == LM_REAL ? 1.0 : 3.0) + 2.0);
-            };
-            for (auto& k : v)
-            {
-                k.j.kind = k.key;
-            }
-            // k_level_all takes every job whose specialisation fits 128 VGPRs, longest chain first; the rest go out as
-            // one launch per (R, mode) run on the side streams
-            std::vector<Keyed> all, rest;
-            for (const auto& k : v)
-            {
-                const int R = k.key / 8, mode = k.key % 8;
-                ((R <= 4 || (mode == LM_REAL && R <= 8)) && !getenv("ACF_HIP_LEVEL_GROUPS") ? all : rest).push_back(k);
-            }
-            std::stable_sort(all.begin(), all.end(), [&](const Keyed& a, const Keyed& b) { return jobCost(a) > jobCost(b); });
-            std::stable_sort(rest.begin(), rest.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
-            std::vector<LevelJob> flat;
-            for (const auto& k : all)
-            {
-                flat.push_back(k.j);
-            }
-            *nAll = int(all.size());
-            groups.clear();
-            for (const auto& k : rest)
-            {
-                if (groups.empty() || groups.back().R * 8 + groups.back().mode != k.key)
-                {
-                    groups.push_back({ k.key / 8, k.key % 8, int(flat.size()), 0, 0.0, 0 });
-                }
-                groups.back().count++;
-                groups.back().cost += jobCost(k);
-                flat.push_back(k.j);
-            }
-            return devUpload(c, dst, flat);
-        };
-        if ((rc = pack(fusedJobs, c->levelGroups, &c->d_levelJobs, &c->nAllJobs)) || (rc = pack(rawJobs, c->levelGroupsRaw, &c->d_levelJobsRaw, &c->nAllJobsRaw)))
-        {
-            return rc;
-        }
-        c->levelsEmitRank = c->fusedOk && c->levelGroups.empty() && c->nAllJobs == int(pl.levels.size());
-        for (const auto& l : pl.levels)
-        {
-            if ((py & 1) && l.hC % 64 == 0)
-            {
-                c->levelsEmitRank = false; // (level_body's paired rank stores: no lane holds row hC)
-            }
-        }
-    }
-    // ---- LDCF post-stage (acf_hip_params::ldcfK): level table of the filtered, halved pyramid + one resample per level
-    c->ldcfLevels.clear();
-    c->ldcfFloats = c->ldcfTmpFloats = 0;
-    if (p.ldcfK > 0)
-    {
-        const int shrink2 = 2 * p.shrink, nCk = pl.nChns * p.ldcfK;
-        c->ldcfDescBase = int(c->h_descs.size());
-        c->ldcfMaxCells = c->ldcfMaxBlocks = 0;
-        std::vector<LdcfJob> ldcfJobs;
-        int64_t off = 0;
-        for (size_t i = 0; i < pl.levels.size(); i++)
-        {
-            acf_hip_level l = pl.levels[i];
-            const acf_hip_level& s0 = pl.levels[i];
-            l.hP = l.hC = int(std::floor(0.5 * s0.hP + 0.5)); // imResample(C, .5): round(.5 * size)
-            l.wP = l.wC = int(std::floor(0.5 * s0.wP + 0.5));
-            if (l.hP < 1 || l.wP < 1)
-            {
-                return fail(c, ACF_HIP_E_UNSUPPORTED, "plan: LDCF level smaller than one cell");
-            }
-            l.nWinR = std::max(0, int(std::ceil(float(l.hP * shrink2 - p.modelDsPad_h + 1) / p.stride)));
-            l.nWinC = std::max(0, int(std::ceil(float(l.wP * shrink2 - p.modelDsPad_w + 1) / p.stride)));
-            l.offset = off;
-            off += int64_t(nCk) * l.hP * l.wP;
-            c->ldcfLevels.push_back(l);
-            ResampleDesc dd;
-            if ((rc = buildResample(s0.hP, s0.wP, l.hP, l.wP, dd, arena)))
-            {
-                return fail(c, rc, "plan: degenerate LDCF resample geometry");
-            }
-            const double one[3] = { 1.0, 1.0, 1.0 };
-            setResampleGain(dd, one, nCk, nCk);
-            dd.nplanes = nCk;
-            dd.src_off = int64_t(p.ldcfK) * s0.offset; // the filtered scratch holds every level: k planes per channel plane
-            dd.dst_off = l.offset;
-            c->h_descs.push_back(dd);
-            LdcfJob j{};
-            j.h = s0.hP;
-            j.w = s0.wP;
-            j.inOff = s0.offset;
-            j.outOff = int64_t(p.ldcfK) * s0.offset;
-            ldcfJobs.push_back(j);
-            c->ldcfMaxCells = std::max(c->ldcfMaxCells, s0.hP * s0.wP);
-            c->ldcfMaxBlocks = std::max(c->ldcfMaxBlocks, resampleBlocks(dd));
-        }
-        c->ldcfTmpFloats = int64_t(p.ldcfK) * pl.pyr_floats;
-        c->ldcfFloats = off;
-        {
-            // fused path: every level tiled for k_resample_tile's passes with 16 output columns per tile
-            std::vector<LdcfTileJob> tj;
-            int maxR = 0, maxC = 0;
-            bool ok = !getenv("ACF_HIP_LDCF_UNFUSED");
-            const int xoMax = 16; // output columns per tile at most (source tile: twice as many columns)
-            for (size_t i = 0; i < c->ldcfLevels.size() && ok; i++)
-            {
-                const ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
-                // the largest tile of at most 64 x 16 outputs whose source tile is at most 128 rows x 32 columns: the filter
-                // stage then has exactly two tile rows per lane and eight column quads (k_ldcf_tile)
-                ResampleTiling tl;
-                int yo = 0, xo = 0;
-                {
-                    std::vector<std::pair<int, int>> cand;
-                    for (int y = RT_YO; y >= 32; y--)
-                    {
-                        for (int x = xoMax; x >= xoMax / 2; x--)
-                        {
-                            cand.push_back({ y, x });
-                        }
-                    }
-                    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first * a.second > b.first * b.second; });
-                    for (const auto& yx : cand)
-                    {
-                        tl = resampleTilePlan(dd, arena, yx.second, int64_t(40) * 1024, yx.first, 128, 2 * xoMax);
-                        if (tl.rows > 0)
-                        {
-                            yo = yx.first;
-                            xo = yx.second;
-                            break;
-                        }
-                    }
-                }
-                if (tl.rows <= 0)
-                {
-                    ok = false;
-                    break;
-                }
-                maxR = std::max(maxR, tl.rows);
-                maxC = std::max(maxC, tl.cols);
-                const int ntY = cdiv(dd.hb, yo), ntX = cdiv(dd.wb, xo);
-                for (int x = 0; x < ntX; x++)
-                {
-                    for (int y = 0; y < ntY; y++)
-                    {
-                        LdcfTileJob j{};
-                        j.level = int(i);
-                        j.ytile = y;
-                        j.xtile = x;
-                        j.tile_y = tl.tile_y;
-                        j.tile_x = tl.tile_x;
-                        j.yo = yo;
-                        j.xo = xo;
-                        tj.push_back(j);
-                    }
-                }
-            }
-            c->ldcfTiles = 0;
-            if (ok && !tj.empty())
-            {
-                c->ldcfTiles = int(tj.size());
-                c->ldcfTileRows = maxR;
-                c->ldcfTileCols = maxC;
-                if ((rc = devUpload(c, &c->d_ldcfTileJobs, tj)))
-                {
-                    return rc;
-                }
-            }
-        }
-        for (size_t i = 0; i < c->ldcfLevels.size(); i++)
-        {
-            ResampleDesc& dd = c->h_descs[size_t(c->ldcfDescBase) + i];
-            dd.src_frame_stride = c->ldcfTmpFloats;
-            dd.dst_frame_stride = c->ldcfFloats;
-        }
-        if ((rc = devUpload(c, &c->d_ldcfJobs, ldcfJobs)))
-        {
-            return rc;
-        }
-        if ((rc = devUpload(c, &c->d_ldcfFilt, c->ldcfFilters)) || (c->ldcfTiles == 0 && (rc = devAlloc(c, &c->d_ldcfTmp, size_t(B) * c->ldcfTmpFloats + 64))) ||
-            (rc = devAlloc(c, &c->d_ldcfPyr, size_t(B) * c->ldcfFloats + 64)))
-        {
-            return rc;
-        }
-    }
-    if ((rc = devUpload(c, &c->d_descs, c->h_descs)) || (rc = devUpload(c, &c->d_it, arena.ints)) || (rc = devUpload(c, &c->d_ft, arena.floats)) ||
-        (rc = devUpload(c, &c->d_realJobs, realJobs)) || (rc = devUpload(c, &c->d_finalJobs, finalJobs)) || (rc = devUpload(c, &c->d_padJobs, padJobs)) || (rc = devUpload(c, &c->d_padJobsR, padJobsR)))
-    {
-        return rc;
-    }
-    if ((rc = devAlloc(c, &c->d_chns, size_t(B) * pl.raw_floats)) || (rc = devAlloc(c, &c->d_pyr, size_t(B) * pl.pyr_floats + 64)) /* + slack: the cascade's 16-byte tile fill may read a few floats past the last plane */)
-    {
-        return rc;
-    }
-    {
-        // k_smooth_vec's column segments: hand-over states of up to 32 segments per plane, one repair flag per plane
-        c->segCap = 32;
-        const size_t nState = size_t(B) * d * c->segCap * size_t(std::max(H, 4));
-        if ((rc = devAlloc(c, &c->d_specState, nState)) || (rc = devAlloc(c, &c->d_trueState, nState)) || (rc = devAlloc(c, &c->d_redo, size_t(B) * d)))
-        {
-            return rc;
-        }
-        // (zero between calls: the repair launch takes its flags down; cleared on the context's own stream, which does not
-        // synchronise with the null stream, and again on the error returns between a verify and its repair launch: clearRepairFlags)
-        HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int32_t) * size_t(B) * d, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->redoInts = size_t(B) * d;
-    }
-    {
-        // k_level_all's column segments: only small batches are bound by a level's chain length
-        c->levelSegFrames = std::min(B, 8);
-        c->levelSegCap = 8;
-        c->levelHMax = std::max(c->finalMaxH, 4);
-        const size_t nState = size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns * c->levelSegCap * size_t(c->levelHMax);
-        if ((rc = devAlloc(c, &c->d_lvSpec, nState)) || (rc = devAlloc(c, &c->d_lvTrue, nState)) ||
-            (rc = devAlloc(c, &c->d_lvRedo, size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns)))
-        {
-            return rc;
-        }
-        HIPCHK(c, hipMemsetAsync(c->d_lvRedo, 0, sizeof(int32_t) * size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->lvRedoInts = size_t(c->levelSegFrames) * pl.levels.size() * pl.nChns;
-    }
-    // cascade
-    // with LDCF the cascade runs on the filtered pyramid: its tables are built for those levels, nChns*k channels, shrink*2
-    const std::vector<acf_hip_level>& cascLevels = p.ldcfK > 0 ? c->ldcfLevels : pl.levels;
-    {
-        ShrinkScope ss(c, p.ldcfK > 0 ? 2 : 1);
-        if ((rc = buildCascadeTables(c, cascLevels, pl.nChns * std::max(p.ldcfK, 1), c->cs, p.ldcfK <= 0)))
-        {
-            return rc;
-        }
-    }
-    if ((rc = devUpload(c, &c->cs.d_thrs, c->thrs)) || (rc = devUpload(c, &c->cs.d_hs, c->hs)) || (rc = devUpload(c, &c->cs.d_child, c->child)) ||
-        (rc = devUpload(c, &c->cs.d_fids, c->fids)))
-    {
-        return rc;
-    }
-    std::vector<BoxLevel> box(pl.levels.size());
-    for (size_t i = 0; i < pl.levels.size(); i++)
-    {
-        box[i].shw_h = pl.levels[i].scalehw_h;
-        box[i].shw_w = pl.levels[i].scalehw_w;
-        // cv::Size(cv::Size2d(modelDs) / scale): saturate_cast<int>(double) == cvRound (ACF.cpp:304)
-        box[i].bh = int(std::lrint(double(p.modelDs_h) / pl.levels[i].scale));
-        box[i].bw = int(std::lrint(double(p.modelDs_w) / pl.levels[i].scale));
-    }
-    if ((rc = devUpload(c, &c->d_boxLevels, box)))
-    {
-        return rc;
-    }
-    if (c->cs.dedupQ > 1 && (rc = devAlloc(c, &c->cs.d_hitsX, size_t(B) * max_hits)))
-    {
-        return rc;
-    }
-    if ((rc = devAlloc(c, &c->cs.d_hits, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->cs.d_sorted, size_t(B) * max_hits)) ||
-        (rc = devAlloc(c, &c->cs.d_dets, size_t(B) * max_hits)) || (rc = devAlloc(c, &c->cs.d_counts, size_t(B))))
-    {
-        return rc;
-    }
-    {
-        int64_t nWinTotal = 0;
-        for (const auto& l : cascLevels)
-        {
-            nWinTotal += int64_t(l.nWinR) * l.nWinC;
-        }
-        c->cs.qcap = int(std::max<int64_t>(nWinTotal, 1));
-        if ((rc = devAlloc(c, &c->cs.d_queue[0], size_t(B) * c->cs.qcap)) || (rc = devAlloc(c, &c->cs.d_queue[1], size_t(B) * c->cs.qcap)) ||
-            (rc = devAlloc(c, &c->cs.d_qcounts, size_t(8) * B + 8))) // (+ 8: k_cascade_tile3's tile counters, one per XCD)
-        {
-            return rc;
-        }
-    }
-    c->h_counts.assign(B, 0);
+    c->h_counts.assign(size_t(max_batch), 0);
     c->hasPlan = true;
     c->pyramidValid = c->detectValid = false;
     c->lastBatch = 0;
@@ -3212,14 +2741,14 @@ static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes);
 // A/B knob: ACF_HIP_RESAMPLE_GENERIC forces the gather kernel for the image resamples (read once)
 static bool resampleGenericOnly()
 {
-    static const bool v = getenv("ACF_HIP_RESAMPLE_GENERIC") != nullptr;
+    const bool v = fallbackForced(FB_RESAMPLE_GENERIC);
     return v;
 }
 
 // k_resample_up applies: both axes up-sampled, whole quads of output rows, 16-byte aligned planes
 static bool resampleUpOk(const ResampleDesc& d)
 {
-    static const bool off = getenv("ACF_HIP_RESAMPLE_NO_UP") != nullptr; // A/B: the generic kernel
+    const bool off = fallbackForced(FB_RESAMPLE_NO_UP);
     return !off && d.xmode == RS_UP && d.ymode == RS_UP && d.hb % 4 == 0 && d.ha >= 4 && d.dst_off % 4 == 0 && d.dst_frame_stride % 4 == 0;
 }
 
@@ -3391,970 +2920,9 @@ int pyramidImpl(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF
     return rc;
 }
 
-int pyramidBody(acf_hip_ctx* c, const float* frames, const PackedSrc* u8, int nF)
-{
-    if (c && !c->kids.empty())
-    {
-        if (u8)
-        {
-            return fail(c, ACF_HIP_E_UNSUPPORTED, "pyramid_u8: not available with option \"streams\" > 1");
-        }
-        if (!frames || nF <= 0 || nF > c->maxBatch)
-        {
-            return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
-        }
-        const size_t per = size_t(c->plan.d_in) * c->plan.H * c->plan.W;
-        int rc = kidsFork(c);
-        for (size_t i = 0; i < c->kids.size() && !rc; i++)
-        {
-            const int n = kidCount(c, i, nF);
-            if (n > 0 && (rc = acf_hip_pyramid(c->kids[i], frames + i * size_t(c->kidChunk) * per, n)))
-            {
-                return kidFail(c, c->kids[i], rc);
-            }
-        }
-        c->lastBatch = nF;
-        c->pyramidValid = true;
-        c->detectValid = false;
-        return rc ? rc : kidsJoin(c);
-    }
-    if (!c || !c->hasPlan)
-    {
-        return c ? fail(c, ACF_HIP_E_NOPLAN, "pyramid: plan first") : ACF_HIP_E_INVALID;
-    }
-    if ((!frames && !u8) || (u8 && !u8->frames) || nF <= 0 || nF > c->maxBatch)
-    {
-        return fail(c, ACF_HIP_E_INVALID, "pyramid: n_frames out of range");
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    const acf_hip_params& p = c->p;
-    const Plan& pl = c->plan;
-    const int H = pl.H, W = pl.W, d = pl.d, d_in = pl.d_in, shrink = p.shrink;
-    const int64_t np0 = int64_t(H) * W;
-    c->pyramidValid = c->detectValid = false;
-    int rc;
-    bool ingestConverted = false; // the 8-bit ingest wrote the converted colour planes itself
-    PackedSrc reduced{};
-    if (u8 && c->rz.on)
-    {
-        // the apps' Resizer (acf.cpp:117-148) in front of the ingest: the caller's frames are rz.rows x rz.cols
-        const int cpp = pixCpp(u8->pix);
-        const int stride = u8->rowStride > 0 ? u8->rowStride : c->rz.cols * cpp;
-        if (stride < c->rz.cols * cpp)
-        {
-            return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: row stride smaller than a row of the unreduced frame");
-        }
-        if ((rc = launchResizeU8(c, c->rz, u8->frames, cpp, stride, nF, c->rz.d_out)))
-        {
-            return rc;
-        }
-        reduced = PackedSrc{ c->rz.d_out, u8->pix, 0 };
-        u8 = &reduced;
-    }
-    if (u8)
-    {
-        // 8-bit ingest (ACF.cpp:114-119,137; MatP.cpp:51-73), fused with the colour conversion below when there is one
-        prof(c, "k_ingest_u8");
-        ingestConverted = c->d_color && p.colorSpace != ACF_HIP_CS_HSV; // (hsv: planar ingest, then k_rgb2hsv like a float frame)
-        if (ingestConverted)
-        {
-            if ((rc = launchIngest(c, *u8, nF, c->d_color, int64_t(d) * np0, true)))
-            {
-                return rc;
-            }
-            frames = nullptr;
-        }
-        else
-        {
-            if (!c->d_stage && (rc = devAlloc(c, &c->d_stage, size_t(c->maxBatch) * d_in * np0)))
-            {
-                return rc;
-            }
-            if ((rc = launchIngest(c, *u8, nF, c->d_stage, int64_t(d_in) * np0, false)))
-            {
-                return rc;
-            }
-            frames = c->d_stage;
-        }
-    }
-    c->lastFrames = frames;
-
-    // ---- colour conversion, once at full resolution (chnsPyramid.cpp:230-263)
-    const float* cur = frames; // "I"
-    int64_t cur_fs = int64_t(d_in) * np0;
-    int curH = H, curW = W;
-    if (ingestConverted)
-    {
-        cur = c->d_color;
-        cur_fs = int64_t(d) * np0;
-    }
-    else if (c->d_color)
-    {
-        prof(c, "k_colour");
-        dim3 grid(cdiv(np0, 256), 1, nF), block(256);
-        const int64_t out_fs = int64_t(d) * np0;
-        if (p.colorSpace == ACF_HIP_CS_LUV)
-        {
-            // d_in == 3, RGB -> LUV; the reference takes the SSE body iff n % 4 == 0 (rgbConvertMex.cpp:92,343)
-            if (np0 % 4 == 0)
-            {
-                hipLaunchKernelGGL(k_rgb2luv<true>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs, x86T(c));
-            }
-            else
-            {
-                hipLaunchKernelGGL(k_rgb2luv<false>, grid, block, 0, c->stream, frames, c->d_color, (const float*)c->d_lTable, makeLuvConsts(), int(np0), cur_fs, out_fs, x86T(c));
-            }
-        }
-        else if (p.colorSpace == ACF_HIP_CS_GRAY)
-        {
-            const float mr = (float).2989360213 * 1.0f, mg = (float).5870430745 * 1.0f, mb = (float).1140209043 * 1.0f;
-            if (d_in == 1)
-            {
-                hipLaunchKernelGGL(k_rgb2gray<true>, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs, mr, mg, mb);
-            }
-            else
-            {
-                hipLaunchKernelGGL(k_rgb2gray<false>, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs, mr, mg, mb);
-            }
-        }
-        else if (p.colorSpace == ACF_HIP_CS_HSV)
-        {
-            hipLaunchKernelGGL(k_rgb2hsv, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs); // (d_in == 3: the plan checked)
-        }
-        else // ORIG / RGB with a 1-plane input: replicate
-        {
-            hipLaunchKernelGGL(k_replicate3, grid, block, 0, c->stream, frames, c->d_color, int(np0), cur_fs, out_fs);
-        }
-        LAUNCHCHK(c, "colour conversion");
-        cur = c->d_color;
-        cur_fs = out_fs;
-    }
-
-    // ---- real scales, in order (chnsPyramid.cpp:297-338 + chnsCompute.cpp:146-338)
-    const float pColor = p.colorSmooth > 0 ? float(12.0 / p.colorSmooth / (p.colorSmooth + 2.0) - 2.0) : 0.f;
-    // which real scale's smoothed image each real scale is resampled from (-1: the input frame), following the
-    // reference's I = I1 adoption (chnsPyramid.cpp:313-316)
-    std::vector<int> srcIdx(c->real.size(), -1);
-    std::vector<char> halfDone(c->real.size(), 0), pairDone(c->real.size() + 1, 0);
-    {
-        int curIdx = -1;
-        for (size_t k = 0; k < c->real.size(); k++)
-        {
-            srcIdx[k] = curIdx;
-            if (c->real[k].adoptAsI)
-            {
-                curIdx = int(k);
-            }
-        }
-    }
-    // Real scale k + 1 needs scale k's SMOOTHED image only (its exact half, or the adopted image it is resampled from); what
-    // follows the smoothing of scale k — gradMag, convTri, the cells: column-sequential chains that leave most of the machine
-    // idle — runs beside the smaller scales' own chains: every scale gets a stream, ordered by "scale k has been smoothed"
-    // events (option scale_streams; A/B: ACF_HIP_SCALES_SERIAL).
-    static const bool scalesSerial = getenv("ACF_HIP_SCALES_SERIAL") != nullptr;
-    if (!scalesSerial && c->scaleStreams && c->real.size() > 1 && !c->taps)
-    {
-        ensureSide(c);
-    }
-    const size_t nSideS = c->side.size();
-    const bool scalePar = !scalesSerial && c->scaleStreams && c->real.size() > 1 && nSideS >= c->real.size() - 1 && c->evJoin.size() >= nSideS && !c->taps;
-    while (scalePar && c->evScale.size() < c->real.size())
-    {
-        hipEvent_t e;
-        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->evScale.push_back(e);
-    }
-    hipStream_t const mainStream = c->stream;
-    struct StreamGuard // the launch helpers all use c->stream: point it at the scale's stream, back on every way out
-    {
-        acf_hip_ctx* c;
-        hipStream_t keep;
-        ~StreamGuard() { c->stream = keep; }
-    } streamGuard{ c, mainStream };
-    for (size_t k = 0; k < c->real.size(); k++)
-    {
-        RealScale& rs = c->real[k];
-        const int64_t np = int64_t(rs.h) * rs.w;
-        if (scalePar)
-        {
-            if (k > 0)
-            {
-                prof(c, "(end)"); // closes the previous scale's last kernel on its stream
-            }
-            c->stream = k == 0 ? mainStream : c->side[k - 1];
-            if (k > 0)
-            {
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->evScale[k - 1], 0));
-            }
-        }
-        const float* img = cur;
-        int64_t img_fs = cur_fs;
-        if (rs.resampled)
-        {
-            if (rs.src_h != curH || rs.src_w != curW)
-            {
-                return fail(c, ACF_HIP_E_INVALID, "pyramid: internal plan mismatch");
-            }
-            if (c->h_descs[rs.descIndex].src_frame_stride != cur_fs)
-            {
-                return fail(c, ACF_HIP_E_INVALID, "pyramid: internal frame-stride mismatch");
-            }
-            prof(c, "k_resample(image)");
-            const ResampleDesc& hd = c->h_descs[rs.descIndex];
-            const bool exactHalf = hd.xmode == RS_EXACT && hd.ymode == RS_EXACT && hd.xk == 2 && hd.yk == 2 && hd.ha % 4 == 0 && hd.hb % 2 == 0 &&
-                hd.src_frame_stride % 4 == 0 && hd.dst_frame_stride % 2 == 0 && hd.src_off % 4 == 0 && hd.dst_off % 2 == 0 &&
-                (uintptr_t(cur) & 15) == 0 && (uintptr_t(rs.img) & 7) == 0; // (k_resample_half's case: one thread per output pair)
-            if (halfDone[k] || pairDone[k])
-            {
-                // already produced by the previous scale's k_smooth_vec, or together with the previous scale's image (k_resample_strip)
-            }
-            else if (rs.strip.ok && !exactHalf && !resampleGenericOnly() && (uintptr_t(cur) & 15) == 0)
-            {
-                // (with the scales on their own streams the next scale's chain would need one more event: the pair is for the one-stream order)
-                const bool pair = rs.stripPair.ok && k + 1 < c->real.size() && srcIdx[k + 1] == srcIdx[k] && !c->taps && !scalePar;
-                if (pair)
-                {
-                    pairDone[k + 1] = 1;
-                }
-                launchStrip(c, pair ? rs.stripPair : rs.strip, c->d_descs, rs.descIndex, pair ? c->real[k + 1].descIndex : -1, hd.nplanes, cur, rs.img,
-                    pair ? c->real[k + 1].img : nullptr, c->d_it, c->d_ft, nF);
-            }
-            else if (exactHalf)
-            {
-                const int64_t items = int64_t(hd.hb / 2) * hd.wb * hd.nplanes;
-                hipLaunchKernelGGL(k_resample_half, dim3(cdiv(items, 256), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
-                    (const ResampleDesc*)(c->d_descs + rs.descIndex));
-            }
-            else if (resampleUpOk(hd) && !resampleGenericOnly() && (uintptr_t(rs.img) & 15) == 0)
-            {
-                // nOctUp > 0: the frame up-sampled (cfg 4)
-                const int nw = hd.nplanes * cdiv(hd.hb, 256) * cdiv(hd.wb, RSU_XC);
-                hipLaunchKernelGGL(k_resample_up, dim3(cdiv(nw, 4), 1, nF), dim3(256), 0, c->stream, cur, rs.img,
-                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft);
-            }
-            else
-            {
-                // small planes: fewer columns per wave, more waves
-                const int xt = int64_t(resampleBlocks(hd)) * nF < 4096 ? 2 : RS_XT;
-                hipLaunchKernelGGL(k_resample, dim3(resampleBlocks(hd, xt), 1, nF), dim3(64, 4), 0, c->stream, cur, rs.img,
-                    (const ResampleDesc*)(c->d_descs + rs.descIndex), (const int32_t*)c->d_it, (const float*)c->d_ft, xt);
-            }
-            LAUNCHCHK(c, "k_resample(image)");
-            img = rs.img;
-            img_fs = int64_t(d) * np;
-        }
-        // convTri(I, I, pColor.smooth, 1) in place (chnsCompute.cpp:239)
-        bool colorDone = false;
-        bool gradFused = false, gradBlocked = false; // M and O written by k_smooth_grad, in blocks
-        bool triXFused = false;                      // ... and U by k_smooth_grad_tri
-        const bool fuseSm = p.colorSmooth > 0 && p.colorEnabled && !c->taps && !c->noFusedSmooth && shrink == 4 && rs.h % 4 == 0 && rs.w % 4 == 0 && rs.w >= 16 &&
-            rs.h / 4 <= SV_MAXW * SV_OWN && img_fs % 4 == 0 && np % 4 == 0 && pl.raw_floats % 1 == 0 && (uintptr_t(img) & 15) == 0;
-        if (fuseSm)
-        {
-            // k_smooth_vec: smoothing + the level's colour channels (+ the next real scale's image when it is an exact half
-            // of this one) from registers; full-resolution smoothed planes are written only where something still reads them
-            const bool halfNext = k + 1 < c->real.size() && srcIdx[k + 1] == int(k) && c->real[k + 1].resampled &&
-                [&] { const ResampleDesc& nd = c->h_descs[c->real[k + 1].descIndex];
-                      return nd.xmode == RS_EXACT && nd.ymode == RS_EXACT && nd.xk == 2 && nd.yk == 2 && nd.ha == rs.h && nd.wa == rs.w; }();
-            bool needFullAll = false;
-            for (size_t m = k + 1; m < c->real.size(); m++)
-            {
-                if (srcIdx[m] == int(k) && !(m == k + 1 && halfNext))
-                {
-                    needFullAll = true;
-                }
-            }
-            SmoothVecArgs sa{};
-            sa.in = img;
-            sa.in_fs = img_fs;
-            sa.in_ps = np;
-            sa.sm = rs.sm;
-            sa.sm_fs = int64_t(d) * np;
-            sa.sm_ps = np;
-            sa.chns = c->d_chns + pl.raw_off[rs.level];
-            sa.chns_fs = pl.raw_floats;
-            sa.cells = int64_t(rs.h / 4) * (rs.w / 4);
-            sa.h = rs.h;
-            sa.w = rs.w;
-            sa.p = pColor;
-            sa.rq_y = shrinkGainY(shrink);
-            sa.dump = c->d_dump;
-            if (halfNext)
-            {
-                const RealScale& nx = c->real[k + 1];
-                const ResampleDesc& nd = c->h_descs[nx.descIndex];
-                sa.half = nx.img;
-                sa.half_ps = int64_t(nx.h) * nx.w;
-                sa.half_fs = int64_t(d) * sa.half_ps;
-                sa.rkHalf = nd.rk[0];
-                halfDone[k + 1] = true;
-            }
-            const int nq = rs.h / 4, nt = cdiv(nq, SV_OWN) * 64; // a wave owns SV_OWN row quads and shadows SV_K of each neighbour
-            const size_t ldsB = size_t(2) * SV_MAXW * 2 * SV_K * 4 * sizeof(float);
-            {
-                uint32_t fullMask = 0;
-                for (int z = 0; z < d; z++)
-                {
-                    if (needFullAll || ((p.gradMagEnabled || p.gradHistEnabled) && z == p.colorChn))
-                    {
-                        fullMask |= 1u << z;
-                    }
-                }
-                sa.plane0 = 0;
-                sa.nPlanes = d;
-                // column segments: as many as give a launch ~6 waves per SIMD (a plane is a chain of column steps with
-                // nt / 64 waves), each at least 4 warm-ups long; one segment = the plain recursion.  `planesOf`: planes in the launch
-                const int warm = std::max(16, c->smoothWarm);
-                auto segmentsFor = [&](int planesOf, int& segW_) {
-                    int n = c->smoothSegments;
-                    if (n == 0 && c->sharedDevice && nF >= 64)
-                    {
-                        n = 1; // (beside other contexts: the plain chain — no warm-up columns, nothing to verify or repair)
-                    }
-                    if (n == 0)
-                    {
-                        const int64_t waves = int64_t(std::max(planesOf, 1)) * nF * (nt / 64);
-                        n = int(std::min<int64_t>((6 * 1024 + waves - 1) / waves, rs.w / (4 * warm)));
-                    }
-                    n = std::max(1, std::min(n, std::min(c->segCap, rs.w / 16)));
-                    segW_ = cdiv(cdiv(rs.w, n), 16) * 16;
-                    return cdiv(rs.w, segW_);
-                };
-                int segW = 0;
-                int nSeg = segmentsFor(d, segW);
-                sa.segW = segW;
-                sa.warm = warm;
-                sa.nSeg = nSeg;
-                sa.segStride = nSeg;
-                sa.specState = c->d_specState;
-                sa.trueState = c->d_trueState;
-                sa.redo = nullptr;
-                sa.skipZ = -1;
-                // the gradient plane's chain also emits gradMag (k_smooth_grad): its smoothed plane is then written only
-                // where a later scale is resampled from it, and k_grad_mag_vec does not run for this scale
-                const bool gradVecOk = rs.h % 4 == 0 && np % 4 == 0;
-                // Where it pays (measured at 1080p, 3 x 96 frames: +4 % frames/s with scale 0 fused, +2 % with every scale; one
-                // frame alone 1.21 -> 1.61 / 2.40 ms): the gradient work rides on a chain of column steps, so it needs many
-                // chains (frames x segments) and a plane big enough for the saved round trip to matter.  A/B: the variables.
-                static const int64_t gradMinPx = getenv("ACF_HIP_FUSED_GRAD_MINPX") ? atoll(getenv("ACF_HIP_FUSED_GRAD_MINPX")) : (int64_t(1) << 20);
-                static const int gradMinF = getenv("ACF_HIP_FUSED_GRAD_MINF") ? atoi(getenv("ACF_HIP_FUSED_GRAD_MINF")) : 16;
-                const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk && !c->arith && // (arith: gradMag is k_grad_mag_strip's)
-                    (c->fusedGrad >= 2 || (c->fusedGrad == 1 && np >= gradMinPx && nF >= gradMinF));
-                if (wantGrad)
-                {
-                    const bool wantTri0 = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
-                    // (the layout of M and O: the decision the y pass takes below, from the same inputs)
-                    ChnsArgs a0{};
-                    a0.M = rs.M;
-                    a0.O = rs.O;
-                    a0.Mn = nullptr; // (no taps on this path)
-                    a0.doNorm = p.normRad != 0;
-                    a0.colorDone = 1;
-                    a0.colorEnabled = p.colorEnabled;
-                    a0.magEnabled = p.gradMagEnabled;
-                    a0.histEnabled = p.gradHistEnabled;
-                    a0.nOrients = p.nOrients;
-                    const bool blocked0 = wantTri0 && triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, &a0, rs.uFloats, rs.moFloats, true).blocked;
-                    gradBlocked = blocked0;
-                    sa.skipZ = p.colorChn;
-                    sa.gM = rs.M;
-                    sa.gO = rs.O;
-                    sa.acos = c->d_acos;
-                    sa.mo_fs = blocked0 ? moBlockedFloats(rs.h, rs.w) : np;
-                    sa.nybM = blocked0 ? (rs.h + 15) / 16 : 0;
-                    sa.full = p.full;
-                    gradFused = true;
-                    if (!needFullAll)
-                    {
-                        fullMask &= ~(1u << p.colorChn);
-                    }
-                    // convTri's x pass on the same chain: running sums have no warm-up, so the gradient plane is then one segment
-                    // (96 workgroups for 96 frames: slower alone, faster beside other contexts' kernels — DESIGN.md 3.0)
-                    static const int triMinF = getenv("ACF_HIP_FUSED_TRI_MINF") ? atoi(getenv("ACF_HIP_FUSED_TRI_MINF")) : 64;
-                    if (blocked0 && p.normRad == 5 && rs.w >= 48 && nt <= 512 && (c->fusedTri >= 2 || (c->fusedTri == 1 && c->sharedDevice && nF >= triMinF)))
-                    {
-                        triXFused = true;
-                        sa.tU = rs.U;
-                        sa.u_fs = uBlockedFloats(rs.h, rs.w);
-                        sa.nybU = (rs.h + 8 + 15) / 16;
-                    }
-                }
-                // the two launches cut their planes on their own: the gradient plane's launch has a third of the chains (more
-                // segments), the other planes' launch two thirds; ACF_HIP_GRAD_SEGMENTS = n fixes the former's (A/B)
-                int nSegG = nSeg, segWG = segW;
-                if (wantGrad && d > 1)
-                {
-                    static const int gradSegEnv = getenv("ACF_HIP_GRAD_SEGMENTS") ? atoi(getenv("ACF_HIP_GRAD_SEGMENTS")) : 0;
-                    nSeg = segmentsFor(d - 1, segW);
-                    nSegG = segmentsFor(1, segWG);
-                    if (triXFused)
-                    {
-                        nSegG = 1;
-                        segWG = cdiv(rs.w, 16) * 16;
-                    }
-                    else if (gradSegEnv > 0)
-                    {
-                        nSegG = std::max(1, std::min(gradSegEnv, std::min(c->segCap, rs.w / 16)));
-                        segWG = cdiv(cdiv(rs.w, nSegG), 16) * 16;
-                        nSegG = cdiv(rs.w, segWG);
-                    }
-                    sa.segW = segW;
-                    sa.nSeg = nSeg;
-                    sa.segStride = std::max(nSeg, nSegG);
-                }
-                const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float);
-                if (wantGrad && d == 1 && triXFused)
-                {
-                    nSeg = nSegG = 1; // (one launch: the gradient plane's)
-                    segW = segWG = cdiv(rs.w, 16) * 16;
-                    sa.segW = segW;
-                    sa.nSeg = 1;
-                    sa.segStride = 1;
-                }
-                if (wantGrad)
-                {
-                    int rcl = 0;
-                    if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true>), ldsG)) ||
-                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false>), ldsG)) ||
-                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<true>), ldsG)) ||
-                        (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<false>), ldsG)))
-                    {
-                        return rcl;
-                    }
-                }
-                auto launchSv = [&](dim3 grid) {
-                    // (profile names: the gradient plane's launch by its form, the other planes' launch "k_smooth_vec")
-                    prof(c, !wantGrad ? "k_smooth_vec" : triXFused ? "k_smooth_grad_tri" : "k_smooth_grad");
-                    if (wantGrad)
-                    {
-                        // (first: its chains are the long ones)
-                        SmoothVecArgs sg = sa;
-                        sg.plane0 = p.colorChn;
-                        sg.skipZ = -1;
-                        if (sa.nSeg > 1 || nSegG > 1) // (not the repair launch: that one is one chain per plane)
-                        {
-                            if (!sa.redo)
-                            {
-                                sg.segW = segWG;
-                                sg.nSeg = nSegG;
-                                grid.y = unsigned(nSegG);
-                            }
-                        }
-                        if (sa.redo && nSegG == 1)
-                        {
-                            // (nothing to repair: the plane was one chain)
-                        }
-                        else if (triXFused)
-                        {
-                            if (halfNext)
-                            {
-                                hipLaunchKernelGGL((k_smooth_grad_tri<true>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
-                            }
-                            else
-                            {
-                                hipLaunchKernelGGL((k_smooth_grad_tri<false>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
-                            }
-                        }
-                        else if (halfNext)
-                        {
-                            hipLaunchKernelGGL((k_smooth_grad<true>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
-                        }
-                        else
-                        {
-                            hipLaunchKernelGGL((k_smooth_grad<false>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
-                        }
-                        grid.x -= 1;
-                        grid.y = unsigned(sa.nSeg);
-                        if (grid.x == 0)
-                        {
-                            return;
-                        }
-                        prof(c, "k_smooth_vec");
-                    }
-                    if (halfNext)
-                    {
-                        hipLaunchKernelGGL((k_smooth_vec<true>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((k_smooth_vec<false>), grid, dim3(nt), ldsB, c->stream, sa, fullMask);
-                    }
-                };
-                const int nSegMax = std::max(nSeg, wantGrad ? nSegG : nSeg);
-                // (the repair flags are zero here: set by k_smooth_verify, taken down by the repair launch that reads them)
-                launchSv(dim3(d, nSeg, nF));
-                LAUNCHCHK(c, "k_smooth_vec");
-                if (nSegMax > 1)
-                {
-                    // the segments' hand-overs, bit for bit; planes with a difference are recomputed as one chain
-                    hipLaunchKernelGGL(k_smooth_verify, dim3(nSegMax - 1, d, nF), dim3(256), 0, c->stream, (const float*)c->d_specState, (const float*)c->d_trueState,
-                        rs.h, sa.segStride, d, c->d_redo, c->smoothForceRedo, nSeg, wantGrad ? p.colorChn : -1, nSegG);
-                    LAUNCHCHK(c, "k_smooth_verify");
-                    if (c->countRepairs)
-                    {
-                        std::vector<int32_t> fl(size_t(nF) * d);
-                        HIPCHK(c, hipMemcpyAsync(fl.data(), c->d_redo, fl.size() * 4, hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(c, hipStreamSynchronize(c->stream));
-                        c->repairs[0] += int64_t(fl.size());
-                        for (int32_t v : fl)
-                        {
-                            c->repairs[1] += v != 0;
-                        }
-                    }
-                    sa.segW = rs.w;
-                    sa.warm = 0;
-                    sa.nSeg = 1;
-                    sa.redo = c->d_redo;
-                    launchSv(dim3(d, 1, nF));
-                    LAUNCHCHK(c, "k_smooth_vec(repair)");
-                }
-            }
-            colorDone = true;
-        }
-        else if (p.colorSmooth > 0)
-        {
-            if ((rc = launchSmooth(c, img, rs.sm, c->d_realJobs + k, 1, d, rs.h, img_fs, int64_t(d) * np, nF, pColor, true)))
-            {
-                return rc;
-            }
-        }
-        else
-        {
-            hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(np * d, 256), 1, nF), dim3(256), 0, c->stream, img, rs.sm,
-                (const SmoothJob*)(c->d_realJobs + k), img_fs, int64_t(d) * np);
-            LAUNCHCHK(c, "k_copy_planes");
-        }
-        if (scalePar)
-        {
-            HIPCHK(c, hipEventRecord(c->evScale[k], c->stream));
-        }
-        if (rs.adoptAsI)
-        {
-            cur = rs.sm;
-            cur_fs = int64_t(d) * np;
-            curH = rs.h;
-            curW = rs.w;
-        }
-        ChnsArgs a{};
-        a.sm = rs.sm;
-        a.M = rs.M;
-        a.S = rs.S;
-        a.O = rs.O;
-        a.Mn = c->taps ? rs.Mn : nullptr;
-        a.chns = c->d_chns + pl.raw_off[rs.level];
-        a.sm_fs = int64_t(d) * np;
-        a.m_fs = np;
-        a.chns_fs = pl.raw_floats;
-        a.h = rs.h;
-        a.w = rs.w;
-        a.d = d;
-        a.colorEnabled = p.colorEnabled;
-        a.colorDone = colorDone ? 1 : 0;
-        a.magEnabled = p.gradMagEnabled;
-        a.histEnabled = p.gradHistEnabled;
-        a.nOrients = p.nOrients;
-        a.doNorm = p.normRad != 0;
-        a.full = p.full;
-        a.hardBin = p.softBin < 0;
-        a.normConst = float(p.normConst);
-        a.rq_y = shrinkGainY(shrink);
-        // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
-        const bool gradVec = rs.h % 4 == 0 && np % 4 == 0 && !c->arith; // (option "arith": the plain forms hold the table arithmetic)
-        const bool fuseCells = shrink == 4 && !c->taps && !c->arith;     // k_triy_chns; else S is written and k_chns normalises
-        a.x86 = x86T(c);
-        const bool wantTri = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
-        const bool blockedMO = wantTri &&
-            triPlan(rs.M, rs.U, rs.h, rs.w, p.normRad, np, fuseCells ? &a : nullptr, rs.uFloats, rs.moFloats, gradVec).blocked;
-        if (gradFused)
-        {
-            // (M and O are there already)
-            if (gradBlocked != blockedMO)
-            {
-                return fail(c, ACF_HIP_E_INVALID, "k_smooth_grad: M / O layout differs from the y pass's");
-            }
-        }
-        else if (p.gradMagEnabled || p.gradHistEnabled)
-        {
-            prof(c, "k_grad_mag");
-            if (gradVec)
-            {
-                // 16 bytes per lane, persistent grid (one 16-wave workgroup per CU around the 80 KB LDS table), grid-stride over (frame, strip, row quad)
-                const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
-                static const int gmvMax = getenv("ACF_HIP_GMV_BLOCKS") ? atoi(getenv("ACF_HIP_GMV_BLOCKS")) : 256;
-                const int blocks = int(std::min<int64_t>(gmvMax, (items + GMV_BLOCK - 1) / GMV_BLOCK));
-                if (blockedMO)
-                {
-                    hipLaunchKernelGGL((k_grad_mag_vec<true>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
-                        rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, moBlockedFloats(rs.h, rs.w), nF, (rs.h + 15) / 16);
-                }
-                else
-                {
-                    hipLaunchKernelGGL((k_grad_mag_vec<false>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
-                        rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF, 0);
-                }
-            }
-            else
-            {
-                // enough workgroups to fill the chip twice over, each long enough to amortise its 80 KB table copy
-                const int rowBlocks = cdiv(rs.h, GM_ROWS), nStrips = cdiv(rs.w, GM_XT);
-                const int want = std::max(1, cdiv(1024, rowBlocks * nF));
-                const int spb = std::max(8, cdiv(nStrips, want));
-                hipLaunchKernelGGL(k_grad_mag_strip, dim3(rowBlocks, cdiv(nStrips, spb), nF), dim3(GM_ROWS), 0, c->stream,
-                    (const float*)(rs.sm + int64_t(p.colorChn) * np), rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, spb, x86T(c));
-            }
-            LAUNCHCHK(c, "k_grad_mag");
-        }
-        bool cellsDone = false;
-        if ((p.gradMagEnabled || p.gradHistEnabled) && p.normRad)
-        {
-            // convTri(M, normRad): x running sums, then the y pass — fused with the channel cells when the level allows it
-            // (S then never reaches HBM), else S is written for k_chns
-            if ((rc = launchTri(c, rs.M, rs.U, rs.S, rs.h, rs.w, p.normRad, np, nF, fuseCells ? &a : nullptr, &cellsDone, rs.uFloats, rs.moFloats,
-                     blockedMO, triXFused)))
-            {
-                return rc;
-            }
-        }
-        if (cellsDone)
-        {
-            continue;
-        }
-        if ((rc = launchChns(c, a, shrink, nF)))
-        {
-            return rc;
-        }
-    }
-
-    if (scalePar)
-    {
-        prof(c, "(end)");
-        c->stream = mainStream;
-        for (size_t k = 1; k < c->real.size(); k++)
-        {
-            HIPCHK(c, hipEventRecord(c->evJoin[k - 1], c->side[k - 1]));
-            HIPCHK(c, hipStreamWaitEvent(mainStream, c->evJoin[k - 1], 0));
-        }
-    }
-
-    // ---- approximated levels, smoothing and padding of frames [f0, f0 + nLF) of the batch
-    bool wroteRank = false, wroteF32 = true;
-    auto launchLevels = [&](int f0, int nLF) -> int {
-        float* const chnsF = c->d_chns + int64_t(f0) * pl.raw_floats;
-        float* const pyrF = c->d_pyr + int64_t(f0) * pl.pyr_floats;
-        const int nL = int(pl.levels.size());
-        const bool waveSmooth = p.smooth > 0 && c->finalMaxH <= 64 * LEVEL_MAX_R_REAL && c->levelMode != 0;
-        const bool fused = waveSmooth && c->fusedOk && c->levelMode == 1;
-        if (!fused && c->nApproxDescs > 0)
-        {
-            // ---- approximated levels: one launch, blockIdx.y = level (chnsPyramid.cpp:385-397)
-            prof(c, "k_resample(approx)");
-            hipLaunchKernelGGL(k_resample, dim3(c->approxMaxBlocks, c->nApproxDescs, nLF), dim3(64, 4), 0, c->stream,
-                (const float*)chnsF, chnsF, (const ResampleDesc*)(c->d_descs + c->nImgDescs), (const int32_t*)c->d_it, (const float*)c->d_ft, RS_XT);
-            LAUNCHCHK(c, "k_resample(approx)");
-        }
-        if (waveSmooth)
-        {
-            // ---- (approximated-scale resample +) smoothing + placement in the padded pyramid: one wave per plane (k_level)
-            const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
-            float* rawOut = (fused && c->taps) ? chnsF : nullptr;
-            const LevelJob* ljobs = fused ? c->d_levelJobs : c->d_levelJobsRaw;
-            const auto& groups = fused ? c->levelGroups : c->levelGroupsRaw;
-            const ResampleDesc* dd = c->d_descs + c->nImgDescs;
-            const int lvChain = (c->cascTurns & 4) ? 0 : 1;
-            const bool lvTurns = (c->cascTurns & 6) && fused && c->nAllJobs > 0;
-            if (lvTurns && (rc = turnBegin(c, 1, lvChain)))
-            {
-                return rc;
-            }
-            prof(c, fused ? "k_level(fused)" : "k_level(smooth)");
-            // fork: every group is an independent launch (disjoint outputs); biggest planes first
-            if (!groups.empty())
-            {
-                ensureSide(c);
-            }
-            const size_t nSide = groups.empty() ? 0 : c->side.size();
-            if (nSide && c->evFork)
-            {
-                HIPCHK(c, hipEventRecord(c->evFork, c->stream));
-                for (size_t k = 0; k < nSide; k++)
-                {
-                    HIPCHK(c, hipStreamWaitEvent(c->side[k], c->evFork, 0));
-                }
-            }
-            const int nAll = fused ? c->nAllJobs : c->nAllJobsRaw;
-            // what the levels leave as: floats (always, unless the caller has declared the float pyramid unneeded), and the
-            // cascade's 16-bit rank cells when every level goes through this one launch
-            // (the rank cells have one reader, the tile kernel: a plan or option that routes the cascade elsewhere keeps floats)
-            const bool emitRank = fused && c->levelsEmitRank && c->cs.useRank && !c->noRank && !c->taps && (c->cs.useTiles || c->cs.useRankD) && !c->noTiles;
-            // (depths other than 2 keep the floats: their queue's overflow path reads them)
-            const bool emitF32 = !(emitRank && !c->keepPyramid && !c->autoLambdas) || c->cs.useRankD;
-            wroteRank = emitRank;
-            wroteF32 = emitF32;
-            if (nAll > 0)
-            {
-                LevelRankArgs ra{};
-                size_t ldsL = size_t(LEVEL_WAVES) * (emitRank ? LEVEL_ALL_WF_RANK : LEVEL_ALL_WF) * sizeof(float);
-                if (emitRank)
-                {
-                    ra.out = c->cs.d_pyrR + int64_t(f0) * c->cs.pyrRCells;
-                    ra.fs = c->cs.pyrRCells;
-                    ra.chan = c->cs.d_rankChan;
-                    ra.rec = c->cs.d_rankRec;
-                    ldsL += size_t(c->cs.rankMaxRec) * sizeof(RankRec);
-                }
-                // column segments for small batches (a level's chain of up to wC column steps is then the launch's duration):
-                // as many as give the launch ~4 waves per SIMD, at most levelSegCap; every hand-over verified on the device
-                int nSegL = 1;
-                const int warmL = std::max(4, c->levelWarm / 4 * 4);
-                if (fused && !c->taps && nLF <= c->levelSegFrames && c->levelSegments != 1 && !c->autoLambdas)
-                {
-                    const int64_t wavesL = int64_t(nAll) * pl.nChns * nLF;
-                    nSegL = c->levelSegments > 1 ? c->levelSegments : int((4 * 1024 + wavesL - 1) / wavesL); // 0: ~4 waves per SIMD
-                    nSegL = std::max(1, std::min(nSegL, c->levelSegCap));
-                }
-                LevelSegArgs lsa{};
-                lsa.nSeg = nSegL;
-                lsa.warm = warmL;
-                lsa.hMax = c->levelHMax;
-                lsa.nJobs = nAll;
-                lsa.spec = c->d_lvSpec;
-                lsa.tru = c->d_lvTrue;
-                lsa.redo = nullptr;
-                dim3 lgrid(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll * nSegL), lblock(64 * LEVEL_WAVES);
-#define LVALL_LAUNCH(OUT)                                                                                                   \
-    if (nSegL > 1)                                                                                                          \
-    {                                                                                                                       \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT, 1>), ldsL)))                                  \
-            return rc;                                                                                                      \
-        hipLaunchKernelGGL((k_level_all<OUT, 1>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd, \
-            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa); \
-        hipLaunchKernelGGL(k_level_verify, dim3(nAll * nSegL, pl.nChns, nLF), dim3(64), 0, c->stream, (const float*)c->d_lvSpec,  \
-            (const float*)c->d_lvTrue, ljobs, lsa, pl.nChns, c->d_lvRedo, c->smoothForceRedo);                               \
-        if (c->countRepairs)                                                                                                \
-        {                                                                                                                   \
-            std::vector<int32_t> fl(size_t(nLF) * nAll * pl.nChns);                                                         \
-            HIPCHK(c, hipMemcpyAsync(fl.data(), c->d_lvRedo, fl.size() * 4, hipMemcpyDeviceToHost, c->stream));             \
-            HIPCHK(c, hipStreamSynchronize(c->stream));                                                                     \
-            c->repairs[2] += int64_t(fl.size());                                                                            \
-            for (int32_t v : fl)                                                                                            \
-            {                                                                                                               \
-                c->repairs[3] += v != 0;                                                                                    \
-            }                                                                                                               \
-        }                                                                                                                   \
-        lsa.nSeg = 1;                                                                                                       \
-        lsa.redo = c->d_lvRedo;                                                                                             \
-        hipLaunchKernelGGL((k_level_all<OUT, 1>), dim3(pl.nChns, cdiv(nLF, LEVEL_WAVES), nAll), lblock, ldsL, c->stream,    \
-            (const float*)chnsF, pyrF, rawOut, ljobs, dd, (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns,         \
-            pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa);                                                     \
-    }                                                                                                                       \
-    else                                                                                                                    \
-    {                                                                                                                       \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_level_all<OUT, 0>), ldsL)))                                  \
-            return rc;                                                                                                      \
-        hipLaunchKernelGGL((k_level_all<OUT, 0>), lgrid, lblock, ldsL, c->stream, (const float*)chnsF, pyrF, rawOut, ljobs, dd, \
-            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF, ra, lsa); \
-    }
-                if (emitRank && emitF32)
-                {
-                    LVALL_LAUNCH(LO_F32 | LO_RANK);
-                }
-                else if (emitRank)
-                {
-                    LVALL_LAUNCH(LO_RANK);
-                }
-                else
-                {
-                    LVALL_LAUNCH(LO_F32);
-                }
-#undef LVALL_LAUNCH
-                LAUNCHCHK(c, "k_level_all");
-                if (lvTurns && (rc = turnEnd(c, 1, lvChain)))
-                {
-                    return rc;
-                }
-            }
-            size_t gi = 0;
-            for (auto git = groups.rbegin(); git != groups.rend(); ++git, ++gi)
-            {
-                const auto& g = *git;
-                hipStream_t lst = (nSide && c->evFork) ? c->side[gi % nSide] : c->stream;
-                dim3 grid(pl.nChns, g.count, cdiv(nLF, LEVEL_WAVES)), block(64 * LEVEL_WAVES);
-    #define LV_LAUNCH(RR, MM)                                                                                                         \
-        hipLaunchKernelGGL((k_level<RR, MM>), grid, block, 0, lst, (const float*)chnsF, pyrF, rawOut, ljobs + g.first, dd, \
-            (const int32_t*)c->d_it, (const float*)c->d_ft, pl.nChns, pl.raw_floats, pl.pyr_floats, pS, c->d_dump, nLF);
-    #define LV_MODES(RR)                                  \
-        switch (g.mode)                                   \
-        {                                                 \
-            case LM_REAL: LV_LAUNCH(RR, LM_REAL); break;  \
-            case LM_DD: LV_LAUNCH(RR, LM_DD); break;      \
-            default: LV_LAUNCH(RR, LM_UU); break;         \
-        }
-                switch (g.R)
-                {
-                    case 1: LV_MODES(1); break;
-                    case 2: LV_MODES(2); break;
-                    case 3: LV_MODES(3); break;
-                    case 4: LV_MODES(4); break;
-                    case 5: LV_MODES(5); break;
-                    case 6: LV_MODES(6); break;
-                    case 7: LV_MODES(7); break;
-                    case 8: LV_MODES(8); break;
-                    default:
-                        // nine rows per lane: the full-resolution level of a 4K frame (540 cells); a real level's copy + smoothing only
-                        if (g.R != LEVEL_MAX_R_REAL || g.mode != LM_REAL)
-                        {
-                            return fail(c, ACF_HIP_E_UNSUPPORTED, "pyramid: level taller than the level kernels' rows per lane");
-                        }
-                        LV_LAUNCH(9, LM_REAL);
-                        break;
-                }
-    #undef LV_MODES
-    #undef LV_LAUNCH
-                LAUNCHCHK(c, "k_level");
-            }
-            if (nSide && c->evFork)
-            {
-                for (size_t k = 0; k < std::min(nSide, groups.size()); k++)
-                {
-                    HIPCHK(c, hipEventRecord(c->evJoin[k], c->side[k]));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evJoin[k], 0));
-                }
-            }
-        }
-        // ---- smooth every plane of every level into the fused, padded pyramid (chnsPyramid.cpp:399-435)
-        if (waveSmooth)
-        {
-        }
-        else if (p.smooth > 0)
-        {
-            const float pS = float(12.0 / p.smooth / (p.smooth + 2.0) - 2.0);
-            if ((rc = launchSmooth(c, chnsF, pyrF, c->d_finalJobs, nL, pl.nChns, c->finalMaxH, pl.raw_floats, pl.pyr_floats, nLF, pS, true)))
-            {
-                return rc;
-            }
-        }
-        else
-        {
-            int64_t maxE = 0;
-            for (const auto& l : pl.levels)
-            {
-                maxE = std::max<int64_t>(maxE, int64_t(pl.nChns) * l.hC * l.wC);
-            }
-            hipLaunchKernelGGL(k_copy_planes, dim3(cdiv(maxE, 256), nL, nLF), dim3(256), 0, c->stream, (const float*)chnsF, pyrF,
-                (const SmoothJob*)c->d_finalJobs, pl.raw_floats, pl.pyr_floats);
-            LAUNCHCHK(c, "k_copy_planes(final)");
-        }
-        if (p.pad_h / shrink > 0 || p.pad_w / shrink > 0)
-        {
-            prof(c, "k_pad_reflect");
-            if (wroteF32)
-            {
-                hipLaunchKernelGGL(k_pad_reflect<float>, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream, pyrF, (const PadJob*)c->d_padJobs, pl.pyr_floats);
-            }
-            if (wroteRank)
-            {
-                hipLaunchKernelGGL(k_pad_reflect<uint16_t>, dim3(cdiv(c->padMaxElems, 256), nL, nLF), dim3(256), 0, c->stream,
-                    c->cs.d_pyrR + int64_t(f0) * c->cs.pyrRCells, (const PadJob*)c->d_padJobsR, c->cs.pyrRCells);
-            }
-            LAUNCHCHK(c, "k_pad_reflect");
-        }
-        return ACF_HIP_OK;
-    };
-    if (!c->autoLambdas)
-    {
-        for (int f = 0; f < nF; f++)
-        {
-            c->h_lambdas[size_t(f) * 3 + 0] = p.lambdas[0];
-            c->h_lambdas[size_t(f) * 3 + 1] = p.lambdas[1];
-            c->h_lambdas[size_t(f) * 3 + 2] = p.lambdas[2];
-        }
-        if ((rc = launchLevels(0, nF)))
-        {
-            return rc;
-        }
-    }
-    else
-    {
-        // Image-specific lambdas (chnsPyramid.cpp:341-374): per-type means of the raw channels at two real levels (f64 plane
-        // sums on the device, k_plane_sums), lambda = -log2(f0/f1) / log2(s0/s1) on the host with the C library the
-        // oracle uses, then the approximated levels frame by frame with that frame's gains written into the descriptors
-        // (stream-ordered copies).  A fallback path for models that ship without lambdas: correctness first — it
-        // synchronises once per batch and launches per frame.
-        prof(c, "k_plane_sums");
-        const int lv0 = pl.lambdaLevel[0], lv1 = pl.lambdaLevel[1];
-        SumJob j0{ pl.raw_off[size_t(lv0)], pl.levels[size_t(lv0)].hC * pl.levels[size_t(lv0)].wC, 0 };
-        SumJob j1{ pl.raw_off[size_t(lv1)], pl.levels[size_t(lv1)].hC * pl.levels[size_t(lv1)].wC, 0 };
-        hipLaunchKernelGGL(k_plane_sums, dim3(pl.nChns, 2, nF), dim3(256), 0, c->stream, (const float*)c->d_chns, pl.raw_floats, j0, j1, pl.nChns, c->d_planeSums);
-        LAUNCHCHK(c, "k_plane_sums");
-        std::vector<double> sums(size_t(nF) * 2 * pl.nChns);
-        HIPCHK(c, hipMemcpyAsync(sums.data(), c->d_planeSums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const int nColorL = p.colorEnabled ? d : 0, nMagL = p.gradMagEnabled ? 1 : 0, nHistL = p.gradHistEnabled ? p.nOrients : 0;
-        const int nTypeCh[3] = { nColorL, nMagL, nHistL };
-        // one copy of the approximated levels' descriptors per frame: each stays untouched until its stream-ordered upload is done
-        std::vector<std::vector<ResampleDesc>> descsAll(size_t(nF),
-            std::vector<ResampleDesc>(c->h_descs.begin() + c->nImgDescs, c->h_descs.begin() + c->nImgDescs + c->nApproxDescs));
-        for (int f = 0; f < nF; f++)
-        {
-            std::vector<ResampleDesc>& descs = descsAll[size_t(f)];
-            double lam[3] = { 0, 0, 0 };
-            int z0 = 0;
-            for (int j = 0; j < 3; j++)
-            {
-                if (!nTypeCh[j])
-                {
-                    continue;
-                }
-                double s0 = 0, s1 = 0; // sum(MatP): the per-plane sums added in plane order (MatP.cpp:97-106)
-                for (int k = 0; k < nTypeCh[j]; k++)
-                {
-                    s0 += sums[(size_t(f) * 2 + 0) * pl.nChns + z0 + k];
-                    s1 += sums[(size_t(f) * 2 + 1) * pl.nChns + z0 + k];
-                }
-                const double f0 = s0 / (double(nTypeCh[j]) * j0.cells), f1 = s1 / (double(nTypeCh[j]) * j1.cells);
-                lam[j] = -(std::log(f0 / f1) / std::log(2.0)) / (std::log(pl.levels[size_t(lv0)].scale / pl.levels[size_t(lv1)].scale) / std::log(2.0));
-                z0 += nTypeCh[j];
-            }
-            for (int j = 0; j < 3; j++)
-            {
-                c->h_lambdas[size_t(f) * 3 + j] = lam[j];
-            }
-            size_t ai = 0;
-            for (size_t i = 0; i < pl.levels.size(); i++)
-            {
-                const acf_hip_level& l = pl.levels[i];
-                if (l.isReal)
-                {
-                    continue;
-                }
-                const acf_hip_level& lr = pl.levels[size_t(l.realIndex)];
-                double ratio[3];
-                for (int j = 0; j < 3; j++)
-                {
-                    ratio[j] = std::pow(l.scale / lr.scale, -lam[j]); // :393
-                }
-                setResampleGain(descs[ai], ratio, nColorL, nColorL + nMagL);
-                ai++;
-            }
-            if (!descs.empty())
-            {
-                HIPCHK(c, hipMemcpyAsync(c->d_descs + c->nImgDescs, descs.data(), descs.size() * sizeof(ResampleDesc), hipMemcpyHostToDevice, c->stream));
-            }
-            if ((rc = launchLevels(f, 1)))
-            {
-                return rc;
-            }
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // descsAll is read by the uploads above
-    }
-    prof(c, "(end)");
-    c->lastBatch = nF;
-    c->pyramidValid = true;
-    c->ranksValid = wroteRank;   // else the cascade converts the float pyramid first (k_rank)
-    c->floatPyramid = wroteF32;
-    return ACF_HIP_OK;
-}
 } // namespace
+
+#include "pyramid_run.hip.h"
 
 int acf_hip_pyramid_u8(acf_hip_ctx* c, const uint8_t* frames, int nF, int pix, int rowStride)
 {
@@ -4594,10 +3162,9 @@ static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int
         const TileGeom& gt = at.g;
         const int64_t total = int64_t(at.nTiles) * nF;
         const int64_t perX = (total + 7) / 8;
-        static const size_t padKb = getenv("ACF_HIP_TILE_PAD_KB") ? size_t(atoi(getenv("ACF_HIP_TILE_PAD_KB"))) : 0; // A/B: fewer workgroups per CU
         const size_t nwin = size_t(gt.NW) * 64;
-        const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8 + padKb * 1024
-                                     : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8 + padKb * 1024;
+        const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8
+                                     : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8;
         // k_cascade_tile3: persistent workgroups (as many as the CUs hold at once) that draw their tiles from one counter per XCD
         // (tilePersist: 0 one workgroup per tile, 1 as many workgroups as the device's CUs hold at once, n > 1 that many, rounded up
         // to a multiple of 8 = the tile counters)

@@ -57,6 +57,13 @@ def kernel_bytes_per_frame(det, model):
     # resampled from (index 1 here); the colour channels (1/16) and, from scale 0, the half-resolution next image (1/4)
     b["k_smooth_vec"] = sum(4 * (d * n + n + d * n // 16) for n in np_real) + (4 * (d - 1) * np_real[1] if len(np_real) > 1 else 0) + \
         (4 * d * np_real[0] // 4 if len(np_real) > 1 else 0)
+    # scale 0's gradient plane as its own launch (profile names k_smooth_grad / k_smooth_grad_tri): the plane read; M, O (and U with
+    # convTri's x pass on the chain) written instead of the smoothed plane; its colour cells (1/16) and its quarter of the half-size
+    # image.  "k_smooth_vec" is then the other planes' launch of scale 0 plus every plane of the other scales.
+    n0 = np_real[0]
+    own = 4 * (n0 + n0 // 16 + (n0 // 4 if len(np_real) > 1 else 0))
+    b["k_smooth_grad"] = own + 4 * 2 * n0
+    b["k_smooth_grad_tri"] = own + 4 * 3 * n0
     b["k_grad_mag"] = sum(3 * n * 4 for n in np_real)
     b["k_tri_x"] = sum(2 * n * 4 for n in np_real)
     b["k_tri_y"] = sum(2 * n * 4 for n in np_real)
@@ -83,7 +90,7 @@ def kernel_bytes_per_frame(det, model):
     return b
 
 
-PMC_FILES = ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json")  # the newest committed pass that exists
+PMC_FILES = ("profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json")  # the newest committed pass that exists
 PMC_FILE = next((f for f in PMC_FILES if os.path.exists(os.path.join(ROOT, f))), PMC_FILES[-1])
 
 
@@ -572,6 +579,10 @@ def main():
         b_in = 3 * 4 * H * W
         b_pyr = 4 * det.pyr_floats
         b_frame = b_in + 2 * b_pyr
+        # the same sum with the pyramid at the 2 bytes per cell the detection-only call really writes and reads (16-bit threshold-rank
+        # cells, columns padded to 8 cells): what THIS data flow makes compulsory, beside SURVEY 8d's 4 bytes per cell
+        b_rank = 2 * sum(det.nChns * l.wP * ((l.hP + 7) // 8 * 8) for l in det.levels)
+        b_frame_rank = b_in + 2 * b_rank
         metric = "detector FPS @1080p, 8 scales/octave, FACE80 model" if args.config == 2 else \
             "detector FPS, BASELINE.json cfg %d (%dx%d)" % (args.config, W, H)
         out = {
@@ -620,6 +631,8 @@ def main():
             # to run); which kernel has the largest launch-to-finish time beside the other contexts flips between runs and is
             # reported next to it (region_dominant_kernel)
             region_dom = max(prof, key=lambda k: prof[k][0])
+            # (with the smoothing launches under their own names this is the cascade's tile kernel at cfg 2: the fat kernel whose
+            # time alone bounds a step, DESIGN.md "Speed of light")
             dom = max((k for k in solo if k in prof), key=lambda k: solo[k][0]) if solo else region_dom
             launches = max(prof[dom][1], 1)
             # a kernel may take several launches per batch (one per real scale): its figures are per BATCH of B frames — the
@@ -651,6 +664,7 @@ def main():
                 "kernel_bytes_per_launch": kb.get(dom, 0) * B,
                 "measured": "inside the timed region (%d contexts sharing the GPU); per batch of %d frames" % (C, B),
                 "path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
+                "path_rank_bytes_per_frame": b_frame_rank, "path_frac_rank_bytes": path * b_frame_rank / b_frame / HBM_PEAK_GBS,
                 # what the whole path really moves per frame (every kernel of a step, same committed PMC passes as `traffic`) and how
                 # that compares with SURVEY 8d's algorithmic bytes: > 1 = intermediates and re-reads, the first thing to cut
                 "traffic_path_bytes_per_frame": pmc_path_bytes_per_frame(B),
@@ -684,6 +698,7 @@ def main():
         else:
             path = b_frame * fps / world / 1e9
             roof.update({"path_bytes_per_frame": b_frame, "path_achieved": path, "path_frac": path / HBM_PEAK_GBS,
+                         "path_rank_bytes_per_frame": b_frame_rank, "path_frac_rank_bytes": path * b_frame_rank / b_frame / HBM_PEAK_GBS,
                          "note": "per-kernel events disabled: whole path on the wall clock only"})
         # what this box delivers to a plain stream: a device-to-device copy of 256 MiB (read + write), outside the timed region —
         # the practical ceiling beside the 8 TB/s of `peak` (profiles/ubench/copy_bw.py: ~4.8 TB/s)

@@ -14,7 +14,7 @@ WIDE = ("k_cascade_tile", "k_cascade_tail3", "k_grad_mag_vec", "k_tri_x5v", "k_t
         "k_triy_chns<6, true>", "k_triy_chns<12, true>")
 GROUP = [("k_cascade_tile", "k_cascade_tile"), ("k_cascade_tail", "k_cascade_tail3"), ("k_tail_scan", "k_tail_scan"), ("k_level", "k_level(fused)"),
          ("k_triy_chns", "k_triy_chns"), ("k_sort_map", "k_sort_map"), ("k_nms", "k_nms"), ("k_export", "k_export"),
-         ("k_chns", "k_chns"), ("k_smooth_vec", "k_smooth_vec"), ("k_smooth_grad", "k_smooth_vec"), ("k_smooth_tri1", "k_smooth_tri1(image)"), ("k_grad_mag", "k_grad_mag"), ("k_tri_x", "k_tri_x"),
+         ("k_chns", "k_chns"), ("k_smooth_vec", "k_smooth_vec"), ("k_smooth_grad_tri", "k_smooth_grad_tri"), ("k_smooth_grad", "k_smooth_grad"), ("k_smooth_tri1", "k_smooth_tri1(image)"), ("k_grad_mag", "k_grad_mag"), ("k_tri_x", "k_tri_x"),
          ("k_tri_y", "k_tri_y"), ("k_resample", "k_resample(image)")]
 
 

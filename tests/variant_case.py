@@ -1,4 +1,4 @@
-"""One process per environment setting (the A/B knobs of DESIGN.md 6c are read once per process): a VGA frame pair through
+"""One process per setting (the environment is read once per process; options come in VARIANT_OPTIONS): a VGA frame pair through
 the library against the oracle — every pyramid level's bits, hits, boxes and scores — for a depth-2 model with a tail
 (300 trees, low cascThr: windows reach the leaf-code stages), and an LDCF model when `ldcf` is given.  tests/test_gpu_variants.py
 runs this file under each setting; exit status 0 = identical."""
@@ -26,7 +26,12 @@ def main():
     model = synth.make_model(seed=11, **kw)
     frames = np.stack([synth.make_frame(900 + i, H, W, "luv") for i in range(nF)])
     plan = ob.Plan(model, H, W, 3)
-    det = HipDetector(model, H, W, 3, max_batch=nF, max_hits=1 << 17)
+    det = HipDetector()
+    for kv in filter(None, os.environ.get("VARIANT_OPTIONS", "").split(",")):   # options of the setting, before the plan
+        k, v = kv.split("=")
+        det.set_option(k, int(v))
+    det.set_model(model)
+    det.plan(H, W, 3, max_batch=nF, max_hits=1 << 17)
     det.run(torch.from_numpy(frames).cuda(), nF)
     total = 0
     for f in range(nF):
