@@ -21,13 +21,16 @@ for it in range(N):
               softBin=int(rng.choice([0, 0, 0, -2, 2])), stride=int(rng.choice([4, 4, 4, 4, 8, 2, 1])))  # (stride < shrink: one evaluation per distinct offset)
     if kw["nApprox"] < 0:
         kw["nApprox"] = kw["nPerOct"] - 1
+    kind = "rgb" if rng.rand() < 0.3 else "luv"   # RGB frames go through rgbConvert (k_rgb2luv) first
+    kw["isLuv"] = int(kind == "luv")
+    arith = int(rng.rand() < 0.25)                # the reference's rcpps / rsqrtps bits (option arith; oracle: acfo_set_approx(3))
     nF = int(rng.choice([1, 2, 3]))
     opts = dict(fused_grad=int(rng.choice([0, 1, 2, 2])), fused_tri=int(rng.choice([0, 1, 2, 2])), smooth_segments=int(rng.choice([0, 1, 3, 5])), smooth_warm=int(rng.choice([16, 32, 96])),
                 scale_streams=int(rng.rand() < 0.5), keep_pyramid=int(rng.rand() < 0.7), rank_cells=int(rng.rand() < 0.7), graph=int(rng.rand() < 0.3),
                 cascade_tiles=int(rng.rand() < 0.8), level_segments=int(rng.choice([0, 1, 4])), tile_persist=int(rng.choice([0, 1, 1, 8])))
     try:
         model = synth.make_model(seed=int(rng.randint(1, 99)), **kw)
-        frames = np.stack([synth.make_frame(int(rng.randint(1, 9999)), H, W, "luv") for _ in range(nF)])
+        frames = np.stack([synth.make_frame(int(rng.randint(1, 9999)), H, W, kind) for _ in range(nF)])
         if rng.rand() < 0.3:
             frames[0, :, : W // 3, H // 4: H // 2] = 0.0
         plan = ob.Plan(model, H, W, 3)
@@ -40,12 +43,20 @@ for it in range(N):
         continue
     for k, v in opts.items():
         det.set_option(k, v)
+    if arith:
+        det.set_x86_tables(*ob.x86_fixture())
+        det.set_option("arith", 1)
+        ob.set_x86_tables(*ob.x86_fixture())
     dev = torch.from_numpy(frames).cuda()
     ok = True
     for rep in range(2 if opts["graph"] else 1):
         det.run(dev, nF)
         for f in range(nF):
-            pyr, _, _ = ob.chns_pyramid(plan, frames[f])
+            ob.set_approx(3 if arith else 0)
+            try:
+                pyr, _, _ = ob.chns_pyramid(plan, frames[f])
+            finally:
+                ob.set_approx(0)
             try:
                 want, wh = ob.detect(plan, pyr)
             except RuntimeError:
@@ -62,5 +73,5 @@ for it in range(N):
     ran += 1
     if not ok:
         bad += 1
-        print("MISMATCH", H, W, nF, kw, opts)
+        print("MISMATCH", H, W, nF, kind, "arith", arith, kw, opts)
 print("cases", N, "ran", ran, "frames_checked", checked, "mismatches", bad)
