@@ -1496,1030 +1496,9 @@ int acf_hip_set_model(acf_hip_ctx* c, const acf_hip_params* p)
     return ACF_HIP_OK;
 }
 
-// The cascade code reads the cell size from c->p.shrink; the LDCF cascade works on cells of 2*shrink pixels.
-struct ShrinkScope
-{
-    acf_hip_ctx* c;
-    int saved;
-    ShrinkScope(acf_hip_ctx* ctx, int factor) : c(ctx), saved(ctx->p.shrink) { c->p.shrink = saved * factor; }
-    ~ShrinkScope() { c->p.shrink = saved; }
-};
+#include "cascade_plan.hip.h"  // ShrinkScope, TileSet, buildTileSet, buildCascadeTables
 
-// Build the cascade tables for a list of level geometries (hP, wP) into the
-// context.  Shared by acf_hip_plan and acf_hip_op_acf_detect1.
-// One set of tile tables of the LDS-tiled cascade: geometry, tile list, node records with tile-layout offsets.  `rank` ==
-// nullptr: float cells, thresholds as float bits; else 16-bit threshold-rank cells, thresholds as rank indices.
-struct TileSet
-{
-    bool ok = false;
-    TileGeom g{};
-    int nTiles = 0, aTB = 4;
-    CascTile* d_tiles = nullptr;
-    TreeNode* d_tileNodes = nullptr;
-    uint32_t* d_tileNodesS = nullptr;
-    // depths other than 2 (k_cascade_tileD): records of trees [0, t1D) in batches of tbD
-    uint32_t* d_nodesD = nullptr;
-    int tbD = 0, t1D = 0;
-    uint32_t* d_tileOffD = nullptr; // k_cascade_tile3D: tile offsets of every node, [tree][nTreeNodes]
-    uint32_t* d_thrsRankD = nullptr; // ... and, on rank cells, the thresholds' rank indices in the same layout
-};
-
-static int buildTileSet(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, const RankTables* rank, TileSet& out, bool allowPooledD = true)
-{
-    const acf_hip_params& p = c->p;
-    const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
-    const int cellBytes = rank ? 2 : 4, CPB = 16 / cellBytes; // cells per 16-byte fill chunk
-    int rc;
-    TileGeom g{};
-    g.step = p.stride / p.shrink;
-    g.TR = 32;
-    g.winFloats = nChns * mW * mH;
-    // Stage boundaries.  k_cascade_tile3 (pooled survivors, the default for depth 2): dense [0,16) on every window, dense
-    // [16,32) on the workgroup's pooled survivors, sparse [32,128) as leaf codes + one ordered chain.
-    // (depths 3, 4, and 1 on rank cells: k_cascade_tile3D, the same stages, for models of at least 32 trees.  Depth 1 on FLOAT cells keeps
-    // k_cascade_tileD + the staged queue: stumps reject slowly, half of a tile's windows are still alive at tree 32, and with the float
-    // tile's two workgroups per CU the queue's lanes = windows form beats items = windows x trees (26 against 37 us per 1080p frame; on
-    // rank cells the pooled kernel takes 19) — ACF_HIP_TILED_POOLED1 pools it there too; ACF_HIP_TILED_STAGED keeps the staged form everywhere)
-    const bool pooledD = allowPooledD && ((p.treeDepth == 1 && (rank || fallbackForced(FB_TILED_POOLED1))) || p.treeDepth == 3 || p.treeDepth == 4) && p.nTrees >= 32 &&
-        !fallbackForced(FB_TILED_STAGED);
-    const bool pooled = p.treeDepth == 2 || pooledD;
-    int bounds[5] = { 0, 32, 32, 64, 128 };
-    if (pooled)
-    {
-        bounds[1] = 16;
-        bounds[3] = 32;
-    }
-    if (const char* e = getenv("ACF_HIP_CASC_BOUNDS")) // tuning knob: "b1,b2,b3,b4"
-    {
-        int v1, v2, v3, v4;
-        if (sscanf(e, "%d,%d,%d,%d", &v1, &v2, &v3, &v4) == 4 && 0 < v1 && v1 <= v2 && v2 <= v3 && v3 <= v4)
-        {
-            bounds[1] = v1;
-            bounds[2] = v2;
-            bounds[3] = v3;
-            bounds[4] = v4;
-        }
-    }
-    if (pooled)
-    {
-        // the dense stages run whole batches of four trees (unless the model ends inside one); at most 128 sparse trees
-        bounds[1] = std::max(4, bounds[1] / 4 * 4);
-        bounds[2] = std::max(bounds[1], bounds[2] / 4 * 4);
-        bounds[3] = bounds[2];
-        bounds[4] = std::min(std::max(bounds[4], bounds[2]), bounds[2] + 128);
-    }
-    for (int i = 0; i < 5; i++)
-    {
-        g.b[i] = std::min(bounds[i], p.nTrees);
-    }
-    g.pooled = pooled ? 1 : 0;
-    if (pooled)
-    {
-        const int tsPad = (g.b[4] - g.b[2] + 15) / 16 * 16;
-        g.pitchC = (tsPad / 4) | 1; // dwords per window, odd: the chain's lanes (windows) read conflict-free
-        g.pitchC *= 4;
-    }
-    // waves per tile: the largest of 8/4/2/1 whose footprint + survivor lists leave room for several workgroups per CU
-    // (160 KiB LDS: three with rank cells, two with floats), else one
-    const int W = 1; // windows per lane in stage A
-    auto ldsBytes = [&](int nw, int passW) {
-        const int tc = nw * W * (64 / g.TR);
-        const int64_t rows = int64_t(g.TR - 1) * g.step + mH, cols = int64_t(tc - 1) * g.step + mW;
-        const int64_t rowsP = (rows + CPB - 1) / CPB * CPB;
-        // k_cascade_tileD (depths other than 2 on float cells): footprint + one survivor list segment per wave (+ its few static words)
-        if (!g.pooled)
-        {
-            return int64_t(nChns) * rowsP * cols * cellBytes + int64_t(nw) * 64 * 8 + 64;
-        }
-        // k_cascade_tile3: leaf table + footprint + list 1 (later the codes of 64 windows) + list 2
-        const int64_t nwin = int64_t(nw) * 64;
-        const int64_t leafBytes = pooledD ? int64_t(128) * 4 * (int64_t(1) << p.treeDepth) : int64_t(TILE3_LEAF_BYTES);
-        if (int64_t(nChns) * rowsP * cols > 65535)
-        {
-            return int64_t(1) << 40; // (its list entries hold a window's first cell in 16 bits)
-        }
-        return leafBytes + int64_t(nChns) * rowsP * cols * cellBytes + ((std::max<int64_t>(nwin * 8, passW * int64_t(g.pitchC)) + 15) / 16 * 16) + nwin * 8 + 64;
-    };
-    int nw = 0;
-    if (const char* e = getenv("ACF_HIP_TILE_TR")) // tuning knobs: rows of windows per tile, waves per tile
-    {
-        const int v = atoi(e);
-        g.TR = (v >= 8 && v <= 64) ? v : g.TR; // (a value that does not divide 64 leaves 64 % TR lanes of a wave idle in stage A)
-    }
-    const int wgPerCu = 3; // the footprint + lists must fit three times into a CU's LDS with rank cells
-    const char* nwEnv = getenv("ACF_HIP_TILE_NW");
-    const int nwForce = nwEnv ? atoi(nwEnv) : 0;
-    for (int64_t limit : { rank ? int64_t(160 * 1024 / wgPerCu / 1280 * 1280) : int64_t(80) * 1024, int64_t(80) * 1024, int64_t(159) * 1024 })
-    {
-        for (int cand : { nwForce == 16 && pooled ? 16 : 8, 8 / W, 4 / W, 2 / W, 1 })
-        {
-            // (k_cascade_tile3's sparse stage: one thread per tree of a window)
-            const int tlp = g.b[4] - g.b[2] <= 32 ? 32 : (g.b[4] - g.b[2] <= 64 ? 64 : 128);
-            for (int passW : { 64, 32 }) // (k_cascade_tile3: windows per pass of the sparse stage)
-            {
-                if (!nw && cand >= 1 && ldsBytes(cand, passW) <= limit && (!nwForce || cand == nwForce) && cand * 64 >= g.TR && (!g.pooled || cand * 64 >= tlp))
-                {
-                    nw = cand;
-                    g.passW = passW;
-                }
-            }
-        }
-    }
-    if (!nw)
-    {
-        return pooledD ? buildTileSet(c, lv, nChns, rank, out, false) : ACF_HIP_OK;
-    }
-    g.NW = nw;
-    g.W = W;
-    g.TC = nw * W * (64 / g.TR);
-    g.rowsT = (g.TR - 1) * g.step + mH;
-    g.colsT = (g.TC - 1) * g.step + mW;
-    g.rowsP = (g.rowsT + CPB - 1) / CPB * CPB;
-    g.tileFloats = nChns * g.rowsP * g.colsT; // cells
-    g.cpsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.rowsP / CPB) - 1) / uint32_t(g.rowsP / CPB));
-    g.colsMagic = uint32_t(((uint64_t(1) << 32) + uint32_t(g.colsT) - 1) / uint32_t(g.colsT));
-    std::vector<CascTile> tiles;
-    bool ok = true;
-    {
-        // the fill kernel divides chunk indices by mulhi with these magics: check every index it will see
-        const uint32_t cps = uint32_t(g.rowsP / CPB), nSeg = uint32_t(nChns * g.colsT);
-        for (uint32_t q = 0; q < nSeg * cps && ok; q++)
-        {
-            const uint32_t seg = uint32_t((uint64_t(q) * g.cpsMagic) >> 32); // a divisor of 1 has magic 2^32 = 0 in 32 bits: caught here
-            ok = seg == q / cps && uint32_t((uint64_t(seg) * g.colsMagic) >> 32) == seg / uint32_t(g.colsT);
-        }
-    }
-    for (size_t i = 0; i < lv.size() && ok; i++)
-    {
-        for (int c0 = 0; c0 < lv[i].nWinC; c0 += g.TC)
-        {
-            for (int r0 = 0; r0 < lv[i].nWinR; r0 += g.TR)
-            {
-                if (r0 > 32767 || c0 > 32767)
-                {
-                    ok = false;
-                    break;
-                }
-                CascTile t{};
-                t.level = int16_t(i);
-                t.r0 = int16_t(r0);
-                t.c0 = int16_t(c0);
-                tiles.push_back(t);
-            }
-        }
-    }
-    if (!ok)
-    {
-        return ACF_HIP_OK;
-    }
-    if (p.treeDepth != 2)
-    {
-        // k_cascade_tileD: stage 0 of the staged path, trees [0, 32) (the staged path's second boundary), on float tiles.
-        // Records per batch of TB trees: {off[TB][NN], thr[TB][NN], hs[TB][NL]}, nodes in heap order, leaves left to right.
-        const int D = p.treeDepth;
-        if ((rank && !g.pooled) || D < 1 || D > 4 || D == 2)
-        {
-            return ACF_HIP_OK; // (rank cells: k_cascade_tile3D only)
-        }
-        const int NN = (1 << D) - 1, NL = 1 << D, TB = D == 1 ? 4 : (D == 3 ? 2 : 1);
-        const int t1 = std::min(32, p.nTrees) / TB * TB;
-        if (t1 <= 0 || (t1 != p.nTrees && t1 != 32) || p.nTreeNodes < NN + NL)
-        {
-            return ACF_HIP_OK; // (a model shorter than 32 trees whose length is not a multiple of the batch: staged path)
-        }
-        std::vector<uint32_t> nd(size_t(t1 / TB) * TB * (2 * NN + NL), 0u);
-        for (int t = 0; t < t1; t++)
-        {
-            const size_t q = size_t(t) * p.nTreeNodes;
-            uint32_t* d = nd.data() + size_t(t / TB) * TB * (2 * NN + NL);
-            const int tq = t % TB;
-            for (int k = 0; k < NN; k++)
-            {
-                const uint32_t f = c->fids[q + k];
-                const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
-                d[tq * NN + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
-                if (rank)
-                {
-                    d[TB * NN + tq * NN + k] = rank->rankOfThreshold(int(z), c->thrs[q + k]);
-                }
-                else
-                {
-                    memcpy(&d[TB * NN + tq * NN + k], &c->thrs[q + k], 4);
-                }
-            }
-            for (int j = 0; j < NL; j++)
-            {
-                memcpy(&d[2 * TB * NN + tq * NL + j], &c->hs[q + NN + j], 4);
-            }
-        }
-        if (g.pooled)
-        {
-            if (t1 != 32 || p.nTreeNodes < NN + NL || g.tileFloats > 65535)
-            {
-                return buildTileSet(c, lv, nChns, rank, out, false); // (k_cascade_tileD + the staged queue)
-            }
-            std::vector<uint32_t> to(size_t(p.nTrees) * p.nTreeNodes, 0u), tr(rank ? size_t(p.nTrees) * p.nTreeNodes : 0, 0u);
-            for (int t = 0; t < p.nTrees; t++)
-            {
-                for (int k = 0; k < NN; k++)
-                {
-                    const uint32_t f = c->fids[size_t(t) * p.nTreeNodes + k];
-                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
-                    to[size_t(t) * p.nTreeNodes + k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
-                    if (rank)
-                    {
-                        tr[size_t(t) * p.nTreeNodes + k] = rank->rankOfThreshold(int(z), c->thrs[size_t(t) * p.nTreeNodes + k]);
-                    }
-                }
-            }
-            if ((rc = devUpload(c, &out.d_tileOffD, to)) || (rank && (rc = devUpload(c, &out.d_thrsRankD, tr))))
-            {
-                return rc;
-            }
-        }
-        out.g = g;
-        out.nTiles = int(tiles.size());
-        out.tbD = TB;
-        out.t1D = t1;
-        if ((rc = devUpload(c, &out.d_nodesD, nd)) || (rc = devUpload(c, &out.d_tiles, tiles)))
-        {
-            return rc;
-        }
-        out.ok = true;
-        return ACF_HIP_OK;
-    }
-    std::vector<TreeNode> tileNodes(size_t(std::max(p.nTrees, 1)));
-    for (int t = 0; t < p.nTrees; t++)
-    {
-        const size_t q = size_t(t) * p.nTreeNodes;
-        TreeNode a{};
-        for (int k = 0; k < 3; k++)
-        {
-            const uint32_t f = c->fids[q + k];
-            const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH; // computeChannelIndexColMajor, acfDetect1.cpp:390-406
-            a.off[k] = (z * uint32_t(g.colsT) + cc) * uint32_t(g.rowsP) + rr;
-            if (rank)
-            {
-                const uint32_t rk = rank->rankOfThreshold(int(z), c->thrs[q + k]);
-                memcpy(&a.thr[k], &rk, 4);
-            }
-            else
-            {
-                a.thr[k] = c->thrs[q + k];
-            }
-        }
-        for (int k = 0; k < 4; k++)
-        {
-            a.hs[k] = c->hs[q + 3 + k];
-        }
-        tileNodes[size_t(t)] = a;
-    }
-    // stage A of the tile kernels reads its trees four at a time through the scalar unit
-    // (batches of 4 measured 4 % faster than batches of 8 once the leaf add went under EXEC)
-    const int aTB = 4;
-    const int nTreesS = (g.pooled ? g.b[2] : g.b[1]) / aTB * aTB; // (k_cascade_tile3: both dense stages read batches)
-    std::vector<uint32_t> nodesS(size_t(std::max(nTreesS / aTB, 1)) * 10 * aTB, 0u);
-    for (int t = 0; t + aTB - 1 < nTreesS; t += aTB)
-    {
-        uint32_t* d = nodesS.data() + size_t(t / aTB) * 10 * aTB;
-        for (int q = 0; q < aTB; q++)
-        {
-            const TreeNode& nd = tileNodes[size_t(t + q)];
-            for (int k = 0; k < 3; k++)
-            {
-                d[3 * q + k] = nd.off[k];
-                memcpy(&d[3 * aTB + 3 * q + k], &nd.thr[k], 4);
-            }
-            for (int k = 0; k < 4; k++)
-            {
-                memcpy(&d[6 * aTB + 4 * q + k], &nd.hs[k], 4);
-            }
-        }
-    }
-    out.aTB = aTB;
-    out.g = g;
-    out.nTiles = int(tiles.size());
-    if ((rc = devUpload(c, &out.d_tileNodesS, nodesS)) || (rc = devUpload(c, &out.d_tiles, tiles)) || (rc = devUpload(c, &out.d_tileNodes, tileNodes)))
-    {
-        return rc;
-    }
-    out.ok = true;
-    return ACF_HIP_OK;
-}
-
-static int buildCascadeTables(acf_hip_ctx* c, const std::vector<acf_hip_level>& lv, int nChns, CascState& cs, bool wantRank = false)
-{
-    CascLevel** d_levels = &cs.d_cascLevels;
-    int32_t** d_blockLevel = &cs.d_blockLevel;
-    int* blocksPerFrame = &cs.blocksPerFrame;
-    uint32_t** d_cidAll = &cs.d_cidAll;
-    CascNode2** d_nodes2 = &cs.d_nodes2;
-    const acf_hip_params& p = c->p;
-    const int mH = p.modelDsPad_h / p.shrink, mW = p.modelDsPad_w / p.shrink;
-    const uint32_t nF = uint32_t(nChns) * mH * mW;
-    const size_t nNodes = size_t(p.nTrees) * p.nTreeNodes;
-    const bool packed = p.treeDepth == 2;
-    std::vector<CascLevel> cl(lv.size());
-    std::vector<int32_t> bl;
-    std::vector<uint32_t> cidAll;
-    std::vector<CascNode2> nodes2;
-    // which nodes carry a feature test
-    std::vector<uint8_t> internal(nNodes, 0);
-    for (int t = 0; t < p.nTrees; t++)
-    {
-        for (int k = 0; k < p.nTreeNodes; k++)
-        {
-            const size_t q = size_t(t) * p.nTreeNodes + k;
-            internal[q] = p.treeDepth > 0 ? (k < (1 << p.treeDepth) - 1) : (c->child[q] != 0);
-            if (internal[q] && c->fids[q] >= nF)
-            {
-                return fail(c, ACF_HIP_E_INVALID, "model: feature id out of range for modelDsPad/shrink/channels");
-            }
-            if (p.treeDepth == 0 && c->child[q] != 0)
-            {
-                // next node = child[k] - (ftr < thr) in 0-based terms child[k] - 1 or child[k] (acfDetect1.cpp:146-155): both must
-                // stay inside the tree AND lie after k — trees are stored parent-first, and a backward or self reference in
-                // an untrusted model file would make the walk `while (child[k])` spin forever on the GPU
-                if (c->child[q] >= uint32_t(p.nTreeNodes) || c->child[q] - 1 <= uint32_t(k))
-                {
-                    return fail(c, ACF_HIP_E_INVALID, "model: child index out of range or not after its parent");
-                }
-            }
-        }
-    }
-    int block = 0;
-    cs.dedupQ = (p.stride < p.shrink && p.shrink % p.stride == 0 && !fallbackForced(FB_NO_DEDUP)) ? p.shrink / p.stride : 1;
-    std::vector<int2> realWin(lv.size());
-    for (size_t i = 0; i < lv.size(); i++)
-    {
-        CascLevel& L = cl[i];
-        L.hP = lv[i].hP;
-        L.wP = lv[i].wP;
-        L.nWinR = lv[i].nWinR;
-        L.nWinC = lv[i].nWinC;
-        realWin[i] = make_int2(L.nWinR, L.nWinC);
-        if (cs.dedupQ > 1)
-        {
-            // distinct offsets r * stride / shrink of the windows r = 0 .. nWinR - 1
-            L.nWinR = L.nWinR > 0 ? (L.nWinR - 1) / cs.dedupQ + 1 : 0;
-            L.nWinC = L.nWinC > 0 ? (L.nWinC - 1) / cs.dedupQ + 1 : 0;
-        }
-        L.nWin = L.nWinR * L.nWinC;
-        L.off = lv[i].offset;
-        L.firstBlock = block;
-        const int nb = cdiv(L.nWin, 256);
-        for (int b = 0; b < nb; b++)
-        {
-            bl.push_back(int32_t(i));
-        }
-        block += nb;
-        const int64_t area = int64_t(L.hP) * L.wP;
-        if (area * nChns >= (int64_t(1) << 31) || L.nWin >= (1 << 24))
-        {
-            return fail(c, ACF_HIP_E_UNSUPPORTED, "level too large for 32-bit channel offsets / 24-bit window ids");
-        }
-        if (packed)
-        {
-            L.nodeOff = 0;
-        }
-        else
-        {
-            L.nodeOff = int64_t(cidAll.size());
-            for (size_t q = 0; q < nNodes; q++)
-            {
-                uint32_t v = 0;
-                if (internal[q])
-                {
-                    const uint32_t f = c->fids[q];
-                    const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
-                    v = uint32_t(z * area + int64_t(cc) * L.hP + rr);
-                }
-                cidAll.push_back(v);
-            }
-        }
-    }
-    if (packed)
-    {
-        // one level-independent table: feature ids kept as (z, c, r) of
-        // computeChannelIndexColMajor (acfDetect1.cpp:390-406); the kernel rebuilds
-        // z*area + c*hP + r from the lane's level geometry
-        if (mW > 4095 || mH > 4095 || nChns > 255 || lv.size() > 255)
-        {
-            return fail(c, ACF_HIP_E_UNSUPPORTED, "model window / channel count too large for the packed node table");
-        }
-        for (int t = 0; t < p.nTrees; t++)
-        {
-            CascNode2 nd{};
-            const size_t q = size_t(t) * p.nTreeNodes;
-            for (int k = 0; k < 3; k++)
-            {
-                const uint32_t f = c->fids[q + k];
-                const uint32_t z = f / (mW * mH), cc = (f / mH) % mW, rr = f % mH;
-                nd.zcr[k] = (z << 24) | (cc << 12) | rr;
-                nd.thr[k] = c->thrs[q + k];
-            }
-            for (int k = 0; k < 4; k++)
-            {
-                nd.hs[k] = c->hs[q + 3 + k];
-            }
-            nodes2.push_back(nd);
-        }
-    }
-    *blocksPerFrame = block;
-    int rc;
-    if (cs.dedupQ > 1 && (rc = devUpload(c, &cs.d_realWin, realWin)))
-    {
-        return rc;
-    }
-    if ((rc = devUpload(c, d_levels, cl)))
-    {
-        return rc;
-    }
-    if ((rc = devUpload(c, d_blockLevel, bl)))
-    {
-        return rc;
-    }
-    if ((rc = devUpload(c, d_cidAll, cidAll)))
-    {
-        return rc;
-    }
-    if ((rc = devUpload(c, d_nodes2, nodes2)))
-    {
-        return rc;
-    }
-    // ---- LDS-tiled path (kernels.hip.h, k_cascade_tile3 + stage E + k_tail_scan, k_cascade_tail3 for queue overflow)
-    cs.useTiles = false;
-    cs.useRank = false;
-    cs.useTileD = false;
-    cs.useRankD = false;
-    cs.codeCapD = 0;
-    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.nTrees > 128 && !fallbackForced(FB_NO_TAIL_CODES))
-    {
-        // the staged path's last stage [128, nTrees) as leaf codes + ordered scan: the first codeCapD queue entries of a frame
-        // (sized like the depth-2 path's), when the scan's leaf table fits a workgroup's LDS
-        const int nT = p.nTrees - 128, NL = 1 << p.treeDepth;
-        if (int64_t((nT + 15) / 16 * 16) * NL * 4 <= 150 * 1024)
-        {
-            cs.codePitchD = (nT + 63) / 64 * 64;
-            int64_t nWinTotal = 0;
-            for (const auto& l : lv)
-            {
-                nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
-            }
-            int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
-            cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitchD), 256));
-            cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
-            void* codes = nullptr;
-            if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cap) * size_t(cs.codePitchD)) == hipSuccess)
-            {
-                c->allocs.push_back(codes);
-                cs.d_codesD = static_cast<uint8_t*>(codes);
-                cs.codeCapD = int(cap);
-            }
-            else
-            {
-                (void)hipGetLastError();
-            }
-        }
-    }
-    // the rank pyramid of a plan: per level nChns planes [wP][pitchR], pitchR = hP rounded up to 8 cells (16 bytes); bucket tables on
-    // the device; the level table again with the rank layout
-    auto setupRankPyramid = [&](const RankTables& rt) -> int {
-        std::vector<RankJob> jobs(lv.size());
-        int64_t off = 0;
-        cs.rankMaxWP = 0;
-        for (size_t i = 0; i < lv.size(); i++)
-        {
-            const int pitch = rankPitch(lv[i].hP);
-            cl[i].offR = off;
-            cl[i].pitchR = pitch;
-            jobs[i].src_off = lv[i].offset;
-            jobs[i].dst_off = off;
-            jobs[i].hP = lv[i].hP;
-            jobs[i].wP = lv[i].wP;
-            jobs[i].pitchR = pitch;
-            off += int64_t(nChns) * pitch * lv[i].wP;
-            cs.rankMaxWP = std::max(cs.rankMaxWP, lv[i].wP);
-        }
-        cs.pyrRCells = off;
-        cs.rankMaxRec = rt.maxRec;
-        int rcl;
-        // + slack: a tile's 16-byte fill chunks run up to rowsP cells past the last column of the last plane
-        if ((rcl = devUpload(c, &cs.d_rankChan, rt.chan)) || (rcl = devUpload(c, &cs.d_rankRec, rt.rec)) || (rcl = devUpload(c, &cs.d_rankJobs, jobs)) ||
-            (rcl = devAlloc(c, &cs.d_pyrR, size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096)))
-        {
-            return rcl;
-        }
-        HIPCHK(c, hipMemset(cs.d_pyrR, 0, (size_t(std::max(c->maxBatch, 1)) * size_t(off) + 4096) * sizeof(uint16_t))); // pitch padding cells: defined
-        HIPCHK(c, hipMemcpy(*d_levels, cl.data(), cl.size() * sizeof(CascLevel), hipMemcpyHostToDevice));
-        return ACF_HIP_OK;
-    };
-    if (!packed && p.treeDepth >= 1 && p.treeDepth <= 4 && p.stride % p.shrink == 0 && p.stride >= p.shrink)
-    {
-        TileSet tsD;
-        if ((rc = buildTileSet(c, lv, nChns, nullptr, tsD)))
-        {
-            return rc;
-        }
-        if (tsD.ok && (tsD.g.NW == 8 || tsD.g.NW == 4))
-        {
-            cs.useTileD = true;
-            cs.d_tilesD = tsD.d_tiles;
-            cs.nTilesD = tsD.nTiles;
-            cs.tbD = tsD.tbD;
-            cs.t1D = tsD.t1D;
-            cs.geomD = tsD.g;
-            cs.d_nodesD = tsD.d_nodesD;
-            cs.d_tileOffD = tsD.d_tileOffD;
-            // ---- the pooled kernel on threshold-rank cells (the rank tables do not depend on the depth): half the fill, three
-            // workgroups per CU.  The float pyramid is still written for these depths (the queue's overflow path reads it).
-            if ((tsD.g.pooled || p.treeDepth == 1) && wantRank && !c->noRank && !fallbackForced(FB_TILED_STAGED))
-            {
-                const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
-                std::vector<int32_t> chnOfNode(nNodes, -1);
-                for (size_t q = 0; q < nNodes; q++)
-                {
-                    if (internal[q])
-                    {
-                        chnOfNode[q] = int32_t(c->fids[q] / uint32_t(mWc * mHc));
-                    }
-                }
-                RankTables rt;
-                buildRankTables(c->thrs.data(), chnOfNode.data(), nNodes, nChns, rt);
-                TileSet tsR;
-                if (rt.ok && (rc = buildTileSet(c, lv, nChns, &rt, tsR)))
-                {
-                    return rc;
-                }
-                if (rt.ok && tsR.ok && tsR.g.pooled && tsR.d_thrsRankD && (tsR.g.NW == 8 || tsR.g.NW == 4))
-                {
-                    if ((rc = setupRankPyramid(rt)))
-                    {
-                        return rc;
-                    }
-                    cs.geomDR = tsR.g;
-                    cs.d_tilesDR = tsR.d_tiles;
-                    cs.nTilesDR = tsR.nTiles;
-                    cs.d_nodesDR = tsR.d_nodesD;
-                    cs.d_tileOffDR = tsR.d_tileOffD;
-                    cs.d_thrsRankD = tsR.d_thrsRankD;
-                    cs.useRank = true;
-                    cs.useRankD = true;
-                }
-            }
-        }
-    }
-    if (packed && p.stride % p.shrink == 0 && p.stride >= p.shrink)
-    {
-        TileSet tsF;
-        if ((rc = buildTileSet(c, lv, nChns, nullptr, tsF)))
-        {
-            return rc;
-        }
-        const int mHc = p.modelDsPad_h / p.shrink, mWc = p.modelDsPad_w / p.shrink;
-        int tw = 0;
-        const int winFloats = nChns * mWc * mHc;
-        const int tailSlab = (std::max(winFloats, TAIL_G * TAIL_PITCH) + 3) / 4 * 4; // footprint, reused as phase 2's transposition tile (16-byte rows)
-        for (int64_t limit : { int64_t(80) * 1024, int64_t(159) * 1024 })
-        {
-            for (int cand : { 2, 1 })
-            {
-                if (!tw && int64_t(cand) * tailSlab * 4 <= limit)
-                {
-                    tw = cand;
-                }
-            }
-        }
-        if (tsF.ok && tw)
-        {
-            const TileGeom& g = tsF.g;
-            std::vector<TreeNode> tailNodes(static_cast<size_t>(p.nTrees));
-            for (int t = 0; t < p.nTrees; t++)
-            {
-                const size_t q = size_t(t) * p.nTreeNodes;
-                TreeNode b{};
-                for (int k = 0; k < 3; k++)
-                {
-                    b.off[k] = c->fids[q + k];
-                    b.thr[k] = c->thrs[q + k];
-                }
-                for (int k = 0; k < 4; k++)
-                {
-                    b.hs[k] = c->hs[q + 3 + k];
-                }
-                tailNodes[size_t(t)] = b;
-            }
-            cs.aTB = tsF.aTB;
-            cs.d_tileNodesS = tsF.d_tileNodesS;
-            cs.d_tileNodes = tsF.d_tileNodes;
-            cs.d_tiles = tsF.d_tiles;
-            cs.nTiles = tsF.nTiles;
-            cs.geom = g;
-            cs.tailWaves = tw;
-            cs.tailSlab = tailSlab;
-            cs.tailPad = (std::max(p.nTrees - g.b[4], 1) + 63) / 64 * 64;
-            cs.tailBlocks = std::max(512, c->maxBatch);
-            // k_cascade_tail3 only takes queue overflow now: its LDS stays small (footprint slabs only, node table from
-            // L2) so that its blocks — which leave at once in the normal case — never wait for a whole CU's LDS while
-            // other streams' kernels are resident (measured: up to 2.7 ms of queueing per launch with 156 KB blocks)
-            cs.tailNodesLds = 0;
-            if (g.b[4] < p.nTrees && (rc = devAlloc(c, &cs.d_tailScratch, size_t(cs.tailBlocks) * tw * TAIL_G * cs.tailPad)))
-            {
-                return rc;
-            }
-            cs.codeCap = 0;
-            if (g.b[4] < p.nTrees && !fallbackForced(FB_TAIL3)) // (forced: every tail window goes to k_cascade_tail3)
-            {
-                const int nT = p.nTrees - g.b[4];
-                cs.codePitch = (nT + 63) / 64 * 64; // stage E writes whole 64-tree batches
-                int64_t nWinTotal = 0;
-                for (const auto& l : lv)
-                {
-                    nWinTotal += int64_t(std::max(l.nWinR, 0)) * std::max(l.nWinC, 0);
-                }
-                // entries per frame with codes: 1/64 of the windows (the tail sees ~1/700 of them on natural
-                // images), at most 256 MB for the batch (the rows are touched per survivor: ~1k of them per 1080p
-                // frame); whatever is beyond goes to k_cascade_tail3, and so does everything if the buffer cannot be had
-                int64_t cap = std::min<int64_t>(std::max<int64_t>(nWinTotal / 64, 1024), 8192);
-                cap = std::min(cap, std::max<int64_t>((int64_t(1) << 28) / (int64_t(std::max(c->maxBatch, 1)) * cs.codePitch), 256));
-                cap = std::min<int64_t>(cap, std::max<int64_t>(nWinTotal, 1));
-                cs.codeCap = int(cap);
-                void* codes = nullptr;
-                if (hipMalloc(&codes, size_t(std::max(c->maxBatch, 1)) * size_t(cs.codeCap) * size_t(cs.codePitch)) == hipSuccess)
-                {
-                    c->allocs.push_back(codes);
-                    cs.d_tailCodes = static_cast<uint8_t*>(codes);
-                }
-                else
-                {
-                    (void)hipGetLastError();
-                    cs.codeCap = 0;
-                }
-            }
-            if ((rc = devUpload(c, &cs.d_tailNodes, tailNodes)))
-            {
-                return rc;
-            }
-            cs.useTiles = true;
-            // ---- the same tiles over threshold-rank cells (16 bits per cell): half the fill, half the LDS
-            if (wantRank && !c->noRank)
-            {
-                std::vector<int32_t> chnOfNode(nNodes, -1);
-                for (size_t q = 0; q < nNodes; q++)
-                {
-                    if (internal[q])
-                    {
-                        chnOfNode[q] = int32_t(c->fids[q] / uint32_t(mWc * mHc));
-                    }
-                }
-                RankTables rt;
-                buildRankTables(c->thrs.data(), chnOfNode.data(), nNodes, nChns, rt);
-                TileSet tsR;
-                if (rt.ok && (rc = buildTileSet(c, lv, nChns, &rt, tsR)))
-                {
-                    return rc;
-                }
-                if (rt.ok && tsR.ok)
-                {
-                    if ((rc = setupRankPyramid(rt)))
-                    {
-                        return rc;
-                    }
-                    std::vector<TreeNode> tailR(static_cast<size_t>(p.nTrees));
-                    for (int t = 0; t < p.nTrees; t++)
-                    {
-                        const size_t q = size_t(t) * p.nTreeNodes;
-                        TreeNode b{};
-                        for (int k = 0; k < 3; k++)
-                        {
-                            const uint32_t f = c->fids[q + k];
-                            const uint32_t z = f / uint32_t(mWc * mHc), cc = (f / uint32_t(mHc)) % uint32_t(mWc), rr = f % uint32_t(mHc);
-                            b.off[k] = (z << 24) | (cc << 12) | rr; // (mW, mH <= 4095 and nChns <= 255: checked for the packed node table above)
-                            const uint32_t rk = rt.rankOfThreshold(int(z), c->thrs[q + k]);
-                            memcpy(&b.thr[k], &rk, 4);
-                        }
-                        for (int k = 0; k < 4; k++)
-                        {
-                            b.hs[k] = c->hs[q + 3 + k];
-                        }
-                        tailR[size_t(t)] = b;
-                    }
-                    if ((rc = devUpload(c, &cs.d_tailNodesR, tailR)))
-                    {
-                        return rc;
-                    }
-                    cs.geomR = tsR.g;
-                    cs.d_tilesR = tsR.d_tiles;
-                    cs.nTilesR = tsR.nTiles;
-                    cs.d_tileNodesR = tsR.d_tileNodes;
-                    cs.d_tileNodesSR = tsR.d_tileNodesS;
-                    cs.useRank = true;
-                }
-            }
-        }
-    }
-    return ACF_HIP_OK;
-}
-
-// k_resample_strip's plan (kernels.hip.h): row tiles of `yt` output rows of A (yt / 2 of B), steps of RS_XO output columns of A
-// (RS_XO / 2 of B); per row tile / per step the union of the two outputs' source ranges, appended to the int arena.
-static StripPlan stripPlan(const ResampleDesc& da, const ResampleDesc* db, TableArena& arena)
-{
-    StripPlan sp;
-    auto down = [](const ResampleDesc& d) { return (d.xmode == RS_DOWN || d.xmode == RS_EXACT) && (d.ymode == RS_DOWN || d.ymode == RS_EXACT); };
-    if (!down(da) || (db && !down(*db)) || da.ha % 4 || da.ha < 8 || da.src_frame_stride % 4 || da.src_off % 4 ||
-        (db && (db->ha != da.ha || db->wa != da.wa || db->nplanes != da.nplanes || db->src_frame_stride != da.src_frame_stride || db->src_off != da.src_off)))
-    {
-        return sp;
-    }
-    const int32_t* it = arena.ints.data();
-    auto rowRange = [&](const ResampleDesc& d, int yb0, int yb1, int& lo, int& hi) {
-        if (d.ymode == RS_EXACT)
-        {
-            lo = d.yk * yb0;
-            hi = d.yk * (yb1 - 1) + d.yk - 1;
-        }
-        else
-        {
-            lo = it[d.y_src + it[d.y_start + yb0]];
-            hi = std::max(it[d.y_src + it[d.y_start + yb1 - 1]] + d.ybd0 - 1, it[d.y_src + it[d.y_start + yb1] - 1]);
-        }
-    };
-    auto colRange = [&](const ResampleDesc& d, int xb0, int xb1, int& lo, int& hi) {
-        lo = it[d.x_col + 8 * xb0];
-        hi = lo;
-        for (int x = xb0; x < xb1; x++)
-        {
-            lo = std::min(lo, it[d.x_col + 8 * x]);
-            hi = std::max(hi, it[d.x_col + 8 * x] + it[d.x_col + 8 * x + 1] - 1);
-        }
-    };
-    // the y pass's slow form (more than four taps) keeps a row's taps in registers: at most 8, each within 15 rows of the first
-    auto slowOk = [&](const ResampleDesc& d) {
-        if (!(d.ymode == RS_DOWN && d.ybd0 > 4))
-        {
-            return true;
-        }
-        for (int yb = 0; yb < d.hb; yb++)
-        {
-            const int q0 = it[d.y_start + yb], q1 = it[d.y_start + yb + 1];
-            if (q1 - q0 > 8)
-            {
-                return false;
-            }
-            for (int q = q0; q < q1; q++)
-            {
-                const int off = it[d.y_src + q] - it[d.y_src + q0];
-                if (off < 0 || off > 15)
-                {
-                    return false;
-                }
-            }
-        }
-        return true;
-    };
-    if (!slowOk(da) || (db && !slowOk(*db)))
-    {
-        return sp;
-    }
-    auto fourTaps = [&](const ResampleDesc& d) {
-        for (int x = 0; x < d.wb; x++)
-        {
-            if (it[d.x_col + 8 * x + 1] > 4)
-            {
-                return false;
-            }
-        }
-        return true;
-    };
-    if (!fourTaps(da) || (db && !fourTaps(*db)))
-    {
-        return sp; // (x ratios above 4: the generic kernels)
-    }
-    const int nSteps = cdiv(da.wb, RS_XO), nStepsB = db ? cdiv(db->wb, RS_XO / 2) : 0;
-    if (nStepsB > nSteps)
-    {
-        return sp;
-    }
-    std::vector<int32_t> tx;
-    int maxC = 0;
-    for (int st = 0; st < nSteps; st++)
-    {
-        int lo, hi;
-        colRange(da, st * RS_XO, std::min((st + 1) * RS_XO, da.wb), lo, hi);
-        if (st < nStepsB)
-        {
-            int lob, hib;
-            colRange(*db, st * (RS_XO / 2), std::min((st + 1) * (RS_XO / 2), db->wb), lob, hib);
-            lo = std::min(lo, lob);
-            hi = std::max(hi, hib);
-        }
-        tx.push_back(lo);
-        tx.push_back(hi - lo + 1);
-        maxC = std::max(maxC, hi - lo + 1);
-    }
-    for (int nty = 1; nty <= 64; nty++)
-    {
-        const int yt = (cdiv(da.hb, nty) + 1) / 2 * 2;
-        const int ntyA = cdiv(da.hb, yt), ntyB = db ? cdiv(db->hb, yt / 2) : 0;
-        if (ntyA != nty || ntyB > nty)
-        {
-            continue;
-        }
-        std::vector<int32_t> tyv;
-        int maxR = 0;
-        for (int t = 0; t < nty; t++)
-        {
-            int lo, hi;
-            rowRange(da, t * yt, std::min((t + 1) * yt, da.hb), lo, hi);
-            if (t < ntyB)
-            {
-                int lob, hib;
-                rowRange(*db, t * (yt / 2), std::min((t + 1) * (yt / 2), db->hb), lob, hib);
-                lo = std::min(lo, lob);
-                hi = std::max(hi, hib);
-            }
-            lo = lo / 4 * 4;
-            tyv.push_back(lo);
-            tyv.push_back(hi - lo + 1);
-            maxR = std::max(maxR, hi - lo + 1);
-        }
-        const int rowsP = (maxR + 3) / 4 * 4;
-        const int64_t items = int64_t(RS_XO) * std::min(yt, da.hb) + (db ? int64_t(RS_XO / 2) * (yt / 2) : 0);
-        const bool slowA = da.ymode == RS_DOWN && da.ybd0 > 4, slowB = db && db->ymode == RS_DOWN && db->ybd0 > 4;
-        const int slowRows = (slowA ? yt : 0) + (slowB ? yt / 2 : 0);
-        // a tile's requests: whole rounds of RS_NT chunks of 16 bytes (the kernel issues a fixed number per wave)
-        const int fillRounds = cdiv(int64_t(maxC) * (rowsP / 4), RS_NT);
-        const int tileFloats = fillRounds * RS_NT * 4;
-        const size_t lds = (size_t(2) * tileFloats + size_t(RS_XO + RS_XO / 2) * RS_CP) * sizeof(float) + size_t(2) * RS_REC * 4 +
-            size_t(std::max(slowRows, 1)) * 8 * sizeof(float);
-        if (rowsP > 64 * RS_KCH || fillRounds > 4 || items > int64_t(RS_ITEMS) * RS_NT || lds + size_t(8) * (nSteps + 2) > size_t(52) * 1024)
-        {
-            continue;
-        }
-        const uint32_t cps = uint32_t(rowsP / 4);
-        const uint32_t magic = uint32_t(((uint64_t(1) << 32) + cps - 1) / cps);
-        bool ok = cps > 1;
-        for (uint32_t q = 0; q < uint32_t(maxC) * cps && ok; q++)
-        {
-            ok = uint32_t((uint64_t(q) * magic) >> 32) == q / cps;
-        }
-        if (!ok)
-        {
-            continue;
-        }
-        sp.ok = true;
-        sp.yt = yt;
-        sp.nty = nty;
-        sp.ntyB = ntyB;
-        sp.nSteps = nSteps;
-        sp.nStepsB = nStepsB;
-        sp.rowsP = rowsP;
-        sp.maxCols = maxC;
-        sp.magic = magic;
-        sp.lds = lds;
-        sp.slowRows = slowRows;
-        sp.fillRounds = fillRounds;
-        sp.tileFloats = tileFloats;
-        sp.tileY = int(arena.ints.size());
-        arena.ints.insert(arena.ints.end(), tyv.begin(), tyv.end());
-        sp.tileX = int(arena.ints.size());
-        arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
-        return sp;
-    }
-    return sp;
-}
-
-// k_resample_strip for one output (descB < 0) or two outputs of one source
-static void launchStrip(acf_hip_ctx* c, const StripPlan& sp, const ResampleDesc* d_descs, int descA, int descB, int nplanes, const float* src, float* dstA,
-    float* dstB, const int32_t* d_it, const float* d_ft, int nF)
-{
-    const bool pair = descB >= 0;
-    StripArgs sa{};
-    sa.src = src;
-    sa.dstA = dstA;
-    sa.dstB = dstB;
-    sa.descs = d_descs;
-    sa.it = d_it;
-    sa.ft = d_ft;
-    sa.descA = descA;
-    sa.descB = descB;
-    sa.yt = sp.yt;
-    sa.nty = sp.nty;
-    sa.nSteps = sp.nSteps;
-    sa.tileY = sp.tileY;
-    sa.tileX = sp.tileX;
-    sa.rowsP = sp.rowsP;
-    sa.maxCols = sp.maxCols;
-    sa.ntyB = sp.ntyB;
-    sa.nStepsB = sp.nStepsB;
-    sa.cpsMagic = sp.magic;
-    sa.slowRows = sp.slowRows;
-    sa.fillRounds = sp.fillRounds;
-    sa.tileFloats = sp.tileFloats;
-    sa.dump = c->d_dump;
-    // column segments (a resample has no history along x: segments are free), each at least 8 steps long: the count that
-    // minimises (rounds of workgroups over what the device holds at once) x (steps per workgroup)
-    const size_t ldsS = sp.lds + size_t(8) * (sp.nSteps + 2);
-    const int64_t wgs = int64_t(nplanes) * sp.nty * nF;
-    const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, std::min<int64_t>(4, int64_t(c->ldsPerCu) / int64_t((ldsS + 1279) / 1280 * 1280)));
-    int64_t bestCost = -1;
-    sa.nSplit = 1;
-    for (int n = 1; n <= std::max(1, sp.nSteps / 8); n++)
-    {
-        const int64_t cost = ((wgs * n + resident - 1) / resident) * (cdiv(sp.nSteps, n) + 2);
-        if (bestCost < 0 || cost < bestCost)
-        {
-            bestCost = cost;
-            sa.nSplit = n;
-        }
-    }
-    const dim3 sgrid(nplanes * sp.nty * sa.nSplit, 1, nF);
-    const bool slow = sp.slowRows > 0;
-    if (pair && slow)
-    {
-        hipLaunchKernelGGL((k_resample_strip<true, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-    }
-    else if (pair)
-    {
-        hipLaunchKernelGGL((k_resample_strip<true, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-    }
-    else if (slow)
-    {
-        hipLaunchKernelGGL((k_resample_strip<false, true>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-    }
-    else
-    {
-        hipLaunchKernelGGL((k_resample_strip<false, false>), sgrid, dim3(RS_NT), ldsS, c->stream, sa);
-    }
-}
-
-// Tiling of a down-sampling descriptor for the passes on LDS tiles (k_ldcf_tile): output columns per tile (the largest of 32/16/8 whose
-// source tile + x-pass buffer fit 64 KB of LDS), the largest source tile, and the per-tile source ranges appended to the
-// int arena ({rowLo,rowHi} per row tile at tile_y, {colLo,colHi} per column tile at tile_x).  rows == 0: not eligible.
-// (yo: output rows per tile — RT_YO for the resample kernels, k_ldcf_tile chooses its own; forceXo may be any column count)
-static ResampleTiling resampleTilePlan(const ResampleDesc& dd, TableArena& arena, int forceXo = 0, int64_t ldsBudget = int64_t(64) * 1024, int yo = RT_YO,
-    int maxRows = 1 << 30, int maxCols = 1 << 30)
-{
-    ResampleTiling tl;
-    if (!((dd.xmode == RS_DOWN || dd.xmode == RS_EXACT) && (dd.ymode == RS_DOWN || dd.ymode == RS_EXACT)))
-    {
-        return tl;
-    }
-    std::vector<int32_t> ty;
-    int maxR = 0;
-    {
-        const int32_t* it = arena.ints.data();
-        for (int yb0 = 0; yb0 < dd.hb; yb0 += yo)
-        {
-            const int yb1 = std::min(yb0 + yo, dd.hb);
-            int lo, hi;
-            if (dd.ymode == RS_EXACT)
-            {
-                lo = dd.yk * yb0;
-                hi = dd.yk * (yb1 - 1) + dd.yk - 1;
-            }
-            else
-            {
-                lo = it[dd.y_src + it[dd.y_start + yb0]];
-                hi = std::max(it[dd.y_src + it[dd.y_start + yb1 - 1]] + dd.ybd0 - 1, it[dd.y_src + it[dd.y_start + yb1] - 1]);
-            }
-            ty.push_back(lo);
-            ty.push_back(hi);
-            maxR = std::max(maxR, hi - lo + 1);
-        }
-    }
-    for (int xo : { forceXo ? forceXo : 32, 16, 8 })
-    {
-        if (forceXo && xo != forceXo)
-        {
-            continue;
-        }
-        std::vector<int32_t> tx;
-        int maxC = 0;
-        const int32_t* it = arena.ints.data();
-        for (int xb0 = 0; xb0 < dd.wb; xb0 += xo)
-        {
-            const int xb1 = std::min(xb0 + xo, dd.wb);
-            const int lo = it[dd.x_col + 8 * xb0], hi = it[dd.x_col + 8 * (xb1 - 1)] + it[dd.x_col + 8 * (xb1 - 1) + 1] - 1;
-            tx.push_back(lo);
-            tx.push_back(hi);
-            maxC = std::max(maxC, hi - lo + 1);
-        }
-        if (maxR > 0 && maxC > 0 && (int64_t(maxC) + xo) * maxR * 4 <= ldsBudget && maxR <= maxRows && maxC <= maxCols)
-        {
-            tl.rows = maxR;
-            tl.cols = maxC;
-            tl.xo = xo;
-            tl.tile_y = int(arena.ints.size());
-            arena.ints.insert(arena.ints.end(), ty.begin(), ty.end());
-            tl.tile_x = int(arena.ints.size());
-            arena.ints.insert(arena.ints.end(), tx.begin(), tx.end());
-            return tl;
-        }
-    }
-    return tl;
-}
+#include "resample_plan.hip.h" // stripPlan, launchStrip, resampleTilePlan
 
 #include "plan_build.hip.h" // acf_hip_plan's stages (PlanBuild), after the helpers they call
 
@@ -3062,683 +2041,7 @@ int acf_hip_op_resize_u8(acf_hip_ctx* c, const uint8_t* src, int rows, int cols,
     return rc;
 }
 
-static int allowLds(acf_hip_ctx* c, const void* kernel, size_t bytes)
-{
-    if (bytes > 64 * 1024)
-    {
-        HIPCHK(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
-    }
-    return ACF_HIP_OK;
-}
-
-// the ONE statement of "the cascade runs on LDS tiles": runCascade's branch and acf_hip_run's early counter clear both ask it
-static inline bool tiledCascadeSelected(const acf_hip_ctx* c)
-{
-    return c->cs.useTiles && !c->noTiles;
-}
-
-static int runCascadeTiled(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, int nF, int nChns)
-{
-    const acf_hip_params& p = c->p;
-    const CascState& cs = c->cs;
-    const TileGeom& g = cs.geom;
-    if (!c->countersZeroed)
-    {
-        HIPCHK(c, hipMemsetAsync(cs.d_qcounts, 0, sizeof(int32_t) * (2 * size_t(c->maxBatch) + 8), c->stream));
-    }
-    TileArgs a{};
-    a.pyr = pyr;
-    a.pyr_fs = pyr_fs;
-    a.levels = cs.d_cascLevels;
-    a.tiles = cs.d_tiles;
-    a.nTiles = cs.nTiles;
-    a.nFrames = nF;
-    a.nChns = nChns;
-    a.mH = p.modelDsPad_h / p.shrink;
-    a.mW = p.modelDsPad_w / p.shrink;
-    a.nTrees = p.nTrees;
-    a.g = g;
-    a.tileNodes = cs.d_tileNodes;
-    a.tileNodesS = cs.d_tileNodesS;
-    a.aTB = cs.aTB;
-    a.tailNodes = cs.d_tailNodes;
-    a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
-    a.q = cs.d_queue[0];
-    a.qcount = cs.d_qcounts;
-    a.qhead = cs.d_qcounts + c->maxBatch;
-    a.tileNext = cs.d_qcounts + 2 * size_t(c->maxBatch);
-    a.qcap = cs.qcap;
-    a.hits = cs.d_hits;
-    a.counts = cs.d_counts;
-    a.maxHits = c->maxHits;
-    a.tailScratch = cs.d_tailScratch;
-    a.tailPad = cs.tailPad;
-    a.tailSlab = cs.tailSlab;
-    a.tailNodesLds = cs.tailNodesLds;
-    a.tailCodes = cs.d_tailCodes;
-    a.codeCap = cs.codeCap;
-    a.codePitch = cs.codePitch;
-    a.debug = 0;
-#ifdef ACF_HIP_STAMPS
-    static const int cascDebug = getenv("ACF_HIP_CASC_DEBUG") ? atoi(getenv("ACF_HIP_CASC_DEBUG")) : 0; // timing experiments (profiles/ab_*.sh)
-    a.debug = cascDebug;
-#endif
-    if (a.debug & 12)
-    {
-        a.debug |= 4;
-        const int64_t total = int64_t(std::max(cs.nTiles, cs.nTilesR)) * nF;
-        HIPCHK(c, hipMalloc(&a.stamps, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long)));
-        HIPCHK(c, hipMemsetAsync(a.stamps, 0, size_t((total + 7) / 8 * 8) * 8 * sizeof(long long), c->stream));
-    }
-    const bool rank = cs.useRank && !c->noRank && pyr == c->d_pyr;
-    if (rank && !c->ranksValid)
-    {
-        // the float pyramid -> threshold-rank cells (levels whose kernels did not emit them)
-        int rc = 0;
-        const size_t ldsR = size_t(cs.rankMaxRec) * sizeof(RankRec);
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_rank), ldsR)))
-        {
-            return rc;
-        }
-        prof(c, "k_rank");
-        hipLaunchKernelGGL(k_rank, dim3(cdiv(cs.rankMaxWP, RANK_CHUNK_COLS), int(c->plan.levels.size()) * nChns, nF), dim3(256), ldsR, c->stream, pyr, pyr_fs,
-            cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const RankRec*)cs.d_rankRec);
-        LAUNCHCHK(c, "k_rank");
-        c->ranksValid = true;
-    }
-    if (cs.nTiles > 0)
-    {
-        TileArgs at = a; // the tile kernel's view: the rank form has its own tile geometry, tile list and node records
-        if (rank)
-        {
-            at.pyrR = cs.d_pyrR;
-            at.pyrR_fs = cs.pyrRCells;
-            at.g = cs.geomR;
-            at.tiles = cs.d_tilesR;
-            at.nTiles = cs.nTilesR;
-            at.tileNodes = cs.d_tileNodesR;
-            at.tileNodesS = cs.d_tileNodesSR;
-        }
-        const TileGeom& gt = at.g;
-        const int64_t total = int64_t(at.nTiles) * nF;
-        const int64_t perX = (total + 7) / 8;
-        const size_t nwin = size_t(gt.NW) * 64;
-        const size_t lds = gt.pooled ? size_t(TILE3_LEAF_BYTES) + size_t(gt.tileFloats) * (rank ? 2 : 4) + ((std::max(nwin * 8, size_t(gt.passW) * size_t(gt.pitchC)) + 15) / 16 * 16) + nwin * 8
-                                     : size_t(gt.tileFloats) * (rank ? 2 : 4) + nwin * 8;
-        // k_cascade_tile3: persistent workgroups (as many as the CUs hold at once) that draw their tiles from one counter per XCD
-        // (tilePersist: 0 one workgroup per tile, 1 as many workgroups as the device's CUs hold at once, n > 1 that many, rounded up
-        // to a multiple of 8 = the tile counters)
-        const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, int64_t(c->ldsPerCu) / int64_t((lds + 1279) / 1280 * 1280));
-        const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
-        const bool persist = gt.pooled && c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
-        if (!persist)
-        {
-            at.tileNext = nullptr;
-        }
-        dim3 grid((unsigned int)(persist ? (gridP + 7) / 8 * 8 : perX * 8)), block(gt.NW * 64);
-        int rc = 0;
-        if ((c->cascTurns & 1) && (rc = turnBegin(c, 0, 0))) // (before the profile event: the wait for the turn is not the kernel's time)
-        {
-            return rc;
-        }
-        prof(c, "k_cascade_tile");
-#define TILE2_LAUNCH(N, CT)                                                                           \
-    {                                                                                                 \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<N, CT>), lds)))          \
-            return rc;                                                                                \
-        hipLaunchKernelGGL((k_cascade_tile3<N, CT>), grid, block, lds, c->stream, at);                \
-    }
-#define TILE3_LAUNCH16(CT)                                                                        \
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3<16, CT>), lds)))             \
-        return rc;                                                                                    \
-    hipLaunchKernelGGL((k_cascade_tile3<16, CT>), grid, block, lds, c->stream, at);
-#define TILE2_NW(CT)                              \
-    switch (gt.NW)                                \
-    {                                             \
-        case 16: TILE3_LAUNCH16(CT); break;       \
-        case 8: TILE2_LAUNCH(8, CT); break;       \
-        case 4: TILE2_LAUNCH(4, CT); break;       \
-        case 2: TILE2_LAUNCH(2, CT); break;       \
-        default: TILE2_LAUNCH(1, CT); break;      \
-    }
-        if (rank)
-        {
-            TILE2_NW(CellRank);
-        }
-        else
-        {
-            TILE2_NW(CellF32);
-        }
-#undef TILE2_NW
-#undef TILE2_LAUNCH
-        LAUNCHCHK(c, "k_cascade_tile");
-        if ((c->cascTurns & 1) && (rc = turnEnd(c, 0, 0)))
-        {
-            return rc;
-        }
-#ifdef ACF_HIP_STAMPS
-        if (a.debug & 4)
-        {
-            // debug only: mean cycles per phase of thread 0 of every block
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            std::vector<long long> st(size_t(grid.x) * 8);
-            HIPCHK(c, hipMemcpy(st.data(), a.stamps, st.size() * 8, hipMemcpyDeviceToHost));
-            if (gt.pooled)
-            {
-                double acc[6] = { 0, 0, 0, 0, 0, 0 }, n1 = 0, n2 = 0, nE = 0, accE = 0;
-                long long nb = 0, nbE = 0;
-                for (size_t b = 0; b < size_t(grid.x); b++)
-                {
-                    if (st[b * 8 + 5] > st[b * 8])
-                    {
-                        for (int k = 0; k < 5; k++)
-                        {
-                            acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
-                        }
-                        n1 += double(st[b * 8 + 7] & 0xffff);
-                        n2 += double((st[b * 8 + 7] >> 16) & 0xffff);
-                        nE += double(st[b * 8 + 7] >> 32);
-                        nb++;
-                        if ((st[b * 8 + 7] >> 32) > 0 && st[b * 8 + 6] > st[b * 8 + 5]) // (tiles with windows in the tail queue: stage E ran)
-                        {
-                            accE += double(st[b * 8 + 6] - st[b * 8 + 5]);
-                            nbE++;
-                        }
-                    }
-                }
-                fprintf(stderr, "[casc stamps, pooled] blocks %lld  fill %.0f  A1 (thread 0) %.0f  barrier %.0f  A2 + barrier %.0f  S %.0f cycles;  survivors per tile: A1 %.1f  A2 %.1f  S %.2f;  E %.0f cycles in %.1f %% of the tiles\n",
-                    nb, acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, n1 / nb, n2 / nb, nE / nb, nbE ? accE / nbE : 0.0, 100.0 * nbE / std::max<long long>(nb, 1));
-            }
-            else
-            {
-                double acc[4] = { 0, 0, 0, 0 }, sub[3] = { 0, 0, 0 };
-                long long nb = 0;
-                for (size_t b = 0; b < size_t(grid.x); b++)
-                {
-                    if (st[b * 8 + 4] > st[b * 8])
-                    {
-                        for (int k = 0; k < 4; k++)
-                        {
-                            acc[k] += double(st[b * 8 + k + 1] - st[b * 8 + k]);
-                        }
-                        for (int k = 0; k < 3; k++)
-                        {
-                            sub[k] += double(st[b * 8 + 5 + k]);
-                        }
-                        nb++;
-                    }
-                }
-                fprintf(stderr, "[casc stamps] blocks %lld (those with tail windows)  fill %.0f  wave 0: A + sparse pieces %.0f  barrier %.0f  E %.0f cycles   (since the fill barrier: A starts %.0f, A evaluated %.0f, compacted %.0f)\n", nb,
-                    acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, sub[0] / nb, sub[1] / nb, sub[2] / nb);
-            }
-            (void)hipFree(a.stamps);
-        }
-#endif
-        if (g.b[4] < p.nTrees && cs.codeCap > 0)
-        {
-            // the first codeCap queue entries of every frame carry leaf codes (stage E of the tile kernel): the ordered scan
-            const size_t ldsS = size_t(p.nTrees - g.b[4]) * 16;
-            if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_tail_scan), ldsS)))
-            {
-                return rc;
-            }
-            prof(c, "k_tail_scan");
-            hipLaunchKernelGGL(k_tail_scan, dim3(nF * ((cs.codeCap + 255) / 256)), dim3(256), ldsS, c->stream, a);
-            LAUNCHCHK(c, "k_tail_scan");
-        }
-        if (g.b[4] < p.nTrees && rank)
-        {
-            // queue entries without codes (beyond codeCap) from the rank cells: a wave per entry; its blocks leave at once
-            // when k_tail_scan has taken the whole queue
-            prof(c, "k_cascade_tail3");
-            hipLaunchKernelGGL(k_cascade_tail_rank, dim3(std::max(1, 1024 / nF) * nF), dim3(64), 0, c->stream, at, (const TreeNode*)cs.d_tailNodesR);
-            LAUNCHCHK(c, "k_cascade_tail_rank");
-        }
-        else if (g.b[4] < p.nTrees)
-        {
-            // queue entries without codes (beyond codeCap, or ACF_HIP_TAIL3): k_cascade_tail3; its blocks leave at once when
-            // k_tail_scan has taken the whole queue
-            dim3 tgrid(std::min(cs.tailBlocks, std::max(1, 512 / nF) * nF)), tblock(cs.tailWaves * 64);
-            const size_t tl = (size_t(cs.tailWaves) * a.tailSlab + size_t(a.tailNodesLds)) * 4;
-            prof(c, "k_cascade_tail3");
-#define TAIL_LAUNCH(N)                                                                                              \
-    if (a.tailNodesLds)                                                                                             \
-    {                                                                                                               \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, true>), tl)))                       \
-            return rc;                                                                                              \
-        hipLaunchKernelGGL((k_cascade_tail3<N, true>), tgrid, tblock, tl, c->stream, a);                            \
-    }                                                                                                               \
-    else                                                                                                            \
-    {                                                                                                               \
-        if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tail3<N, false>), tl)))                      \
-            return rc;                                                                                              \
-        hipLaunchKernelGGL((k_cascade_tail3<N, false>), tgrid, tblock, tl, c->stream, a);                           \
-    }
-            switch (cs.tailWaves)
-            {
-                case 4:
-                    TAIL_LAUNCH(4);
-                    break;
-                case 2:
-                    TAIL_LAUNCH(2);
-                    break;
-                default:
-                    TAIL_LAUNCH(1);
-                    break;
-            }
-#undef TAIL_LAUNCH
-            LAUNCHCHK(c, "k_cascade_tail3");
-        }
-    }
-    return ACF_HIP_OK;
-}
-
-static const size_t kNmsLds = size_t(NMS_CAP) * (8 + 16 + 4 + 1);
-
-static void fillNmsArgs(NmsArgs& a, const acf_hip_nms_params& q)
-{
-    a.greedy = q.type == 2;
-    a.ovrUnion = q.ovrDnmUnion != 0;
-    a.doPrune = q.prune != 0;
-    a.maxCount = q.maxCount;
-    a.overlap = q.overlap;
-    a.thr = q.thr;
-    a.pruneRatio = q.pruneRatio;
-}
-
-// bbNms + prune of every frame's detections (k_nms, one workgroup per frame)
-static int launchNms(acf_hip_ctx* c, int nF)
-{
-    int rc;
-    if (!c->d_nmsKeep)
-    {
-        if ((rc = devAlloc(c, &c->d_nmsKeep, size_t(c->maxBatch) * NMS_CAP)) || (rc = devAlloc(c, &c->d_nmsN, size_t(c->maxBatch))) ||
-            (rc = devAlloc(c, &c->d_nmsCounts, size_t(c->maxBatch))) || (rc = devAlloc(c, &c->d_nmsDets, size_t(c->maxBatch) * c->maxHits)))
-        {
-            return rc;
-        }
-    }
-    NmsArgs a{};
-    a.dets = c->cs.d_dets;
-    a.counts = c->cs.d_counts;
-    a.maxHits = c->maxHits;
-    fillNmsArgs(a, c->nms);
-    a.keep = c->d_nmsKeep;
-    a.nKeep = c->d_nmsN;
-    a.outDets = c->d_nmsDets;
-    a.outCounts = c->d_nmsCounts;
-    if ((rc = allowLds(c, reinterpret_cast<const void*>(&k_nms), kNmsLds)))
-    {
-        return rc;
-    }
-    prof(c, "k_nms");
-    hipLaunchKernelGGL(k_nms, dim3(nF), dim3(1024), kNmsLds, c->stream, a);
-    LAUNCHCHK(c, "k_nms");
-    return ACF_HIP_OK;
-}
-
-static inline bool nmsActive(const acf_hip_ctx* c)
-{
-    return c->nmsOn && c->nms.type != 0 && c->d_nmsDets;
-}
-
-static int runCascade(acf_hip_ctx* c, const float* pyr, int64_t pyr_fs, const BoxLevel* d_box, int nF, int nChns)
-{
-    const acf_hip_params& p = c->p;
-    const CascLevel* d_levels = c->cs.d_cascLevels;
-    const int32_t* d_blockLevel = c->cs.d_blockLevel;
-    const int blocksPerFrame = c->cs.blocksPerFrame;
-    const uint32_t* d_cidAll = c->cs.d_cidAll;
-    const CascNode2* d_nodes2 = c->cs.d_nodes2;
-    prof(c, "k_cascade");
-    const bool rankPath = c->cs.useTiles && !c->noTiles && c->cs.useRank && !c->noRank;
-    if (pyr == c->d_pyr && !c->floatPyramid && !(rankPath && c->ranksValid))
-    {
-        // (options changed between acf_hip_pyramid and acf_hip_detect: the float cells this path reads were never written)
-        return fail(c, ACF_HIP_E_INVALID, "detect: the float pyramid of this batch was not written (keep_pyramid = 0) and the selected cascade reads floats");
-    }
-    if (!c->countersZeroed)
-    {
-        HIPCHK(c, hipMemsetAsync(c->cs.d_counts, 0, sizeof(int32_t) * nF, c->stream));
-    }
-    if (tiledCascadeSelected(c))
-    {
-        int rc = runCascadeTiled(c, pyr, pyr_fs, nF, nChns);
-        if (rc)
-        {
-            return rc;
-        }
-    }
-    else if (blocksPerFrame > 0)
-    {
-        // stage boundaries (see kernels.hip.h): [0,16) [16,32) [32,128) [128,nTrees)
-        std::vector<int> bounds;
-        for (int b : { 16, 32, 128 })
-        {
-            if (b < p.nTrees)
-            {
-                bounds.push_back(b);
-            }
-        }
-        bounds.push_back(p.nTrees);
-        const int nStages = int(bounds.size());
-        HIPCHK(c, hipMemsetAsync(c->cs.d_qcounts, 0, sizeof(int32_t) * size_t(nStages) * c->maxBatch, c->stream));
-        CascArgs a{};
-        a.pyr = pyr;
-        a.pyr_fs = pyr_fs;
-        a.levels = d_levels;
-        a.blockLevel = d_blockLevel;
-        a.blocksPerFrame = blocksPerFrame;
-        a.nFrames = nF;
-        a.mH = p.modelDsPad_h / p.shrink;
-        a.mW = p.modelDsPad_w / p.shrink;
-        a.nChns = nChns;
-        a.fids = c->cs.d_fids;
-        a.nTrees = p.nTrees;
-        a.nTreeNodes = p.nTreeNodes;
-        a.treeDepth = p.treeDepth;
-        a.stride = c->cs.dedupQ > 1 ? p.shrink : p.stride; // (the grid of distinct offsets: its windows are one cell apart)
-        a.shrink = p.shrink;
-        a.cascThr = float(p.cascThr); // DetectionParams::cascThr is a float (acfDetect1.cpp:63,323)
-        a.cidAll = d_cidAll;
-        a.thrs = c->cs.d_thrs;
-        a.hs = c->cs.d_hs;
-        a.child = c->cs.d_child;
-        a.nodes2 = d_nodes2;
-        a.qcap = c->cs.qcap;
-        a.hits = c->cs.d_hits;
-        a.counts = c->cs.d_counts;
-        a.maxHits = c->maxHits;
-        const int mode = p.treeDepth == 2 ? 2 : (p.treeDepth > 0 ? 1 : 0);
-        // later stages see a shrinking survivor set; grid-stride loops cover any count
-        const int qGrid[3] = { std::max(1, blocksPerFrame / 2), std::max(1, blocksPerFrame / 8), std::max(1, std::min(blocksPerFrame, 64)) };
-        int firstStage = 0;
-        bool pooledTail = false; // k_cascade_tile3D has written the tail's leaf codes: no k_tail_codesD
-        if (c->cs.useTileD && !c->noTiles)
-        {
-            // depths 1, 3, 4: trees [0, t1D) of every window from LDS tiles (k_cascade_tileD) instead of the first stages'
-            // per-lane gathers from the pyramid; its survivors enter the queue of the stage that ends at t1D
-            const auto& cs = c->cs;
-            int sD = -1;
-            const bool rankD = cs.useRankD && !c->noRank && pyr == c->d_pyr;
-            const bool pooledRun = rankD || cs.geomD.pooled;
-            const int endD = rankD ? cs.geomDR.b[4] : (cs.geomD.pooled ? cs.geomD.b[4] : cs.t1D); // last tree the tile kernel evaluates
-            for (int i = 0; i < nStages; i++)
-            {
-                if (bounds[size_t(i)] == endD)
-                {
-                    sD = i;
-                }
-            }
-            if (sD >= 0)
-            {
-                TileDArgs at{};
-                at.pyr = pyr;
-                at.pyr_fs = pyr_fs;
-                at.levels = d_levels;
-                at.tiles = cs.d_tilesD;
-                at.nTiles = cs.nTilesD;
-                at.nFrames = nF;
-                at.nChns = nChns;
-                at.nBatches = cs.t1D / cs.tbD;
-                at.g = cs.geomD;
-                at.nodesD = cs.d_nodesD;
-                at.cascThr = float(p.cascThr);
-                at.last = sD == nStages - 1;
-                at.qout = cs.d_queue[sD & 1];
-                at.qoutCount = cs.d_qcounts + size_t(sD) * c->maxBatch;
-                at.qcap = cs.qcap;
-                at.hits = cs.d_hits;
-                at.counts = cs.d_counts;
-                at.maxHits = c->maxHits;
-                int rcl = 0;
-                const int64_t total = int64_t(rankD ? cs.nTilesDR : at.nTiles) * nF;
-                const int64_t perX = (total + 7) / 8;
-                if (rankD && !c->ranksValid)
-                {
-                    // the float pyramid -> threshold-rank cells (levels whose kernels did not emit them)
-                    const size_t ldsR = size_t(cs.rankMaxRec) * sizeof(RankRec);
-                    if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_rank), ldsR)))
-                    {
-                        return rcl;
-                    }
-                    prof(c, "k_rank");
-                    hipLaunchKernelGGL(k_rank, dim3(cdiv(cs.rankMaxWP, RANK_CHUNK_COLS), int(c->plan.levels.size()) * nChns, nF), dim3(256), ldsR, c->stream, pyr, pyr_fs,
-                        cs.d_pyrR, cs.pyrRCells, (const RankJob*)cs.d_rankJobs, nChns, (const RankChan*)cs.d_rankChan, (const RankRec*)cs.d_rankRec);
-                    LAUNCHCHK(c, "k_rank");
-                    c->ranksValid = true;
-                    prof(c, "k_cascade");
-                }
-                if (pooledRun)
-                {
-                    // k_cascade_tile3D: everything up to tree b[4]; the tail's codes come from its stage E
-                    at.tileOff = cs.d_tileOffD;
-                    at.thrs = c->cs.d_thrs;
-                    if (rankD)
-                    {
-                        at.g = cs.geomDR;
-                        at.tiles = cs.d_tilesDR;
-                        at.nTiles = cs.nTilesDR;
-                        at.nodesD = cs.d_nodesDR;
-                        at.tileOff = cs.d_tileOffDR;
-                        at.thrs = reinterpret_cast<const float*>(cs.d_thrsRankD);
-                        at.pyrR = cs.d_pyrR;
-                        at.pyrR_fs = cs.pyrRCells;
-                    }
-                    at.hs = c->cs.d_hs;
-                    at.nTrees = p.nTrees;
-                    at.nTreeNodes = p.nTreeNodes;
-                    pooledTail = !at.last && cs.codeCapD > 0;
-                    at.codes = pooledTail ? cs.d_codesD : nullptr;
-                    at.codeCap = pooledTail ? cs.codeCapD : 0;
-                    at.codePitch = cs.codePitchD;
-                    const size_t nwin = size_t(at.g.NW) * 64;
-                    const size_t lds = size_t(128) * 4 * (size_t(1) << p.treeDepth) + size_t(at.g.tileFloats) * (rankD ? 2 : 4) +
-                        ((std::max(nwin * 8, size_t(at.g.passW) * size_t(at.g.pitchC)) + 15) / 16 * 16) + nwin * 8;
-                    const int64_t resident = int64_t(c->numCus) * std::max<int64_t>(1, int64_t(c->ldsPerCu) / int64_t((lds + 1279) / 1280 * 1280));
-                    const int64_t gridP = c->tilePersist > 1 ? int64_t(c->tilePersist) : resident;
-                    const bool persist = c->tilePersist > 0 && (gridP + 7) / 8 * 8 < perX * 8;
-                    // (the staged path's counters [stage][frame] start at d_qcounts; the tile counters sit behind them)
-                    at.tileNext = persist ? cs.d_qcounts + size_t(8) * c->maxBatch : nullptr;
-                    if (persist)
-                    {
-                        HIPCHK(c, hipMemsetAsync(at.tileNext, 0, sizeof(int32_t) * 8, c->stream));
-                    }
-                    dim3 grid((unsigned int)(persist ? (gridP + 7) / 8 * 8 : perX * 8)), block(at.g.NW * 64);
-                    prof(c, "k_cascade_tile");
-#define TILE3D_LAUNCH(N, DD, TT)                                                                                   \
-    if (rankD)                                                                                                     \
-    {                                                                                                              \
-        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT, CellRank>), lds)))       \
-            return rcl;                                                                                            \
-        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT, CellRank>), grid, block, lds, c->stream, at);              \
-    }                                                                                                              \
-    else                                                                                                           \
-    {                                                                                                              \
-        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tile3D<N, DD, TT, CellF32>), lds)))        \
-            return rcl;                                                                                            \
-        hipLaunchKernelGGL((k_cascade_tile3D<N, DD, TT, CellF32>), grid, block, lds, c->stream, at);               \
-    }
-#define TILE3D_DEPTH(N)                                    \
-    switch (p.treeDepth)                                   \
-    {                                                      \
-        case 1: TILE3D_LAUNCH(N, 1, 4); break;             \
-        case 3: TILE3D_LAUNCH(N, 3, 2); break;             \
-        default: TILE3D_LAUNCH(N, 4, 1); break;            \
-    }
-                    if (at.g.NW == 8)
-                    {
-                        TILE3D_DEPTH(8)
-                    }
-                    else
-                    {
-                        TILE3D_DEPTH(4)
-                    }
-#undef TILE3D_DEPTH
-#undef TILE3D_LAUNCH
-                    LAUNCHCHK(c, "k_cascade_tile3D");
-                    prof(c, "k_cascade");
-                }
-                else
-                {
-                const size_t lds = size_t(at.g.tileFloats) * 4;
-                dim3 grid((unsigned int)(perX * 8)), block(at.g.NW * 64);
-#define TILED_LAUNCH(N, DD, TT)                                                                          \
-    {                                                                                                    \
-        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_cascade_tileD<N, DD, TT>), lds)))        \
-            return rcl;                                                                                  \
-        hipLaunchKernelGGL((k_cascade_tileD<N, DD, TT>), grid, block, lds, c->stream, at);               \
-    }
-#define TILED_DEPTH(N)                                    \
-    switch (p.treeDepth)                                  \
-    {                                                     \
-        case 1: TILED_LAUNCH(N, 1, 4); break;             \
-        case 3: TILED_LAUNCH(N, 3, 2); break;             \
-        default: TILED_LAUNCH(N, 4, 1); break;            \
-    }
-                if (at.g.NW == 8)
-                {
-                    TILED_DEPTH(8)
-                }
-                else
-                {
-                    TILED_DEPTH(4)
-                }
-#undef TILED_DEPTH
-#undef TILED_LAUNCH
-                LAUNCHCHK(c, "k_cascade_tileD");
-                }
-                firstStage = sD + 1;
-            }
-        }
-        for (int sidx = firstStage; sidx < nStages; sidx++)
-        {
-            a.t0 = sidx == 0 ? 0 : bounds[sidx - 1];
-            a.t1 = bounds[sidx];
-            a.last = sidx == nStages - 1;
-            a.qin = sidx > 0 ? c->cs.d_queue[(sidx - 1) & 1] : nullptr;
-            a.qinCount = sidx > 0 ? c->cs.d_qcounts + size_t(sidx - 1) * c->maxBatch : nullptr;
-            a.qout = c->cs.d_queue[sidx & 1];
-            a.qoutCount = c->cs.d_qcounts + size_t(sidx) * c->maxBatch;
-            dim3 block(256);
-            const size_t winBytes = sizeof(float) * size_t(nChns) * a.mH * a.mW;
-            const bool tail = a.last && sidx > 0 && a.t0 >= 128 && winBytes <= 64 * 1024;
-            if (sidx == 0)
-            {
-                dim3 grid(blocksPerFrame * nF);
-                if (mode == 2)
-                {
-                    hipLaunchKernelGGL(k_cascade_first<2>, grid, block, 0, c->stream, a);
-                }
-                else if (mode == 1)
-                {
-                    hipLaunchKernelGGL(k_cascade_first<1>, grid, block, 0, c->stream, a);
-                }
-                else
-                {
-                    hipLaunchKernelGGL(k_cascade_first<0>, grid, block, 0, c->stream, a);
-                }
-            }
-            else if (tail)
-            {
-                // one wave per surviving window; enough waves per frame to fill the chip
-                dim3 grid(std::max(1, 8192 / nF) * nF);
-                if (mode == 1 && c->cs.codeCapD > 0 && a.t0 == 128)
-                {
-                    // leaf codes of the first codeCapD entries, then their ordered sums with lanes = windows; k_cascade_tail
-                    // (below) takes the entries beyond and leaves at once when there are none
-                    a.codes = c->cs.d_codesD;
-                    a.codeCap = c->cs.codeCapD;
-                    a.codePitch = c->cs.codePitchD;
-                    if (!pooledTail)
-                    {
-                        hipLaunchKernelGGL(k_tail_codesD, grid, dim3(64), winBytes, c->stream, a);
-                        LAUNCHCHK(c, "k_tail_codesD");
-                    }
-                    const int nT = a.t1 - a.t0, NL = 1 << p.treeDepth;
-                    const size_t ldsS = size_t((nT + 15) / 16 * 16) * NL * sizeof(float);
-                    dim3 gridS(nF * ((a.codeCap + 255) / 256));
-                    int rcl = 0;
-#define TSD_LAUNCH(DD)                                                                              \
-    {                                                                                               \
-        if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_tail_scanD<DD>), ldsS)))            \
-            return rcl;                                                                             \
-        hipLaunchKernelGGL(k_tail_scanD<DD>, gridS, dim3(256), ldsS, c->stream, a);                 \
-    }
-                    switch (p.treeDepth)
-                    {
-                        case 1: TSD_LAUNCH(1); break;
-                        case 3: TSD_LAUNCH(3); break;
-                        case 4: TSD_LAUNCH(4); break;
-                        default: TSD_LAUNCH(2); break;
-                    }
-#undef TSD_LAUNCH
-                    LAUNCHCHK(c, "k_tail_scanD");
-                    a.qskip = a.codeCap;
-                }
-                if (mode == 2)
-                {
-                    hipLaunchKernelGGL(k_cascade_tail<2>, grid, dim3(64), winBytes, c->stream, a);
-                }
-                else if (mode == 1)
-                {
-                    hipLaunchKernelGGL(k_cascade_tail<1>, grid, dim3(64), winBytes, c->stream, a);
-                }
-                else
-                {
-                    hipLaunchKernelGGL(k_cascade_tail<0>, grid, dim3(64), winBytes, c->stream, a);
-                }
-            }
-            else
-            {
-                dim3 grid(qGrid[std::min(sidx - 1, 2)] * nF);
-                if (mode == 2)
-                {
-                    hipLaunchKernelGGL(k_cascade_queue<2>, grid, block, 0, c->stream, a);
-                }
-                else if (mode == 1)
-                {
-                    hipLaunchKernelGGL(k_cascade_queue<1>, grid, block, 0, c->stream, a);
-                }
-                else
-                {
-                    hipLaunchKernelGGL(k_cascade_queue<0>, grid, block, 0, c->stream, a);
-                }
-            }
-            LAUNCHCHK(c, "k_cascade stage");
-        }
-    }
-    // shift = (modelDsPad - modelDs)/2 - pad (ACF.cpp:275; cv::Size integer arithmetic)
-    const int shift_h = (p.modelDsPad_h - p.modelDs_h) / 2 - p.pad_h;
-    const int shift_w = (p.modelDsPad_w - p.modelDs_w) / 2 - p.pad_w;
-    const acf_hip_hit* hitsForSort = c->cs.d_hits;
-    if (c->cs.dedupQ > 1)
-    {
-        if (!c->cs.d_hitsX || !c->cs.d_realWin)
-        {
-            return fail(c, ACF_HIP_E_INVALID, "detect: no buffer for the windows that share an offset (stride < shrink)");
-        }
-        hipLaunchKernelGGL(k_expand_hits, dim3(nF), dim3(256), 0, c->stream, (const acf_hip_hit*)c->cs.d_hits, c->cs.d_counts, c->cs.d_hitsX, c->maxHits,
-            (const int2*)c->cs.d_realWin, c->cs.dedupQ);
-        LAUNCHCHK(c, "k_expand_hits");
-        hitsForSort = c->cs.d_hitsX;
-    }
-    prof(c, "k_sort_map");
-    hipLaunchKernelGGL(k_sort_map, dim3(SM_BLOCKS, nF), dim3(256), 0, c->stream, hitsForSort, (const int32_t*)c->cs.d_counts, c->maxHits,
-        d_box, p.stride, shift_h, shift_w, c->cs.d_sorted, c->cs.d_dets);
-    LAUNCHCHK(c, "k_sort_map");
-    if (c->nmsOn && c->nms.type != 0)
-    {
-        int rc = launchNms(c, nF);
-        if (rc)
-        {
-            return rc;
-        }
-    }
-    prof(c, "(end)");
-    c->countsFetched = false;
-    return ACF_HIP_OK;
-}
+#include "cascade_run.hip.h"    // allowLds, runCascadeTiled, launchNms, runCascade
 
 int acf_hip_detect(acf_hip_ctx* c)
 {
