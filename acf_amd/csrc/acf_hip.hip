@@ -141,7 +141,7 @@ struct acf_hip_ctx
     int taps = 0;
     int arith = 0;            // option "arith": 1 = the reference's rcpps / rsqrtps bits from d_x86 (acf_hip_set_x86_tables)
     bool x86Owned = false;
-    uint32_t* d_x86 = nullptr; // [4096]: rcp over [1, 2) by m >> 12, then rsqrt over [1, 4) by parity and m >> 13
+    uint32_t* d_x86 = nullptr; // [12288]: rcp over [1, 2) by m >> 11 (4096), then rsqrt over [1, 4) by parity and m >> 11 (2 x 4096)
     int profile = 0;
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
@@ -3307,10 +3307,10 @@ int acf_hip_op_conv_tri(acf_hip_ctx* c, const float* in, float* out, int h, int 
     return ACF_HIP_OK;
 }
 
-int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp4096, const uint32_t* rsqrt8192)
 {
     OP_PROLOGUE(c);
-    if (!rcp2048 || !rsqrt2048)
+    if (!rcp4096 || !rsqrt8192)
     {
         return fail(c, ACF_HIP_E_INVALID, "set_x86_tables: null table");
     }
@@ -3318,12 +3318,12 @@ int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp2048, const uint32
     if (!c->d_x86)
     {
         // (not one of the plan's buffers: it outlives a re-plan; freed by acf_hip_destroy)
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_x86), 4096 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_x86), 12288 * sizeof(uint32_t)));
         c->x86Owned = true;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // (a run in flight may be reading the previous tables)
-    HIPCHK(c, hipMemcpy(c->d_x86, rcp2048, 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_x86 + 2048, rsqrt2048, 2048 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_x86, rcp4096, 4096 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_x86 + 4096, rsqrt8192, 8192 * sizeof(uint32_t), hipMemcpyHostToDevice));
     for (acf_hip_ctx* k : c->kids)
     {
         k->d_x86 = c->d_x86;

@@ -29,9 +29,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
 
 // ------------------------------------------------------------------------
 // The reference's arithmetic at its three approximate sites (gradientMex.cpp:209-219,266; rgbConvertMex.cpp:161; sse.hpp:185-192).
-// _mm_rcp_ps / _mm_rsqrt_ps are functions of (sign, exponent / its parity, the top 11 / 10 mantissa bits) on the CPUs probed
-// (tests/golden/make_x86_tables.py checks all 2^32 inputs): T[0 .. 2047] holds rcp over [1, 2) by m >> 12, T[2048 .. 4095] rsqrt over
-// [1, 2) and [2, 4) by m >> 13.  Zero / subnormal -> inf of that sign, inf -> 0, NaN quieted, rcp results below the normal range
+// _mm_rcp_ps / _mm_rsqrt_ps are functions of (sign, exponent / its parity, the top 12 mantissa bits) on the CPUs probed — an Intel Xeon
+// and an AMD EPYC (tests/golden/make_x86_tables.py checks all 2^32 inputs): T[0 .. 4095] holds rcp over [1, 2) by m >> 11,
+// T[4096 .. 12287] rsqrt over [1, 2) and [2, 4) by m >> 11.  Zero / subnormal -> inf of that sign, inf -> 0, NaN quieted, rcp results below the normal range
 // flushed to zero, rsqrt of a negative -> the default NaN.  The device's functions and the CPU checker's are compared over
 // every input by digest (acf_hip_selftest_x86, tests/test_gpu_arith.py).
 // ------------------------------------------------------------------------
@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t x86_rcp_bits(uint32_t u, const uint32_t* __r
     {
         return s | 0x7f800000u;
     }
-    const uint32_t t = T[m >> 12];
+    const uint32_t t = T[m >> 11];
     const int re = int((t >> 23) & 0xffu) + 127 - int(e);
     return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
 }
@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t x86_rsqrt_bits(uint32_t u, const uint32_t* _
         return 0xffc00000u;
     }
     const int ue = int(e) - 127, odd = ue & 1, half = (ue - odd) / 2;
-    const uint32_t t = T[2048 + ((odd << 10) | int(m >> 13))];
+    const uint32_t t = T[4096 + ((odd << 12) | int(m >> 11))];
     return (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
 }
 __device__ __forceinline__ float x86_rcp(float x, const uint32_t* __restrict__ T)

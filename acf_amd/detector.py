@@ -209,11 +209,11 @@ class HipDetector:
         self._chk(self.lib.acf_hip_set_option(self.ctx, key.encode(), int(value)))
 
     def set_x86_tables(self, rcp, rsqrt):
-        """Install one x86 CPU's _mm_rcp_ps / _mm_rsqrt_ps tables (2 x 2048 uint32, acf_hip_set_x86_tables); option "arith" = 1
+        """Install one x86 CPU's _mm_rcp_ps / _mm_rsqrt_ps tables (4096 + 2 x 4096 uint32, acf_hip_set_x86_tables); option "arith" = 1
         then makes the reference's three approximate sites return that CPU's bits."""
         rcp = np.ascontiguousarray(rcp, dtype=np.uint32)
         rsqrt = np.ascontiguousarray(rsqrt, dtype=np.uint32)
-        assert rcp.shape == (2048,) and rsqrt.shape == (2048,)
+        assert rcp.shape == (4096,) and rsqrt.shape == (8192,)
         u32p = C.POINTER(C.c_uint32)
         self._chk(self.lib.acf_hip_set_x86_tables(self.ctx, rcp.ctypes.data_as(u32p), rsqrt.ctypes.data_as(u32p)))
 

@@ -1278,7 +1278,7 @@ inline uint32_t tblRcp(uint32_t u, const uint32_t* T)
     {
         return s | 0x7f800000u;
     }
-    const uint32_t t = T[m >> 12];
+    const uint32_t t = T[m >> 11];
     const int re = int((t >> 23) & 0xffu) + 127 - int(e);
     return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
 }
@@ -1298,7 +1298,7 @@ inline uint32_t tblRsqrt(uint32_t u, const uint32_t* T)
         return 0xffc00000u;
     }
     const int ue = int(e) - 127, odd = ue & 1, half = (ue - odd) / 2;
-    const uint32_t t = T[(odd << 10) | int(m >> 13)];
+    const uint32_t t = T[(odd << 12) | int(m >> 11)];
     return (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
 }
 #if defined(__SSE__)
@@ -1324,16 +1324,13 @@ inline uint32_t hwRsqrt(uint32_t u)
 bool HipDetector::probeHostArithmetic(std::vector<uint32_t>& rcp, std::vector<uint32_t>& rsq)
 {
 #if defined(__SSE__)
-    rcp.resize(2048);
-    rsq.resize(2048);
-    for (uint32_t i = 0; i < 2048; i++)
+    rcp.resize(4096);
+    rsq.resize(8192);
+    for (uint32_t i = 0; i < 4096; i++)
     {
-        rcp[i] = hwRcp((127u << 23) | (i << 12));
-    }
-    for (uint32_t i = 0; i < 1024; i++)
-    {
-        rsq[i] = hwRsqrt((127u << 23) | (i << 13));
-        rsq[1024 + i] = hwRsqrt((128u << 23) | (i << 13));
+        rcp[i] = hwRcp((127u << 23) | (i << 11));
+        rsq[i] = hwRsqrt((127u << 23) | (i << 11));
+        rsq[4096 + i] = hwRsqrt((128u << 23) | (i << 11));
     }
     // are this CPU's instructions those table functions?  2^22 inputs spread over all bit patterns, every mantissa of one binade,
     // and the exponent range's two ends (tests/golden/make_x86_tables.py runs the same comparison over all 2^32)
@@ -1367,26 +1364,26 @@ bool HipDetector::probeHostArithmetic(std::vector<uint32_t>& rcp, std::vector<ui
 #endif
 }
 
-void HipDetector::setReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+void HipDetector::setReferenceArithmetic(const uint32_t* rcp4096, const uint32_t* rsqrt8192)
 {
     if (!m_ctx)
     {
         m_api = &hip::load();
         check(m_api->acf_hip_create(0, nullptr, &m_ctx), "acf_hip_create");
     }
-    check(m_api->acf_hip_set_x86_tables(m_ctx, rcp2048, rsqrt2048), "acf_hip_set_x86_tables");
+    check(m_api->acf_hip_set_x86_tables(m_ctx, rcp4096, rsqrt8192), "acf_hip_set_x86_tables");
     check(m_api->acf_hip_set_option(m_ctx, "arith", 1), "acf_hip_set_option(arith)");
 }
 
-void HipDetector::setChnsComputeReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048, int device)
+void HipDetector::setChnsComputeReferenceArithmetic(const uint32_t* rcp4096, const uint32_t* rsqrt8192, int device)
 {
     const hip::Api& api = hip::load();
     UtilCtx& u = utilCtx();
     std::lock_guard<std::mutex> lock(u.m);
     acf_hip_ctx* c = utilContext(api, device);
-    if (rcp2048 && rsqrt2048)
+    if (rcp4096 && rsqrt8192)
     {
-        utilCheck(api, c, api.acf_hip_set_x86_tables(c, rcp2048, rsqrt2048), "acf_hip_set_x86_tables");
+        utilCheck(api, c, api.acf_hip_set_x86_tables(c, rcp4096, rsqrt8192), "acf_hip_set_x86_tables");
         utilCheck(api, c, api.acf_hip_set_option(c, "arith", 1), "acf_hip_set_option(arith)");
     }
     else
@@ -1408,7 +1405,7 @@ void HipDetector::setReferenceArithmetic(bool on)
     std::vector<uint32_t> rcp, rsq;
     if (!probeHostArithmetic(rcp, rsq))
     {
-        throw Exception(ACF_HIP_E_UNSUPPORTED, "setReferenceArithmetic: this CPU's rcpps / rsqrtps are not functions of the top mantissa bits (or not an SSE host)");
+        throw Exception(ACF_HIP_E_UNSUPPORTED, "setReferenceArithmetic: this CPU's rcpps / rsqrtps are not functions of the top 12 mantissa bits (or not an SSE host)");
     }
     setReferenceArithmetic(rcp.data(), rsq.data());
 }

@@ -317,12 +317,12 @@ public:
     // option "arith"): with the tables of a CPU installed the pyramid and the detections are what the reference's compiled
     // kernels give on that CPU, bit for bit (default: exact 1/sqrt, 1/x).  setReferenceArithmetic(true) probes the CPU this
     // process runs on — "what acf::Detector would return HERE" — and throws if its instructions are not table functions;
-    // the second form installs given tables (2 x 2048 entries, acf_hip_set_x86_tables).
+    // the second form installs given tables (4096 + 2 x 4096 entries, acf_hip_set_x86_tables).
     void setReferenceArithmetic(bool on);
-    void setReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048);
-    static bool probeHostArithmetic(std::vector<uint32_t>& rcp2048, std::vector<uint32_t>& rsqrt2048);
+    void setReferenceArithmetic(const uint32_t* rcp4096, const uint32_t* rsqrt8192);
+    static bool probeHostArithmetic(std::vector<uint32_t>& rcp4096, std::vector<uint32_t>& rsqrt8192);
     // ... and for the static chnsCompute / computeChannels (their utility context on `device`): tables, or nullptr = exact again
-    static void setChnsComputeReferenceArithmetic(const uint32_t* rcp2048, const uint32_t* rsqrt2048, int device = 0);
+    static void setChnsComputeReferenceArithmetic(const uint32_t* rcp4096, const uint32_t* rsqrt8192, int device = 0);
     // chnsPyramid.cpp:160-456.  With a logger, every real scale reports the planes chnsCompute hands to its logger, in its order
     // and with its tags (chnsCompute.cpp:241-250 L,U,V; gradientMag.cpp:119-123 M; chnsCompute.cpp:285-300 Mnorm, O; :322-329 H).
     int chnsPyramid(const MatP& I, const Options::Pyramid* pPyramid, Pyramid& pyramid, bool isInit = false, const MatLoggerType& logger = {});

@@ -8,7 +8,7 @@
 //   acf_hip_detect --model m.acfm --frames f.raw --rows W --cols H --channels d --count N --chns out.raw [--luv] [--log-taps] [--defaults]
 //                  Detector::chnsCompute per frame (static; --defaults: computeChannels' toolbox defaults instead of the model's Chns):
 //                  the channels [nChns][W/shrink][H/shrink] of every frame appended to out.raw, one "chns ..." line per frame
-//   ... --ref-arith host|tables.bin   the reference's rcpps / rsqrtps bits (probed from this CPU, or 2 x 2048 uint32 from a file)
+//   ... --ref-arith host|tables.bin   the reference's rcpps / rsqrtps bits (probed from this CPU, or 4096 + 8192 uint32 from a file)
 //   ... --log-levels                  Detector::setLogger: a "level <tag> <hash>" line per pyramid level
 //   acf_hip_detect --convert in.acfm|in.cpb --out out.cpb                                  (model file conversion, no GPU)
 //   acf_hip_detect --dump-defaults                                                         (default Options tree, no GPU)
@@ -175,15 +175,15 @@ int main(int argc, char** argv)
             }
             else
             {
-                arithTables.resize(4096);
+                arithTables.resize(12288);
                 std::ifstream is(a["ref-arith"], std::ios::binary);
-                is.read(reinterpret_cast<char*>(arithTables.data()), 4096 * 4);
+                is.read(reinterpret_cast<char*>(arithTables.data()), 12288 * 4);
                 if (!is)
                 {
                     std::fprintf(stderr, "short table file\n");
                     return 2;
                 }
-                det.setReferenceArithmetic(arithTables.data(), arithTables.data() + 2048);
+                det.setReferenceArithmetic(arithTables.data(), arithTables.data() + 4096);
             }
         }
         if (a.count("log-levels"))
@@ -273,7 +273,7 @@ int main(int argc, char** argv)
             // Detector::chnsCompute / computeChannels (static, ACF.h:342-349,419-420) on every frame
             if (!arithTables.empty())
             {
-                HipDetector::setChnsComputeReferenceArithmetic(arithTables.data(), arithTables.data() + 2048);
+                HipDetector::setChnsComputeReferenceArithmetic(arithTables.data(), arithTables.data() + 4096);
             }
             std::ofstream os(a["chns"], std::ios::binary);
             for (int f = 0; f < cnt; f++)

@@ -259,16 +259,17 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
 ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value);
 
 /* The reference's arithmetic at its three approximate sites (option "arith" = 1).  _mm_rcp_ps and _mm_rsqrt_ps
- * (toolbox/sse.hpp:185-192) are 12-bit approximations whose bits belong to the CPU.  On the CPUs probed they are functions
- * of the input's sign, exponent (its parity for rsqrt) and top mantissa bits:
- *   rcp2048[m >> 12]                      = bits of _mm_rcp_ps(x)   for x = 1.m in [1, 2)        (2048 entries)
- *   rsqrt2048[(odd << 10) | (m >> 13)]    = bits of _mm_rsqrt_ps(x) for x in [1, 2) (odd = 0) and [2, 4) (odd = 1)
+ * (toolbox/sse.hpp:185-192) are 12-bit approximations whose bits belong to the CPU.  On the CPUs probed (an Intel Xeon and an AMD
+ * EPYC, each checked for all 2^32 inputs) they are functions of the input's sign, exponent (its parity for rsqrt) and top 12
+ * mantissa bits:
+ *   rcp4096[m >> 11]                      = bits of _mm_rcp_ps(x)   for x = 1.m in [1, 2)        (4096 entries)
+ *   rsqrt8192[(odd << 12) | (m >> 11)]    = bits of _mm_rsqrt_ps(x) for x in [1, 2) (odd = 0) and [2, 4) (odd = 1)
  * and every other input follows by exponent arithmetic (zero / subnormal -> inf, inf -> 0, results below the normal range
  * -> 0, NaN quieted, rsqrt of a negative -> 0xffc00000).  A host that wants "what the reference gives HERE" fills the tables
  * from its own CPU (acf::HipDetector::setReferenceArithmetic does, acf_amd/host/HipDetector.h); tests install the build
- * host's (tests/golden/x86_rcp_rsqrt.npz, checked there against the instructions for all 2^32 inputs).  The tables are
- * copied to the device; the call may be repeated.  Sub-batch contexts ("streams" > 1) share their parent's tables. */
-ACF_HIP_API int acf_hip_set_x86_tables(acf_hip_ctx* ctx, const uint32_t* rcp2048, const uint32_t* rsqrt2048);
+ * host's (tests/golden/x86_rcp_rsqrt.npz) or probe the host they run on.  The tables are copied to the device; the call may be
+ * repeated.  Sub-batch contexts ("streams" > 1) share their parent's tables. */
+ACF_HIP_API int acf_hip_set_x86_tables(acf_hip_ctx* ctx, const uint32_t* rcp4096, const uint32_t* rsqrt8192);
 /* Self-check of the device's table functions: position-mixed 64-bit digests of rcp (digest[0]) and rsqrt (digest[1]) over the
  * bit patterns first + i * stride, i < count — the sums the CPU oracle's acfo_x86_digest forms from the same tables, so the
  * two implementations are compared for every input without moving 2^32 results. */

@@ -117,21 +117,23 @@ static inline float approx12(float v)
 
 /* ------------------------------------------------------------------------
  * The T-ref tier as a TABLE: acfo_set_approx(3).  _mm_rcp_ps / _mm_rsqrt_ps (T/sse.hpp:185-192) are, on the CPUs probed so far
- * (tests/golden/make_x86_tables.py, which checks it for all 2^32 inputs), pure functions of few input bits:
- *   rcp(x)   = sign | 2^(127 - e) scaled RCP[m >> 12]            2048 entries: the results for x in [1, 2), by the top 11 mantissa bits
- *   rsqrt(x) = 2^(-(e - 127 - odd) / 2) scaled RSQ[odd][m >> 13]  2 x 1024 entries: the results for x in [1, 2) and [2, 4)
+ * (tests/golden/make_x86_tables.py, which checks it for all 2^32 inputs: an Intel Xeon, family 6 model 207 — the build host — and an
+ * AMD EPYC 9575F — the GPU boxes' host), pure functions of few input bits:
+ *   rcp(x)   = sign | 2^(127 - e) scaled RCP[m >> 11]            4096 entries: the results for x in [1, 2), by the top 12 mantissa bits
+ *   rsqrt(x) = 2^(-(e - 127 - odd) / 2) scaled RSQ[odd][m >> 11]  2 x 4096 entries: the results for x in [1, 2) and [2, 4)
+ * (the Intel part decides on 11 / 10 bits: its entries repeat in pairs / fours; the AMD part uses all 12)
  * with zero / subnormal inputs -> inf of the input's sign (the instruction treats subnormals as zero), inf -> 0, NaN -> quiet NaN,
  * results below the normal range flushed to zero, rsqrt of a negative -> the default NaN (0xffc00000).  With the tables of a
  * CPU installed (acfo_set_x86_tables) the three sites below return that CPU's bits: gradMag, gradMagNorm and rgb2luv_sse become
  * BIT-EXACT against the reference's own compiled kernels on that CPU (tests/test_oracle_vs_ref.py), and the whole path reproduces
  * the reference's detections (tests/test_tref_end_to_end.py).  acfo_x86_probe reads the tables from the CPU this runs on.
  * ---------------------------------------------------------------------- */
-static uint32_t g_x86Rcp[2048], g_x86Rsq[2048];
+static uint32_t g_x86Rcp[4096], g_x86Rsq[8192];
 static int g_x86Set = 0;
-ACFO_API void acfo_set_x86_tables(const uint32_t* rcp2048, const uint32_t* rsqrt2048)
+ACFO_API void acfo_set_x86_tables(const uint32_t* rcp4096, const uint32_t* rsqrt8192)
 {
-    memcpy(g_x86Rcp, rcp2048, sizeof(g_x86Rcp));
-    memcpy(g_x86Rsq, rsqrt2048, sizeof(g_x86Rsq));
+    memcpy(g_x86Rcp, rcp4096, sizeof(g_x86Rcp));
+    memcpy(g_x86Rsq, rsqrt8192, sizeof(g_x86Rsq));
     g_x86Set = 1;
 }
 ACFO_API uint32_t acfo_x86_rcp_bits(uint32_t u)
@@ -145,7 +147,7 @@ ACFO_API uint32_t acfo_x86_rcp_bits(uint32_t u)
     {
         return s | 0x7f800000u; /* zero and subnormals: inf */
     }
-    const uint32_t t = g_x86Rcp[m >> 12];
+    const uint32_t t = g_x86Rcp[m >> 11];
     const int re = (int)((t >> 23) & 0xffu) + 127 - (int)e;
     if (re <= 0)
     {
@@ -169,7 +171,7 @@ ACFO_API uint32_t acfo_x86_rsqrt_bits(uint32_t u)
         return 0xffc00000u;
     }
     const int ue = (int)e - 127, odd = ue & 1, half = (ue - odd) / 2; /* x = 4^half * [1, 4) */
-    const uint32_t t = g_x86Rsq[(odd << 10) | (m >> 13)];
+    const uint32_t t = g_x86Rsq[(odd << 12) | (m >> 11)];
     const int re = (int)((t >> 23) & 0xffu) - half;
     return ((uint32_t)re << 23) | (t & 0x7fffffu);
 }
@@ -232,16 +234,13 @@ static inline uint32_t hw_rsqrt_bits(uint32_t u)
     return u;
 }
 /* The tables of the CPU this runs on: _mm_rcp_ps over [1, 2) and _mm_rsqrt_ps over [1, 4) at the first input of every table cell. */
-ACFO_API int acfo_x86_probe(uint32_t* rcp2048, uint32_t* rsqrt2048)
+ACFO_API int acfo_x86_probe(uint32_t* rcp4096, uint32_t* rsqrt8192)
 {
-    for (uint32_t i = 0; i < 2048; i++)
+    for (uint32_t i = 0; i < 4096; i++)
     {
-        rcp2048[i] = hw_rcp_bits((127u << 23) | (i << 12));
-    }
-    for (uint32_t i = 0; i < 1024; i++)
-    {
-        rsqrt2048[i] = hw_rsqrt_bits((127u << 23) | (i << 13));
-        rsqrt2048[1024 + i] = hw_rsqrt_bits((128u << 23) | (i << 13));
+        rcp4096[i] = hw_rcp_bits((127u << 23) | (i << 11));
+        rsqrt8192[i] = hw_rsqrt_bits((127u << 23) | (i << 11));
+        rsqrt8192[4096 + i] = hw_rsqrt_bits((128u << 23) | (i << 11));
     }
     return 1;
 }
@@ -261,10 +260,10 @@ ACFO_API int acfo_x86_verify(uint32_t first, uint64_t count, uint32_t stride, ui
     return 1;
 }
 #else
-ACFO_API int acfo_x86_probe(uint32_t* rcp2048, uint32_t* rsqrt2048)
+ACFO_API int acfo_x86_probe(uint32_t* rcp4096, uint32_t* rsqrt8192)
 {
-    (void)rcp2048;
-    (void)rsqrt2048;
+    (void)rcp4096;
+    (void)rsqrt8192;
     return 0;
 }
 ACFO_API int acfo_x86_verify(uint32_t first, uint64_t count, uint32_t stride, uint64_t bad[2])

@@ -195,10 +195,10 @@ def _x86_lib():
 
 
 def x86_probe():
-    """(rcp[2048], rsqrt[2048]) uint32 tables of the CPU THIS process runs on (_mm_rcp_ps over [1, 2), _mm_rsqrt_ps over [1, 4)),
+    """(rcp[4096], rsqrt[8192]) uint32 tables of the CPU THIS process runs on (_mm_rcp_ps over [1, 2), _mm_rsqrt_ps over [1, 4)),
     or None where the oracle was not built for an SSE host."""
     o = _x86_lib()
-    rcp, rsq = np.zeros(2048, np.uint32), np.zeros(2048, np.uint32)
+    rcp, rsq = np.zeros(4096, np.uint32), np.zeros(8192, np.uint32)
     if not o.acfo_x86_probe(rcp.ctypes.data_as(u32p), rsq.ctypes.data_as(u32p)):
         return None
     return rcp, rsq
@@ -216,7 +216,7 @@ def set_x86_tables(rcp, rsq):
     o = _x86_lib()
     rcp = np.ascontiguousarray(rcp, np.uint32)
     rsq = np.ascontiguousarray(rsq, np.uint32)
-    assert rcp.shape == (2048,) and rsq.shape == (2048,)
+    assert rcp.shape == (4096,) and rsq.shape == (8192,)
     o.acfo_set_x86_tables(rcp.ctypes.data_as(u32p), rsq.ctypes.data_as(u32p))
 
 

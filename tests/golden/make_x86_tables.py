@@ -8,9 +8,12 @@ macros T/sse.hpp:185-192).  Their results are ~12-bit approximations whose bits 
 exists only per CPU.  This script shows that on THIS CPU each instruction is a pure function of few input bits and writes that
 function down:
 
-  rcp(x)   : sign, exponent 127 - e (+ the table entry's), mantissa RCP[m >> 12]              (2048 entries, x in [1, 2))
-  rsqrt(x) : exponent -(e - 127 - odd) / 2 (+ the entry's), mantissa RSQ[odd][m >> 13]        (2 x 1024 entries, x in [1, 4))
+  rcp(x)   : sign, exponent 127 - e (+ the table entry's), mantissa RCP[m >> 11]              (4096 entries, x in [1, 2))
+  rsqrt(x) : exponent -(e - 127 - odd) / 2 (+ the entry's), mantissa RSQ[odd][m >> 11]        (2 x 4096 entries, x in [1, 4))
   zero / subnormal -> inf of the input's sign, inf -> 0, NaN -> quiet NaN, underflow -> 0, rsqrt(negative) -> 0xffc00000
+
+(12 mantissa bits cover both parts probed so far: the Intel Xeon of the build host decides on 11 / 10 of them — its entries repeat
+in pairs / fours —, the AMD EPYC 9575F of the GPU boxes on all 12: profiles/r06_ab/probe_x86_structure.c.)
 
 (1) probes the tables from the live instructions (oracle/acf_oracle.c: acfo_x86_probe), (2) checks the table functions
 (acfo_x86_rcp_bits / acfo_x86_rsqrt_bits) against the live instructions for ALL 2^32 inputs — 0 mismatches or the script fails —,
@@ -57,12 +60,13 @@ def main():
     bad_rcp, bad_rsq = sum(b[0] for b in bad), sum(b[1] for b in bad)
     print("inputs checked: 2^32; mismatches rcp %d, rsqrt %d" % (bad_rcp, bad_rsq))
     assert bad_rcp == 0 and bad_rsq == 0, "this CPU's rcpps / rsqrtps are not the table functions: no fixture written"
-    # structure: 12 significant result bits, entries strictly ordered
+    # structure: 12 significant result bits
     assert not (rcp & 0x7ff).any() and not (rsq & 0x7ff).any()
-    np.savez_compressed(os.path.join(HERE, "x86_rcp_rsqrt.npz"), rcp=rcp, rsqrt=rsq, cpu=np.asarray(cpu_name()),
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "x86_rcp_rsqrt.npz")   # (another path: a probe of another host)
+    np.savez_compressed(out, rcp=rcp, rsqrt=rsq, cpu=np.asarray(cpu_name()),
                         checked=np.asarray([1 << 32, bad_rcp, bad_rsq], np.int64))
     print("cpu:", cpu_name())
-    print("rcp[0..2] %08x %08x %08x  rsqrt[0] %08x rsqrt[1024] %08x" % (rcp[0], rcp[1], rcp[2], rsq[0], rsq[1024]))
+    print("rcp[0..2] %08x %08x %08x  rsqrt[0] %08x rsqrt[4096] %08x" % (rcp[0], rcp[1], rcp[2], rsq[0], rsq[4096]))
 
 
 if __name__ == "__main__":

@@ -179,3 +179,98 @@ def test_u8_ingest_in_reference_arithmetic(oracle):
     got = det.read_pyramid(0)
     assert np.array_equal(bits(got), bits(want))
     det.close()
+
+
+def test_reference_arithmetic_with_sub_batch_contexts_and_taps(oracle):
+    """Option "streams" > 1 (sub-batch contexts share their parent's tables) and option "taps" (the unfused forms anyway) in the T-ref tier."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 240, 320
+    model = synth.make_model(seed=3, name="INRIA", nTrees=64)
+    frames = np.stack([synth.make_frame(15 + f, H, W, "rgb") for f in range(6)])
+    plan = oracle.Plan(model, H, W, 3)
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    want = []
+    for f in range(6):
+        oracle.set_approx(3)
+        try:
+            pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        finally:
+            oracle.set_approx(0)
+        want.append((pyr, oracle.detect(plan, pyr)))
+    for kw in (dict(streams=2), dict(taps=True)):
+        det = HipDetector(streams=kw.get("streams", 1), taps=kw.get("taps", False))
+        det.set_x86_tables(*oracle.x86_fixture())     # before the plan: the children are created by it
+        det.set_option("arith", 1)
+        det.set_model(model)
+        det.plan(H, W, 3, max_batch=6, max_hits=1 << 15)
+        det.run(torch.from_numpy(frames).cuda())
+        for f in range(6):
+            d, h = det.detections(f)
+            assert d.tobytes() == want[f][1][0].tobytes() and h.tobytes() == want[f][1][1].tobytes(), (kw, f)
+            if "taps" in kw:
+                assert np.array_equal(bits(det.read_pyramid(f)), bits(want[f][0])), f
+        det.close()
+    # tables installed AFTER the plan reach the children too
+    det = HipDetector(model, H, W, 3, max_batch=6, max_hits=1 << 15, streams=2)
+    det.set_x86_tables(*oracle.x86_fixture())
+    det.set_option("arith", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    for f in range(6):
+        d, h = det.detections(f)
+        assert d.tobytes() == want[f][1][0].tobytes() and h.tobytes() == want[f][1][1].tobytes(), f
+    det.close()
+
+
+@pytest.mark.parametrize("cfg", list(TREF_CFG))
+def test_hits_equal_the_reference_kernels_running_on_this_host(oracle, cfg):
+    """The strongest form of the parity claim, LIVE on the box the test runs on: the reference's own compiled SSE kernels
+    (oracle/_ref/libacfref.so: convTri1, convTri, gradMag, gradMagNorm, gradHist, resample, rgbConvert — built in the build container
+    from the sources where they lie, shipped as a binary) execute on THIS host's CPU under the restated orchestration, and the HIP path,
+    with the tables probed from the same CPU (what acf::HipDetector::setReferenceArithmetic(true) installs), must give the same hits,
+    positions and score bits — on an Intel build host or an AMD EPYC GPU box alike.  Skips where the reference binary is absent or
+    the CPU's rcpps / rsqrtps are not functions of the top 12 mantissa bits."""
+    import torch
+    from acf_amd.detector import HipDetector
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libacfref.so not shipped")
+    t = oracle.x86_probe()
+    if t is None:
+        pytest.skip("not an SSE host")
+    oracle.set_x86_tables(*t)
+    if oracle.x86_verify(0, 1 << 24, 255) != (0, 0) or oracle.x86_verify(0x3f800000, 1 << 23, 1) != (0, 0) or oracle.x86_verify(0x7f000000, 1 << 24, 1) != (0, 0):
+        pytest.skip("this CPU's rcpps / rsqrtps are not table functions of the top 12 mantissa bits")
+    fix = np.load(os.path.join(GOLD, "tref_study.npz"))
+    H, W, d_in, nframes, seed0, mseed = [int(v) for v in fix[cfg + "_meta"]]
+    kind, preset = TREF_CFG[cfg]
+    model = synth.make_model(seed=mseed, name=preset)
+    n = 3 if H > 600 else 6
+    frames = np.stack([synth.make_frame(seed0 + 100 + f, H, W, kind) for f in range(n)])   # (other frames than the fixture's)
+    plan = oracle.Plan(model, H, W, d_in)
+    det = HipDetector(model, H, W, d_in, max_batch=n, max_hits=1 << 15)
+    det.set_x86_tables(*t)
+    det.set_option("arith", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    total = 0
+    for f in range(n):
+        oracle.set_tref(True)                        # every toolbox kernel = the reference's compiled one, on this CPU
+        try:
+            pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        finally:
+            oracle.set_tref(False)
+        _, want = oracle.detect(plan, pyr)
+        _, gh = det.detections(f)
+        assert gh.tobytes() == want.tobytes(), (cfg, f, len(gh), len(want))
+        if f == 0:
+            det.set_option("keep_pyramid", 1)
+        total += len(want)
+    assert total > 0
+    # and the pyramid itself, level by level, for one frame
+    det.pyramid(torch.from_numpy(frames[:1]).cuda())
+    oracle.set_tref(True)
+    try:
+        pyr, _, _ = oracle.chns_pyramid(plan, frames[0])
+    finally:
+        oracle.set_tref(False)
+    assert np.array_equal(bits(det.read_pyramid(0)), bits(pyr))
+    det.close()

@@ -232,3 +232,49 @@ def test_cli_reference_arithmetic_and_level_logger(cli, oracle, tmp_path):
     assert [l[1] for l in levels[:plan.nScales]] == ["%06d" % i for i in range(plan.nScales)]
     l0 = plan.levels[0]
     assert levels[0][2] == "%dx%d" % (plan.nChns * l0.wP, l0.hP)     # transposed: cols x rows of the canvas
+
+
+@pytest.mark.gpu
+def test_cli_reference_arithmetic_probed_from_this_host(cli, oracle, tmp_path):
+    """setReferenceArithmetic(true): the C++ host probes the CPU it runs on (whatever the GPU box has) and the detector then returns
+    what the reference would return HERE: the oracle's table tier with tables probed from the same CPU.  A CPU whose rcpps / rsqrtps
+    are not table functions must be refused with an exception, not emulated wrongly."""
+    H, W = 112, 96
+    model = synth.make_model(seed=3, name="INRIA", nTrees=64, cascThr=-1.5)
+    frames = [synth.make_frame(40 + i, H, W, "rgb") for i in range(3)]
+    write_model(str(tmp_path / "m.acfm"), model)
+    (tmp_path / "f.raw").write_bytes(np.stack(frames).tobytes())
+    e = dict(os.environ)
+    e["ACF_HIP_LIBRARY"] = capi.LIB_PATH
+    p = subprocess.run([cli, "--model", str(tmp_path / "m.acfm"), "--frames", str(tmp_path / "f.raw"), "--rows", str(W), "--cols", str(H), "--channels", "3",
+                        "--count", "3", "--ref-arith", "host"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    t = oracle.x86_probe()
+    table_cpu = False
+    if t is not None:
+        oracle.set_x86_tables(*t)
+        table_cpu = oracle.x86_verify(0, 1 << 22, 1021) == (0, 0) and oracle.x86_verify(0x3f800000, 1 << 23, 7) == (0, 0)
+    if not table_cpu:
+        assert p.returncode != 0 and "rcpps" in p.stderr, (p.returncode, p.stderr[-300:])
+        return
+    assert p.returncode == 0, p.stderr[-500:]
+    got, cur = [], None
+    for line in p.stdout.splitlines():
+        w = line.split()
+        if w[0] == "frame":
+            cur = []
+            got.append(cur)
+        else:
+            cur.append((int(w[0]), int(w[1]), int(w[2]), int(w[3]), int(w[5], 16)))
+    plan = oracle.Plan(model, H, W, 3)
+    total = 0
+    for f in range(3):
+        oracle.set_approx(3)
+        try:
+            pyr, _, _ = oracle.chns_pyramid(plan, frames[f])
+        finally:
+            oracle.set_approx(0)
+        det, _ = oracle.detect(plan, pyr)
+        want = [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), int(np.float32(d["score"]).view(np.uint32))) for d in det]
+        assert got[f] == want, f
+        total += len(want)
+    assert total > 0

@@ -2,7 +2,7 @@
 
 `_mm_rcp_ps` / `_mm_rsqrt_ps` at the reference's three sites (T/gradientMex.cpp:209-219,266; T/rgbConvertMex.cpp:161;
 T/sse.hpp:185-192) are per-CPU 12-bit approximations.  tests/golden/make_x86_tables.py showed that on the build host each is
-a function of (sign, exponent / its parity, top 11 / 10 mantissa bits) for ALL 2^32 inputs and froze the 2 x 2048 entries in
+a function of (sign, exponent / its parity, top 12 mantissa bits) for ALL 2^32 inputs and froze the 4096 + 2 x 4096 entries in
 tests/golden/x86_rcp_rsqrt.npz.  Here:
 
  * the fixture's structure and its record of the exhaustive check;
@@ -39,17 +39,34 @@ def live_tables(oracle):
 def test_fixture_structure(oracle):
     z = np.load(oracle.X86_FIXTURE)
     rcp, rsq = z["rcp"], z["rsqrt"]
-    assert rcp.shape == (2048,) and rsq.shape == (2048,) and rcp.dtype == np.uint32
+    assert rcp.shape == (4096,) and rsq.shape == (8192,) and rcp.dtype == np.uint32
     assert list(z["checked"]) == [1 << 32, 0, 0]          # every input, no mismatch, on the CPU named in `cpu`
     assert len(str(z["cpu"])) > 4
     assert not (rcp & 0x7ff).any() and not (rsq & 0x7ff).any()  # 12 significant bits
     f = rcp.view(np.float32)
-    x = 1.0 + np.arange(2048) / 2048.0
-    assert (np.abs(f * (x + 1.0 / 4096) - 1.0) < 1.5 * 2.0 ** -12).all()   # within the documented bound at the cell centres
-    assert (np.diff(f.astype(np.float64)) < 0).all()
+    x = 1.0 + np.arange(4096) / 4096.0
+    assert (np.abs(f * (x + 1.0 / 8192) - 1.0) < 1.5 * 2.0 ** -12).all()   # within the documented bound at the cell centres
+    assert (np.diff(f.astype(np.float64)) <= 0).all()
     g = rsq.view(np.float32).astype(np.float64)
-    xs = np.concatenate([1.0 + (np.arange(1024) + 0.5) / 1024.0, 2.0 + 2.0 * (np.arange(1024) + 0.5) / 1024.0])
+    xs = np.concatenate([1.0 + (np.arange(4096) + 0.5) / 4096.0, 2.0 + 2.0 * (np.arange(4096) + 0.5) / 4096.0])
     assert (np.abs(g * np.sqrt(xs) - 1.0) < 1.5 * 2.0 ** -12).all()
+    assert (np.diff(g[:4096]) <= 0).all() and (np.diff(g[4096:]) <= 0).all()
+
+
+def test_second_fixture_from_the_gpu_boxes_host(oracle):
+    """The same probe + exhaustive check run on a GPU box's host (AMD EPYC 9575F, tests/golden/make_x86_tables.py <path> there): another
+    vendor's instructions are table functions of the same 12 mantissa bits with other entries — which is why the tier takes tables and
+    the host class probes the CPU it runs on (tests/test_gpu_arith.py compares the HIP path with the reference's compiled kernels LIVE
+    on whatever host it runs on)."""
+    a = np.load(oracle.X86_FIXTURE)
+    b = np.load(os.path.join(HERE, "golden", "x86_rcp_rsqrt_amd_epyc_9575f.npz"))
+    assert list(b["checked"]) == [1 << 32, 0, 0] and "EPYC" in str(b["cpu"])
+    assert b["rcp"].shape == (4096,) and b["rsqrt"].shape == (8192,)
+    assert not (b["rcp"] & 0x7ff).any() and not (b["rsqrt"] & 0x7ff).any()
+    assert (a["rcp"] != b["rcp"]).sum() > 1000 and (a["rsqrt"] != b["rsqrt"]).sum() > 1000      # different CPUs, different bits
+    x = 1.0 + (np.arange(4096) + 0.5) / 4096.0
+    for t in (a, b):                                                                             # ... both inside the documented bound
+        assert (np.abs(t["rcp"].view(np.float32).astype(np.float64) * x - 1.0) < 1.5 * 2.0 ** -12).all()
 
 
 def test_table_functions_special_values(oracle):
