@@ -125,10 +125,44 @@ def study(nframes):
     return table, store
 
 
+SMALL = {
+    # name -> (H, W, kind, d_in, model kwargs): whole T-ref PYRAMIDS at sizes small enough to commit ("every scale of the fused
+    # pyramid, both T-ref bytes and T-exact bytes"; the T-exact ones are tests/golden/pipeline_*.npz)
+    "luv_tiny_160x120": (120, 160, "luv", 3, dict(name="TINY", nTrees=64, cascThr=-3.0)),
+    "rgb_inria_160x120": (120, 160, "rgb", 3, dict(name="INRIA", nTrees=64, cascThr=-1.5)),
+    "gray_face64_320x240": (240, 320, "gray", 1, dict(name="FACE64", nTrees=96, cascThr=-1.0)),
+}
+
+
+def small_pyramids():
+    """tests/golden/tref_pyramids.npz: frame + model seeds, the fused pyramid and the hits computed with the reference's OWN compiled
+    kernels (this host's rsqrtps / rcpps) under the restated orchestration.  What the table tier (oracle: acfo_set_approx(3) with
+    tests/golden/x86_rcp_rsqrt.npz; device: option arith) must reproduce bit for bit, on any box."""
+    assert ob.have_ref()
+    store = {}
+    for name, (H, W, kind, d_in, kw) in SMALL.items():
+        model = synth.make_model(seed=3, **kw)
+        frame = synth.make_frame(77, H, W, kind)
+        plan = ob.Plan(model, H, W, d_in)
+        pr, dr, hr = run_tier(plan, frame, True)
+        pe, de, he = run_tier(plan, frame, False)
+        assert not np.array_equal(pr, pe)
+        store[name + "_pyramid_ref"] = pr
+        store[name + "_hits_ref"] = hr
+        store[name + "_det_ref"] = dr
+        store[name + "_meta"] = np.asarray([H, W, d_in, 77, 3], np.int64)
+        print(name, pr.size, "floats,", len(hr), "hits (T-exact:", len(he), "), cells differing from T-exact: %.1f %%" % (100 * float((pr != pe).mean())))
+    np.savez_compressed(os.path.join(HERE, "tref_pyramids.npz"), **store)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--small-only", action="store_true", help="only tests/golden/tref_pyramids.npz (the small whole-pyramid fixtures)")
     a = ap.parse_args()
+    small_pyramids()
+    if a.small_only:
+        sys.exit(0)
     table, store = study(a.frames)
     import platform
     cpu = ""

@@ -274,3 +274,25 @@ def test_hits_equal_the_reference_kernels_running_on_this_host(oracle, cfg):
         oracle.set_tref(False)
     assert np.array_equal(bits(det.read_pyramid(0)), bits(pyr))
     det.close()
+
+
+@pytest.mark.parametrize("name,kind,kw", [("luv_tiny_160x120", "luv", dict(name="TINY", nTrees=64, cascThr=-3.0)),
+                                          ("rgb_inria_160x120", "rgb", dict(name="INRIA", nTrees=64, cascThr=-1.5)),
+                                          ("gray_face64_320x240", "gray", dict(name="FACE64", nTrees=96, cascThr=-1.0))])
+def test_whole_pyramid_equals_the_frozen_reference_kernel_pyramid(oracle, name, kind, kw):
+    """Every cell of every level, the hits and the mapped boxes against tests/golden/tref_pyramids.npz (the reference's compiled kernels
+    on the build host), with the committed Intel tables: the device-side counterpart of tests/test_x86_tables.py's check."""
+    import torch
+    from acf_amd.detector import HipDetector
+    fix = np.load(os.path.join(GOLD, "tref_pyramids.npz"))
+    H, W, d_in, fseed, mseed = [int(v) for v in fix[name + "_meta"]]
+    model = synth.make_model(seed=mseed, **kw)
+    frame = synth.make_frame(fseed, H, W, kind)
+    det = HipDetector(model, H, W, d_in, max_batch=1, max_hits=1 << 15)
+    det.set_x86_tables(*oracle.x86_fixture())
+    det.set_option("arith", 1)
+    det.run(torch.from_numpy(frame[None]).cuda())
+    assert np.array_equal(bits(det.read_pyramid(0)), bits(fix[name + "_pyramid_ref"]))
+    d, h = det.detections(0)
+    assert h.tobytes() == fix[name + "_hits_ref"].tobytes() and d.tobytes() == fix[name + "_det_ref"].tobytes() and len(h) > 0
+    det.close()

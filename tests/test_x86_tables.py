@@ -253,3 +253,27 @@ def test_fixture_tables_reproduce_the_frozen_reference_bytes(oracle):
             assert np.array_equal(luv.view(np.uint32), rsl["luv_out%d" % k].view(np.uint32)), k
     finally:
         oracle.set_approx(0)
+
+
+@pytest.mark.parametrize("name,kind,kw", [("luv_tiny_160x120", "luv", dict(name="TINY", nTrees=64, cascThr=-3.0)),
+                                          ("rgb_inria_160x120", "rgb", dict(name="INRIA", nTrees=64, cascThr=-1.5)),
+                                          ("gray_face64_320x240", "gray", dict(name="FACE64", nTrees=96, cascThr=-1.0))])
+def test_fixture_tables_reproduce_whole_reference_kernel_pyramids(oracle, name, kind, kw):
+    """tests/golden/tref_pyramids.npz (make_tref.py --small-only, build host): every cell of every level of the fused pyramid as the
+    reference's own compiled kernels give it, and the hits on it.  The oracle's table tier with the committed Intel tables must equal
+    it bit for bit on any box (tests/test_gpu_arith.py holds the device against the same bytes)."""
+    fix = np.load(os.path.join(HERE, "golden", "tref_pyramids.npz"))
+    H, W, d_in, fseed, mseed = [int(v) for v in fix[name + "_meta"]]
+    model = synth.make_model(seed=mseed, **kw)
+    frame = synth.make_frame(fseed, H, W, kind)
+    plan = oracle.Plan(model, H, W, d_in)
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    oracle.set_approx(3)
+    try:
+        pyr, _, _ = oracle.chns_pyramid(plan, frame)
+    finally:
+        oracle.set_approx(0)
+    det, hits = oracle.detect(plan, pyr)
+    assert np.array_equal(pyr.view(np.uint32), fix[name + "_pyramid_ref"].view(np.uint32))
+    assert hits.tobytes() == fix[name + "_hits_ref"].tobytes() and det.tobytes() == fix[name + "_det_ref"].tobytes()
+    assert len(hits) > 0
