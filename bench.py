@@ -120,7 +120,7 @@ def pmc_path_bytes_per_frame(batch):
         return None
 
 
-def verify_frames(model, H, W, frames, recs, cap, nms, picks):
+def verify_frames(model, H, W, frames, recs, cap, nms, picks, ref_arith=False):
     """Outside the clock: the records the TIMED contexts exported for `picks` = [(context, frame in batch), ...] against the
     oracle on the very same frames (pulled back from HBM): chnsPyramid + acfDetect (+ bbNms + prune) on the CPU, boxes and
     levels exact, score bits exact.  Returns the number of frames checked; raises on the first difference."""
@@ -131,7 +131,13 @@ def verify_frames(model, H, W, frames, recs, cap, nms, picks):
     n = 0
     for (ci, fi) in picks:
         frame = frames[ci][fi].cpu().numpy()
-        pyr, _, _ = ob.chns_pyramid(plan, frame)
+        if ref_arith:
+            ob.set_x86_tables(*ob.x86_fixture())
+            ob.set_approx(3)
+        try:
+            pyr, _, _ = ob.chns_pyramid(plan, frame)
+        finally:
+            ob.set_approx(0)
         want, _ = ob.detect(plan, pyr)
         if nms is not None:
             keep = ob.nms(np.stack([want["x"], want["y"], want["w"], want["h"]], axis=1), want["score"].astype(np.float64), nms)
@@ -298,6 +304,8 @@ def main():
     ap.add_argument("--turns", type=int, default=-1, help="A/B: option cascade_turns of every context (default: what DetectorPool sets, 5 with several contexts)")
     ap.add_argument("--persist", type=int, default=-1, help="A/B: option tile_persist of every context (default: what DetectorPool sets, 0 with several contexts)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="A/B: acf_hip_set_option(KEY, INT) on every context (repeatable)")
+    ap.add_argument("--ref-arith", action="store_true", help="the reference-arithmetic tier (option arith = 1 with the committed build-host tables, "
+                    "tests/golden/x86_rcp_rsqrt.npz): the three rsqrtps / rcpps sites return that CPU's bits; the self-check then uses the oracle's table tier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency launches (PMC passes: every launch in the trace is then a full batch)")
@@ -384,6 +392,10 @@ def main():
             det.set_option("tile_persist", args.persist)
         for kv in args.opt:
             det.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        if args.ref_arith:
+            z_ = np.load(os.path.join(ROOT, "tests", "golden", "x86_rcp_rsqrt.npz"))
+            det.set_x86_tables(z_["rcp"], z_["rsqrt"])
+            det.set_option("arith", 1)
         if not args.keep_pyramid and args.config != 5:
             det.set_option("keep_pyramid", 0)
         if not args.no_profile:
@@ -527,7 +539,7 @@ def main():
         # the timed contexts' own last records (still in their record buffers), three frames of three different contexts
         recs = [pipes[i].rec[(pipes[i].k - 1) & 1].cpu().numpy() for i in range(C)]
         picks = [(i % C, (7 + 31 * i) % B) for i in range(3)]
-        verified = verify_frames(model, H, W, [frames[i * B:(i + 1) * B] for i in range(C)], recs, args.cap, nms_params, picks)
+        verified = verify_frames(model, H, W, [frames[i * B:(i + 1) * B] for i in range(C)], recs, args.cap, nms_params, picks, ref_arith=args.ref_arith)
     strong64 = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_latency and not args.frames_total and C * B >= 64:
         # BASELINE cfg 3 as worded (64 frames per step) on this one GPU: 2 contexts x 32 frames, same contexts and buffers
