@@ -768,25 +768,35 @@ int launchTri(acf_hip_ctx* c, const float* in, float* U, float* S, int h, int w,
             fuse->nybM = nybM;
         }
         const dim3 grid(cdiv(w, 256), 1, nFrames), block(256);
+#define TRIY_LAUNCH(MAXO_, UT_)                                                                                                         \
+    if (fuse->x86)                                                                                                                      \
+    {                                                                                                                                   \
+        hipLaunchKernelGGL((k_triy_chns<MAXO_, UT_, true>), grid, block, 0, c->stream, (const float*)U, *fuse, UT_ ? ufs : fs, UT_ ? nyb : 0); \
+    }                                                                                                                                   \
+    else                                                                                                                                \
+    {                                                                                                                                   \
+        hipLaunchKernelGGL((k_triy_chns<MAXO_, UT_, false>), grid, block, 0, c->stream, (const float*)U, *fuse, UT_ ? ufs : fs, UT_ ? nyb : 0); \
+    }
         if (fuse->nOrients <= 6)
         {
             if (ut)
             {
-                hipLaunchKernelGGL((k_triy_chns<6, true>), grid, block, 0, c->stream, (const float*)U, *fuse, ufs, nyb);
+                TRIY_LAUNCH(6, true)
             }
             else
             {
-                hipLaunchKernelGGL((k_triy_chns<6, false>), grid, block, 0, c->stream, (const float*)U, *fuse, fs, 0);
+                TRIY_LAUNCH(6, false)
             }
         }
         else if (ut)
         {
-            hipLaunchKernelGGL((k_triy_chns<12, true>), grid, block, 0, c->stream, (const float*)U, *fuse, ufs, nyb);
+            TRIY_LAUNCH(12, true)
         }
         else
         {
-            hipLaunchKernelGGL((k_triy_chns<12, false>), grid, block, 0, c->stream, (const float*)U, *fuse, fs, 0);
+            TRIY_LAUNCH(12, false)
         }
+#undef TRIY_LAUNCH
         LAUNCHCHK(c, "k_triy_chns");
         *fused = true;
         return ACF_HIP_OK;

@@ -35,39 +35,27 @@ typedef __attribute__((address_space(3))) void* lptr_t;        // LDS
 // flushed to zero, rsqrt of a negative -> the default NaN.  The device's functions and the CPU checker's are compared over
 // every input by digest (acf_hip_selftest_x86, tests/test_gpu_arith.py).
 // ------------------------------------------------------------------------
+// (selects, not branches: the callers are column loops whose lanes must not diverge; the table index is in range for every input)
 __device__ __forceinline__ uint32_t x86_rcp_bits(uint32_t u, const uint32_t* __restrict__ T)
 {
     const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
-    if (e == 0xffu)
-    {
-        return m ? (u | 0x400000u) : s;
-    }
-    if (e == 0)
-    {
-        return s | 0x7f800000u;
-    }
     const uint32_t t = T[m >> 11];
     const int re = int((t >> 23) & 0xffu) + 127 - int(e);
-    return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
+    uint32_t r = re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu)); // (underflow: flushed to zero)
+    r = e == 0 ? (s | 0x7f800000u) : r;                                      // zero, subnormals: inf
+    r = e == 0xffu ? (m ? (u | 0x400000u) : s) : r;                          // NaN quieted; 1 / inf = 0 of the same sign
+    return r;
 }
 __device__ __forceinline__ uint32_t x86_rsqrt_bits(uint32_t u, const uint32_t* __restrict__ T)
 {
     const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
-    if (e == 0xffu)
-    {
-        return m ? (u | 0x400000u) : (s ? 0xffc00000u : 0u);
-    }
-    if (e == 0)
-    {
-        return s | 0x7f800000u;
-    }
-    if (s)
-    {
-        return 0xffc00000u;
-    }
     const int ue = int(e) - 127, odd = ue & 1, half = (ue - odd) / 2;
     const uint32_t t = T[4096 + ((odd << 12) | int(m >> 11))];
-    return (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
+    uint32_t r = (uint32_t(int((t >> 23) & 0xffu) - half) << 23) | (t & 0x7fffffu);
+    r = s ? 0xffc00000u : r;                                                 // negative: the default NaN
+    r = e == 0 ? (s | 0x7f800000u) : r;                                      // +-0, subnormals: inf of that sign
+    r = e == 0xffu ? (m ? (u | 0x400000u) : (s ? 0xffc00000u : 0u)) : r;     // NaN quieted; inf -> 0; -inf -> the default NaN
+    return r;
 }
 __device__ __forceinline__ float x86_rcp(float x, const uint32_t* __restrict__ T)
 {

@@ -62,6 +62,7 @@ struct SmoothVecArgs
     float* tU;           // [frame] U blocks
     int64_t u_fs;        // frame stride of U in floats
     int32_t nybU;        // (h + 8 + 15) / 16
+    const uint32_t* x86; // ARITH (option "arith"): the CPU tables gradMag's rsqrt / rcp come from
 };
 
 __device__ __forceinline__ float wave_rol1(float v)
@@ -97,6 +98,7 @@ constexpr int SV_MAXW = 10;          // waves per plane at most: planes of up to
 // recomputed as one chain by a second launch of this kernel (`redo`) before anything reads it.  Exactness therefore does
 // not rest on the contraction argument; only speed does (no repair has been observed with warm >= 32).
 #define GM_ACOS_N 20020
+#define X86_TABLE_N 12288 // rcp 4096 + rsqrt 2 x 4096 (kernels.hip.h)
 // gradMag's two reciprocals (gradientMex.cpp:209-219 with exact arithmetic): m = min(1 / sqrt(m2), 1e10),
 // M = 1 / m, every operation rounded as IEEE.  gm_inv_ieee is that text; the compiler's expansion of it is ~36 VALU
 // instructions per pixel (a correctly rounded sqrt with range scaling, two divisions with v_div_scale / v_div_fmas /
@@ -132,6 +134,14 @@ __device__ __forceinline__ void gm_inv_fast(float m2, float& m, float& M)
     m = in ? t : 1e10f;
     M = in ? q : 1.0f / 1e10f;
 }
+// The reference's own text at this site (gradientMex.cpp:209-210: m = MIN(RCPSQRT(M2), 1e10); M = RCP(m)) with one x86 CPU's
+// instructions from its tables (kernels.hip.h: x86_rsqrt / x86_rcp): option "arith".
+__device__ __forceinline__ void gm_inv_x86(float m2, float& m, float& M, const uint32_t* __restrict__ T)
+{
+    const float t = x86_rsqrt(m2, T);
+    m = t < 1e10f ? t : 1e10f; // _mm_min_ps(a, b): a < b ? a : b
+    M = x86_rcp(m, T);
+}
 // bit patterns first .. first + count - 1 (as m2): mismatches of gm_inv_fast against gm_inv_ieee; bad[0] = their number,
 // bad[1] = the smallest mismatching pattern
 __global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigned long long count, unsigned long long* __restrict__ bad)
@@ -156,8 +166,8 @@ __global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigne
         atomicMin(&bad[1], lo);
     }
 }
-template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false, bool TRIX = false>
-__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr)
+template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false, bool TRIX = false, bool ARITH = false>
+__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr, const uint32_t* x86L = nullptr)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
     const int seg = blockIdx.y;
@@ -280,7 +290,14 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             const float gy = (gb - ga) * ry;                                                      \
             const float m2 = gx * gx + gy * gy;                                                   \
             float m;                                                                              \
-            gm_inv_fast(m2, m, mo[k]);                                                            \
+            if (ARITH)                                                                            \
+            {                                                                                     \
+                gm_inv_x86(m2, m, mo[k], x86L);                                                   \
+            }                                                                                     \
+            else                                                                                  \
+            {                                                                                     \
+                gm_inv_fast(m2, m, mo[k]);                                                        \
+            }                                                                                     \
             float g = (gx * m) * 10000.0f;                                                        \
             g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));            \
             /* g < 10009 ? g : 10009, then > -10009 (gradientMex.cpp:224-226) as ONE v_med3_f32: the two selects compile to  */ \
@@ -532,7 +549,7 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_vec(SmoothVecArgs a, ui
 // chain's registers.  The smoothed plane then makes no HBM round trip between the two (8.3 MB written and read per 1080p
 // frame and scale 0; it is still written at a scale later scales are resampled from).  Its workgroups carry the acos table
 // (80 KB of LDS), which is why the other planes stay in k_smooth_vec's launch (a launch has ONE LDS size).
-template <bool HALF>
+template <bool HALF, bool ARITH = false>
 __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, uint32_t fullMask)
 {
     extern __shared__ float lds[]; // the waves' edge state (k_smooth_vec), then the acos table
@@ -554,21 +571,29 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, u
     {
         acosL[i] = a.acos[i];
     }
+    uint32_t* x86L = reinterpret_cast<uint32_t*>(acosL + GM_ACOS_N); // ARITH: the CPU tables behind the acos table (48 KB more LDS: the host asks for it)
+    if (ARITH)
+    {
+        for (int i = threadIdx.x; i < X86_TABLE_N; i += blockDim.x)
+        {
+            x86L[i] = a.x86[i];
+        }
+    }
     __syncthreads();
     if ((fullMask >> z) & 1u)
     {
-        smooth_vec_body<true, HALF, true, true>(a, lds, z, acosL + 10010);
+        smooth_vec_body<true, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86L);
     }
     else
     {
-        smooth_vec_body<false, HALF, true, true>(a, lds, z, acosL + 10010);
+        smooth_vec_body<false, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86L);
     }
 }
 
 // k_smooth_grad with convTri's x pass over M on the same chain (smooth_vec_body's TRIX): M is written once and not read back by a
 // separate x pass (8.3 MB per 1080p frame and one launch less per scale).  One segment per plane; up to 8 waves (1920 rows): the
 // ring of sixteen M columns costs 64 registers, which a workgroup of ten waves cannot have.
-template <bool HALF>
+template <bool HALF, bool ARITH = false>
 __global__ void __launch_bounds__(512) k_smooth_grad_tri(SmoothVecArgs a, uint32_t fullMask)
 {
     extern __shared__ float lds[]; // (k_smooth_grad's)
@@ -578,14 +603,22 @@ __global__ void __launch_bounds__(512) k_smooth_grad_tri(SmoothVecArgs a, uint32
     {
         acosL[i] = a.acos[i];
     }
+    uint32_t* x86L = reinterpret_cast<uint32_t*>(acosL + GM_ACOS_N); // ARITH: the CPU tables behind the acos table (48 KB more LDS: the host asks for it)
+    if (ARITH)
+    {
+        for (int i = threadIdx.x; i < X86_TABLE_N; i += blockDim.x)
+        {
+            x86L[i] = a.x86[i];
+        }
+    }
     __syncthreads();
     if ((fullMask >> z) & 1u)
     {
-        smooth_vec_body<true, HALF, true, true, true>(a, lds, z, acosL + 10010);
+        smooth_vec_body<true, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86L);
     }
     else
     {
-        smooth_vec_body<false, HALF, true, true, true>(a, lds, z, acosL + 10010);
+        smooth_vec_body<false, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86L);
     }
 }
 
@@ -806,14 +839,22 @@ __global__ void __launch_bounds__(GM_ROWS) k_grad_mag_strip(const float* __restr
 #define GMV_BLOCK 1024
 // BL: M and O leave in 64-column x 16-row blocks ([x >> 6][y >> 4][x & 63][y & 15], 4 KB each; nyb = ceil(h / 16), out_fs the
 // blocked frame stride): the layout k_tri_x5v<true> and k_triy_chns<.., true> read, see k_tri_x5v.
-template <bool BL>
+template <bool BL, bool ARITH = false>
 __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restrict__ in, float* __restrict__ M, float* __restrict__ O,
-    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames, int nyb)
+    const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames, int nyb, const uint32_t* __restrict__ x86 = nullptr)
 {
     __shared__ float acosL[GM_ACOS_N];
+    __shared__ uint32_t x86L[ARITH ? X86_TABLE_N : 1]; // (option "arith": 48 KB beside the 80 KB acos table: still one workgroup per CU)
     for (int i = threadIdx.x; i < GM_ACOS_N; i += GMV_BLOCK)
     {
         acosL[i] = acosBase[i];
+    }
+    if (ARITH)
+    {
+        for (int i = threadIdx.x; i < X86_TABLE_N; i += GMV_BLOCK)
+        {
+            x86L[i] = x86[i];
+        }
     }
     __syncthreads();
     const float* acosT = acosL + 10010; // index 0 = centre of the table
@@ -867,7 +908,14 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
                 const float gy = (b - a) * ry;
                 const float m2 = gx * gx + gy * gy;
                 float m;
-                gm_inv_fast(m2, m, mo[k]); // m = min(1 / sqrt(m2), 1e10), M = 1 / m: the IEEE results, see gm_inv_fast
+                if (ARITH)
+                {
+                    gm_inv_x86(m2, m, mo[k], x86L); // option "arith": the reference's rsqrtps / rcpps bits
+                }
+                else
+                {
+                    gm_inv_fast(m2, m, mo[k]); // m = min(1 / sqrt(m2), 1e10), M = 1 / m: the IEEE results, see gm_inv_fast
+                }
                 float g = (gx * m) * 10000.0f;
                 g = __int_as_float(__float_as_int(g) ^ (__float_as_int(gy) & 0x80000000));
                 g = g < 10009.0f ? g : 10009.0f;
@@ -1408,7 +1456,7 @@ struct ChnsArgs
     float normConst, rq; // rq = (1/S)/(1+1e-6) then /S in the y pass (imResampleMex.cpp:145-157,316)
     float rq_y;
     int32_t nybM;      // blocked M / O (k_triy_chns<.., true>): 16-row blocks per column block, ceil(h / 16); m_fs is then the blocked frame stride
-    const uint32_t* x86; // option "arith": gradMagNorm's reciprocal from the CPU tables (k_chns only; null: exact)
+    const uint32_t* x86; // option "arith": gradMagNorm's reciprocal from the CPU tables (k_chns: when not null; k_triy_chns<.., true>: its ARITH form)
 };
 
 template <int S>
@@ -1445,7 +1493,7 @@ __device__ __forceinline__ void chns_load_vec(const float* __restrict__ p, float
 // ------------------------------------------------------------------------
 // UT: U comes in k_tri_x5v<true>'s blocked layout (ufs, nyb as there): a step's rows are four 16-byte loads per lane from one
 // contiguous 4 KB block, already in the lane that owns the column.
-template <int MAXO, bool UT>
+template <int MAXO, bool UT, bool ARITH = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_triy_chns(const float* __restrict__ Ui, ChnsArgs ca, int64_t ufs, int nyb)
 {
     __shared__ float ty_lds[4][UT ? 1 : 2][64 * TY_PITCH];
@@ -1459,6 +1507,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
     constexpr int CB_P = 20, NCB = MAXO + 1; // row pitch of a (channel, cell column) of the buffer; slots: the magnitude, the bins
     __shared__ float ty_cb[4][STG ? NCB * 16 * CB_P : 1];
+    __shared__ uint32_t ty_rcp[ARITH ? 4096 : 1]; // option "arith": the rcp table of the CPU (16 KB: two workgroups per CU still fit)
+    if (ARITH)
+    {
+        for (int i = threadIdx.x; i < 4096; i += 256)
+        {
+            ty_rcp[i] = ca.x86[i];
+        }
+        __syncthreads();
+    }
     int cs = 0, cr0 = 0; // steps in the buffer; cell row of its row 0
     const int h = ca.h, w = ca.w;
     const int64_t fs = ca.m_fs;
@@ -1554,7 +1611,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             ov[xx][0] = oq[xx].x, ov[xx][1] = oq[xx].y, ov[xx][2] = oq[xx].z, ov[xx][3] = oq[xx].w;          \
             _Pragma("unroll") for (int yy = 0; yy < 4; yy++)                                                \
             {                                                                                               \
-                mn[xx][yy] = mr_[yy] * (1.0f / (sq[xx][yy] + ca.normConst)); /* gradMagNorm: M * rcp(S + norm) */ \
+                /* gradMagNorm: M * rcp(S + norm); ARITH: the rcp of one x86 CPU (n % 4 == 0 here: no scalar tail) */ \
+                mn[xx][yy] = ARITH ? mr_[yy] * x86_rcp(sq[xx][yy] + ca.normConst, ty_rcp) : mr_[yy] * (1.0f / (sq[xx][yy] + ca.normConst)); \
             }                                                                                               \
         }                                                                                                   \
         __builtin_amdgcn_wave_barrier();                                                                    \

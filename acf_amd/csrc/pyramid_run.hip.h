@@ -403,7 +403,7 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
             // chains (frames x segments) and a plane big enough for the saved round trip to matter.  A/B: the variables.
             const int64_t gradMinPx = int64_t(1) << 20;
             const int gradMinF = 16;
-            const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk && !c->arith && // (arith: gradMag is k_grad_mag_strip's)
+            const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk &&
                 (c->fusedGrad >= 2 || (c->fusedGrad == 1 && np >= gradMinPx && nF >= gradMinF));
             if (wantGrad)
             {
@@ -460,7 +460,7 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
                 sa.nSeg = nSeg;
                 sa.segStride = std::max(nSeg, nSegG);
             }
-            const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float);
+            const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float) + (c->arith ? size_t(X86_TABLE_N) * sizeof(uint32_t) : 0); // (+ the CPU tables, option "arith")
             if (wantGrad && d == 1 && triXFused)
             {
                 nSeg = nSegG = 1; // (one launch: the gradient plane's)
@@ -472,10 +472,14 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
             if (wantGrad)
             {
                 int rcl = 0;
-                if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true>), ldsG)) ||
-                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false>), ldsG)) ||
-                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<true>), ldsG)) ||
-                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<false>), ldsG)))
+                if ((rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true, false>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false, false>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<true, false>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<false, false>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<true, true>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad<false, true>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<true, true>), ldsG)) ||
+                    (rcl = allowLds(c, reinterpret_cast<const void*>(&k_smooth_grad_tri<false, true>), ldsG)))
                 {
                     return rcl;
                 }
@@ -502,24 +506,41 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
                     {
                         // (nothing to repair: the plane was one chain)
                     }
-                    else if (triXFused)
+                    else
                     {
-                        if (halfNext)
+                        // (the gradient plane's launch: with convTri's x pass on the chain or without, the next scale's half image or not,
+                        // exact reciprocals or — option "arith" — one x86 CPU's)
+                        sg.x86 = x86T(c);
+                        const dim3 gg = triXFused ? dim3(1, 1, grid.z) : dim3(1, grid.y, grid.z);
+#define SG_LAUNCH(KERNEL)                                                                                          \
+    if (halfNext)                                                                                                  \
+    {                                                                                                              \
+        if (sg.x86)                                                                                                \
+        {                                                                                                          \
+            hipLaunchKernelGGL((KERNEL<true, true>), gg, dim3(nt), ldsG, c->stream, sg, fullMask);                 \
+        }                                                                                                          \
+        else                                                                                                       \
+        {                                                                                                          \
+            hipLaunchKernelGGL((KERNEL<true, false>), gg, dim3(nt), ldsG, c->stream, sg, fullMask);                \
+        }                                                                                                          \
+    }                                                                                                              \
+    else if (sg.x86)                                                                                               \
+    {                                                                                                              \
+        hipLaunchKernelGGL((KERNEL<false, true>), gg, dim3(nt), ldsG, c->stream, sg, fullMask);                    \
+    }                                                                                                              \
+    else                                                                                                           \
+    {                                                                                                              \
+        hipLaunchKernelGGL((KERNEL<false, false>), gg, dim3(nt), ldsG, c->stream, sg, fullMask);                   \
+    }
+                        if (triXFused)
                         {
-                            hipLaunchKernelGGL((k_smooth_grad_tri<true>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                            SG_LAUNCH(k_smooth_grad_tri)
                         }
                         else
                         {
-                            hipLaunchKernelGGL((k_smooth_grad_tri<false>), dim3(1, 1, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+                            SG_LAUNCH(k_smooth_grad)
                         }
-                    }
-                    else if (halfNext)
-                    {
-                        hipLaunchKernelGGL((k_smooth_grad<true>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((k_smooth_grad<false>), dim3(1, grid.y, grid.z), dim3(nt), ldsG, c->stream, sg, fullMask);
+#undef SG_LAUNCH
                     }
                     grid.x -= 1;
                     grid.y = unsigned(sa.nSeg);
@@ -616,8 +637,8 @@ int PyramidRun::gradientChannels(size_t k, const SmoothOut& so)
     a.normConst = float(p.normConst);
     a.rq_y = shrinkGainY(shrink);
     // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
-    const bool gradVec = rs.h % 4 == 0 && np % 4 == 0 && !c->arith; // (option "arith": the plain forms hold the table arithmetic)
-    const bool fuseCells = shrink == 4 && !c->taps && !c->arith;     // k_triy_chns; else S is written and k_chns normalises
+    const bool gradVec = rs.h % 4 == 0 && np % 4 == 0;
+    const bool fuseCells = shrink == 4 && !c->taps; // k_triy_chns; else S is written and k_chns normalises
     a.x86 = x86T(c);
     const bool wantTri = (p.gradMagEnabled || p.gradHistEnabled) && p.normRad;
     const bool blockedMO = wantTri &&
@@ -639,16 +660,31 @@ int PyramidRun::gradientChannels(size_t k, const SmoothOut& so)
             const int64_t items = int64_t(cdiv(rs.w, GMV_XT)) * (rs.h / 4) * nF;
             const int gmvMax = 256;
             const int blocks = int(std::min<int64_t>(gmvMax, (items + GMV_BLOCK - 1) / GMV_BLOCK));
+            const float* gsrc = rs.sm + int64_t(p.colorChn) * np;
+            const uint32_t* xt = x86T(c);
+#define GMV_LAUNCH(BL_, AR_, FS_, NYB_)                                                                                                     \
+    hipLaunchKernelGGL((k_grad_mag_vec<BL_, AR_>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, gsrc, rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, \
+        int64_t(d) * np, FS_, nF, NYB_, xt);
             if (blockedMO)
             {
-                hipLaunchKernelGGL((k_grad_mag_vec<true>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
-                    rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, moBlockedFloats(rs.h, rs.w), nF, (rs.h + 15) / 16);
+                if (xt)
+                {
+                    GMV_LAUNCH(true, true, moBlockedFloats(rs.h, rs.w), (rs.h + 15) / 16)
+                }
+                else
+                {
+                    GMV_LAUNCH(true, false, moBlockedFloats(rs.h, rs.w), (rs.h + 15) / 16)
+                }
+            }
+            else if (xt)
+            {
+                GMV_LAUNCH(false, true, np, 0)
             }
             else
             {
-                hipLaunchKernelGGL((k_grad_mag_vec<false>), dim3(blocks), dim3(GMV_BLOCK), 0, c->stream, (const float*)(rs.sm + int64_t(p.colorChn) * np),
-                    rs.M, rs.O, (const float*)c->d_acos, rs.h, rs.w, p.full, int64_t(d) * np, np, nF, 0);
+                GMV_LAUNCH(false, false, np, 0)
             }
+#undef GMV_LAUNCH
         }
         else
         {
