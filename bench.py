@@ -514,6 +514,35 @@ def main():
         if not args.no_profile:
             for d_ in dets:
                 d_.profile()  # these launches are not the timed region's
+    ref_fps, ref_verified = None, None
+    if world == 1 and not args.ref_arith and not args.keep_pyramid and args.config != 5 and not args.no_latency:
+        # the reference-arithmetic tier beside the headline (option arith = 1 with the committed build-host tables: the reference's own
+        # rsqrtps / rcpps bits): the same steps, timed the same way, one frame per context checked against the
+        # oracle's table tier; reported in config, never `value`
+        z_ = np.load(os.path.join(ROOT, "tests", "golden", "x86_rcp_rsqrt.npz"))
+        for d_ in dets:
+            d_.set_x86_tables(z_["rcp"], z_["rsqrt"])
+            d_.set_option("arith", 1)
+        step()
+        finish()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        ref_fps = C * B * args.steps / (time.perf_counter() - t1)
+        if rank == 0 and not args.no_verify:
+            recs_ = [pipes[i].rec[(pipes[i].k - 1) & 1].cpu().numpy() for i in range(C)]
+            ref_verified = verify_frames(model, H, W, [frames[i * B:(i + 1) * B] for i in range(C)], recs_, args.cap, nms_params,
+                                         [(i % C, (11 + 17 * i) % B) for i in range(min(C, 3))], ref_arith=True)
+        for d_ in dets:
+            d_.set_option("arith", 0)
+        step()  # (the records of the default tier are what the self-check below reads)
+        finish()
+        if not args.no_profile:
+            for d_ in dets:
+                d_.profile()
     if rank == 0 and not args.no_latency:
         # one frame through one context, submit -> results on the device (cfg 2 is worded "single frame")
         lat = []
@@ -658,6 +687,9 @@ def main():
                        "cfg3_as_worded_8gpu_estimate_fps": (8 * batch8) if batch8 else None,
                        # the Pyramid-returning call (float levels written as well as the rank cells), same steps, timed the same way
                        "keep_pyramid_fps": keep_fps,
+                       # the reference-arithmetic tier (the reference's own rsqrtps / rcpps bits, build-host tables), same steps on this box,
+                       # and the frames of it checked against the oracle's table tier
+                       "ref_arith_fps": ref_fps, "ref_arith_verified_frames": ref_verified,
                        "cfg3_scaling_expectation": "weak scaling (--gpus N: every GPU its own 3 x 96 frames, one 772-byte record gather per frame) is "
                                                    "expected near-linear; strong scaling of cfg 3 as worded (64 frames per step over 8 GPUs = 8 per GPU) is bound by "
                                                    "per-launch floors: 8 x batch8_fps_1gpu (measured on one GPU) against this line's value.  No multi-GPU node was "

@@ -130,4 +130,5 @@ def test_bench_line_contract():
     cfg = d["config"]
     assert "workload" in cfg and cfg["contexts"] == 2 and cfg["frames_per_launch"] == 8
     assert cfg["batch8_fps_1gpu"] > 0 and cfg["batch8_pipelined_fps_1gpu"] > 0 and d["latency_ms_batch1"] > 0
+    assert cfg["ref_arith_fps"] > 0 and cfg["ref_arith_verified_frames"] == 2   # the reference-arithmetic tier beside the headline, self-checked
     assert d["cpu_baseline"] is None or "value" in d["cpu_baseline"]
