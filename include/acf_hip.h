@@ -313,7 +313,11 @@ ACF_HIP_API int acf_hip_get_lambdas(acf_hip_ctx* ctx, int frame, double out[3]);
 
 /* Detector::chnsPyramid for a batch (chnsPyramid.cpp:160-456).  `frames_dev`:
  * n_frames x d planes of float[w][h] already on the device.  Asynchronous on
- * the context's stream. */
+ * the context's stream.
+ * Values: the reference feeds images in [0, 1] (ACF.cpp:119).  Bit parity with it is checked for every finite input whose
+ * squared gradients stay finite (|values| up to ~1e18: flat regions, denormal-sized and very large gradients included,
+ * tests/test_gpu_arith.py); frames holding NaN / inf, or values whose squares overflow f32, are outside the contract (the
+ * reference itself turns those into inf / NaN channels). */
 ACF_HIP_API int acf_hip_pyramid(acf_hip_ctx* ctx, const float* frames_dev, int n_frames);
 
 /* Detector::operator()(const Pyramid&) without NMS (ACF.cpp:268-367) on the

@@ -296,3 +296,36 @@ def test_whole_pyramid_equals_the_frozen_reference_kernel_pyramid(oracle, name, 
     d, h = det.detections(0)
     assert h.tobytes() == fix[name + "_hits_ref"].tobytes() and d.tobytes() == fix[name + "_det_ref"].tobytes() and len(h) > 0
     det.close()
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_extreme_but_finite_planes_in_both_tiers(oracle, arith):
+    """Flat regions (M2 = 0: rsqrt = inf, clamped to 1e10), denormal-sized and very large gradients (squares still finite) through the
+    FAST kernel forms (k_smooth_grad / _tri, k_triy_chns) of both arithmetic tiers against the oracle's tier."""
+    import torch
+    from acf_amd.detector import HipDetector
+    H, W = 256, 512
+    model = synth.make_model(seed=3, name="TINY", nTrees=64, cascThr=-2.0)
+    base = synth.make_frame(21, H, W, "luv")
+    frames = np.stack([base * s for s in (1.0, 1e-30, 1e-12, 1e12)]).astype(np.float32)
+    frames[0, :, 100:200, :] = 0.0
+    frames[0, :, :, 50:60] = 0.25           # constant: zero gradient
+    frames[3, :, 300:, :] *= np.float32(1e3)
+    plan = oracle.Plan(model, H, W, 3)
+    oracle.set_x86_tables(*oracle.x86_fixture())
+    det = HipDetector(model, H, W, 3, max_batch=4, max_hits=1 << 16)
+    det.set_option("fused_grad", 2)
+    det.set_option("fused_tri", 2)
+    if arith:
+        det.set_x86_tables(*oracle.x86_fixture())
+        det.set_option("arith", 1)
+    det.run(torch.from_numpy(frames).cuda())
+    for f in range(4):
+        oracle.set_approx(3 if arith else 0)
+        try:
+            want, _, _ = oracle.chns_pyramid(plan, frames[f])
+        finally:
+            oracle.set_approx(0)
+        assert np.isfinite(want).all()
+        assert np.array_equal(bits(det.read_pyramid(f)), bits(want)), (arith, f)
+    det.close()
