@@ -141,7 +141,7 @@ struct acf_hip_ctx
     int taps = 0;
     int arith = 0;            // option "arith": 1 = the reference's rcpps / rsqrtps bits from d_x86 (acf_hip_set_x86_tables)
     bool x86Owned = false;
-    uint32_t* d_x86 = nullptr; // [12288]: rcp over [1, 2) by m >> 11 (4096), then rsqrt over [1, 4) by parity and m >> 11 (2 x 4096)
+    uint32_t* d_x86 = nullptr; // [X86_BUF_N]: rcp over [1, 2) by m >> 11 (4096), rsqrt over [1, 4) by parity and m >> 11 (2 x 4096), then gradMag's composed pairs
     int profile = 0;
     int noFusedSmooth = 0; // option "fused_smooth" = 0: separate smoothing / half resample / colour-channel kernels
     // option "fused_grad": 0 = gradMag as its own kernel (k_grad_mag_vec), 1 = inside the gradient plane's smoothing chain
@@ -3317,6 +3317,23 @@ int acf_hip_op_conv_tri(acf_hip_ctx* c, const float* in, float* out, int h, int 
     return ACF_HIP_OK;
 }
 
+// the device's table functions on the host (kernels.hip.h: x86_rcp_bits), for the composed table of gm_inv_x86g
+static uint32_t hostX86RcpBits(uint32_t u, const uint32_t* rcp4096)
+{
+    const uint32_t s = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu)
+    {
+        return m ? (u | 0x400000u) : s;
+    }
+    if (e == 0)
+    {
+        return s | 0x7f800000u;
+    }
+    const uint32_t t = rcp4096[m >> 11];
+    const int re = int((t >> 23) & 0xffu) + 127 - int(e);
+    return re <= 0 ? s : (s | (uint32_t(re) << 23) | (t & 0x7fffffu));
+}
+
 int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp4096, const uint32_t* rsqrt8192)
 {
     OP_PROLOGUE(c);
@@ -3328,12 +3345,26 @@ int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp4096, const uint32
     if (!c->d_x86)
     {
         // (not one of the plan's buffers: it outlives a re-plan; freed by acf_hip_destroy)
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_x86), 12288 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_x86), X86_BUF_N * sizeof(uint32_t)));
         c->x86Owned = true;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream)); // (a run in flight may be reading the previous tables)
-    HIPCHK(c, hipMemcpy(c->d_x86, rcp4096, 4096 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_x86 + 4096, rsqrt8192, 8192 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // [rcp 4096][rsqrt 8192][gradMag's pairs {RSQ[i], rcp(RSQ[i])} x 8192][rcp(1e10)] (kernels_channels.hip.h: gm_inv_x86g)
+    std::vector<uint32_t> buf(X86_BUF_N, 0u);
+    memcpy(buf.data(), rcp4096, 4096 * sizeof(uint32_t));
+    memcpy(buf.data() + 4096, rsqrt8192, 8192 * sizeof(uint32_t));
+    for (int i = 0; i < X86_GM_N; i++)
+    {
+        buf[size_t(X86_TABLE_N) + 2 * size_t(i)] = rsqrt8192[i];
+        buf[size_t(X86_TABLE_N) + 2 * size_t(i) + 1] = hostX86RcpBits(rsqrt8192[i], rcp4096);
+    }
+    {
+        const float big = 1e10f;
+        uint32_t bb;
+        memcpy(&bb, &big, 4);
+        buf[size_t(X86_TABLE_N) + 2 * size_t(X86_GM_N)] = hostX86RcpBits(bb, rcp4096);
+    }
+    HIPCHK(c, hipMemcpy(c->d_x86, buf.data(), buf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     for (acf_hip_ctx* k : c->kids)
     {
         k->d_x86 = c->d_x86;
@@ -3341,7 +3372,7 @@ int acf_hip_set_x86_tables(acf_hip_ctx* c, const uint32_t* rcp4096, const uint32
     return ACF_HIP_OK;
 }
 
-int acf_hip_selftest_x86(acf_hip_ctx* c, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[2])
+int acf_hip_selftest_x86(acf_hip_ctx* c, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[3])
 {
     OP_PROLOGUE(c);
     if (!digest || !c->d_x86)
@@ -3349,19 +3380,23 @@ int acf_hip_selftest_x86(acf_hip_ctx* c, uint32_t first_bits, uint64_t count, ui
         return fail(c, ACF_HIP_E_INVALID, "selftest_x86: install tables first (acf_hip_set_x86_tables)");
     }
     Scratch s;
-    unsigned long long* d = s.alloc<unsigned long long>(2);
+    unsigned long long* d = s.alloc<unsigned long long>(3);
     if (!d)
     {
         return fail(c, ACF_HIP_E_HIP, "selftest_x86: allocation");
     }
-    HIPCHK(c, hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemset(d, 0, 3 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_x86_digest, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->d_x86, first_bits, (unsigned long long)count, stride, d);
     LAUNCHCHK(c, "k_x86_digest");
+    // ... and gradMag's one-read form against the two table functions over the same patterns (negative non-NaN ones skipped)
+    hipLaunchKernelGGL(k_gm_x86_selftest, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->d_x86, first_bits, (unsigned long long)count, stride, d + 2);
+    LAUNCHCHK(c, "k_gm_x86_selftest");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    unsigned long long out[2];
+    unsigned long long out[3];
     HIPCHK(c, hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
     digest[0] = out[0];
     digest[1] = out[1];
+    digest[2] = out[2];
     return ACF_HIP_OK;
 }
 

@@ -99,6 +99,10 @@ constexpr int SV_MAXW = 10;          // waves per plane at most: planes of up to
 // not rest on the contraction argument; only speed does (no repair has been observed with warm >= 32).
 #define GM_ACOS_N 20020
 #define X86_TABLE_N 12288 // rcp 4096 + rsqrt 2 x 4096 (kernels.hip.h)
+// ... followed in the device buffer by gradMag's own form of them (acf_hip_set_x86_tables builds it): X86_GM_N pairs {RSQ[i], rcp(RSQ[i])}
+// and the bits of rcp(1e10) — see gm_inv_x86g
+#define X86_GM_N 8192
+#define X86_BUF_N (X86_TABLE_N + 2 * X86_GM_N + 8)
 // gradMag's two reciprocals (gradientMex.cpp:209-219 with exact arithmetic): m = min(1 / sqrt(m2), 1e10),
 // M = 1 / m, every operation rounded as IEEE.  gm_inv_ieee is that text; the compiler's expansion of it is ~36 VALU
 // instructions per pixel (a correctly rounded sqrt with range scaling, two divisions with v_div_scale / v_div_fmas /
@@ -142,6 +146,55 @@ __device__ __forceinline__ void gm_inv_x86(float m2, float& m, float& M, const u
     m = t < 1e10f ? t : 1e10f; // _mm_min_ps(a, b): a < b ? a : b
     M = x86_rcp(m, T);
 }
+// The same two results for the column kernels, whose time is their instruction stream: ONE 8-byte table read instead of two dependent
+// 4-byte ones.  m2 = gx * gx + gy * gy is +0, positive or NaN — never negative — and for a normal m2 = 4^half * [1, 4) with table index i
+//   t = rsqrt(m2) = 2^-half * RSQ[i]        and, when t < 1e10,        rcp(t) = 2^half * rcp(RSQ[i]):
+// rcp decides on the top 12 mantissa bits of its input, which are all RSQ[i] has, and its exponent arithmetic is exact — so G[i] =
+// {RSQ[i], rcp(RSQ[i])} (built on the host from the same tables) gives both with an exponent adjustment.  Everything else takes
+// constants: zero / subnormal (t = inf) and NaN (the min returns its second operand) -> m = 1e10, M = rcp(1e10) = K; t >= 1e10 the
+// same; m2 = inf -> t = 0, M = rcp(0) = inf.  The same floats as gm_inv_x86 for every m2 that is not negative (checked on the device for
+// all 2^31 of them against gm_inv_x86: acf_hip_selftest_x86's third digest, tests/test_gpu_arith.py).
+__device__ __forceinline__ void gm_inv_x86g(float m2, float& m, float& M, const uint2* __restrict__ G, float K)
+{
+    const uint32_t u = __float_as_uint(m2);
+    const bool normal = (u - 0x00800000u) < 0x7f000000u; // [0x00800000, 0x7f7fffff]: positive normal (a set sign bit = NaN here)
+    const uint32_t e1 = u >> 23;
+    const uint32_t i = (((e1 & 1u) ^ 1u) << 12) | ((u >> 11) & 0xfffu); // odd = (e - 127) & 1
+    const uint32_t hs = (((e1 + 1u) >> 1) - 64u) << 23;                  // half = (e - 127 - odd) / 2, in the exponent's place
+    const uint2 q = G[i];
+    const float t = __uint_as_float(q.x - hs);
+    const bool in = normal && t < 1e10f;
+    m = in ? t : 1e10f;
+    M = in ? __uint_as_float(q.y + hs) : K;
+    const bool isInf = u == 0x7f800000u;
+    m = isInf ? 0.f : m;
+    M = isInf ? __uint_as_float(0x7f800000u) : M;
+}
+// gm_inv_x86g against gm_inv_x86 over the bit patterns first + i * stride (as m2 >= 0 or NaN): number of patterns where m or M differ
+__global__ void __launch_bounds__(256) k_gm_x86_selftest(const uint32_t* __restrict__ T, uint32_t first, unsigned long long count, uint32_t stride,
+    unsigned long long* __restrict__ bad)
+{
+    const uint2* G = reinterpret_cast<const uint2*>(T + X86_TABLE_N);
+    const float K = __uint_as_float(T[X86_TABLE_N + 2 * X86_GM_N]);
+    unsigned long long nb = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256)
+    {
+        const uint32_t bits = first + uint32_t(i * stride);
+        const float x = __uint_as_float(bits);
+        if ((bits & 0x80000000u) && !((bits & 0x7f800000u) == 0x7f800000u && (bits & 0x7fffffu)))
+        {
+            continue; // negative and not NaN: outside gradMag's domain
+        }
+        float m0, M0, m1, M1;
+        gm_inv_x86(x, m0, M0, T);
+        gm_inv_x86g(x, m1, M1, G, K);
+        nb += __float_as_uint(m0) != __float_as_uint(m1) || __float_as_uint(M0) != __float_as_uint(M1);
+    }
+    if (nb)
+    {
+        atomicAdd(&bad[0], nb);
+    }
+}
 // bit patterns first .. first + count - 1 (as m2): mismatches of gm_inv_fast against gm_inv_ieee; bad[0] = their number,
 // bad[1] = the smallest mismatching pattern
 __global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigned long long count, unsigned long long* __restrict__ bad)
@@ -167,7 +220,7 @@ __global__ void __launch_bounds__(256) k_gm_inv_selftest(uint32_t first, unsigne
     }
 }
 template <bool FULL, bool HALF, bool SHRINK, bool GRAD = false, bool TRIX = false, bool ARITH = false>
-__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr, const uint32_t* x86L = nullptr)
+__device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* lds, int z, const float* acosT = nullptr, const uint2* x86G = nullptr, float x86K = 0.f)
 {
     const int h = a.h, w = a.w, nq = h >> 2;
     const int seg = blockIdx.y;
@@ -292,7 +345,7 @@ __device__ __forceinline__ void smooth_vec_body(const SmoothVecArgs& a, float* l
             float m;                                                                              \
             if (ARITH)                                                                            \
             {                                                                                     \
-                gm_inv_x86(m2, m, mo[k], x86L);                                                   \
+                gm_inv_x86g(m2, m, mo[k], x86G, x86K);                                            \
             }                                                                                     \
             else                                                                                  \
             {                                                                                     \
@@ -571,22 +624,25 @@ __global__ void __launch_bounds__(64 * SV_MAXW) k_smooth_grad(SmoothVecArgs a, u
     {
         acosL[i] = a.acos[i];
     }
-    uint32_t* x86L = reinterpret_cast<uint32_t*>(acosL + GM_ACOS_N); // ARITH: the CPU tables behind the acos table (48 KB more LDS: the host asks for it)
+    uint2* x86G = reinterpret_cast<uint2*>(acosL + GM_ACOS_N); // ARITH: gradMag's table pairs behind the acos table (64 KB more LDS: the host asks for it)
+    float x86K = 0.f;
     if (ARITH)
     {
-        for (int i = threadIdx.x; i < X86_TABLE_N; i += blockDim.x)
+        const uint2* gsrc = reinterpret_cast<const uint2*>(a.x86 + X86_TABLE_N);
+        for (int i = threadIdx.x; i < X86_GM_N; i += blockDim.x)
         {
-            x86L[i] = a.x86[i];
+            x86G[i] = gsrc[i];
         }
+        x86K = __uint_as_float(a.x86[X86_TABLE_N + 2 * X86_GM_N]);
     }
     __syncthreads();
     if ((fullMask >> z) & 1u)
     {
-        smooth_vec_body<true, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86L);
+        smooth_vec_body<true, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86G, x86K);
     }
     else
     {
-        smooth_vec_body<false, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86L);
+        smooth_vec_body<false, HALF, true, true, false, ARITH>(a, lds, z, acosL + 10010, x86G, x86K);
     }
 }
 
@@ -603,22 +659,25 @@ __global__ void __launch_bounds__(512) k_smooth_grad_tri(SmoothVecArgs a, uint32
     {
         acosL[i] = a.acos[i];
     }
-    uint32_t* x86L = reinterpret_cast<uint32_t*>(acosL + GM_ACOS_N); // ARITH: the CPU tables behind the acos table (48 KB more LDS: the host asks for it)
+    uint2* x86G = reinterpret_cast<uint2*>(acosL + GM_ACOS_N); // ARITH: gradMag's table pairs behind the acos table (64 KB more LDS: the host asks for it)
+    float x86K = 0.f;
     if (ARITH)
     {
-        for (int i = threadIdx.x; i < X86_TABLE_N; i += blockDim.x)
+        const uint2* gsrc = reinterpret_cast<const uint2*>(a.x86 + X86_TABLE_N);
+        for (int i = threadIdx.x; i < X86_GM_N; i += blockDim.x)
         {
-            x86L[i] = a.x86[i];
+            x86G[i] = gsrc[i];
         }
+        x86K = __uint_as_float(a.x86[X86_TABLE_N + 2 * X86_GM_N]);
     }
     __syncthreads();
     if ((fullMask >> z) & 1u)
     {
-        smooth_vec_body<true, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86L);
+        smooth_vec_body<true, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86G, x86K);
     }
     else
     {
-        smooth_vec_body<false, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86L);
+        smooth_vec_body<false, HALF, true, true, true, ARITH>(a, lds, z, acosL + 10010, x86G, x86K);
     }
 }
 
@@ -844,17 +903,20 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
     const float* __restrict__ acosBase, int h, int w, int full, int64_t in_fs, int64_t out_fs, int nFrames, int nyb, const uint32_t* __restrict__ x86 = nullptr)
 {
     __shared__ float acosL[GM_ACOS_N];
-    __shared__ uint32_t x86L[ARITH ? X86_TABLE_N : 1]; // (option "arith": 48 KB beside the 80 KB acos table: still one workgroup per CU)
+    __shared__ uint2 x86G[ARITH ? X86_GM_N : 1]; // (option "arith": gradMag's table pairs, 64 KB beside the 80 KB acos table: still one workgroup per CU)
+    float x86K = 0.f;
     for (int i = threadIdx.x; i < GM_ACOS_N; i += GMV_BLOCK)
     {
         acosL[i] = acosBase[i];
     }
     if (ARITH)
     {
-        for (int i = threadIdx.x; i < X86_TABLE_N; i += GMV_BLOCK)
+        const uint2* gsrc = reinterpret_cast<const uint2*>(x86 + X86_TABLE_N);
+        for (int i = threadIdx.x; i < X86_GM_N; i += GMV_BLOCK)
         {
-            x86L[i] = x86[i];
+            x86G[i] = gsrc[i];
         }
+        x86K = __uint_as_float(x86[X86_TABLE_N + 2 * X86_GM_N]);
     }
     __syncthreads();
     const float* acosT = acosL + 10010; // index 0 = centre of the table
@@ -910,7 +972,7 @@ __global__ void __launch_bounds__(GMV_BLOCK) k_grad_mag_vec(const float* __restr
                 float m;
                 if (ARITH)
                 {
-                    gm_inv_x86(m2, m, mo[k], x86L); // option "arith": the reference's rsqrtps / rcpps bits
+                    gm_inv_x86g(m2, m, mo[k], x86G, x86K); // option "arith": the reference's rsqrtps / rcpps bits
                 }
                 else
                 {

@@ -460,7 +460,7 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
                 sa.nSeg = nSeg;
                 sa.segStride = std::max(nSeg, nSegG);
             }
-            const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float) + (c->arith ? size_t(X86_TABLE_N) * sizeof(uint32_t) : 0); // (+ the CPU tables, option "arith")
+            const size_t ldsG = ldsB + size_t(GM_ACOS_N) * sizeof(float) + (c->arith ? size_t(X86_GM_N) * sizeof(uint2) : 0); // (+ gradMag's table pairs, option "arith")
             if (wantGrad && d == 1 && triXFused)
             {
                 nSeg = nSegG = 1; // (one launch: the gradient plane's)

@@ -218,10 +218,10 @@ class HipDetector:
         self._chk(self.lib.acf_hip_set_x86_tables(self.ctx, rcp.ctypes.data_as(u32p), rsqrt.ctypes.data_as(u32p)))
 
     def selftest_x86(self, first, count, stride=1):
-        """(rcp digest, rsqrt digest) of the device's table functions over the bit patterns first + i * stride."""
-        out = (C.c_uint64 * 2)()
+        """(rcp digest, rsqrt digest, mismatches of gradMag's one-read form) of the device's table functions over first + i * stride."""
+        out = (C.c_uint64 * 3)()
         self._chk(self.lib.acf_hip_selftest_x86(self.ctx, C.c_uint32(first), C.c_uint64(count), C.c_uint32(stride), out))
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def profile(self):
         """{kernel name: (total ms, launches)} since the last call (option "profile")."""

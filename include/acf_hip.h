@@ -247,7 +247,7 @@ ACF_HIP_API const char* acf_hip_last_error(const acf_hip_ctx* ctx);
  * 1: they return the bits of one x86 CPU's instructions, from the tables installed with
  * acf_hip_set_x86_tables — the pyramid and the detections are then what the reference's own
  * compiled kernels give on that CPU, bit for bit.  Every kernel form of the default path has
- * this arithmetic too (the tables ride in LDS beside the acos table): ~91 % of the default
+ * this arithmetic too (the tables ride in LDS beside the acos table): ~94 % of the default
  * tier's frames/s).
  *
  * Capacity: `max_hits` of acf_hip_plan bounds the hits kept per frame.  With stride < shrink
@@ -273,8 +273,10 @@ ACF_HIP_API int acf_hip_set_option(acf_hip_ctx* ctx, const char* key, int value)
 ACF_HIP_API int acf_hip_set_x86_tables(acf_hip_ctx* ctx, const uint32_t* rcp4096, const uint32_t* rsqrt8192);
 /* Self-check of the device's table functions: position-mixed 64-bit digests of rcp (digest[0]) and rsqrt (digest[1]) over the
  * bit patterns first + i * stride, i < count — the sums the CPU oracle's acfo_x86_digest forms from the same tables, so the
- * two implementations are compared for every input without moving 2^32 results. */
-ACF_HIP_API int acf_hip_selftest_x86(acf_hip_ctx* ctx, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[2]);
+ * two implementations are compared for every input without moving 2^32 results — and digest[2] = the number of those patterns
+ * (taken as gradMag's M2: the negative non-NaN ones skipped) for which the column kernels' one-read form of
+ * m = min(rsqrt(M2), 1e10), M = rcp(m) differs from the two table functions applied in turn: must be 0. */
+ACF_HIP_API int acf_hip_selftest_x86(acf_hip_ctx* ctx, uint32_t first_bits, uint64_t count, uint32_t stride, uint64_t digest[3]);
 
 /* Detector::getScales (static, chnsPyramid.cpp:461-529): host only, no context.
  * Writes up to `cap` scales and returns the total count in *n. */

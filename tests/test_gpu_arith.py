@@ -57,7 +57,9 @@ def test_device_table_functions_equal_the_oracles_for_every_input(oracle, dev):
     with ThreadPoolExecutor(min(32, os.cpu_count() or 4)) as ex:
         want = list(ex.map(lambda k: oracle.x86_digest(k * per, per, 1), range(chunks)))
     for k in range(chunks):
-        assert dev.selftest_x86(k * per, per, 1) == want[k], k
+        got = dev.selftest_x86(k * per, per, 1)
+        assert got[:2] == want[k], k
+        assert got[2] == 0, k     # gradMag's one-read form (gm_inv_x86g) == rsqrt table, min, rcp table in turn, for every M2 >= 0 and NaN
 
 
 def test_gradient_mag_and_norm_equal_the_reference_bytes(dev):
