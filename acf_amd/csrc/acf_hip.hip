@@ -3481,7 +3481,7 @@ int acf_hip_chns_compute(acf_hip_ctx* c, const acf_hip_params* pIn, const float*
         return fail(c, ACF_HIP_E_INVALID, "chns_compute: no parameters (pass them, or set a model first)");
     }
     acf_hip_params p = *pp;
-    if (!in || h <= 0 || w <= 0 || (d != 1 && d != 3))
+    if (!in || h <= 0 || w <= 0 || (d != 1 && d != 3 && d != 5)) // (5: the image's own M, O planes behind three image planes, chnsCompute.cpp:219-226)
     {
         return fail(c, ACF_HIP_E_INVALID, "chns_compute: arguments");
     }
@@ -3551,7 +3551,7 @@ int acf_hip_chns_compute(acf_hip_ctx* c, const acf_hip_params* pIn, const float*
         return fail(c, ACF_HIP_E_HIP, "chns_compute: allocation");
     }
     // rgbConvert(I, I, colorSpace, true, isLuv) (chnsCompute.cpp:235; rgbConvert.cpp:101-170)
-    const bool passthrough = (d == 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+    const bool passthrough = (d >= 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
     {
         dim3 grid(cdiv(np, 256), 1, 1), block(256);
         if (passthrough)
@@ -3639,7 +3639,14 @@ int acf_hip_chns_compute(acf_hip_ctx* c, const acf_hip_params* pIn, const float*
     a.normConst = float(p.normConst);
     a.rq_y = shrinkGainY(shrink);
     a.x86 = x86T(c);
-    if (p.gradMagEnabled || p.gradHistEnabled)
+    if (d == 5)
+    {
+        // M = MO[0], O = MO[1] (chnsCompute.cpp:265-269): no gradientMag, no normalisation
+        a.M = dI + 3 * np;
+        a.O = dI + 4 * np;
+        a.doNorm = 0;
+    }
+    else if (p.gradMagEnabled || p.gradHistEnabled)
     {
         hipLaunchKernelGGL(k_grad_mag_strip, dim3(cdiv(hc, GM_ROWS), 1, 1), dim3(GM_ROWS), 0, c->stream, (const float*)(dCol + int64_t(p.colorChn) * np), dM, dO,
             (const float*)c->d_acos, hc, wc, p.full, int64_t(0), int64_t(0), cdiv(wc, GM_XT), x86T(c));

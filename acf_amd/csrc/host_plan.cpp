@@ -381,7 +381,9 @@ int checkChnsParams(const acf_hip_params& p, int d_in, std::string& err)
 int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::string& err)
 {
     plan = Plan();
-    if (H <= 0 || W <= 0 || (d_in != 1 && d_in != 3))
+    // d_in: 1 or 3 image planes, or 5 = three image planes + the gradient magnitude and orientation that come WITH the image
+    // (chnsPyramid.cpp:248-255: the GL pipeline's LUVMO frames; M and O then replace gradientMag at the first real scale, :318-322)
+    if (H <= 0 || W <= 0 || (d_in != 1 && d_in != 3 && d_in != 5))
     {
         err = "plan: bad frame geometry";
         return ACF_HIP_E_INVALID;
@@ -476,6 +478,13 @@ int buildPlan(const acf_hip_params& p, int H, int W, int d_in, Plan& plan, std::
     }
     plan.pyr_floats = off;
     plan.raw_floats = roff;
+    if (d_in == 5 && (plan.real.empty() || plan.real_h[0] != H || plan.real_w[0] != W))
+    {
+        // (the reference pushes the full-size M, O planes onto the first real scale's image whatever its size, chnsPyramid.cpp:318-322:
+        // only a first real scale of the image's own size makes sense of that)
+        err = "plan: five input planes (image + M, O) need the first real scale to be the image's own size (nOctUp = 0, sizes divisible by shrink)";
+        return ACF_HIP_E_UNSUPPORTED;
+    }
     plan.lambdaLevel[0] = plan.lambdaLevel[1] = -1;
     if (p.nApprox > 0 && p.nLambdas == 0)
     {

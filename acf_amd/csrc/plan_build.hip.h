@@ -50,7 +50,7 @@ int PlanBuild::colourBuffer()
     int rc = ACF_HIP_OK;
     (void)rc;
     // colour conversion buffer (chnsPyramid.cpp:230-263)
-    const bool passthrough = (d_in == 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+    const bool passthrough = (d_in >= 3) && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
     if (!passthrough)
     {
         if ((rc = devAlloc(c, &c->d_color, size_t(B) * d * np0)))

@@ -63,6 +63,10 @@ struct PyramidRun
 int PyramidRun::ingest(const PackedSrc* u8, bool& ingestConverted)
 {
     int rc;
+    if (d_in == 5)
+    {
+        return fail(c, ACF_HIP_E_INVALID, "pyramid_u8: a plan for five input planes (image + M, O) takes float frames");
+    }
     if (u8 && c->rz.on)
     {
         // the apps' Resizer (acf.cpp:117-148) in front of the ingest: the caller's frames are rz.rows x rz.cols
@@ -403,7 +407,7 @@ int PyramidRun::smoothImage(size_t k, const float* img, int64_t img_fs, SmoothOu
             // chains (frames x segments) and a plane big enough for the saved round trip to matter.  A/B: the variables.
             const int64_t gradMinPx = int64_t(1) << 20;
             const int gradMinF = 16;
-            const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk &&
+            const bool wantGrad = (p.gradMagEnabled || p.gradHistEnabled) && gradVecOk && !(d_in == 5 && k == 0) && // (five planes: M, O came with the image)
                 (c->fusedGrad >= 2 || (c->fusedGrad == 1 && np >= gradMinPx && nF >= gradMinF));
             if (wantGrad)
             {
@@ -637,6 +641,18 @@ int PyramidRun::gradientChannels(size_t k, const SmoothOut& so)
     a.normConst = float(p.normConst);
     a.rq_y = shrinkGainY(shrink);
     // M, O and U of this scale in 64 x 16 blocks when every kernel that touches them is the vector form (triPlan)
+    if (d_in == 5 && k == 0)
+    {
+        // chnsCompute.cpp:219-226,265-269 (chnsPyramid.cpp:318-322): the first real scale takes the M, O planes that came with the image —
+        // no gradientMag, no normalisation; magnitude channel and histogram from them (k_chns)
+        a.M = frames + 3 * np0;
+        a.O = frames + 4 * np0;
+        a.S = nullptr;
+        a.Mn = nullptr;
+        a.m_fs = int64_t(d_in) * np0;
+        a.doNorm = 0;
+        return launchChns(c, a, shrink, nF);
+    }
     const bool gradVec = rs.h % 4 == 0 && np % 4 == 0;
     const bool fuseCells = shrink == 4 && !c->taps; // k_triy_chns; else S is written and k_chns normalises
     a.x86 = x86T(c);

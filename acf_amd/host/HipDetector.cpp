@@ -1129,6 +1129,7 @@ int HipDetector::chnsCompute(const MatP& IIn, const Options::Pyramid::Chns& pChn
         // stage by stage through the single-operator entries, reporting what chnsCompute reports
         const int shrink = p.shrink, H = h - h % shrink, W = w - w % shrink;
         const size_t np = size_t(H) * W, ns = size_t(hc) * wc;
+        const int dImg = d == 5 ? 3 : d; // (five planes: the image's own M, O behind three image planes, chnsCompute.cpp:219-226)
         MatP I(W, H, d);
         for (int z = 0; z < d; z++)
         {
@@ -1138,7 +1139,7 @@ int HipDetector::chnsCompute(const MatP& IIn, const Options::Pyramid::Chns& pChn
             }
         }
         MatP col(W, H, dcol);
-        const bool pass = d == 3 && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
+        const bool pass = dImg == 3 && (p.colorSpace == ACF_HIP_CS_ORIG || p.colorSpace == ACF_HIP_CS_RGB || (p.isLuv && p.colorSpace == ACF_HIP_CS_LUV));
         if (pass)
         {
             std::memcpy(col.data(), I.data(), sizeof(float) * 3 * np);
@@ -1184,11 +1185,20 @@ int HipDetector::chnsCompute(const MatP& IIn, const Options::Pyramid::Chns& pChn
         if (p.gradMagEnabled || p.gradHistEnabled)
         {
             MatP M(W, H, 1), O(W, H, 1), Mn(W, H, 1), On(W, H, 1);
-            utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], M.data(), O.data(), nullptr, H, W, 0, p.normConst, p.full), "acf_hip_op_gradient_mag");
-            pLogger(M, planeTag("M", H, W)); // gradientMag.cpp:119-123: before the normalisation
-            utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], Mn.data(), On.data(), nullptr, H, W, p.normRad, p.normConst, p.full), "acf_hip_op_gradient_mag");
-            pLogger(Mn, planeTag("Mnorm", H, W));
-            pLogger(On, planeTag("O", H, W));
+            if (d == 5)
+            {
+                // M = MO[0], O = MO[1] (:265-269): nothing computed, nothing logged for them
+                std::memcpy(Mn.data(), I[3], sizeof(float) * np);
+                std::memcpy(On.data(), I[4], sizeof(float) * np);
+            }
+            else
+            {
+                utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], M.data(), O.data(), nullptr, H, W, 0, p.normConst, p.full), "acf_hip_op_gradient_mag");
+                pLogger(M, planeTag("M", H, W)); // gradientMag.cpp:119-123: before the normalisation
+                utilCheck(api, c, api.acf_hip_op_gradient_mag(c, col[p.colorChn], Mn.data(), On.data(), nullptr, H, W, p.normRad, p.normConst, p.full), "acf_hip_op_gradient_mag");
+                pLogger(Mn, planeTag("Mnorm", H, W));
+                pLogger(On, planeTag("O", H, W));
+            }
             if (p.gradMagEnabled)
             {
                 utilCheck(api, c, api.acf_hip_op_im_resample(c, Mn.data(), o, H, W, hc, wc, 1, 1.0), "acf_hip_op_im_resample");

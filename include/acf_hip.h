@@ -294,7 +294,9 @@ ACF_HIP_API int acf_hip_plan_levels(const acf_hip_params* p, int h, int w, int d
  * which the caller applies to the struct before the call. */
 ACF_HIP_API int acf_hip_set_model(acf_hip_ctx* ctx, const acf_hip_params* p);
 
-/* Plan for frames of h x w with `d` input planes (1 or 3) and up to
+/* Plan for frames of h x w with `d` input planes (1 or 3; or 5 = three image planes followed by the gradient magnitude and
+ * orientation that come WITH the image — the GL pipeline's LUVMO frames, chnsPyramid.cpp:248-255: M and O then replace
+ * gradientMag at the first real scale, :318-322, which must be the image's own size: nOctUp = 0) and up to
  * `max_batch` frames per call and `max_hits` hits per frame: runs getScales
  * (chnsPyramid.cpp:461-529) and the real/approximate split
  * (chnsPyramid.cpp:272-292), builds resampling tables and allocates every
@@ -485,7 +487,8 @@ ACF_HIP_API int acf_hip_selftest_gradmag(acf_hip_ctx* ctx, uint32_t first_bits, 
  * every enabled type reduced by `shrink` (addChn's imResample) and concatenated: colour, magnitude, histogram.
  *   p     the Options::Pyramid::Chns fields of acf_hip_params are read (shrink .. isLuv; classifier and pyramid fields ignored);
  *         NULL: the context's model (acf_hip_set_model)
- *   in    HOST planes [d][w][h], d = 1 or 3, the transposed planar layout of every entry here
+ *   in    HOST planes [d][w][h], d = 1 or 3 — or 5: three image planes followed by the gradient magnitude and orientation that came
+ *         with the image (chnsCompute.cpp:219-226: they replace gradientMag and its normalisation) —, the transposed planar layout
  *   out   HOST buffer of `cap` floats receiving [nChns][w / shrink][h / shrink] (cropped sizes); NULL: only the sizes are reported
  * *nChns, *hC, *wC (each may be NULL) receive the channel count and the cell-plane size.  Honours option "arith". */
 ACF_HIP_API int acf_hip_chns_compute(acf_hip_ctx* ctx, const acf_hip_params* p, const float* in, int h, int w, int d, float* out, int64_t cap,

@@ -1543,7 +1543,14 @@ typedef struct acfo_taps
     float* Mnorm;
 } acfo_taps;
 
+/* MO: NULL, or two planes [w][h] — gradient magnitude and orientation that came WITH the image (an input of five planes,
+ * chnsCompute.cpp:219-226,263-269: `M = MO[0]; O = MO[1]` instead of gradientMag, normalisation included). */
+static int chns_compute_mo(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps, const float* MO);
 static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps)
+{
+    return chns_compute_mo(I, h, w, d, p, out, taps, NULL);
+}
+static int chns_compute_mo(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps, const float* MO)
 {
     const int shrink = p->shrink;
     if (h % shrink || w % shrink)
@@ -1597,7 +1604,15 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
         free(O);
         return ACF_HIP_E_INVALID;
     }
-    rc = st_grad_mag(I + np * (size_t)p->colorChn, M, O, h, w, 1, p->full); /* gradientMag.cpp:90-98: d = 1 */
+    if (MO) /* chnsCompute.cpp:265-269: the planes that came with the image; no gradientMag, no normalisation */
+    {
+        memcpy(M, MO, sizeof(float) * np);
+        memcpy(O, MO + np, sizeof(float) * np);
+    }
+    else
+    {
+        rc = st_grad_mag(I + np * (size_t)p->colorChn, M, O, h, w, 1, p->full); /* gradientMag.cpp:90-98: d = 1 */
+    }
     if (rc)
     {
         free(M);
@@ -1612,7 +1627,7 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
     {
         memcpy(taps->O, O, sizeof(float) * np);
     }
-    if (p->normRad != 0) /* gradientMag.cpp:120-132 */
+    if (p->normRad != 0 && !MO) /* gradientMag.cpp:120-132 */
     {
         float* S = (float*)xmalloc(sizeof(float) * np);
         rc = acfo_conv_tri_dispatch(M, S, h, w, 1, (double)p->normRad, 1);
@@ -1667,6 +1682,11 @@ static int chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, 
 ACFO_API int acfo_chns_compute(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const acfo_taps* taps)
 {
     return chns_compute(I, h, w, d, p, out, taps);
+}
+/* the same with the image's own M, O planes (two planes [w][h]; chnsCompute.cpp:219-226) */
+ACFO_API int acfo_chns_compute_mo(float* I, int h, int w, int d, const acf_hip_params* p, float* out, const float* MO)
+{
+    return chns_compute_mo(I, h, w, d, p, out, NULL, MO);
 }
 
 /* cv::copyMakeBorder(BORDER_REFLECT) on one plane [w][h] -> [w+2px][h+2py]
@@ -1916,10 +1936,11 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
             }
             dI = 3;
         }
-        else if (d_in == 3)
+        else if (d_in == 3 || d_in == 5) /* five planes: M, O come with the image (:248-255): they stay aside until the first real scale */
         {
             pI = (float*)xmalloc(sizeof(float) * np0 * 3);
             memcpy(pI, frame, sizeof(float) * np0 * 3);
+            dI = 3;
         }
         else
         {
@@ -1940,7 +1961,7 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
         }
         else if (cs == ACF_HIP_CS_HSV)
         {
-            if (p->isLuv || d_in != 3)
+            if (p->isLuv || d_in == 1)
             {
                 free(pI);
                 return ACF_HIP_E_INVALID; /* CV_Assert(flag == 2) :150-155; CV_Assert(flag == 0) for one plane :140-148 */
@@ -2026,7 +2047,16 @@ ACFO_API int acfo_chns_pyramid(const float* frame, int H, int W, int d_in, const
                 I1_is_I = 1;
             }
         }
-        rc = chns_compute(I1, h1, w1, d, p, data[i], taps ? &taps[realOrd] : NULL);
+        if (d_in == 5 && realOrd == 0)
+        {
+            /* :318-322: the image's M, O planes ride with the FIRST real scale only — which must be the image's own size (the reference
+             * pushes the full-size planes onto I1 whatever its size) */
+            rc = (h1 == H && w1 == W) ? chns_compute_mo(I1, h1, w1, d, p, data[i], taps ? &taps[realOrd] : NULL, frame + 3 * np0) : ACF_HIP_E_UNSUPPORTED;
+        }
+        else
+        {
+            rc = chns_compute(I1, h1, w1, d, p, data[i], taps ? &taps[realOrd] : NULL);
+        }
         if (!I1_is_I)
         {
             free(I1);

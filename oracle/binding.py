@@ -66,6 +66,8 @@ def lib():
         o.acfo_plan.restype = C.c_int
         o.acfo_chns_compute.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, fp, C.POINTER(Taps)]
         o.acfo_chns_compute.restype = C.c_int
+        o.acfo_chns_compute_mo.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, fp, fp]
+        o.acfo_chns_compute_mo.restype = C.c_int
         o.acfo_chns_pyramid.argtypes = [fp, C.c_int, C.c_int, C.c_int, P, L, C.c_int, fp, C.POINTER(Taps), C.POINTER(fp)]
         o.acfo_chns_pyramid.restype = C.c_int
         o.acfo_nms.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
@@ -351,6 +353,11 @@ def chns_compute(model, frame):
     d, w, h = frame.shape
     sh = int(prm.shrink)
     hc, wc = h - h % sh, w - w % sh
+    MO = None
+    if d == 5:   # the image's own M, O planes (chnsCompute.cpp:219-226)
+        MO = aligned_copy(frame[3:, :wc, :hc])
+        frame = frame[:3]
+        d = 3
     I = aligned_copy(frame[:, :wc, :hc])
     n = hc * wc
     cs = int(prm.colorSpace)
@@ -371,7 +378,10 @@ def chns_compute(model, frame):
     dcol = col.shape[0]
     nC = (dcol if prm.colorEnabled else 0) + (1 if prm.gradMagEnabled else 0) + (int(prm.nOrients) if prm.gradHistEnabled else 0)
     out = aligned((nC, wc // sh, hc // sh))
-    rc = o.acfo_chns_compute(F(col), hc, wc, dcol, C.byref(prm), F(out), None)
+    if MO is not None:
+        rc = o.acfo_chns_compute_mo(F(col), hc, wc, dcol, C.byref(prm), F(out), F(MO))
+    else:
+        rc = o.acfo_chns_compute(F(col), hc, wc, dcol, C.byref(prm), F(out), None)
     if rc:
         raise RuntimeError("acfo_chns_compute rc=%d" % rc)
     return np.array(out)
